@@ -1,0 +1,326 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (survey container only).
+
+    python tools/make_golden.py            # all fixtures
+    python tools/make_golden.py sac_alpha  # one group
+
+The reference checkout (/root/reference, read-only) is imported through tools/_ref_harness.py;
+inputs are drawn from seeded numpy generators, noise is injected (torch.randn wrapped), and only
+plain arrays (inputs + the reference's outputs) are written.  While generating, every fixture is
+also cross-checked against our restatement in oracle/ so a broken oracle is caught here.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_harness as H  # noqa: E402
+
+H.install()
+from oracle import mlp as omlp  # noqa: E402
+from oracle import tanh_gaussian as otg  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.set_num_threads(1)
+
+
+def save(name, **arrs):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def n(x):
+    return x.detach().cpu().numpy().copy()
+
+
+def set_flat(module, flat):
+    """Load a flat fp32 vector (oracle/mlp.py layout == parameters() order) into a torch module."""
+    off = 0
+    with torch.no_grad():
+        for p in module.parameters():
+            k = p.numel()
+            p.copy_(t(flat[off:off + k]).view_as(p))
+            off += k
+    assert off == flat.size
+
+
+def get_flat(module):
+    return np.concatenate([n(p).ravel() for p in module.parameters()]).astype(np.float32)
+
+
+def get_flat_grad(module):
+    return np.concatenate([n(p.grad).ravel() for p in module.parameters()]).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_head():
+    """G1: tanh-Gaussian head forward + float64 gradients + get_log_prob inverse path."""
+    from rlkit.torch.common.distributions import ReparamTanhMultivariateNormal
+    rng = np.random.default_rng(101)
+    B, A = 64, 6
+    mu = rng.normal(0, 1.0, (B, A)).astype(np.float32)
+    ls_raw = rng.normal(-1.0, 1.5, (B, A)).astype(np.float32)
+    ls_raw[0, :] = [-25.0, -20.0, 2.0, 2.5, 0.0, -19.999]  # clamp edges (policies.py:15-16,267)
+    eps = rng.normal(0, 1, (B, A)).astype(np.float32)
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        m = t(mu).to(dt).requires_grad_(True)
+        lr = t(ls_raw).to(dt).requires_grad_(True)
+        ls = torch.clamp(lr, -20, 2)
+        with H.NoiseInjector() as inj:
+            inj.push(t(eps).to(dt))
+            dist = ReparamTanhMultivariateNormal(m, ls)
+            a, z = dist.sample(return_pretanh_value=True)
+        lp = dist.log_prob(a, pre_tanh_value=z)
+        g_a = t(rng.normal(0, 1, (B, A)).astype(np.float32)).to(dt) if tag == "f32" else g_a64
+        if tag == "f32":
+            g_a64 = g_a.double()
+            g_lp32 = t(rng.normal(0, 1, (B, 1)).astype(np.float32))
+        g_lp = g_lp32.to(dt)
+        ((a * g_a).sum() + (lp * g_lp).sum()).backward()
+        out.update({f"action_{tag}": n(a), f"z_{tag}": n(z), f"log_std_{tag}": n(ls),
+                    f"log_prob_{tag}": n(lp), f"d_mu_{tag}": n(m.grad), f"d_ls_raw_{tag}": n(lr.grad)})
+        # inverse path (policies.py:329-345): log_prob of given actions
+        dist2 = ReparamTanhMultivariateNormal(t(mu).to(dt), torch.clamp(t(ls_raw).to(dt), -20, 2))
+        out[f"log_prob_of_action_{tag}"] = n(dist2.log_prob(a.detach()))
+    out.update(mu=mu, log_std_raw=ls_raw, eps=eps, g_action=n(g_a64).astype(np.float32), g_logp=n(g_lp32))
+    # oracle cross-check
+    fw = otg.head_forward(mu, ls_raw, eps)
+    # fp32 log(1 - a^2 + 1e-6) amplifies a 1-ulp tanh difference by 2|a|/(1-a^2+1e-6): per-row tolerance
+    tol = otg.logp_fp32_tolerance(out["action_f32"])
+    assert np.all(np.abs(fw["log_prob"] - out["log_prob_f32"]) <= tol), "head fwd mismatch"
+    fw64 = otg.head_forward(mu, ls_raw, eps, dtype=np.float64)
+    dmu, dls = otg.head_backward(fw64, eps, ls_raw, out["g_action"], out["g_logp"], dtype=np.float64)
+    # autograd keeps the two cancelling +-eps/sigma terms (sigma down to e^-20): 1e-7 residual even in f64
+    assert np.allclose(dmu, out["d_mu_f64"], rtol=1e-6, atol=1e-6), np.abs(dmu - out["d_mu_f64"]).max()
+    assert np.allclose(dls, out["d_ls_raw_f64"], rtol=1e-6, atol=1e-6)
+    save("g1_tanh_gaussian_head", **out)
+
+
+def gen_mlp():
+    """G2: Mlp / FlattenMlp forward + backward, relu and tanh."""
+    import torch.nn.functional as F
+    from rlkit.torch.common.networks import FlattenMlp
+    rng = np.random.default_rng(202)
+    out = {}
+    for tag, act, fn in (("relu", omlp.RELU, F.relu), ("tanh", omlp.TANH, torch.tanh)):
+        o, a, Hh, B = 11, 3, [32, 32], 24
+        flat = omlp.init_mlp(rng, o + a, Hh, 1)
+        net = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1, hidden_activation=fn)
+        set_flat(net, flat)
+        obs = rng.normal(0, 1, (B, o)).astype(np.float32)
+        actn = np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32)
+        to, ta = t(obs).requires_grad_(True), t(actn).requires_grad_(True)
+        y = net(to, ta)
+        gy = rng.normal(0, 1, (B, 1)).astype(np.float32)
+        (y * t(gy)).sum().backward()
+        out.update({f"{tag}_params": flat, f"{tag}_obs": obs, f"{tag}_act": actn, f"{tag}_y": n(y),
+                    f"{tag}_gy": gy, f"{tag}_grad": get_flat_grad(net),
+                    f"{tag}_dx": np.concatenate([n(to.grad), n(ta.grad)], 1)})
+        x = np.concatenate([obs, actn], 1)
+        outs, hs = omlp.forward(flat, x, o + a, Hh, 1, act=act)
+        assert np.allclose(outs[0], out[f"{tag}_y"], rtol=1e-5, atol=1e-6)
+        g, dx = omlp.backward(flat, hs, [gy], o + a, Hh, 1, act=act)
+        assert np.allclose(g, out[f"{tag}_grad"], rtol=1e-4, atol=1e-6)
+        assert np.allclose(dx, out[f"{tag}_dx"], rtol=1e-4, atol=1e-6)
+    # G3 init statistics of the reference rule (bounds, not bit values)
+    net = FlattenMlp(hidden_sizes=[256, 256], input_size=14, output_size=1)
+    ps = [n(p) for p in net.parameters()]
+    out["init_fc0_w_absmax"] = np.abs(ps[0]).max()
+    out["init_fc1_w_absmax"] = np.abs(ps[2]).max()
+    out["init_fc0_b"] = ps[1][:4]
+    out["init_last_w_absmax"] = np.abs(ps[4]).max()
+    save("g2_mlp", **out)
+
+
+class _Env:  # dummy `env` kwarg for sac_alpha.py:55-58
+    def __init__(self, a):
+        self.action_space = type("S", (), {"shape": (a,)})()
+
+
+def _sac_case(seed, o, a, Hh, B, steps, kwargs, full):
+    from rlkit.torch.algorithms.sac.sac_alpha import SoftActorCritic
+    from rlkit.torch.common.networks import FlattenMlp
+    from rlkit.torch.common.policies import ReparamTanhMultivariateGaussianPolicy
+    from oracle.sac_alpha import SacAlphaOracle
+
+    rng = np.random.default_rng(seed)
+    pi0 = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, n_heads=2)
+    q10 = omlp.init_mlp(rng, o + a, Hh, 1)
+    q20 = omlp.init_mlp(rng, o + a, Hh, 1)
+    # make the head outputs non-trivial so log_std / tanh saturate a little
+    pol = ReparamTanhMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a)
+    qf1 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1)
+    qf2 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1)
+    set_flat(pol, pi0), set_flat(qf1, q10), set_flat(qf2, q20)
+    tr = SoftActorCritic(policy=pol, qf1=qf1, qf2=qf2, env=_Env(a), **kwargs)
+    orc = SacAlphaOracle(o, a, Hh, pi0, q10, q20, **kwargs)
+
+    grads = {}
+
+    def hook(opt, name, mod):
+        orig = opt.step
+
+        def step(*aa, **kk):
+            grads[name] = get_flat_grad(mod)
+            return orig(*aa, **kk)
+        opt.step = step
+    hook(tr.qf1_optimizer, "q1", qf1), hook(tr.qf2_optimizer, "q2", qf2), hook(tr.policy_optimizer, "pi", pol)
+
+    rec = dict(pi0=pi0, q10=q10, q20=q20, dims=np.array([o, a, B, steps] + list(Hh)))
+    scal = {k: [] for k in ("qf1_loss", "qf2_loss", "policy_loss", "alpha_loss", "log_alpha",
+                            "q1_mean", "q2_mean", "log_pi_mean", "mu_mean", "log_std_mean")}
+    for s in range(steps):
+        batch = dict(
+            observations=rng.normal(0, 1, (B, o)).astype(np.float32),
+            actions=np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32),
+            rewards=rng.normal(0, 1, (B, 1)).astype(np.float32),
+            terminals=(rng.random((B, 1)) < 0.1).astype(np.float32),
+            next_observations=rng.normal(0, 1, (B, o)).astype(np.float32))
+        e1 = rng.normal(0, 1, (B, a)).astype(np.float32)
+        e2 = rng.normal(0, 1, (B, a)).astype(np.float32)
+        tr.eval_statistics = None
+        with H.NoiseInjector() as inj:
+            inj.push(e1), inj.push(e2)
+            tr.train_step({k: t(v) for k, v in batch.items()})
+        st = tr.eval_statistics
+        res = orc.train_step(batch, e1, e2)
+        scal["qf1_loss"].append(st["QF1 Loss"]); scal["qf2_loss"].append(st["QF2 Loss"])
+        scal["policy_loss"].append(st["Policy Loss"]); scal["alpha_loss"].append(st["Alpha Loss"])
+        scal["log_alpha"].append(float(tr.log_alpha.detach()))
+        scal["q1_mean"].append(st["Q1 Predictions Mean"]); scal["q2_mean"].append(st["Q2 Predictions Mean"])
+        scal["log_pi_mean"].append(st["Log Pis Mean"]); scal["mu_mean"].append(st["Policy mu Mean"])
+        scal["log_std_mean"].append(st["Policy log std Mean"])
+        # oracle cross-check, per step
+        for k_ref, k_or in (("QF1 Loss", "qf1_loss"), ("QF2 Loss", "qf2_loss"), ("Policy Loss", "policy_loss"),
+                            ("Alpha Loss", "alpha_loss")):
+            assert np.allclose(st[k_ref], res[k_or], rtol=2e-4, atol=1e-6), (s, k_ref, st[k_ref], res[k_or])
+        for nm, g in (("q1", res["q1_grad"]), ("q2", res["q2_grad"]), ("pi", res["pi_grad"])):
+            err = np.abs(grads[nm] - g).max() / (np.abs(grads[nm]).max() + 1e-12)
+            assert err < 2e-3, (s, nm, err)
+        if full or s == 0:
+            rec.update({f"s{s}_{k}": v for k, v in batch.items()})
+            rec.update({f"s{s}_eps_next": e1, f"s{s}_eps_cur": e2})
+        if full:
+            rec.update({f"s{s}_grad_q1": grads["q1"], f"s{s}_grad_q2": grads["q2"], f"s{s}_grad_pi": grads["pi"],
+                        f"s{s}_pi": get_flat(pol), f"s{s}_q1": get_flat(qf1), f"s{s}_q2": get_flat(qf2),
+                        f"s{s}_tq1": get_flat(tr.target_qf1), f"s{s}_tq2": get_flat(tr.target_qf2)})
+    fin = dict(pi=get_flat(pol), q1=get_flat(qf1), q2=get_flat(qf2), tq1=get_flat(tr.target_qf1),
+               tq2=get_flat(tr.target_qf2))
+    for k, v in fin.items():
+        ov = getattr(orc, k)
+        err = np.abs(ov - v).max()
+        assert err < 5e-5, (k, err)
+        if full:
+            rec["final_" + k] = v
+        else:  # checksums + strided sample keep the H=256 fixture small
+            rec["final_" + k + "_sum"] = np.float64(v.astype(np.float64).sum())
+            rec["final_" + k + "_abssum"] = np.float64(np.abs(v.astype(np.float64)).sum())
+            rec["final_" + k + "_sample"] = v[::97].copy()
+    rec.update({k: np.asarray(v, dtype=np.float64) for k, v in scal.items()})
+    rec["seed"] = np.array(seed)
+    return rec
+
+
+def gen_sac_alpha():
+    """G4: SoftActorCritic.train_step (sac_alpha.py:78-181), 5 chained steps, everything pinned."""
+    kw = dict(reward_scale=1.0, discount=0.99, policy_lr=3e-4, qf_lr=3e-4, alpha_lr=3e-4,
+              soft_target_tau=0.005, alpha=0.2, train_alpha=True, policy_mean_reg_weight=1e-3,
+              policy_std_reg_weight=1e-3, beta_1=0.9)
+    save("g4_sac_alpha_small", **_sac_case(404, 11, 3, [32, 32], 32, 5, kw, full=True))
+    # GAIL-style hyper-parameters (gail_walker.yaml:12,74: reward_scale 2, beta_1 0.25), Walker dims
+    kw2 = dict(kw, reward_scale=2.0, beta_1=0.25, target_entropy=-4.0)
+    save("g4_sac_alpha_walker", **_sac_case(405, 17, 6, [32, 32], 16, 3, kw2, full=True))
+    # Hopper BASELINE dims (H=256, B=256): losses per step + checksums / strided samples of the weights
+    save("g4_sac_alpha_h256", **_sac_case(406, 11, 3, [256, 256], 256, 3, kw, full=False))
+
+
+def gen_replay():
+    """G10: ring semantics of SimpleReplayBuffer via EnvReplayBuffer-free scripted sequence."""
+    from rlkit.data_management.simple_replay_buffer import SimpleReplayBuffer
+    from oracle.replay import ReplayOracle
+    rng = np.random.default_rng(1010)
+    cap, o, a = 23, 4, 2
+    rb = SimpleReplayBuffer(cap, o, a, random_seed=1995)
+    orc = ReplayOracle(cap, o, a, random_seed=1995)
+    # script: episode lengths and how each ends: 't' terminal flag on last sample, 'x' terminate_episode()
+    script = [(5, "t"), (7, "x"), (3, "t"), (1, "t"), (9, "x"), (6, "t"), (4, "x"), (8, "t"), (2, "x")]
+    N = sum(l for l, _ in script)
+    obs = rng.normal(0, 1, (N, o)); nobs = rng.normal(0, 1, (N, o)); act = rng.normal(0, 1, (N, a))
+    rew = rng.normal(0, 1, (N,)); term = np.zeros(N, np.uint8); ep_end = np.zeros(N, np.uint8)
+    snaps, i = [], 0
+    for L, how in script:
+        for j in range(L):
+            last = j == L - 1
+            term[i] = 1 if (last and how == "t") else 0
+            rb.add_sample(obs[i], act[i], rew[i], term[i], nobs[i])
+            orc.add_sample(obs[i], act[i], rew[i], int(term[i]), nobs[i])
+            i += 1
+        ep_end[i - 1] = 1
+        rb.terminate_episode(); orc.terminate_episode()
+        ends = np.array(sorted(rb._traj_endpoints.items()), dtype=np.int64).reshape(-1, 2)
+        assert rb._top == orc.top and rb._size == orc.size and dict(rb._traj_endpoints) == orc.traj_endpoints
+        snaps.append((rb._top, rb._size, i, ends))
+    idx = np.array([0, 5, 22, 7, 7, 13])
+    gb = rb._get_batch_using_indices(idx)
+    trajs = rb.sample_all_trajs()
+    starts = np.array(list(rb._traj_endpoints.keys())); ends_ = np.array(list(rb._traj_endpoints.values()))
+    out = dict(cap=cap, o=o, a=a, obs=obs, next_obs=nobs, act=act, rew=rew, term=term, ep_end=ep_end,
+               snap_top=np.array([s[0] for s in snaps]), snap_size=np.array([s[1] for s in snaps]),
+               snap_n=np.array([s[2] for s in snaps]),
+               idx=idx, gather_obs=gb["observations"], gather_act=gb["actions"], gather_rew=gb["rewards"],
+               gather_term=gb["terminals"], gather_next_obs=gb["next_observations"],
+               final_traj_starts=starts, final_traj_ends=ends_,
+               traj_lens=np.array([len(tj["rewards"]) for tj in trajs]),
+               traj_rew_concat=np.concatenate([tj["rewards"].ravel() for tj in trajs]),
+               randint_1995=np.random.RandomState(1995).randint(0, 1000, 8))
+    for k, s in enumerate(snaps):
+        out[f"snap{k}_ends"] = s[3]
+    otr = orc.sample_all_trajs()
+    assert [len(x["rewards"]) for x in otr] == list(out["traj_lens"])
+    assert np.allclose(np.concatenate([x["rewards"].ravel() for x in otr]), out["traj_rew_concat"], atol=1e-6)
+    save("g10_replay", **out)
+
+
+def gen_rms_actionmap():
+    """G11 RunningMeanStd + normalize_obs (normalizer.py:128-152, vecenvs.py:299-327);
+    G12 NormalizedBoxEnv action map (wrappers.py:342-346)."""
+    from rlkit.data_management.normalizer import RunningMeanStd
+    rng = np.random.default_rng(1111)
+    rms = RunningMeanStd()
+    xs = [rng.normal(2.0, 3.0, (nb, 5)) for nb in (4, 7, 1, 16)]
+    means, vars_, counts = [], [], []
+    for x in xs:
+        rms.update(x)
+        means.append(np.array(rms.mean)); vars_.append(np.array(rms.var)); counts.append(rms.count)
+    eps = np.finfo(np.float32).eps.item()  # vecenvs.py:107
+    probe = rng.normal(2.0, 30.0, (6, 5))
+    normed = np.clip((probe - rms.mean) / np.sqrt(rms.var + eps), -10.0, 10.0)
+    # action map: lb + (a+1)/2*(ub-lb), clip
+    lb = np.array([-1.0, -2.0, 0.0]); ub = np.array([1.0, 2.0, 0.4])
+    acts = rng.uniform(-1.5, 1.5, (10, 3))
+    scaled = np.clip(lb + (acts + 1.0) * 0.5 * (ub - lb), lb, ub)
+    save("g11_g12_rms_actionmap", x0=xs[0], x1=xs[1], x2=xs[2], x3=xs[3], means=np.array(means),
+         vars=np.array(vars_), counts=np.array(counts), probe=probe, normed=normed, eps=eps,
+         lb=lb, ub=ub, acts=acts, scaled=scaled)
+
+
+GROUPS = dict(head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+              rms=gen_rms_actionmap)
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(GROUPS)
+    for g in which:
+        GROUPS[g]()
