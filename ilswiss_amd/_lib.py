@@ -1,0 +1,116 @@
+"""ctypes binding of libilsx.so (include/ilsx.h).  No CPU fallback: importing the product path without
+the built HIP library raises, and creating a context without an MI355X raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libilsx.so")
+
+c_f32p = C.POINTER(C.c_float)
+c_u8p = C.POINTER(C.c_uint8)
+c_i64p = C.POINTER(C.c_int64)
+vp = C.c_void_p
+
+
+class MlpCfg(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32),
+                ("out_dim", C.c_int32), ("n_heads", C.c_int32), ("act", C.c_int32)]
+
+
+class SacCfg(C.Structure):
+    _fields_ = [("reward_scale", C.c_float), ("discount", C.c_float), ("policy_lr", C.c_float),
+                ("qf_lr", C.c_float), ("alpha_lr", C.c_float), ("soft_target_tau", C.c_float),
+                ("alpha", C.c_float), ("train_alpha", C.c_int32),
+                ("policy_mean_reg_weight", C.c_float), ("policy_std_reg_weight", C.c_float),
+                ("beta_1", C.c_float), ("has_target_entropy", C.c_int32), ("target_entropy", C.c_float),
+                ("max_batch", C.c_int32), ("grad_world", C.c_int32)]
+
+
+class SacStats(C.Structure):
+    _fields_ = [("qf1_loss", C.c_float), ("qf2_loss", C.c_float), ("policy_loss", C.c_float),
+                ("alpha_loss", C.c_float), ("alpha", C.c_float), ("q1_mean", C.c_float),
+                ("q2_mean", C.c_float), ("log_pi_mean", C.c_float), ("policy_mu_mean", C.c_float),
+                ("policy_log_std_mean", C.c_float), ("log_alpha", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/ilsx.h declares
+PROTOTYPES = {
+    "ilsx_abi_version": (C.c_int, []),
+    "ilsx_last_error": (C.c_char_p, []),
+    "ilsx_ctx_create": (C.c_int, [C.c_int, vp, C.c_uint64, C.POINTER(vp)]),
+    "ilsx_ctx_sync": (C.c_int, [vp]),
+    "ilsx_ctx_destroy": (C.c_int, [vp]),
+    "ilsx_ctx_stream": (vp, [vp]),
+    "ilsx_ctx_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "ilsx_ctx_free": (C.c_int, [vp, vp]),
+    "ilsx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "ilsx_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "ilsx_net_create": (C.c_int, [vp, C.POINTER(MlpCfg), C.POINTER(vp)]),
+    "ilsx_net_destroy": (C.c_int, [vp]),
+    "ilsx_net_num_params": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "ilsx_net_init": (C.c_int, [vp, C.c_uint64, C.c_float, C.c_float]),
+    "ilsx_net_set_params": (C.c_int, [vp, vp, C.c_size_t, C.c_int]),
+    "ilsx_net_get_params": (C.c_int, [vp, vp, C.c_size_t, C.c_int]),
+    "ilsx_mlp_forward": (C.c_int, [vp, vp, C.c_int, vp]),
+    "ilsx_policy_act": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "ilsx_policy_log_prob": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "ilsx_replay_create": (C.c_int, [vp, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "ilsx_replay_destroy": (C.c_int, [vp]),
+    "ilsx_replay_add": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int]),
+    "ilsx_replay_terminate_episode": (C.c_int, [vp]),
+    "ilsx_replay_sample": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "ilsx_replay_sample_many": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "ilsx_replay_record_floats": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "ilsx_replay_size": (C.c_int, [vp, c_i64p, c_i64p]),
+    "ilsx_replay_clear": (C.c_int, [vp]),
+    "ilsx_replay_traj_endpoints": (C.c_int, [vp, c_i64p, c_i64p, C.c_int, C.POINTER(C.c_int)]),
+    "ilsx_sac_create": (C.c_int, [vp, C.POINTER(SacCfg), vp, vp, vp, C.POINTER(vp)]),
+    "ilsx_sac_destroy": (C.c_int, [vp]),
+    "ilsx_sac_train_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.POINTER(SacStats)]),
+    "ilsx_sac_train_from_replay": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(SacStats)]),
+    "ilsx_sac_set_batch": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "ilsx_sac_critic_backward": (C.c_int, [vp]),
+    "ilsx_sac_critic_update": (C.c_int, [vp]),
+    "ilsx_sac_actor_backward": (C.c_int, [vp]),
+    "ilsx_sac_actor_update": (C.c_int, [vp]),
+    "ilsx_sac_last_stats": (C.c_int, [vp, C.POINTER(SacStats)]),
+    "ilsx_sac_get_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int]),
+    "ilsx_sac_set_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int]),
+    "ilsx_sac_get_grads": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int]),
+    "ilsx_sac_grads_ptr": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "ilsx_sac_get_log_alpha": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "ilsx_sac_set_log_alpha": (C.c_int, [vp, C.c_double]),
+    "ilsx_sac_get_adam": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, c_i64p]),
+    "ilsx_sac_set_adam": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, C.c_int64]),
+    "ilsx_sac_get_alpha_opt": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64p, C.POINTER(C.c_uint64)]),
+    "ilsx_sac_set_alpha_opt": (C.c_int, [vp, C.c_double, C.c_double, C.c_int64, C.c_uint64]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libilsx.so (once).  Raises RuntimeError if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ilswiss_amd/csrc`.  ilswiss_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ilsx_abi_version() != 1:
+        raise RuntimeError(f"libilsx ABI {lib.ilsx_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ilsx_last_error()
+        raise RuntimeError(f"libilsx error {rc}: {msg.decode() if msg else '?'}")

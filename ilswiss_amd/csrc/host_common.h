@@ -1,0 +1,111 @@
+// host_common.h — host-side objects behind the opaque handles of include/ilsx.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ilsx.h"
+#include "kernels.h"
+
+void ilsx_set_err(const char* fmt, ...);
+
+#define ILSX_FAIL(code, ...)   \
+  do {                         \
+    ilsx_set_err(__VA_ARGS__); \
+    return (code);             \
+  } while (0)
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      ilsx_set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+      return ILSX_ERR_HIP;                                                                        \
+    }                                                                                             \
+  } while (0)
+
+#define ILSX_TRY(expr)        \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != ILSX_OK) return rc_; \
+  } while (0)
+
+struct ilsx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  uint64_t seed = 0;
+  uint32_t next_rng_stream = 1;
+  std::vector<void*> allocs;
+  // small reusable staging buffer for host->device row uploads
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+};
+
+int ctx_alloc(ilsx_ctx* c, size_t bytes, void** out, bool zero = true);
+int ctx_free(ilsx_ctx* c, void* p);
+int ctx_stage(ilsx_ctx* c, size_t bytes, void** out);
+
+// Layout of one network: flat ABI order <-> internal (first-layer rows padded to KP, heads fused).
+struct NetLayout {
+  ilsx_mlp_cfg cfg;
+  int KP = 0, NO = 0;
+  int off_W[ILSX_MAX_HID], off_b[ILSX_MAX_HID], ld[ILSX_MAX_HID];
+  int off_Wh = 0, off_bh = 0;
+  size_t n_int = 0;   // internal floats (multiple of 4)
+  size_t n_flat = 0;  // ABI floats
+  int in_of(int l) const { return l == 0 ? cfg.in_dim : cfg.hidden; }
+};
+int net_layout_build(const ilsx_mlp_cfg& cfg, NetLayout* L);
+void net_flat_to_internal(const NetLayout& L, const float* flat, float* internal);
+void net_internal_to_flat(const NetLayout& L, const float* internal, float* flat);
+NetView net_view(const NetLayout& L, float* base);
+
+struct ilsx_net {
+  ilsx_ctx* ctx = nullptr;
+  NetLayout lay;
+  float* base = nullptr;  // device, internal layout
+  bool owns = true;
+  // lazily sized workspace for the standalone forward / act entry points
+  float* ws_out = nullptr;
+  int ws_rows = 0;
+};
+
+int net_upload_flat(ilsx_ctx* ctx, const NetLayout& L, float* dev_base, const float* src, size_t n, int src_is_device);
+int net_download_flat(ilsx_ctx* ctx, const NetLayout& L, const float* dev_base, float* dst, size_t n, int dst_is_device);
+
+int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A, int H, int act, int KP);
+int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act);
+int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows);
+int launch_adam(ilsx_ctx* ctx, const AdamArgs& A);
+// appends the dW/db jobs of one network to `jobs`
+void build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
+                   float* const* dsave, const float* dhead, std::vector<DwJob>* jobs);
+
+// Replay ring: HBM-resident transition records + host mirror of the reference's cursors.
+struct DevReplayState {
+  long long size, top;
+};
+struct ilsx_replay {
+  ilsx_ctx* ctx = nullptr;
+  int64_t cap = 0;
+  int o = 0, a = 0, rec = 0;  // rec = floats per record (multiple of 32)
+  float* data = nullptr;      // [cap][rec]
+  DevReplayState* dstate = nullptr;
+  uint64_t seed = 0;
+  uint32_t rng_stream = 0;
+  unsigned long long sample_ctr = 0;  // host-side Philox step for standalone sample calls
+  // reference cursors (simple_replay_buffer.py:61-68)
+  int64_t top = 0, size = 0, cur_start = 0;
+  std::deque<std::pair<int64_t, int64_t>> trajs;  // insertion-ordered (start,end)
+  std::vector<uint8_t> start_flag;                // slot is a key of `trajs`
+};
+int replay_launch_sample(ilsx_replay* rb, int B, const int64_t* idx, const DevScalars* scal,
+                         unsigned long long step_host, float* obs, float* act, float* rew, float* done,
+                         float* nobs, int64_t* idx_out);

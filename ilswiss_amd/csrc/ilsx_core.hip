@@ -1,0 +1,449 @@
+// ilsx_core.hip — context, networks and kernel launch helpers of libilsx.so (gfx950 only).
+#include <algorithm>
+#include <cmath>
+#include <random>
+
+#define ILSX_KERNEL_IMPL 1  // the shared __global__ kernels of kernels.h are emitted by this TU only
+#include "host_common.h"
+
+static thread_local std::string g_err = "";
+
+void ilsx_set_err(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+static int kernels_init_once();
+extern "C" int ilsx_abi_version(void) { return ILSX_ABI_VERSION; }
+extern "C" const char* ilsx_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------ ctx
+int ctx_alloc(ilsx_ctx* c, size_t bytes, void** out, bool zero) {
+  if (bytes == 0) bytes = 16;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) ILSX_FAIL(ILSX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, c->stream));
+  c->allocs.push_back(p);
+  *out = p;
+  return ILSX_OK;
+}
+int ctx_free(ilsx_ctx* c, void* p) {
+  if (!p) return ILSX_OK;
+  auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+  if (it == c->allocs.end()) ILSX_FAIL(ILSX_ERR_ARG, "ctx_free: pointer not owned by this ctx");
+  c->allocs.erase(it);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(p));
+  return ILSX_OK;
+}
+int ctx_stage(ilsx_ctx* c, size_t bytes, void** out) {
+  if (bytes > c->stage_bytes) {
+    if (c->stage) ILSX_TRY(ctx_free(c, c->stage));
+    c->stage = nullptr;
+    size_t nb = std::max(bytes, (size_t)1 << 20);
+    ILSX_TRY(ctx_alloc(c, nb, &c->stage, false));
+    c->stage_bytes = nb;
+  }
+  *out = c->stage;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_ctx_create(int hip_device, void* hip_stream, uint64_t seed, ilsx_ctx** out) {
+  if (!out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ctx_create: out is NULL");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (hip_device < 0 || hip_device >= ndev)
+    ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ctx_create: device %d out of range (%d visible)", hip_device, ndev);
+  HIPCHK(hipSetDevice(hip_device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, hip_device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "libilsx is built for gfx950 (MI355X) only; device reports %s", prop.gcnArchName);
+  ILSX_TRY(kernels_init_once());
+  ilsx_ctx* c = new ilsx_ctx();
+  c->device = hip_device;
+  c->seed = seed;
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      ILSX_FAIL(ILSX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return ILSX_OK;
+}
+extern "C" int ilsx_ctx_sync(ilsx_ctx* c) {
+  if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ILSX_OK;
+}
+extern "C" int ilsx_ctx_destroy(ilsx_ctx* c) {
+  if (!c) return ILSX_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return ILSX_OK;
+}
+extern "C" void* ilsx_ctx_stream(ilsx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int ilsx_ctx_alloc(ilsx_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ctx_alloc: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  return ctx_alloc(c, bytes, out, true);
+}
+extern "C" int ilsx_ctx_free(ilsx_ctx* c, void* p) {
+  if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
+  return ctx_free(c, p);
+}
+extern "C" int ilsx_memcpy_h2d(ilsx_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || (!dst && bytes) || (!src && bytes)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_memcpy_h2d: NULL argument");
+  // synchronous w.r.t. the host buffer, ordered on the ctx stream
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ILSX_OK;
+}
+extern "C" int ilsx_memcpy_d2h(ilsx_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || (!dst && bytes) || (!src && bytes)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_memcpy_d2h: NULL argument");
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ILSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ layout
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+int net_layout_build(const ilsx_mlp_cfg& cfg, NetLayout* L) {
+  if (cfg.n_hidden < 1 || cfg.n_hidden > ILSX_MAX_HID)
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "n_hidden=%d not in 1..%d", cfg.n_hidden, ILSX_MAX_HID);
+  if (cfg.hidden != 64 && cfg.hidden != 128 && cfg.hidden != 256)
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "hidden=%d: supported widths are 64, 128, 256", cfg.hidden);
+  if (cfg.in_dim < 1 || cfg.in_dim > 1024) ILSX_FAIL(ILSX_ERR_ARG, "in_dim=%d out of range", cfg.in_dim);
+  if (cfg.n_heads < 1 || cfg.n_heads > 2 || cfg.out_dim < 1 || cfg.n_heads * cfg.out_dim > ILSX_MAX_NO)
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "heads: n_heads=%d out_dim=%d (n_heads*out_dim must be <= %d)", cfg.n_heads,
+              cfg.out_dim, ILSX_MAX_NO);
+  if (cfg.act != ILSX_ACT_RELU && cfg.act != ILSX_ACT_TANH) ILSX_FAIL(ILSX_ERR_ARG, "act=%d unknown", cfg.act);
+  L->cfg = cfg;
+  L->KP = round_up(cfg.in_dim, 16);
+  L->NO = cfg.n_heads * cfg.out_dim;
+  const int H = cfg.hidden;
+  size_t off = 0, nflat = 0;
+  for (int l = 0; l < cfg.n_hidden; ++l) {
+    L->ld[l] = l == 0 ? L->KP : H;
+    L->off_W[l] = (int)off;
+    off += (size_t)H * L->ld[l];
+    L->off_b[l] = (int)off;
+    off += H;
+    nflat += (size_t)H * L->in_of(l) + H;
+  }
+  L->off_Wh = (int)off;
+  off += (size_t)L->NO * H;
+  L->off_bh = (int)off;
+  off += round_up(L->NO, 4);
+  nflat += (size_t)L->NO * H + L->NO;
+  L->n_int = off;
+  L->n_flat = nflat;
+  return ILSX_OK;
+}
+
+void net_flat_to_internal(const NetLayout& L, const float* flat, float* in) {
+  std::fill(in, in + L.n_int, 0.0f);
+  const int H = L.cfg.hidden;
+  size_t f = 0;
+  for (int l = 0; l < L.cfg.n_hidden; ++l) {
+    const int ind = L.in_of(l);
+    for (int n = 0; n < H; ++n)
+      for (int k = 0; k < ind; ++k) in[L.off_W[l] + (size_t)n * L.ld[l] + k] = flat[f + (size_t)n * ind + k];
+    f += (size_t)H * ind;
+    for (int n = 0; n < H; ++n) in[L.off_b[l] + n] = flat[f + n];
+    f += H;
+  }
+  const int od = L.cfg.out_dim;
+  for (int h = 0; h < L.cfg.n_heads; ++h) {
+    for (int j = 0; j < od; ++j)
+      for (int k = 0; k < H; ++k) in[L.off_Wh + (size_t)(h * od + j) * H + k] = flat[f + (size_t)j * H + k];
+    f += (size_t)od * H;
+    for (int j = 0; j < od; ++j) in[L.off_bh + h * od + j] = flat[f + j];
+    f += od;
+  }
+}
+
+void net_internal_to_flat(const NetLayout& L, const float* in, float* flat) {
+  const int H = L.cfg.hidden;
+  size_t f = 0;
+  for (int l = 0; l < L.cfg.n_hidden; ++l) {
+    const int ind = L.in_of(l);
+    for (int n = 0; n < H; ++n)
+      for (int k = 0; k < ind; ++k) flat[f + (size_t)n * ind + k] = in[L.off_W[l] + (size_t)n * L.ld[l] + k];
+    f += (size_t)H * ind;
+    for (int n = 0; n < H; ++n) flat[f + n] = in[L.off_b[l] + n];
+    f += H;
+  }
+  const int od = L.cfg.out_dim;
+  for (int h = 0; h < L.cfg.n_heads; ++h) {
+    for (int j = 0; j < od; ++j)
+      for (int k = 0; k < H; ++k) flat[f + (size_t)j * H + k] = in[L.off_Wh + (size_t)(h * od + j) * H + k];
+    f += (size_t)od * H;
+    for (int j = 0; j < od; ++j) flat[f + j] = in[L.off_bh + h * od + j];
+    f += od;
+  }
+}
+
+NetView net_view(const NetLayout& L, float* base) {
+  NetView v;
+  v.base = base;
+  for (int l = 0; l < ILSX_MAX_HID; ++l) {
+    v.off_W[l] = l < L.cfg.n_hidden ? L.off_W[l] : 0;
+    v.off_b[l] = l < L.cfg.n_hidden ? L.off_b[l] : 0;
+    v.ld[l] = l < L.cfg.n_hidden ? L.ld[l] : 0;
+  }
+  v.off_Wh = L.off_Wh;
+  v.off_bh = L.off_bh;
+  v.nhid = L.cfg.n_hidden;
+  v.H = L.cfg.hidden;
+  v.in_dim = L.cfg.in_dim;
+  v.KP = L.KP;
+  v.NO = L.NO;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ launches
+static size_t fwd_lds_bytes(int H, int KP) {
+  return sizeof(float) * (16 * (KP + ILSX_LDS_PAD) + 2 * 16 * (H + ILSX_LDS_PAD) + 16 * ILSX_MAX_NO);
+}
+static size_t bwd_lds_bytes(int H) { return sizeof(float) * (2 * 16 * (H + ILSX_LDS_PAD) + 16 * ILSX_MAX_NO); }
+
+// Raise the dynamic-LDS cap of every forward instantiation once (never inside a stream capture).
+static int kernels_init_once() {
+  static bool done = false;
+  if (done) return ILSX_OK;
+  const int cap = 160 * 1024;
+#define SET_FWD(HH, AA) HIPCHK(hipFuncSetAttribute((const void*)k_mlp_fwd<HH, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
+  SET_FWD(64, ACT_RELU); SET_FWD(128, ACT_RELU); SET_FWD(256, ACT_RELU);
+  SET_FWD(64, ACT_TANH); SET_FWD(128, ACT_TANH); SET_FWD(256, ACT_TANH);
+#undef SET_FWD
+  done = true;
+  return ILSX_OK;
+}
+
+#define DISPATCH_H_ACT(H, act, CALL)                                   \
+  do {                                                                 \
+    if (act == ILSX_ACT_RELU) {                                        \
+      if (H == 64) { CALL(64, ACT_RELU); }                             \
+      else if (H == 128) { CALL(128, ACT_RELU); }                      \
+      else { CALL(256, ACT_RELU); }                                    \
+    } else {                                                           \
+      if (H == 64) { CALL(64, ACT_TANH); }                             \
+      else if (H == 128) { CALL(128, ACT_TANH); }                      \
+      else { CALL(256, ACT_TANH); }                                    \
+    }                                                                  \
+  } while (0)
+
+int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A, int H, int act, int KPmax) {
+  if (A.rows <= 0) return ILSX_OK;
+  const size_t lds = fwd_lds_bytes(H, KPmax);
+  if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
+  dim3 grid((A.rows + 15) / 16, A.ntasks), block(256);
+#define CALL_FWD(HH, AA) hipLaunchKernelGGL((k_mlp_fwd<HH, AA>), grid, block, lds, ctx->stream, A)
+  DISPATCH_H_ACT(H, act, CALL_FWD);
+#undef CALL_FWD
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act) {
+  if (A.rows <= 0) return ILSX_OK;
+  const size_t lds = bwd_lds_bytes(H);
+  dim3 grid((A.rows + 15) / 16, A.ntasks), block(256);
+#define CALL_BWD(HH, AA) hipLaunchKernelGGL((k_mlp_bwd_dx<HH, AA>), grid, block, lds, ctx->stream, A)
+  DISPATCH_H_ACT(H, act, CALL_BWD);
+#undef CALL_BWD
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows) {
+  if (njobs <= 0 || rows <= 0) return ILSX_OK;
+  hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(njobs), dim3(256), 0, ctx->stream, jobs_dev, rows);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+int launch_adam(ilsx_ctx* ctx, const AdamArgs& A) {
+  const int n4 = A.n / 4;
+  int blocks = (n4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_adam_polyak, dim3(blocks), dim3(256), 0, ctx->stream, A);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+void build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
+                   float* const* dsave, const float* dhead, std::vector<DwJob>* jobs) {
+  const int H = L.cfg.hidden;
+  auto add = [&](const float* A, int lda, int NA, const float* Bm, int ldb, int NB, float* dW, int ldw, float* db) {
+    for (int n0 = 0; n0 < NA; n0 += 64)
+      for (int k0 = 0; k0 < NB; k0 += 64) {
+        DwJob j;
+        j.A = A; j.Bm = Bm; j.dW = dW; j.db = db;
+        j.lda = lda; j.NA = NA; j.ldb = ldb; j.NB = NB; j.ldw = ldw; j.n0 = n0; j.k0 = k0; j.pad = 0;
+        jobs->push_back(j);
+      }
+  };
+  for (int l = 0; l < L.cfg.n_hidden; ++l) {
+    const float* Bm = l == 0 ? xsave : hsave[l - 1];
+    const int ldb = l == 0 ? L.KP : H;
+    add(dsave[l], H, H, Bm, ldb, ldb, gbase + L.off_W[l], L.ld[l], gbase + L.off_b[l]);
+  }
+  add(dhead, L.NO, L.NO, hsave[L.cfg.n_hidden - 1], H, H, gbase + L.off_Wh, H, gbase + L.off_bh);
+}
+
+// ------------------------------------------------------------------------------------------ nets
+extern "C" int ilsx_net_create(ilsx_ctx* ctx, const ilsx_mlp_cfg* cfg, ilsx_net** out) {
+  if (!ctx || !cfg || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_net_create: NULL argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  ilsx_net* n = new ilsx_net();
+  n->ctx = ctx;
+  int rc = net_layout_build(*cfg, &n->lay);
+  if (rc != ILSX_OK) { delete n; return rc; }
+  rc = ctx_alloc(ctx, n->lay.n_int * sizeof(float), (void**)&n->base, true);
+  if (rc != ILSX_OK) { delete n; return rc; }
+  *out = n;
+  return ILSX_OK;
+}
+extern "C" int ilsx_net_destroy(ilsx_net* n) {
+  if (!n) return ILSX_OK;
+  if (n->owns && n->base) ctx_free(n->ctx, n->base);
+  if (n->ws_out) ctx_free(n->ctx, n->ws_out);
+  delete n;
+  return ILSX_OK;
+}
+extern "C" int ilsx_net_num_params(const ilsx_net* n, size_t* out) {
+  if (!n || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_net_num_params: NULL argument");
+  *out = n->lay.n_flat;
+  return ILSX_OK;
+}
+
+int net_upload_flat(ilsx_ctx* ctx, const NetLayout& L, float* dev_base, const float* src, size_t n, int src_is_device) {
+  if (n != L.n_flat) ILSX_FAIL(ILSX_ERR_ARG, "parameter count %zu != expected %zu", n, L.n_flat);
+  std::vector<float> flat(L.n_flat), in(L.n_int);
+  if (src_is_device) {
+    HIPCHK(hipMemcpyAsync(flat.data(), src, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  } else {
+    memcpy(flat.data(), src, n * sizeof(float));
+  }
+  net_flat_to_internal(L, flat.data(), in.data());
+  HIPCHK(hipMemcpyAsync(dev_base, in.data(), L.n_int * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return ILSX_OK;
+}
+int net_download_flat(ilsx_ctx* ctx, const NetLayout& L, const float* dev_base, float* dst, size_t n, int dst_is_device) {
+  if (n != L.n_flat) ILSX_FAIL(ILSX_ERR_ARG, "parameter count %zu != expected %zu", n, L.n_flat);
+  std::vector<float> flat(L.n_flat), in(L.n_int);
+  HIPCHK(hipMemcpyAsync(in.data(), dev_base, L.n_int * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  net_internal_to_flat(L, in.data(), flat.data());
+  if (dst_is_device) {
+    HIPCHK(hipMemcpyAsync(dst, flat.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  } else {
+    memcpy(dst, flat.data(), n * sizeof(float));
+  }
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_net_set_params(ilsx_net* n, const float* src, size_t cnt, int src_is_device) {
+  if (!n || !src) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_net_set_params: NULL argument");
+  HIPCHK(hipSetDevice(n->ctx->device));
+  return net_upload_flat(n->ctx, n->lay, n->base, src, cnt, src_is_device);
+}
+extern "C" int ilsx_net_get_params(const ilsx_net* n, float* dst, size_t cnt, int dst_is_device) {
+  if (!n || !dst) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_net_get_params: NULL argument");
+  HIPCHK(hipSetDevice(n->ctx->device));
+  return net_download_flat(n->ctx, n->lay, n->base, dst, cnt, dst_is_device);
+}
+
+extern "C" int ilsx_net_init(ilsx_net* n, uint64_t seed, float init_w, float b_init) {
+  if (!n) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_net_init: NULL net");
+  // networks.py:57-83, pytorch_util.py:20-29: bound = 1/sqrt(weight.size(0)) = 1/sqrt(OUT features)
+  const NetLayout& L = n->lay;
+  std::mt19937_64 gen(seed);
+  std::vector<float> flat(L.n_flat);
+  size_t f = 0;
+  const int H = L.cfg.hidden;
+  for (int l = 0; l < L.cfg.n_hidden; ++l) {
+    const float bound = 1.0f / std::sqrt((float)H);
+    std::uniform_real_distribution<float> u(-bound, bound);
+    const size_t nw = (size_t)H * L.in_of(l);
+    for (size_t i = 0; i < nw; ++i) flat[f + i] = u(gen);
+    f += nw;
+    for (int i = 0; i < H; ++i) flat[f + i] = b_init;
+    f += H;
+  }
+  std::uniform_real_distribution<float> uh(-init_w, init_w);
+  for (; f < L.n_flat; ++f) flat[f] = uh(gen);
+  return ilsx_net_set_params(n, flat.data(), flat.size(), 0);
+}
+
+extern "C" int ilsx_mlp_forward(ilsx_net* n, const float* x, int rows, float* y) {
+  if (!n || !x || !y || rows < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_mlp_forward: bad argument");
+  HIPCHK(hipSetDevice(n->ctx->device));
+  FwdArgs A;
+  memset(&A, 0, sizeof A);
+  FwdTask& t = A.t[0];
+  t.net = net_view(n->lay, n->base);
+  t.x0 = x; t.d0 = n->lay.cfg.in_dim; t.s0 = n->lay.cfg.in_dim;
+  t.out = y;
+  t.head = HEAD_RAW;
+  A.rows = rows; A.ntasks = 1; A.seed = n->ctx->seed;
+  return launch_fwd(n->ctx, A, n->lay.cfg.hidden, n->lay.cfg.act, n->lay.KP);
+}
+
+extern "C" int ilsx_policy_act(ilsx_net* pi, const float* obs, int nrows, int deterministic, const float* eps,
+                               float* act, float* logp) {
+  if (!pi || !obs || !act || nrows < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_act: bad argument");
+  if (pi->lay.cfg.n_heads != 2) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_act: network has %d heads (need mean|log_std)", pi->lay.cfg.n_heads);
+  HIPCHK(hipSetDevice(pi->ctx->device));
+  static unsigned long long act_calls = 0;
+  FwdArgs A;
+  memset(&A, 0, sizeof A);
+  FwdTask& t = A.t[0];
+  t.net = net_view(pi->lay, pi->base);
+  t.x0 = obs; t.d0 = pi->lay.cfg.in_dim; t.s0 = pi->lay.cfg.in_dim;
+  t.head = deterministic ? HEAD_TANH_DET : HEAD_TANH_SAMPLE;
+  t.eps = eps;
+  t.action = act;
+  t.logp = logp;
+  t.rng_stream = 0x41435400u;  // 'ACT'
+  A.rows = nrows; A.ntasks = 1; A.seed = pi->ctx->seed;
+  A.scal = nullptr;
+  A.step_host = ++act_calls;
+  return launch_fwd(pi->ctx, A, pi->lay.cfg.hidden, pi->lay.cfg.act, pi->lay.KP);
+}
+
+extern "C" int ilsx_policy_log_prob(ilsx_net* pi, const float* obs, const float* act, int nrows, float* logp) {
+  if (!pi || !obs || !act || !logp || nrows < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_log_prob: bad argument");
+  if (pi->lay.cfg.n_heads != 2) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_log_prob: network is not a Gaussian policy");
+  HIPCHK(hipSetDevice(pi->ctx->device));
+  FwdArgs A;
+  memset(&A, 0, sizeof A);
+  FwdTask& t = A.t[0];
+  t.net = net_view(pi->lay, pi->base);
+  t.x0 = obs; t.d0 = pi->lay.cfg.in_dim; t.s0 = pi->lay.cfg.in_dim;
+  t.head = HEAD_TANH_LOGP_OF_ACT;
+  t.act_in = act;
+  t.logp = logp;
+  A.rows = nrows; A.ntasks = 1; A.seed = pi->ctx->seed;
+  return launch_fwd(pi->ctx, A, pi->lay.cfg.hidden, pi->lay.cfg.act, pi->lay.KP);
+}

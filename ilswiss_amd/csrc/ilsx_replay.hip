@@ -1,0 +1,259 @@
+// ilsx_replay.hip — HBM-resident replay ring (rlkit/data_management/simple_replay_buffer.py:17-442,
+// env_replay_buffer.py:7-49).
+//
+// Layout: one transition = one record [obs(o) | act(a) | rew | done | next_obs(o) | pad] of
+// `rec` = round_up(2o+a+2, 32) floats, so a random-row gather touches whole 128-byte lines (Hopper:
+// exactly one line per transition) instead of the 5-6 partial lines an SoA layout would cost.
+// HBM-bound: algorithmic bytes per sampled row = 2*(2o+a+2)*4 (read + write), SURVEY.md §8d.
+#include "host_common.h"
+
+__global__ __launch_bounds__(256) void k_replay_add(float* __restrict__ data, int rec, long long cap, long long top,
+                                                    const float* __restrict__ obs, const float* __restrict__ act,
+                                                    const float* __restrict__ rew, const unsigned char* __restrict__ done,
+                                                    const float* __restrict__ nobs, int n, int o, int a) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)n * rec) return;
+  const int i = (int)(e / rec), c = (int)(e - (long long)i * rec);
+  float v = 0.0f;
+  if (c < o) v = obs[(size_t)i * o + c];
+  else if (c < o + a) v = act[(size_t)i * a + (c - o)];
+  else if (c == o + a) v = rew[i];
+  else if (c == o + a + 1) v = done[i] ? 1.0f : 0.0f;
+  else if (c < 2 * o + a + 2) v = nobs[(size_t)i * o + (c - o - a - 2)];
+  long long slot = top + i;
+  if (slot >= cap) slot -= cap;
+  data[(size_t)slot * rec + c] = v;
+}
+
+__global__ void k_replay_set_state(DevReplayState* s, long long size, long long top) {
+  s->size = size;
+  s->top = top;
+}
+
+__device__ __forceinline__ long long replay_draw(uint64_t seed, uint64_t step, uint32_t stream, uint32_t r, long long size) {
+  uint32_t c[4] = {r >> 2, 0x52425546u /* 'RBUF' */, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream * 0x9E3779B9u)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
+  const uint32_t u = c[r & 3];
+  return (long long)(((unsigned long long)u * (unsigned long long)size) >> 32);  // uniform on [0,size), with replacement
+}
+
+// random_batch: one thread per (row, record column); splits the record into the reference's batch keys.
+__global__ __launch_bounds__(256) void k_replay_sample(const float* __restrict__ data, int rec, const DevReplayState* st,
+                                                       const long long* __restrict__ idx, uint64_t seed, uint32_t stream,
+                                                       const DevScalars* scal, unsigned long long step_host, int B, int o,
+                                                       int a, float* __restrict__ obs, float* __restrict__ act,
+                                                       float* __restrict__ rew, float* __restrict__ done,
+                                                       float* __restrict__ nobs, long long* __restrict__ idx_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int used = 2 * o + a + 2;
+  if (e >= B * rec) return;
+  const int r = e / rec, c = e - r * rec;
+  if (c >= used) return;
+  long long row;
+  if (idx) row = idx[r];
+  else row = replay_draw(seed, scal ? scal->step : step_host, stream, (uint32_t)r, st->size);
+  const float v = data[(size_t)row * rec + c];
+  if (c < o) obs[(size_t)r * o + c] = v;
+  else if (c < o + a) act[(size_t)r * a + (c - o)] = v;
+  else if (c == o + a) rew[r] = v;
+  else if (c == o + a + 1) done[r] = v;
+  else nobs[(size_t)r * o + (c - o - a - 2)] = v;
+  if (idx_out && c == 0) idx_out[r] = row;
+}
+
+// Bandwidth form: n_batches*B whole records per launch, 16 bytes per lane.
+__global__ __launch_bounds__(256) void k_replay_sample_many(const float4* __restrict__ data, int rec4, const DevReplayState* st,
+                                                            uint64_t seed, uint32_t stream, unsigned long long step0, int B,
+                                                            long long total_rows, float4* __restrict__ out) {
+  const long long nthreads = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total_rows * rec4; e += nthreads) {
+    const long long gr = e / rec4;
+    const int c = (int)(e - gr * rec4);
+    const long long batch = gr / B;
+    const uint32_t r = (uint32_t)(gr - batch * B);
+    const long long row = replay_draw(seed, step0 + batch, stream, r, st->size);
+    out[gr * rec4 + c] = data[row * rec4 + c];
+  }
+}
+
+static int replay_push_state(ilsx_replay* rb) {
+  hipLaunchKernelGGL(k_replay_set_state, dim3(1), dim3(1), 0, rb->ctx->stream, rb->dstate, (long long)rb->size,
+                     (long long)rb->top);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_replay_create(ilsx_ctx* ctx, int64_t capacity, int obs_dim, int act_dim, uint64_t seed,
+                                  ilsx_replay** out) {
+  if (!ctx || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_create: NULL argument");
+  if (capacity < 1 || obs_dim < 1 || act_dim < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_create: bad sizes");
+  HIPCHK(hipSetDevice(ctx->device));
+  ilsx_replay* rb = new ilsx_replay();
+  rb->ctx = ctx;
+  rb->cap = capacity;
+  rb->o = obs_dim;
+  rb->a = act_dim;
+  rb->rec = (2 * obs_dim + act_dim + 2 + 31) / 32 * 32;
+  rb->seed = seed;
+  rb->rng_stream = ctx->next_rng_stream++;
+  rb->start_flag.assign((size_t)capacity, 0);
+  int rc = ctx_alloc(ctx, (size_t)capacity * rb->rec * sizeof(float), (void**)&rb->data, true);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(DevReplayState), (void**)&rb->dstate, true);
+  if (rc != ILSX_OK) { delete rb; return rc; }
+  *out = rb;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_replay_destroy(ilsx_replay* rb) {
+  if (!rb) return ILSX_OK;
+  ctx_free(rb->ctx, rb->data);
+  ctx_free(rb->ctx, rb->dstate);
+  delete rb;
+  return ILSX_OK;
+}
+
+// host mirror of add_sample/_advance/terminate_episode cursor logic (simple_replay_buffer.py:78-132,228-237)
+static void host_advance(ilsx_replay* rb) {
+  if (rb->start_flag[rb->top]) {  // O(1) membership test; the overwritten start is normally the oldest entry
+    for (auto it = rb->trajs.begin(); it != rb->trajs.end(); ++it)
+      if (it->first == rb->top) { rb->trajs.erase(it); break; }
+    rb->start_flag[rb->top] = 0;
+  }
+  rb->top = (rb->top + 1) % rb->cap;
+  if (rb->size < rb->cap) rb->size++;
+}
+static void host_set_endpoint(ilsx_replay* rb, int64_t start, int64_t end) {
+  if (rb->start_flag[start]) {
+    for (auto& p : rb->trajs)
+      if (p.first == start) { p.second = end; return; }  // dict assignment keeps the original position
+  }
+  rb->start_flag[start] = 1;
+  rb->trajs.emplace_back(start, end);
+}
+static void host_terminate(ilsx_replay* rb) {
+  if (rb->cur_start != rb->top) {
+    host_set_endpoint(rb, rb->cur_start, rb->top);
+    rb->cur_start = rb->top;
+  }
+}
+
+extern "C" int ilsx_replay_add(ilsx_replay* rb, const float* obs, const float* act, const float* rew,
+                               const uint8_t* done, const float* nobs, int n, const uint8_t* ep_end_host,
+                               int data_is_device) {
+  if (!rb || n < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_add: bad argument");
+  if (n == 0) return ILSX_OK;
+  if (!obs || !act || !rew || !done || !nobs) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_add: NULL row array");
+  if (n > rb->cap) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_add: n=%d exceeds capacity %lld", n, (long long)rb->cap);
+  ilsx_ctx* ctx = rb->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int o = rb->o, a = rb->a;
+  const float *d_obs = obs, *d_act = act, *d_rew = rew, *d_nobs = nobs;
+  const uint8_t* d_done = done;
+  std::vector<uint8_t> done_host;
+  if (!data_is_device) {
+    const size_t fl = (size_t)n * (2 * o + a + 1);
+    void* st = nullptr;
+    ILSX_TRY(ctx_stage(ctx, fl * sizeof(float) + (size_t)n + 64, &st));
+    float* f = (float*)st;
+    float* s_obs = f; float* s_act = s_obs + (size_t)n * o; float* s_rew = s_act + (size_t)n * a;
+    float* s_nobs = s_rew + n; uint8_t* s_done = (uint8_t*)(s_nobs + (size_t)n * o);
+    HIPCHK(hipMemcpyAsync(s_obs, obs, (size_t)n * o * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s_act, act, (size_t)n * a * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s_rew, rew, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s_nobs, nobs, (size_t)n * o * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s_done, done, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    d_obs = s_obs; d_act = s_act; d_rew = s_rew; d_nobs = s_nobs; d_done = s_done;
+    done_host.assign(done, done + n);
+  } else {
+    done_host.resize(n);
+    HIPCHK(hipMemcpyAsync(done_host.data(), done, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  const long long total = (long long)n * rb->rec;
+  hipLaunchKernelGGL(k_replay_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rb->data, rb->rec,
+                     (long long)rb->cap, (long long)rb->top, d_obs, d_act, d_rew, d_done, d_nobs, n, o, a);
+  HIPCHK(hipGetLastError());
+  if (!data_is_device) HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next call
+  for (int i = 0; i < n; ++i) {
+    if (done_host[i]) {  // add_sample :95-98
+      const int64_t nxt = (rb->top + 1) % rb->cap;
+      host_set_endpoint(rb, rb->cur_start, nxt);
+      rb->cur_start = nxt;
+    }
+    host_advance(rb);
+    if (ep_end_host && ep_end_host[i]) host_terminate(rb);
+  }
+  return replay_push_state(rb);
+}
+
+extern "C" int ilsx_replay_terminate_episode(ilsx_replay* rb) {
+  if (!rb) ILSX_FAIL(ILSX_ERR_ARG, "replay is NULL");
+  host_terminate(rb);
+  return ILSX_OK;
+}
+
+int replay_launch_sample(ilsx_replay* rb, int B, const int64_t* idx, const DevScalars* scal,
+                         unsigned long long step_host, float* obs, float* act, float* rew, float* done, float* nobs,
+                         int64_t* idx_out) {
+  const int total = B * rb->rec;
+  hipLaunchKernelGGL(k_replay_sample, dim3((total + 255) / 256), dim3(256), 0, rb->ctx->stream, rb->data, rb->rec,
+                     rb->dstate, (const long long*)idx, rb->seed, rb->rng_stream, scal, step_host, B, rb->o, rb->a, obs,
+                     act, rew, done, nobs, (long long*)idx_out);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_replay_sample(ilsx_replay* rb, int B, const int64_t* idx, float* obs, float* act, float* rew,
+                                  float* done, float* nobs, int64_t* idx_out) {
+  if (!rb || B < 1 || !obs || !act || !rew || !done || !nobs) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_sample: bad argument");
+  if (rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_replay_sample: buffer is empty");
+  HIPCHK(hipSetDevice(rb->ctx->device));
+  return replay_launch_sample(rb, B, idx, nullptr, ++rb->sample_ctr, obs, act, rew, done, nobs, idx_out);
+}
+
+extern "C" int ilsx_replay_sample_many(ilsx_replay* rb, int n_batches, int B, float* out_records) {
+  if (!rb || n_batches < 1 || B < 1 || !out_records) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_sample_many: bad argument");
+  if (rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_replay_sample_many: buffer is empty");
+  HIPCHK(hipSetDevice(rb->ctx->device));
+  const long long rows = (long long)n_batches * B;
+  const int rec4 = rb->rec / 4;
+  long long blocks = (rows * rec4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;  // >> 256 CUs, grid-stride the rest
+  hipLaunchKernelGGL(k_replay_sample_many, dim3((unsigned)blocks), dim3(256), 0, rb->ctx->stream,
+                     (const float4*)rb->data, rec4, rb->dstate, rb->seed, rb->rng_stream, rb->sample_ctr + 1, B, rows,
+                     (float4*)out_records);
+  rb->sample_ctr += n_batches;
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_replay_record_floats(const ilsx_replay* rb, int* out) {
+  if (!rb || !out) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  *out = rb->rec;
+  return ILSX_OK;
+}
+extern "C" int ilsx_replay_size(ilsx_replay* rb, int64_t* size, int64_t* top) {
+  if (!rb) ILSX_FAIL(ILSX_ERR_ARG, "replay is NULL");
+  if (size) *size = rb->size;
+  if (top) *top = rb->top;
+  return ILSX_OK;
+}
+extern "C" int ilsx_replay_clear(ilsx_replay* rb) {
+  if (!rb) ILSX_FAIL(ILSX_ERR_ARG, "replay is NULL");
+  HIPCHK(hipSetDevice(rb->ctx->device));
+  HIPCHK(hipMemsetAsync(rb->data, 0, (size_t)rb->cap * rb->rec * sizeof(float), rb->ctx->stream));  // :397-442
+  rb->top = rb->size = rb->cur_start = 0;
+  rb->trajs.clear();
+  std::fill(rb->start_flag.begin(), rb->start_flag.end(), 0);
+  return replay_push_state(rb);
+}
+extern "C" int ilsx_replay_traj_endpoints(ilsx_replay* rb, int64_t* starts, int64_t* ends, int max, int* n) {
+  if (!rb || !n) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  int k = 0;
+  for (auto& p : rb->trajs) {
+    if (k < max && starts && ends) { starts[k] = p.first; ends[k] = p.second; }
+    ++k;
+  }
+  *n = k;
+  return ILSX_OK;
+}

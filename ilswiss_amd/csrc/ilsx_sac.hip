@@ -1,0 +1,603 @@
+// ilsx_sac.hip — SoftActorCritic (twin Q, auto alpha): rlkit/torch/algorithms/sac/sac_alpha.py:21-181.
+//
+// One agent = one parameter arena in HBM  P = [Q1 | Q2 | pi | TQ1 | TQ2], a gradient arena
+// G = [Q1 | Q2 | pi | alpha-slot], Adam moments M,V = [Q1 | Q2 | pi], device scalars (log_alpha in
+// float64, step counters) and a per-batch activation workspace.  A train step is 14 launches
+// (sequence below), captured once per (replay, B) into a hipGraph for train_from_replay.
+//
+//   critic_backward : fwd{pi(s'), Q1(s,a), Q2(s,a)} ; fwd{TQ1(s',a'), TQ2(s',a')} ;
+//                     bwd_dx{Q1,Q2 with the TD-target loss head} ; bwd_dw{Q1,Q2}
+//   critic_update   : adam+polyak over [Q1|Q2] -> also writes [TQ1|TQ2]   (targets use post-Adam Q,
+//                     and nothing reads them again this step: bitwise the same as sac_alpha.py:181)
+//   actor_backward  : fwd{pi(s)} ; fwd{Q1(s,a~), Q2(s,a~)} (updated critics) ;
+//                     bwd_dx{Q1,Q2 -> d(-min Q)/da~} ; bwd_dx{pi with the tanh-Gaussian loss head} ;
+//                     bwd_dw{pi} ; stats (+ alpha gradient into the arena slot)
+//   actor_update    : adam over pi ; finish (alpha Adam in float64, counters)
+#include <cmath>
+#include <cstdlib>
+
+#include "host_common.h"
+
+enum { W_PI = 0, W_Q1 = 1, W_Q2 = 2, W_TQ1 = 3, W_TQ2 = 4 };
+
+struct SacWs {  // device workspace for B <= max_batch rows
+  float *s, *a, *r, *d, *s2, *eps1, *eps2;     // batch staging
+  float *a2, *logp2, *q1, *q2, *tq1, *tq2;       // critic phase
+  float *xq[2], *hq[2][ILSX_MAX_HID], *dq[2][ILSX_MAX_HID], *dhq[2];
+  float *raw, *an, *logp, *epss, *q1n, *q2n, *ga[2];
+  float *xp, *hp[ILSX_MAX_HID], *dp[ILSX_MAX_HID], *dhp;
+};
+
+struct ilsx_sac {
+  ilsx_ctx* ctx = nullptr;
+  ilsx_sac_cfg cfg;
+  ilsx_net *pi = nullptr, *q1 = nullptr, *q2 = nullptr;
+  NetLayout Lq, Lp;
+  int o = 0, a = 0;
+  size_t nq = 0, np = 0;     // internal floats per critic / policy
+  float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
+  DevScalars* scal = nullptr;
+  SacWs ws;
+  DwJob *jobs_q = nullptr, *jobs_p = nullptr;
+  int njobs_q = 0, njobs_p = 0;
+  int B = 0;                 // rows of the batch currently staged
+  bool eps_explicit = false;
+  float target_entropy = 0.f;
+  uint32_t rng_stream = 0;
+  // hipGraph cache for train_from_replay
+  hipGraphExec_t graph = nullptr;
+  ilsx_replay* graph_rb = nullptr;
+  int graph_B = 0;
+  float* base(int which) const {
+    switch (which) {
+      case W_Q1: return P;
+      case W_Q2: return P + nq;
+      case W_PI: return P + 2 * nq;
+      case W_TQ1: return P + 2 * nq + np;
+      default: return P + 3 * nq + np;
+    }
+  }
+  float* gbase(int which) const { return which == W_Q1 ? G : which == W_Q2 ? G + nq : G + 2 * nq; }
+  size_t trainable_off(int which) const { return which == W_Q1 ? 0 : which == W_Q2 ? nq : 2 * nq; }
+};
+
+// ------------------------------------------------------------------------------------------------
+struct StatsArgs {
+  const float *q1, *q2, *tq1, *tq2, *logp2, *r, *d, *logp, *q1n, *q2n, *raw;
+  int B, a;
+  float gamma, reward_scale, w_mu, w_std, target_entropy, inv_B;
+  DevScalars* scal;
+  float* alpha_grad_slot;  // G arena slot: -(sum(logp + target_entropy)) * inv_B
+};
+
+// single workgroup: losses of sac_alpha.py:122-123,148-153,161-162 + the alpha gradient
+__global__ __launch_bounds__(256) void k_sac_stats(const StatsArgs S) {
+  __shared__ float sh[4];
+  const float alpha = S.scal->alpha;
+  float l1 = 0, l2 = 0, pl = 0, lp = 0, mu2 = 0, ls2 = 0, mus = 0, lss = 0, q1s = 0, q2s = 0, lpe = 0;
+  for (int r = threadIdx.x; r < S.B; r += 256) {
+    const float y = S.reward_scale * S.r[r] +
+                    (1.0f - S.d[r]) * S.gamma * (fminf(S.tq1[r], S.tq2[r]) - alpha * S.logp2[r]);
+    const float e1 = S.q1[r] - y, e2 = S.q2[r] - y;
+    l1 += e1 * e1; l2 += e2 * e2; q1s += S.q1[r]; q2s += S.q2[r];
+    pl += alpha * S.logp[r] - fminf(S.q1n[r], S.q2n[r]);
+    lp += S.logp[r];
+    lpe += S.logp[r] + S.target_entropy;
+    for (int j = 0; j < S.a; ++j) {
+      const float mu = S.raw[(size_t)r * 2 * S.a + j];
+      const float ls = fminf(fmaxf(S.raw[(size_t)r * 2 * S.a + S.a + j], LOG_SIG_MIN), LOG_SIG_MAX);
+      mu2 += mu * mu; ls2 += ls * ls; mus += mu; lss += ls;
+    }
+  }
+  l1 = block256_sum(l1, sh); l2 = block256_sum(l2, sh); pl = block256_sum(pl, sh); lp = block256_sum(lp, sh);
+  mu2 = block256_sum(mu2, sh); ls2 = block256_sum(ls2, sh); mus = block256_sum(mus, sh); lss = block256_sum(lss, sh);
+  q1s = block256_sum(q1s, sh); q2s = block256_sum(q2s, sh); lpe = block256_sum(lpe, sh);
+  if (threadIdx.x == 0) {
+    const float iB = 1.0f / (float)S.B, iBa = iB / (float)S.a;
+    DevScalars* sc = S.scal;
+    sc->qf1_loss = 0.5f * l1 * iB;
+    sc->qf2_loss = 0.5f * l2 * iB;
+    sc->policy_loss = pl * iB + S.w_mu * mu2 * iBa + S.w_std * ls2 * iBa;
+    sc->alpha_loss = -(float)sc->log_alpha * (lpe * iB);
+    sc->q1_mean = q1s * iB; sc->q2_mean = q2s * iB; sc->log_pi_mean = lp * iB;
+    sc->mu_mean = mus * iBa; sc->log_std_mean = lss * iBa;
+    sc->alpha_used = alpha;
+    sc->log_alpha_used = sc->log_alpha;
+    S.alpha_grad_slot[0] = -lpe * S.inv_B;  // d(alpha_loss)/d(log_alpha), summed over ranks by the all-reduce
+    S.alpha_grad_slot[1] = 0.f; S.alpha_grad_slot[2] = 0.f; S.alpha_grad_slot[3] = 0.f;
+  }
+}
+
+// alpha Adam in float64 (sac_alpha.py:51-53,160-166) + step counters
+__global__ void k_sac_finish(DevScalars* sc, const float* alpha_grad_slot, int train_alpha, float lr, float b1,
+                             float b2, float eps) {
+  if (train_alpha) {
+    const double g = (double)alpha_grad_slot[0];
+    const int t = sc->t_alpha + 1;
+    sc->m_alpha = sc->m_alpha * (double)b1 + (1.0 - (double)b1) * g;
+    sc->v_alpha = sc->v_alpha * (double)b2 + (1.0 - (double)b2) * g * g;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const double denom = sqrt(sc->v_alpha) / sqrt(bc2) + (double)eps;
+    sc->log_alpha -= ((double)lr / bc1) * (sc->m_alpha / denom);
+    sc->alpha = (float)exp(sc->log_alpha);
+    sc->t_alpha = t;
+  }
+  sc->t_q += 1;
+  sc->t_pi += 1;
+  sc->step += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int sac_alloc_ws(ilsx_sac* s) {
+  ilsx_ctx* c = s->ctx;
+  const size_t B = (size_t)s->cfg.max_batch;
+  const int o = s->o, a = s->a, H = s->Lq.cfg.hidden;
+  SacWs& w = s->ws;
+  auto A = [&](float** p, size_t n) { return ctx_alloc(c, n * sizeof(float), (void**)p, true); };
+  ILSX_TRY(A(&w.s, B * o)); ILSX_TRY(A(&w.a, B * a)); ILSX_TRY(A(&w.r, B)); ILSX_TRY(A(&w.d, B));
+  ILSX_TRY(A(&w.s2, B * o)); ILSX_TRY(A(&w.eps1, B * a)); ILSX_TRY(A(&w.eps2, B * a));
+  ILSX_TRY(A(&w.a2, B * a)); ILSX_TRY(A(&w.logp2, B)); ILSX_TRY(A(&w.q1, B)); ILSX_TRY(A(&w.q2, B));
+  ILSX_TRY(A(&w.tq1, B)); ILSX_TRY(A(&w.tq2, B));
+  for (int i = 0; i < 2; ++i) {
+    ILSX_TRY(A(&w.xq[i], B * s->Lq.KP));
+    for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) { ILSX_TRY(A(&w.hq[i][l], B * H)); ILSX_TRY(A(&w.dq[i][l], B * H)); }
+    ILSX_TRY(A(&w.dhq[i], B * 4));
+    ILSX_TRY(A(&w.ga[i], B * a));
+  }
+  ILSX_TRY(A(&w.raw, B * 2 * a)); ILSX_TRY(A(&w.an, B * a)); ILSX_TRY(A(&w.logp, B)); ILSX_TRY(A(&w.epss, B * a));
+  ILSX_TRY(A(&w.q1n, B)); ILSX_TRY(A(&w.q2n, B));
+  ILSX_TRY(A(&w.xp, B * s->Lp.KP));
+  for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) { ILSX_TRY(A(&w.hp[l], B * H)); ILSX_TRY(A(&w.dp[l], B * H)); }
+  ILSX_TRY(A(&w.dhp, B * 2 * a));
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net* pi, ilsx_net* q1, ilsx_net* q2,
+                               ilsx_sac** out) {
+  if (!ctx || !cfg || !pi || !q1 || !q2 || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_create: NULL argument");
+  if (pi->ctx != ctx || q1->ctx != ctx || q2->ctx != ctx) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_create: nets belong to another ctx");
+  const ilsx_mlp_cfg &cp = pi->lay.cfg, &c1 = q1->lay.cfg, &c2 = q2->lay.cfg;
+  if (cp.n_heads != 2) ILSX_FAIL(ILSX_ERR_ARG, "policy must have 2 heads (mean | log_std), policies.py:231-239");
+  if (c1.n_heads != 1 || c1.out_dim != 1 || memcmp(&c1, &c2, sizeof c1) != 0)
+    ILSX_FAIL(ILSX_ERR_ARG, "qf1/qf2 must be identical single-output FlattenMlp's");
+  if (c1.in_dim != cp.in_dim + cp.out_dim) ILSX_FAIL(ILSX_ERR_ARG, "qf input %d != obs %d + act %d", c1.in_dim, cp.in_dim, cp.out_dim);
+  if (c1.hidden != cp.hidden || c1.n_hidden != cp.n_hidden || c1.act != cp.act)
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "policy and critics must share hidden width/depth/activation");
+  if (!pi->owns || !q1->owns || !q2->owns) ILSX_FAIL(ILSX_ERR_STATE, "a network already belongs to an agent");
+  if (cfg->max_batch < 1 || cfg->max_batch > (1 << 20)) ILSX_FAIL(ILSX_ERR_ARG, "max_batch=%d out of range", cfg->max_batch);
+  HIPCHK(hipSetDevice(ctx->device));
+  ilsx_sac* s = new ilsx_sac();
+  s->ctx = ctx; s->cfg = *cfg; s->pi = pi; s->q1 = q1; s->q2 = q2;
+  if (s->cfg.grad_world < 1) s->cfg.grad_world = 1;
+  s->Lq = q1->lay; s->Lp = pi->lay;
+  s->o = cp.in_dim; s->a = cp.out_dim;
+  s->nq = s->Lq.n_int; s->np = s->Lp.n_int;
+  s->target_entropy = cfg->has_target_entropy ? cfg->target_entropy : -(float)s->a / 2.0f;  // sac_alpha.py:56-58
+  s->rng_stream = ctx->next_rng_stream;
+  ctx->next_rng_stream += 2;
+  const size_t nP = 4 * s->nq + s->np, nT = 2 * s->nq + s->np;
+  int rc = ctx_alloc(ctx, nP * 4, (void**)&s->P);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, (nT + 4) * 4, (void**)&s->G);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, nT * 4, (void**)&s->M);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, nT * 4, (void**)&s->V);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(DevScalars), (void**)&s->scal);
+  if (rc == ILSX_OK) rc = sac_alloc_ws(s);
+  if (rc != ILSX_OK) { delete s; return rc; }
+  // adopt the networks' storage: copy into the arena, targets = copies (sac_alpha.py:60-61)
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(s->base(W_Q1), q1->base, s->nq * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->base(W_Q2), q2->base, s->nq * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->base(W_PI), pi->base, s->np * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->base(W_TQ1), q1->base, s->nq * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->base(W_TQ2), q2->base, s->nq * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  ilsx_net* nets[3] = {pi, q1, q2};
+  const int wh[3] = {W_PI, W_Q1, W_Q2};
+  for (int i = 0; i < 3; ++i) {
+    ILSX_TRY(ctx_free(ctx, nets[i]->base));
+    nets[i]->base = s->base(wh[i]);
+    nets[i]->owns = false;
+  }
+  DevScalars h;
+  memset(&h, 0, sizeof h);
+  h.log_alpha = std::log((double)cfg->alpha);  // sac_alpha.py:51-53 (np.log -> float64)
+  h.alpha = (float)std::exp(h.log_alpha);
+  h.alpha_used = h.alpha;
+  h.log_alpha_used = h.log_alpha;
+  HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  // weight-gradient job tables
+  std::vector<DwJob> jq, jp;
+  for (int i = 0; i < 2; ++i)
+    build_dw_jobs(s->Lq, s->gbase(i == 0 ? W_Q1 : W_Q2), s->ws.xq[i], s->ws.hq[i], s->ws.dq[i], s->ws.dhq[i], &jq);
+  build_dw_jobs(s->Lp, s->gbase(W_PI), s->ws.xp, s->ws.hp, s->ws.dp, s->ws.dhp, &jp);
+  s->njobs_q = (int)jq.size(); s->njobs_p = (int)jp.size();
+  ILSX_TRY(ctx_alloc(ctx, jq.size() * sizeof(DwJob), (void**)&s->jobs_q));
+  ILSX_TRY(ctx_alloc(ctx, jp.size() * sizeof(DwJob), (void**)&s->jobs_p));
+  HIPCHK(hipMemcpyAsync(s->jobs_q, jq.data(), jq.size() * sizeof(DwJob), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->jobs_p, jp.data(), jp.size() * sizeof(DwJob), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *out = s;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
+  if (!s) return ILSX_OK;
+  hipSetDevice(s->ctx->device);
+  hipStreamSynchronize(s->ctx->stream);
+  if (s->graph) hipGraphExecDestroy(s->graph);
+  // give the networks private storage back so their handles stay usable
+  ilsx_net* nets[3] = {s->pi, s->q1, s->q2};
+  const int wh[3] = {W_PI, W_Q1, W_Q2};
+  for (int i = 0; i < 3; ++i) {
+    float* nb = nullptr;
+    if (ctx_alloc(s->ctx, nets[i]->lay.n_int * 4, (void**)&nb, false) == ILSX_OK) {
+      hipMemcpyAsync(nb, s->base(wh[i]), nets[i]->lay.n_int * 4, hipMemcpyDeviceToDevice, s->ctx->stream);
+      hipStreamSynchronize(s->ctx->stream);
+      nets[i]->base = nb;
+      nets[i]->owns = true;
+    }
+  }
+  // workspace / arenas are released with the ctx (ctx owns every allocation); free the big ones now
+  ctx_free(s->ctx, s->P); ctx_free(s->ctx, s->G); ctx_free(s->ctx, s->M); ctx_free(s->ctx, s->V);
+  delete s;
+  return ILSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static float sac_inv_B(const ilsx_sac* s) { return 1.0f / ((float)s->B * (float)s->cfg.grad_world); }
+
+static int sac_critic_backward(ilsx_sac* s) {
+  const SacWs& w = s->ws;
+  const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act;
+  {  // fwd: pi(s') with eps_next ; Q1(s,a) ; Q2(s,a)
+    FwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = B; A.ntasks = 3; A.seed = s->ctx->seed; A.scal = s->scal;
+    FwdTask& t = A.t[0];
+    t.net = net_view(s->Lp, s->base(W_PI));
+    t.x0 = w.s2; t.d0 = s->o; t.s0 = s->o;
+    t.head = HEAD_TANH_SAMPLE; t.rng_stream = s->rng_stream;
+    t.eps = s->eps_explicit ? w.eps1 : nullptr;
+    t.action = w.a2; t.logp = w.logp2;
+    for (int i = 0; i < 2; ++i) {
+      FwdTask& q = A.t[1 + i];
+      q.net = net_view(s->Lq, s->base(i == 0 ? W_Q1 : W_Q2));
+      q.x0 = w.s; q.d0 = s->o; q.s0 = s->o; q.x1 = w.a; q.d1 = s->a; q.s1 = s->a;
+      q.xsave = w.xq[i];
+      for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) q.hsave[l] = w.hq[i][l];
+      q.out = i == 0 ? w.q1 : w.q2;
+      q.head = HEAD_RAW;
+    }
+    ILSX_TRY(launch_fwd(s->ctx, A, H, act, std::max(s->Lq.KP, s->Lp.KP)));
+  }
+  {  // fwd: TQ1(s',a'), TQ2(s',a')
+    FwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal;
+    for (int i = 0; i < 2; ++i) {
+      FwdTask& q = A.t[i];
+      q.net = net_view(s->Lq, s->base(i == 0 ? W_TQ1 : W_TQ2));
+      q.x0 = w.s2; q.d0 = s->o; q.s0 = s->o; q.x1 = w.a2; q.d1 = s->a; q.s1 = s->a;
+      q.out = i == 0 ? w.tq1 : w.tq2;
+      q.head = HEAD_RAW;
+    }
+    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP));
+  }
+  {  // bwd_dx with the TD-target loss head
+    BwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = B; A.ntasks = 2; A.inv_B = sac_inv_B(s);
+    A.gamma = s->cfg.discount; A.reward_scale = s->cfg.reward_scale; A.scal = s->scal;
+    for (int i = 0; i < 2; ++i) {
+      BwdTask& t = A.t[i];
+      t.net = net_view(s->Lq, s->base(i == 0 ? W_Q1 : W_Q2));
+      for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) { t.hsave[l] = w.hq[i][l]; t.dsave[l] = w.dq[i][l]; }
+      t.dhead = w.dhq[i];
+      t.loss = LOSS_SAC_CRITIC;
+      t.q = i == 0 ? w.q1 : w.q2; t.tq1 = w.tq1; t.tq2 = w.tq2; t.logp_next = w.logp2; t.rew = w.r; t.done = w.d;
+    }
+    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act));
+  }
+  return launch_bwd_dw(s->ctx, s->jobs_q, s->njobs_q, B);
+}
+
+static int sac_critic_update(ilsx_sac* s) {
+  AdamArgs A;
+  A.p = s->P; A.g = s->G; A.m = s->M; A.v = s->V; A.tgt = s->base(W_TQ1);
+  A.n = (int)(2 * s->nq);
+  A.lr = s->cfg.qf_lr; A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = s->cfg.soft_target_tau;
+  A.t_ctr = &s->scal->t_q;
+  return launch_adam(s->ctx, A);  // t_q is advanced by k_sac_finish at the end of the step
+}
+
+static int sac_actor_backward(ilsx_sac* s) {
+  const SacWs& w = s->ws;
+  const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act;
+  {  // fwd pi(s) with eps_cur
+    FwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = B; A.ntasks = 1; A.seed = s->ctx->seed; A.scal = s->scal;
+    FwdTask& t = A.t[0];
+    t.net = net_view(s->Lp, s->base(W_PI));
+    t.x0 = w.s; t.d0 = s->o; t.s0 = s->o;
+    t.xsave = w.xp;
+    for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) t.hsave[l] = w.hp[l];
+    t.out = w.raw;
+    t.head = HEAD_TANH_SAMPLE; t.rng_stream = s->rng_stream + 1;
+    t.eps = s->eps_explicit ? w.eps2 : nullptr;
+    t.eps_save = w.epss; t.action = w.an; t.logp = w.logp;
+    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lp.KP));
+  }
+  {  // fwd Q1(s,a~), Q2(s,a~) with the just-updated critics (sac_alpha.py:144-146)
+    FwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal;
+    for (int i = 0; i < 2; ++i) {
+      FwdTask& q = A.t[i];
+      q.net = net_view(s->Lq, s->base(i == 0 ? W_Q1 : W_Q2));
+      q.x0 = w.s; q.d0 = s->o; q.s0 = s->o; q.x1 = w.an; q.d1 = s->a; q.s1 = s->a;
+      for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) q.hsave[l] = w.hq[i][l];
+      q.out = i == 0 ? w.q1n : w.q2n;
+      q.head = HEAD_RAW;
+    }
+    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP));
+  }
+  {  // bwd_dx through both critics to the action columns
+    BwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = B; A.ntasks = 2; A.inv_B = sac_inv_B(s); A.scal = s->scal;
+    for (int i = 0; i < 2; ++i) {
+      BwdTask& t = A.t[i];
+      t.net = net_view(s->Lq, s->base(i == 0 ? W_Q1 : W_Q2));
+      for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) t.hsave[l] = w.hq[i][l];
+      t.loss = LOSS_SAC_ACTORQ; t.which = i; t.q1n = w.q1n; t.q2n = w.q2n;
+      t.dx = w.ga[i]; t.dx_col0 = s->o; t.dx_cols = s->a;
+    }
+    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act));
+  }
+  {  // bwd_dx of the policy with the tanh-Gaussian loss head
+    BwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = B; A.ntasks = 1; A.inv_B = sac_inv_B(s); A.scal = s->scal;
+    A.w_mu = s->cfg.policy_mean_reg_weight; A.w_std = s->cfg.policy_std_reg_weight;
+    BwdTask& t = A.t[0];
+    t.net = net_view(s->Lp, s->base(W_PI));
+    for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) { t.hsave[l] = w.hp[l]; t.dsave[l] = w.dp[l]; }
+    t.dhead = w.dhp;
+    t.loss = LOSS_SAC_POLICY;
+    t.raw = w.raw; t.eps = w.epss; t.action = w.an; t.ga1 = w.ga[0]; t.ga2 = w.ga[1];
+    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act));
+  }
+  ILSX_TRY(launch_bwd_dw(s->ctx, s->jobs_p, s->njobs_p, B));
+  StatsArgs S;
+  S.q1 = w.q1; S.q2 = w.q2; S.tq1 = w.tq1; S.tq2 = w.tq2; S.logp2 = w.logp2; S.r = w.r; S.d = w.d;
+  S.logp = w.logp; S.q1n = w.q1n; S.q2n = w.q2n; S.raw = w.raw;
+  S.B = B; S.a = s->a;
+  S.gamma = s->cfg.discount; S.reward_scale = s->cfg.reward_scale;
+  S.w_mu = s->cfg.policy_mean_reg_weight; S.w_std = s->cfg.policy_std_reg_weight;
+  S.target_entropy = s->target_entropy; S.inv_B = sac_inv_B(s);
+  S.scal = s->scal; S.alpha_grad_slot = s->G + 2 * s->nq + s->np;
+  hipLaunchKernelGGL(k_sac_stats, dim3(1), dim3(256), 0, s->ctx->stream, S);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+static int sac_actor_update(ilsx_sac* s) {
+  AdamArgs A;
+  const size_t off = 2 * s->nq;
+  A.p = s->P + off; A.g = s->G + off; A.m = s->M + off; A.v = s->V + off; A.tgt = nullptr;
+  A.n = (int)s->np;
+  A.lr = s->cfg.policy_lr; A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = 0.f;
+  A.t_ctr = &s->scal->t_pi;
+  ILSX_TRY(launch_adam(s->ctx, A));
+  hipLaunchKernelGGL(k_sac_finish, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, (const float*)(s->G + 2 * s->nq + s->np),
+                     s->cfg.train_alpha, s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+static int sac_full_step(ilsx_sac* s) {
+  ILSX_TRY(sac_critic_backward(s));
+  ILSX_TRY(sac_critic_update(s));
+  ILSX_TRY(sac_actor_backward(s));
+  return sac_actor_update(s);
+}
+
+static int sac_read_stats(ilsx_sac* s, ilsx_sac_stats* out) {
+  DevScalars h;
+  HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  out->qf1_loss = h.qf1_loss; out->qf2_loss = h.qf2_loss; out->policy_loss = h.policy_loss;
+  out->alpha_loss = h.alpha_loss; out->alpha = h.alpha;
+  out->q1_mean = h.q1_mean; out->q2_mean = h.q2_mean; out->log_pi_mean = h.log_pi_mean;
+  out->policy_mu_mean = h.mu_mean; out->policy_log_std_mean = h.log_std_mean;
+  out->log_alpha = h.log_alpha;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_sac_set_batch(ilsx_sac* s, const float* obs, const float* act, const float* rew,
+                                  const float* done, const float* nobs, int B, const float* eps_next,
+                                  const float* eps_cur) {
+  if (!s || !obs || !act || !rew || !done || !nobs) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_set_batch: NULL argument");
+  if (B < 1 || B > s->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch=%d", B, s->cfg.max_batch);
+  if ((eps_next == nullptr) != (eps_cur == nullptr)) ILSX_FAIL(ILSX_ERR_ARG, "give both eps_next and eps_cur or neither");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  hipStream_t st = s->ctx->stream;
+  const SacWs& w = s->ws;
+  const size_t o = s->o, a = s->a, b = B;
+  HIPCHK(hipMemcpyAsync(w.s, obs, b * o * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(w.a, act, b * a * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(w.r, rew, b * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(w.d, done, b * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(w.s2, nobs, b * o * 4, hipMemcpyDeviceToDevice, st));
+  if (eps_next) {
+    HIPCHK(hipMemcpyAsync(w.eps1, eps_next, b * a * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(w.eps2, eps_cur, b * a * 4, hipMemcpyDeviceToDevice, st));
+  }
+  s->eps_explicit = eps_next != nullptr;
+  s->B = B;
+  return ILSX_OK;
+}
+
+#define SAC_PHASE(name, fn)                                                        \
+  extern "C" int name(ilsx_sac* s) {                                               \
+    if (!s) ILSX_FAIL(ILSX_ERR_ARG, #name ": NULL agent");                         \
+    if (s->B < 1) ILSX_FAIL(ILSX_ERR_STATE, #name ": no batch staged (ilsx_sac_set_batch)"); \
+    HIPCHK(hipSetDevice(s->ctx->device));                                          \
+    return fn(s);                                                                  \
+  }
+SAC_PHASE(ilsx_sac_critic_backward, sac_critic_backward)
+SAC_PHASE(ilsx_sac_critic_update, sac_critic_update)
+SAC_PHASE(ilsx_sac_actor_backward, sac_actor_backward)
+SAC_PHASE(ilsx_sac_actor_update, sac_actor_update)
+
+extern "C" int ilsx_sac_last_stats(ilsx_sac* s, ilsx_sac_stats* stats) {
+  if (!s || !stats) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_last_stats: NULL argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  return sac_read_stats(s, stats);
+}
+
+extern "C" int ilsx_sac_train_step(ilsx_sac* s, const float* obs, const float* act, const float* rew,
+                                   const float* done, const float* nobs, int B, const float* eps_next,
+                                   const float* eps_cur, ilsx_sac_stats* stats) {
+  ILSX_TRY(ilsx_sac_set_batch(s, obs, act, rew, done, nobs, B, eps_next, eps_cur));
+  ILSX_TRY(sac_full_step(s));
+  if (stats) return sac_read_stats(s, stats);
+  return ILSX_OK;
+}
+
+static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
+  const SacWs& w = s->ws;
+  ILSX_TRY(replay_launch_sample(rb, B, nullptr, s->scal, 0, w.s, w.a, w.r, w.d, w.s2, nullptr));
+  return sac_full_step(s);
+}
+
+extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats) {
+  if (!s || !rb || n_steps < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_train_from_replay: bad argument");
+  if (B < 1 || B > s->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch=%d", B, s->cfg.max_batch);
+  if (rb->o != s->o || rb->a != s->a) ILSX_FAIL(ILSX_ERR_ARG, "replay dims (%d,%d) != agent dims (%d,%d)", rb->o, rb->a, s->o, s->a);
+  if (rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "replay buffer is empty");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  hipStream_t st = s->ctx->stream;
+  s->B = B;
+  s->eps_explicit = false;
+  static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
+  if (no_graph) {
+    for (int i = 0; i < n_steps; ++i) ILSX_TRY(sac_sample_and_step(s, rb, B));
+  } else {
+    if (!s->graph || s->graph_rb != rb || s->graph_B != B) {
+      if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
+      hipGraph_t g = nullptr;
+      HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int rc = sac_sample_and_step(s, rb, B);
+      hipError_t e = hipStreamEndCapture(st, &g);
+      if (rc != ILSX_OK) { if (g) hipGraphDestroy(g); return rc; }
+      if (e != hipSuccess) ILSX_FAIL(ILSX_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      if (e != hipSuccess) { s->graph = nullptr; ILSX_FAIL(ILSX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+      s->graph_rb = rb; s->graph_B = B;
+    }
+    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(s->graph, st));
+  }
+  if (stats) return sac_read_stats(s, stats);
+  return ILSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static const NetLayout* sac_layout(const ilsx_sac* s, int which) { return which == W_PI ? &s->Lp : &s->Lq; }
+
+extern "C" int ilsx_sac_get_params(ilsx_sac* s, int which, float* dst, size_t n, int dst_is_device) {
+  if (!s || !dst || which < 0 || which > 4) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_get_params: bad argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  return net_download_flat(s->ctx, *sac_layout(s, which), s->base(which), dst, n, dst_is_device);
+}
+extern "C" int ilsx_sac_set_params(ilsx_sac* s, int which, const float* src, size_t n, int src_is_device) {
+  if (!s || !src || which < 0 || which > 4) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_set_params: bad argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  return net_upload_flat(s->ctx, *sac_layout(s, which), s->base(which), src, n, src_is_device);
+}
+extern "C" int ilsx_sac_get_grads(ilsx_sac* s, int which, float* dst, size_t n, int dst_is_device) {
+  if (!s || !dst || which < 0 || which > 2) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_get_grads: bad argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  return net_download_flat(s->ctx, *sac_layout(s, which), s->gbase(which), dst, n, dst_is_device);
+}
+extern "C" int ilsx_sac_grads_ptr(ilsx_sac* s, int segment, float** dev_ptr, size_t* n) {
+  if (!s || !dev_ptr || !n || segment < 0 || segment > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_grads_ptr: bad argument");
+  if (segment == 0) { *dev_ptr = s->G; *n = 2 * s->nq; }
+  else { *dev_ptr = s->G + 2 * s->nq; *n = s->np + 4; }
+  return ILSX_OK;
+}
+extern "C" int ilsx_sac_get_log_alpha(ilsx_sac* s, double* out) {
+  if (!s || !out) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  DevScalars h;
+  HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  *out = h.log_alpha;
+  return ILSX_OK;
+}
+extern "C" int ilsx_sac_set_log_alpha(ilsx_sac* s, double v) {
+  if (!s) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  DevScalars h;
+  HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  h.log_alpha = v;
+  h.alpha = (float)std::exp(v);
+  HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  return ILSX_OK;
+}
+extern "C" int ilsx_sac_get_adam(ilsx_sac* s, int which, float* m_host, float* v_host, size_t n, int64_t* t) {
+  if (!s || !m_host || !v_host || which < 0 || which > 2) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_get_adam: bad argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const size_t off = s->trainable_off(which);
+  ILSX_TRY(net_download_flat(s->ctx, *sac_layout(s, which), s->M + off, m_host, n, 0));
+  ILSX_TRY(net_download_flat(s->ctx, *sac_layout(s, which), s->V + off, v_host, n, 0));
+  if (t) {
+    DevScalars h;
+    HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    *t = which == W_PI ? h.t_pi : h.t_q;
+  }
+  return ILSX_OK;
+}
+extern "C" int ilsx_sac_set_adam(ilsx_sac* s, int which, const float* m_host, const float* v_host, size_t n, int64_t t) {
+  if (!s || !m_host || !v_host || which < 0 || which > 2) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_set_adam: bad argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const size_t off = s->trainable_off(which);
+  ILSX_TRY(net_upload_flat(s->ctx, *sac_layout(s, which), s->M + off, m_host, n, 0));
+  ILSX_TRY(net_upload_flat(s->ctx, *sac_layout(s, which), s->V + off, v_host, n, 0));
+  DevScalars h;
+  HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  if (which == W_PI) h.t_pi = (int)t; else h.t_q = (int)t;
+  HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  return ILSX_OK;
+}
+extern "C" int ilsx_sac_get_alpha_opt(ilsx_sac* s, double* m, double* v, int64_t* t, uint64_t* rng_step) {
+  if (!s) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  DevScalars h;
+  HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  if (m) *m = h.m_alpha;
+  if (v) *v = h.v_alpha;
+  if (t) *t = h.t_alpha;
+  if (rng_step) *rng_step = h.step;
+  return ILSX_OK;
+}
+extern "C" int ilsx_sac_set_alpha_opt(ilsx_sac* s, double m, double v, int64_t t, uint64_t rng_step) {
+  if (!s) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  DevScalars h;
+  HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  h.m_alpha = m; h.v_alpha = v; h.t_alpha = (int)t; h.step = rng_step;
+  HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  return ILSX_OK;
+}

@@ -1,0 +1,185 @@
+/* ilsx.h — C ABI of libilsx.so, the MI355X (gfx950) engine behind ILSwiss's hot path.
+ *
+ * The reference (Ericonaldo/ILSwiss) is pure Python and has no FFI; the boundary this library sits
+ * behind is the set of duck-typed Python interfaces its training loop calls.  Each
+ * entry point below names the reference interface (file:line under /root/reference) whose arithmetic
+ * it replaces; ilswiss_amd/*.py binds them with ctypes and re-exposes the reference's class/method
+ * names.  INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - return value: 0 = OK, <0 = ilsx_status; text via ilsx_last_error() (thread-local). No C++
+ *     exception crosses the ABI.
+ *   - pointers are DEVICE pointers on the ctx's GPU unless the name/flag says host.
+ *   - caller owns every input/output buffer; the library owns what *_create returned until *_destroy.
+ *   - a ctx is bound to one HIP stream; calls are asynchronous on that stream unless they return
+ *     host-visible values (stats, sizes), in which case they synchronise the stream themselves.
+ *   - flat parameter layout of a network ("torch parameters() order", rlkit/torch/common/networks.py:57-83,
+ *     policies.py:231-239): fc0.W[H,in] row-major | fc0.b[H] | fc1.W[H,H] | fc1.b[H] | ... |
+ *     head0.W[out,H] | head0.b[out] [| head1.W[out,H] | head1.b[out]]      (y = x W^T + b).
+ *   - stochastic entry points take optional explicit noise / indices (parity mode) and otherwise use
+ *     counter-based Philox4x32-10 keyed by (ctx seed, stream id, step counter).
+ */
+#ifndef ILSX_H
+#define ILSX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILSX_ABI_VERSION 1
+
+typedef enum {
+  ILSX_OK = 0,
+  ILSX_ERR_ARG = -1,      /* bad argument / shape */
+  ILSX_ERR_HIP = -2,      /* a HIP runtime call failed */
+  ILSX_ERR_NOMEM = -3,
+  ILSX_ERR_STATE = -4,    /* call not valid in the object's current state */
+  ILSX_ERR_UNSUPPORTED = -5
+} ilsx_status;
+
+typedef struct ilsx_ctx ilsx_ctx;
+typedef struct ilsx_net ilsx_net;
+typedef struct ilsx_replay ilsx_replay;
+typedef struct ilsx_sac ilsx_sac;
+typedef struct ilsx_vecenv ilsx_vecenv;
+
+enum { ILSX_ACT_RELU = 0, ILSX_ACT_TANH = 1 };
+
+/* ---------------------------------------------------------------- context */
+int ilsx_abi_version(void);
+const char* ilsx_last_error(void);
+/* stream: an existing hipStream_t to run on (e.g. torch's current stream), or NULL to create one. */
+int ilsx_ctx_create(int hip_device, void* hip_stream, uint64_t seed, ilsx_ctx** out);
+int ilsx_ctx_sync(ilsx_ctx* ctx);
+int ilsx_ctx_destroy(ilsx_ctx* ctx);
+void* ilsx_ctx_stream(ilsx_ctx* ctx);
+/* Device scratch owned by the ctx (freed with it); used by the Python adapters for staging. */
+int ilsx_ctx_alloc(ilsx_ctx* ctx, size_t bytes, void** out);
+int ilsx_ctx_free(ilsx_ctx* ctx, void* ptr);
+int ilsx_memcpy_h2d(ilsx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int ilsx_memcpy_d2h(ilsx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* syncs */
+
+/* ---------------------------------------------------------------- networks
+ * Replaces rlkit/torch/common/networks.py:23-115 (Mlp / FlattenMlp) and the heads of
+ * rlkit/torch/common/policies.py:191-345 (n_heads = 2: mean | log_std). */
+typedef struct {
+  int32_t in_dim;      /* FlattenMlp: sum of the concatenated input dims */
+  int32_t n_hidden;    /* 1..3 hidden layers, all `hidden` wide */
+  int32_t hidden;      /* 64, 128 or 256 */
+  int32_t out_dim;     /* per head */
+  int32_t n_heads;     /* 1 (Mlp) or 2 (Gaussian policy: last_fc, last_fc_log_std) */
+  int32_t act;         /* ILSX_ACT_* hidden activation */
+} ilsx_mlp_cfg;
+
+int ilsx_net_create(ilsx_ctx* ctx, const ilsx_mlp_cfg* cfg, ilsx_net** out);
+int ilsx_net_destroy(ilsx_net* net);
+int ilsx_net_num_params(const ilsx_net* net, size_t* out);
+/* networks.py:57-83 + pytorch_util.py:20-29 init rule: hidden W ~ U(+-1/sqrt(out_features)),
+ * hidden b = b_init, heads W,b ~ U(+-init_w); host RNG (splitmix64/xoshiro) seeded by `seed`. */
+int ilsx_net_init(ilsx_net* net, uint64_t seed, float init_w, float b_init);
+int ilsx_net_set_params(ilsx_net* net, const float* src, size_t n, int src_is_device);
+int ilsx_net_get_params(const ilsx_net* net, float* dst, size_t n, int dst_is_device);
+/* Mlp.forward (networks.py:85-101): x[rows,in_dim] -> y[rows, n_heads*out_dim] (raw head outputs). */
+int ilsx_mlp_forward(ilsx_net* net, const float* x, int rows, float* y);
+/* ReparamTanhMultivariateGaussianPolicy.get_actions / forward (policies.py:241-307):
+ * obs[n,o] -> act[n,a]; deterministic: tanh(mean); else tanh(mean + std*eps), eps[n,a] or NULL=Philox.
+ * logp (nullable) [n] receives log pi(a|s) (distributions.py:74-97). */
+int ilsx_policy_act(ilsx_net* pi, const float* obs, int n, int deterministic, const float* eps,
+                    float* act, float* logp);
+/* ReparamTanhMultivariateNormal.log_prob with pre_tanh_value=None (policies.py:329-345):
+ * logp[n] of GIVEN actions act[n,a] under pi(.|obs). */
+int ilsx_policy_log_prob(ilsx_net* pi, const float* obs, const float* act, int n, float* logp);
+
+/* ---------------------------------------------------------------- replay buffer
+ * Replaces rlkit/data_management/simple_replay_buffer.py:17-442 + env_replay_buffer.py:7-49.
+ * HBM-resident ring of transition records (obs|act|rew|done|next_obs, one 128-byte-aligned record per
+ * transition).  Cursor semantics (_top/_size/_traj_endpoints) follow the reference exactly. */
+int ilsx_replay_create(ilsx_ctx* ctx, int64_t capacity, int obs_dim, int act_dim, uint64_t seed,
+                       ilsx_replay** out);
+int ilsx_replay_destroy(ilsx_replay* rb);
+/* n x add_sample (+ terminate_episode() after rows whose ep_end flag is set; simple_replay_buffer.py:78-132).
+ * Row arrays are contiguous [n,dim]; `data_is_device` says where obs/act/rew/done/nobs live;
+ * ep_end_host is a HOST array of n flags or NULL. */
+int ilsx_replay_add(ilsx_replay* rb, const float* obs, const float* act, const float* rew,
+                    const uint8_t* done, const float* nobs, int n, const uint8_t* ep_end_host,
+                    int data_is_device);
+int ilsx_replay_terminate_episode(ilsx_replay* rb);
+/* random_batch (simple_replay_buffer.py:239-293): idx (device int64[B]) or NULL = uniform with
+ * replacement over [0,size) from Philox.  Outputs (device): obs[B,o] act[B,a] rew[B] done[B] (0/1 as
+ * float, rlkit/torch/core.py:124-143) nobs[B,o]; idx_out (nullable device int64[B]) gets the rows used. */
+int ilsx_replay_sample(ilsx_replay* rb, int B, const int64_t* idx, float* obs, float* act, float* rew,
+                       float* done, float* nobs, int64_t* idx_out);
+/* Bandwidth microbenchmark form of the same kernel: n_batches x B rows gathered in ONE launch into
+ * out[n_batches*B, record] (device, record = ilsx_replay_record_floats()). */
+int ilsx_replay_sample_many(ilsx_replay* rb, int n_batches, int B, float* out_records);
+int ilsx_replay_record_floats(const ilsx_replay* rb, int* out);
+int ilsx_replay_size(ilsx_replay* rb, int64_t* size, int64_t* top);
+int ilsx_replay_clear(ilsx_replay* rb);
+/* _traj_endpoints in insertion order: writes up to max pairs (start,end) to HOST arrays; *n = count. */
+int ilsx_replay_traj_endpoints(ilsx_replay* rb, int64_t* starts_host, int64_t* ends_host, int max, int* n);
+
+/* ---------------------------------------------------------------- SAC (twin Q, auto alpha)
+ * Replaces rlkit/torch/algorithms/sac/sac_alpha.py:21-76 (ctor kwargs == cfg fields) and
+ * :78-181 (train_step), :245-247 (_update_target_network). */
+typedef struct {
+  float reward_scale, discount, policy_lr, qf_lr, alpha_lr, soft_target_tau, alpha;
+  int32_t train_alpha;
+  float policy_mean_reg_weight, policy_std_reg_weight, beta_1;
+  int32_t has_target_entropy;  /* 0: default -dim(A)/2 (sac_alpha.py:56-58) */
+  float target_entropy;
+  int32_t max_batch;           /* largest B any train call will use (workspace size) */
+  int32_t grad_world;          /* split-run mode: number of ranks sharing one batch (1 = off); the
+                                  mean-over-batch scale becomes 1/(B*grad_world) */
+} ilsx_sac_cfg;
+
+typedef struct {              /* scalars of sac_alpha.py:186-233 for the step just taken */
+  float qf1_loss, qf2_loss, policy_loss, alpha_loss, alpha;
+  float q1_mean, q2_mean, log_pi_mean, policy_mu_mean, policy_log_std_mean;
+  double log_alpha;
+} ilsx_sac_stats;
+
+/* Takes over the storage of pi/q1/q2 (they become views into the agent's parameter arena and stay
+ * valid for ilsx_policy_act / get_params until the agent is destroyed). */
+int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net* pi, ilsx_net* q1, ilsx_net* q2,
+                    ilsx_sac** out);
+int ilsx_sac_destroy(ilsx_sac* sac);
+/* One SoftActorCritic.train_step on an explicit batch (device pointers, fp32; rew/done are [B]).
+ * eps_next / eps_cur: the two N(0,1) draws [B,a] (sac_alpha.py:102,142) or NULL = Philox. */
+int ilsx_sac_train_step(ilsx_sac* sac, const float* obs, const float* act, const float* rew,
+                        const float* done, const float* nobs, int B, const float* eps_next,
+                        const float* eps_cur, ilsx_sac_stats* stats);
+/* TorchRLAlgorithm._do_training (torch_rl_algorithm.py:28-34): n_steps x (random_batch + train_step)
+ * with on-device sampling; one hipGraph replay per step, no host round trip. */
+int ilsx_sac_train_from_replay(ilsx_sac* sac, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats);
+/* Split-run (multi-GPU) phases: train_step == critic_backward ; critic_update ; actor_backward ;
+ * actor_update, with an all-reduce(sum) of the gradient arena between backward and update. */
+int ilsx_sac_set_batch(ilsx_sac* sac, const float* obs, const float* act, const float* rew,
+                       const float* done, const float* nobs, int B, const float* eps_next,
+                       const float* eps_cur);
+int ilsx_sac_critic_backward(ilsx_sac* sac);
+int ilsx_sac_critic_update(ilsx_sac* sac);
+int ilsx_sac_actor_backward(ilsx_sac* sac);
+int ilsx_sac_actor_update(ilsx_sac* sac);
+int ilsx_sac_last_stats(ilsx_sac* sac, ilsx_sac_stats* stats);
+/* flat fp32 views: which = 0 pi, 1 q1, 2 q2, 3 target_q1, 4 target_q2 */
+int ilsx_sac_get_params(ilsx_sac* sac, int which, float* dst, size_t n, int dst_is_device);
+int ilsx_sac_set_params(ilsx_sac* sac, int which, const float* src, size_t n, int src_is_device);
+/* gradients of the last backward, same layout/which as the parameters (0 pi, 1 q1, 2 q2) */
+int ilsx_sac_get_grads(ilsx_sac* sac, int which, float* dst, size_t n, int dst_is_device);
+/* gradient arena for the RCCL all-reduce: segment 0 = critics (q1|q2), 1 = actor (pi | alpha slot) */
+int ilsx_sac_grads_ptr(ilsx_sac* sac, int segment, float** dev_ptr, size_t* n);
+int ilsx_sac_get_log_alpha(ilsx_sac* sac, double* out);
+int ilsx_sac_set_log_alpha(ilsx_sac* sac, double v);
+/* optimiser state for snapshots (sac_alpha.py:249-273): which = 0 pi, 1 q1, 2 q2; m,v host fp32[n] */
+int ilsx_sac_get_adam(ilsx_sac* sac, int which, float* m_host, float* v_host, size_t n, int64_t* t);
+int ilsx_sac_set_adam(ilsx_sac* sac, int which, const float* m_host, const float* v_host, size_t n, int64_t t);
+/* alpha_optimizer state (float64 scalar Adam, sac_alpha.py:74-76) + the Philox step counter */
+int ilsx_sac_get_alpha_opt(ilsx_sac* sac, double* m, double* v, int64_t* t, uint64_t* rng_step);
+int ilsx_sac_set_alpha_opt(ilsx_sac* sac, double m, double v, int64_t t, uint64_t rng_step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILSX_H */

@@ -1,0 +1,66 @@
+"""CPU suite: libilsx.so loads and exports every symbol include/ilsx.h declares; the ctypes table covers
+the header; the product path fails loudly without a GPU (no fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ilsx.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ilsx_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from ilswiss_amd import _lib
+    return _lib
+
+
+def test_header_declares_symbols():
+    syms = declared_symbols()
+    assert "ilsx_sac_train_step" in syms and "ilsx_replay_sample" in syms and len(syms) >= 40
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = ctypes.CDLL(built.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in include/ilsx.h but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header(built):
+    assert sorted(built.PROTOTYPES) == declared_symbols()
+    lib = built.load()
+    assert lib.ilsx_abi_version() == 1
+
+
+def test_struct_sizes_match_header(built):
+    # ilsx_mlp_cfg: 6 x int32 ; ilsx_sac_cfg: 15 x 4 bytes ; ilsx_sac_stats: 10 floats + double
+    assert ctypes.sizeof(built.MlpCfg) == 24
+    assert ctypes.sizeof(built.SacCfg) == 60
+    assert ctypes.sizeof(built.SacStats) == 48
+
+
+def test_no_gpu_means_loud_failure(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ilswiss_amd
+    with pytest.raises(RuntimeError, match="libilsx error"):
+        ilswiss_amd.Context(0)
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ilswiss_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
