@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py — the BASELINE.json metric on MI355X: env-steps/s + SAC grad-steps/s, Hopper-v2 dims,
+4096 parallel envs, 256-256 MLPs, batch 256 (config C2).
+
+One "step" = one iteration of the reference's outer loop (rlkit/core/base_algorithm.py:183-286) at
+env_num = 4096 with the YAML knobs of exp_specs/sac/sac_hopper.yaml:17-20: ONE vec-env step of all 4096
+envs (policy inference -> physics -> replay insert; 4096 env-steps) followed by ONE train call of
+num_train_steps_per_train_call = 1000 SAC gradient steps (on-device replay sampling + update).
+`value` is the whole-loop gradient-step rate (grad steps / total wall time, max over ranks);
+`env_steps_per_s` / `grad_steps_per_s_train_phase` are the reference's own phase-timed definitions
+(Sample Time / Train Time, base_algorithm.py:284-290,329-343).
+
+N > 1: one process per GPU, independent replicas (seeds shard with no data-path collective,
+run_experiment.py:57-78) -> weak scaling; torch.distributed (RCCL) only for the barrier + max-time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+O, A, H, B = 11, 3, 256, 256          # Hopper-v2 obs/act, hidden width, batch (BASELINE.json)
+N_ENV = 4096
+GRAD_PER_CALL = 1000                  # sac_hopper.yaml:20
+REPLAY_CAP = 1_000_000                # sac_hopper.yaml:28
+SAC_KW = dict(reward_scale=5.0, discount=0.99, soft_target_tau=0.005, policy_lr=3e-4, qf_lr=3e-4, alpha=0.2,
+              policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3)  # sac_hopper.yaml:36-47
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_step():
+    """ALGORITHMIC FLOPs of one SAC-alpha gradient step, split by kernel."""
+    Wq, Wp = (O + A) * H + H * H + H, O * H + H * H + 2 * H * A
+    fwd = 6 * Wq + 2 * Wp
+    bwd_dx = 2 * (H * H + H) + 2 * (H + H * H + H * A) + (H * H + 2 * H * A)
+    bwd_dw = 2 * Wq + Wp
+    return {0: 2 * B * fwd, 1: 2 * B * bwd_dx, 2: 2 * B * bwd_dw, "total": 2 * B * (fwd + bwd_dx + bwd_dw)}
+
+
+def synth_rows(rng, n):
+    """C2 synthetic transitions: obs,next_obs ~ N(0,1); act = tanh(N(0,1)); rew ~ N(0,1);
+    done ~ Bernoulli(1e-3)."""
+    return (rng.standard_normal((n, O), dtype=np.float32), np.tanh(rng.standard_normal((n, A), dtype=np.float32)),
+            rng.standard_normal(n, dtype=np.float32), (rng.random(n) < 1e-3).astype(np.uint8),
+            rng.standard_normal((n, O), dtype=np.float32))
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle (numpy fp32 restatement of sac_alpha.py:78-181 + replay gather) timed on the host cores."""
+    from oracle import mlp as omlp
+    from oracle.replay import ReplayOracle
+    from oracle.sac_alpha import SacAlphaOracle
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    hid = [H, H]
+    orc = SacAlphaOracle(O, A, hid, omlp.init_mlp(rng, O, hid, A, init_w=1e-3, n_heads=2),
+                         omlp.init_mlp(rng, O + A, hid, 1), omlp.init_mlp(rng, O + A, hid, 1),
+                         **{k: v for k, v in SAC_KW.items()})
+    n = 100_000
+    rb = ReplayOracle(n, O, A)
+    ob, ac, rw, dn, nob = synth_rows(rng, n)
+    rb.obs[:], rb.act[:], rb.rew[:, 0], rb.term[:, 0], rb.next_obs[:] = ob, ac, rw, dn, nob
+    rb.size = n
+
+    def one():
+        bt = rb.gather(rb.draw_indices(B))
+        bt["terminals"] = bt["terminals"].astype(np.float32)
+        orc.train_step(bt, rng.standard_normal((B, A), dtype=np.float32), rng.standard_normal((B, A), dtype=np.float32))
+    for _ in range(3):
+        one()
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        one()
+        k += 1
+    dt = time.perf_counter() - t0
+    return dict(value=k / dt, unit="grad-steps/s", cores=int(cores), kind="port",
+                sample=f"{k} SAC-alpha grad steps (replay gather + train_step, B={B}, H={H}, Hopper dims) in {dt:.1f} s, "
+                       "oracle/sac_alpha.py numpy fp32")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import ctypes as C
+
+    import ilswiss_amd as ia
+    from ilswiss_amd import _lib
+    ctx = ia.Context(local, seed=1000 + rank)   # independent seed per replica
+    lib = ctx.lib
+    hid = [H, H]
+    pol = ia.ReparamTanhMultivariateGaussianPolicy(hid, O, A, ctx=ctx, seed=10 + rank)
+    q1 = ia.FlattenMlp(hid, 1, O + A, ctx=ctx, seed=20 + rank)
+    q2 = ia.FlattenMlp(hid, 1, O + A, ctx=ctx, seed=30 + rank)
+    tr = ia.SoftActorCritic(pol, q1, q2, max_batch=B, **SAC_KW)
+    rb = ia.SimpleReplayBuffer(REPLAY_CAP, O, A, random_seed=rank, ctx=ctx)
+    rng = np.random.default_rng(rank)
+    chunk = 250_000
+    for _ in range(REPLAY_CAP // chunk):   # pre-filled N = 1,000,000 rows (C2)
+        rb.add_rows(*synth_rows(rng, chunk))
+
+    from bench_rollout import Rollout
+    ro = Rollout(ctx, pol, rb, N_ENV, seed=rank)
+
+    tr.eval_statistics = {}  # no per-step stats readback inside the loop
+
+    def step():
+        ro.vec_step()                                    # 4096 env-steps
+        tr.train_from_replay(rb, GRAD_PER_CALL, B)       # 1000 grad steps
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    t_sample = t_train = 0.0
+    for _ in range(args.steps):
+        a0 = time.perf_counter()
+        ro.vec_step()
+        ctx.sync()
+        a1 = time.perf_counter()
+        tr.train_from_replay(rb, GRAD_PER_CALL, B)
+        ctx.sync()
+        a2 = time.perf_counter()
+        t_sample += a1 - a0
+        t_train += a2 - a1
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt, t_sample, t_train], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, t_sample, t_train = [float(x) for x in tt.tolist()]
+
+    result = None
+    if rank == 0:
+        grad_total = world * args.steps * GRAD_PER_CALL
+        env_total = world * args.steps * N_ENV
+        # ---- roofline leg: HIP events around every kernel launch (library instrumentation; graph bypassed)
+        _lib.check(lib.ilsx_prof_reset(ctx.h))
+        _lib.check(lib.ilsx_prof_enable(ctx.h, 1))
+        tr.train_from_replay(rb, 200, B)
+        ro.vec_step()
+        _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
+        prof = {}
+        for kid in range(10):
+            nl, ms = C.c_uint64(), C.c_double()
+            _lib.check(lib.ilsx_prof_read(ctx.h, kid, C.byref(nl), C.byref(ms)))
+            if nl.value:
+                prof[kid] = (lib.ilsx_kernel_name(kid).decode(), nl.value, ms.value)
+        fl = flops_per_step()
+        dom = max((k for k in prof if k in (0, 1, 2)), key=lambda k: prof[k][2])
+        name, nl, ms = prof[dom]
+        launches_per_step = nl / 200.0
+        flops_per_launch = fl[dom] / launches_per_step
+        avg_s = ms * 1e-3 / nl
+        achieved = flops_per_launch / avg_s / 1e12
+        roofline = dict(bound="mfma", kernel=name, achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_us=avg_s * 1e6,
+                        algorithmic_flop_per_launch=flops_per_launch,
+                        kernel_ms_per_grad_step={prof[k][0]: prof[k][2] / 200.0 for k in prof if k not in (5, 9)})
+        # ---- HBM-bound kernel: replay sample (4096 batches x 256 rows per launch)
+        nb = 4096
+        rec = C.c_int()
+        _lib.check(lib.ilsx_replay_record_floats(rb.h, C.byref(rec)))
+        out = ctx.empty((nb * B, rec.value))
+        _lib.check(lib.ilsx_replay_sample_many(rb.h, nb, B, out.ptr))
+        _lib.check(lib.ilsx_prof_reset(ctx.h))
+        _lib.check(lib.ilsx_prof_enable(ctx.h, 1))
+        for _ in range(10):
+            _lib.check(lib.ilsx_replay_sample_many(rb.h, nb, B, out.ptr))
+        _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
+        nl, ms = C.c_uint64(), C.c_double()
+        _lib.check(lib.ilsx_prof_read(ctx.h, 6, C.byref(nl), C.byref(ms)))
+        alg_bytes = 2.0 * nb * B * (2 * O + A + 2) * 4
+        gbs = alg_bytes / (ms.value * 1e-3 / nl.value) / 1e9
+        roofline_replay = dict(bound="hbm", kernel="k_replay_sample_many", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
+                               frac=gbs / PEAK_HBM_GBS, traffic=None, avg_launch_us=ms.value * 1e3 / nl.value,
+                               algorithmic_bytes_per_launch=alg_bytes)
+        result = dict(
+            metric="env-steps/s + SAC grad-steps/s, Hopper-v2 4096 envs", value=grad_total / dt, unit="grad-steps/s",
+            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload="SAC Hopper-v2 dims (o=11,a=3), 4096 parallel envs, 256-256 MLP, batch 256, "
+                                 "replay 1e6 rows; step = 1 vec-env step (4096 env-steps) + 1000 grad steps "
+                                 "(sac_hopper.yaml:17-20)", env=ro.describe(), replicas=world,
+                        parallelism=f"{world} independent replicas (seed sharding, no collective)"),
+            env_steps_per_s=env_total / dt, env_steps_per_s_sample_phase=env_total / t_sample,
+            grad_steps_per_s_train_phase=grad_total / t_train, roofline=roofline, roofline_replay=roofline_replay)
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,10 @@ PROTOTYPES = {
     "ilsx_ctx_free": (C.c_int, [vp, vp]),
     "ilsx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ilsx_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "ilsx_prof_enable": (C.c_int, [vp, C.c_int]),
+    "ilsx_prof_reset": (C.c_int, [vp]),
+    "ilsx_prof_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "ilsx_kernel_name": (C.c_char_p, [C.c_int]),
     "ilsx_net_create": (C.c_int, [vp, C.POINTER(MlpCfg), C.POINTER(vp)]),
     "ilsx_net_destroy": (C.c_int, [vp]),
     "ilsx_net_num_params": (C.c_int, [vp, C.POINTER(C.c_size_t)]),

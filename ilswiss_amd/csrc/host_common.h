@@ -46,6 +46,20 @@ struct ilsx_ctx {
   // small reusable staging buffer for host->device row uploads
   void* stage = nullptr;
   size_t stage_bytes = 0;
+  // optional per-kernel HIP-event timing (include/ilsx.h "kernel timing")
+  bool prof_on = false;
+  struct ProfRec { int kid; hipEvent_t a, b; };
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_free;
+  double prof_ms[ILSX_K_COUNT] = {0};
+  uint64_t prof_n[ILSX_K_COUNT] = {0};
+};
+
+// RAII bracket around ONE kernel launch: records start/stop events on the ctx stream when profiling.
+struct ProfScope {
+  ilsx_ctx* c; int kid; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(ilsx_ctx* ctx, int k);
+  ~ProfScope();
 };
 
 int ctx_alloc(ilsx_ctx* c, size_t bytes, void** out, bool zero = true);

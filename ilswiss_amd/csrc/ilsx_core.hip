@@ -90,6 +90,8 @@ extern "C" int ilsx_ctx_destroy(ilsx_ctx* c) {
   if (!c) return ILSX_OK;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  for (auto& r : c->prof_pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (hipEvent_t e : c->prof_free) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -117,6 +119,59 @@ extern "C" int ilsx_memcpy_d2h(ilsx_ctx* c, void* dst, const void* src, size_t b
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return ILSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ profiling
+static hipEvent_t prof_event(ilsx_ctx* c) {
+  if (!c->prof_free.empty()) { hipEvent_t e = c->prof_free.back(); c->prof_free.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+ProfScope::ProfScope(ilsx_ctx* ctx, int k) : c(ctx), kid(k) {
+  if (!c->prof_on) return;
+  a = prof_event(c); b = prof_event(c);
+  (void)hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+  if (!a) return;
+  (void)hipEventRecord(b, c->stream);
+  c->prof_pending.push_back({kid, a, b});
+}
+static int prof_collect(ilsx_ctx* c) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& r : c->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.kid] += ms; c->prof_n[r.kid] += 1; }
+    c->prof_free.push_back(r.a); c->prof_free.push_back(r.b);
+  }
+  c->prof_pending.clear();
+  return ILSX_OK;
+}
+extern "C" int ilsx_prof_enable(ilsx_ctx* c, int on) {
+  if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
+  ILSX_TRY(prof_collect(c));
+  c->prof_on = on != 0;
+  return ILSX_OK;
+}
+extern "C" int ilsx_prof_reset(ilsx_ctx* c) {
+  if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
+  ILSX_TRY(prof_collect(c));
+  for (int i = 0; i < ILSX_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  return ILSX_OK;
+}
+extern "C" int ilsx_prof_read(ilsx_ctx* c, int kid, uint64_t* launches, double* total_ms) {
+  if (!c || kid < 0 || kid >= ILSX_K_COUNT) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_prof_read: bad argument");
+  ILSX_TRY(prof_collect(c));
+  if (launches) *launches = c->prof_n[kid];
+  if (total_ms) *total_ms = c->prof_ms[kid];
+  return ILSX_OK;
+}
+extern "C" const char* ilsx_kernel_name(int kid) {
+  static const char* names[ILSX_K_COUNT] = {"k_mlp_fwd", "k_mlp_bwd_dx", "k_mlp_bwd_dw", "k_adam_polyak",
+      "k_replay_sample", "k_replay_add", "k_replay_sample_many", "k_sac_stats", "k_sac_finish", "k_env_step",
+      "", "", "", "", "", ""};
+  return (kid >= 0 && kid < ILSX_K_COUNT) ? names[kid] : "";
 }
 
 // ------------------------------------------------------------------------------------------ layout
@@ -253,6 +308,7 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A, int H, int act, int KPmax) {
   const size_t lds = fwd_lds_bytes(H, KPmax);
   if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
   dim3 grid((A.rows + 15) / 16, A.ntasks), block(256);
+  ProfScope ps(ctx, ILSX_K_MLP_FWD);
 #define CALL_FWD(HH, AA) hipLaunchKernelGGL((k_mlp_fwd<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_FWD);
 #undef CALL_FWD
@@ -264,6 +320,7 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act) {
   if (A.rows <= 0) return ILSX_OK;
   const size_t lds = bwd_lds_bytes(H);
   dim3 grid((A.rows + 15) / 16, A.ntasks), block(256);
+  ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
 #define CALL_BWD(HH, AA) hipLaunchKernelGGL((k_mlp_bwd_dx<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_BWD);
 #undef CALL_BWD
@@ -273,6 +330,7 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act) {
 
 int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows) {
   if (njobs <= 0 || rows <= 0) return ILSX_OK;
+  ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
   hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(njobs), dim3(256), 0, ctx->stream, jobs_dev, rows);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
@@ -283,6 +341,7 @@ int launch_adam(ilsx_ctx* ctx, const AdamArgs& A) {
   int blocks = (n4 + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
+  ProfScope ps(ctx, ILSX_K_ADAM);
   hipLaunchKernelGGL(k_adam_polyak, dim3(blocks), dim3(256), 0, ctx->stream, A);
   HIPCHK(hipGetLastError());
   return ILSX_OK;

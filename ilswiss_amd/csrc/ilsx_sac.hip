@@ -378,6 +378,7 @@ static int sac_actor_backward(ilsx_sac* s) {
   S.w_mu = s->cfg.policy_mean_reg_weight; S.w_std = s->cfg.policy_std_reg_weight;
   S.target_entropy = s->target_entropy; S.inv_B = sac_inv_B(s);
   S.scal = s->scal; S.alpha_grad_slot = s->G + 2 * s->nq + s->np;
+  ProfScope ps(s->ctx, ILSX_K_SAC_STATS);
   hipLaunchKernelGGL(k_sac_stats, dim3(1), dim3(256), 0, s->ctx->stream, S);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
@@ -391,6 +392,7 @@ static int sac_actor_update(ilsx_sac* s) {
   A.lr = s->cfg.policy_lr; A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = 0.f;
   A.t_ctr = &s->scal->t_pi;
   ILSX_TRY(launch_adam(s->ctx, A));
+  ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
   hipLaunchKernelGGL(k_sac_finish, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, (const float*)(s->G + 2 * s->nq + s->np),
                      s->cfg.train_alpha, s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f);
   HIPCHK(hipGetLastError());
@@ -483,7 +485,7 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   s->B = B;
   s->eps_explicit = false;
   static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
-  if (no_graph) {
+  if (no_graph || s->ctx->prof_on) {
     for (int i = 0; i < n_steps; ++i) ILSX_TRY(sac_sample_and_step(s, rb, B));
   } else {
     if (!s->graph || s->graph_rb != rb || s->graph_B != B) {
