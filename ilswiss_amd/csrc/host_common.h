@@ -47,6 +47,7 @@ struct ilsx_ctx {
   void* stage = nullptr;
   size_t stage_bytes = 0;
   // optional per-kernel HIP-event timing (include/ilsx.h "kernel timing")
+  unsigned long long* dbg_stamps = nullptr;  // device buffer for ILSX_STAMP (debug)
   bool prof_on = false;
   struct ProfRec { int kid; hipEvent_t a, b; };
   std::vector<ProfRec> prof_pending;
@@ -70,7 +71,7 @@ int ctx_stage(ilsx_ctx* c, size_t bytes, void** out);
 struct NetLayout {
   ilsx_mlp_cfg cfg;
   int KP = 0, NO = 0;
-  int off_W[ILSX_MAX_HID], off_b[ILSX_MAX_HID], ld[ILSX_MAX_HID];
+  int off_W[ILSX_MAX_HID], off_Wb[ILSX_MAX_HID], off_b[ILSX_MAX_HID], ld[ILSX_MAX_HID];
   int off_Wh = 0, off_bh = 0;
   size_t n_int = 0;   // internal floats (multiple of 4)
   size_t n_flat = 0;  // ABI floats

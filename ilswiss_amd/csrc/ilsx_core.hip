@@ -196,6 +196,11 @@ int net_layout_build(const ilsx_mlp_cfg& cfg, NetLayout* L) {
     L->ld[l] = l == 0 ? L->KP : H;
     L->off_W[l] = (int)off;
     off += (size_t)H * L->ld[l];
+    L->off_Wb[l] = 0;
+    if (l > 0) {  // second, backward-packed copy of every hidden->hidden matrix
+      L->off_Wb[l] = (int)off;
+      off += (size_t)H * H;
+    }
     L->off_b[l] = (int)off;
     off += H;
     nflat += (size_t)H * L->in_of(l) + H;
@@ -217,7 +222,11 @@ void net_flat_to_internal(const NetLayout& L, const float* flat, float* in) {
   for (int l = 0; l < L.cfg.n_hidden; ++l) {
     const int ind = L.in_of(l);
     for (int n = 0; n < H; ++n)
-      for (int k = 0; k < ind; ++k) in[L.off_W[l] + (size_t)n * L.ld[l] + k] = flat[f + (size_t)n * ind + k];
+      for (int k = 0; k < ind; ++k) {
+        const float v = flat[f + (size_t)n * ind + k];
+        in[L.off_W[l] + pack_f(n, k, L.ld[l])] = v;
+        if (l > 0) in[L.off_Wb[l] + pack_b(n, k, H)] = v;
+      }
     f += (size_t)H * ind;
     for (int n = 0; n < H; ++n) in[L.off_b[l] + n] = flat[f + n];
     f += H;
@@ -238,7 +247,7 @@ void net_internal_to_flat(const NetLayout& L, const float* in, float* flat) {
   for (int l = 0; l < L.cfg.n_hidden; ++l) {
     const int ind = L.in_of(l);
     for (int n = 0; n < H; ++n)
-      for (int k = 0; k < ind; ++k) flat[f + (size_t)n * ind + k] = in[L.off_W[l] + (size_t)n * L.ld[l] + k];
+      for (int k = 0; k < ind; ++k) flat[f + (size_t)n * ind + k] = in[L.off_W[l] + pack_f(n, k, L.ld[l])];
     f += (size_t)H * ind;
     for (int n = 0; n < H; ++n) flat[f + n] = in[L.off_b[l] + n];
     f += H;
@@ -258,6 +267,7 @@ NetView net_view(const NetLayout& L, float* base) {
   v.base = base;
   for (int l = 0; l < ILSX_MAX_HID; ++l) {
     v.off_W[l] = l < L.cfg.n_hidden ? L.off_W[l] : 0;
+    v.off_Wb[l] = l < L.cfg.n_hidden ? L.off_Wb[l] : 0;
     v.off_b[l] = l < L.cfg.n_hidden ? L.off_b[l] : 0;
     v.ld[l] = l < L.cfg.n_hidden ? L.ld[l] : 0;
   }
@@ -286,6 +296,7 @@ static int kernels_init_once() {
   SET_FWD(64, ACT_RELU); SET_FWD(128, ACT_RELU); SET_FWD(256, ACT_RELU);
   SET_FWD(64, ACT_TANH); SET_FWD(128, ACT_TANH); SET_FWD(256, ACT_TANH);
 #undef SET_FWD
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   done = true;
   return ILSX_OK;
 }
@@ -303,11 +314,19 @@ static int kernels_init_once() {
     }                                                                  \
   } while (0)
 
-int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A, int H, int act, int KPmax) {
-  if (A.rows <= 0) return ILSX_OK;
+extern "C" int ilsx_debug_set_stamp_buffer(ilsx_ctx* c, void* dev_u64x16) {
+  if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
+  c->dbg_stamps = (unsigned long long*)dev_u64x16;
+  return ILSX_OK;
+}
+
+int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax) {
+  if (A0.rows <= 0) return ILSX_OK;
+  FwdArgs A = A0;
+  A.dbg = ctx->dbg_stamps;
   const size_t lds = fwd_lds_bytes(H, KPmax);
   if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
-  dim3 grid((A.rows + 15) / 16, A.ntasks), block(256);
+  dim3 grid((A.rows + 15) / 16, A.ntasks), block(4 * H);
   ProfScope ps(ctx, ILSX_K_MLP_FWD);
 #define CALL_FWD(HH, AA) hipLaunchKernelGGL((k_mlp_fwd<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_FWD);
@@ -319,7 +338,7 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A, int H, int act, int KPmax) {
 int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act) {
   if (A.rows <= 0) return ILSX_OK;
   const size_t lds = bwd_lds_bytes(H);
-  dim3 grid((A.rows + 15) / 16, A.ntasks), block(256);
+  dim3 grid((A.rows + 15) / 16, A.ntasks), block(4 * H);
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
 #define CALL_BWD(HH, AA) hipLaunchKernelGGL((k_mlp_bwd_dx<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_BWD);
@@ -331,7 +350,7 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act) {
 int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows) {
   if (njobs <= 0 || rows <= 0) return ILSX_OK;
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-  hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(njobs), dim3(256), 0, ctx->stream, jobs_dev, rows);
+  hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(njobs), dim3(1024), DW_LDS_BYTES, ctx->stream, jobs_dev, rows);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
@@ -350,21 +369,23 @@ int launch_adam(ilsx_ctx* ctx, const AdamArgs& A) {
 void build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
                    float* const* dsave, const float* dhead, std::vector<DwJob>* jobs) {
   const int H = L.cfg.hidden;
-  auto add = [&](const float* A, int lda, int NA, const float* Bm, int ldb, int NB, float* dW, int ldw, float* db) {
-    for (int n0 = 0; n0 < NA; n0 += 64)
-      for (int k0 = 0; k0 < NB; k0 += 64) {
+  auto add = [&](const float* A, int lda, int NA, const float* Bm, int ldb, int NB, float* dW, float* dWb, int ldw,
+                 float* db, int mode) {
+    for (int n0 = 0; n0 < NA; n0 += DW_TILE_N)
+      for (int k0 = 0; k0 < NB; k0 += DW_TILE_K) {
         DwJob j;
-        j.A = A; j.Bm = Bm; j.dW = dW; j.db = db;
-        j.lda = lda; j.NA = NA; j.ldb = ldb; j.NB = NB; j.ldw = ldw; j.n0 = n0; j.k0 = k0; j.pad = 0;
+        j.A = A; j.Bm = Bm; j.dW = dW; j.dWb = dWb; j.db = db;
+        j.lda = lda; j.NA = NA; j.ldb = ldb; j.NB = NB; j.ldw = ldw; j.n0 = n0; j.k0 = k0; j.mode = mode;
         jobs->push_back(j);
       }
   };
   for (int l = 0; l < L.cfg.n_hidden; ++l) {
     const float* Bm = l == 0 ? xsave : hsave[l - 1];
     const int ldb = l == 0 ? L.KP : H;
-    add(dsave[l], H, H, Bm, ldb, ldb, gbase + L.off_W[l], L.ld[l], gbase + L.off_b[l]);
+    add(dsave[l], H, H, Bm, ldb, ldb, gbase + L.off_W[l], l > 0 ? gbase + L.off_Wb[l] : nullptr, L.ld[l],
+        gbase + L.off_b[l], l > 0 ? DW_OUT_PACK_FB : DW_OUT_PACK_F);
   }
-  add(dhead, L.NO, L.NO, hsave[L.cfg.n_hidden - 1], H, H, gbase + L.off_Wh, H, gbase + L.off_bh);
+  add(dhead, L.NO, L.NO, hsave[L.cfg.n_hidden - 1], H, H, gbase + L.off_Wh, nullptr, H, gbase + L.off_bh, DW_OUT_NATURAL);
 }
 
 // ------------------------------------------------------------------------------------------ nets

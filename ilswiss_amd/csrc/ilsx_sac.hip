@@ -109,8 +109,13 @@ __global__ __launch_bounds__(256) void k_sac_stats(const StatsArgs S) {
 }
 
 // alpha Adam in float64 (sac_alpha.py:51-53,160-166) + step counters
+__device__ __host__ inline void adam_scalars(double lr, double b1, double b2, int t, float* step, float* bc2s) {
+  *step = (float)(lr / (1.0 - pow(b1, (double)t)));
+  *bc2s = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+
 __global__ void k_sac_finish(DevScalars* sc, const float* alpha_grad_slot, int train_alpha, float lr, float b1,
-                             float b2, float eps) {
+                             float b2, float eps, float qf_lr, float policy_lr) {
   if (train_alpha) {
     const double g = (double)alpha_grad_slot[0];
     const int t = sc->t_alpha + 1;
@@ -125,7 +130,16 @@ __global__ void k_sac_finish(DevScalars* sc, const float* alpha_grad_slot, int t
   sc->t_q += 1;
   sc->t_pi += 1;
   sc->step += 1;
+  adam_scalars(qf_lr, b1, b2, sc->t_q + 1, &sc->adam_q_step, &sc->adam_q_bc2s);
+  adam_scalars(policy_lr, b1, b2, sc->t_pi + 1, &sc->adam_pi_step, &sc->adam_pi_bc2s);
 }
+
+// device-side (re)computation of the Adam scalars so every path uses the same pow()
+__global__ void k_sac_refresh_adam(DevScalars* sc, float qf_lr, float policy_lr, float b1, float b2) {
+  adam_scalars(qf_lr, b1, b2, sc->t_q + 1, &sc->adam_q_step, &sc->adam_q_bc2s);
+  adam_scalars(policy_lr, b1, b2, sc->t_pi + 1, &sc->adam_pi_step, &sc->adam_pi_bc2s);
+}
+static int sac_refresh_adam(struct ilsx_sac* s);
 
 // ------------------------------------------------------------------------------------------------
 static int sac_alloc_ws(ilsx_sac* s) {
@@ -206,6 +220,7 @@ extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net*
   h.log_alpha_used = h.log_alpha;
   HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
+  ILSX_TRY(sac_refresh_adam(s));
   // weight-gradient job tables
   std::vector<DwJob> jq, jp;
   for (int i = 0; i < 2; ++i)
@@ -306,8 +321,8 @@ static int sac_critic_update(ilsx_sac* s) {
   AdamArgs A;
   A.p = s->P; A.g = s->G; A.m = s->M; A.v = s->V; A.tgt = s->base(W_TQ1);
   A.n = (int)(2 * s->nq);
-  A.lr = s->cfg.qf_lr; A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = s->cfg.soft_target_tau;
-  A.t_ctr = &s->scal->t_q;
+  A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = s->cfg.soft_target_tau;
+  A.step_size = &s->scal->adam_q_step; A.bc2_sqrt = &s->scal->adam_q_bc2s;
   return launch_adam(s->ctx, A);  // t_q is advanced by k_sac_finish at the end of the step
 }
 
@@ -389,12 +404,19 @@ static int sac_actor_update(ilsx_sac* s) {
   const size_t off = 2 * s->nq;
   A.p = s->P + off; A.g = s->G + off; A.m = s->M + off; A.v = s->V + off; A.tgt = nullptr;
   A.n = (int)s->np;
-  A.lr = s->cfg.policy_lr; A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = 0.f;
-  A.t_ctr = &s->scal->t_pi;
+  A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = 0.f;
+  A.step_size = &s->scal->adam_pi_step; A.bc2_sqrt = &s->scal->adam_pi_bc2s;
   ILSX_TRY(launch_adam(s->ctx, A));
   ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
   hipLaunchKernelGGL(k_sac_finish, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, (const float*)(s->G + 2 * s->nq + s->np),
-                     s->cfg.train_alpha, s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f);
+                     s->cfg.train_alpha, s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+static int sac_refresh_adam(ilsx_sac* s) {
+  hipLaunchKernelGGL(k_sac_refresh_adam, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, s->cfg.qf_lr, s->cfg.policy_lr,
+                     s->cfg.beta_1, 0.999f);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
@@ -578,7 +600,7 @@ extern "C" int ilsx_sac_set_adam(ilsx_sac* s, int which, const float* m_host, co
   if (which == W_PI) h.t_pi = (int)t; else h.t_q = (int)t;
   HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, s->ctx->stream));
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
-  return ILSX_OK;
+  return sac_refresh_adam(s);
 }
 extern "C" int ilsx_sac_get_alpha_opt(ilsx_sac* s, double* m, double* v, int64_t* t, uint64_t* rng_step) {
   if (!s) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");

@@ -2,8 +2,11 @@
 //
 // All GEMM-shaped work runs on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32): results are an
 // fmaf chain in fp32, so parity with the reference's fp32 PyTorch path holds to summation order.
-// Row tiles are 16 batch rows per workgroup (the MFMA M), 4 waves split the hidden width; hidden
-// activations never leave LDS inside a forward / backward-to-input chain.
+// Row tiles are 16 batch rows per workgroup (the MFMA M); H/16 waves (16 for H=256) each own 16 output
+// columns, so a wave's whole weight slice of a hidden layer (16 x H floats = H/4 VGPRs per lane) is
+// fetched with ONE burst of loads issued before the previous layer runs: the k-loop is pure
+// ds_read + MFMA with 4 waves per SIMD interleaving.  Hidden activations never leave LDS inside a
+// forward / backward-to-input chain.
 //
 // Fragment maps used below (MI355X guide §3): for D = A(16x4) * B(4x16)
 //   lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
@@ -30,9 +33,15 @@ enum { ACT_RELU = 0, ACT_TANH = 1 };
 #define HALF_LOG_2PI (0.91893853320467274178f)
 
 // View of one network inside a flat fp32 arena (internal layout: first-layer rows padded to KP).
+//   W_l   (off_W[l])  : "forward-packed"  16x16 blocks [n/16][k/16][(k%16)/4][n%16][k%4]  (ld[l] = K of layer l)
+//   W_l^b (off_Wb[l]) : "backward-packed" 16x16 blocks [k/16][n/16][(n%16)/4][k%16][n%4]  (l >= 1 only)
+//   heads (off_Wh)    : natural [NO][H]
+// Each 16x16 block is 1 KiB contiguous in exactly the order the 64 lanes of an MFMA B-fragment consume
+// it, so a wave fetches a k16 chunk with ONE fully coalesced 16-byte-per-lane load (measured 3.6x faster
+// than fetching fragments from a row-major matrix: tools/ubench/wload.hip).
 struct NetView {
   float* base;
-  int off_W[ILSX_MAX_HID], off_b[ILSX_MAX_HID], ld[ILSX_MAX_HID];
+  int off_W[ILSX_MAX_HID], off_Wb[ILSX_MAX_HID], off_b[ILSX_MAX_HID], ld[ILSX_MAX_HID];
   int off_Wh, off_bh;
   int nhid, H, in_dim, KP, NO;
 };
@@ -49,6 +58,8 @@ struct DevScalars {
   // stats of the step just taken (sac_alpha.py:186-233)
   float qf1_loss, qf2_loss, policy_loss, alpha_loss;
   float q1_mean, q2_mean, log_pi_mean, mu_mean, log_std_mean;
+  // Adam bias-correction scalars for the NEXT step: lr/(1-b1^t), sqrt(1-b2^t)   (t = t_x + 1)
+  float adam_q_step, adam_q_bc2s, adam_pi_step, adam_pi_bc2s;
   float pad1;
 };
 
@@ -86,66 +97,35 @@ template <int ACT> __device__ __forceinline__ float act_grad_from_out(float h) {
   return 1.0f - h * h;
 }
 
-// ------------------------------------------------------------------------------------------------
-// out[r][n] += sum_k cur[r][k] * W[n][k]   (cur: LDS row tile [16][ldc]; W: global, k-contiguous)
-template <int NT>
-__device__ __forceinline__ void gemm_rowtile_nk(const float* cur, int ldc, int K, const float* __restrict__ W,
-                                                int ldw, int n_base, int li, int g, f32x4 (&acc)[NT]) {
-  const float* ap = cur + li * ldc + 4 * g;
-  const float* bp = W + (size_t)(n_base + li) * ldw + 4 * g;
-  for (int kc = 0; kc < K; kc += 16) {
-    const float4 a = *reinterpret_cast<const float4*>(ap + kc);
-    float4 b[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(bp + (size_t)t * 16 * ldw + kc);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
-  }
+
+// phase timestamps (shader clock) of workgroup (0,0), wave 0: debugging aid, off unless a buffer is set
+#define ILSX_STAMP(dbg, i) do { if ((dbg) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (dbg)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// element (n,k) of a forward-packed matrix with K columns / of a backward-packed matrix with N rows
+__host__ __device__ __forceinline__ int pack_f(int n, int k, int K) {
+  return (((n >> 4) * (K >> 4) + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3);
+}
+__host__ __device__ __forceinline__ int pack_b(int n, int k, int N) {
+  return (((k >> 4) * (N >> 4) + (n >> 4)) * 64 + ((n & 15) >> 2) * 16 + (k & 15)) * 4 + (n & 3);
 }
 
-// out[r][c] += sum_n cur[r][n] * W[n][c]   (backward-to-input: contraction over W's ROW index)
-template <int NT>
-__device__ __forceinline__ void gemm_rowtile_kn(const float* cur, int ldc, int Kn, const float* __restrict__ W,
-                                                int ldw, int c_base, int li, int g, f32x4 (&acc)[NT]) {
-  const float* ap = cur + li * ldc + 4 * g;
-  const float* bp = W + (size_t)(4 * g) * ldw + c_base + li;
-  for (int nc = 0; nc < Kn; nc += 16) {
-    const float4 a = *reinterpret_cast<const float4*>(ap + nc);
-    float b[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) b[t][s] = bp[(size_t)(nc + s) * ldw + 16 * t];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t][0], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t][1], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t][2], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t][3], acc[t], 0, 0, 0);
-  }
-}
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// sum over the 16 lanes of a lane group (lanes sharing l>>4)
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
   return v;
+}
+template <int N> __device__ __forceinline__ void load_vec(const float* p, float (&v)[N]) {
+  if (N == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  else if (N == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+  else { v[0] = p[0]; }
 }
 
 // ================================================================================================
 // Fused MLP forward over 16-row tiles (Mlp.forward, networks.py:85-101; FlattenMlp cat, :108-115;
 // tanh-Gaussian head, policies.py:262-307 + distributions.py:23-28,43-50,74-97).
-// grid = (ceil(rows/16), ntasks), block = 256.
+// grid = (ceil(rows/16), ntasks), block = 4*H threads (H/16 waves, wave w owns columns [16w,16w+16)).
 struct FwdTask {
   NetView net;
   const float* x0; const float* x1;  // input segments (cat along dim 1)
@@ -167,12 +147,13 @@ struct FwdArgs {
   uint64_t seed;
   const DevScalars* scal;  // nullable: step counter for Philox
   uint64_t step_host;      // used when scal == null
+  unsigned long long* dbg; // nullable phase timestamps
 };
 
 #ifdef ILSX_KERNEL_IMPL
 template <int H, int ACT>
-__global__ __launch_bounds__(256) void k_mlp_fwd(const FwdArgs A) {
-  constexpr int NT = H / 64;
+__global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
+  constexpr int NW = H / 16, NTH = 4 * H, NC = H / 16, KPL = H / 64, RPW = 16 / NW;
   constexpr int LDH = H + ILSX_LDS_PAD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const FwdTask& T = A.t[blockIdx.y];
@@ -181,12 +162,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const FwdArgs A) {
   float* xs = smem;
   float* bufA = xs + 16 * LDX;
   float* bufB = bufA + 16 * LDH;
-  float* hout = bufB + 16 * LDH;  // [16][NO]
+  float* hout = bufB + 16 * LDH;  // [16][ILSX_MAX_NO]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int r0 = blockIdx.x * 16, rows = A.rows;
+  const int r0 = blockIdx.x * 16, rows = A.rows, n0 = wave * 16;
+  ILSX_STAMP(A.dbg, 0);
 
   // ---- stage the (concatenated, zero-padded) input tile
-  for (int e = tid; e < 16 * KP; e += 256) {
+  for (int e = tid; e < 16 * KP; e += NTH) {
     const int r = e / KP, k = e - r * KP, gr = r0 + r;
     float v = 0.0f;
     if (gr < rows) {
@@ -196,96 +178,142 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const FwdArgs A) {
     }
     xs[r * LDX + k] = v;
   }
+  // ---- this wave's whole slice of hidden layer 1 (16 columns x H): one burst, lands while layer 0 runs
+  float4 wreg[NC];
+  if (N.nhid > 1) {
+    const float* wp = N.base + N.off_W[1] + (size_t)wave * NC * 256 + 4 * lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+  }
   __syncthreads();
+  ILSX_STAMP(A.dbg, 1);
 
-  // ---- hidden layers on the matrix pipe
-  const float* cur = xs;
-  int K = KP, ldc = LDX;
-  for (int l = 0; l < N.nhid; ++l) {
-    float* nxt = (l & 1) ? bufB : bufA;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int n_base = wave * (16 * NT);
-    gemm_rowtile_nk<NT>(cur, ldc, K, N.base + N.off_W[l], N.ld[l], n_base, li, g, acc);
-    const float* bias = N.base + N.off_b[l];
-    float* hs = T.hsave[l];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int col = n_base + 16 * t + li;
-      const float bv = bias[col];
+  // ---- layer 0: K = KP (16 for Hopper, 400 for Humanoid critics), weights streamed with a 1-deep prefetch
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  {
+    const float* ap = xs + li * LDX + 4 * g;
+    const float* bp = N.base + N.off_W[0] + (size_t)wave * (KP >> 4) * 256 + 4 * lane;
+    float4 b = *reinterpret_cast<const float4*>(bp);
+    for (int kc = 0; kc < KP; kc += 16) {
+      float4 bn = b;
+      if (kc + 16 < KP) bn = *reinterpret_cast<const float4*>(bp + (kc + 16) * 16);
+      const float4 a = *reinterpret_cast<const float4*>(ap + kc);
+      acc0 = MFMA16(a.x, b.x, acc0); acc1 = MFMA16(a.y, b.y, acc1);
+      acc0 = MFMA16(a.z, b.z, acc0); acc1 = MFMA16(a.w, b.w, acc1);
+      b = bn;
+    }
+  }
+  float* cur = bufA;
+  for (int l = 0;; ++l) {
+    // epilogue of layer l: bias + activation -> LDS (next layer's A operand) and the saved activations
+    {
+      const float bv = (N.base + N.off_b[l])[n0 + li];
+      float* hs = T.hsave[l];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = 4 * g + v;
-        const float h = act_fn<ACT>(acc[t][v] + bv);
-        nxt[row * LDH + col] = h;
-        if (hs && r0 + row < rows) hs[(size_t)(r0 + row) * H + col] = h;
+        const float h = act_fn<ACT>(acc0[v] + acc1[v] + bv);
+        cur[row * LDH + n0 + li] = h;
+        if (hs && r0 + row < rows) hs[(size_t)(r0 + row) * H + n0 + li] = h;
       }
     }
     __syncthreads();
-    cur = nxt; K = H; ldc = LDH;
+    ILSX_STAMP(A.dbg, 2 + l);
+    if (l + 1 >= N.nhid) break;
+    // layer l+1 straight out of registers
+    acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
+    const float* ap = cur + li * LDH + 4 * g;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
+      acc0 = MFMA16(a.x, wreg[c].x, acc0); acc1 = MFMA16(a.y, wreg[c].y, acc1);
+      acc0 = MFMA16(a.z, wreg[c].z, acc0); acc1 = MFMA16(a.w, wreg[c].w, acc1);
+    }
+    if (l + 2 < N.nhid) {
+      const float* wp = N.base + N.off_W[l + 2] + (size_t)wave * NC * 256 + 4 * lane;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+    }
+    cur = (cur == bufA) ? bufB : bufA;
   }
 
-  // ---- heads (NO <= 64 outputs): 16 lanes per row, shuffle-reduced dot products
-  {
-    const int row = tid >> 4, part = tid & 15;
-    const float* hrow = cur + row * ldc;
-    const float* Wh = N.base + N.off_Wh;
-    const float* bh = N.base + N.off_bh;
-    for (int j = 0; j < NO; ++j) {
-      float s = 0.0f;
-      for (int k = 4 * part; k < K; k += 64) {
-        const float4 hv = *reinterpret_cast<const float4*>(hrow + k);
-        const float4 wv = *reinterpret_cast<const float4*>(Wh + (size_t)j * H + k);
-        s = fmaf(hv.x, wv.x, s); s = fmaf(hv.y, wv.y, s); s = fmaf(hv.z, wv.z, s); s = fmaf(hv.w, wv.w, s);
+  // ---- heads (NO <= 64 outputs): one wave per row, lanes split K, 4 outputs in flight
+  const float* Wh = N.base + N.off_Wh;
+  const float* bh = N.base + N.off_bh;
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = wave * RPW + rr;
+    float hv[KPL];
+    load_vec<KPL>(cur + row * LDH + KPL * lane, hv);
+    for (int j0 = 0; j0 < NO; j0 += 4) {
+      float s[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + u, NO - 1);
+        float wv[KPL];
+        load_vec<KPL>(Wh + (size_t)j * H + KPL * lane, wv);
+        float t = 0.0f;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) t = fmaf(hv[c], wv[c], t);
+        s[u] = t;
       }
-      s = group16_sum(s);
-      if (part == 0) hout[row * ILSX_MAX_NO + j] = s + bh[j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] = wave_sum(s[u]);
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u < NO) hout[row * ILSX_MAX_NO + j0 + u] = s[u] + bh[j0 + u];
+      }
     }
   }
   __syncthreads();
+  ILSX_STAMP(A.dbg, 6);
 
-  // ---- head epilogue
-  if (T.out) {
-    for (int e = tid; e < 16 * NO; e += 256) {
-      const int r = e / NO, j = e - r * NO;
-      if (r0 + r < rows) T.out[(size_t)(r0 + r) * NO + j] = hout[r * ILSX_MAX_NO + j];
-    }
-  }
-  if (T.head != HEAD_RAW && tid < 16 && r0 + tid < rows) {
-    const int r = tid, gr = r0 + r, a = NO >> 1;
-    const float* ho = hout + r * ILSX_MAX_NO;
-    const uint64_t step = A.scal ? A.scal->step : A.step_host;
+  // ---- head epilogue: wave <-> row, lane <-> output / action dim
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = wave * RPW + rr, gr = r0 + row;
+    if (gr >= rows) continue;  // wave-uniform
+    const float* ho = hout + row * ILSX_MAX_NO;
+    if (T.out && lane < NO) T.out[(size_t)gr * NO + lane] = ho[lane];
+    if (T.head == HEAD_RAW) continue;
+    const int a = NO >> 1, j = lane;
     float lp_quad = 0.f, lp_ls = 0.f, lp_jac = 0.f;
-    for (int j0 = 0; j0 < a; j0 += 4) {
-      float z4[4] = {0.f, 0.f, 0.f, 0.f};
-      if (T.head == HEAD_TANH_SAMPLE && !T.eps) philox_normal4(A.seed, step, T.rng_stream, gr, j0 >> 2, z4);
-      for (int jj = 0; jj < 4 && j0 + jj < a; ++jj) {
-        const int j = j0 + jj;
-        const float mu = ho[j];
-        const float ls = fminf(fmaxf(ho[a + j], LOG_SIG_MIN), LOG_SIG_MAX);
-        const float sd = expf(ls);
-        float e = 0.f, z, act;
-        if (T.head == HEAD_TANH_DET) {
-          z = mu; act = tanhf(mu);
-        } else if (T.head == HEAD_TANH_LOGP_OF_ACT) {
-          act = T.act_in[(size_t)gr * a + j];
-          z = 0.5f * (logf(1.0f + act + TANH_EPS) - logf(1.0f - act + TANH_EPS));  // distributions.py:85-88
+    if (j < a) {
+      const float mu = ho[j];
+      const float ls = fminf(fmaxf(ho[a + j], LOG_SIG_MIN), LOG_SIG_MAX);
+      const float sd = expf(ls);
+      float e = 0.f, z, act;
+      if (T.head == HEAD_TANH_DET) {
+        z = mu; act = tanhf(mu);
+      } else if (T.head == HEAD_TANH_LOGP_OF_ACT) {
+        act = T.act_in[(size_t)gr * a + j];
+        z = 0.5f * (logf(1.0f + act + TANH_EPS) - logf(1.0f - act + TANH_EPS));  // distributions.py:85-88
+      } else {
+        if (T.eps) {
+          e = T.eps[(size_t)gr * a + j];
         } else {
-          e = T.eps ? T.eps[(size_t)gr * a + j] : z4[jj];
-          z = e * sd + mu;        // distributions.py:27
-          act = tanhf(z);
+          float z4[4];
+          philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+          const int q = j & 3;
+          e = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
         }
-        const float dm = mu - z;
-        lp_quad += dm * dm / expf(2.0f * ls);                 // distributions.py:45-47
-        lp_ls += ls;
-        lp_jac += logf(1.0f - act * act + TANH_EPS);          // distributions.py:91-93
-        if (T.action) T.action[(size_t)gr * a + j] = act;
-        if (T.eps_save) T.eps_save[(size_t)gr * a + j] = e;
+        z = e * sd + mu;        // distributions.py:27
+        act = tanhf(z);
       }
+      const float dm = mu - z;
+      lp_quad = dm * dm / expf(2.0f * ls);                 // distributions.py:45-47
+      lp_ls = ls;
+      lp_jac = logf(1.0f - act * act + TANH_EPS);          // distributions.py:91-93
+      if (T.action) T.action[(size_t)gr * a + j] = act;
+      if (T.eps_save) T.eps_save[(size_t)gr * a + j] = e;
     }
-    if (T.logp) T.logp[gr] = -0.5f * lp_quad - (lp_ls + HALF_LOG_2PI) - lp_jac;
+    if (T.logp) {  // wave-uniform
+      lp_quad = wave_sum(lp_quad); lp_ls = wave_sum(lp_ls); lp_jac = wave_sum(lp_jac);
+      if (lane == 0) T.logp[gr] = -0.5f * lp_quad - (lp_ls + HALF_LOG_2PI) - lp_jac;
+    }
   }
+  ILSX_STAMP(A.dbg, 7);
 }
 #endif  // ILSX_KERNEL_IMPL
 
@@ -312,72 +340,81 @@ struct BwdArgs {
   float inv_B;          // 1/(B*grad_world)
   float gamma, reward_scale, w_mu, w_std;
   const DevScalars* scal;
+  unsigned long long* dbg;
 };
 
 #ifdef ILSX_KERNEL_IMPL
 template <int H, int ACT>
-__global__ __launch_bounds__(256) void k_mlp_bwd_dx(const BwdArgs A) {
-  constexpr int NT = H / 64;
+__global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
+  constexpr int NW = H / 16, NTH = 4 * H, NC = H / 16, KPL = H / 64, RPW = 16 / NW;
   constexpr int LDH = H + ILSX_LDS_PAD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const BwdTask& T = A.t[blockIdx.y];
   const NetView& N = T.net;
-  const int NO = N.NO;
+  const int NO = N.NO, L = N.nhid;
   float* bufA = smem;
   float* bufB = bufA + 16 * LDH;
   float* dout = bufB + 16 * LDH;  // [16][ILSX_MAX_NO]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int r0 = blockIdx.x * 16, rows = A.rows;
+  const int r0 = blockIdx.x * 16, rows = A.rows, c0 = wave * 16;
 
-  // ---- head gradient
-  for (int e = tid; e < 16 * ILSX_MAX_NO; e += 256) dout[e] = 0.0f;
-  __syncthreads();
-  if (tid < 16 && r0 + tid < rows) {
-    const int gr = r0 + tid;
-    float* d = dout + tid * ILSX_MAX_NO;
-    if (T.loss == LOSS_GIVEN) {
-      for (int j = 0; j < NO; ++j) d[j] = T.given[(size_t)gr * NO + j];
-    } else if (T.loss == LOSS_SAC_CRITIC) {
-      // sac_alpha.py:110-123: y = r + (1-d)*gamma*(min(TQ1,TQ2) - alpha*logpi'); dL/dq = (q-y)/B
-      const float alpha = A.scal->alpha;
-      const float r = A.reward_scale * T.rew[gr];
-      const float y = r + (1.0f - T.done[gr]) * A.gamma * (fminf(T.tq1[gr], T.tq2[gr]) - alpha * T.logp_next[gr]);
-      d[0] = (T.q[gr] - y) * A.inv_B;
-    } else if (T.loss == LOSS_SAC_ACTORQ) {
-      // sac_alpha.py:144-148: -mean(min(Q1,Q2)); torch.minimum splits ties evenly
-      const float a1 = T.q1n[gr], a2 = T.q2n[gr];
-      const float w1 = a1 < a2 ? 1.0f : (a1 == a2 ? 0.5f : 0.0f);
-      d[0] = -(T.which == 0 ? w1 : 1.0f - w1) * A.inv_B;
-    } else {  // LOSS_SAC_POLICY: SURVEY Appendix A.1/A.2
-      const int a = NO >> 1;
-      const float alpha = A.scal->alpha;
-      const float glp = alpha * A.inv_B;
-      const float inv_Ba = A.inv_B / (float)a;
-      for (int j = 0; j < a; ++j) {
-        const float mu = T.raw[(size_t)gr * NO + j], lsr = T.raw[(size_t)gr * NO + a + j];
+  // ---- this wave's slice of W_{L-1} (all H rows x its 16 columns), in flight during the head phases
+  float4 wreg[NC];
+  if (L > 1) {
+    const float* wp = N.base + N.off_Wb[L - 1] + (size_t)wave * NC * 256 + 4 * lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+  }
+
+  // ---- head gradient: thread <-> (row, output)
+  for (int e = tid; e < 16 * ILSX_MAX_NO; e += NTH) {
+    const int row = e >> 6, j = e & 63, gr = r0 + row;
+    float d = 0.0f;
+    if (gr < rows && j < NO) {
+      if (T.loss == LOSS_GIVEN) {
+        d = T.given[(size_t)gr * NO + j];
+      } else if (T.loss == LOSS_SAC_CRITIC) {
+        // sac_alpha.py:110-123: y = r + (1-d)*gamma*(min(TQ1,TQ2) - alpha*logpi'); dL/dq = (q-y)/B
+        const float alpha = A.scal->alpha;
+        const float r = A.reward_scale * T.rew[gr];
+        const float y = r + (1.0f - T.done[gr]) * A.gamma * (fminf(T.tq1[gr], T.tq2[gr]) - alpha * T.logp_next[gr]);
+        d = (T.q[gr] - y) * A.inv_B;
+      } else if (T.loss == LOSS_SAC_ACTORQ) {
+        // sac_alpha.py:144-148: -mean(min(Q1,Q2)); torch.minimum splits ties evenly
+        const float a1 = T.q1n[gr], a2 = T.q2n[gr];
+        const float w1 = a1 < a2 ? 1.0f : (a1 == a2 ? 0.5f : 0.0f);
+        d = -(T.which == 0 ? w1 : 1.0f - w1) * A.inv_B;
+      } else {  // LOSS_SAC_POLICY: SURVEY Appendix A.1/A.2 ; j < a -> d mu_j, else d log_std_raw_{j-a}
+        const int a = NO >> 1, jj = j < a ? j : j - a;
+        const float alpha = A.scal->alpha;
+        const float glp = alpha * A.inv_B;
+        const float inv_Ba = A.inv_B / (float)a;
+        const float mu = T.raw[(size_t)gr * NO + jj], lsr = T.raw[(size_t)gr * NO + a + jj];
         const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
-        const float sd = expf(ls), e = T.eps[(size_t)gr * a + j], act = T.action[(size_t)gr * a + j];
-        const float ga = T.ga1[(size_t)gr * a + j] + T.ga2[(size_t)gr * a + j];
+        const float sd = expf(ls), ep = T.eps[(size_t)gr * a + jj], act = T.action[(size_t)gr * a + jj];
+        const float ga = T.ga1[(size_t)gr * a + jj] + T.ga2[(size_t)gr * a + jj];
         const float om = 1.0f - act * act;
         const float dz = ga * om + glp * (2.0f * act * om / (om + TANH_EPS));
-        const float dmu = dz + 2.0f * A.w_mu * mu * inv_Ba;
-        const float dls = dz * sd * e - glp + 2.0f * A.w_std * ls * inv_Ba;
-        d[j] = dmu;
-        d[a + j] = (lsr >= LOG_SIG_MIN && lsr <= LOG_SIG_MAX) ? dls : 0.0f;
+        if (j < a) {
+          d = dz + 2.0f * A.w_mu * mu * inv_Ba;
+        } else {
+          const float dls = dz * sd * ep - glp + 2.0f * A.w_std * ls * inv_Ba;
+          d = (lsr >= LOG_SIG_MIN && lsr <= LOG_SIG_MAX) ? dls : 0.0f;
+        }
       }
+      if (T.dhead) T.dhead[(size_t)gr * NO + j] = d;
     }
-    if (T.dhead) for (int j = 0; j < NO; ++j) T.dhead[(size_t)gr * NO + j] = d[j];
+    dout[e] = d;
   }
   __syncthreads();
 
-  // ---- delta_L = (dout Wh) * act'(h_L): small contraction (NO <= 64) on the VALU
-  const int L = N.nhid;
+  // ---- delta_{L-1} = (dout Wh) * act'(h_{L-1}): small contraction (NO <= 64) on the VALU
   {
-    const int row = tid >> 4, part = tid & 15, gr = r0 + row;
     const float* Wh = N.base + N.off_Wh;
     const float* hl = T.hsave[L - 1];
     float* ds = T.dsave[L - 1];
-    for (int k = part; k < H; k += 16) {
+    for (int e = tid; e < 16 * H; e += NTH) {
+      const int row = e / H, k = e - row * H, gr = r0 + row;
       float s = 0.0f;
       for (int j = 0; j < NO; ++j) s = fmaf(dout[row * ILSX_MAX_NO + j], Wh[(size_t)j * H + k], s);
       float dv = 0.0f;
@@ -390,45 +427,57 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_dx(const BwdArgs A) {
   }
   __syncthreads();
 
-  // ---- delta_{l-1} = (delta_l W_l) * act'(h_{l-1})  for l = L-1 .. 1   (matrix pipe)
+  // ---- delta_{l-1} = (delta_l W_l) * act'(h_{l-1})  for l = L-1 .. 1   (matrix pipe, W_l from registers)
   float* cur = bufA;
   for (int l = L - 1; l >= 1; --l) {
     float* nxt = (cur == bufA) ? bufB : bufA;
-    f32x4 acc[NT];
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const float* ap = cur + li * LDH + 4 * g;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int c_base = wave * (16 * NT);
-    gemm_rowtile_kn<NT>(cur, LDH, H, N.base + N.off_W[l], N.ld[l], c_base, li, g, acc);
+    for (int c = 0; c < NC; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
+      acc0 = MFMA16(a.x, wreg[c].x, acc0); acc1 = MFMA16(a.y, wreg[c].y, acc1);
+      acc0 = MFMA16(a.z, wreg[c].z, acc0); acc1 = MFMA16(a.w, wreg[c].w, acc1);
+    }
+    if (l - 1 >= 1) {
+      const float* wp = N.base + N.off_Wb[l - 1] + (size_t)wave * NC * 256 + 4 * lane;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+    }
     const float* hp = T.hsave[l - 1];
     float* ds = T.dsave[l - 1];
+    const int col = c0 + li;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int col = c_base + 16 * t + li;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 4 * g + v, gr = r0 + row;
-        float dv = 0.0f;
-        if (gr < rows) {
-          dv = acc[t][v] * act_grad_from_out<ACT>(hp[(size_t)gr * H + col]);
-          if (ds) ds[(size_t)gr * H + col] = dv;
-        }
-        nxt[row * LDH + col] = dv;
+    for (int v = 0; v < 4; ++v) {
+      const int row = 4 * g + v, gr = r0 + row;
+      float dv = 0.0f;
+      if (gr < rows) {
+        dv = (acc0[v] + acc1[v]) * act_grad_from_out<ACT>(hp[(size_t)gr * H + col]);
+        if (ds) ds[(size_t)gr * H + col] = dv;
       }
+      nxt[row * LDH + col] = dv;
     }
     __syncthreads();
     cur = nxt;
   }
 
-  // ---- dL/dx columns (action columns for the actor; contraction over H on the VALU)
+  // ---- dL/dx columns (action columns for the actor): wave <-> row, lanes split the H contraction
   if (T.dx) {
-    const int row = tid >> 4, part = tid & 15, gr = r0 + row;
     const float* W0 = N.base + N.off_W[0];
     const int ld0 = N.ld[0];
-    for (int c = 0; c < T.dx_cols; ++c) {
-      float s = 0.0f;
-      for (int k = part; k < H; k += 16) s = fmaf(cur[row * LDH + k], W0[(size_t)k * ld0 + T.dx_col0 + c], s);
-      s = group16_sum(s);
-      if (part == 0 && gr < rows) T.dx[(size_t)gr * T.dx_cols + c] = s;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = wave * RPW + rr, gr = r0 + row;
+      float dv[KPL];
+#pragma unroll
+      for (int i = 0; i < KPL; ++i) dv[i] = cur[row * LDH + lane + 64 * i];
+      for (int c = 0; c < T.dx_cols; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) s = fmaf(dv[i], W0[pack_f(lane + 64 * i, T.dx_col0 + c, ld0)], s);
+        s = wave_sum(s);
+        if (lane == 0 && gr < rows) T.dx[(size_t)gr * T.dx_cols + c] = s;
+      }
     }
   }
 }
@@ -436,18 +485,27 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_dx(const BwdArgs A) {
 
 // ================================================================================================
 // Weight gradients: dW[n][k] = sum_r A[r][n] * Bm[r][k], db[n] = sum_r A[r][n]  (contraction over
-// the batch).  One workgroup per 64(n) x 64(k) output tile; wave w owns n rows [16w,16w+16).
+// the batch).  One 1024-thread workgroup per 32(n) x 64(k) output tile: wave = (n-half, row-eighth);
+// each wave issues all its operand loads up front, runs its MFMAs, and the 8 row-partials are summed
+// through LDS.  dynamic LDS = DW_LDS_BYTES.
+enum { DW_OUT_NATURAL = 0, DW_OUT_PACK_F = 1, DW_OUT_PACK_FB = 2 };
 struct DwJob {
-  const float* A; const float* Bm; float* dW; float* db;
-  int lda, NA, ldb, NB, ldw, n0, k0, pad;
+  const float* A; const float* Bm; float* dW; float* dWb; float* db;
+  int lda, NA, ldb, NB, ldw, n0, k0, mode;   // ldw: natural row stride, or K (PACK_F) ; NA rows for PACK_B
 };
+#define DW_TILE_N 32
+#define DW_TILE_K 64
+#define DW_LDS_BYTES ((16 * 16 * 64 + 16 * 16) * 4)
 
 #ifdef ILSX_KERNEL_IMPL
-__global__ __launch_bounds__(256) void k_mlp_bwd_dw(const DwJob* __restrict__ jobs, int rows) {
+__global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ jobs, int rows) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* part = smem;                    // [16 waves][16 acc regs][64 lanes]
+  float* bpart = smem + 16 * 16 * 64;    // [16 waves][16]
   const DwJob J = jobs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int nsub = J.n0 + 16 * wave;
-  if (nsub >= J.NA) return;
+  const int wn = wave & 1, wr = wave >> 1;
+  const int nsub = J.n0 + 16 * wn;
   const bool n_ok = nsub + li < J.NA;
   int ntk = (J.NB - J.k0 + 15) / 16;
   if (ntk > 4) ntk = 4;
@@ -458,7 +516,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_dw(const DwJob* __restrict__ jo
   bool k_ok[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) k_ok[t] = J.k0 + 16 * t + li < J.NB;
-  for (int rc = 0; rc < rows; rc += 16) {
+  for (int rc = 16 * wr; rc < rows; rc += 128) {
     float a[4], b[4][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -473,51 +531,63 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_dw(const DwJob* __restrict__ jo
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (t < ntk) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+        if (t < ntk) acc[t] = MFMA16(a[s], b[t][s], acc[t]);
       bsum += a[s];
     }
   }
+  // partial tiles -> LDS
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int k = J.k0 + 16 * t + li;
-    if (t < ntk && k < J.NB) {
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int n = nsub + 4 * g + v;
-        if (n < J.NA) J.dW[(size_t)n * J.ldw + k] = acc[t][v];
+    for (int v = 0; v < 4; ++v) part[(wave * 16 + t * 4 + v) * 64 + lane] = acc[t][v];
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (g == 0) bpart[wave * 16 + li] = bsum;
+  __syncthreads();
+  // sum the 8 row-partials; thread <-> (n-half, tile, reg, lane)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int e = tid + 1024 * h;
+    const int on = e >> 10, rest = e & 1023, t = rest >> 8, v = (rest >> 6) & 3, ol = rest & 63;
+    float s = 0.0f;
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * 2 + on) * 16 + t * 4 + v) * 64 + ol];
+    const int n = J.n0 + 16 * on + 4 * (ol >> 4) + v, k = J.k0 + 16 * t + (ol & 15);
+    if (t < ntk && n < J.NA && k < J.NB) {
+      if (J.mode == DW_OUT_NATURAL) {
+        J.dW[(size_t)n * J.ldw + k] = s;
+      } else {
+        J.dW[pack_f(n, k, J.ldw)] = s;
+        if (J.mode == DW_OUT_PACK_FB) J.dWb[pack_b(n, k, J.NA)] = s;
       }
     }
   }
-  if (J.db && J.k0 == 0) {
-    bsum += __shfl_xor(bsum, 16, 64);
-    bsum += __shfl_xor(bsum, 32, 64);
-    if (g == 0 && n_ok) J.db[nsub + li] = bsum;
+  if (J.db && J.k0 == 0 && tid < 32) {
+    const int on = tid >> 4, ol = tid & 15;
+    float s = 0.0f;
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) s += bpart[(r8 * 2 + on) * 16 + ol];
+    if (J.n0 + 16 * on + ol < J.NA) J.db[J.n0 + 16 * on + ol] = s;
   }
 }
 #endif  // ILSX_KERNEL_IMPL
 
 // ================================================================================================
 // Fused Adam (+ optional Polyak target update) over a flat arena segment.
-// torch 1.9 Adam (sac_alpha.py:65-76) + pytorch_util.py:10-12.
+// torch 1.9 Adam (sac_alpha.py:65-76) + pytorch_util.py:10-12.  The bias-correction scalars
+// step_size = lr/(1-b1^t) and sqrt(1-b2^t) are kept in device memory (float64 pow done once per step
+// by the step's tail kernel) so this kernel is pure streaming.
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; float* tgt;  // tgt nullable
   int n;
-  float lr, b1, b2, eps, tau;
-  const int* t_ctr;  // completed-step counter (device); this step uses t = *t_ctr + 1
+  float b1, b2, eps, tau;
+  const float* step_size;  // device scalars for THIS step
+  const float* bc2_sqrt;
 };
 
 #ifdef ILSX_KERNEL_IMPL
 __global__ __launch_bounds__(256) void k_adam_polyak(const AdamArgs A) {
-  __shared__ float s_step, s_bc2s;
-  if (threadIdx.x == 0) {
-    const int t = *A.t_ctr + 1;
-    const double bc1 = 1.0 - pow((double)A.b1, (double)t);
-    const double bc2 = 1.0 - pow((double)A.b2, (double)t);
-    s_step = (float)((double)A.lr / bc1);
-    s_bc2s = (float)sqrt(bc2);
-  }
-  __syncthreads();
-  const float step = s_step, bc2s = s_bc2s, b1 = A.b1, b2 = A.b2, ob1 = 1.0f - A.b1, ob2 = 1.0f - A.b2;
+  const float step = *A.step_size, bc2s = *A.bc2_sqrt, b1 = A.b1, b2 = A.b2, ob1 = 1.0f - A.b1, ob2 = 1.0f - A.b2;
   const float tau = A.tau, otau = 1.0f - A.tau, eps = A.eps;
   const int n4 = A.n >> 2;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {

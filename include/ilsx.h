@@ -71,6 +71,9 @@ int ilsx_prof_enable(ilsx_ctx* ctx, int on);
 int ilsx_prof_reset(ilsx_ctx* ctx);
 int ilsx_prof_read(ilsx_ctx* ctx, int kernel_id, uint64_t* launches, double* total_ms);
 const char* ilsx_kernel_name(int kernel_id);
+/* debugging aid: workgroup (0,0) of the MLP forward kernel writes shader-clock phase stamps into a
+ * device uint64[16] buffer (NULL = off). */
+int ilsx_debug_set_stamp_buffer(ilsx_ctx* ctx, void* dev_u64x16);
 
 /* ---------------------------------------------------------------- networks
  * Replaces rlkit/torch/common/networks.py:23-115 (Mlp / FlattenMlp) and the heads of
