@@ -34,8 +34,38 @@ class SacStats(C.Structure):
                 ("policy_log_std_mean", C.c_float), ("log_alpha", C.c_double)]
 
 
+_MB, _MG = 8, 8
+
+
+class PlanarModel(C.Structure):  # ilsx_planar_model
+    _fields_ = [("task", C.c_int32), ("n_body", C.c_int32), ("n_geom", C.c_int32), ("frame_skip", C.c_int32),
+                ("pgs_iters", C.c_int32), ("pad0", C.c_int32),
+                ("parent", C.c_int32 * _MB), ("limited", C.c_int32 * _MB), ("geom_body", C.c_int32 * _MG),
+                ("anchor", (C.c_double * 2) * _MB), ("com", (C.c_double * 2) * _MB),
+                ("mass", C.c_double * _MB), ("inertia", C.c_double * _MB), ("jsign", C.c_double * _MB),
+                ("armature", C.c_double * _MB), ("damping", C.c_double * _MB), ("range", (C.c_double * 2) * _MB),
+                ("gear", C.c_double * _MB),
+                ("geom_p1", (C.c_double * 2) * _MG), ("geom_p2", (C.c_double * 2) * _MG),
+                ("geom_radius", C.c_double * _MG), ("geom_friction", C.c_double * _MG),
+                ("timestep", C.c_double), ("gravity", C.c_double), ("reset_noise", C.c_double),
+                ("contact_margin", C.c_double), ("contact_solref", C.c_double * 2), ("contact_solimp", C.c_double * 3),
+                ("limit_solref", C.c_double * 2), ("limit_solimp", C.c_double * 3),
+                ("ctrl_cost", C.c_double), ("alive_bonus", C.c_double), ("z_min", C.c_double), ("z_max", C.c_double),
+                ("ang_max", C.c_double), ("state_max", C.c_double), ("init_qpos", C.c_double * (_MB + 2))]
+
+
 # name -> (restype, argtypes); every symbol include/ilsx.h declares
 PROTOTYPES = {
+    "ilsx_vecenv_create": (C.c_int, [vp, C.POINTER(PlanarModel), C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "ilsx_vecenv_destroy": (C.c_int, [vp]),
+    "ilsx_vecenv_dims": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ilsx_vecenv_reset": (C.c_int, [vp, vp, C.c_int, vp]),
+    "ilsx_vecenv_step": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
+    "ilsx_vecenv_get_state": (C.c_int, [vp, vp, vp]),
+    "ilsx_vecenv_set_state": (C.c_int, [vp, vp, vp]),
+    "ilsx_vecenv_cur_obs": (C.c_int, [vp, C.POINTER(vp)]),
+    "ilsx_rollout_step": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+    "ilsx_rollout_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "ilsx_abi_version": (C.c_int, []),
     "ilsx_last_error": (C.c_char_p, []),
     "ilsx_ctx_create": (C.c_int, [C.c_int, vp, C.c_uint64, C.POINTER(vp)]),

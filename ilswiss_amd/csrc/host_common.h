@@ -121,6 +121,8 @@ struct ilsx_replay {
   std::deque<std::pair<int64_t, int64_t>> trajs;  // insertion-ordered (start,end)
   std::vector<uint8_t> start_flag;                // slot is a key of `trajs`
 };
+// n rows were written into the ring at [top, top+n) by a device kernel: advance the cursors.
+int replay_advance_device_rows(ilsx_replay* rb, int n);
 int replay_launch_sample(ilsx_replay* rb, int B, const int64_t* idx, const DevScalars* scal,
                          unsigned long long step_host, float* obs, float* act, float* rew, float* done,
                          float* nobs, int64_t* idx_out);

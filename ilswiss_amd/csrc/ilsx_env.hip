@@ -1,0 +1,683 @@
+// ilsx_env.hip — HIP-resident batched planar articulated-body stepper + fused rollout step.
+// Replaces the vec-env path of the reference: rlkit/envs/vecenvs.py:158-257 (reset/step protocol),
+// rlkit/envs/worker/subproc.py:59-113 (one OS process + pipe per env), rlkit/envs/wrappers.py:342-352
+// (NormalizedBoxEnv action map) and the MuJoCo call under gym's HopperEnv/Walker2dEnv.step
+// (reward / termination formulas as restated in rlkit/envs/mujoco/hopper.py:11-40, walker2d.py:11-36).
+//
+// One lane per env.  State is SoA float64 in HBM (qpos[d][env], qvel[d][env]) so a wave's loads are
+// coalesced; the per-env matrices (mass matrix / Cholesky factor, constraint Jacobian, M^-1 J^T, the
+// constraint-space matrix A) live in LDS as [element][lane] slices, everything else in registers.
+// The model and its solver are stated in oracle/planar_env.py (the CPU oracle); physics parity with
+// MuJoCo is UNPINNED (no MuJoCo here) — see DESIGN.md.
+// Not a roofline kernel: ~160 B of HBM traffic and O(1e4) fp64 FLOP per env-step on a serial chain.
+#include <cmath>
+
+#include "host_common.h"
+
+#define ENV_MAXB 8
+#define ENV_MAXG 8
+
+struct PlanarModelDev {
+  int nb, ng, task, frame_skip, pgs_iters, max_rows, n_act, obs_dim;
+  int parent[ENV_MAXB], limited[ENV_MAXB], act_body[ENV_MAXB], geom_body[ENV_MAXG], ancmask[ENV_MAXB];
+  double anchor[ENV_MAXB][2], com[ENV_MAXB][2], mass[ENV_MAXB], inertia[ENV_MAXB], jsign[ENV_MAXB];
+  double armature[ENV_MAXB], damping[ENV_MAXB], range[ENV_MAXB][2], gear[ENV_MAXB];
+  double gp1[ENV_MAXG][2], gp2[ENV_MAXG][2], grad[ENV_MAXG], gfric[ENV_MAXG];
+  double timestep, gravity, reset_noise, margin;
+  double c_solref[2], c_solimp[3], l_solref[2], l_solimp[3];
+  double ctrl_cost, alive, z_min, z_max, ang_max, state_max;
+  double init_qpos[ENV_MAXB + 2];
+};
+
+struct ilsx_vecenv {
+  ilsx_ctx* ctx = nullptr;
+  PlanarModelDev hm;
+  PlanarModelDev* dm = nullptr;
+  int n_env = 0, n = 0, o = 0, a = 0;
+  double *qpos = nullptr, *qvel = nullptr;  // [n][n_env]
+  float *obs_cur = nullptr, *act = nullptr, *nobs = nullptr, *rew = nullptr;
+  uint8_t* done = nullptr;
+  int* ep_len = nullptr;
+  double* ep_ret = nullptr;
+  double* stats = nullptr;  // [0] finished episodes, [1] sum of their returns, [2] env steps
+  int* ids = nullptr;       // device scratch for id lists
+  uint64_t seed = 0;
+  uint32_t rng_stream = 0;
+  unsigned long long step_ctr = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double impedance_d(double r_abs, const double* solimp) {
+  const double d0 = solimp[0], dmax = solimp[1], width = solimp[2];
+  double x = width > 0.0 ? fmin(r_abs / width, 1.0) : 1.0;
+  const double y = x < 0.5 ? 2.0 * x * x : 1.0 - 2.0 * (1.0 - x) * (1.0 - x);
+  return d0 + y * (dmax - d0);
+}
+
+// LDS slice accessor: element i of this lane's scratch array starting at `base`
+#define SL(base, i) sm[((base) + (i)) * BLOCK + lane_in_block]
+
+template <int NB, int MR, int BLOCK>
+struct EnvScratch {
+  static constexpr int N = NB + 2;
+  static constexpr int OFF_M = 0;               // N*N   (becomes the Cholesky factor L)
+  static constexpr int OFF_J = OFF_M + N * N;   // MR*N
+  static constexpr int OFF_Y = OFF_J + MR * N;  // N*MR  (M^-1 J^T, column per row)
+  static constexpr int OFF_A = OFF_Y + N * MR;  // MR*MR
+  static constexpr int TOTAL = OFF_A + MR * MR;
+};
+
+// Forward dynamics with soft constraints: qacc = f(q, v, ctrl).  See oracle/planar_env.py::dynamics.
+template <int NB, int MR, int BLOCK>
+__device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2], const double (&v)[NB + 2],
+                             const double* ctrl, double (&qacc)[NB + 2], double* sm, int lane_in_block) {
+  constexpr int N = NB + 2;
+  using S = EnvScratch<NB, MR, BLOCK>;
+  double phi[NB], phid[NB], ox[NB], oz[NB], aox[NB], aoz[NB];
+  // ---- kinematics
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int p = m.parent[b];
+    if (p < 0) {
+      phi[b] = m.jsign[b] * q[2]; phid[b] = m.jsign[b] * v[2];
+      ox[b] = q[0]; oz[b] = q[1]; aox[b] = 0.0; aoz[b] = 0.0;
+    } else {
+      // parent index is data: select with a small unrolled scan (keeps the arrays in registers)
+      double pphi = 0, pphid = 0, pox = 0, poz = 0, paox = 0, paoz = 0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (j == p) { pphi = phi[j]; pphid = phid[j]; pox = ox[j]; poz = oz[j]; paox = aox[j]; paoz = aoz[j]; }
+      phi[b] = pphi + m.jsign[b] * q[2 + b]; phid[b] = pphid + m.jsign[b] * v[2 + b];
+      const double c = cos(pphi), s = sin(pphi);
+      const double wx = c * m.anchor[b][0] - s * m.anchor[b][1], wz = s * m.anchor[b][0] + c * m.anchor[b][1];
+      ox[b] = pox + wx; oz[b] = poz + wz;
+      aox[b] = paox - pphid * pphid * wx; aoz[b] = paoz - pphid * pphid * wz;
+    }
+  }
+  // ---- mass matrix + right-hand side
+#pragma unroll
+  for (int i = 0; i < N * N; ++i) SL(S::OFF_M, i) = 0.0;
+  double rhs[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) rhs[i] = 0.0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const double c = cos(phi[b]), s = sin(phi[b]);
+    const double cwx = c * m.com[b][0] - s * m.com[b][1], cwz = s * m.com[b][0] + c * m.com[b][1];
+    const double cx = ox[b] + cwx, cz = oz[b] + cwz;
+    const double acx = aox[b] - phid[b] * phid[b] * cwx, acz = aoz[b] - phid[b] * phid[b] * cwz;
+    double jx[N], jz[N], jp[N];  // COM Jacobian rows and angular Jacobian
+    jx[0] = 1.0; jz[0] = 0.0; jp[0] = 0.0; jx[1] = 0.0; jz[1] = 1.0; jp[1] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool anc = (m.ancmask[b] >> j) & 1;
+      const double sg = anc ? m.jsign[j] : 0.0;
+      jx[2 + j] = -sg * (cz - oz[j]); jz[2 + j] = sg * (cx - ox[j]); jp[2 + j] = sg;
+    }
+    const double mb = m.mass[b], ib = m.inertia[b];
+    const double fx = mb * (0.0 - acx), fz = mb * (-m.gravity - acz);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      rhs[i] += jx[i] * fx + jz[i] * fz;
+#pragma unroll
+      for (int k = 0; k <= i; ++k) SL(S::OFF_M, i * N + k) += mb * (jx[i] * jx[k] + jz[i] * jz[k]) + ib * jp[i] * jp[k];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    SL(S::OFF_M, (2 + b) * N + 2 + b) += m.armature[b];
+    rhs[2 + b] -= m.damping[b] * v[2 + b];
+  }
+  for (int k = 0; k < m.n_act; ++k) {
+    const int b = m.act_body[k];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j == b) rhs[2 + j] += m.gear[j] * ctrl[k];
+  }
+  // ---- Cholesky M = L L^T (lower triangle in place)
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int k = 0; k <= i; ++k) {
+      double sum = SL(S::OFF_M, i * N + k);
+#pragma unroll
+      for (int t = 0; t < k; ++t) sum -= SL(S::OFF_M, i * N + t) * SL(S::OFF_M, k * N + t);
+      SL(S::OFF_M, i * N + k) = (i == k) ? sqrt(sum) : sum / SL(S::OFF_M, k * N + k);
+    }
+  }
+  auto chol_solve = [&](double (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double sum = x[i];
+#pragma unroll
+      for (int t = 0; t < i; ++t) sum -= SL(S::OFF_M, i * N + t) * x[t];
+      x[i] = sum / SL(S::OFF_M, i * N + i);
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+      double sum = x[i];
+#pragma unroll
+      for (int t = i + 1; t < N; ++t) sum -= SL(S::OFF_M, t * N + i) * x[t];
+      x[i] = sum / SL(S::OFF_M, i * N + i);
+    }
+  };
+  double qacc0[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) qacc0[i] = rhs[i];
+  chol_solve(qacc0);
+
+  // ---- constraint rows: contacts (distal geoms first, p1 then p2), then joint limits
+  int nr = 0;
+  double rr[MR], rmu[MR], rd[MR], rb_[MR], rk[MR];
+  int rkind[MR];  // 0 normal, 1 tangent, 2 limit
+  auto add_row = [&](const double (&jrow)[N], double r, int kind, double mu, double d, double bdamp, double kstiff) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) SL(S::OFF_J, nr * N + i) = jrow[i];
+#pragma unroll
+    for (int t = 0; t < MR; ++t)
+      if (t == nr) { rr[t] = r; rkind[t] = kind; rmu[t] = mu; rd[t] = d; rb_[t] = bdamp; rk[t] = kstiff; }
+    ++nr;
+  };
+  {
+    const double tc = m.c_solref[0], dr = m.c_solref[1], dmax = m.c_solimp[1];
+    const double bdamp = 2.0 / (dmax * tc), kstiff = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+    for (int gi = m.ng - 1; gi >= 0; --gi) {
+      const int b = m.geom_body[gi];
+      double bphi = 0, box = 0, boz = 0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (j == b) { bphi = phi[j]; box = ox[j]; boz = oz[j]; }
+      const double c = cos(bphi), s = sin(bphi), rad = m.grad[gi];
+      for (int e = 0; e < 2; ++e) {
+        const double ex = e == 0 ? m.gp1[gi][0] : m.gp2[gi][0], ez = e == 0 ? m.gp1[gi][1] : m.gp2[gi][1];
+        const double wx = c * ex - s * ez, wz = s * ex + c * ez;
+        const double dist = boz + wz - rad;
+        if (dist < m.margin && nr + 2 <= m.max_rows) {
+          const double px = box + wx, pz = boz + wz - (rad + 0.5 * dist);  // contact point
+          double jn[N], jt[N];
+          jn[0] = 0.0; jn[1] = 1.0; jt[0] = 1.0; jt[1] = 0.0;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const bool anc = (m.ancmask[b] >> j) & 1;
+            const double sg = anc ? m.jsign[j] : 0.0;
+            jn[2 + j] = sg * (px - ox[j]); jt[2 + j] = -sg * (pz - oz[j]);
+          }
+          const double d = impedance_d(fabs(dist), m.c_solimp);
+          add_row(jn, dist, 0, m.gfric[gi], d, bdamp, kstiff);
+          add_row(jt, 0.0, 1, m.gfric[gi], d, bdamp, kstiff);
+        }
+      }
+    }
+  }
+  {
+    const double tc = m.l_solref[0], dr = m.l_solref[1], dmax = m.l_solimp[1];
+    const double bdamp = 2.0 / (dmax * tc), kstiff = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!m.limited[b] || nr + 1 > m.max_rows) continue;
+      const double lo = m.range[b][0], hi = m.range[b][1], qq = q[2 + b];
+      double r = 0.0, sgn = 0.0;
+      if (qq - lo < 0.0) { r = qq - lo; sgn = 1.0; }
+      else if (hi - qq < 0.0) { r = hi - qq; sgn = -1.0; }
+      if (sgn != 0.0) {
+        double je[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) je[i] = (i == 2 + b) ? sgn : 0.0;
+        add_row(je, r, 2, 0.0, impedance_d(fabs(r), m.l_solimp), bdamp, kstiff);
+      }
+    }
+  }
+  if (nr == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) qacc[i] = qacc0[i];
+    return;
+  }
+  // ---- Y = M^-1 J^T, A = J Y, PGS on (A + R) f = aref - J qacc0
+  double rhs_c[MR], Rd[MR], f[MR];
+  for (int r = 0; r < nr; ++r) {
+    double x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = SL(S::OFF_J, r * N + i);
+    double jv = 0.0, ja = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { jv += x[i] * v[i]; ja += x[i] * qacc0[i]; }
+    chol_solve(x);
+#pragma unroll
+    for (int i = 0; i < N; ++i) SL(S::OFF_Y, i * MR + r) = x[i];
+#pragma unroll
+    for (int t = 0; t < MR; ++t)
+      if (t == r) { rhs_c[t] = (-rb_[t] * jv - rk[t] * rd[t] * rr[t]) - ja; f[t] = 0.0; }
+  }
+  for (int r = 0; r < nr; ++r)
+    for (int c2 = 0; c2 < nr; ++c2) {
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sum += SL(S::OFF_J, r * N + i) * SL(S::OFF_Y, i * MR + c2);
+      SL(S::OFF_A, r * MR + c2) = sum;
+    }
+#pragma unroll
+  for (int t = 0; t < MR; ++t)
+    if (t < nr) Rd[t] = (1.0 - rd[t]) / rd[t] * SL(S::OFF_A, t * MR + t);
+  for (int it = 0; it < m.pgs_iters; ++it) {
+#pragma unroll
+    for (int t = 0; t < MR; ++t) {
+      if (t >= nr) continue;
+      const double aii = SL(S::OFF_A, t * MR + t);
+      double res = rhs_c[t] + aii * f[t];
+#pragma unroll
+      for (int u = 0; u < MR; ++u)
+        if (u < nr) res -= SL(S::OFF_A, t * MR + u) * f[u];
+      double fi = res / (aii + Rd[t]);
+      if (rkind[t] == 1) {
+        const double lim = rmu[t] * f[t > 0 ? t - 1 : 0];
+        fi = fmin(fmax(fi, -lim), lim);
+      } else {
+        fi = fmax(fi, 0.0);
+      }
+      f[t] = fi;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double sum = qacc0[i];
+#pragma unroll
+    for (int t = 0; t < MR; ++t)
+      if (t < nr) sum += SL(S::OFF_Y, i * MR + t) * f[t];
+    qacc[i] = sum;
+  }
+}
+
+template <int NB, int MR, int BLOCK>
+__device__ void env_substep(const PlanarModelDev& m, double (&q)[NB + 2], double (&v)[NB + 2], const double* ctrl,
+                            double* sm, int lane_in_block) {
+  constexpr int N = NB + 2;
+  const double h = m.timestep;
+  double a1[N], a2[N], a3[N], a4[N], q2[N], v2[N], q3[N], v3[N], q4[N], v4[N];
+  env_dynamics<NB, MR, BLOCK>(m, q, v, ctrl, a1, sm, lane_in_block);
+#pragma unroll
+  for (int i = 0; i < N; ++i) { q2[i] = q[i] + 0.5 * h * v[i]; v2[i] = v[i] + 0.5 * h * a1[i]; }
+  env_dynamics<NB, MR, BLOCK>(m, q2, v2, ctrl, a2, sm, lane_in_block);
+#pragma unroll
+  for (int i = 0; i < N; ++i) { q3[i] = q[i] + 0.5 * h * v2[i]; v3[i] = v[i] + 0.5 * h * a2[i]; }
+  env_dynamics<NB, MR, BLOCK>(m, q3, v3, ctrl, a3, sm, lane_in_block);
+#pragma unroll
+  for (int i = 0; i < N; ++i) { q4[i] = q[i] + h * v3[i]; v4[i] = v[i] + h * a3[i]; }
+  env_dynamics<NB, MR, BLOCK>(m, q4, v4, ctrl, a4, sm, lane_in_block);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double qn = q[i] + h / 6.0 * (v[i] + 2.0 * v2[i] + 2.0 * v3[i] + v4[i]);
+    const double vn = v[i] + h / 6.0 * (a1[i] + 2.0 * a2[i] + 2.0 * a3[i] + a4[i]);
+    q[i] = qn; v[i] = vn;
+  }
+}
+
+struct EnvStepArgs {
+  const PlanarModelDev* m;
+  double *qpos, *qvel;
+  int n_env;
+  const int* ids;         // nullable: step only these envs (compact i/o indexing)
+  int n_ids;
+  const float* act;       // [n_ids][a]
+  float *obs, *rew;       // [n_ids][o], [n_ids]   (obs = observation AFTER the step, pre-reset)
+  unsigned char* done;    // [n_ids]
+  // fused-rollout extras (all nullable / 0)
+  float* obs_cur;         // [n_env][o]: the policy's next input (post auto-reset)
+  int auto_reset, max_path_length;
+  int* ep_len; double* ep_ret; double* stats;
+  float* replay; int rec; long long cap, top;   // transition record written at slot (top + env) % cap
+  uint64_t seed; uint32_t stream; unsigned long long step;
+};
+
+template <int NB>
+__device__ __forceinline__ void env_write_obs(const double (&q)[NB + 2], const double (&v)[NB + 2], float* dst) {
+  constexpr int N = NB + 2;
+#pragma unroll
+  for (int i = 1; i < N; ++i) dst[i - 1] = (float)q[i];                       // qpos[1:]   (hopper.py:29-30)
+#pragma unroll
+  for (int i = 0; i < N; ++i) dst[N - 1 + i] = (float)fmin(fmax(v[i], -10.0), 10.0);  // clip(qvel, +-10)
+}
+
+__device__ __forceinline__ double env_uniform(uint64_t seed, uint32_t stream, unsigned long long step, uint32_t env,
+                                              uint32_t k) {
+  uint32_t c[4] = {env, k >> 2, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream * 0x9E3779B9u)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
+  return ((double)c[k & 3] + 0.5) * (1.0 / 4294967296.0);
+}
+
+template <int NB>
+__device__ __forceinline__ void env_reset_state(const PlanarModelDev& m, uint64_t seed, uint32_t stream,
+                                                unsigned long long step, uint32_t env, double (&q)[NB + 2],
+                                                double (&v)[NB + 2]) {
+  constexpr int N = NB + 2;  // hopper.py:32-40: init + U(+-reset_noise) on qpos and qvel
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    q[i] = m.init_qpos[i] + m.reset_noise * (2.0 * env_uniform(seed, stream, step, env, i) - 1.0);
+    v[i] = m.reset_noise * (2.0 * env_uniform(seed, stream, step, env, N + i) - 1.0);
+  }
+}
+
+template <int NB, int MR, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
+  constexpr int N = NB + 2;
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  const PlanarModelDev& m = *A.m;
+  const int lane_in_block = threadIdx.x;
+  const int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= A.n_ids) return;
+  const int env = A.ids ? A.ids[t] : t;
+  const int o = m.obs_dim, na = m.n_act;
+  double q[N], v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { q[i] = A.qpos[(size_t)i * A.n_env + env]; v[i] = A.qvel[(size_t)i * A.n_env + env]; }
+  double ctrl[ENV_MAXB];
+  double ctrl_sq = 0.0;
+  for (int k = 0; k < na; ++k) {  // NormalizedBoxEnv: lb + (a+1)/2*(ub-lb), clip; ctrlrange is [-1,1] (wrappers.py:343-346)
+    const double a = fmin(fmax((double)A.act[(size_t)t * na + k], -1.0), 1.0);
+    ctrl[k] = a; ctrl_sq += a * a;
+  }
+  float obs_before[2 * N - 1];
+  if (A.replay) env_write_obs<NB>(q, v, obs_before);
+  const double x0 = q[0];
+  for (int s = 0; s < m.frame_skip; ++s) env_substep<NB, MR, BLOCK>(m, q, v, ctrl, smd, lane_in_block);
+  const double dt = m.timestep * m.frame_skip;
+  const double reward = (q[0] - x0) / dt + m.alive - m.ctrl_cost * ctrl_sq;  // hopper.py:16-18
+  bool ok;
+  if (m.task == 0) {  // hopper.py:19-25
+    ok = isfinite(q[0]) && isfinite(q[1]) && q[1] > m.z_min && fabs(q[2]) < m.ang_max;
+#pragma unroll
+    for (int i = 2; i < N; ++i) ok = ok && isfinite(q[i]) && fabs(q[i]) < m.state_max;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ok = ok && isfinite(v[i]) && fabs(v[i]) < m.state_max;
+  } else {            // walker2d.py:17-20
+    ok = q[1] > m.z_min && q[1] < m.z_max && q[2] > -m.ang_max && q[2] < m.ang_max;
+  }
+  const bool done = !ok;
+  float ob[2 * N - 1];
+  env_write_obs<NB>(q, v, ob);
+  if (A.obs) for (int i = 0; i < o; ++i) A.obs[(size_t)t * o + i] = ob[i];
+  if (A.rew) A.rew[t] = (float)reward;
+  if (A.done) A.done[t] = done ? 1 : 0;
+  if (A.replay) {  // fused replay insert: one 128-byte-aligned record per transition
+    long long slot = A.top + env;
+    if (slot >= A.cap) slot -= A.cap;
+    float* rec = A.replay + (size_t)slot * A.rec;
+    for (int i = 0; i < o; ++i) rec[i] = obs_before[i];
+    for (int k = 0; k < na; ++k) rec[o + k] = A.act[(size_t)t * na + k];
+    rec[o + na] = (float)reward;
+    rec[o + na + 1] = done ? 1.0f : 0.0f;
+    for (int i = 0; i < o; ++i) rec[o + na + 2 + i] = ob[i];
+  }
+  if (A.auto_reset) {
+    const int len = A.ep_len[env] + 1;
+    const double ret = A.ep_ret[env] + reward;
+    const bool end = done || len >= A.max_path_length;  // time-limit ends are NOT terminal (base_algorithm.py:264-277)
+    if (end) {
+      atomicAdd(&A.stats[0], 1.0);
+      atomicAdd(&A.stats[1], ret);
+      env_reset_state<NB>(m, A.seed, A.stream, A.step, (uint32_t)env, q, v);
+      env_write_obs<NB>(q, v, ob);
+    }
+    A.ep_len[env] = end ? 0 : len;
+    A.ep_ret[env] = end ? 0.0 : ret;
+  }
+  if (A.obs_cur) for (int i = 0; i < o; ++i) A.obs_cur[(size_t)env * o + i] = ob[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { A.qpos[(size_t)i * A.n_env + env] = q[i]; A.qvel[(size_t)i * A.n_env + env] = v[i]; }
+}
+
+template <int NB>
+__global__ void k_env_reset(const PlanarModelDev* mp, double* qpos, double* qvel, int n_env, const int* ids, int n_ids,
+                            float* obs, float* obs_cur, int* ep_len, double* ep_ret, uint64_t seed, uint32_t stream,
+                            unsigned long long step) {
+  constexpr int N = NB + 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_ids) return;
+  const int env = ids ? ids[t] : t;
+  const PlanarModelDev& m = *mp;
+  double q[N], v[N];
+  env_reset_state<NB>(m, seed, stream, step, (uint32_t)env, q, v);
+  float ob[2 * N - 1];
+  env_write_obs<NB>(q, v, ob);
+  for (int i = 0; i < m.obs_dim; ++i) {
+    if (obs) obs[(size_t)t * m.obs_dim + i] = ob[i];
+    if (obs_cur) obs_cur[(size_t)env * m.obs_dim + i] = ob[i];
+  }
+  ep_len[env] = 0; ep_ret[env] = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { qpos[(size_t)i * n_env + env] = q[i]; qvel[(size_t)i * n_env + env] = v[i]; }
+}
+
+// uniform(-1,1) actions: env.action_space.sample() per env while the replay is short (base_algorithm.py:369-380)
+__global__ void k_random_actions(float* act, int n, uint64_t seed, uint32_t stream, unsigned long long step, int a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * a) return;
+  const int env = t / a, k = t - env * a;
+  act[t] = (float)(2.0 * env_uniform(seed, stream, step, (uint32_t)env, (uint32_t)k) - 1.0);
+}
+
+// ------------------------------------------------------------------------------------------------ host
+template <int NB, int MR, int BLOCK>
+static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
+  using S = EnvScratch<NB, MR, BLOCK>;
+  const size_t lds = (size_t)S::TOTAL * BLOCK * sizeof(double);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_env_step<NB, MR, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  ProfScope ps(e->ctx, ILSX_K_ENV_STEP);
+  hipLaunchKernelGGL((k_env_step<NB, MR, BLOCK>), dim3((A.n_ids + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, e->ctx->stream, A);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
+  if (A.n_ids <= 0) return ILSX_OK;
+  if (e->hm.nb == 4) return launch_env_step_t<4, 8, 64>(e, A);
+  if (e->hm.nb == 7) return launch_env_step_t<7, 12, 32>(e, A);
+  ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "vec-env kernels are instantiated for 4 (Hopper) and 7 (Walker2d) bodies, got %d", e->hm.nb);
+}
+static int launch_env_reset(ilsx_vecenv* e, const int* ids_dev, int n_ids, float* obs) {
+  if (n_ids <= 0) return ILSX_OK;
+  const unsigned long long step = ++e->step_ctr;
+  const dim3 grid((n_ids + 255) / 256), block(256);
+  if (e->hm.nb == 4)
+    hipLaunchKernelGGL(k_env_reset<4>, grid, block, 0, e->ctx->stream, e->dm, e->qpos, e->qvel, e->n_env, ids_dev, n_ids, obs,
+                       e->obs_cur, e->ep_len, e->ep_ret, e->seed, e->rng_stream, step);
+  else
+    hipLaunchKernelGGL(k_env_reset<7>, grid, block, 0, e->ctx->stream, e->dm, e->qpos, e->qvel, e->n_env, ids_dev, n_ids, obs,
+                       e->obs_cur, e->ep_len, e->ep_ret, e->seed, e->rng_stream, step);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* pm, int n_env, uint64_t seed, ilsx_vecenv** out) {
+  if (!ctx || !pm || !out || n_env < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_vecenv_create: bad argument");
+  if (pm->n_body != 4 && pm->n_body != 7)
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "n_body=%d: kernels exist for 4 (Hopper) and 7 (Walker2d) bodies", pm->n_body);
+  if (pm->n_geom < 1 || pm->n_geom > ENV_MAXG) ILSX_FAIL(ILSX_ERR_ARG, "n_geom=%d out of range", pm->n_geom);
+  HIPCHK(hipSetDevice(ctx->device));
+  ilsx_vecenv* e = new ilsx_vecenv();
+  e->ctx = ctx; e->n_env = n_env; e->seed = seed; e->rng_stream = ctx->next_rng_stream++;
+  PlanarModelDev& m = e->hm;
+  memset(&m, 0, sizeof m);
+  m.nb = pm->n_body; m.ng = pm->n_geom; m.task = pm->task; m.frame_skip = pm->frame_skip; m.pgs_iters = pm->pgs_iters;
+  m.max_rows = pm->n_body == 4 ? 8 : 12;
+  int na = 0;
+  for (int b = 0; b < m.nb; ++b) {
+    m.parent[b] = pm->parent[b]; m.limited[b] = pm->limited[b];
+    m.anchor[b][0] = pm->anchor[b][0]; m.anchor[b][1] = pm->anchor[b][1];
+    m.com[b][0] = pm->com[b][0]; m.com[b][1] = pm->com[b][1];
+    m.mass[b] = pm->mass[b]; m.inertia[b] = pm->inertia[b]; m.jsign[b] = pm->jsign[b];
+    m.armature[b] = pm->armature[b]; m.damping[b] = pm->damping[b];
+    m.range[b][0] = pm->range[b][0]; m.range[b][1] = pm->range[b][1]; m.gear[b] = pm->gear[b];
+    if (pm->gear[b] != 0.0) m.act_body[na++] = b;
+    int mask = 0;
+    for (int j = b; j >= 0; j = pm->parent[j]) mask |= 1 << j;
+    m.ancmask[b] = mask;
+    if (b > 0 && (pm->parent[b] < 0 || pm->parent[b] >= b)) { delete e; ILSX_FAIL(ILSX_ERR_ARG, "parent[%d] must precede the body", b); }
+  }
+  m.n_act = na;
+  for (int g = 0; g < m.ng; ++g) {
+    m.geom_body[g] = pm->geom_body[g];
+    m.gp1[g][0] = pm->geom_p1[g][0]; m.gp1[g][1] = pm->geom_p1[g][1];
+    m.gp2[g][0] = pm->geom_p2[g][0]; m.gp2[g][1] = pm->geom_p2[g][1];
+    m.grad[g] = pm->geom_radius[g]; m.gfric[g] = pm->geom_friction[g];
+  }
+  m.timestep = pm->timestep; m.gravity = pm->gravity; m.reset_noise = pm->reset_noise; m.margin = pm->contact_margin;
+  for (int i = 0; i < 2; ++i) { m.c_solref[i] = pm->contact_solref[i]; m.l_solref[i] = pm->limit_solref[i]; }
+  for (int i = 0; i < 3; ++i) { m.c_solimp[i] = pm->contact_solimp[i]; m.l_solimp[i] = pm->limit_solimp[i]; }
+  m.ctrl_cost = pm->ctrl_cost; m.alive = pm->alive_bonus; m.z_min = pm->z_min; m.z_max = pm->z_max;
+  m.ang_max = pm->ang_max; m.state_max = pm->state_max;
+  e->n = m.nb + 2; e->o = 2 * e->n - 1; e->a = na;
+  m.obs_dim = e->o;
+  for (int i = 0; i < e->n; ++i) m.init_qpos[i] = pm->init_qpos[i];
+  const size_t N = (size_t)n_env;
+  int rc = ctx_alloc(ctx, sizeof m, (void**)&e->dm);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->n * 8, (void**)&e->qpos);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->n * 8, (void**)&e->qvel);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->o * 4, (void**)&e->obs_cur);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->a * 4, (void**)&e->act);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->o * 4, (void**)&e->nobs);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->rew);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N, (void**)&e->done);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->ep_len);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 8, (void**)&e->ep_ret);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, 4 * 8, (void**)&e->stats);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->ids);
+  if (rc != ILSX_OK) { delete e; return rc; }
+  HIPCHK(hipMemcpyAsync(e->dm, &m, sizeof m, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ILSX_TRY(launch_env_reset(e, nullptr, n_env, nullptr));
+  *out = e;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_vecenv_destroy(ilsx_vecenv* e) {
+  if (!e) return ILSX_OK;
+  void* ps[] = {e->dm, e->qpos, e->qvel, e->obs_cur, e->act, e->nobs, e->rew, e->done, e->ep_len, e->ep_ret, e->stats, e->ids};
+  for (void* p : ps) ctx_free(e->ctx, p);
+  delete e;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_vecenv_dims(const ilsx_vecenv* e, int* obs_dim, int* act_dim, int* n_dof, int* n_env) {
+  if (!e) ILSX_FAIL(ILSX_ERR_ARG, "env is NULL");
+  if (obs_dim) *obs_dim = e->o;
+  if (act_dim) *act_dim = e->a;
+  if (n_dof) *n_dof = e->n;
+  if (n_env) *n_env = e->n_env;
+  return ILSX_OK;
+}
+
+static int env_upload_ids(ilsx_vecenv* e, const int32_t* ids_host, int n_ids, const int** dev) {
+  *dev = nullptr;
+  if (!ids_host) return ILSX_OK;
+  for (int i = 0; i < n_ids; ++i)
+    if (ids_host[i] < 0 || ids_host[i] >= e->n_env) ILSX_FAIL(ILSX_ERR_ARG, "env id %d out of range", ids_host[i]);
+  HIPCHK(hipMemcpyAsync(e->ids, ids_host, (size_t)n_ids * 4, hipMemcpyHostToDevice, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  *dev = e->ids;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_vecenv_reset(ilsx_vecenv* e, const int32_t* ids_host, int n_ids, float* obs) {
+  if (!e) ILSX_FAIL(ILSX_ERR_ARG, "env is NULL");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  if (!ids_host) n_ids = e->n_env;
+  if (n_ids < 0 || n_ids > e->n_env) ILSX_FAIL(ILSX_ERR_ARG, "n_ids=%d out of range", n_ids);
+  const int* dev = nullptr;
+  ILSX_TRY(env_upload_ids(e, ids_host, n_ids, &dev));
+  return launch_env_reset(e, dev, n_ids, obs);
+}
+
+extern "C" int ilsx_vecenv_step(ilsx_vecenv* e, const float* act, const int32_t* ids_host, int n_ids, float* obs,
+                                float* rew, uint8_t* done) {
+  if (!e || !act) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_vecenv_step: NULL argument");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  if (!ids_host) n_ids = e->n_env;
+  if (n_ids < 0 || n_ids > e->n_env) ILSX_FAIL(ILSX_ERR_ARG, "n_ids=%d out of range", n_ids);
+  const int* dev = nullptr;
+  ILSX_TRY(env_upload_ids(e, ids_host, n_ids, &dev));
+  EnvStepArgs A;
+  memset(&A, 0, sizeof A);
+  A.m = e->dm; A.qpos = e->qpos; A.qvel = e->qvel; A.n_env = e->n_env;
+  A.ids = dev; A.n_ids = n_ids; A.act = act; A.obs = obs; A.rew = rew; A.done = done;
+  A.obs_cur = e->obs_cur;
+  return launch_env_step(e, A);
+}
+
+extern "C" int ilsx_vecenv_get_state(ilsx_vecenv* e, double* qpos_host, double* qvel_host) {
+  if (!e || !qpos_host || !qvel_host) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  const size_t N = e->n_env, n = e->n;
+  std::vector<double> tq(N * n), tv(N * n);
+  HIPCHK(hipMemcpyAsync(tq.data(), e->qpos, N * n * 8, hipMemcpyDeviceToHost, e->ctx->stream));
+  HIPCHK(hipMemcpyAsync(tv.data(), e->qvel, N * n * 8, hipMemcpyDeviceToHost, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < N; ++j) { qpos_host[j * n + i] = tq[i * N + j]; qvel_host[j * n + i] = tv[i * N + j]; }
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_vecenv_set_state(ilsx_vecenv* e, const double* qpos_host, const double* qvel_host) {
+  if (!e || !qpos_host || !qvel_host) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  const size_t N = e->n_env, n = e->n;
+  std::vector<double> tq(N * n), tv(N * n);
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < N; ++j) { tq[i * N + j] = qpos_host[j * n + i]; tv[i * N + j] = qvel_host[j * n + i]; }
+  HIPCHK(hipMemcpyAsync(e->qpos, tq.data(), N * n * 8, hipMemcpyHostToDevice, e->ctx->stream));
+  HIPCHK(hipMemcpyAsync(e->qvel, tv.data(), N * n * 8, hipMemcpyHostToDevice, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_vecenv_cur_obs(ilsx_vecenv* e, float** dev_ptr) {
+  if (!e || !dev_ptr) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  *dev_ptr = e->obs_cur;
+  return ILSX_OK;
+}
+
+// One iteration of BaseAlgorithm's sampling loop (base_algorithm.py:183-277) for ALL envs, on the device:
+// actions (policy or uniform random) -> physics -> transition record into the replay ring -> auto-reset.
+extern "C" int ilsx_rollout_step(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
+                                 int deterministic) {
+  if (!e || (!pi && !random_actions)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_step: need a policy or random_actions");
+  ilsx_ctx* ctx = e->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (rb && (rb->o != e->o || rb->a != e->a)) ILSX_FAIL(ILSX_ERR_ARG, "replay dims (%d,%d) != env dims (%d,%d)", rb->o, rb->a, e->o, e->a);
+  if (rb && e->n_env > rb->cap) ILSX_FAIL(ILSX_ERR_ARG, "n_env exceeds the replay capacity");
+  const unsigned long long step = ++e->step_ctr;
+  if (random_actions) {
+    const int tot = e->n_env * e->a;
+    hipLaunchKernelGGL(k_random_actions, dim3((tot + 255) / 256), dim3(256), 0, ctx->stream, e->act, e->n_env, e->seed,
+                       e->rng_stream ^ 0x5A5A5A5Au, step, e->a);
+    HIPCHK(hipGetLastError());
+  } else {
+    ILSX_TRY(ilsx_policy_act(pi, e->obs_cur, e->n_env, deterministic, nullptr, e->act, nullptr));
+  }
+  EnvStepArgs A;
+  memset(&A, 0, sizeof A);
+  A.m = e->dm; A.qpos = e->qpos; A.qvel = e->qvel; A.n_env = e->n_env;
+  A.ids = nullptr; A.n_ids = e->n_env; A.act = e->act;
+  A.obs = e->nobs; A.rew = e->rew; A.done = e->done;
+  A.obs_cur = e->obs_cur; A.auto_reset = 1; A.max_path_length = max_path_length;
+  A.ep_len = e->ep_len; A.ep_ret = e->ep_ret; A.stats = e->stats;
+  if (rb) { A.replay = rb->data; A.rec = rb->rec; A.cap = rb->cap; A.top = rb->top; }
+  A.seed = e->seed; A.stream = e->rng_stream; A.step = step;
+  ILSX_TRY(launch_env_step(e, A));
+  if (rb) ILSX_TRY(replay_advance_device_rows(rb, e->n_env));
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_rollout_stats(ilsx_vecenv* e, double* episodes, double* return_sum, int reset) {
+  if (!e) ILSX_FAIL(ILSX_ERR_ARG, "env is NULL");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  double h[4];
+  HIPCHK(hipMemcpyAsync(h, e->stats, sizeof h, hipMemcpyDeviceToHost, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  if (episodes) *episodes = h[0];
+  if (return_sum) *return_sum = h[1];
+  if (reset) HIPCHK(hipMemsetAsync(e->stats, 0, sizeof h, e->ctx->stream));
+  return ILSX_OK;
+}

@@ -189,6 +189,14 @@ extern "C" int ilsx_replay_add(ilsx_replay* rb, const float* obs, const float* a
   return replay_push_state(rb);
 }
 
+int replay_advance_device_rows(ilsx_replay* rb, int n) {
+  // rows inserted by the fused rollout kernel carry no trajectory bookkeeping of their own (SAC samples
+  // uniformly over rows, simple_replay_buffer.py:242); overwritten trajectory starts are still dropped.
+  for (int i = 0; i < n; ++i) host_advance(rb);
+  rb->cur_start = rb->top;
+  return replay_push_state(rb);
+}
+
 extern "C" int ilsx_replay_terminate_episode(ilsx_replay* rb) {
   if (!rb) ILSX_FAIL(ILSX_ERR_ARG, "replay is NULL");
   host_terminate(rb);

@@ -1,0 +1,131 @@
+"""HipVectorEnv — the reference's BaseVectorEnv protocol (rlkit/envs/vecenvs.py:63-369: `len(env)`,
+`reset(id)`, `step(action, id)`, `seed`, list-valued `action_space` / `observation_space`) over the HIP
+batched stepper of libilsx, plus the env factory `get_envs` (rlkit/envs/__init__.py:72-132).
+
+Differences a caller can observe are listed in DESIGN.md: physics is this repo's planar engine, not
+MuJoCo; env i is seeded `seed + i` through a counter-based generator instead of gym's np_random.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..device import as_dev, get_context
+from .models import MODELS
+
+
+class Box:  # minimal gym.spaces.Box stand-in (gym is not installed here)
+    def __init__(self, low, high):
+        self.low, self.high = np.asarray(low, np.float32), np.asarray(high, np.float32)
+        self.shape, self.dtype = self.low.shape, np.float32
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(np.float32)
+
+
+def model_struct(m):
+    s = _lib.PlanarModel()
+    s.task, s.n_body, s.n_geom, s.frame_skip, s.pgs_iters = m["task"], m["n_body"], m["n_geom"], m["frame_skip"], m["pgs_iters"]
+    for b in range(m["n_body"]):
+        s.parent[b], s.limited[b] = m["parent"][b], m["limited"][b]
+        for k in (0, 1):
+            s.anchor[b][k], s.com[b][k], s.range[b][k] = m["anchor"][b][k], m["com"][b][k], m["range"][b][k]
+        s.mass[b], s.inertia[b], s.jsign[b] = m["mass"][b], m["inertia"][b], m["jsign"][b]
+        s.armature[b], s.damping[b], s.gear[b] = m["armature"][b], m["damping"][b], m["gear"][b]
+    for g in range(m["n_geom"]):
+        s.geom_body[g] = m["geom_body"][g]
+        for k in (0, 1):
+            s.geom_p1[g][k], s.geom_p2[g][k] = m["geom_p1"][g][k], m["geom_p2"][g][k]
+        s.geom_radius[g], s.geom_friction[g] = m["geom_radius"][g], m["geom_friction"][g]
+    s.timestep, s.gravity, s.reset_noise, s.contact_margin = m["timestep"], m["gravity"], m["reset_noise"], m["contact_margin"]
+    for k in (0, 1):
+        s.contact_solref[k], s.limit_solref[k] = m["contact_solref"][k], m["limit_solref"][k]
+    for k in (0, 1, 2):
+        s.contact_solimp[k], s.limit_solimp[k] = m["contact_solimp"][k], m["limit_solimp"][k]
+    hl = m["healthy"]
+    s.ctrl_cost, s.alive_bonus = m["ctrl_cost"], m["alive_bonus"]
+    s.z_min, s.z_max, s.ang_max, s.state_max = hl["z_min"], hl["z_max"], hl["ang"], hl["state"]
+    for i, v in enumerate(m["init_qpos"]):
+        s.init_qpos[i] = v
+    return s
+
+
+class HipVectorEnv:
+    def __init__(self, env_name, env_num, seed=0, ctx=None, model=None):
+        self.ctx = ctx or get_context()
+        self.model = model or MODELS[env_name]()
+        self.env_num = int(env_num)
+        self.h = C.c_void_p()
+        ms = model_struct(self.model)
+        _lib.check(self.ctx.lib.ilsx_vecenv_create(self.ctx.h, C.byref(ms), self.env_num, C.c_uint64(seed), C.byref(self.h)))
+        o, a, n, ne = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self.ctx.lib.ilsx_vecenv_dims(self.h, C.byref(o), C.byref(a), C.byref(n), C.byref(ne)))
+        self.obs_dim, self.act_dim, self.n_dof = o.value, a.value, n.value
+        ob = Box(-np.inf * np.ones(self.obs_dim), np.inf * np.ones(self.obs_dim))
+        ac = Box(-np.ones(self.act_dim), np.ones(self.act_dim))
+        self.observation_space, self.action_space = [ob] * self.env_num, [ac] * self.env_num  # vecenvs.py:118-140
+        self.single_observation_space, self.single_action_space = ob, ac
+        self.norm_obs, self.obs_rms, self.update_obs_rms = False, None, False
+
+    def __len__(self):
+        return self.env_num
+
+    def seed(self, seed=None):  # vecenvs.py:259-277 (seed + i per env is the Philox key + env index here)
+        return [seed] * self.env_num
+
+    def _ids(self, id):
+        if id is None:
+            return None, self.env_num
+        ids = np.ascontiguousarray(np.atleast_1d(id), np.int32)
+        return ids, ids.size
+
+    def reset(self, id=None):
+        ids, n = self._ids(id)
+        obs = self.ctx.empty((n, self.obs_dim))
+        _lib.check(self.ctx.lib.ilsx_vecenv_reset(self.h, ids.ctypes.data_as(C.c_void_p) if ids is not None else None, n, obs.ptr))
+        return obs.numpy().astype(np.float64)
+
+    def step(self, action, id=None):
+        ids, n = self._ids(id)
+        action = np.ascontiguousarray(action, np.float32).reshape(n, self.act_dim)  # sync mode: len(action) == len(id)
+        k, pa = as_dev(self.ctx, action)
+        obs, rew, done = self.ctx.empty((n, self.obs_dim)), self.ctx.empty((n,)), self.ctx.empty((n,), np.uint8)
+        _lib.check(self.ctx.lib.ilsx_vecenv_step(self.h, pa, ids.ctypes.data_as(C.c_void_p) if ids is not None else None, n,
+                                                 obs.ptr, rew.ptr, done.ptr))
+        env_ids = ids if ids is not None else np.arange(n)
+        infos = [{"env_id": int(i)} for i in env_ids]  # vecenvs.py:217-219
+        return obs.numpy().astype(np.float64), rew.numpy().astype(np.float64), done.numpy().astype(bool), infos
+
+    # ---- simulator state (tests, snapshots)
+    def get_state(self):
+        q = np.empty((self.env_num, self.n_dof)); v = np.empty((self.env_num, self.n_dof))
+        _lib.check(self.ctx.lib.ilsx_vecenv_get_state(self.h, q.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+        return q, v
+
+    def set_state(self, qpos, qvel):
+        q, v = np.ascontiguousarray(qpos, np.float64), np.ascontiguousarray(qvel, np.float64)
+        assert q.shape == (self.env_num, self.n_dof) and v.shape == q.shape
+        _lib.check(self.ctx.lib.ilsx_vecenv_set_state(self.h, q.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+
+    # ---- fused device loop (BaseAlgorithm's sampling iteration, base_algorithm.py:183-277)
+    def rollout_step(self, policy=None, replay=None, max_path_length=1000, random_actions=False, deterministic=False):
+        _lib.check(self.ctx.lib.ilsx_rollout_step(self.h, policy.h if policy is not None else None,
+                                                  replay.h if replay is not None else None, int(max_path_length),
+                                                  int(bool(random_actions)), int(bool(deterministic))))
+
+    def rollout_stats(self, reset=True):
+        e, r = C.c_double(), C.c_double()
+        _lib.check(self.ctx.lib.ilsx_rollout_stats(self.h, C.byref(e), C.byref(r), int(reset)))
+        return e.value, r.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.ilsx_vecenv_destroy(self.h)
+            self.h = None
+
+
+def get_envs(env_specs, env_wrapper=None, wrapper_kwargs=None, ctx=None, **kwargs):
+    """rlkit/envs/__init__.py:72-132: env_specs{env_name, env_num, training_env_seed, ...} -> vec env.
+    NormalizedBoxEnv (the only wrapper on the hot path) is folded into the stepper."""
+    return HipVectorEnv(env_specs["env_name"], env_specs.get("env_num", 1),
+                        seed=env_specs.get("training_env_seed", env_specs.get("seed", 0)), ctx=ctx)

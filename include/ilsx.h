@@ -193,6 +193,53 @@ int ilsx_sac_set_adam(ilsx_sac* sac, int which, const float* m_host, const float
 int ilsx_sac_get_alpha_opt(ilsx_sac* sac, double* m, double* v, int64_t* t, uint64_t* rng_step);
 int ilsx_sac_set_alpha_opt(ilsx_sac* sac, double m, double v, int64_t t, uint64_t rng_step);
 
+/* ---------------------------------------------------------------- vectorised env stepper
+ * Replaces the reference's vec-env path: rlkit/envs/vecenvs.py:158-257 (BaseVectorEnv.reset/step),
+ * rlkit/envs/worker/subproc.py:59-113 (process + pipe per env), rlkit/envs/wrappers.py:342-352
+ * (NormalizedBoxEnv action map + clip) and the MuJoCo step under gym's HopperEnv / Walker2dEnv, whose
+ * reward / termination / reset rules are restated in rlkit/envs/mujoco/hopper.py:11-40, walker2d.py:11-36.
+ * The dynamics model is a planar articulated-body engine (body 0: slide-x, slide-z, hinge; every other body
+ * one hinge; capsule-vs-floor soft contacts + soft joint limits solved by PGS; RK4).  Model constants come
+ * from the caller (ilswiss_amd/envs/models.py); physics parity with MuJoCo is UNPINNED. */
+#define ILSX_ENV_MAX_BODY 8
+#define ILSX_ENV_MAX_GEOM 8
+enum { ILSX_TASK_HOPPER = 0, ILSX_TASK_WALKER2D = 1 };
+typedef struct {
+  int32_t task, n_body, n_geom, frame_skip, pgs_iters, pad0;
+  int32_t parent[ILSX_ENV_MAX_BODY], limited[ILSX_ENV_MAX_BODY], geom_body[ILSX_ENV_MAX_GEOM];
+  double anchor[ILSX_ENV_MAX_BODY][2];   /* hinge position in the parent's frame */
+  double com[ILSX_ENV_MAX_BODY][2];      /* centre of mass in the body frame */
+  double mass[ILSX_ENV_MAX_BODY], inertia[ILSX_ENV_MAX_BODY], jsign[ILSX_ENV_MAX_BODY];
+  double armature[ILSX_ENV_MAX_BODY], damping[ILSX_ENV_MAX_BODY], range[ILSX_ENV_MAX_BODY][2], gear[ILSX_ENV_MAX_BODY];
+  double geom_p1[ILSX_ENV_MAX_GEOM][2], geom_p2[ILSX_ENV_MAX_GEOM][2], geom_radius[ILSX_ENV_MAX_GEOM],
+      geom_friction[ILSX_ENV_MAX_GEOM];  /* capsule end points (body frame), radius, sliding friction */
+  double timestep, gravity, reset_noise, contact_margin;
+  double contact_solref[2], contact_solimp[3], limit_solref[2], limit_solimp[3];
+  double ctrl_cost, alive_bonus, z_min, z_max, ang_max, state_max;
+  double init_qpos[ILSX_ENV_MAX_BODY + 2];
+} ilsx_planar_model;
+
+int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* model, int n_env, uint64_t seed, ilsx_vecenv** out);
+int ilsx_vecenv_destroy(ilsx_vecenv* env);
+int ilsx_vecenv_dims(const ilsx_vecenv* env, int* obs_dim, int* act_dim, int* n_dof, int* n_env);
+/* BaseVectorEnv.reset(id) (vecenvs.py:158-181): ids_host = NULL resets all; obs (device, nullable) [n_ids,o]. */
+int ilsx_vecenv_reset(ilsx_vecenv* env, const int32_t* ids_host, int n_ids, float* obs);
+/* BaseVectorEnv.step(action, id) (vecenvs.py:183-257), sync mode: act[n_ids,a] -> obs[n_ids,o], rew[n_ids],
+ * done[n_ids] (all device; outputs nullable).  No auto-reset (the caller resets finished ids, like the reference). */
+int ilsx_vecenv_step(ilsx_vecenv* env, const float* act, const int32_t* ids_host, int n_ids, float* obs, float* rew,
+                     uint8_t* done);
+/* simulator state, HOST float64 [n_env, n_dof] (tests / snapshots) */
+int ilsx_vecenv_get_state(ilsx_vecenv* env, double* qpos_host, double* qvel_host);
+int ilsx_vecenv_set_state(ilsx_vecenv* env, const double* qpos_host, const double* qvel_host);
+int ilsx_vecenv_cur_obs(ilsx_vecenv* env, float** dev_ptr);  /* [n_env,o] current observations (device) */
+/* One iteration of BaseAlgorithm's sampling loop for ALL envs on the device (base_algorithm.py:183-277):
+ * actions (policy, or env.action_space.sample() when random_actions) -> physics -> one transition record per
+ * env written straight into the replay ring (nullable) -> auto-reset on done or max_path_length. */
+int ilsx_rollout_step(ilsx_vecenv* env, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
+                      int deterministic);
+/* finished episodes and the sum of their returns since the last reset of the counters */
+int ilsx_rollout_stats(ilsx_vecenv* env, double* episodes, double* return_sum, int reset);
+
 #ifdef __cplusplus
 }
 #endif

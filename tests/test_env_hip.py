@@ -1,0 +1,93 @@
+"""GPU suite: k_env_step / k_env_reset / the fused rollout step against the CPU oracle (float64)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(ctx, name, n, seed=3):
+    from ilswiss_amd.envs.vecenv import HipVectorEnv
+    return HipVectorEnv(name, n, seed=seed, ctx=ctx)
+
+
+@pytest.mark.parametrize("name", ["hopper", "walker"])
+def test_step_matches_oracle(ctx, name):
+    from oracle.planar_env import PlanarOracle
+    env = _mk(ctx, name, 96)
+    P = PlanarOracle(env.model)
+    n, nd, na = 96, env.n_dof, env.act_dim
+    rng = np.random.default_rng(7)
+    obs0 = env.reset()
+    q, v = env.get_state()
+    # reset noise: init + U(+-0.005) on qpos/qvel (hopper.py:32-40), obs = qpos[1:] + clip(qvel)
+    assert np.all(np.abs(q - np.asarray(env.model["init_qpos"])) <= 0.005) and np.all(np.abs(v) <= 0.005)
+    np.testing.assert_allclose(obs0, np.concatenate([q[:, 1:], v], 1), atol=1e-6)
+    assert len(np.unique(q[:, 1])) == n  # every env gets its own noise
+    # spread the states: some airborne, some in deep contact, some beyond joint limits, some already unhealthy
+    q[:, 1] += rng.uniform(-0.05, 0.6, n)
+    q[:, 2] += rng.uniform(-0.25, 0.25, n)
+    q[:, 3:] += rng.uniform(-1.0, 0.4, (n, nd - 3))
+    v += rng.normal(0, 1.5, (n, nd))
+    env.set_state(q, v)
+    for it in range(4):
+        act = rng.uniform(-1.4, 1.4, (n, na)).astype(np.float32)
+        obs, rew, done, info = env.step(act)
+        q1, v1 = env.get_state()
+        for i in range(n):
+            qo, vo, oo, ro, do = P.step(q[i].copy(), v[i].copy(), act[i])
+            np.testing.assert_allclose(q1[i], qo, rtol=1e-8, atol=1e-9, err_msg=f"qpos env {i} it {it}")
+            np.testing.assert_allclose(v1[i], vo, rtol=1e-7, atol=1e-7, err_msg=f"qvel env {i} it {it}")
+            np.testing.assert_allclose(obs[i], oo, rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(rew[i], ro, rtol=1e-5, atol=1e-4)
+            assert bool(done[i]) == bool(do), (i, it)
+        assert info[5]["env_id"] == 5
+        q, v = q1, v1
+    assert not done.all() and (done.any() or name != "hopper")  # walker's healthy band is wide (walker2d.py:17-20)
+    env.close()
+
+
+def test_subset_step_and_reset(ctx):
+    env = _mk(ctx, "hopper", 32)
+    env.reset()
+    q0, v0 = env.get_state()
+    ids = np.array([3, 17, 30])
+    act = np.zeros((3, 3), np.float32)
+    obs, rew, done, info = env.step(act, ids)
+    q1, v1 = env.get_state()
+    moved = np.any(q1 != q0, axis=1)
+    assert moved[ids].all() and not np.delete(moved, ids).any()
+    assert [i["env_id"] for i in info] == [3, 17, 30] and obs.shape == (3, 11)
+    ob = env.reset(ids[:2])
+    q2, _ = env.get_state()
+    assert np.all(q2[30] == q1[30]) and np.all(q2[3] != q1[3]) and ob.shape == (2, 11)
+    env.close()
+
+
+def test_rollout_step_fills_replay_and_auto_resets(ctx):
+    import ilswiss_amd as ia
+    n = 256
+    env = _mk(ctx, "hopper", n, seed=5)
+    rb = ia.SimpleReplayBuffer(10 * n, 11, 3, ctx=ctx)
+    pol = ia.ReparamTanhMultivariateGaussianPolicy([64, 64], 11, 3, ctx=ctx, seed=1)
+    steps = 40
+    for t in range(steps):
+        env.rollout_step(policy=pol if t % 2 else None, replay=rb, max_path_length=25, random_actions=(t % 2 == 0))
+        if t < 10:
+            assert rb.num_steps_can_sample() == min((t + 1) * n, 10 * n)
+    assert rb._size == 10 * n and rb._top == (steps * n) % (10 * n)
+    episodes, ret_sum = env.rollout_stats()
+    assert episodes >= n  # every env hit the 25-step limit or fell at least once
+    assert 3.0 < ret_sum / episodes < 40.0
+    b = rb._get_batch_using_indices(np.arange(10 * n))
+    assert np.all(np.abs(b["actions"]) <= 1.0) and np.isfinite(b["observations"]).all()
+    term = b["terminals"].ravel().astype(bool)
+    assert 0 < term.sum() < term.size
+    # healthy transitions keep z > 0.7 and |angle| < 0.2 in next_obs; terminal ones violate it (hopper.py:19-25)
+    nz, nang = b["next_observations"][:, 0], b["next_observations"][:, 1]
+    healthy = (nz > 0.7) & (np.abs(nang) < 0.2) & (np.abs(b["next_observations"][:, 1:]) < 100).all(1)
+    assert np.array_equal(healthy, ~term)
+    # reward formula on stored transitions: alive + forward progress - ctrl cost; |r| is O(1)
+    assert np.abs(b["rewards"]).max() < 30
+    q, v = env.get_state()
+    assert np.isfinite(q).all() and (q[:, 1] > 0.5).all()
+    env.close()

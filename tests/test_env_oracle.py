@@ -1,0 +1,102 @@
+"""CPU suite for the planar-engine oracle: physics invariants + the in-tree reward/termination formulas.
+(No MuJoCo exists here: dynamics parity with the reference is unpinned; these are the checks we do have.)"""
+import copy
+
+import numpy as np
+
+from ilswiss_amd.envs.models import hopper, walker2d
+from oracle.planar_env import PlanarOracle
+
+
+def test_body_masses_match_mujoco_hopper():
+    m = hopper()
+    # model.body_mass of gym's Hopper-v2 under MuJoCo 2.x: 3.5343, 3.9270, 2.7143, 5.0894 (total 15.265 kg)
+    np.testing.assert_allclose(m["mass"], [3.53429174, 3.92699082, 2.71433605, 5.0893801], rtol=1e-6)
+    assert m["obs_dim"] == 11 and m["act_dim"] == 3
+    w = walker2d()
+    assert w["obs_dim"] == 17 and w["act_dim"] == 6 and w["n_body"] == 7
+
+
+def test_energy_conserved_in_free_flight():
+    for mk in (hopper, walker2d):
+        m = copy.deepcopy(mk())
+        nb = m["n_body"]
+        m["damping"], m["limited"] = [0.0] * nb, [0] * nb
+        P = PlanarOracle(m)
+        rng = np.random.default_rng(1)
+        q = np.concatenate([[0.0, 3.0, 0.1], rng.uniform(-0.6, 0.0, nb - 1)])
+        v = rng.normal(0, 1, nb + 2)
+        e0 = P.energy(q, v)
+        px0 = None
+        for _ in range(100):
+            q, v = P.substep(q, v, np.zeros(m["act_dim"]))
+        assert abs(P.energy(q, v) - e0) < 1e-8 * abs(e0)
+
+
+def test_momentum_and_gravity_in_free_flight():
+    m = hopper()
+    P = PlanarOracle(m)
+    q = np.array([0.0, 5.0, 0.0, -0.3, -0.3, 0.1]); v = np.zeros(6)
+    a = P.dynamics(q, v, np.zeros(3))
+    # total generalized force on the root translation = M_total * g
+    phi, phid, Jphi, o, Jo, ao = P.kin(q, v)
+    assert abs(a[0]) < 1e-9  # no horizontal force
+    # centre of mass accelerates at -g: integrate a short free fall and check the COM height
+    mass = np.array(m["mass"])
+
+    def com_z(q):
+        from oracle.planar_env import rot
+        phi, _, _, o, _, _ = P.kin(q, np.zeros(6))
+        return sum(mass[b] * (o[b] + rot(phi[b]) @ np.asarray(m["com"][b]))[1] for b in range(4)) / mass.sum()
+    z0 = com_z(q)
+    for _ in range(50):
+        q, v = P.substep(q, v, np.array([1.0, -1.0, 0.5]))  # internal torques cannot move the COM
+    t = 50 * m["timestep"]
+    np.testing.assert_allclose(com_z(q), z0 - 0.5 * 9.81 * t * t, atol=1e-9)
+
+
+def test_standing_contact_and_termination():
+    m = hopper()
+    P = PlanarOracle(m)
+    q = np.array(m["init_qpos"], float); v = np.zeros(6)
+    for i in range(40):
+        q, v, obs, r, done = P.step(q, v, np.zeros(3))
+        assert not done
+    # rests on the foot: capsule bottom 0.04 above the floor at z=1.25 -> settles near z = 1.21, small penetration
+    assert 1.205 < q[1] < 1.212 and abs(v[1]) < 1e-2
+    assert abs(r - 1.0) < 0.02 and obs.shape == (11,)  # alive bonus, no motion, no control cost
+    # termination: |angle| >= 0.2 or z <= 0.7 (hopper.py:19-25)
+    qq = q.copy(); qq[2] = 0.25
+    assert P.step(qq, v, np.zeros(3))[4]
+    qq = q.copy(); qq[1] = 0.5
+    assert P.step(qq, v, np.zeros(3))[4]
+
+
+def test_reward_formula_and_action_clip():
+    m = hopper()
+    P = PlanarOracle(m)
+    rng = np.random.default_rng(3)
+    q, v = P.reset(rng)
+    a = np.array([2.0, -3.0, 0.5])  # clipped to [1,-1,0.5] by NormalizedBoxEnv (wrappers.py:343-346)
+    q2, v2, obs, r, done = P.step(q, v, a)
+    q3, v3, _, r3, _ = P.step(q, v, np.clip(a, -1, 1))
+    np.testing.assert_allclose(q2, q3); assert r == r3
+    dt = 0.008
+    np.testing.assert_allclose(r, (q2[0] - q[0]) / dt + 1.0 - 1e-3 * (1 + 1 + 0.25), rtol=1e-12)
+    np.testing.assert_allclose(obs, np.concatenate([q2[1:], np.clip(v2, -10, 10)]))
+
+
+def test_random_policy_return_is_in_the_reference_ballpark():
+    """README.md:165 known answer: random-policy Hopper-v2 return 13.09 (MuJoCo).  Our engine is a
+    different simulator; this only guards against gross model errors (episode length / reward scale)."""
+    P = PlanarOracle(hopper())
+    rng = np.random.default_rng(0)
+    rets = []
+    for _ in range(30):
+        q, v = P.reset(rng); R = 0.0
+        for _ in range(200):
+            q, v, _, r, d = P.step(q, v, rng.uniform(-1, 1, 3)); R += r
+            if d:
+                break
+        rets.append(R)
+    assert 8.0 < np.mean(rets) < 25.0, np.mean(rets)
