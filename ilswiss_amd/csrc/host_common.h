@@ -95,8 +95,11 @@ struct ilsx_net {
 int net_upload_flat(ilsx_ctx* ctx, const NetLayout& L, float* dev_base, const float* src, size_t n, int src_is_device);
 int net_download_flat(ilsx_ctx* ctx, const NetLayout& L, const float* dev_base, float* dst, size_t n, int dst_is_device);
 
-int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A, int H, int act, int KP);
-int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act);
+int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A, int H, int act, int KP, int cs = 1);
+int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act, int cs = 1);
+int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P);
+// column-split factor the 2-hidden-layer fast path uses for width H (1 = generic kernels)
+int mlp2_split_factor(int n_hidden, int H);
 int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows);
 int launch_adam(ilsx_ctx* ctx, const AdamArgs& A);
 // appends the dW/db jobs of one network to `jobs`

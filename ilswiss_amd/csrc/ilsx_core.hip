@@ -170,7 +170,7 @@ extern "C" int ilsx_prof_read(ilsx_ctx* c, int kid, uint64_t* launches, double* 
 extern "C" const char* ilsx_kernel_name(int kid) {
   static const char* names[ILSX_K_COUNT] = {"k_mlp_fwd", "k_mlp_bwd_dx", "k_mlp_bwd_dw", "k_adam_polyak",
       "k_replay_sample", "k_replay_add", "k_replay_sample_many", "k_sac_stats", "k_sac_finish", "k_env_step",
-      "", "", "", "", "", ""};
+      "k_policy_finish", "", "", "", "", ""};
   return (kid >= 0 && kid < ILSX_K_COUNT) ? names[kid] : "";
 }
 
@@ -297,6 +297,10 @@ static int kernels_init_once() {
   SET_FWD(64, ACT_TANH); SET_FWD(128, ACT_TANH); SET_FWD(256, ACT_TANH);
 #undef SET_FWD
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   done = true;
   return ILSX_OK;
 }
@@ -320,14 +324,43 @@ extern "C" int ilsx_debug_set_stamp_buffer(ilsx_ctx* c, void* dev_u64x16) {
   return ILSX_OK;
 }
 
-int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax) {
+int mlp2_split_factor(int n_hidden, int H) {
+  if (n_hidden != 2) return 1;
+  return H == 256 ? 4 : H == 128 ? 2 : 1;
+}
+
+static size_t fwd_split_lds_bytes(int H, int KP, int cs) {
+  return sizeof(float) * (16 * (KP + ILSX_LDS_PAD) + 16 * (H + ILSX_LDS_PAD) + 16 * (H / cs + ILSX_LDS_PAD) +
+                          4 * (4 * H / cs / 64) * 4 * 64);
+}
+static size_t bwd_split_lds_bytes(int H, int cs) {
+  return sizeof(float) * (16 * (H + ILSX_LDS_PAD) + 16 * (H / cs + ILSX_LDS_PAD) + 16 * ILSX_MAX_NO);
+}
+
+int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int cs) {
   if (A0.rows <= 0) return ILSX_OK;
   FwdArgs A = A0;
   A.dbg = ctx->dbg_stamps;
+  ProfScope ps(ctx, ILSX_K_MLP_FWD);
+  if (cs > 1) {
+    const size_t lds = fwd_split_lds_bytes(H, KPmax, cs);
+    if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
+    dim3 grid((A.rows + 15) / 16, A.ntasks, cs), block(4 * H / cs);
+    if (H == 256 && cs == 4) {
+      if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, A);
+      else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, A);
+    } else if (H == 128 && cs == 2) {
+      if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, A);
+      else hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_TANH, 2>), grid, block, lds, ctx->stream, A);
+    } else {
+      ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "no column-split forward kernel for H=%d cs=%d", H, cs);
+    }
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   const size_t lds = fwd_lds_bytes(H, KPmax);
   if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
   dim3 grid((A.rows + 15) / 16, A.ntasks), block(4 * H);
-  ProfScope ps(ctx, ILSX_K_MLP_FWD);
 #define CALL_FWD(HH, AA) hipLaunchKernelGGL((k_mlp_fwd<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_FWD);
 #undef CALL_FWD
@@ -335,14 +368,40 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax) {
   return ILSX_OK;
 }
 
-int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act) {
-  if (A.rows <= 0) return ILSX_OK;
+int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
+  if (A0.rows <= 0) return ILSX_OK;
+  BwdArgs A = A0;
+  A.dbg = ctx->dbg_stamps;
+  if (A.ga_parts < 1) A.ga_parts = 1;
+  ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
+  if (cs > 1) {
+    const size_t lds = bwd_split_lds_bytes(H, cs);
+    dim3 grid((A.rows + 15) / 16, A.ntasks, cs), block(4 * H / cs);
+    if (H == 256 && cs == 4) {
+      if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, A);
+      else hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, A);
+    } else if (H == 128 && cs == 2) {
+      if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, A);
+      else hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_TANH, 2>), grid, block, lds, ctx->stream, A);
+    } else {
+      ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "no column-split backward kernel for H=%d cs=%d", H, cs);
+    }
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   const size_t lds = bwd_lds_bytes(H);
   dim3 grid((A.rows + 15) / 16, A.ntasks), block(4 * H);
-  ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
 #define CALL_BWD(HH, AA) hipLaunchKernelGGL((k_mlp_bwd_dx<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_BWD);
 #undef CALL_BWD
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P) {
+  if (P.rows <= 0) return ILSX_OK;
+  ProfScope ps(ctx, ILSX_K_POLICY_FINISH);
+  hipLaunchKernelGGL(k_policy_finish, dim3((P.rows + 63) / 64), dim3(64), 0, ctx->stream, P);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

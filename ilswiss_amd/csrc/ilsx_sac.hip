@@ -26,6 +26,7 @@ struct SacWs {  // device workspace for B <= max_batch rows
   float *xq[2], *hq[2][ILSX_MAX_HID], *dq[2][ILSX_MAX_HID], *dhq[2];
   float *raw, *an, *logp, *epss, *q1n, *q2n, *ga[2];
   float *xp, *hp[ILSX_MAX_HID], *dp[ILSX_MAX_HID], *dhp;
+  float* ppart;  // policy head partials [cs][max_batch][2a] (column-split path)
 };
 
 struct ilsx_sac {
@@ -40,6 +41,7 @@ struct ilsx_sac {
   SacWs ws;
   DwJob *jobs_q = nullptr, *jobs_p = nullptr;
   int njobs_q = 0, njobs_p = 0;
+  int cs = 1;                // column-split factor of the 2-hidden-layer fast path (1 = generic kernels)
   int B = 0;                 // rows of the batch currently staged
   bool eps_explicit = false;
   float target_entropy = 0.f;
@@ -57,13 +59,15 @@ struct ilsx_sac {
       default: return P + 3 * nq + np;
     }
   }
+  PartVal pv(const float* p) const { return PartVal{p, cs, cfg.max_batch}; }
   float* gbase(int which) const { return which == W_Q1 ? G : which == W_Q2 ? G + nq : G + 2 * nq; }
   size_t trainable_off(int which) const { return which == W_Q1 ? 0 : which == W_Q2 ? nq : 2 * nq; }
 };
 
 // ------------------------------------------------------------------------------------------------
 struct StatsArgs {
-  const float *q1, *q2, *tq1, *tq2, *logp2, *r, *d, *logp, *q1n, *q2n, *raw;
+  PartVal q1, q2, tq1, tq2, q1n, q2n;
+  const float *logp2, *r, *d, *logp, *raw;
   int B, a;
   float gamma, reward_scale, w_mu, w_std, target_entropy, inv_B;
   DevScalars* scal;
@@ -77,10 +81,11 @@ __global__ __launch_bounds__(256) void k_sac_stats(const StatsArgs S) {
   float l1 = 0, l2 = 0, pl = 0, lp = 0, mu2 = 0, ls2 = 0, mus = 0, lss = 0, q1s = 0, q2s = 0, lpe = 0;
   for (int r = threadIdx.x; r < S.B; r += 256) {
     const float y = S.reward_scale * S.r[r] +
-                    (1.0f - S.d[r]) * S.gamma * (fminf(S.tq1[r], S.tq2[r]) - alpha * S.logp2[r]);
-    const float e1 = S.q1[r] - y, e2 = S.q2[r] - y;
-    l1 += e1 * e1; l2 += e2 * e2; q1s += S.q1[r]; q2s += S.q2[r];
-    pl += alpha * S.logp[r] - fminf(S.q1n[r], S.q2n[r]);
+                    (1.0f - S.d[r]) * S.gamma * (fminf(S.tq1.get(r), S.tq2.get(r)) - alpha * S.logp2[r]);
+    const float q1v = S.q1.get(r), q2v = S.q2.get(r);
+    const float e1 = q1v - y, e2 = q2v - y;
+    l1 += e1 * e1; l2 += e2 * e2; q1s += q1v; q2s += q2v;
+    pl += alpha * S.logp[r] - fminf(S.q1n.get(r), S.q2n.get(r));
     lp += S.logp[r];
     lpe += S.logp[r] + S.target_entropy;
     for (int j = 0; j < S.a; ++j) {
@@ -150,16 +155,17 @@ static int sac_alloc_ws(ilsx_sac* s) {
   auto A = [&](float** p, size_t n) { return ctx_alloc(c, n * sizeof(float), (void**)p, true); };
   ILSX_TRY(A(&w.s, B * o)); ILSX_TRY(A(&w.a, B * a)); ILSX_TRY(A(&w.r, B)); ILSX_TRY(A(&w.d, B));
   ILSX_TRY(A(&w.s2, B * o)); ILSX_TRY(A(&w.eps1, B * a)); ILSX_TRY(A(&w.eps2, B * a));
-  ILSX_TRY(A(&w.a2, B * a)); ILSX_TRY(A(&w.logp2, B)); ILSX_TRY(A(&w.q1, B)); ILSX_TRY(A(&w.q2, B));
-  ILSX_TRY(A(&w.tq1, B)); ILSX_TRY(A(&w.tq2, B));
+  const size_t CS = (size_t)s->cs;
+  ILSX_TRY(A(&w.a2, B * a)); ILSX_TRY(A(&w.logp2, B)); ILSX_TRY(A(&w.q1, CS * B)); ILSX_TRY(A(&w.q2, CS * B));
+  ILSX_TRY(A(&w.tq1, CS * B)); ILSX_TRY(A(&w.tq2, CS * B)); ILSX_TRY(A(&w.ppart, CS * B * 2 * a));
   for (int i = 0; i < 2; ++i) {
     ILSX_TRY(A(&w.xq[i], B * s->Lq.KP));
     for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) { ILSX_TRY(A(&w.hq[i][l], B * H)); ILSX_TRY(A(&w.dq[i][l], B * H)); }
     ILSX_TRY(A(&w.dhq[i], B * 4));
-    ILSX_TRY(A(&w.ga[i], B * a));
+    ILSX_TRY(A(&w.ga[i], CS * B * a));
   }
   ILSX_TRY(A(&w.raw, B * 2 * a)); ILSX_TRY(A(&w.an, B * a)); ILSX_TRY(A(&w.logp, B)); ILSX_TRY(A(&w.epss, B * a));
-  ILSX_TRY(A(&w.q1n, B)); ILSX_TRY(A(&w.q2n, B));
+  ILSX_TRY(A(&w.q1n, CS * B)); ILSX_TRY(A(&w.q2n, CS * B));
   ILSX_TRY(A(&w.xp, B * s->Lp.KP));
   for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) { ILSX_TRY(A(&w.hp[l], B * H)); ILSX_TRY(A(&w.dp[l], B * H)); }
   ILSX_TRY(A(&w.dhp, B * 2 * a));
@@ -186,6 +192,7 @@ extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net*
   s->Lq = q1->lay; s->Lp = pi->lay;
   s->o = cp.in_dim; s->a = cp.out_dim;
   s->nq = s->Lq.n_int; s->np = s->Lp.n_int;
+  s->cs = getenv("ILSX_NO_SPLIT") ? 1 : mlp2_split_factor(cp.n_hidden, cp.hidden);
   s->target_entropy = cfg->has_target_entropy ? cfg->target_entropy : -(float)s->a / 2.0f;  // sac_alpha.py:56-58
   s->rng_stream = ctx->next_rng_stream;
   ctx->next_rng_stream += 2;
@@ -262,57 +269,85 @@ extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
 // ------------------------------------------------------------------------------------------------
 static float sac_inv_B(const ilsx_sac* s) { return 1.0f / ((float)s->B * (float)s->cfg.grad_world); }
 
+// forward of the policy on `obs` (+ its tanh-Gaussian epilogue) as task `slot` of a forward launch; when the
+// column-split path is on, the epilogue runs in k_policy_finish right after the launch (sac_policy_finish).
+static void sac_policy_task(ilsx_sac* s, FwdTask& t, const float* obs, const float* eps, uint32_t stream, bool save,
+                            float* action, float* logp) {
+  const SacWs& w = s->ws;
+  t.net = net_view(s->Lp, s->base(W_PI));
+  t.x0 = obs; t.d0 = s->o; t.s0 = s->o;
+  if (save) {
+    t.xsave = w.xp;
+    for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) t.hsave[l] = w.hp[l];
+  }
+  t.head = HEAD_TANH_SAMPLE; t.rng_stream = stream;
+  if (s->cs > 1) {
+    t.part = w.ppart;
+  } else {
+    t.eps = eps; t.action = action; t.logp = logp;
+    if (save) { t.out = w.raw; t.eps_save = w.epss; }
+  }
+}
+static int sac_policy_finish(ilsx_sac* s, const float* eps, uint32_t stream, bool save, float* action, float* logp) {
+  if (s->cs == 1) return ILSX_OK;
+  const SacWs& w = s->ws;
+  PolicyFinishArgs P;
+  memset(&P, 0, sizeof P);
+  P.part = w.ppart; P.cs = s->cs; P.part_stride = s->cfg.max_batch; P.rows = s->B; P.a = s->a;
+  P.head = HEAD_TANH_SAMPLE; P.rng_stream = stream; P.seed = s->ctx->seed; P.scal = s->scal;
+  P.eps = eps; P.action = action; P.logp = logp;
+  if (save) { P.raw = w.raw; P.eps_save = w.epss; }
+  return launch_policy_finish(s->ctx, P);
+}
+static void sac_q_task(ilsx_sac* s, FwdTask& q, int which, const float* obs, const float* act, float* out, bool save_x,
+                       bool save_h, int i) {
+  const SacWs& w = s->ws;
+  q.net = net_view(s->Lq, s->base(which));
+  q.x0 = obs; q.d0 = s->o; q.s0 = s->o; q.x1 = act; q.d1 = s->a; q.s1 = s->a;
+  if (save_x) q.xsave = w.xq[i];
+  if (save_h) for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) q.hsave[l] = w.hq[i][l];
+  q.head = HEAD_RAW;
+  if (s->cs > 1) q.part = out; else q.out = out;
+}
+
 static int sac_critic_backward(ilsx_sac* s) {
   const SacWs& w = s->ws;
-  const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act;
+  const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
+  const float* eps1 = s->eps_explicit ? w.eps1 : nullptr;
   {  // fwd: pi(s') with eps_next ; Q1(s,a) ; Q2(s,a)
     FwdArgs A;
     memset(&A, 0, sizeof A);
-    A.rows = B; A.ntasks = 3; A.seed = s->ctx->seed; A.scal = s->scal;
-    FwdTask& t = A.t[0];
-    t.net = net_view(s->Lp, s->base(W_PI));
-    t.x0 = w.s2; t.d0 = s->o; t.s0 = s->o;
-    t.head = HEAD_TANH_SAMPLE; t.rng_stream = s->rng_stream;
-    t.eps = s->eps_explicit ? w.eps1 : nullptr;
-    t.action = w.a2; t.logp = w.logp2;
-    for (int i = 0; i < 2; ++i) {
-      FwdTask& q = A.t[1 + i];
-      q.net = net_view(s->Lq, s->base(i == 0 ? W_Q1 : W_Q2));
-      q.x0 = w.s; q.d0 = s->o; q.s0 = s->o; q.x1 = w.a; q.d1 = s->a; q.s1 = s->a;
-      q.xsave = w.xq[i];
-      for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) q.hsave[l] = w.hq[i][l];
-      q.out = i == 0 ? w.q1 : w.q2;
-      q.head = HEAD_RAW;
-    }
-    ILSX_TRY(launch_fwd(s->ctx, A, H, act, std::max(s->Lq.KP, s->Lp.KP)));
+    A.rows = B; A.ntasks = 3; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
+    sac_policy_task(s, A.t[0], w.s2, eps1, s->rng_stream, false, w.a2, w.logp2);
+    sac_q_task(s, A.t[1], W_Q1, w.s, w.a, w.q1, true, true, 0);
+    sac_q_task(s, A.t[2], W_Q2, w.s, w.a, w.q2, true, true, 1);
+    ILSX_TRY(launch_fwd(s->ctx, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
+    ILSX_TRY(sac_policy_finish(s, eps1, s->rng_stream, false, w.a2, w.logp2));
   }
   {  // fwd: TQ1(s',a'), TQ2(s',a')
     FwdArgs A;
     memset(&A, 0, sizeof A);
-    A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal;
-    for (int i = 0; i < 2; ++i) {
-      FwdTask& q = A.t[i];
-      q.net = net_view(s->Lq, s->base(i == 0 ? W_TQ1 : W_TQ2));
-      q.x0 = w.s2; q.d0 = s->o; q.s0 = s->o; q.x1 = w.a2; q.d1 = s->a; q.s1 = s->a;
-      q.out = i == 0 ? w.tq1 : w.tq2;
-      q.head = HEAD_RAW;
-    }
-    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP));
+    A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
+    sac_q_task(s, A.t[0], W_TQ1, w.s2, w.a2, w.tq1, false, false, 0);
+    sac_q_task(s, A.t[1], W_TQ2, w.s2, w.a2, w.tq2, false, false, 1);
+    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx with the TD-target loss head
     BwdArgs A;
     memset(&A, 0, sizeof A);
     A.rows = B; A.ntasks = 2; A.inv_B = sac_inv_B(s);
     A.gamma = s->cfg.discount; A.reward_scale = s->cfg.reward_scale; A.scal = s->scal;
+    A.part_stride = s->cfg.max_batch;
     for (int i = 0; i < 2; ++i) {
       BwdTask& t = A.t[i];
       t.net = net_view(s->Lq, s->base(i == 0 ? W_Q1 : W_Q2));
       for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) { t.hsave[l] = w.hq[i][l]; t.dsave[l] = w.dq[i][l]; }
       t.dhead = w.dhq[i];
       t.loss = LOSS_SAC_CRITIC;
-      t.q = i == 0 ? w.q1 : w.q2; t.tq1 = w.tq1; t.tq2 = w.tq2; t.logp_next = w.logp2; t.rew = w.r; t.done = w.d;
+      t.q = s->pv(i == 0 ? w.q1 : w.q2); t.tq1 = s->pv(w.tq1); t.tq2 = s->pv(w.tq2);
+      t.logp_next = w.logp2; t.rew = w.r; t.done = w.d;
     }
-    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act));
+    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act, cs));
   }
   return launch_bwd_dw(s->ctx, s->jobs_q, s->njobs_q, B);
 }
@@ -328,66 +363,56 @@ static int sac_critic_update(ilsx_sac* s) {
 
 static int sac_actor_backward(ilsx_sac* s) {
   const SacWs& w = s->ws;
-  const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act;
+  const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
+  const float* eps2 = s->eps_explicit ? w.eps2 : nullptr;
   {  // fwd pi(s) with eps_cur
     FwdArgs A;
     memset(&A, 0, sizeof A);
-    A.rows = B; A.ntasks = 1; A.seed = s->ctx->seed; A.scal = s->scal;
-    FwdTask& t = A.t[0];
-    t.net = net_view(s->Lp, s->base(W_PI));
-    t.x0 = w.s; t.d0 = s->o; t.s0 = s->o;
-    t.xsave = w.xp;
-    for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) t.hsave[l] = w.hp[l];
-    t.out = w.raw;
-    t.head = HEAD_TANH_SAMPLE; t.rng_stream = s->rng_stream + 1;
-    t.eps = s->eps_explicit ? w.eps2 : nullptr;
-    t.eps_save = w.epss; t.action = w.an; t.logp = w.logp;
-    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lp.KP));
+    A.rows = B; A.ntasks = 1; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
+    sac_policy_task(s, A.t[0], w.s, eps2, s->rng_stream + 1, true, w.an, w.logp);
+    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lp.KP, cs));
+    ILSX_TRY(sac_policy_finish(s, eps2, s->rng_stream + 1, true, w.an, w.logp));
   }
   {  // fwd Q1(s,a~), Q2(s,a~) with the just-updated critics (sac_alpha.py:144-146)
     FwdArgs A;
     memset(&A, 0, sizeof A);
-    A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal;
-    for (int i = 0; i < 2; ++i) {
-      FwdTask& q = A.t[i];
-      q.net = net_view(s->Lq, s->base(i == 0 ? W_Q1 : W_Q2));
-      q.x0 = w.s; q.d0 = s->o; q.s0 = s->o; q.x1 = w.an; q.d1 = s->a; q.s1 = s->a;
-      for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) q.hsave[l] = w.hq[i][l];
-      q.out = i == 0 ? w.q1n : w.q2n;
-      q.head = HEAD_RAW;
-    }
-    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP));
+    A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
+    sac_q_task(s, A.t[0], W_Q1, w.s, w.an, w.q1n, false, true, 0);
+    sac_q_task(s, A.t[1], W_Q2, w.s, w.an, w.q2n, false, true, 1);
+    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx through both critics to the action columns
     BwdArgs A;
     memset(&A, 0, sizeof A);
-    A.rows = B; A.ntasks = 2; A.inv_B = sac_inv_B(s); A.scal = s->scal;
+    A.rows = B; A.ntasks = 2; A.inv_B = sac_inv_B(s); A.scal = s->scal; A.part_stride = s->cfg.max_batch;
     for (int i = 0; i < 2; ++i) {
       BwdTask& t = A.t[i];
       t.net = net_view(s->Lq, s->base(i == 0 ? W_Q1 : W_Q2));
       for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) t.hsave[l] = w.hq[i][l];
-      t.loss = LOSS_SAC_ACTORQ; t.which = i; t.q1n = w.q1n; t.q2n = w.q2n;
+      t.loss = LOSS_SAC_ACTORQ; t.which = i; t.q1n = s->pv(w.q1n); t.q2n = s->pv(w.q2n);
       t.dx = w.ga[i]; t.dx_col0 = s->o; t.dx_cols = s->a;
     }
-    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act));
+    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act, cs));
   }
   {  // bwd_dx of the policy with the tanh-Gaussian loss head
     BwdArgs A;
     memset(&A, 0, sizeof A);
-    A.rows = B; A.ntasks = 1; A.inv_B = sac_inv_B(s); A.scal = s->scal;
+    A.rows = B; A.ntasks = 1; A.inv_B = sac_inv_B(s); A.scal = s->scal; A.part_stride = s->cfg.max_batch;
     A.w_mu = s->cfg.policy_mean_reg_weight; A.w_std = s->cfg.policy_std_reg_weight;
+    A.ga_parts = cs; A.ga_stride = s->cfg.max_batch;
     BwdTask& t = A.t[0];
     t.net = net_view(s->Lp, s->base(W_PI));
     for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) { t.hsave[l] = w.hp[l]; t.dsave[l] = w.dp[l]; }
     t.dhead = w.dhp;
     t.loss = LOSS_SAC_POLICY;
     t.raw = w.raw; t.eps = w.epss; t.action = w.an; t.ga1 = w.ga[0]; t.ga2 = w.ga[1];
-    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act));
+    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act, cs));
   }
   ILSX_TRY(launch_bwd_dw(s->ctx, s->jobs_p, s->njobs_p, B));
   StatsArgs S;
-  S.q1 = w.q1; S.q2 = w.q2; S.tq1 = w.tq1; S.tq2 = w.tq2; S.logp2 = w.logp2; S.r = w.r; S.d = w.d;
-  S.logp = w.logp; S.q1n = w.q1n; S.q2n = w.q2n; S.raw = w.raw;
+  S.q1 = s->pv(w.q1); S.q2 = s->pv(w.q2); S.tq1 = s->pv(w.tq1); S.tq2 = s->pv(w.tq2);
+  S.q1n = s->pv(w.q1n); S.q2n = s->pv(w.q2n);
+  S.logp2 = w.logp2; S.r = w.r; S.d = w.d; S.logp = w.logp; S.raw = w.raw;
   S.B = B; S.a = s->a;
   S.gamma = s->cfg.discount; S.reward_scale = s->cfg.reward_scale;
   S.w_mu = s->cfg.policy_mean_reg_weight; S.w_std = s->cfg.policy_std_reg_weight;

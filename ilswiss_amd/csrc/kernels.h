@@ -140,6 +140,23 @@ struct FwdTask {
   float* eps_save;                   // [rows][a] nullable
   float* action;                     // [rows][a] nullable
   float* logp;                       // [rows] nullable
+  float* part;                       // column-split kernels: partial head sums [CS][part_stride][NO]
+};
+// A per-row scalar (Q value) that may still be split into CS column-slice partial sums: summed in a fixed
+// order by whoever consumes it (the "combine in the next kernel's prologue" seam of a split-K reduction).
+struct PartVal {
+  const float* p; int cs; int stride;
+  __device__ __forceinline__ float get(int r) const {  // cs <= 4; the loads are independent and issue together
+    const float v0 = p[r];
+    const float v1 = cs > 1 ? p[(size_t)stride + r] : 0.0f;
+    const float v2 = cs > 2 ? p[(size_t)2 * stride + r] : 0.0f;
+    const float v3 = cs > 3 ? p[(size_t)3 * stride + r] : 0.0f;
+    float s = v0;
+    if (cs > 1) s += v1;
+    if (cs > 2) s += v2;
+    if (cs > 3) s += v3;
+    return s;
+  }
 };
 struct FwdArgs {
   FwdTask t[4];
@@ -148,6 +165,7 @@ struct FwdArgs {
   const DevScalars* scal;  // nullable: step counter for Philox
   uint64_t step_host;      // used when scal == null
   unsigned long long* dbg; // nullable phase timestamps
+  int part_stride;         // rows of one partial slab (column-split kernels)
 };
 
 #ifdef ILSX_KERNEL_IMPL
@@ -328,8 +346,9 @@ struct BwdTask {
   int loss;
   int which;                    // LOSS_SAC_ACTORQ: 0 -> this net is Q1, 1 -> Q2
   const float* given;           // LOSS_GIVEN: dL/dout [rows][NO]
-  const float *q, *tq1, *tq2, *logp_next, *rew, *done;  // LOSS_SAC_CRITIC
-  const float *q1n, *q2n;                                 // LOSS_SAC_ACTORQ
+  PartVal q, tq1, tq2;                                    // LOSS_SAC_CRITIC
+  const float *logp_next, *rew, *done;
+  PartVal q1n, q2n;                                       // LOSS_SAC_ACTORQ
   const float *raw, *eps, *action, *ga1, *ga2;            // LOSS_SAC_POLICY (raw = mu|log_std_raw)
   float* dx;                    // [rows][dx_cols] = dL/dx[:, dx_col0:dx_col0+dx_cols], nullable
   int dx_col0, dx_cols;
@@ -341,7 +360,49 @@ struct BwdArgs {
   float gamma, reward_scale, w_mu, w_std;
   const DevScalars* scal;
   unsigned long long* dbg;
+  int ga_parts, ga_stride;  // LOSS_SAC_POLICY: ga1/ga2 hold ga_parts partial slabs of ga_stride rows each
+  int part_stride;          // column-split kernels: rows of one dx partial slab
 };
+
+// dL/d(head output j) of row gr for the loss functor of task T (shared by the generic and the column-split
+// backward kernels).
+__device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& A, int gr, int j, int NO) {
+  float d = 0.0f;
+  if (T.loss == LOSS_GIVEN) {
+    d = T.given[(size_t)gr * NO + j];
+  } else if (T.loss == LOSS_SAC_CRITIC) {
+    // sac_alpha.py:110-123: y = r + (1-d)*gamma*(min(TQ1,TQ2) - alpha*logpi'); dL/dq = (q-y)/B
+    const float alpha = A.scal->alpha;
+    const float r = A.reward_scale * T.rew[gr];
+    const float y = r + (1.0f - T.done[gr]) * A.gamma * (fminf(T.tq1.get(gr), T.tq2.get(gr)) - alpha * T.logp_next[gr]);
+    d = (T.q.get(gr) - y) * A.inv_B;
+  } else if (T.loss == LOSS_SAC_ACTORQ) {
+    // sac_alpha.py:144-148: -mean(min(Q1,Q2)); torch.minimum splits ties evenly
+    const float a1 = T.q1n.get(gr), a2 = T.q2n.get(gr);
+    const float w1 = a1 < a2 ? 1.0f : (a1 == a2 ? 0.5f : 0.0f);
+    d = -(T.which == 0 ? w1 : 1.0f - w1) * A.inv_B;
+  } else {  // LOSS_SAC_POLICY: SURVEY Appendix A.1/A.2 ; j < a -> d mu_j, else d log_std_raw_{j-a}
+    const int a = NO >> 1, jj = j < a ? j : j - a;
+    const float alpha = A.scal->alpha;
+    const float glp = alpha * A.inv_B;
+    const float inv_Ba = A.inv_B / (float)a;
+    const float mu = T.raw[(size_t)gr * NO + jj], lsr = T.raw[(size_t)gr * NO + a + jj];
+    const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
+    const float sd = expf(ls), ep = T.eps[(size_t)gr * a + jj], act = T.action[(size_t)gr * a + jj];
+    float ga = 0.0f;  // d(-min Q)/da~: both critics, each possibly in column-slice partial slabs
+    for (int pc = 0; pc < A.ga_parts; ++pc)
+      ga += T.ga1[((size_t)pc * A.ga_stride + gr) * a + jj] + T.ga2[((size_t)pc * A.ga_stride + gr) * a + jj];
+    const float om = 1.0f - act * act;
+    const float dz = ga * om + glp * (2.0f * act * om / (om + TANH_EPS));
+    if (j < a) {
+      d = dz + 2.0f * A.w_mu * mu * inv_Ba;
+    } else {
+      const float dls = dz * sd * ep - glp + 2.0f * A.w_std * ls * inv_Ba;
+      d = (lsr >= LOG_SIG_MIN && lsr <= LOG_SIG_MAX) ? dls : 0.0f;
+    }
+  }
+  return d;
+}
 
 #ifdef ILSX_KERNEL_IMPL
 template <int H, int ACT>
@@ -367,44 +428,14 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
   }
 
   // ---- head gradient: thread <-> (row, output)
-  for (int e = tid; e < 16 * ILSX_MAX_NO; e += NTH) {
-    const int row = e >> 6, j = e & 63, gr = r0 + row;
+  for (int e = tid; e < 16 * NO; e += NTH) {
+    const int row = e / NO, j = e - row * NO, gr = r0 + row;
     float d = 0.0f;
-    if (gr < rows && j < NO) {
-      if (T.loss == LOSS_GIVEN) {
-        d = T.given[(size_t)gr * NO + j];
-      } else if (T.loss == LOSS_SAC_CRITIC) {
-        // sac_alpha.py:110-123: y = r + (1-d)*gamma*(min(TQ1,TQ2) - alpha*logpi'); dL/dq = (q-y)/B
-        const float alpha = A.scal->alpha;
-        const float r = A.reward_scale * T.rew[gr];
-        const float y = r + (1.0f - T.done[gr]) * A.gamma * (fminf(T.tq1[gr], T.tq2[gr]) - alpha * T.logp_next[gr]);
-        d = (T.q[gr] - y) * A.inv_B;
-      } else if (T.loss == LOSS_SAC_ACTORQ) {
-        // sac_alpha.py:144-148: -mean(min(Q1,Q2)); torch.minimum splits ties evenly
-        const float a1 = T.q1n[gr], a2 = T.q2n[gr];
-        const float w1 = a1 < a2 ? 1.0f : (a1 == a2 ? 0.5f : 0.0f);
-        d = -(T.which == 0 ? w1 : 1.0f - w1) * A.inv_B;
-      } else {  // LOSS_SAC_POLICY: SURVEY Appendix A.1/A.2 ; j < a -> d mu_j, else d log_std_raw_{j-a}
-        const int a = NO >> 1, jj = j < a ? j : j - a;
-        const float alpha = A.scal->alpha;
-        const float glp = alpha * A.inv_B;
-        const float inv_Ba = A.inv_B / (float)a;
-        const float mu = T.raw[(size_t)gr * NO + jj], lsr = T.raw[(size_t)gr * NO + a + jj];
-        const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
-        const float sd = expf(ls), ep = T.eps[(size_t)gr * a + jj], act = T.action[(size_t)gr * a + jj];
-        const float ga = T.ga1[(size_t)gr * a + jj] + T.ga2[(size_t)gr * a + jj];
-        const float om = 1.0f - act * act;
-        const float dz = ga * om + glp * (2.0f * act * om / (om + TANH_EPS));
-        if (j < a) {
-          d = dz + 2.0f * A.w_mu * mu * inv_Ba;
-        } else {
-          const float dls = dz * sd * ep - glp + 2.0f * A.w_std * ls * inv_Ba;
-          d = (lsr >= LOG_SIG_MIN && lsr <= LOG_SIG_MAX) ? dls : 0.0f;
-        }
-      }
+    if (gr < rows) {
+      d = bwd_head_grad(T, A, gr, j, NO);
       if (T.dhead) T.dhead[(size_t)gr * NO + j] = d;
     }
-    dout[e] = d;
+    dout[row * ILSX_MAX_NO + j] = d;
   }
   __syncthreads();
 
@@ -480,6 +511,334 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
       }
     }
   }
+}
+#endif  // ILSX_KERNEL_IMPL
+
+// ================================================================================================
+// Column-split kernels for 2-hidden-layer nets (every BASELINE config): the last hidden layer of a 16-row
+// tile is split over CS workgroups (blockIdx.z), each owning H/CS columns, so the per-workgroup weight
+// burst (H*H/CS floats) and MFMA time (both ~1/CS of the unsplit kernel) stop bounding the launch and
+// 16*CS*ntasks workgroups spread over the chip.  Layer 0 (K = KP, tiny) is recomputed by every slice.
+// Head outputs leave as CS partial sums per row (FwdTask::part) and are combined in the consumer's
+// prologue (PartVal) or by k_policy_finish; backward input-gradients leave as CS partial slabs likewise.
+// block = 4*H/CS threads; wave w owns column tile(s) [w*CS, (w+1)*CS) of layer 0 and tile cs*NWV+w of layer 1.
+#ifdef ILSX_KERNEL_IMPL
+template <int H, int ACT, int CS>
+__global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) {
+  constexpr int NTH = 4 * H / CS, NWV = NTH / 64, NC = H / 16, SLW = H / CS, NCS = SLW / 16;
+  constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
+  static_assert(NCS == NWV, "one k16 chunk of the slice per wave in the head phase");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const FwdTask& T = A.t[blockIdx.y];
+  const NetView& N = T.net;
+  const int KP = N.KP, LDX = KP + ILSX_LDS_PAD, NO = N.NO, NCH0 = KP >> 4, NOT = (NO + 15) >> 4;
+  float* xs = smem;                 // [16][LDX]
+  float* h0 = xs + 16 * LDX;        // [16][LDH]   layer-0 activations, all H columns
+  float* hs = h0 + 16 * LDH;        // [16][LDSL]  this slice of the layer-1 activations
+  float* red = hs + 16 * LDSL;      // [4 tiles][NWV][4][64] head partial tiles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int r0 = blockIdx.x * 16, rows = A.rows, cs = blockIdx.z;
+  const bool lead = cs == 0;
+  ILSX_STAMP(A.dbg, 0);
+
+  // ---- every small global operand is requested up front, in the order it is needed
+  const float* w0p = N.base + N.off_W[0] + (size_t)(wave * CS) * NCH0 * 256 + 4 * lane;
+  float4 b0[CS];
+#pragma unroll
+  for (int i = 0; i < CS; ++i) b0[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256);
+  for (int e = tid; e < 16 * KP; e += NTH) {
+    const int r = e / KP, k = e - r * KP, gr = r0 + r;
+    float v = 0.0f;
+    if (gr < rows) {
+      if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
+      else if (k < T.d0 + T.d1) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
+      if (T.xsave && lead) T.xsave[(size_t)gr * KP + k] = v;
+    }
+    xs[r * LDX + k] = v;
+  }
+  float bias0[CS];
+#pragma unroll
+  for (int i = 0; i < CS; ++i) bias0[i] = (N.base + N.off_b[0])[(wave * CS + i) * 16 + li];
+  const int lc = wave * 16 + li, col1 = cs * SLW + lc;
+  const float bias1 = (N.base + N.off_b[1])[col1];
+  // head weights of this slice as MFMA B fragments: wave w owns k16 chunk w of the slice, rows j = 16t + li
+  float4 whf[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = 16 * t + li;
+    whf[t] = (t < NOT && j < NO) ? *reinterpret_cast<const float4*>(N.base + N.off_Wh + (size_t)j * H + cs * SLW + 16 * wave + 4 * g)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  ILSX_STAMP(A.dbg, 1);
+  // ---- this wave's slice of layer 1 (16 columns x H): one coalesced burst, lands under layer 0
+  float4 wreg[NC];
+  {
+    const float* wp = N.base + N.off_W[1] + (size_t)(cs * NWV + wave) * NC * 256 + 4 * lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+  }
+  // ---- layer 0, full width: CS column tiles per wave
+  {
+    f32x4 acc[CS];
+#pragma unroll
+    for (int i = 0; i < CS; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* ap = xs + li * LDX + 4 * g;
+    for (int kc = 0; kc < KP; kc += 16) {
+      float4 bn[CS];
+#pragma unroll
+      for (int i = 0; i < CS; ++i) {
+        bn[i] = b0[i];
+        if (kc + 16 < KP) bn[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256 + (kc + 16) * 16);
+      }
+      const float4 a = *reinterpret_cast<const float4*>(ap + kc);
+#pragma unroll
+      for (int i = 0; i < CS; ++i) acc[i] = MFMA16(a.x, b0[i].x, acc[i]);
+#pragma unroll
+      for (int i = 0; i < CS; ++i) acc[i] = MFMA16(a.y, b0[i].y, acc[i]);
+#pragma unroll
+      for (int i = 0; i < CS; ++i) acc[i] = MFMA16(a.z, b0[i].z, acc[i]);
+#pragma unroll
+      for (int i = 0; i < CS; ++i) acc[i] = MFMA16(a.w, b0[i].w, acc[i]);
+#pragma unroll
+      for (int i = 0; i < CS; ++i) b0[i] = bn[i];
+    }
+    float* hsv = lead ? T.hsave[0] : nullptr;
+#pragma unroll
+    for (int i = 0; i < CS; ++i) {
+      const int col = (wave * CS + i) * 16 + li;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = 4 * g + v;
+        const float h = act_fn<ACT>(acc[i][v] + bias0[i]);
+        h0[row * LDH + col] = h;
+        if (hsv && r0 + row < rows) hsv[(size_t)(r0 + row) * H + col] = h;
+      }
+    }
+  }
+  __syncthreads();
+  ILSX_STAMP(A.dbg, 2);
+  // ---- layer 1, this slice: straight out of registers
+  {
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const float* ap = h0 + li * LDH + 4 * g;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
+      acc0 = MFMA16(a.x, wreg[c].x, acc0); acc1 = MFMA16(a.y, wreg[c].y, acc1);
+      acc0 = MFMA16(a.z, wreg[c].z, acc0); acc1 = MFMA16(a.w, wreg[c].w, acc1);
+    }
+    float* hsv = T.hsave[1];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 4 * g + v;
+      const float h = act_fn<ACT>(acc0[v] + acc1[v] + bias1);
+      hs[row * LDSL + lc] = h;
+      if (hsv && r0 + row < rows) hsv[(size_t)(r0 + row) * H + col1] = h;
+    }
+  }
+  __syncthreads();
+  ILSX_STAMP(A.dbg, 3);
+  // ---- head partial sums over this column slice on the matrix pipe: wave w contracts k16 chunk w of the
+  //      slice for every 16-output tile, the NWV partial tiles are summed through LDS
+  {
+    const float4 a = *reinterpret_cast<const float4*>(hs + li * LDSL + 16 * wave + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < NOT) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc = MFMA16(a.x, whf[t].x, acc); acc = MFMA16(a.y, whf[t].y, acc);
+        acc = MFMA16(a.z, whf[t].z, acc); acc = MFMA16(a.w, whf[t].w, acc);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[((t * NWV + wave) * 4 + v) * 64 + lane] = acc[v];
+      }
+    }
+  }
+  __syncthreads();
+  const float* bh = N.base + N.off_bh;
+  for (int e = tid; e < NOT * 256; e += NTH) {
+    const int t = e >> 8, v = (e >> 6) & 3, ol = e & 63;
+    float sum = 0.0f;
+#pragma unroll
+    for (int w2 = 0; w2 < NWV; ++w2) sum += red[((t * NWV + w2) * 4 + v) * 64 + ol];
+    const int row = 4 * (ol >> 4) + v, j = 16 * t + (ol & 15), gr = r0 + row;
+    if (j < NO && gr < rows) T.part[((size_t)cs * A.part_stride + gr) * NO + j] = sum + (lead ? bh[j] : 0.0f);
+  }
+  ILSX_STAMP(A.dbg, 7);
+}
+#endif  // ILSX_KERNEL_IMPL
+// Combine the CS head partials of a tanh-Gaussian policy and run its epilogue (policies.py:262-307):
+// one thread per row.  Launched right after k_mlp2_fwd_split for policy tasks.
+struct PolicyFinishArgs {
+  const float* part; int cs, part_stride, rows, a, head;
+  uint32_t rng_stream; uint64_t seed; const DevScalars* scal; uint64_t step_host;
+  const float* eps; const float* act_in;
+  float *raw, *eps_save, *action, *logp;
+};
+#ifdef ILSX_KERNEL_IMPL
+__global__ __launch_bounds__(64) void k_policy_finish(const PolicyFinishArgs P) {
+  const int gr = blockIdx.x * 64 + threadIdx.x;
+  if (gr >= P.rows) return;
+  const int a = P.a, NO = 2 * a;
+  float lp_quad = 0.f, lp_ls = 0.f, lp_jac = 0.f;
+  const uint64_t step = P.scal ? P.scal->step : P.step_host;
+  for (int j0 = 0; j0 < a; j0 += 4) {
+    float z4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (P.head == HEAD_TANH_SAMPLE && !P.eps) philox_normal4(P.seed, step, P.rng_stream, gr, j0 >> 2, z4);
+    for (int jj = 0; jj < 4 && j0 + jj < a; ++jj) {
+      const int j = j0 + jj;
+      float mu = 0.f, lsr = 0.f;
+      for (int c = 0; c < P.cs; ++c) {
+        mu += P.part[((size_t)c * P.part_stride + gr) * NO + j];
+        lsr += P.part[((size_t)c * P.part_stride + gr) * NO + a + j];
+      }
+      if (P.raw) { P.raw[(size_t)gr * NO + j] = mu; P.raw[(size_t)gr * NO + a + j] = lsr; }
+      const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
+      const float sd = expf(ls);
+      float e = 0.f, z, act;
+      if (P.head == HEAD_TANH_DET) {
+        z = mu; act = tanhf(mu);
+      } else if (P.head == HEAD_TANH_LOGP_OF_ACT) {
+        act = P.act_in[(size_t)gr * a + j];
+        z = 0.5f * (logf(1.0f + act + TANH_EPS) - logf(1.0f - act + TANH_EPS));
+      } else {
+        e = P.eps ? P.eps[(size_t)gr * a + j] : z4[jj];
+        z = e * sd + mu;
+        act = tanhf(z);
+      }
+      const float dm = mu - z;
+      lp_quad += dm * dm / expf(2.0f * ls);
+      lp_ls += ls;
+      lp_jac += logf(1.0f - act * act + TANH_EPS);
+      if (P.action) P.action[(size_t)gr * a + j] = act;
+      if (P.eps_save) P.eps_save[(size_t)gr * a + j] = e;
+    }
+  }
+  if (P.logp) P.logp[gr] = -0.5f * lp_quad - (lp_ls + HALF_LOG_2PI) - lp_jac;
+}
+
+template <int H, int ACT, int CS>
+__global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) {
+  constexpr int NTH = 4 * H / CS, NWV = NTH / 64, NC = H / 16, SLW = H / CS, RPW = 16 / NWV, KPL = SLW / 64;
+  constexpr int RPT = 16 * H / NTH, RSTEP = NTH / H;   // delta_1: thread <-> one column, RPT rows RSTEP apart
+  constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
+  static_assert(NTH % H == 0 && RPW >= 1 && KPL >= 1, "unsupported split geometry");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const BwdTask& T = A.t[blockIdx.y];
+  const NetView& N = T.net;
+  const int NO = N.NO;
+  float* d1 = smem;                      // [16][LDH]  delta_1, all H columns
+  float* d0s = d1 + 16 * LDH;            // [16][LDSL] this slice of delta_0
+  float* dout = d0s + 16 * LDSL;         // [16][ILSX_MAX_NO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int r0 = blockIdx.x * 16, rows = A.rows, cs = blockIdx.z;
+  const bool lead = cs == 0;
+  ILSX_STAMP(A.dbg, 8);
+
+  // ---- operands of the later phases, requested first (they land while the loss head is evaluated)
+  const int k1 = tid % H, rb1 = tid / H;
+  float h1v[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int gr = r0 + rb1 + RSTEP * i;
+    h1v[i] = gr < rows ? T.hsave[1][(size_t)gr * H + k1] : 0.0f;
+  }
+  const int lc = wave * 16 + li, col0 = cs * SLW + lc;
+  float h0v[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int gr = r0 + 4 * g + v;
+    h0v[v] = gr < rows ? T.hsave[0][(size_t)gr * H + col0] : 0.0f;
+  }
+  // ---- head gradient (every slice recomputes it; the lead slice publishes it for the dW kernel)
+  for (int e = tid; e < 16 * NO; e += NTH) {  // only the NO live outputs per row: one pass, loads batched
+    const int row = e / NO, j = e - row * NO, gr = r0 + row;
+    float d = 0.0f;
+    if (gr < rows) {
+      d = bwd_head_grad(T, A, gr, j, NO);
+      if (T.dhead && lead) T.dhead[(size_t)gr * NO + j] = d;
+    }
+    dout[row * ILSX_MAX_NO + j] = d;
+  }
+  // ---- this wave's slice of W_1 (backward-packed: all H rows x its 16 columns), one coalesced burst
+  float4 wreg[NC];
+  {
+    const float* wp = N.base + N.off_Wb[1] + (size_t)(cs * NWV + wave) * NC * 256 + 4 * lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+  }
+  __syncthreads();
+  ILSX_STAMP(A.dbg, 9);
+  // ---- delta_1 = (dout Wh) * act'(h_1), full width on the VALU: thread <-> column k1
+  {
+    const float* Wh = N.base + N.off_Wh;
+    float accd[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) accd[i] = 0.0f;
+#pragma unroll 4
+    for (int j = 0; j < NO; ++j) {
+      const float w = Wh[(size_t)j * H + k1];
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) accd[i] = fmaf(dout[(rb1 + RSTEP * i) * ILSX_MAX_NO + j], w, accd[i]);
+    }
+    float* ds = lead ? T.dsave[1] : nullptr;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int row = rb1 + RSTEP * i, gr = r0 + row;
+      float dv = 0.0f;
+      if (gr < rows) {
+        dv = accd[i] * act_grad_from_out<ACT>(h1v[i]);
+        if (ds) ds[(size_t)gr * H + k1] = dv;
+      }
+      d1[row * LDH + k1] = dv;
+    }
+  }
+  __syncthreads();
+  ILSX_STAMP(A.dbg, 10);
+  // ---- delta_0 slice = (delta_1 W_1)[:, slice] * act'(h_0[:, slice])
+  {
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const float* ap = d1 + li * LDH + 4 * g;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
+      acc0 = MFMA16(a.x, wreg[c].x, acc0); acc1 = MFMA16(a.y, wreg[c].y, acc1);
+      acc0 = MFMA16(a.z, wreg[c].z, acc0); acc1 = MFMA16(a.w, wreg[c].w, acc1);
+    }
+    float* ds = T.dsave[0];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 4 * g + v, gr = r0 + row;
+      float dv = 0.0f;
+      if (gr < rows) {
+        dv = (acc0[v] + acc1[v]) * act_grad_from_out<ACT>(h0v[v]);
+        if (ds) ds[(size_t)gr * H + col0] = dv;
+      }
+      d0s[row * LDSL + lc] = dv;
+    }
+  }
+  ILSX_STAMP(A.dbg, 11);
+  // ---- partial dL/dx over this slice of the H contraction
+  if (T.dx) {
+    __syncthreads();
+    const float* W0 = N.base + N.off_W[0];
+    const int ld0 = N.ld[0];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = wave * RPW + rr, gr = r0 + row;
+      float dv[KPL];
+#pragma unroll
+      for (int i = 0; i < KPL; ++i) dv[i] = d0s[row * LDSL + lane + 64 * i];
+      for (int c = 0; c < T.dx_cols; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) s = fmaf(dv[i], W0[pack_f(cs * SLW + lane + 64 * i, T.dx_col0 + c, ld0)], s);
+        s = wave_sum(s);
+        if (lane == 0 && gr < rows) T.dx[((size_t)cs * A.part_stride + gr) * T.dx_cols + c] = s;
+      }
+    }
+  }
+  ILSX_STAMP(A.dbg, 12);
 }
 #endif  // ILSX_KERNEL_IMPL
 

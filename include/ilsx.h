@@ -66,7 +66,7 @@ int ilsx_memcpy_d2h(ilsx_ctx* ctx, void* dst_host, const void* src_dev, size_t b
  * path is bypassed while profiling); ilsx_prof_read synchronises and returns launches + summed ms. */
 enum { ILSX_K_MLP_FWD = 0, ILSX_K_MLP_BWD_DX = 1, ILSX_K_MLP_BWD_DW = 2, ILSX_K_ADAM = 3,
        ILSX_K_REPLAY_SAMPLE = 4, ILSX_K_REPLAY_ADD = 5, ILSX_K_REPLAY_SAMPLE_MANY = 6, ILSX_K_SAC_STATS = 7,
-       ILSX_K_SAC_FINISH = 8, ILSX_K_ENV_STEP = 9, ILSX_K_COUNT = 16 };
+       ILSX_K_SAC_FINISH = 8, ILSX_K_ENV_STEP = 9, ILSX_K_POLICY_FINISH = 10, ILSX_K_COUNT = 16 };
 int ilsx_prof_enable(ilsx_ctx* ctx, int on);
 int ilsx_prof_reset(ilsx_ctx* ctx);
 int ilsx_prof_read(ilsx_ctx* ctx, int kernel_id, uint64_t* launches, double* total_ms);
