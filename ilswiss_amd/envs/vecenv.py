@@ -70,6 +70,11 @@ class HipVectorEnv:
     def __len__(self):
         return self.env_num
 
+    def single_env_view(self):
+        """What the run scripts pass as `env` to trainers / EnvReplayBuffer: spaces of ONE env."""
+        return type("EnvView", (), dict(observation_space=self.single_observation_space,
+                                        action_space=self.single_action_space))()
+
     def seed(self, seed=None):  # vecenvs.py:259-277 (seed + i per env is the Philox key + env index here)
         return [seed] * self.env_num
 

@@ -154,6 +154,11 @@ class SoftActorCritic(Trainer):
     def log_alpha(self, v):
         _lib.check(self.ctx.lib.ilsx_sac_set_log_alpha(self.h, float(v)))
 
+    def grad_tensor(self, segment):
+        """torch tensor aliasing gradient-arena segment `segment` (SplitRunStep's trainer interface)."""
+        import torch
+        return torch.as_tensor(self.grads_view(segment), device=f"cuda:{self.ctx.device}")
+
     def grads_view(self, segment):
         """Non-owning device view of the gradient arena (0 = critics, 1 = actor + alpha slot) for the
         RCCL all-reduce: `torch.as_tensor(view, device='cuda')` aliases it."""

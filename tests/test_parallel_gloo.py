@@ -1,0 +1,116 @@
+"""CPU suite, world_size 2 over gloo: the N>1 plumbing (ilswiss_amd/parallel.py).  The compute engine behind
+the SplitRunStep interface here is the numpy oracle (no GPU in this container); on the GPU box the same
+orchestration drives libilsx (tests/test_hip_parity.py::test_sac_two_way_batch_split_matches_single checks
+the arithmetic of the split on the device)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ilswiss_amd.parallel import SplitRunStep, shard_batch, shard_items
+from oracle import mlp as omlp
+from oracle.sac_alpha import SacAlphaOracle
+
+KW = dict(reward_scale=1.0, discount=0.99, policy_lr=3e-4, qf_lr=3e-4, alpha_lr=3e-4, soft_target_tau=0.005,
+          alpha=0.2, train_alpha=True, policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3, beta_1=0.9)
+O, A, HID, B = 11, 3, [32, 32], 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_items_and_batch():
+    seeds = list(range(32))
+    parts = [shard_items(seeds, 8, r) for r in range(8)]
+    assert sum(parts, []) == seeds and all(len(p) == 4 for p in parts)      # config 5: 32 seeds on 8 GPUs
+    parts = [shard_items(range(10), 4, r) for r in range(4)]
+    assert [len(p) for p in parts] == [3, 3, 2, 2] and sum(parts, []) == list(range(10))
+    b = dict(x=np.arange(12).reshape(6, 2))
+    assert np.array_equal(shard_batch(b, 3, 1)["x"], b["x"][2:4])
+    with pytest.raises(ValueError):
+        shard_batch(b, 4, 0)
+
+
+class OracleTrainer:
+    """SplitRunStep's trainer interface over the numpy oracle; the gradient arenas are torch views."""
+
+    def __init__(self, world):
+        rng = np.random.default_rng(5)
+        self.o = SacAlphaOracle(O, A, HID, omlp.init_mlp(rng, O, HID, A, init_w=1e-3, n_heads=2),
+                                omlp.init_mlp(rng, O + A, HID, 1), omlp.init_mlp(rng, O + A, HID, 1), **KW)
+        self.o.grad_world = world
+
+    def set_batch(self, batch, e1, e2):
+        self.batch, self.e1, self.e2 = batch, e1, e2
+
+    def critic_backward(self):
+        self.o.critic_backward(self.batch, self.e1)
+
+    def critic_update(self):
+        self.o.critic_update()
+
+    def actor_backward(self):
+        self.o.actor_backward(self.e2)
+
+    def actor_update(self):
+        self.o.actor_update()
+
+    def grad_tensor(self, seg):
+        return torch.from_numpy(self.o.g_critic if seg == 0 else self.o.g_actor)  # shares memory
+
+
+def _data(steps):
+    rng = np.random.default_rng(9)
+    out = []
+    for _ in range(steps):
+        out.append((dict(observations=rng.normal(0, 1, (B, O)).astype(np.float32),
+                         actions=np.tanh(rng.normal(0, 1, (B, A))).astype(np.float32),
+                         rewards=rng.normal(0, 1, (B, 1)).astype(np.float32),
+                         terminals=(rng.random((B, 1)) < 0.1).astype(np.float32),
+                         next_observations=rng.normal(0, 1, (B, O)).astype(np.float32)),
+                    rng.normal(0, 1, (B, A)).astype(np.float32), rng.normal(0, 1, (B, A)).astype(np.float32)))
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = OracleTrainer(world)
+    step = SplitRunStep(tr)
+    for batch, e1, e2 in _data(3):
+        sl = slice(rank * B // world, (rank + 1) * B // world)
+        step.train_step(shard_batch(batch, world, rank), e1[sl], e2[sl])
+    q.put((rank, tr.o.pi.copy(), tr.o.q1.copy(), tr.o.tq2.copy(), float(tr.o.log_alpha[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_split_run_equals_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single = OracleTrainer(1)
+    for batch, e1, e2 in _data(3):
+        single.o.train_step(batch, e1, e2)
+    for r in res:  # every replica took the identical optimiser steps, == the un-split run up to fp32 summation order
+        np.testing.assert_array_equal(r[1], res[0][1])
+        np.testing.assert_allclose(r[1], single.o.pi, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r[2], single.o.q1, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r[3], single.o.tq2, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r[4], single.o.log_alpha[0], rtol=0, atol=1e-7)
