@@ -1,0 +1,172 @@
+"""The outer RL loop with the reference's knobs and log schema:
+`BaseAlgorithm.start_training / _try_to_train / _try_to_eval / evaluate` (rlkit/core/base_algorithm.py:
+166-348,599-656) + `TorchRLAlgorithm._do_training` (rlkit/torch/algorithms/torch_rl_algorithm.py:16-34),
+driven entirely on the device: one `rollout_step` per vec step (policy -> physics -> replay record ->
+auto-reset) and `trainer.train_from_replay` per train call.  `rl_alg_params` YAML keys are the kwargs.
+
+Log layout follows rlkit/launchers/launcher_util.py:209-297 + rlkit/core/logger.py:226-367:
+`<log_dir>/{variant.json, progress.csv, params.pkl, best.pkl, extra_data.pkl}`; column names of progress.csv
+are the reference's ("Test Returns Mean", "AverageReturn", "QF1 Loss", "Train Time (s)", ...).
+"""
+import csv
+import json
+import os
+import pickle
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from .networks import MakeDeterministic
+from .replay import EnvReplayBuffer
+from .samplers import VecPathSampler, get_average_returns, get_generic_path_information
+
+
+class TabularLogger:
+    """Minimal rllab-style tabular logger (rlkit/core/logger.py:226-227,300-336): stdout + progress.csv."""
+
+    def __init__(self, log_dir=None):
+        self.log_dir, self.row, self._header = log_dir, OrderedDict(), None
+        if log_dir:
+            os.makedirs(log_dir, exist_ok=True)
+
+    def record_tabular(self, k, v):
+        self.row[k] = v
+
+    def dump_tabular(self):
+        width = max(len(k) for k in self.row)
+        print("-" * (width + 18))
+        for k, v in self.row.items():
+            print(f"{k:<{width}}  {v:>14.6g}" if isinstance(v, (int, float, np.floating, np.integer)) else f"{k:<{width}}  {v}")
+        print("-" * (width + 18), flush=True)
+        if self.log_dir:
+            path = os.path.join(self.log_dir, "progress.csv")
+            new = self._header is None
+            if new:
+                self._header = list(self.row.keys())
+            with open(path, "a", newline="") as f:
+                w = csv.DictWriter(f, fieldnames=self._header, extrasaction="ignore")
+                if new:
+                    w.writeheader()
+                w.writerow(self.row)
+        self.row = OrderedDict()
+
+    def save(self, name, obj):
+        if self.log_dir:
+            with open(os.path.join(self.log_dir, name), "wb") as f:
+                pickle.dump(obj, f)
+
+
+class DeviceRLAlgorithm:
+    """TorchRLAlgorithm(trainer, env, training_env, eval_env, exploration_policy, **rl_alg_params)."""
+
+    def __init__(self, trainer, env, training_env, eval_env, exploration_policy, num_epochs=100,
+                 num_steps_per_epoch=10000, num_steps_between_train_calls=1000, num_train_steps_per_train_call=1000,
+                 num_steps_per_eval=1000, max_path_length=1000, min_steps_before_training=0, batch_size=256,
+                 replay_buffer_size=1000000, no_terminal=False, eval_deterministic=True, freq_saving=1, save_best=True,
+                 save_replay_buffer=False, replay_buffer=None, log_dir=None, best_key="AverageReturn", **kwargs):
+        if no_terminal:
+            raise NotImplementedError("no_terminal (used by the adv-IRL configs) arrives with the discriminator row")
+        self.trainer, self.env, self.training_env, self.eval_env = trainer, env, training_env, eval_env
+        self.exploration_policy = exploration_policy
+        self.num_epochs, self.num_env_steps_per_epoch = num_epochs, num_steps_per_epoch
+        self.num_steps_between_train_calls = num_steps_between_train_calls
+        self.num_train_steps_per_train_call = num_train_steps_per_train_call
+        self.num_steps_per_eval, self.max_path_length = num_steps_per_eval, max_path_length
+        self.min_steps_before_training, self.batch_size = min_steps_before_training, batch_size
+        self.freq_saving, self.save_best, self.best_key = freq_saving, save_best, best_key
+        self.env_num = len(training_env)
+        if replay_buffer is None:
+            seed = int(np.random.randint(10000))  # base_algorithm.py:118-120
+            replay_buffer = EnvReplayBuffer(replay_buffer_size, env, random_seed=seed, ctx=trainer.ctx)
+        self.replay_buffer = replay_buffer
+        eval_policy = MakeDeterministic(exploration_policy) if eval_deterministic else exploration_policy
+        self.eval_sampler = VecPathSampler(eval_env, eval_policy, num_steps_per_eval, max_path_length)
+        self.logger = TabularLogger(log_dir)
+        self._n_env_steps_total = self._n_train_steps_total = self._n_prev_train_env_steps = 0
+        self._n_rollouts_total, self.best_statistic_so_far = 0, -np.inf
+        self._t_sample = self._t_train = self._t_eval = 0.0
+
+    # base_algorithm.py:364-367
+    def _can_train(self):
+        return self.replay_buffer.num_steps_can_sample() >= max(self.min_steps_before_training, 1)
+
+    def train(self, start_epoch=0):
+        ctx = self.trainer.ctx
+        t_start = time.perf_counter()
+        for epoch in range(start_epoch, self.num_epochs + 1):  # num_epochs + 1 (base_algorithm.py:64)
+            t_epoch = time.perf_counter()
+            self._t_sample = self._t_train = 0.0
+            self.training_env.rollout_stats(reset=True)
+            for _ in range(self.num_env_steps_per_epoch // self.env_num):
+                t0 = time.perf_counter()
+                random_actions = self.replay_buffer.num_steps_can_sample() < self.min_steps_before_training
+                self.training_env.rollout_step(self.exploration_policy, self.replay_buffer, self.max_path_length,
+                                               random_actions=random_actions)
+                self._n_env_steps_total += self.env_num
+                if self._n_env_steps_total - self._n_prev_train_env_steps >= self.num_steps_between_train_calls:
+                    ctx.sync()
+                    t1 = time.perf_counter()
+                    self._t_sample += t1 - t0
+                    self._n_prev_train_env_steps = self._n_env_steps_total
+                    if self._can_train():
+                        self.trainer.train_from_replay(self.replay_buffer, self.num_train_steps_per_train_call, self.batch_size)
+                        self._n_train_steps_total += self.num_train_steps_per_train_call
+                        ctx.sync()
+                    self._t_train += time.perf_counter() - t1
+                else:
+                    self._t_sample += time.perf_counter() - t0
+            ctx.sync()
+            t0 = time.perf_counter()
+            self.evaluate(epoch, time.perf_counter() - t_epoch, time.perf_counter() - t_start)
+            self._t_eval = time.perf_counter() - t0
+            self.trainer.end_epoch()
+
+    def evaluate(self, epoch, epoch_time, total_time):
+        st = OrderedDict()
+        ts = self.trainer.get_eval_statistics()
+        if ts:
+            st.update(ts)
+        test_paths = self.eval_sampler.obtain_samples()
+        st.update(get_generic_path_information(test_paths, stat_prefix="Test"))
+        episodes, ret_sum = self.training_env.rollout_stats(reset=True)
+        self._n_rollouts_total += int(episodes)
+        if episodes > 0:
+            st["Exploration Returns Mean"] = ret_sum / episodes
+            st["Exploration Num Paths"] = episodes
+        st["AverageReturn"] = get_average_returns(test_paths)
+        lg = self.logger
+        for k, v in st.items():
+            lg.record_tabular(k, float(np.mean(v)))
+        # base_algorithm.py:322-343
+        lg.record_tabular("Number of train calls total", self._n_train_steps_total // max(self.num_train_steps_per_train_call, 1))
+        lg.record_tabular("Number of train steps total", self._n_train_steps_total)
+        lg.record_tabular("Number of env steps total", self._n_env_steps_total)
+        lg.record_tabular("Number of rollouts total", self._n_rollouts_total)
+        lg.record_tabular("Train Time (s)", self._t_train)
+        lg.record_tabular("(Previous) Eval Time (s)", self._t_eval)
+        lg.record_tabular("Sample Time (s)", self._t_sample)
+        lg.record_tabular("Epoch Time (s)", epoch_time)
+        lg.record_tabular("Total Train Time (s)", total_time)
+        lg.record_tabular("Epoch", epoch)
+        lg.dump_tabular()
+        snap = dict(epoch=epoch, statistics=dict(st))
+        if self.freq_saving and epoch % self.freq_saving == 0:
+            lg.save("params.pkl", dict(snap, **self.trainer.get_snapshot()))
+        if st[self.best_key] > self.best_statistic_so_far:
+            self.best_statistic_so_far = st[self.best_key]
+            if self.save_best:
+                lg.save("best.pkl", dict(snap, **self.trainer.get_snapshot()))
+        lg.save("extra_data.pkl", dict(_n_env_steps_total=self._n_env_steps_total,
+                                       _n_train_steps_total=self._n_train_steps_total, epoch=epoch))
+        return st
+
+
+def setup_log_dir(exp_name, exp_id, seed, variant, base_dir="logs"):
+    """logs/<exp-name>/<exp_name>_<timestamp>_<id>--s-<seed>/ + variant.json (launcher_util.py:209-297)."""
+    ts = time.strftime("%Y_%m_%d_%H_%M_%S")
+    d = os.path.join(base_dir, exp_name.replace("_", "-"), f"{exp_name}_{ts}_{exp_id:04d}--s-{seed}")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "variant.json"), "w") as f:
+        json.dump(variant, f, indent=2, sort_keys=True, default=str)
+    return d

@@ -1,0 +1,93 @@
+"""Evaluation sampler + path statistics: the reference's `VecPathSampler.obtain_samples` / `rollout`
+(rlkit/samplers/vec_sampler.py:5-142), `PathBuilder` (rlkit/data_management/path_builder.py:4-60) and
+`eval_util.get_generic_path_information` / `get_average_returns` (rlkit/core/eval_util.py:15-142).
+
+Semantics kept: reset every env, step the policy for up to `max_path_length`; an env that terminates is
+dropped from the ready set (no auto-reset), so one call yields exactly one episode per env; repeat until
+at least `num_steps` transitions were collected.  The column names produced by
+`get_generic_path_information` are the `progress.csv` schema curves are compared on.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+
+class PathBuilder(dict):
+    def __init__(self):
+        super().__init__()
+        self._path_length = 0
+
+    def add_all(self, **key_to_value):
+        for k, v in key_to_value.items():
+            self.setdefault(k, []).append(v)
+        self._path_length += 1
+
+    def __len__(self):
+        return self._path_length
+
+
+def rollout(env, policy, max_path_length, no_terminal=False):
+    n = len(env)
+    paths = [PathBuilder() for _ in range(n)]
+    ready = np.arange(n)
+    obs = env.reset(ready)
+    for _ in range(max_path_length):
+        actions = policy.get_actions(obs)
+        next_obs, rewards, terminals, infos = env.step(actions, ready)
+        if no_terminal:
+            terminals = np.zeros(len(ready), dtype=bool)
+        for i, e in enumerate(ready):
+            paths[e].add_all(observations=obs[i], actions=actions[i], rewards=np.array([rewards[i]]),
+                             next_observations=next_obs[i], terminals=np.array([terminals[i]]),
+                             absorbings=np.array([0.0, 0.0]), env_infos=infos[i])
+        terminals = np.asarray(terminals, dtype=bool)
+        obs = next_obs[~terminals]
+        if terminals.any():
+            ready = ready[~terminals]
+            if len(ready) == 0:
+                break
+    return paths
+
+
+class VecPathSampler:
+    def __init__(self, env, policy, num_steps, max_path_length, no_terminal=False, **kwargs):
+        self.env, self.policy = env, policy
+        self.num_steps, self.max_path_length, self.no_terminal = num_steps, max_path_length, no_terminal
+
+    def obtain_samples(self, num_steps=None):
+        paths, total = [], 0
+        num_steps = self.num_steps if num_steps is None else num_steps
+        while total < num_steps:
+            new = rollout(self.env, self.policy, self.max_path_length, no_terminal=self.no_terminal)
+            paths.extend(new)
+            total += sum(len(p) for p in new)
+        return paths
+
+
+def create_stats_ordered_dict(name, data, stat_prefix=None, always_show_all_stats=False):
+    """rlkit/core/eval_util.py create_stats_ordered_dict: `<prefix> <name> Mean/Std/Max/Min`."""
+    if stat_prefix is not None:
+        name = "{} {}".format(stat_prefix, name)
+    if isinstance(data, (list, tuple)) and len(data) and isinstance(data[0], (list, np.ndarray)):
+        data = np.concatenate([np.asarray(d).ravel() for d in data])
+    data = np.asarray(data, dtype=np.float64)
+    if data.size == 1 and not always_show_all_stats:
+        return OrderedDict({name: float(data.ravel()[0])})
+    return OrderedDict([(name + " Mean", np.mean(data)), (name + " Std", np.std(data)),
+                        (name + " Max", np.max(data)), (name + " Min", np.min(data))])
+
+
+def get_generic_path_information(paths, stat_prefix=""):
+    st = OrderedDict()
+    returns = [float(np.sum(p["rewards"])) for p in paths]
+    rewards = np.concatenate([np.asarray(p["rewards"]).ravel() for p in paths])
+    st.update(create_stats_ordered_dict("Rewards", rewards, stat_prefix, True))
+    st.update(create_stats_ordered_dict("Returns", returns, stat_prefix, True))
+    st.update(create_stats_ordered_dict("Actions", [np.asarray(p["actions"]) for p in paths], stat_prefix, True))
+    st.update(create_stats_ordered_dict("Ep. Len.", np.array([len(p["terminals"]) for p in paths]), stat_prefix, True))
+    st["Num Paths"] = len(paths)
+    return st
+
+
+def get_average_returns(paths):
+    return float(np.mean([np.sum(p["rewards"]) for p in paths]))
