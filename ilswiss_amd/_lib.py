@@ -54,8 +54,26 @@ class PlanarModel(C.Structure):  # ilsx_planar_model
                 ("ang_max", C.c_double), ("state_max", C.c_double), ("init_qpos", C.c_double * (_MB + 2))]
 
 
+class DiscCfg(C.Structure):  # ilsx_disc_cfg
+    _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("hid_dim", C.c_int32), ("hid_act", C.c_int32),
+                ("use_grad_pen", C.c_int32), ("clamp_magnitude", C.c_float), ("disc_lr", C.c_float),
+                ("disc_momentum", C.c_float), ("grad_pen_weight", C.c_float), ("max_batch", C.c_int32)]
+
+
+class DiscStats(C.Structure):
+    _fields_ = [("ce_loss", C.c_float), ("grad_pen", C.c_float), ("accuracy", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/ilsx.h declares
 PROTOTYPES = {
+    "ilsx_disc_create": (C.c_int, [vp, C.POINTER(DiscCfg), C.POINTER(vp)]),
+    "ilsx_disc_destroy": (C.c_int, [vp]),
+    "ilsx_disc_num_params": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "ilsx_disc_set_params": (C.c_int, [vp, vp, C.c_size_t]),
+    "ilsx_disc_get_params": (C.c_int, [vp, vp, C.c_size_t]),
+    "ilsx_disc_get_grads": (C.c_int, [vp, vp, C.c_size_t]),
+    "ilsx_disc_train_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(DiscStats)]),
+    "ilsx_disc_reward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, vp, vp]),
     "ilsx_vecenv_create": (C.c_int, [vp, C.POINTER(PlanarModel), C.c_int, C.c_uint64, C.POINTER(vp)]),
     "ilsx_vecenv_destroy": (C.c_int, [vp]),
     "ilsx_vecenv_dims": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

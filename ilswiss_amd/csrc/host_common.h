@@ -100,16 +100,13 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act, int cs = 1);
 int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P);
 // column-split factor the 2-hidden-layer fast path uses for width H (1 = generic kernels)
 int mlp2_split_factor(int n_hidden, int H);
-int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows);
+int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows, const AdamFuse* fuse = nullptr);
 int launch_adam(ilsx_ctx* ctx, const AdamArgs& A);
 // appends the dW/db jobs of one network to `jobs`
 void build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
                    float* const* dsave, const float* dhead, std::vector<DwJob>* jobs);
 
 // Replay ring: HBM-resident transition records + host mirror of the reference's cursors.
-struct DevReplayState {
-  long long size, top;
-};
 struct ilsx_replay {
   ilsx_ctx* ctx = nullptr;
   int64_t cap = 0;

@@ -170,7 +170,7 @@ extern "C" int ilsx_prof_read(ilsx_ctx* c, int kid, uint64_t* launches, double* 
 extern "C" const char* ilsx_kernel_name(int kid) {
   static const char* names[ILSX_K_COUNT] = {"k_mlp_fwd", "k_mlp_bwd_dx", "k_mlp_bwd_dw", "k_adam_polyak",
       "k_replay_sample", "k_replay_add", "k_replay_sample_many", "k_sac_stats", "k_sac_finish", "k_env_step",
-      "k_policy_finish", "", "", "", "", ""};
+      "k_policy_finish", "k_disc_bwd", "", "", "", ""};
   return (kid >= 0 && kid < ILSX_K_COUNT) ? names[kid] : "";
 }
 
@@ -406,10 +406,13 @@ int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P) {
   return ILSX_OK;
 }
 
-int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows) {
+int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows, const AdamFuse* fuse) {
   if (njobs <= 0 || rows <= 0) return ILSX_OK;
+  AdamFuse F;
+  memset(&F, 0, sizeof F);
+  if (fuse) F = *fuse;
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-  hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(njobs), dim3(1024), DW_LDS_BYTES, ctx->stream, jobs_dev, rows);
+  hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(njobs), dim3(1024), DW_LDS_BYTES, ctx->stream, jobs_dev, rows, F);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
@@ -435,6 +438,7 @@ void build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* 
         DwJob j;
         j.A = A; j.Bm = Bm; j.dW = dW; j.dWb = dWb; j.db = db;
         j.lda = lda; j.NA = NA; j.ldb = ldb; j.NB = NB; j.ldw = ldw; j.n0 = n0; j.k0 = k0; j.mode = mode;
+        j.rows = 0; j.bias_rows = 0;
         jobs->push_back(j);
       }
   };

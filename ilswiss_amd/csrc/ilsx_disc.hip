@@ -1,0 +1,510 @@
+// ilsx_disc.hip — adversarial-IRL discriminator: rlkit/torch/algorithms/adv_irl/adv_irl.py:133-216
+// (_do_reward_training: BCE-with-logits + WGAN-GP gradient penalty), :277-298 (reward modes) and
+// disc_models/simple_disc_models.py:8-48 (MLPDisc: Linear-act-Linear-act-Linear, clamp +-10, no BN).
+//
+// The reference gets the gradient-penalty gradient from autograd's double backward; here it is derived by
+// hand (oracle/disc.py) and fused into ONE row-tile kernel.  One step =
+//   k_disc_prep   X = [expert (B) ; policy (B) ; eps*expert + (1-eps)*policy (B)]
+//   forward       the shared MLP forward kernels over all 3B rows (h1, h2, raw logits kept)
+//   k_disc_bwd    per 16-row tile: CE rows -> delta2, delta1 ; GP rows -> dD/dx, its norm, and the whole
+//                 second-order chain (3 MFMA GEMMs with W2 / W2^T), written as ROW-STACKED operand
+//                 matrices so that every weight gradient is a single A^T.B contraction
+//   k_mlp_bwd_dw  3 stacked jobs: dW1 over 4B rows, dW2 over 4B rows, dw3 over 3B rows (bias rows limited)
+//   k_adam_polyak Adam(lr, betas=(disc_momentum, 0.999))
+//   k_disc_tail   losses / accuracy, step counter, Adam scalars of the next step
+#include <cmath>
+
+#include "host_common.h"
+
+struct DiscScalars {
+  float ce_loss, grad_pen, accuracy, pad;
+  float adam_step, adam_bc2s;
+  int t, pad1;
+};
+
+struct DiscBwdArgs {
+  NetView net;
+  int B, rows, use_gp, D;
+  float clamp, gp_w;
+  PartVal raw;
+  float* hs0;    // [4B][H]  rows < 3B: h1 (read); rows 3B..4B: v1-bar (written)
+  float* hs1;    // [3B][H]  h2 (read); GP rows are overwritten with u2-bar * phi2'
+  float* xs;     // [4B][KP] rows < 3B: X; rows 3B..4B: g-bar (written, zero-padded)
+  float* A2;     // [4B][H]  delta2 | z2-bar | u2
+  float* A1;     // [4B][H]  delta1 | z1-bar | gate*u1
+  float* dhead;  // [3B]     dL/dlogit for CE rows, 1 for GP rows
+  float *ce_row, *correct, *gp_row;
+};
+
+template <int ACT> __device__ __forceinline__ float d2act_from_out(float h) {  // d phi'(z)/dz in terms of h
+  if (ACT == ACT_RELU) return 0.0f;
+  return -2.0f * h * (1.0f - h * h);
+}
+
+__global__ void k_disc_prep(const float* __restrict__ eo, const float* __restrict__ ea, const float* __restrict__ po,
+                            const float* __restrict__ pa, const float* __restrict__ eps, int B, int o, int a, int use_gp,
+                            uint64_t seed, uint32_t stream, unsigned long long step, float* __restrict__ X,
+                            float* __restrict__ eps_used) {
+  const int D = o + a, e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * D) return;
+  const int r = e / D, c = e - r * D;
+  const float xe = c < o ? eo[(size_t)r * o + c] : ea[(size_t)r * a + (c - o)];
+  const float xp = c < o ? po[(size_t)r * o + c] : pa[(size_t)r * a + (c - o)];
+  X[(size_t)r * D + c] = xe;
+  X[(size_t)(B + r) * D + c] = xp;
+  if (use_gp) {
+    float w;
+    if (eps) {
+      w = eps[r];
+    } else {  // ptu.rand(B, 1): U[0,1) (adv_irl.py:184)
+      uint32_t ctr[4] = {(uint32_t)r >> 2, 0x44495343u, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream * 0x9E3779B9u)};
+      philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
+      w = (float)(ctr[r & 3] >> 8) * (1.0f / 16777216.0f);
+    }
+    X[(size_t)(2 * B + r) * D + c] = w * xe + (1.0f - w) * xp;   // adv_irl.py:187
+    if (c == 0 && eps_used) eps_used[r] = w;
+  }
+}
+
+template <int H, int ACT>
+__global__ __launch_bounds__(4 * H) void k_disc_bwd(const DiscBwdArgs A) {
+  constexpr int NW = H / 16, NTH = 4 * H, NC = H / 16, KPL = H / 64, RPW = 16 / NW;
+  constexpr int RPT = 16 * H / NTH, RSTEP = NTH / H;
+  constexpr int LDH = H + ILSX_LDS_PAD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bufA = smem;               // MFMA A operand of the current GEMM
+  float* bufB = bufA + 16 * LDH;    // v1, later phi1'-bar
+  float* bufC = bufB + 16 * LDH;    // u1, later z2-bar
+  float* gs = bufC + 16 * LDH;      // [16][64]  dD/dx, then g-bar
+  float* rowf = gs + 16 * 64;       // [16][4]   dlogit, gate, isgp
+  const NetView& N = A.net;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int r0 = blockIdx.x * 16, rows = A.rows, B = A.B, KP = N.KP, D = A.D;
+  const int k1 = tid % H, rb1 = tid / H, c0 = wave * 16, col = c0 + li;
+  const float* Wh = N.base + N.off_Wh;
+
+  // ---- operands of every phase, requested up front
+  float h1v[RPT], h2v[RPT], h1m[4], h2m[4];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int gr = r0 + rb1 + RSTEP * i;
+    h1v[i] = gr < rows ? A.hs0[(size_t)gr * H + k1] : 0.0f;
+    h2v[i] = gr < rows ? A.hs1[(size_t)gr * H + k1] : 0.0f;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int gr = r0 + 4 * g + v;
+    h1m[v] = gr < rows ? A.hs0[(size_t)gr * H + col] : 0.0f;
+    h2m[v] = gr < rows ? A.hs1[(size_t)gr * H + col] : 0.0f;
+  }
+  const float w3k = Wh[k1], w3m = Wh[col];
+  float4 wreg[NC];
+  {
+    const float* wp = N.base + N.off_Wb[1] + (size_t)wave * NC * 256 + 4 * lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+  }
+  // ---- per-row loss head: BCE-with-logits through the clamp gate (adv_irl.py:176-179, simple_disc_models.py:45-47)
+  if (tid < 16) {
+    const int gr = r0 + tid;
+    float dl = 0.0f, gate = 0.0f, isgp = 0.0f;
+    if (gr < rows) {
+      const float raw = A.raw.get(gr);
+      gate = (raw >= -A.clamp && raw <= A.clamp) ? 1.0f : 0.0f;
+      const float l = fminf(fmaxf(raw, -A.clamp), A.clamp);
+      if (gr < 2 * B) {
+        const float t = gr < B ? 1.0f : 0.0f;
+        dl = gate * (1.0f / (1.0f + expf(-l)) - t) / (float)(2 * B);
+        A.ce_row[gr] = fmaxf(l, 0.0f) - l * t + log1pf(expf(-fabsf(l)));
+        A.correct[gr] = ((l > 0.0f) == (t > 0.5f)) ? 1.0f : 0.0f;
+        A.dhead[gr] = dl;
+      } else {
+        isgp = 1.0f;
+        A.dhead[gr] = 1.0f;   // the "ones" rows that carry (u2-bar * phi2') into dw3
+      }
+    }
+    rowf[tid * 4 + 0] = dl; rowf[tid * 4 + 1] = gate; rowf[tid * 4 + 2] = isgp;
+  }
+  __syncthreads();
+  // ---- GEMM 1 operand: CE rows delta2 = dlogit*w3*phi2' ; GP rows u2 = phi2'*w3
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int row = rb1 + RSTEP * i, gr = r0 + row;
+    const bool gp = rowf[row * 4 + 2] > 0.5f;
+    const float p2 = act_grad_from_out<ACT>(h2v[i]);
+    float val = 0.0f;
+    if (gr < rows) {
+      val = gp ? p2 * w3k : rowf[row * 4 + 0] * w3k * p2;
+      A.A2[(size_t)(gp ? gr + B : gr) * H + k1] = val;
+    }
+    bufA[row * LDH + k1] = val;
+  }
+  __syncthreads();
+  auto gemm = [&](const float* src) {
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const float* ap = src + li * LDH + 4 * g;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
+      acc0 = MFMA16(a.x, wreg[c].x, acc0); acc1 = MFMA16(a.y, wreg[c].y, acc1);
+      acc0 = MFMA16(a.z, wreg[c].z, acc0); acc1 = MFMA16(a.w, wreg[c].w, acc1);
+    }
+    return acc0 + acc1;
+  };
+  // ---- GEMM 1 (x W2): CE rows -> delta1 ; GP rows -> v1, u1
+  {
+    const f32x4 acc = gemm(bufA);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 4 * g + v, gr = r0 + row;
+      const bool gp = rowf[row * 4 + 2] > 0.5f;
+      const float p1 = act_grad_from_out<ACT>(h1m[v]);
+      float v1 = 0.0f, u1 = 0.0f;
+      if (gr < rows) {
+        if (!gp) {
+          A.A1[(size_t)gr * H + col] = acc[v] * p1;
+        } else {
+          v1 = acc[v]; u1 = p1 * v1;
+          A.A1[(size_t)(gr + B) * H + col] = rowf[row * 4 + 1] * u1;
+        }
+      }
+      bufB[row * LDH + col] = v1;
+      bufC[row * LDH + col] = u1;
+    }
+  }
+  if (!A.use_gp || r0 + 15 < 2 * B) return;   // tile has no gradient-penalty row (workgroup-uniform)
+  __syncthreads();
+  // ---- g = gate * u1 W1 (dD/dx), its norm, g-bar = dGP/dg    (wave <-> rows, lanes split H)
+  const float* W1 = N.base + N.off_W[0];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = wave * RPW + rr, gr = r0 + row;
+    float uv[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) uv[i] = bufC[row * LDH + lane + 64 * i];
+    float mine = 0.0f;
+    for (int d = 0; d < D; ++d) {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < KPL; ++i) s = fmaf(uv[i], W1[pack_f(lane + 64 * i, d, KP)], s);
+      s = wave_sum(s);
+      if (lane == d) mine = s * rowf[row * 4 + 1];
+    }
+    float sq = wave_sum(mine * mine);
+    const float n = sqrtf(sq);
+    const bool gp = rowf[row * 4 + 2] > 0.5f && gr < rows;
+    const float coef = gp ? A.gp_w / (float)B * 2.0f * (n - 1.0f) / n : 0.0f;   // adv_irl.py:201-202
+    const float gb = coef * mine;
+    gs[row * 64 + lane] = gb;
+    if (gp) {
+      if (lane < KP) A.xs[(size_t)(gr + B) * KP + lane] = gb;
+      if (lane == 0) A.gp_row[gr - 2 * B] = (n - 1.0f) * (n - 1.0f);
+    }
+  }
+  __syncthreads();
+  // ---- u1-bar = gate * g-bar W1^T ; v1-bar = u1-bar*phi1' ; phi1'-bar = u1-bar*v1   (thread <-> column k1)
+  {
+    const float* wp = N.base + N.off_W[1] + (size_t)wave * NC * 256 + 4 * lane;   // W2 forward-packed for GEMM 2
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+    float ub[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) ub[i] = 0.0f;
+    for (int d4 = 0; d4 < KP; d4 += 4) {
+      const float4 w = *reinterpret_cast<const float4*>(W1 + pack_f(k1, d4, KP));
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const float* gr_ = gs + (rb1 + RSTEP * i) * 64 + d4;
+        ub[i] = fmaf(gr_[0], w.x, ub[i]); ub[i] = fmaf(gr_[1], w.y, ub[i]);
+        ub[i] = fmaf(gr_[2], w.z, ub[i]); ub[i] = fmaf(gr_[3], w.w, ub[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int row = rb1 + RSTEP * i, gr = r0 + row;
+      const bool gp = rowf[row * 4 + 2] > 0.5f && gr < rows;
+      const float u1b = gp ? rowf[row * 4 + 1] * ub[i] : 0.0f;
+      const float v1 = bufB[row * LDH + k1];
+      const float v1b = u1b * act_grad_from_out<ACT>(h1v[i]);
+      bufA[row * LDH + k1] = v1b;
+      bufB[row * LDH + k1] = u1b * v1;           // phi1'-bar
+      if (gp) A.hs0[(size_t)(gr + B) * H + k1] = v1b;
+    }
+  }
+  __syncthreads();
+  // ---- GEMM 2 (x W2^T): u2-bar ; z2-bar = u2-bar*w3*phi2'' ; (u2-bar*phi2') -> the stacked dw3 operand
+  {
+    const f32x4 acc = gemm(bufA);
+    {
+      const float* wp = N.base + N.off_Wb[1] + (size_t)wave * NC * 256 + 4 * lane;   // W2 backward-packed for GEMM 3
+#pragma unroll
+      for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 4 * g + v, gr = r0 + row;
+      const bool gp = rowf[row * 4 + 2] > 0.5f && gr < rows;
+      float z2b = 0.0f;
+      if (gp) {
+        z2b = acc[v] * w3m * d2act_from_out<ACT>(h2m[v]);
+        A.A2[(size_t)gr * H + col] = z2b;
+        A.hs1[(size_t)gr * H + col] = acc[v] * act_grad_from_out<ACT>(h2m[v]);
+      }
+      bufC[row * LDH + col] = z2b;
+    }
+  }
+  __syncthreads();
+  // ---- GEMM 3 (x W2): h1-bar ; z1-bar = h1-bar*phi1' + phi1'-bar*phi1''
+  {
+    const f32x4 acc = gemm(bufC);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 4 * g + v, gr = r0 + row;
+      if (rowf[row * 4 + 2] > 0.5f && gr < rows)
+        A.A1[(size_t)gr * H + col] = acc[v] * act_grad_from_out<ACT>(h1m[v]) + bufB[row * LDH + col] * d2act_from_out<ACT>(h1m[v]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_disc_tail(DiscScalars* sc, const float* ce_row, const float* correct,
+                                                   const float* gp_row, int B, int use_gp, float lr, float b1, float b2) {
+  __shared__ float sh[4];
+  float ce = 0.f, ac = 0.f, gp = 0.f;
+  for (int r = threadIdx.x; r < 2 * B; r += 256) { ce += ce_row[r]; ac += correct[r]; }
+  if (use_gp) for (int r = threadIdx.x; r < B; r += 256) gp += gp_row[r];
+  ce = block256_sum(ce, sh); ac = block256_sum(ac, sh); gp = block256_sum(gp, sh);
+  if (threadIdx.x == 0) {
+    sc->ce_loss = ce / (float)(2 * B);
+    sc->accuracy = ac / (float)(2 * B);
+    sc->grad_pen = use_gp ? gp / (float)B : 0.0f;
+    sc->t += 1;
+    const int t = sc->t + 1;
+    sc->adam_step = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+    sc->adam_bc2s = (float)sqrt(1.0 - pow((double)b2, (double)t));
+  }
+}
+__global__ void k_disc_refresh(DiscScalars* sc, float lr, float b1, float b2) {
+  const int t = sc->t + 1;
+  sc->adam_step = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+  sc->adam_bc2s = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+
+// reward relabelling (adv_irl.py:277-298) from raw logits
+__global__ void k_disc_reward(PartVal raw, int n, float clamp, int mode, int has_min, float rmin, int has_max, float rmax,
+                              float* __restrict__ rew, float* __restrict__ logits) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const float x = fminf(fmaxf(raw.get(r), -clamp), clamp);
+  float v;
+  if (mode == ILSX_DISC_AIRL) v = x;
+  else if (mode == ILSX_DISC_GAIL) v = x > 20.0f ? x : log1pf(expf(x));                 // F.softplus(x, beta=1)
+  else if (mode == ILSX_DISC_GAIL2) v = -x > 20.0f ? x : -log1pf(expf(-x));             // F.softplus(x, beta=-1)
+  else v = expf(x) * (-1.0f * x);                                                        // fairl
+  if (has_max) v = fminf(v, rmax);
+  if (has_min) v = fmaxf(v, rmin);
+  if (rew) rew[r] = v;
+  if (logits) logits[r] = x;
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct ilsx_disc {
+  ilsx_ctx* ctx = nullptr;
+  ilsx_disc_cfg cfg;
+  NetLayout L;
+  int cs = 1, D = 0, o = 0, a = 0;
+  float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
+  DiscScalars* scal = nullptr;
+  float *X = nullptr, *xs = nullptr, *hs0 = nullptr, *hs1 = nullptr, *A2 = nullptr, *A1 = nullptr, *dhead = nullptr;
+  float *raw = nullptr, *ce_row = nullptr, *correct = nullptr, *gp_row = nullptr, *eps_used = nullptr;
+  DwJob* jobs = nullptr;
+  int njobs = 0, jobs_B = -1;
+  uint32_t rng_stream = 0;
+  unsigned long long step_ctr = 0;
+  PartVal pv() const { return PartVal{raw, cs, 3 * cfg.max_batch}; }
+};
+
+static int disc_refresh(ilsx_disc* d) {
+  hipLaunchKernelGGL(k_disc_refresh, dim3(1), dim3(1), 0, d->ctx->stream, d->scal, d->cfg.disc_lr, d->cfg.disc_momentum, 0.999f);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_disc** out) {
+  if (!ctx || !cfg || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_disc_create: NULL argument");
+  if (cfg->obs_dim < 1 || cfg->act_dim < 1 || cfg->obs_dim + cfg->act_dim > 64)
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "discriminator input obs+act=%d: this kernel supports up to 64", cfg->obs_dim + cfg->act_dim);
+  if (cfg->max_batch < 1) ILSX_FAIL(ILSX_ERR_ARG, "max_batch must be >= 1");
+  HIPCHK(hipSetDevice(ctx->device));
+  ilsx_disc* d = new ilsx_disc();
+  d->ctx = ctx; d->cfg = *cfg; d->o = cfg->obs_dim; d->a = cfg->act_dim; d->D = d->o + d->a;
+  ilsx_mlp_cfg mc = {d->D, 2, cfg->hid_dim, 1, 1, cfg->hid_act};
+  int rc = net_layout_build(mc, &d->L);
+  if (rc != ILSX_OK) { delete d; return rc; }
+  d->cs = getenv("ILSX_NO_SPLIT") ? 1 : mlp2_split_factor(2, cfg->hid_dim);
+  d->rng_stream = ctx->next_rng_stream++;
+  const size_t n = d->L.n_int, B = (size_t)cfg->max_batch, H = (size_t)cfg->hid_dim, KP = (size_t)d->L.KP;
+  auto A = [&](float** p, size_t cnt) { return ctx_alloc(ctx, cnt * sizeof(float), (void**)p, true); };
+  rc = A(&d->P, n);
+  if (rc == ILSX_OK) rc = A(&d->G, n);
+  if (rc == ILSX_OK) rc = A(&d->M, n);
+  if (rc == ILSX_OK) rc = A(&d->V, n);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(DiscScalars), (void**)&d->scal);
+  if (rc == ILSX_OK) rc = A(&d->X, 3 * B * d->D);
+  if (rc == ILSX_OK) rc = A(&d->xs, 4 * B * KP);
+  if (rc == ILSX_OK) rc = A(&d->hs0, 4 * B * H);
+  if (rc == ILSX_OK) rc = A(&d->hs1, 3 * B * H);
+  if (rc == ILSX_OK) rc = A(&d->A2, 4 * B * H);
+  if (rc == ILSX_OK) rc = A(&d->A1, 4 * B * H);
+  if (rc == ILSX_OK) rc = A(&d->dhead, 3 * B);
+  if (rc == ILSX_OK) rc = A(&d->raw, (size_t)d->cs * 3 * B);
+  if (rc == ILSX_OK) rc = A(&d->ce_row, 2 * B);
+  if (rc == ILSX_OK) rc = A(&d->correct, 2 * B);
+  if (rc == ILSX_OK) rc = A(&d->gp_row, B);
+  if (rc == ILSX_OK) rc = A(&d->eps_used, B);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, 256 * sizeof(DwJob), (void**)&d->jobs);
+  if (rc == ILSX_OK) rc = disc_refresh(d);
+  if (rc != ILSX_OK) { delete d; return rc; }
+  *out = d;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_disc_destroy(ilsx_disc* d) {
+  if (!d) return ILSX_OK;
+  void* ps[] = {d->P, d->G, d->M, d->V, d->scal, d->X, d->xs, d->hs0, d->hs1, d->A2, d->A1, d->dhead, d->raw, d->ce_row,
+                d->correct, d->gp_row, d->eps_used, d->jobs};
+  for (void* p : ps) ctx_free(d->ctx, p);
+  delete d;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_disc_num_params(const ilsx_disc* d, size_t* out) {
+  if (!d || !out) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  *out = d->L.n_flat;
+  return ILSX_OK;
+}
+extern "C" int ilsx_disc_set_params(ilsx_disc* d, const float* src, size_t n) {
+  if (!d || !src) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(d->ctx->device));
+  return net_upload_flat(d->ctx, d->L, d->P, src, n, 0);
+}
+extern "C" int ilsx_disc_get_params(ilsx_disc* d, float* dst, size_t n) {
+  if (!d || !dst) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(d->ctx->device));
+  return net_download_flat(d->ctx, d->L, d->P, dst, n, 0);
+}
+extern "C" int ilsx_disc_get_grads(ilsx_disc* d, float* dst, size_t n) {
+  if (!d || !dst) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(d->ctx->device));
+  return net_download_flat(d->ctx, d->L, d->G, dst, n, 0);
+}
+
+// shared forward over `rows` rows of X (row stride D): raw head partials -> d->raw, optional activation saves
+static int disc_forward(ilsx_disc* d, const float* x0, int d0, int s0, const float* x1, int d1, int s1, int rows, bool save) {
+  FwdArgs A;
+  memset(&A, 0, sizeof A);
+  A.rows = rows; A.ntasks = 1; A.seed = d->ctx->seed; A.part_stride = 3 * d->cfg.max_batch;
+  FwdTask& t = A.t[0];
+  t.net = net_view(d->L, d->P);
+  t.x0 = x0; t.d0 = d0; t.s0 = s0; t.x1 = x1; t.d1 = d1; t.s1 = s1;
+  if (save) { t.xsave = d->xs; t.hsave[0] = d->hs0; t.hsave[1] = d->hs1; }
+  t.head = HEAD_RAW;
+  if (d->cs > 1) t.part = d->raw; else t.out = d->raw;
+  return launch_fwd(d->ctx, A, d->cfg.hid_dim, d->cfg.hid_act, d->L.KP, d->cs);
+}
+
+static int disc_build_jobs(ilsx_disc* d, int B) {
+  if (d->jobs_B == B) return ILSX_OK;
+  const int H = d->cfg.hid_dim, KP = d->L.KP, gp = d->cfg.use_grad_pen ? 1 : 0;
+  const int rows_h = gp ? 4 * B : 2 * B, bias_h = gp ? 3 * B : 2 * B, rows_o = gp ? 3 * B : 2 * B;
+  std::vector<DwJob> jobs;
+  auto add = [&](const float* A, int lda, int NA, const float* Bm, int ldb, int NB, float* dW, float* dWb, int ldw, float* db,
+                 int mode, int rows, int brows) {
+    for (int n0 = 0; n0 < NA; n0 += DW_TILE_N)
+      for (int k0 = 0; k0 < NB; k0 += DW_TILE_K) {
+        DwJob j;
+        j.A = A; j.Bm = Bm; j.dW = dW; j.dWb = dWb; j.db = db;
+        j.lda = lda; j.NA = NA; j.ldb = ldb; j.NB = NB; j.ldw = ldw; j.n0 = n0; j.k0 = k0; j.mode = mode;
+        j.rows = rows; j.bias_rows = brows;
+        jobs.push_back(j);
+      }
+  };
+  const NetLayout& L = d->L;
+  add(d->A1, H, H, d->xs, KP, KP, d->G + L.off_W[0], nullptr, KP, d->G + L.off_b[0], DW_OUT_PACK_F, rows_h, bias_h);
+  add(d->A2, H, H, d->hs0, H, H, d->G + L.off_W[1], d->G + L.off_Wb[1], H, d->G + L.off_b[1], DW_OUT_PACK_FB, rows_h, bias_h);
+  add(d->dhead, 1, 1, d->hs1, H, H, d->G + L.off_Wh, nullptr, H, d->G + L.off_bh, DW_OUT_NATURAL, rows_o, 2 * B);
+  if (jobs.size() > 256) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "too many dW jobs");
+  HIPCHK(hipMemcpyAsync(d->jobs, jobs.data(), jobs.size() * sizeof(DwJob), hipMemcpyHostToDevice, d->ctx->stream));
+  HIPCHK(hipStreamSynchronize(d->ctx->stream));
+  d->njobs = (int)jobs.size();
+  d->jobs_B = B;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_disc_train_step(ilsx_disc* d, const float* exp_obs, const float* exp_act, const float* pol_obs,
+                                    const float* pol_act, int B, const float* eps, ilsx_disc_stats* stats) {
+  if (!d || !exp_obs || !exp_act || !pol_obs || !pol_act) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_disc_train_step: NULL argument");
+  if (B < 1 || B > d->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch=%d", B, d->cfg.max_batch);
+  ilsx_ctx* ctx = d->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  ILSX_TRY(disc_build_jobs(d, B));
+  const int gp = d->cfg.use_grad_pen ? 1 : 0, rows = gp ? 3 * B : 2 * B, H = d->cfg.hid_dim;
+  {
+    const int tot = B * d->D;
+    hipLaunchKernelGGL(k_disc_prep, dim3((tot + 255) / 256), dim3(256), 0, ctx->stream, exp_obs, exp_act, pol_obs, pol_act, eps,
+                       B, d->o, d->a, gp, ctx->seed, d->rng_stream, ++d->step_ctr, d->X, d->eps_used);
+    HIPCHK(hipGetLastError());
+  }
+  ILSX_TRY(disc_forward(d, d->X, d->D, d->D, nullptr, 0, 0, rows, true));
+  {
+    DiscBwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.net = net_view(d->L, d->P);
+    A.B = B; A.rows = rows; A.use_gp = gp; A.D = d->D;
+    A.clamp = d->cfg.clamp_magnitude; A.gp_w = d->cfg.grad_pen_weight;
+    A.raw = d->pv();
+    A.hs0 = d->hs0; A.hs1 = d->hs1; A.xs = d->xs; A.A2 = d->A2; A.A1 = d->A1; A.dhead = d->dhead;
+    A.ce_row = d->ce_row; A.correct = d->correct; A.gp_row = d->gp_row;
+    const size_t lds = sizeof(float) * (3 * 16 * (H + ILSX_LDS_PAD) + 16 * 64 + 16 * 4);
+    dim3 grid((rows + 15) / 16), block(4 * H);
+    ProfScope ps(ctx, ILSX_K_DISC_BWD);
+    if (d->cfg.hid_act == ILSX_ACT_TANH) {
+      if (H == 64) hipLaunchKernelGGL((k_disc_bwd<64, ACT_TANH>), grid, block, lds, ctx->stream, A);
+      else if (H == 128) hipLaunchKernelGGL((k_disc_bwd<128, ACT_TANH>), grid, block, lds, ctx->stream, A);
+      else hipLaunchKernelGGL((k_disc_bwd<256, ACT_TANH>), grid, block, lds, ctx->stream, A);
+    } else {
+      if (H == 64) hipLaunchKernelGGL((k_disc_bwd<64, ACT_RELU>), grid, block, lds, ctx->stream, A);
+      else if (H == 128) hipLaunchKernelGGL((k_disc_bwd<128, ACT_RELU>), grid, block, lds, ctx->stream, A);
+      else hipLaunchKernelGGL((k_disc_bwd<256, ACT_RELU>), grid, block, lds, ctx->stream, A);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  ILSX_TRY(launch_bwd_dw(ctx, d->jobs, d->njobs, rows));
+  AdamArgs Ad;
+  Ad.p = d->P; Ad.g = d->G; Ad.m = d->M; Ad.v = d->V; Ad.tgt = nullptr; Ad.n = (int)d->L.n_int;
+  Ad.b1 = d->cfg.disc_momentum; Ad.b2 = 0.999f; Ad.eps = 1e-8f; Ad.tau = 0.f;
+  Ad.step_size = &d->scal->adam_step; Ad.bc2_sqrt = &d->scal->adam_bc2s;
+  ILSX_TRY(launch_adam(ctx, Ad));
+  hipLaunchKernelGGL(k_disc_tail, dim3(1), dim3(256), 0, ctx->stream, d->scal, d->ce_row, d->correct, d->gp_row, B, gp,
+                     d->cfg.disc_lr, d->cfg.disc_momentum, 0.999f);
+  HIPCHK(hipGetLastError());
+  if (stats) {
+    DiscScalars h;
+    HIPCHK(hipMemcpyAsync(&h, d->scal, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    stats->ce_loss = h.ce_loss; stats->grad_pen = h.grad_pen; stats->accuracy = h.accuracy;
+  }
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_disc_reward(ilsx_disc* d, const float* obs, const float* act, int n, int mode, int has_min, float rmin,
+                                int has_max, float rmax, float* rew, float* logits) {
+  if (!d || !obs || !act || (!rew && !logits)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_disc_reward: NULL argument");
+  if (n < 1 || n > 3 * d->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "n=%d not in 1..3*max_batch", n);
+  if (mode < 0 || mode > 3) ILSX_FAIL(ILSX_ERR_ARG, "unknown reward mode %d", mode);
+  HIPCHK(hipSetDevice(d->ctx->device));
+  ILSX_TRY(disc_forward(d, obs, d->o, d->o, act, d->a, d->a, n, false));
+  hipLaunchKernelGGL(k_disc_reward, dim3((n + 255) / 256), dim3(256), 0, d->ctx->stream, d->pv(), n, d->cfg.clamp_magnitude,
+                     mode, has_min, rmin, has_max, rmax, rew, logits);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}

@@ -30,13 +30,6 @@ __global__ void k_replay_set_state(DevReplayState* s, long long size, long long 
   s->top = top;
 }
 
-__device__ __forceinline__ long long replay_draw(uint64_t seed, uint64_t step, uint32_t stream, uint32_t r, long long size) {
-  uint32_t c[4] = {r >> 2, 0x52425546u /* 'RBUF' */, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream * 0x9E3779B9u)};
-  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
-  const uint32_t u = c[r & 3];
-  return (long long)(((unsigned long long)u * (unsigned long long)size) >> 32);  // uniform on [0,size), with replacement
-}
-
 // random_batch: one thread per (row, record column); splits the record into the reference's batch keys.
 __global__ __launch_bounds__(256) void k_replay_sample(const float* __restrict__ data, int rec, const DevReplayState* st,
                                                        const long long* __restrict__ idx, uint64_t seed, uint32_t stream,

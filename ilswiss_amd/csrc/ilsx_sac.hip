@@ -41,6 +41,8 @@ struct ilsx_sac {
   SacWs ws;
   DwJob *jobs_q = nullptr, *jobs_p = nullptr;
   int njobs_q = 0, njobs_p = 0;
+  ilsx_replay* gather_rb = nullptr;  // train_from_replay: the first forward launch draws its rows from this ring
+  bool fuse_now = false;     // this step applies Adam(+Polyak) inside the dW epilogue (not in split-run phases)
   int cs = 1;                // column-split factor of the 2-hidden-layer fast path (1 = generic kernels)
   int B = 0;                 // rows of the batch currently staged
   bool eps_explicit = false;
@@ -75,7 +77,7 @@ struct StatsArgs {
 };
 
 // single workgroup: losses of sac_alpha.py:122-123,148-153,161-162 + the alpha gradient
-__global__ __launch_bounds__(256) void k_sac_stats(const StatsArgs S) {
+__device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
   __shared__ float sh[4];
   const float alpha = S.scal->alpha;
   float l1 = 0, l2 = 0, pl = 0, lp = 0, mu2 = 0, ls2 = 0, mus = 0, lss = 0, q1s = 0, q2s = 0, lpe = 0;
@@ -119,8 +121,10 @@ __device__ __host__ inline void adam_scalars(double lr, double b1, double b2, in
   *bc2s = (float)sqrt(1.0 - pow(b2, (double)t));
 }
 
-__global__ void k_sac_finish(DevScalars* sc, const float* alpha_grad_slot, int train_alpha, float lr, float b1,
-                             float b2, float eps, float qf_lr, float policy_lr) {
+__global__ __launch_bounds__(256) void k_sac_stats(const StatsArgs S) { sac_stats_dev(S); }
+
+__device__ __forceinline__ void sac_finish_dev(DevScalars* sc, const float* alpha_grad_slot, int train_alpha, float lr,
+                                               float b1, float b2, float eps, float qf_lr, float policy_lr) {
   if (train_alpha) {
     const double g = (double)alpha_grad_slot[0];
     const int t = sc->t_alpha + 1;
@@ -137,6 +141,16 @@ __global__ void k_sac_finish(DevScalars* sc, const float* alpha_grad_slot, int t
   sc->step += 1;
   adam_scalars(qf_lr, b1, b2, sc->t_q + 1, &sc->adam_q_step, &sc->adam_q_bc2s);
   adam_scalars(policy_lr, b1, b2, sc->t_pi + 1, &sc->adam_pi_step, &sc->adam_pi_bc2s);
+}
+__global__ void k_sac_finish(DevScalars* sc, const float* alpha_grad_slot, int train_alpha, float lr, float b1,
+                             float b2, float eps, float qf_lr, float policy_lr) {
+  sac_finish_dev(sc, alpha_grad_slot, train_alpha, lr, b1, b2, eps, qf_lr, policy_lr);
+}
+// stats + alpha Adam + counters in ONE launch (the un-split step: nothing has to be all-reduced in between)
+__global__ __launch_bounds__(256) void k_sac_tail(const StatsArgs S, int train_alpha, float lr, float b1, float b2,
+                                                  float eps, float qf_lr, float policy_lr) {
+  sac_stats_dev(S);
+  if (threadIdx.x == 0) sac_finish_dev(S.scal, S.alpha_grad_slot, train_alpha, lr, b1, b2, eps, qf_lr, policy_lr);
 }
 
 // device-side (re)computation of the Adam scalars so every path uses the same pow()
@@ -288,16 +302,17 @@ static void sac_policy_task(ilsx_sac* s, FwdTask& t, const float* obs, const flo
     if (save) { t.out = w.raw; t.eps_save = w.epss; }
   }
 }
-static int sac_policy_finish(ilsx_sac* s, const float* eps, uint32_t stream, bool save, float* action, float* logp) {
-  if (s->cs == 1) return ILSX_OK;
+// the policy's tanh-Gaussian epilogue runs in the prologue of the launch that consumes its actions (column-split path)
+static void sac_policy_fin(ilsx_sac* s, FwdArgs& A, const float* eps, uint32_t stream, bool save, float* action, float* logp) {
+  if (s->cs == 1) return;
   const SacWs& w = s->ws;
-  PolicyFinishArgs P;
+  PolicyFinishArgs& P = A.fin;
   memset(&P, 0, sizeof P);
   P.part = w.ppart; P.cs = s->cs; P.part_stride = s->cfg.max_batch; P.rows = s->B; P.a = s->a;
   P.head = HEAD_TANH_SAMPLE; P.rng_stream = stream; P.seed = s->ctx->seed; P.scal = s->scal;
   P.eps = eps; P.action = action; P.logp = logp;
   if (save) { P.raw = w.raw; P.eps_save = w.epss; }
-  return launch_policy_finish(s->ctx, P);
+  A.fin_on = 1;
 }
 static void sac_q_task(ilsx_sac* s, FwdTask& q, int which, const float* obs, const float* act, float* out, bool save_x,
                        bool save_h, int i) {
@@ -321,8 +336,17 @@ static int sac_critic_backward(ilsx_sac* s) {
     sac_policy_task(s, A.t[0], w.s2, eps1, s->rng_stream, false, w.a2, w.logp2);
     sac_q_task(s, A.t[1], W_Q1, w.s, w.a, w.q1, true, true, 0);
     sac_q_task(s, A.t[2], W_Q2, w.s, w.a, w.q2, true, true, 1);
+    if (s->gather_rb && cs > 1) {  // fused sample+index: rows are drawn from the ring inside this launch
+      ilsx_replay* rb = s->gather_rb;
+      GatherSpec& G = A.gather;
+      G.records = rb->data; G.st = rb->dstate; G.rec = rb->rec; G.seed = rb->seed; G.stream = rb->rng_stream;
+      G.o = s->o; G.adim = s->a; G.on = 1;
+      G.s = w.s; G.a = w.a; G.r = w.r; G.d = w.d; G.s2 = w.s2;
+      A.t[0].g0_off = s->o + s->a + 2; A.t[0].publish = 2;               // pi reads next_obs
+      A.t[1].g0_off = 0; A.t[1].g1_off = s->o; A.t[1].publish = 1;      // Q1 reads (obs, act) and publishes s,a,r,d
+      A.t[2].g0_off = 0; A.t[2].g1_off = s->o; A.t[2].publish = 0;
+    }
     ILSX_TRY(launch_fwd(s->ctx, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
-    ILSX_TRY(sac_policy_finish(s, eps1, s->rng_stream, false, w.a2, w.logp2));
   }
   {  // fwd: TQ1(s',a'), TQ2(s',a')
     FwdArgs A;
@@ -330,6 +354,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
     sac_q_task(s, A.t[0], W_TQ1, w.s2, w.a2, w.tq1, false, false, 0);
     sac_q_task(s, A.t[1], W_TQ2, w.s2, w.a2, w.tq2, false, false, 1);
+    sac_policy_fin(s, A, eps1, s->rng_stream, false, w.a2, w.logp2);
     ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx with the TD-target loss head
@@ -349,10 +374,18 @@ static int sac_critic_backward(ilsx_sac* s) {
     }
     ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act, cs));
   }
-  return launch_bwd_dw(s->ctx, s->jobs_q, s->njobs_q, B);
+  AdamFuse F;
+  memset(&F, 0, sizeof F);
+  if (s->fuse_now) {
+    F.on = 1; F.Gbase = s->G; F.P = s->P; F.M = s->M; F.V = s->V; F.T = s->base(W_TQ1);
+    F.b1 = s->cfg.beta_1; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = s->cfg.soft_target_tau;
+    F.step_size = &s->scal->adam_q_step; F.bc2_sqrt = &s->scal->adam_q_bc2s;
+  }
+  return launch_bwd_dw(s->ctx, s->jobs_q, s->njobs_q, B, &F);
 }
 
 static int sac_critic_update(ilsx_sac* s) {
+  if (s->fuse_now) return ILSX_OK;  // already applied by the dW epilogue
   AdamArgs A;
   A.p = s->P; A.g = s->G; A.m = s->M; A.v = s->V; A.tgt = s->base(W_TQ1);
   A.n = (int)(2 * s->nq);
@@ -361,6 +394,7 @@ static int sac_critic_update(ilsx_sac* s) {
   return launch_adam(s->ctx, A);  // t_q is advanced by k_sac_finish at the end of the step
 }
 
+static StatsArgs sac_stats_args(ilsx_sac* s);
 static int sac_actor_backward(ilsx_sac* s) {
   const SacWs& w = s->ws;
   const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
@@ -371,7 +405,6 @@ static int sac_actor_backward(ilsx_sac* s) {
     A.rows = B; A.ntasks = 1; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
     sac_policy_task(s, A.t[0], w.s, eps2, s->rng_stream + 1, true, w.an, w.logp);
     ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lp.KP, cs));
-    ILSX_TRY(sac_policy_finish(s, eps2, s->rng_stream + 1, true, w.an, w.logp));
   }
   {  // fwd Q1(s,a~), Q2(s,a~) with the just-updated critics (sac_alpha.py:144-146)
     FwdArgs A;
@@ -379,6 +412,7 @@ static int sac_actor_backward(ilsx_sac* s) {
     A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
     sac_q_task(s, A.t[0], W_Q1, w.s, w.an, w.q1n, false, true, 0);
     sac_q_task(s, A.t[1], W_Q2, w.s, w.an, w.q2n, false, true, 1);
+    sac_policy_fin(s, A, eps2, s->rng_stream + 1, true, w.an, w.logp);
     ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx through both critics to the action columns
@@ -408,7 +442,27 @@ static int sac_actor_backward(ilsx_sac* s) {
     t.raw = w.raw; t.eps = w.epss; t.action = w.an; t.ga1 = w.ga[0]; t.ga2 = w.ga[1];
     ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act, cs));
   }
-  ILSX_TRY(launch_bwd_dw(s->ctx, s->jobs_p, s->njobs_p, B));
+  {
+    AdamFuse F;
+    memset(&F, 0, sizeof F);
+    if (s->fuse_now) {  // pi has no target network; its arena offset is handled by the job pointers (Gbase = G)
+      F.on = 1; F.Gbase = s->G; F.P = s->P; F.M = s->M; F.V = s->V; F.T = nullptr;
+      F.b1 = s->cfg.beta_1; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
+      F.step_size = &s->scal->adam_pi_step; F.bc2_sqrt = &s->scal->adam_pi_bc2s;
+    }
+    ILSX_TRY(launch_bwd_dw(s->ctx, s->jobs_p, s->njobs_p, B, &F));
+  }
+  if (s->fuse_now) return ILSX_OK;  // stats run inside k_sac_tail (sac_actor_update)
+  StatsArgs S = sac_stats_args(s);
+  ProfScope ps(s->ctx, ILSX_K_SAC_STATS);
+  hipLaunchKernelGGL(k_sac_stats, dim3(1), dim3(256), 0, s->ctx->stream, S);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+static StatsArgs sac_stats_args(ilsx_sac* s) {
+  const SacWs& w = s->ws;
+  const int B = s->B;
   StatsArgs S;
   S.q1 = s->pv(w.q1); S.q2 = s->pv(w.q2); S.tq1 = s->pv(w.tq1); S.tq2 = s->pv(w.tq2);
   S.q1n = s->pv(w.q1n); S.q2n = s->pv(w.q2n);
@@ -418,10 +472,7 @@ static int sac_actor_backward(ilsx_sac* s) {
   S.w_mu = s->cfg.policy_mean_reg_weight; S.w_std = s->cfg.policy_std_reg_weight;
   S.target_entropy = s->target_entropy; S.inv_B = sac_inv_B(s);
   S.scal = s->scal; S.alpha_grad_slot = s->G + 2 * s->nq + s->np;
-  ProfScope ps(s->ctx, ILSX_K_SAC_STATS);
-  hipLaunchKernelGGL(k_sac_stats, dim3(1), dim3(256), 0, s->ctx->stream, S);
-  HIPCHK(hipGetLastError());
-  return ILSX_OK;
+  return S;
 }
 
 static int sac_actor_update(ilsx_sac* s) {
@@ -431,6 +482,13 @@ static int sac_actor_update(ilsx_sac* s) {
   A.n = (int)s->np;
   A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = 0.f;
   A.step_size = &s->scal->adam_pi_step; A.bc2_sqrt = &s->scal->adam_pi_bc2s;
+  if (s->fuse_now) {
+    ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
+    hipLaunchKernelGGL(k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, sac_stats_args(s), s->cfg.train_alpha,
+                       s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr);
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   ILSX_TRY(launch_adam(s->ctx, A));
   ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
   hipLaunchKernelGGL(k_sac_finish, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, (const float*)(s->G + 2 * s->nq + s->np),
@@ -447,10 +505,14 @@ static int sac_refresh_adam(ilsx_sac* s) {
 }
 
 static int sac_full_step(ilsx_sac* s) {
-  ILSX_TRY(sac_critic_backward(s));
-  ILSX_TRY(sac_critic_update(s));
-  ILSX_TRY(sac_actor_backward(s));
-  return sac_actor_update(s);
+  static const bool no_fuse = getenv("ILSX_NO_FUSE") != nullptr;
+  s->fuse_now = !no_fuse && s->cfg.grad_world == 1;
+  int rc = sac_critic_backward(s);
+  if (rc == ILSX_OK) rc = sac_critic_update(s);
+  if (rc == ILSX_OK) rc = sac_actor_backward(s);
+  if (rc == ILSX_OK) rc = sac_actor_update(s);
+  s->fuse_now = false;
+  return rc;
 }
 
 static int sac_read_stats(ilsx_sac* s, ilsx_sac_stats* out) {
@@ -518,6 +580,12 @@ extern "C" int ilsx_sac_train_step(ilsx_sac* s, const float* obs, const float* a
 
 static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
   const SacWs& w = s->ws;
+  if (s->cs > 1) {
+    s->gather_rb = rb;   // sampling is fused into the first forward launch
+    const int rc = sac_full_step(s);
+    s->gather_rb = nullptr;
+    return rc;
+  }
   ILSX_TRY(replay_launch_sample(rb, B, nullptr, s->scal, 0, w.s, w.a, w.r, w.d, w.s2, nullptr));
   return sac_full_step(s);
 }

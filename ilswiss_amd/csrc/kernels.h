@@ -122,6 +122,24 @@ template <int N> __device__ __forceinline__ void load_vec(const float* p, float 
   else { v[0] = p[0]; }
 }
 
+// ---- replay ring state + the on-device index draw (random_batch: uniform with replacement over [0,size))
+struct DevReplayState {
+  long long size, top;
+};
+__device__ __forceinline__ long long replay_draw(uint64_t seed, uint64_t step, uint32_t stream, uint32_t r, long long size) {
+  uint32_t c[4] = {r >> 2, 0x52425546u /* 'RBUF' */, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream * 0x9E3779B9u)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
+  const uint32_t u = c[r & 3];
+  return (long long)(((unsigned long long)u * (unsigned long long)size) >> 32);
+}
+// Fused sample+index: the rows of a forward launch are drawn from the replay ring inside the kernel
+// (record = [obs | act | rew | done | next_obs]); designated slices publish the batch keys for later kernels.
+struct GatherSpec {
+  const float* records; const DevReplayState* st;
+  float *s, *a, *r, *d, *s2;   // staging batch written by the publishing slices
+  uint64_t seed; uint32_t stream; int rec, o, adim, on;
+};
+
 // ================================================================================================
 // Fused MLP forward over 16-row tiles (Mlp.forward, networks.py:85-101; FlattenMlp cat, :108-115;
 // tanh-Gaussian head, policies.py:262-307 + distributions.py:23-28,43-50,74-97).
@@ -141,6 +159,7 @@ struct FwdTask {
   float* action;                     // [rows][a] nullable
   float* logp;                       // [rows] nullable
   float* part;                       // column-split kernels: partial head sums [CS][part_stride][NO]
+  int g0_off, g1_off, publish;       // GatherSpec: record offsets of the x0 / x1 segments; 1 = publish s,a,r,d ; 2 = s2
 };
 // A per-row scalar (Q value) that may still be split into CS column-slice partial sums: summed in a fixed
 // order by whoever consumes it (the "combine in the next kernel's prologue" seam of a split-K reduction).
@@ -158,6 +177,14 @@ struct PartVal {
     return s;
   }
 };
+// Combine the CS head partials of a tanh-Gaussian policy and run its epilogue (policies.py:262-307):
+// one thread per row.  Launched right after k_mlp2_fwd_split for policy tasks.
+struct PolicyFinishArgs {
+  const float* part; int cs, part_stride, rows, a, head;
+  uint32_t rng_stream; uint64_t seed; const DevScalars* scal; uint64_t step_host;
+  const float* eps; const float* act_in;
+  float *raw, *eps_save, *action, *logp;
+};
 struct FwdArgs {
   FwdTask t[4];
   int rows, ntasks;
@@ -166,6 +193,9 @@ struct FwdArgs {
   uint64_t step_host;      // used when scal == null
   unsigned long long* dbg; // nullable phase timestamps
   int part_stride;         // rows of one partial slab (column-split kernels)
+  int fin_on;              // column-split kernels: the x1 segment (actions) of EVERY task is the output of a
+  PolicyFinishArgs fin;    //   policy whose head partials are combined + squashed here, in the consumer
+  GatherSpec gather;       // rows drawn from the replay ring in-kernel (first launch of a SAC step)
 };
 
 #ifdef ILSX_KERNEL_IMPL
@@ -546,15 +576,83 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   float4 b0[CS];
 #pragma unroll
   for (int i = 0; i < CS; ++i) b0[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256);
+  const bool fin = A.fin_on != 0;
   for (int e = tid; e < 16 * KP; e += NTH) {
     const int r = e / KP, k = e - r * KP, gr = r0 + r;
+    const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
+    if (fin && act_col) continue;   // filled by the policy epilogue below
     float v = 0.0f;
     if (gr < rows) {
-      if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
-      else if (k < T.d0 + T.d1) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
+      if (A.gather.on) {   // fused sample+index (simple_replay_buffer.py:239-293): row gr of the batch is record idx
+        const GatherSpec& G = A.gather;
+        const long long idx = replay_draw(G.seed, A.scal->step, G.stream, (uint32_t)gr, G.st->size);
+        const float* rec = G.records + (size_t)idx * G.rec;
+        if (k < T.d0) v = rec[T.g0_off + k];
+        else if (act_col) v = rec[T.g1_off + (k - T.d0)];
+        if (lead && T.publish == 1) {
+          if (k < T.d0) G.s[(size_t)gr * G.o + k] = v;
+          else if (act_col) G.a[(size_t)gr * G.adim + (k - T.d0)] = v;
+          if (k == 0) { G.r[gr] = rec[G.o + G.adim]; G.d[gr] = rec[G.o + G.adim + 1]; }
+        } else if (lead && T.publish == 2 && k < T.d0) {
+          G.s2[(size_t)gr * G.o + k] = v;
+        }
+      } else {
+        if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
+        else if (act_col) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
+      }
       if (T.xsave && lead) T.xsave[(size_t)gr * KP + k] = v;
     }
     xs[r * LDX + k] = v;
+  }
+  if (fin) {
+    // the action columns are pi's output: combine its CS head partials, squash (policies.py:262-283,
+    // distributions.py:23-28,43-50,74-97); slice 0 of task 0 publishes action / logp / raw / eps for later kernels
+    const PolicyFinishArgs& P = A.fin;
+    const int a = P.a, NOp = 2 * a;
+    const bool pub = lead && blockIdx.y == 0;
+    float* lp3 = red;   // [16][32][3] log-prob contributions (quad, log_std, jacobian)
+    for (int e = tid; e < 16 * a; e += NTH) {
+      const int row = e / a, j = e - row * a, gr = r0 + row;
+      float act = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+      if (gr < rows) {
+        float mu = 0.f, lsr = 0.f;
+        for (int c = 0; c < P.cs; ++c) {
+          mu += P.part[((size_t)c * P.part_stride + gr) * NOp + j];
+          lsr += P.part[((size_t)c * P.part_stride + gr) * NOp + a + j];
+        }
+        const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
+        const float sd = expf(ls);
+        float ep;
+        if (P.eps) {
+          ep = P.eps[(size_t)gr * a + j];
+        } else {
+          float z4[4];
+          philox_normal4(P.seed, P.scal ? P.scal->step : P.step_host, P.rng_stream, gr, j >> 2, z4);
+          const int q = j & 3;
+          ep = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
+        }
+        const float z = ep * sd + mu;
+        act = tanhf(z);
+        const float dm = mu - z;
+        c0 = dm * dm / expf(2.0f * ls); c1 = ls; c2 = logf(1.0f - act * act + TANH_EPS);
+        if (T.xsave && lead) T.xsave[(size_t)gr * KP + T.d0 + j] = act;
+        if (pub) {
+          if (P.raw) { P.raw[(size_t)gr * NOp + j] = mu; P.raw[(size_t)gr * NOp + a + j] = lsr; }
+          if (P.action) P.action[(size_t)gr * a + j] = act;
+          if (P.eps_save) P.eps_save[(size_t)gr * a + j] = ep;
+        }
+      }
+      xs[row * LDX + T.d0 + j] = act;
+      lp3[(row * 32 + j) * 3 + 0] = c0; lp3[(row * 32 + j) * 3 + 1] = c1; lp3[(row * 32 + j) * 3 + 2] = c2;
+    }
+    if (pub && P.logp) {
+      __syncthreads();
+      if (tid < 16 && r0 + tid < rows) {
+        float q = 0.f, l = 0.f, jc = 0.f;
+        for (int j = 0; j < a; ++j) { q += lp3[(tid * 32 + j) * 3]; l += lp3[(tid * 32 + j) * 3 + 1]; jc += lp3[(tid * 32 + j) * 3 + 2]; }
+        P.logp[r0 + tid] = -0.5f * q - (l + HALF_LOG_2PI) - jc;
+      }
+    }
   }
   float bias0[CS];
 #pragma unroll
@@ -667,14 +765,6 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   ILSX_STAMP(A.dbg, 7);
 }
 #endif  // ILSX_KERNEL_IMPL
-// Combine the CS head partials of a tanh-Gaussian policy and run its epilogue (policies.py:262-307):
-// one thread per row.  Launched right after k_mlp2_fwd_split for policy tasks.
-struct PolicyFinishArgs {
-  const float* part; int cs, part_stride, rows, a, head;
-  uint32_t rng_stream; uint64_t seed; const DevScalars* scal; uint64_t step_host;
-  const float* eps; const float* act_in;
-  float *raw, *eps_save, *action, *logp;
-};
 #ifdef ILSX_KERNEL_IMPL
 __global__ __launch_bounds__(64) void k_policy_finish(const PolicyFinishArgs P) {
   const int gr = blockIdx.x * 64 + threadIdx.x;
@@ -851,23 +941,50 @@ enum { DW_OUT_NATURAL = 0, DW_OUT_PACK_F = 1, DW_OUT_PACK_FB = 2 };
 struct DwJob {
   const float* A; const float* Bm; float* dW; float* dWb; float* db;
   int lda, NA, ldb, NB, ldw, n0, k0, mode;   // ldw: natural row stride, or K (PACK_F) ; NA rows for PACK_B
+  int rows, bias_rows;  // > 0: this job contracts over `rows` (instead of the launch-wide count) and only the
+                        // first `bias_rows` of them feed db (row-stacked jobs of the discriminator step)
+};
+// Optional optimiser epilogue of the dW kernel: every workgroup owns its output tile completely (the batch
+// contraction happens inside it), so Adam (+ Polyak) can be applied to that tile right there; the separate
+// k_adam_polyak pass and a kernel boundary disappear.  Gbase/P/M/V/T are arena bases with identical layouts.
+struct AdamFuse {
+  const float* Gbase; float* P; float* M; float* V; float* T;   // T nullable (no target network)
+  float b1, b2, eps, tau;
+  const float* step_size; const float* bc2_sqrt;
+  int on;
 };
 #define DW_TILE_N 32
 #define DW_TILE_K 64
 #define DW_LDS_BYTES ((16 * 16 * 64 + 16 * 16) * 4)
 
 #ifdef ILSX_KERNEL_IMPL
-__global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ jobs, int rows) {
+__device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float bc2s, size_t i0, size_t i1, bool two, float g) {
+  const float m = F.M[i0] * F.b1 + (1.0f - F.b1) * g;
+  const float v = F.V[i0] * F.b2 + (1.0f - F.b2) * g * g;
+  const float p = F.P[i0] - step * (m / (sqrtf(v) / bc2s + F.eps));
+  F.M[i0] = m; F.V[i0] = v; F.P[i0] = p;
+  float tg = 0.0f;
+  if (F.T) { tg = F.T[i0] * (1.0f - F.tau) + p * F.tau; F.T[i0] = tg; }
+  if (two) {  // second packing of the same matrix
+    F.M[i1] = m; F.V[i1] = v; F.P[i1] = p;
+    if (F.T) F.T[i1] = tg;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ jobs, int rows_all, const AdamFuse F) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* part = smem;                    // [16 waves][16 acc regs][64 lanes]
   float* bpart = smem + 16 * 16 * 64;    // [16 waves][16]
   const DwJob J = jobs[blockIdx.x];
+  const int rows = J.rows > 0 ? J.rows : rows_all, brows = J.rows > 0 ? J.bias_rows : rows_all;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int wn = wave & 1, wr = wave >> 1;
   const int nsub = J.n0 + 16 * wn;
   const bool n_ok = nsub + li < J.NA;
   int ntk = (J.NB - J.k0 + 15) / 16;
   if (ntk > 4) ntk = 4;
+  float ad_step = 0.f, ad_bc2s = 1.f;
+  if (F.on) { ad_step = *F.step_size; ad_bc2s = *F.bc2_sqrt; }
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -891,7 +1008,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ j
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (t < ntk) acc[t] = MFMA16(a[s], b[t][s], acc[t]);
-      bsum += a[s];
+      bsum += (rc + 4 * g + s < brows) ? a[s] : 0.0f;
     }
   }
   // partial tiles -> LDS
@@ -913,12 +1030,11 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ j
     for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * 2 + on) * 16 + t * 4 + v) * 64 + ol];
     const int n = J.n0 + 16 * on + 4 * (ol >> 4) + v, k = J.k0 + 16 * t + (ol & 15);
     if (t < ntk && n < J.NA && k < J.NB) {
-      if (J.mode == DW_OUT_NATURAL) {
-        J.dW[(size_t)n * J.ldw + k] = s;
-      } else {
-        J.dW[pack_f(n, k, J.ldw)] = s;
-        if (J.mode == DW_OUT_PACK_FB) J.dWb[pack_b(n, k, J.NA)] = s;
-      }
+      float* g0 = J.mode == DW_OUT_NATURAL ? J.dW + (size_t)n * J.ldw + k : J.dW + pack_f(n, k, J.ldw);
+      float* g1 = J.mode == DW_OUT_PACK_FB ? J.dWb + pack_b(n, k, J.NA) : nullptr;
+      *g0 = s;
+      if (g1) *g1 = s;
+      if (F.on) adam_apply(F, ad_step, ad_bc2s, (size_t)(g0 - F.Gbase), g1 ? (size_t)(g1 - F.Gbase) : 0, g1 != nullptr, s);
     }
   }
   if (J.db && J.k0 == 0 && tid < 32) {
@@ -926,7 +1042,11 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ j
     float s = 0.0f;
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) s += bpart[(r8 * 2 + on) * 16 + ol];
-    if (J.n0 + 16 * on + ol < J.NA) J.db[J.n0 + 16 * on + ol] = s;
+    if (J.n0 + 16 * on + ol < J.NA) {
+      float* g0 = J.db + J.n0 + 16 * on + ol;
+      *g0 = s;
+      if (F.on) adam_apply(F, ad_step, ad_bc2s, (size_t)(g0 - F.Gbase), 0, false, s);
+    }
   }
 }
 #endif  // ILSX_KERNEL_IMPL

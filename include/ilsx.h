@@ -44,6 +44,7 @@ typedef struct ilsx_net ilsx_net;
 typedef struct ilsx_replay ilsx_replay;
 typedef struct ilsx_sac ilsx_sac;
 typedef struct ilsx_vecenv ilsx_vecenv;
+typedef struct ilsx_disc ilsx_disc;
 
 enum { ILSX_ACT_RELU = 0, ILSX_ACT_TANH = 1 };
 
@@ -66,7 +67,7 @@ int ilsx_memcpy_d2h(ilsx_ctx* ctx, void* dst_host, const void* src_dev, size_t b
  * path is bypassed while profiling); ilsx_prof_read synchronises and returns launches + summed ms. */
 enum { ILSX_K_MLP_FWD = 0, ILSX_K_MLP_BWD_DX = 1, ILSX_K_MLP_BWD_DW = 2, ILSX_K_ADAM = 3,
        ILSX_K_REPLAY_SAMPLE = 4, ILSX_K_REPLAY_ADD = 5, ILSX_K_REPLAY_SAMPLE_MANY = 6, ILSX_K_SAC_STATS = 7,
-       ILSX_K_SAC_FINISH = 8, ILSX_K_ENV_STEP = 9, ILSX_K_POLICY_FINISH = 10, ILSX_K_COUNT = 16 };
+       ILSX_K_SAC_FINISH = 8, ILSX_K_ENV_STEP = 9, ILSX_K_POLICY_FINISH = 10, ILSX_K_DISC_BWD = 11, ILSX_K_COUNT = 16 };
 int ilsx_prof_enable(ilsx_ctx* ctx, int on);
 int ilsx_prof_reset(ilsx_ctx* ctx);
 int ilsx_prof_read(ilsx_ctx* ctx, int kernel_id, uint64_t* launches, double* total_ms);
@@ -192,6 +193,35 @@ int ilsx_sac_set_adam(ilsx_sac* sac, int which, const float* m_host, const float
 /* alpha_optimizer state (float64 scalar Adam, sac_alpha.py:74-76) + the Philox step counter */
 int ilsx_sac_get_alpha_opt(ilsx_sac* sac, double* m, double* v, int64_t* t, uint64_t* rng_step);
 int ilsx_sac_set_alpha_opt(ilsx_sac* sac, double m, double v, int64_t t, uint64_t rng_step);
+
+/* ---------------------------------------------------------------- adversarial-IRL discriminator
+ * Replaces rlkit/torch/algorithms/adv_irl/disc_models/simple_disc_models.py:8-48 (MLPDisc, use_bn=False),
+ * AdvIRL._do_reward_training (adv_irl.py:133-216: BCE-with-logits on [expert; policy] + WGAN-GP gradient
+ * penalty, the double backward derived by hand) and the reward modes of _do_policy_training (:277-298).
+ * cfg fields == the YAML keys (exp_specs/gail/gail_walker.yaml:24-28,55-59). */
+enum { ILSX_DISC_AIRL = 0, ILSX_DISC_GAIL = 1, ILSX_DISC_GAIL2 = 2, ILSX_DISC_FAIRL = 3 };
+typedef struct {
+  int32_t obs_dim, act_dim;       /* discriminator input = cat(obs, act)  (state_only=False) */
+  int32_t hid_dim, hid_act;       /* 2 layer blocks of hid_dim (64/128/256), ILSX_ACT_* */
+  int32_t use_grad_pen;
+  float clamp_magnitude, disc_lr, disc_momentum, grad_pen_weight;
+  int32_t max_batch;              /* disc_optim_batch_size upper bound (rows per class) */
+} ilsx_disc_cfg;
+typedef struct { float ce_loss, grad_pen, accuracy; } ilsx_disc_stats;   /* "Disc CE Loss", "Grad Pen", "Disc Acc" */
+int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_disc** out);
+int ilsx_disc_destroy(ilsx_disc* disc);
+int ilsx_disc_num_params(const ilsx_disc* disc, size_t* out);
+/* flat layout: fc0.W | fc0.b | fc1.W | fc1.b | out.W | out.b (nn.Sequential parameters() order); HOST arrays */
+int ilsx_disc_set_params(ilsx_disc* disc, const float* src_host, size_t n);
+int ilsx_disc_get_params(ilsx_disc* disc, float* dst_host, size_t n);
+int ilsx_disc_get_grads(ilsx_disc* disc, float* dst_host, size_t n);
+/* one _do_reward_training step; inputs are device rows exp_obs[B,o] exp_act[B,a] pol_obs[B,o] pol_act[B,a];
+ * eps (device [B], U[0,1) interpolation weights) or NULL = Philox. */
+int ilsx_disc_train_step(ilsx_disc* disc, const float* exp_obs, const float* exp_act, const float* pol_obs,
+                         const float* pol_act, int B, const float* eps, ilsx_disc_stats* stats);
+/* reward relabelling: rew[n] (nullable) by mode + optional clip; logits[n] (nullable) = clamped D(s,a) */
+int ilsx_disc_reward(ilsx_disc* disc, const float* obs, const float* act, int n, int mode, int has_min, float rew_clip_min,
+                     int has_max, float rew_clip_max, float* rew, float* logits);
 
 /* ---------------------------------------------------------------- vectorised env stepper
  * Replaces the reference's vec-env path: rlkit/envs/vecenvs.py:158-257 (BaseVectorEnv.reset/step),

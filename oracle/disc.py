@@ -1,0 +1,137 @@
+"""Adversarial-IRL discriminator step + reward relabelling: restatement of
+rlkit/torch/algorithms/adv_irl/adv_irl.py:133-216 (_do_reward_training: BCE-with-logits + WGAN-GP gradient
+penalty, double backward), :238-314 (_do_policy_training reward modes) and
+rlkit/torch/algorithms/adv_irl/disc_models/simple_disc_models.py:8-48 (MLPDisc: Linear-act-Linear-act-Linear,
+output clamped to +-clamp_magnitude; use_bn=False as in exp_specs/gail/gail_walker.yaml:24-28).
+numpy fp32 with a hand-derived second-order backward.  Test infrastructure.
+"""
+import numpy as np
+
+from . import mlp, optim
+
+F32 = np.float32
+RELU, TANH = 0, 1
+
+
+def _act(z, act):
+    return np.maximum(z, F32(0)) if act == RELU else np.tanh(z).astype(F32)
+
+
+def _dact(h, act):   # phi'(z) from the output h
+    return (h > 0).astype(F32) if act == RELU else (F32(1) - h * h).astype(F32)
+
+
+def _d2act_over(h, act):  # d phi'(z) / d z  expressed with h:  tanh: -2 h (1-h^2) ; relu: 0
+    return np.zeros_like(h) if act == RELU else (F32(-2) * h * (F32(1) - h * h)).astype(F32)
+
+
+def bce_with_logits(x, t):
+    """torch.nn.BCEWithLogitsLoss (mean): max(x,0) - x t + log(1 + exp(-|x|))."""
+    return np.mean(np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x))), dtype=F32)
+
+
+def sigmoid(x):
+    return (F32(1) / (F32(1) + np.exp(-x))).astype(F32)
+
+
+class DiscOracle:
+    def __init__(self, in_dim, hid_dim, flat, act=TANH, clamp=10.0, disc_lr=3e-4, disc_momentum=0.9,
+                 use_grad_pen=True, grad_pen_weight=10.0):
+        self.D, self.H, self.act, self.clamp = in_dim, hid_dim, act, F32(clamp)
+        self.p = flat.copy()
+        self.lr, self.b1 = disc_lr, disc_momentum
+        self.use_gp, self.gp_w = use_grad_pen, grad_pen_weight
+        self.opt = optim.AdamState(flat.size)
+
+    def _layers(self):
+        return mlp.unpack(self.p, self.D, [self.H, self.H], 1)
+
+    def forward(self, x):
+        (W1, b1), (W2, b2), (W3, b3) = self._layers()
+        h1 = _act(x @ W1.T + b1, self.act).astype(F32)
+        h2 = _act(h1 @ W2.T + b2, self.act).astype(F32)
+        raw = (h2 @ W3.T + b3).astype(F32)
+        return np.clip(raw, -self.clamp, self.clamp), raw, h1, h2
+
+    def logits(self, x):
+        return self.forward(np.ascontiguousarray(x, F32))[0]
+
+    def train_step(self, x_exp, x_pol, eps_gp):
+        """x_exp / x_pol: [B, D] expert / policy (s,a) rows; eps_gp: [B,1] U(0,1) interpolation weights."""
+        (W1, b1), (W2, b2), (W3, b3) = self._layers()
+        act, B = self.act, x_exp.shape[0]
+        x = np.concatenate([x_exp, x_pol], 0).astype(F32)
+        t = np.concatenate([np.ones((B, 1), F32), np.zeros((B, 1), F32)], 0)   # adv_irl.py:80-86
+        logit, raw, h1, h2 = self.forward(x)
+        ce = bce_with_logits(logit, t)
+        acc = np.mean(((logit > 0).astype(F32) == t).astype(F32))
+        gate = ((raw >= -self.clamp) & (raw <= self.clamp)).astype(F32)       # torch.clamp passes grad on [min,max]
+        dlogit = (sigmoid(logit) - t) / F32(2 * B) * gate
+        d2 = (dlogit @ W3) * _dact(h2, act)
+        d1 = (d2 @ W2) * _dact(h1, act)
+        gW3, gb3 = dlogit.T @ h2, dlogit.sum(0)
+        gW2, gb2 = d2.T @ h1, d2.sum(0)
+        gW1, gb1 = d1.T @ x, d1.sum(0)
+        out = dict(logits=logit, ce_loss=ce, accuracy=acc)
+        gp_loss = F32(0)
+        if self.use_gp:
+            e = eps_gp.astype(F32).reshape(B, 1)
+            xh = (e * x_exp + (F32(1) - e) * x_pol).astype(F32)                 # adv_irl.py:187-189
+            _, rawh, g1, g2 = self.forward(xh)
+            gt = ((rawh >= -self.clamp) & (rawh <= self.clamp)).astype(F32)     # [B,1]
+            p1, p2 = _dact(g1, act), _dact(g2, act)
+            u2 = p2 * W3                                                        # [B,H]
+            v1 = u2 @ W2                                                        # [B,H]  (W2^T u2 per row)
+            u1 = p1 * v1
+            g = gt * (u1 @ W1)                                                  # [B,D]  dD/dx
+            n = np.sqrt(np.sum(g * g, 1, keepdims=True)).astype(F32)
+            gp = np.mean((n - F32(1)) ** 2, dtype=F32)
+            gp_loss = F32(gp * F32(self.gp_w))
+            gbar = (F32(self.gp_w) / F32(B) * F32(2) * (n - F32(1)) / n * g).astype(F32)   # dGP/dg
+            gW1 += (gt * u1).T @ gbar
+            u1b = gt * (gbar @ W1.T)
+            v1b, p1b = u1b * p1, u1b * v1
+            gW2 += u2.T @ v1b
+            u2b = v1b @ W2.T
+            gW3 += (u2b * p2).sum(0, keepdims=True)
+            p2b = u2b * W3
+            z2b = p2b * _d2act_over(g2, act)
+            gW2 += z2b.T @ g1
+            gb2 += z2b.sum(0)
+            h1b = z2b @ W2
+            z1b = h1b * p1 + p1b * _d2act_over(g1, act)
+            gW1 += z1b.T @ xh
+            gb1 += z1b.sum(0)
+            out.update(interp=xh, dDdx=g, grad_norm=n)
+        out["grad_pen_loss"] = gp_loss
+        grad = mlp.pack([(gW1.astype(F32), gb1.astype(F32)), (gW2.astype(F32), gb2.astype(F32)),
+                         (gW3.astype(F32), gb3.astype(F32))])
+        out["grad"] = grad
+        optim.adam_step(self.p, grad, self.opt, self.lr, self.b1)   # adv_irl.py:75-77 betas (disc_momentum, 0.999)
+        return out
+
+
+def softplus(x, beta):
+    """torch F.softplus(x, beta, threshold=20): (1/beta) log(1 + exp(beta x)), linear where beta*x > 20."""
+    bx = F32(beta) * x
+    return np.where(bx > 20, x, np.log1p(np.exp(np.minimum(bx, F32(20)))) / F32(beta)).astype(F32)
+
+
+def disc_reward(logits, mode, rew_clip_min=None, rew_clip_max=None):
+    """adv_irl.py:277-298."""
+    x = logits.astype(F32)
+    if mode == "airl":
+        r = x
+    elif mode == "gail":
+        r = softplus(x, 1.0)
+    elif mode == "gail2":
+        r = softplus(x, -1.0)
+    elif mode == "fairl":
+        r = np.exp(x) * (F32(-1) * x)
+    else:
+        raise ValueError(mode)
+    if rew_clip_max is not None:
+        r = np.minimum(r, F32(rew_clip_max))
+    if rew_clip_min is not None:
+        r = np.maximum(r, F32(rew_clip_min))
+    return r.astype(F32)

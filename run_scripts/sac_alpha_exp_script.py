@@ -36,7 +36,9 @@ def experiment(variant, gpu=0, log_dir=None):
     env_specs = dict(variant["env_specs"])
     env_specs["eval_env_seed"] = env_specs["training_env_seed"] = seed  # sac_alpha_exp_script.py:128-132
     training_env = get_envs(env_specs, ctx=ctx)
-    eval_env = get_envs(dict(env_specs, training_env_seed=seed + 10007), ctx=ctx)
+    # the eval sampler walks its paths on the host (one episode per env): keep it small
+    n_eval = int(env_specs.get("eval_env_num", min(int(env_specs.get("env_num", 1)), 16)))
+    eval_env = get_envs(dict(env_specs, env_num=n_eval, training_env_seed=seed + 10007), ctx=ctx)
     env = training_env.single_env_view()
     obs_dim, action_dim = training_env.obs_dim, training_env.act_dim
     net_size, num_hidden = variant["net_size"], variant["num_hidden_layers"]

@@ -317,7 +317,143 @@ def gen_rms_actionmap():
          lb=lb, ub=ub, acts=acts, scaled=scaled)
 
 
-GROUPS = dict(head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+def gen_disc():
+    """G8: AdvIRL._do_reward_training (adv_irl.py:133-216) driven as an unbound function on a namespace that
+    carries the attributes it touches; G9: the reward modes of _do_policy_training (adv_irl.py:277-298)."""
+    import types
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import torch.optim as optim
+    from rlkit.torch.algorithms.adv_irl.adv_irl import AdvIRL
+    from rlkit.torch.algorithms.adv_irl.disc_models.simple_disc_models import MLPDisc
+    from oracle.disc import DiscOracle, disc_reward, RELU, TANH
+    out = {}
+    for tag, act, D, Hd, B, steps, scale in (("tanh", TANH, 23, 128, 32, 3, 1.0), ("relu", RELU, 14, 64, 16, 2, 1.0),
+                                               ("tanh_sat", TANH, 23, 128, 32, 2, 40.0)):
+        rng = np.random.default_rng(808 + len(tag))
+        flat = omlp.init_mlp(rng, D, [Hd, Hd], 1, init_w=0.3, b_init=0.05)
+        if scale != 1.0:   # push some logits past +-10 so the clamp gate matters (simple_disc_models.py:45-47)
+            lay = omlp.unpack(flat.copy(), D, [Hd, Hd], 1)
+            lay[2] = (lay[2][0] * np.float32(scale), lay[2][1])
+            flat = omlp.pack(lay)
+        disc = MLPDisc(D, num_layer_blocks=2, hid_dim=Hd, hid_act=tag.split("_")[0], use_bn=False, clamp_magnitude=10.0)
+        set_flat(disc, flat)
+        # the saturated case runs WITHOUT the gradient penalty: a clamped interpolate has dD/dx = 0 and the
+        # reference's own d||g||/dg is 0/0 = NaN there, so only the BCE path can pin the clamp gate
+        use_gp = scale == 1.0
+        kw = dict(disc_lr=3e-4, disc_momentum=0.9, use_grad_pen=use_gp, grad_pen_weight=8.0)
+        orc = DiscOracle(D, Hd, flat, act=act, **kw)
+        ns = types.SimpleNamespace(
+            discriminator=disc, disc_optimizer=optim.Adam(disc.parameters(), lr=kw["disc_lr"], betas=(kw["disc_momentum"], 0.999)),
+            state_only=False, wrap_absorbing=False, disc_optim_batch_size=B, bce=nn.BCEWithLogitsLoss(),
+            bce_targets=torch.cat([torch.ones(B, 1), torch.zeros(B, 1)], 0), use_grad_pen=use_gp,
+            grad_pen_weight=kw["grad_pen_weight"], disc_eval_statistics=None)
+        o_dim = D - 6 if D == 23 else D - 3
+        out[f"{tag}_params0"] = flat
+        out[f"{tag}_dims"] = np.array([D, Hd, B, steps, o_dim])
+        for st in range(steps):
+            xe = rng.normal(0, 1, (B, D)).astype(np.float32)
+            xp = (rng.normal(0, 1, (B, D)) * 1.5 + 0.3).astype(np.float32)
+            eps = rng.random((B, 1)).astype(np.float32)
+            batches = {True: dict(observations=t(xe[:, :o_dim]), actions=t(xe[:, o_dim:])),
+                       False: dict(observations=t(xp[:, :o_dim]), actions=t(xp[:, o_dim:]))}
+            ns.get_batch = lambda bs, from_expert, keys=None: batches[from_expert]
+            ns.disc_eval_statistics = None
+            with H.NoiseInjector() as inj:
+                if use_gp:
+                    inj.push(eps)
+                AdvIRL._do_reward_training(ns, 0)
+            stt = ns.disc_eval_statistics
+            res = orc.train_step(xe, xp, eps)
+            assert np.allclose(stt["Disc CE Loss"], res["ce_loss"], rtol=1e-4, atol=1e-6), (tag, st, stt["Disc CE Loss"], res["ce_loss"])
+            if use_gp:
+                assert np.allclose(stt["Grad Pen"] * 8.0, res["grad_pen_loss"], rtol=2e-3, atol=1e-5), (tag, st, stt["Grad Pen"] * 8, res["grad_pen_loss"])
+            assert np.allclose(stt["Disc Acc"], res["accuracy"])
+            gref = get_flat_grad(disc)
+            err = np.abs(gref - res["grad"]).max() / np.abs(gref).max()
+            assert err < 5e-3, (tag, st, err)
+            assert np.abs(get_flat(disc) - orc.p).max() < 5e-5, (tag, st)
+            out.update({f"{tag}_s{st}_x_exp": xe, f"{tag}_s{st}_x_pol": xp, f"{tag}_s{st}_eps": eps,
+                        f"{tag}_s{st}_ce": stt["Disc CE Loss"], f"{tag}_s{st}_gp": stt.get("Grad Pen", 0.0), f"{tag}_s{st}_acc": stt["Disc Acc"],
+                        f"{tag}_s{st}_grad": gref, f"{tag}_s{st}_params": get_flat(disc)})
+        probe = rng.normal(0, 2, (40, D)).astype(np.float32)
+        out[f"{tag}_probe"] = probe
+        out[f"{tag}_probe_logits"] = n(disc(t(probe)))
+        assert np.allclose(orc.logits(probe), out[f"{tag}_probe_logits"], rtol=1e-4, atol=1e-5)
+    # G9 reward modes on a logits grid (incl. the softplus threshold and the clamp range)
+    grid = np.concatenate([np.linspace(-12, 12, 97), [-25.0, 25.0, 20.5, -20.5]]).astype(np.float32).reshape(-1, 1)
+    tg_ = t(grid)
+    refs = dict(airl=tg_, gail=F.softplus(tg_, beta=1), gail2=F.softplus(tg_, beta=-1), fairl=torch.exp(tg_) * (-1.0 * tg_))
+    out["rew_grid"] = grid
+    for mode, r in refs.items():
+        out[f"rew_{mode}"] = n(r)
+        assert np.allclose(disc_reward(grid, mode), n(r), rtol=1e-5, atol=1e-6), mode
+    out["rew_gail2_clip"] = n(torch.clamp(torch.clamp(refs["gail2"], max=-0.5), min=-5.0))
+    assert np.allclose(disc_reward(grid, "gail2", rew_clip_min=-5.0, rew_clip_max=-0.5), out["rew_gail2_clip"])
+    save("g8_g9_disc", **out)
+
+
+def gen_ppo():
+    """G7: PPO.calc_adv + train_step (ppo.py:57-170) on scripted trajectories with injected permutations."""
+    from rlkit.torch.algorithms.ppo.ppo import PPO
+    from rlkit.torch.common.networks import FlattenMlp
+    from rlkit.torch.common.policies import ReparamMultivariateGaussianPolicy
+    from oracle.ppo import PPOOracle, gae_one_traj
+    rng = np.random.default_rng(707)
+    o, a, Hh = 11, 3, [32, 32]
+    kw = dict(reward_scale=1.0, discount=0.99, clip_eps=0.2, policy_lr=3e-4, value_lr=3e-4, gae_tau=0.95,
+              value_l2_reg=1e-3, mini_batch_size=16, update_epoch=2)
+    vf = FlattenMlp(hidden_sizes=Hh, input_size=o, output_size=1, hidden_activation=torch.tanh)
+    pol = ReparamMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a, conditioned_std=False,
+                                            hidden_activation=torch.tanh)
+    vf0 = omlp.init_mlp(rng, o, Hh, 1)
+    pim = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, last_scale=(0.1, 0.0))   # policies.py:378-379
+    ls0 = rng.normal(-0.3, 0.2, a).astype(np.float32)
+    pi0 = np.concatenate([pim, ls0])                      # our layout: mean net | action_log_std
+    set_flat(vf, vf0)
+    set_flat(pol, np.concatenate([ls0, pim]))             # torch yields action_log_std first
+    assert [k for k, _ in pol.named_parameters()][0] == "action_log_std"
+    tr = PPO(policy=pol, vf=vf, **kw)
+    orc = PPOOracle(o, a, Hh, pi0, vf0, **kw)
+    lens = [2, 7, 50, 13]
+    trajs = []
+    for L in lens:
+        trajs.append(dict(observations=rng.normal(0, 1, (L, o)).astype(np.float32),
+                          actions=rng.normal(0, 0.8, (L, a)).astype(np.float32),
+                          rewards=rng.normal(1.0, 1.0, (L, 1)).astype(np.float32)))
+    N = sum(lens)
+    perms = [rng.permutation(N) for _ in range(kw["update_epoch"])]
+    ttrajs = [{k: t(v) for k, v in tj.items()} for tj in trajs]
+    with torch.no_grad():
+        ref_obs, ref_act, ref_ret, ref_adv, ref_val = tr.calc_adv(ttrajs)
+        ref_lp = pol.get_log_prob(ref_obs, ref_act)
+    obs_, act_, R_, A_, V_ = orc.calc_adv(trajs)
+    assert np.allclose(R_, n(ref_ret), rtol=1e-5, atol=1e-5) and np.allclose(A_, n(ref_adv), rtol=2e-4, atol=2e-5)
+    assert np.allclose(orc.log_prob(obs_, act_)[0], n(ref_lp), rtol=1e-5, atol=1e-5)
+    q = list(perms)
+    orig = torch.randperm
+    torch.randperm = lambda nn_: torch.as_tensor(q.pop(0))
+    try:
+        tr.train_step(ttrajs)
+    finally:
+        torch.randperm = orig
+    res = orc.train_step(trajs, perms)
+    pi_ref_t = get_flat(pol)
+    pi_ref = np.concatenate([pi_ref_t[a:], pi_ref_t[:a]])
+    assert np.abs(orc.vf - get_flat(vf)).max() < 5e-5, np.abs(orc.vf - get_flat(vf)).max()
+    assert np.abs(orc.pi - pi_ref).max() < 5e-5, np.abs(orc.pi - pi_ref).max()
+    out = dict(dims=np.array([o, a] + Hh), lens=np.array(lens), vf0=vf0, pi0=pi0, perms=np.array(perms),
+               returns=n(ref_ret), advantages=n(ref_adv), values=n(ref_val), fixed_log_probs=n(ref_lp),
+               vf_final=get_flat(vf), pi_final=pi_ref)
+    for i, tj in enumerate(trajs):
+        out.update({f"t{i}_{k}": v for k, v in tj.items()})
+    # one more case: large gradient so that clip_grad_norm_(20) bites (huge advantages)
+    gb = rng.normal(0, 1, (40, o)).astype(np.float32)
+    out.update(clip_obs=gb)
+    save("g7_ppo", **out)
+
+
+GROUPS = dict(ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap)
 
 if __name__ == "__main__":
