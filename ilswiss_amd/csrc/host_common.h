@@ -47,6 +47,7 @@ struct ilsx_ctx {
   void* stage = nullptr;
   size_t stage_bytes = 0;
   // optional per-kernel HIP-event timing (include/ilsx.h "kernel timing")
+  int xcd_shift = 0;  // ILSX_XCD_SHIFT: confine the split-MLP / dW kernels to every 2^k-th workgroup slot (3 = one XCD)
   unsigned long long* dbg_stamps = nullptr;  // device buffer for ILSX_STAMP (debug)
   bool prof_on = false;
   struct ProfRec { int kid; hipEvent_t a, b; };
@@ -100,11 +101,14 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act, int cs = 1);
 int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P);
 // column-split factor the 2-hidden-layer fast path uses for width H (1 = generic kernels)
 int mlp2_split_factor(int n_hidden, int H);
-int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows, const AdamFuse* fuse = nullptr);
+int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* fuse = nullptr);
+// appends one matrix to a dW table (computes its tile range)
+int dw_table_add(DwArgs* T, const float* A, int lda, int NA, const float* Bm, int ldb, int NB, float* dW, float* dWb, int ldw,
+                 float* db, int mode, int rows = 0, int bias_rows = 0);
 int launch_adam(ilsx_ctx* ctx, const AdamArgs& A);
-// appends the dW/db jobs of one network to `jobs`
-void build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
-                   float* const* dsave, const float* dhead, std::vector<DwJob>* jobs);
+// appends the dW/db matrices of one network to a dW table
+int build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
+                  float* const* dsave, const float* dhead, DwArgs* table);
 
 // Replay ring: HBM-resident transition records + host mirror of the reference's cursors.
 struct ilsx_replay {

@@ -1,6 +1,7 @@
 // ilsx_core.hip — context, networks and kernel launch helpers of libilsx.so (gfx950 only).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <random>
 
 #define ILSX_KERNEL_IMPL 1  // the shared __global__ kernels of kernels.h are emitted by this TU only
@@ -68,6 +69,7 @@ extern "C" int ilsx_ctx_create(int hip_device, void* hip_stream, uint64_t seed, 
   ilsx_ctx* c = new ilsx_ctx();
   c->device = hip_device;
   c->seed = seed;
+  if (const char* e = getenv("ILSX_XCD_SHIFT")) c->xcd_shift = atoi(e);
   if (hip_stream) {
     c->stream = (hipStream_t)hip_stream;
   } else {
@@ -345,7 +347,8 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
   if (cs > 1) {
     const size_t lds = fwd_split_lds_bytes(H, KPmax, cs);
     if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
-    dim3 grid((A.rows + 15) / 16, A.ntasks, cs), block(4 * H / cs);
+    A.xs = ctx->xcd_shift;
+    dim3 grid(((A.rows + 15) / 16) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (H == 256 && cs == 4) {
       if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, A);
       else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, A);
@@ -376,7 +379,8 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
   if (cs > 1) {
     const size_t lds = bwd_split_lds_bytes(H, cs);
-    dim3 grid((A.rows + 15) / 16, A.ntasks, cs), block(4 * H / cs);
+    A.xs = ctx->xcd_shift;
+    dim3 grid(((A.rows + 15) / 16) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (H == 256 && cs == 4) {
       if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, A);
       else hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, A);
@@ -406,14 +410,29 @@ int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P) {
   return ILSX_OK;
 }
 
-int launch_bwd_dw(ilsx_ctx* ctx, const DwJob* jobs_dev, int njobs, int rows, const AdamFuse* fuse) {
-  if (njobs <= 0 || rows <= 0) return ILSX_OK;
-  AdamFuse F;
-  memset(&F, 0, sizeof F);
-  if (fuse) F = *fuse;
+int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* fuse) {
+  if (table.ntiles <= 0 || rows <= 0) return ILSX_OK;
+  DwArgs D = table;
+  D.rows_all = rows;
+  memset(&D.F, 0, sizeof D.F);
+  if (fuse) D.F = *fuse;
+  D.dbg = ctx->dbg_stamps ? ctx->dbg_stamps + 4 : nullptr;
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-  hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(njobs), dim3(1024), DW_LDS_BYTES, ctx->stream, jobs_dev, rows, F);
+  D.xs = ctx->xcd_shift;
+  hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
   HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+int dw_table_add(DwArgs* T, const float* A, int lda, int NA, const float* Bm, int ldb, int NB, float* dW, float* dWb, int ldw,
+                 float* db, int mode, int rows, int bias_rows) {
+  if (T->nmat >= DW_MAX_MATS) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "dW table full (%d matrices)", DW_MAX_MATS);
+  DwMat& m = T->m[T->nmat++];
+  m.A = A; m.Bm = Bm; m.dW = dW; m.dWb = dWb; m.db = db;
+  m.lda = lda; m.NA = NA; m.ldb = ldb; m.NB = NB; m.ldw = ldw; m.mode = mode; m.rows = rows; m.bias_rows = bias_rows;
+  m.ktiles = (NB + DW_TILE_K - 1) / DW_TILE_K;
+  m.tile0 = T->ntiles;
+  T->ntiles += ((NA + DW_TILE_N - 1) / DW_TILE_N) * m.ktiles;
   return ILSX_OK;
 }
 
@@ -428,27 +447,17 @@ int launch_adam(ilsx_ctx* ctx, const AdamArgs& A) {
   return ILSX_OK;
 }
 
-void build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
-                   float* const* dsave, const float* dhead, std::vector<DwJob>* jobs) {
+int build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
+                  float* const* dsave, const float* dhead, DwArgs* table) {
   const int H = L.cfg.hidden;
-  auto add = [&](const float* A, int lda, int NA, const float* Bm, int ldb, int NB, float* dW, float* dWb, int ldw,
-                 float* db, int mode) {
-    for (int n0 = 0; n0 < NA; n0 += DW_TILE_N)
-      for (int k0 = 0; k0 < NB; k0 += DW_TILE_K) {
-        DwJob j;
-        j.A = A; j.Bm = Bm; j.dW = dW; j.dWb = dWb; j.db = db;
-        j.lda = lda; j.NA = NA; j.ldb = ldb; j.NB = NB; j.ldw = ldw; j.n0 = n0; j.k0 = k0; j.mode = mode;
-        j.rows = 0; j.bias_rows = 0;
-        jobs->push_back(j);
-      }
-  };
   for (int l = 0; l < L.cfg.n_hidden; ++l) {
     const float* Bm = l == 0 ? xsave : hsave[l - 1];
     const int ldb = l == 0 ? L.KP : H;
-    add(dsave[l], H, H, Bm, ldb, ldb, gbase + L.off_W[l], l > 0 ? gbase + L.off_Wb[l] : nullptr, L.ld[l],
-        gbase + L.off_b[l], l > 0 ? DW_OUT_PACK_FB : DW_OUT_PACK_F);
+    ILSX_TRY(dw_table_add(table, dsave[l], H, H, Bm, ldb, ldb, gbase + L.off_W[l], l > 0 ? gbase + L.off_Wb[l] : nullptr,
+                          L.ld[l], gbase + L.off_b[l], l > 0 ? DW_OUT_PACK_FB : DW_OUT_PACK_F));
   }
-  add(dhead, L.NO, L.NO, hsave[L.cfg.n_hidden - 1], H, H, gbase + L.off_Wh, nullptr, H, gbase + L.off_bh, DW_OUT_NATURAL);
+  return dw_table_add(table, dhead, L.NO, L.NO, hsave[L.cfg.n_hidden - 1], H, H, gbase + L.off_Wh, nullptr, H,
+                      gbase + L.off_bh, DW_OUT_NATURAL);
 }
 
 // ------------------------------------------------------------------------------------------ nets

@@ -316,8 +316,8 @@ struct ilsx_disc {
   DiscScalars* scal = nullptr;
   float *X = nullptr, *xs = nullptr, *hs0 = nullptr, *hs1 = nullptr, *A2 = nullptr, *A1 = nullptr, *dhead = nullptr;
   float *raw = nullptr, *ce_row = nullptr, *correct = nullptr, *gp_row = nullptr, *eps_used = nullptr;
-  DwJob* jobs = nullptr;
-  int njobs = 0, jobs_B = -1;
+  DwArgs jobs;
+  int jobs_B = -1;
   uint32_t rng_stream = 0;
   unsigned long long step_ctr = 0;
   PartVal pv() const { return PartVal{raw, cs, 3 * cfg.max_batch}; }
@@ -361,7 +361,6 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
   if (rc == ILSX_OK) rc = A(&d->correct, 2 * B);
   if (rc == ILSX_OK) rc = A(&d->gp_row, B);
   if (rc == ILSX_OK) rc = A(&d->eps_used, B);
-  if (rc == ILSX_OK) rc = ctx_alloc(ctx, 256 * sizeof(DwJob), (void**)&d->jobs);
   if (rc == ILSX_OK) rc = disc_refresh(d);
   if (rc != ILSX_OK) { delete d; return rc; }
   *out = d;
@@ -371,7 +370,7 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
 extern "C" int ilsx_disc_destroy(ilsx_disc* d) {
   if (!d) return ILSX_OK;
   void* ps[] = {d->P, d->G, d->M, d->V, d->scal, d->X, d->xs, d->hs0, d->hs1, d->A2, d->A1, d->dhead, d->raw, d->ce_row,
-                d->correct, d->gp_row, d->eps_used, d->jobs};
+                d->correct, d->gp_row, d->eps_used};
   for (void* p : ps) ctx_free(d->ctx, p);
   delete d;
   return ILSX_OK;
@@ -416,26 +415,14 @@ static int disc_build_jobs(ilsx_disc* d, int B) {
   if (d->jobs_B == B) return ILSX_OK;
   const int H = d->cfg.hid_dim, KP = d->L.KP, gp = d->cfg.use_grad_pen ? 1 : 0;
   const int rows_h = gp ? 4 * B : 2 * B, bias_h = gp ? 3 * B : 2 * B, rows_o = gp ? 3 * B : 2 * B;
-  std::vector<DwJob> jobs;
-  auto add = [&](const float* A, int lda, int NA, const float* Bm, int ldb, int NB, float* dW, float* dWb, int ldw, float* db,
-                 int mode, int rows, int brows) {
-    for (int n0 = 0; n0 < NA; n0 += DW_TILE_N)
-      for (int k0 = 0; k0 < NB; k0 += DW_TILE_K) {
-        DwJob j;
-        j.A = A; j.Bm = Bm; j.dW = dW; j.dWb = dWb; j.db = db;
-        j.lda = lda; j.NA = NA; j.ldb = ldb; j.NB = NB; j.ldw = ldw; j.n0 = n0; j.k0 = k0; j.mode = mode;
-        j.rows = rows; j.bias_rows = brows;
-        jobs.push_back(j);
-      }
-  };
   const NetLayout& L = d->L;
-  add(d->A1, H, H, d->xs, KP, KP, d->G + L.off_W[0], nullptr, KP, d->G + L.off_b[0], DW_OUT_PACK_F, rows_h, bias_h);
-  add(d->A2, H, H, d->hs0, H, H, d->G + L.off_W[1], d->G + L.off_Wb[1], H, d->G + L.off_b[1], DW_OUT_PACK_FB, rows_h, bias_h);
-  add(d->dhead, 1, 1, d->hs1, H, H, d->G + L.off_Wh, nullptr, H, d->G + L.off_bh, DW_OUT_NATURAL, rows_o, 2 * B);
-  if (jobs.size() > 256) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "too many dW jobs");
-  HIPCHK(hipMemcpyAsync(d->jobs, jobs.data(), jobs.size() * sizeof(DwJob), hipMemcpyHostToDevice, d->ctx->stream));
-  HIPCHK(hipStreamSynchronize(d->ctx->stream));
-  d->njobs = (int)jobs.size();
+  memset(&d->jobs, 0, sizeof d->jobs);
+  ILSX_TRY(dw_table_add(&d->jobs, d->A1, H, H, d->xs, KP, KP, d->G + L.off_W[0], nullptr, KP, d->G + L.off_b[0],
+                        DW_OUT_PACK_F, rows_h, bias_h));
+  ILSX_TRY(dw_table_add(&d->jobs, d->A2, H, H, d->hs0, H, H, d->G + L.off_W[1], d->G + L.off_Wb[1], H, d->G + L.off_b[1],
+                        DW_OUT_PACK_FB, rows_h, bias_h));
+  ILSX_TRY(dw_table_add(&d->jobs, d->dhead, 1, 1, d->hs1, H, H, d->G + L.off_Wh, nullptr, H, d->G + L.off_bh,
+                        DW_OUT_NATURAL, rows_o, 2 * B));
   d->jobs_B = B;
   return ILSX_OK;
 }
@@ -478,7 +465,7 @@ extern "C" int ilsx_disc_train_step(ilsx_disc* d, const float* exp_obs, const fl
     }
     HIPCHK(hipGetLastError());
   }
-  ILSX_TRY(launch_bwd_dw(ctx, d->jobs, d->njobs, rows));
+  ILSX_TRY(launch_bwd_dw(ctx, d->jobs, rows));
   AdamArgs Ad;
   Ad.p = d->P; Ad.g = d->G; Ad.m = d->M; Ad.v = d->V; Ad.tgt = nullptr; Ad.n = (int)d->L.n_int;
   Ad.b1 = d->cfg.disc_momentum; Ad.b2 = 0.999f; Ad.eps = 1e-8f; Ad.tau = 0.f;

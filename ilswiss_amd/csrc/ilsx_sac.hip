@@ -39,8 +39,7 @@ struct ilsx_sac {
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
   DevScalars* scal = nullptr;
   SacWs ws;
-  DwJob *jobs_q = nullptr, *jobs_p = nullptr;
-  int njobs_q = 0, njobs_p = 0;
+  DwArgs jobs_q, jobs_p;     // dW tables (critics / policy), passed by value in the kernel arguments
   ilsx_replay* gather_rb = nullptr;  // train_from_replay: the first forward launch draws its rows from this ring
   bool fuse_now = false;     // this step applies Adam(+Polyak) inside the dW epilogue (not in split-run phases)
   int cs = 1;                // column-split factor of the 2-hidden-layer fast path (1 = generic kernels)
@@ -242,17 +241,12 @@ extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net*
   HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   ILSX_TRY(sac_refresh_adam(s));
-  // weight-gradient job tables
-  std::vector<DwJob> jq, jp;
+  // weight-gradient tables
+  memset(&s->jobs_q, 0, sizeof s->jobs_q);
+  memset(&s->jobs_p, 0, sizeof s->jobs_p);
   for (int i = 0; i < 2; ++i)
-    build_dw_jobs(s->Lq, s->gbase(i == 0 ? W_Q1 : W_Q2), s->ws.xq[i], s->ws.hq[i], s->ws.dq[i], s->ws.dhq[i], &jq);
-  build_dw_jobs(s->Lp, s->gbase(W_PI), s->ws.xp, s->ws.hp, s->ws.dp, s->ws.dhp, &jp);
-  s->njobs_q = (int)jq.size(); s->njobs_p = (int)jp.size();
-  ILSX_TRY(ctx_alloc(ctx, jq.size() * sizeof(DwJob), (void**)&s->jobs_q));
-  ILSX_TRY(ctx_alloc(ctx, jp.size() * sizeof(DwJob), (void**)&s->jobs_p));
-  HIPCHK(hipMemcpyAsync(s->jobs_q, jq.data(), jq.size() * sizeof(DwJob), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(s->jobs_p, jp.data(), jp.size() * sizeof(DwJob), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));
+    ILSX_TRY(build_dw_jobs(s->Lq, s->gbase(i == 0 ? W_Q1 : W_Q2), s->ws.xq[i], s->ws.hq[i], s->ws.dq[i], s->ws.dhq[i], &s->jobs_q));
+  ILSX_TRY(build_dw_jobs(s->Lp, s->gbase(W_PI), s->ws.xp, s->ws.hp, s->ws.dp, s->ws.dhp, &s->jobs_p));
   *out = s;
   return ILSX_OK;
 }
@@ -381,7 +375,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     F.b1 = s->cfg.beta_1; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = s->cfg.soft_target_tau;
     F.step_size = &s->scal->adam_q_step; F.bc2_sqrt = &s->scal->adam_q_bc2s;
   }
-  return launch_bwd_dw(s->ctx, s->jobs_q, s->njobs_q, B, &F);
+  return launch_bwd_dw(s->ctx, s->jobs_q, B, &F);
 }
 
 static int sac_critic_update(ilsx_sac* s) {
@@ -450,7 +444,7 @@ static int sac_actor_backward(ilsx_sac* s) {
       F.b1 = s->cfg.beta_1; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
       F.step_size = &s->scal->adam_pi_step; F.bc2_sqrt = &s->scal->adam_pi_bc2s;
     }
-    ILSX_TRY(launch_bwd_dw(s->ctx, s->jobs_p, s->njobs_p, B, &F));
+    ILSX_TRY(launch_bwd_dw(s->ctx, s->jobs_p, B, &F));
   }
   if (s->fuse_now) return ILSX_OK;  // stats run inside k_sac_tail (sac_actor_update)
   StatsArgs S = sac_stats_args(s);

@@ -196,6 +196,7 @@ struct FwdArgs {
   int fin_on;              // column-split kernels: the x1 segment (actions) of EVERY task is the output of a
   PolicyFinishArgs fin;    //   policy whose head partials are combined + squashed here, in the consumer
   GatherSpec gather;       // rows drawn from the replay ring in-kernel (first launch of a SAC step)
+  int xs;                  // XCD confinement: only workgroups with (blockIdx.x & ((1<<xs)-1)) == 0 work (grid.x <<= xs)
 };
 
 #ifdef ILSX_KERNEL_IMPL
@@ -392,6 +393,7 @@ struct BwdArgs {
   unsigned long long* dbg;
   int ga_parts, ga_stride;  // LOSS_SAC_POLICY: ga1/ga2 hold ga_parts partial slabs of ga_stride rows each
   int part_stride;          // column-split kernels: rows of one dx partial slab
+  int xs;                   // XCD confinement (see FwdArgs)
 };
 
 // dL/d(head output j) of row gr for the loss functor of task T (shared by the generic and the column-split
@@ -566,8 +568,9 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   float* h0 = xs + 16 * LDX;        // [16][LDH]   layer-0 activations, all H columns
   float* hs = h0 + 16 * LDH;        // [16][LDSL]  this slice of the layer-1 activations
   float* red = hs + 16 * LDSL;      // [4 tiles][NWV][4][64] head partial tiles
+  if (blockIdx.x & ((1u << A.xs) - 1u)) return;   // XCD confinement: the dispatcher deals workgroups round-robin to the 8 XCDs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int r0 = blockIdx.x * 16, rows = A.rows, cs = blockIdx.z;
+  const int r0 = (blockIdx.x >> A.xs) * 16, rows = A.rows, cs = blockIdx.z;
   const bool lead = cs == 0;
   ILSX_STAMP(A.dbg, 0);
 
@@ -820,8 +823,9 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
   float* d1 = smem;                      // [16][LDH]  delta_1, all H columns
   float* d0s = d1 + 16 * LDH;            // [16][LDSL] this slice of delta_0
   float* dout = d0s + 16 * LDSL;         // [16][ILSX_MAX_NO]
+  if (blockIdx.x & ((1u << A.xs) - 1u)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int r0 = blockIdx.x * 16, rows = A.rows, cs = blockIdx.z;
+  const int r0 = (blockIdx.x >> A.xs) * 16, rows = A.rows, cs = blockIdx.z;
   const bool lead = cs == 0;
   ILSX_STAMP(A.dbg, 8);
 
@@ -938,12 +942,15 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
 // each wave issues all its operand loads up front, runs its MFMAs, and the 8 row-partials are summed
 // through LDS.  dynamic LDS = DW_LDS_BYTES.
 enum { DW_OUT_NATURAL = 0, DW_OUT_PACK_F = 1, DW_OUT_PACK_FB = 2 };
-struct DwJob {
+// One weight matrix of a dW launch.  The table travels in the kernel arguments (scalar registers), so a
+// workgroup finds its tile without a dependent global load.
+struct DwMat {
   const float* A; const float* Bm; float* dW; float* dWb; float* db;
-  int lda, NA, ldb, NB, ldw, n0, k0, mode;   // ldw: natural row stride, or K (PACK_F) ; NA rows for PACK_B
-  int rows, bias_rows;  // > 0: this job contracts over `rows` (instead of the launch-wide count) and only the
-                        // first `bias_rows` of them feed db (row-stacked jobs of the discriminator step)
+  int lda, NA, ldb, NB, ldw, mode;   // ldw: natural row stride, or K (PACK_F); NA rows for PACK_B
+  int rows, bias_rows;               // > 0: contract over `rows` (row-stacked jobs); only the first bias_rows feed db
+  int tile0, ktiles;                 // first workgroup of this matrix, number of 64-wide k tiles
 };
+#define DW_MAX_MATS 10
 // Optional optimiser epilogue of the dW kernel: every workgroup owns its output tile completely (the batch
 // contraction happens inside it), so Adam (+ Polyak) can be applied to that tile right there; the separate
 // k_adam_polyak pass and a kernel boundary disappear.  Gbase/P/M/V/T are arena bases with identical layouts.
@@ -953,45 +960,90 @@ struct AdamFuse {
   const float* step_size; const float* bc2_sqrt;
   int on;
 };
+struct DwArgs {
+  DwMat m[DW_MAX_MATS];
+  int nmat, rows_all, ntiles, pad;
+  AdamFuse F;
+  unsigned long long* dbg;
+  int xs;
+};
 #define DW_TILE_N 32
 #define DW_TILE_K 64
 #define DW_LDS_BYTES ((16 * 16 * 64 + 16 * 16) * 4)
 
 #ifdef ILSX_KERNEL_IMPL
-__device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float bc2s, size_t i0, size_t i1, bool two, float g) {
-  const float m = F.M[i0] * F.b1 + (1.0f - F.b1) * g;
-  const float v = F.V[i0] * F.b2 + (1.0f - F.b2) * g * g;
-  const float p = F.P[i0] - step * (m / (sqrtf(v) / bc2s + F.eps));
+struct AdamOperands { float p, m, v, t; };
+__device__ __forceinline__ AdamOperands adam_prefetch(const AdamFuse& F, size_t i0) {
+  AdamOperands o;
+  o.p = F.P[i0]; o.m = F.M[i0]; o.v = F.V[i0]; o.t = F.T ? F.T[i0] : 0.0f;
+  return o;
+}
+__device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float bc2s, const AdamOperands& o, size_t i0,
+                                           size_t i1, bool two, float g) {
+  const float m = o.m * F.b1 + (1.0f - F.b1) * g;
+  const float v = o.v * F.b2 + (1.0f - F.b2) * g * g;
+  const float p = o.p - step * (m / (sqrtf(v) / bc2s + F.eps));
   F.M[i0] = m; F.V[i0] = v; F.P[i0] = p;
   float tg = 0.0f;
-  if (F.T) { tg = F.T[i0] * (1.0f - F.tau) + p * F.tau; F.T[i0] = tg; }
+  if (F.T) { tg = o.t * (1.0f - F.tau) + p * F.tau; F.T[i0] = tg; }
   if (two) {  // second packing of the same matrix
     F.M[i1] = m; F.V[i1] = v; F.P[i1] = p;
     if (F.T) F.T[i1] = tg;
   }
 }
 
-__global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ jobs, int rows_all, const AdamFuse F) {
+__global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* part = smem;                    // [16 waves][16 acc regs][64 lanes]
   float* bpart = smem + 16 * 16 * 64;    // [16 waves][16]
-  const DwJob J = jobs[blockIdx.x];
-  const int rows = J.rows > 0 ? J.rows : rows_all, brows = J.rows > 0 ? J.bias_rows : rows_all;
+  if (blockIdx.x & ((1u << D.xs) - 1u)) return;
+  const int bx = blockIdx.x >> D.xs;
+  int mi = 0;
+#pragma unroll
+  for (int i = 1; i < DW_MAX_MATS; ++i)
+    if (i < D.nmat && bx >= D.m[i].tile0) mi = i;
+  const DwMat& J = D.m[mi];
+  const AdamFuse& F = D.F;
+  const int local = bx - J.tile0;
+  const int n0 = (local / J.ktiles) * DW_TILE_N, k0 = (local % J.ktiles) * DW_TILE_K;
+  const int rows = J.rows > 0 ? J.rows : D.rows_all, brows = J.rows > 0 ? J.bias_rows : D.rows_all;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int wn = wave & 1, wr = wave >> 1;
-  const int nsub = J.n0 + 16 * wn;
+  const int nsub = n0 + 16 * wn;
   const bool n_ok = nsub + li < J.NA;
-  int ntk = (J.NB - J.k0 + 15) / 16;
+  int ntk = (J.NB - k0 + 15) / 16;
   if (ntk > 4) ntk = 4;
+  if (D.dbg && bx == 5 && tid == 0) D.dbg[0] = __builtin_amdgcn_s_memtime();
+  // ---- the two output elements this thread will finish (and their optimiser operands, requested now)
+  float* g0p[2]; float* g1p[2]; bool live[2];
+  AdamOperands ao[2];
   float ad_step = 0.f, ad_bc2s = 1.f;
   if (F.on) { ad_step = *F.step_size; ad_bc2s = *F.bc2_sqrt; }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int e = tid + 1024 * h;
+    const int on = e >> 10, rest = e & 1023, t = rest >> 8, v = (rest >> 6) & 3, ol = rest & 63;
+    const int n = n0 + 16 * on + 4 * (ol >> 4) + v, k = k0 + 16 * t + (ol & 15);
+    live[h] = t < ntk && n < J.NA && k < J.NB;
+    g0p[h] = nullptr; g1p[h] = nullptr;
+    if (live[h]) {
+      g0p[h] = J.mode == DW_OUT_NATURAL ? J.dW + (size_t)n * J.ldw + k : J.dW + pack_f(n, k, J.ldw);
+      g1p[h] = J.mode == DW_OUT_PACK_FB ? J.dWb + pack_b(n, k, J.NA) : nullptr;
+      if (F.on) ao[h] = adam_prefetch(F, (size_t)(g0p[h] - F.Gbase));
+    }
+  }
+  const bool bias_thread = J.db && k0 == 0 && tid < 32 && n0 + 16 * (tid >> 4) + (tid & 15) < J.NA;
+  float* gbp = bias_thread ? J.db + n0 + 16 * (tid >> 4) + (tid & 15) : nullptr;
+  AdamOperands aob;
+  if (bias_thread && F.on) aob = adam_prefetch(F, (size_t)(gbp - F.Gbase));
+
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.0f;
   bool k_ok[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) k_ok[t] = J.k0 + 16 * t + li < J.NB;
+  for (int t = 0; t < 4; ++t) k_ok[t] = k0 + 16 * t + li < J.NB;
   for (int rc = 16 * wr; rc < rows; rc += 128) {
     float a[4], b[4][4];
 #pragma unroll
@@ -1001,7 +1053,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ j
       a[s] = (r_ok && n_ok) ? J.A[(size_t)r * J.lda + nsub + li] : 0.0f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        b[t][s] = (r_ok && k_ok[t]) ? J.Bm[(size_t)r * J.ldb + J.k0 + 16 * t + li] : 0.0f;
+        b[t][s] = (r_ok && k_ok[t]) ? J.Bm[(size_t)r * J.ldb + k0 + 16 * t + li] : 0.0f;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1011,6 +1063,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ j
       bsum += (rc + 4 * g + s < brows) ? a[s] : 0.0f;
     }
   }
+  if (D.dbg && bx == 5 && tid == 0) D.dbg[1] = __builtin_amdgcn_s_memtime();
   // partial tiles -> LDS
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -1020,6 +1073,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ j
   bsum += __shfl_xor(bsum, 32, 64);
   if (g == 0) bpart[wave * 16 + li] = bsum;
   __syncthreads();
+  if (D.dbg && bx == 5 && tid == 0) D.dbg[2] = __builtin_amdgcn_s_memtime();
   // sum the 8 row-partials; thread <-> (n-half, tile, reg, lane)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1028,26 +1082,22 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwJob* __restrict__ j
     float s = 0.0f;
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * 2 + on) * 16 + t * 4 + v) * 64 + ol];
-    const int n = J.n0 + 16 * on + 4 * (ol >> 4) + v, k = J.k0 + 16 * t + (ol & 15);
-    if (t < ntk && n < J.NA && k < J.NB) {
-      float* g0 = J.mode == DW_OUT_NATURAL ? J.dW + (size_t)n * J.ldw + k : J.dW + pack_f(n, k, J.ldw);
-      float* g1 = J.mode == DW_OUT_PACK_FB ? J.dWb + pack_b(n, k, J.NA) : nullptr;
-      *g0 = s;
-      if (g1) *g1 = s;
-      if (F.on) adam_apply(F, ad_step, ad_bc2s, (size_t)(g0 - F.Gbase), g1 ? (size_t)(g1 - F.Gbase) : 0, g1 != nullptr, s);
+    if (live[h]) {
+      *g0p[h] = s;
+      if (g1p[h]) *g1p[h] = s;
+      if (F.on) adam_apply(F, ad_step, ad_bc2s, ao[h], (size_t)(g0p[h] - F.Gbase), g1p[h] ? (size_t)(g1p[h] - F.Gbase) : 0,
+                           g1p[h] != nullptr, s);
     }
   }
-  if (J.db && J.k0 == 0 && tid < 32) {
+  if (bias_thread) {
     const int on = tid >> 4, ol = tid & 15;
     float s = 0.0f;
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) s += bpart[(r8 * 2 + on) * 16 + ol];
-    if (J.n0 + 16 * on + ol < J.NA) {
-      float* g0 = J.db + J.n0 + 16 * on + ol;
-      *g0 = s;
-      if (F.on) adam_apply(F, ad_step, ad_bc2s, (size_t)(g0 - F.Gbase), 0, false, s);
-    }
+    *gbp = s;
+    if (F.on) adam_apply(F, ad_step, ad_bc2s, aob, (size_t)(gbp - F.Gbase), 0, false, s);
   }
+  if (D.dbg && bx == 5 && tid == 0) D.dbg[3] = __builtin_amdgcn_s_memtime();
 }
 #endif  // ILSX_KERNEL_IMPL
 

@@ -18,6 +18,7 @@ _lib.check(ctx.lib.ilsx_debug_set_stamp_buffer(ctx.h, buf.ptr))
 for rep in range(4):
     tr.train_step(batch); ctx.sync()
     t = buf.numpy()
+    print("   dW (policy launch, tile 5): loads+mfma=%d lds=%d reduce+adam+store=%d total=%d" % (*np.diff(t[4:8]), t[7] - t[4]))
     f = np.diff(t[[0, 1, 2, 3, 7]]); b = np.diff(t[[8, 9, 10, 11, 12]])
     print(rep, "fwd(last launch: policy bwd? no: Q1n/Q2n) x=%d layer0=%d layer1=%d head=%d total=%d | bwd(last: policy) dout=%d delta1=%d delta0=%d dx=%d total=%d"
           % (*f, t[7] - t[0], *b, t[12] - t[8]))
