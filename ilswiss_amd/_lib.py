@@ -54,6 +54,14 @@ class PlanarModel(C.Structure):  # ilsx_planar_model
                 ("ang_max", C.c_double), ("state_max", C.c_double), ("init_qpos", C.c_double * (_MB + 2))]
 
 
+class PpoCfg(C.Structure):  # ilsx_ppo_cfg
+    _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32),
+                ("reward_scale", C.c_float), ("discount", C.c_float), ("clip_eps", C.c_float),
+                ("policy_lr", C.c_float), ("value_lr", C.c_float), ("gae_tau", C.c_float),
+                ("value_l2_reg", C.c_float), ("mini_batch_size", C.c_int32), ("update_epoch", C.c_int32),
+                ("max_samples", C.c_int32)]
+
+
 class DiscCfg(C.Structure):  # ilsx_disc_cfg
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("hid_dim", C.c_int32), ("hid_act", C.c_int32),
                 ("use_grad_pen", C.c_int32), ("clamp_magnitude", C.c_float), ("disc_lr", C.c_float),
@@ -66,6 +74,14 @@ class DiscStats(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/ilsx.h declares
 PROTOTYPES = {
+    "ilsx_ppo_create": (C.c_int, [vp, C.POINTER(PpoCfg), C.POINTER(vp)]),
+    "ilsx_ppo_destroy": (C.c_int, [vp]),
+    "ilsx_ppo_num_params": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
+    "ilsx_ppo_set_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "ilsx_ppo_get_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "ilsx_ppo_gae": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
+    "ilsx_ppo_train": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp]),
+    "ilsx_ppo_policy_act": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "ilsx_disc_create": (C.c_int, [vp, C.POINTER(DiscCfg), C.POINTER(vp)]),
     "ilsx_disc_destroy": (C.c_int, [vp]),
     "ilsx_disc_num_params": (C.c_int, [vp, C.POINTER(C.c_size_t)]),

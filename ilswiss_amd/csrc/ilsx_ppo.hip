@@ -1,0 +1,384 @@
+// ilsx_ppo.hip — PPO: rlkit/torch/algorithms/ppo/ppo.py:57-100 (calc_adv: per-trajectory GAE with zero
+// bootstrap + per-trajectory advantage standardisation with the unbiased std) and :102-170 (train_step:
+// update_epoch x shuffled minibatches; value MSE + L2 over all vf parameters; clipped surrogate; grad-norm clip
+// 20), policy = ReparamMultivariateGaussianPolicy(conditioned_std=False) (policies.py:348-478: tanh-hidden mean
+// network + state-independent action_log_std parameter), value net = tanh FlattenMlp (ppo_exp_script.py:82-96).
+//
+// Device pipeline for one train_step over N on-policy samples (T trajectories):
+//   forward(vf) over all N rows -> k_ppo_gae (one lane per trajectory: reverse scan, mean/std, normalise)
+//   forward(pi) over all N rows with the Gaussian log-prob head -> fixed log-probs
+//   per minibatch (rows gathered through an index list, nothing is copied):
+//     value : forward(gather) ; backward (LOSS_MSE head) ; dW with Adam + L2 fused in the epilogue
+//     policy: forward(gather, log-prob head) ; backward (LOSS_PPO_POLICY head, also emits d/d log_std rows) ;
+//             dW ; k_ppo_norm (sum of squares of the whole policy gradient, log_std column sums) ;
+//             k_ppo_clip_adam (clip_grad_norm_(20) scale + Adam over the policy arena)
+// HBM-bound pieces: k_ppo_gae streams 5 fp32 arrays once (20 B per sample).
+#include <cmath>
+#include <numeric>
+#include <random>
+
+#include "host_common.h"
+
+struct PpoScalars {
+  float v_step, v_bc2s, p_step, p_bc2s;
+  float vf_loss, pg_loss, grad_norm, pad;
+  int t_v, t_p, pad2[2];
+};
+
+// ---- GAE: one lane per trajectory (ppo.py:73-86)
+__global__ void k_ppo_gae(const float* __restrict__ values, const float* __restrict__ rewards, const int* __restrict__ offs,
+                          int n_traj, float reward_scale, float gamma, float tau, float* __restrict__ returns,
+                          float* __restrict__ adv) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_traj) return;
+  const int b = offs[t], e = offs[t + 1], T = e - b;
+  float prev_v = 0.0f, prev_a = 0.0f, sum = 0.0f;
+  for (int i = e - 1; i >= b; --i) {
+    const float v = values[i];
+    const float delta = reward_scale * rewards[i] + gamma * prev_v - v;
+    const float a = delta + gamma * tau * prev_a;
+    adv[i] = a;
+    returns[i] = v + a;
+    prev_v = v; prev_a = a;
+    sum += a;
+  }
+  const float mean = sum / (float)T;
+  double ss = 0.0;
+  for (int i = b; i < e; ++i) { const double d = (double)adv[i] - (double)mean; ss += d * d; }
+  const float sd = (float)sqrt(ss / (double)(T - 1));   // torch.std(): unbiased; T == 1 -> nan like the reference
+  for (int i = b; i < e; ++i) adv[i] = (adv[i] - mean) / sd;
+}
+
+// ---- sum of squares of the policy gradient (every parameter once) + d/d log_std = column sums of the aux rows
+struct PpoNormArgs {
+  const float* G; int n;
+  int skip0[2], skip1[2];                    // [skip0, skip1): second packings of hidden->hidden matrices (not parameters)
+  const float* aux; int rows, a;
+  float* g_logstd;                           // [a] (part of the gradient arena)
+  float* partial;                            // [gridDim.x]
+};
+__global__ __launch_bounds__(256) void k_ppo_norm(const PpoNormArgs P) {
+  __shared__ float sh[4];
+  float s = 0.0f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < P.n; i += gridDim.x * 256)
+    if ((i < P.skip0[0] || i >= P.skip1[0]) && (i < P.skip0[1] || i >= P.skip1[1])) { const float g = P.G[i]; s += g * g; }
+  if (blockIdx.x == 0 && threadIdx.x < P.a) {   // log_std gradient, fixed summation order
+    float c = 0.0f;
+    for (int r = 0; r < P.rows; ++r) c += P.aux[(size_t)r * P.a + threadIdx.x];
+    P.g_logstd[threadIdx.x] = c;
+    s += c * c;
+  }
+  s = block256_sum(s, sh);
+  if (threadIdx.x == 0) P.partial[blockIdx.x] = s;
+}
+
+struct PpoClipAdamArgs {
+  float* P; const float* G; float* M; float* V; int n;   // whole policy arena incl. log_std (and both W1 packings)
+  const float* partial; int nparts;
+  float max_norm, b1, b2, eps;
+  PpoScalars* sc;
+};
+__global__ __launch_bounds__(256) void k_ppo_clip_adam(const PpoClipAdamArgs A) {
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < A.nparts; ++i) tot += (double)A.partial[i];
+    const double norm = sqrt(tot);
+    const double coef = (double)A.max_norm / (norm + 1e-6);   // torch.nn.utils.clip_grad_norm_
+    s_coef = coef < 1.0 ? (float)coef : 1.0f;
+    if (blockIdx.x == 0) A.sc->grad_norm = (float)norm;
+  }
+  __syncthreads();
+  const float coef = s_coef, step = A.sc->p_step, bc2s = A.sc->p_bc2s;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < A.n; i += gridDim.x * 256) {
+    const float g = A.G[i] * coef;
+    const float m = A.M[i] * A.b1 + (1.0f - A.b1) * g;
+    const float v = A.V[i] * A.b2 + (1.0f - A.b2) * g * g;
+    A.M[i] = m; A.V[i] = v;
+    A.P[i] = A.P[i] - step * (m / (sqrtf(v) / bc2s + A.eps));
+  }
+}
+
+// Adam bias-correction scalars of the NEXT value / policy step (which: 0 = a value step just ran, 1 = policy, -1 = init)
+__global__ void k_ppo_refresh(PpoScalars* sc, int which, float v_lr, float p_lr) {
+  if (which == 0) sc->t_v += 1;
+  if (which == 1) sc->t_p += 1;
+  const double b1 = 0.9, b2 = 0.999;
+  sc->v_step = (float)((double)v_lr / (1.0 - pow(b1, (double)(sc->t_v + 1))));
+  sc->v_bc2s = (float)sqrt(1.0 - pow(b2, (double)(sc->t_v + 1)));
+  sc->p_step = (float)((double)p_lr / (1.0 - pow(b1, (double)(sc->t_p + 1))));
+  sc->p_bc2s = (float)sqrt(1.0 - pow(b2, (double)(sc->t_p + 1)));
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct ilsx_ppo {
+  ilsx_ctx* ctx = nullptr;
+  ilsx_ppo_cfg cfg;
+  NetLayout Lp, Lv;
+  int o = 0, a = 0, N = 0;
+  size_t np = 0, nv = 0;       // internal floats: policy arena = mean net + log_std (padded to 4), value net
+  float *Pp = nullptr, *Gp = nullptr, *Mp = nullptr, *Vp = nullptr;   // policy
+  float *Pv = nullptr, *Gv = nullptr, *Mv = nullptr, *Vv = nullptr;   // value
+  PpoScalars* sc = nullptr;
+  float *values = nullptr, *returns = nullptr, *adv = nullptr, *lp_old = nullptr;      // [max_samples]
+  // minibatch workspace (mb rows)
+  float *xv = nullptr, *hv[ILSX_MAX_HID], *dv[ILSX_MAX_HID], *dhv = nullptr, *vpred = nullptr;
+  float *xp = nullptr, *hp[ILSX_MAX_HID], *dp[ILSX_MAX_HID], *dhp = nullptr, *mu = nullptr, *lp = nullptr, *aux = nullptr;
+  float* partial = nullptr;
+  int *offs = nullptr, *perm = nullptr;
+  DwArgs jobs_v, jobs_p;
+  float* log_std() const { return Pp + Lp.n_int; }
+  float* g_log_std() const { return Gp + Lp.n_int; }
+};
+
+static int ppo_refresh(ilsx_ppo* p, int which) {
+  hipLaunchKernelGGL(k_ppo_refresh, dim3(1), dim3(1), 0, p->ctx->stream, p->sc, which, p->cfg.value_lr, p->cfg.policy_lr);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo** out) {
+  if (!ctx || !cfg || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_create: NULL argument");
+  if (cfg->max_samples < 1 || cfg->mini_batch_size < 1) ILSX_FAIL(ILSX_ERR_ARG, "max_samples / mini_batch_size must be >= 1");
+  HIPCHK(hipSetDevice(ctx->device));
+  ilsx_ppo* p = new ilsx_ppo();
+  p->ctx = ctx; p->cfg = *cfg; p->o = cfg->obs_dim; p->a = cfg->act_dim;
+  ilsx_mlp_cfg mp = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, cfg->act_dim, 1, ILSX_ACT_TANH};
+  ilsx_mlp_cfg mv = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, 1, 1, ILSX_ACT_TANH};
+  int rc = net_layout_build(mp, &p->Lp);
+  if (rc == ILSX_OK) rc = net_layout_build(mv, &p->Lv);
+  if (rc != ILSX_OK) { delete p; return rc; }
+  p->np = p->Lp.n_int + ((cfg->act_dim + 3) / 4) * 4;
+  p->nv = p->Lv.n_int;
+  const size_t N = (size_t)cfg->max_samples, mb = (size_t)cfg->mini_batch_size, H = (size_t)cfg->hidden;
+  auto A = [&](float** q, size_t cnt) { return ctx_alloc(ctx, cnt * sizeof(float), (void**)q, true); };
+  rc = A(&p->Pp, p->np);
+  if (rc == ILSX_OK) rc = A(&p->Gp, p->np);
+  if (rc == ILSX_OK) rc = A(&p->Mp, p->np);
+  if (rc == ILSX_OK) rc = A(&p->Vp, p->np);
+  if (rc == ILSX_OK) rc = A(&p->Pv, p->nv);
+  if (rc == ILSX_OK) rc = A(&p->Gv, p->nv);
+  if (rc == ILSX_OK) rc = A(&p->Mv, p->nv);
+  if (rc == ILSX_OK) rc = A(&p->Vv, p->nv);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(PpoScalars), (void**)&p->sc);
+  if (rc == ILSX_OK) rc = A(&p->values, N);
+  if (rc == ILSX_OK) rc = A(&p->returns, N);
+  if (rc == ILSX_OK) rc = A(&p->adv, N);
+  if (rc == ILSX_OK) rc = A(&p->lp_old, N);
+  if (rc == ILSX_OK) rc = A(&p->xv, mb * p->Lv.KP);
+  if (rc == ILSX_OK) rc = A(&p->xp, mb * p->Lp.KP);
+  for (int l = 0; l < cfg->n_hidden && rc == ILSX_OK; ++l) {
+    rc = A(&p->hv[l], mb * H);
+    if (rc == ILSX_OK) rc = A(&p->dv[l], mb * H);
+    if (rc == ILSX_OK) rc = A(&p->hp[l], mb * H);
+    if (rc == ILSX_OK) rc = A(&p->dp[l], mb * H);
+  }
+  if (rc == ILSX_OK) rc = A(&p->dhv, mb);
+  if (rc == ILSX_OK) rc = A(&p->vpred, mb);
+  if (rc == ILSX_OK) rc = A(&p->dhp, mb * p->a);
+  if (rc == ILSX_OK) rc = A(&p->mu, mb * p->a);
+  if (rc == ILSX_OK) rc = A(&p->lp, mb);
+  if (rc == ILSX_OK) rc = A(&p->aux, mb * p->a);
+  if (rc == ILSX_OK) rc = A(&p->partial, 64);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, (N + 1) * sizeof(int), (void**)&p->offs);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * sizeof(int), (void**)&p->perm);
+  if (rc != ILSX_OK) { delete p; return rc; }
+  memset(&p->jobs_v, 0, sizeof p->jobs_v);
+  memset(&p->jobs_p, 0, sizeof p->jobs_p);
+  ILSX_TRY(build_dw_jobs(p->Lv, p->Gv, p->xv, p->hv, p->dv, p->dhv, &p->jobs_v));
+  ILSX_TRY(build_dw_jobs(p->Lp, p->Gp, p->xp, p->hp, p->dp, p->dhp, &p->jobs_p));
+  ILSX_TRY(ppo_refresh(p, -1));
+  *out = p;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_ppo_destroy(ilsx_ppo* p) {
+  if (!p) return ILSX_OK;
+  hipSetDevice(p->ctx->device);
+  hipStreamSynchronize(p->ctx->stream);
+  // arenas and workspaces are released with the ctx
+  delete p;
+  return ILSX_OK;
+}
+
+// which: 0 = policy (flat: mean-net parameters | action_log_std[a]), 1 = value net
+extern "C" int ilsx_ppo_num_params(const ilsx_ppo* p, int which, size_t* out) {
+  if (!p || !out || which < 0 || which > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_num_params: bad argument");
+  *out = which == 0 ? p->Lp.n_flat + p->a : p->Lv.n_flat;
+  return ILSX_OK;
+}
+extern "C" int ilsx_ppo_set_params(ilsx_ppo* p, int which, const float* src, size_t n) {
+  if (!p || !src || which < 0 || which > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_set_params: bad argument");
+  HIPCHK(hipSetDevice(p->ctx->device));
+  if (which == 1) return net_upload_flat(p->ctx, p->Lv, p->Pv, src, n, 0);
+  if (n != p->Lp.n_flat + p->a) ILSX_FAIL(ILSX_ERR_ARG, "policy parameter count %zu != %zu", n, p->Lp.n_flat + p->a);
+  ILSX_TRY(net_upload_flat(p->ctx, p->Lp, p->Pp, src, p->Lp.n_flat, 0));
+  HIPCHK(hipMemcpyAsync(p->log_std(), src + p->Lp.n_flat, p->a * sizeof(float), hipMemcpyHostToDevice, p->ctx->stream));
+  HIPCHK(hipStreamSynchronize(p->ctx->stream));
+  return ILSX_OK;
+}
+extern "C" int ilsx_ppo_get_params(ilsx_ppo* p, int which, float* dst, size_t n) {
+  if (!p || !dst || which < 0 || which > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_get_params: bad argument");
+  HIPCHK(hipSetDevice(p->ctx->device));
+  if (which == 1) return net_download_flat(p->ctx, p->Lv, p->Pv, dst, n, 0);
+  if (n != p->Lp.n_flat + p->a) ILSX_FAIL(ILSX_ERR_ARG, "policy parameter count %zu != %zu", n, p->Lp.n_flat + p->a);
+  ILSX_TRY(net_download_flat(p->ctx, p->Lp, p->Pp, dst, p->Lp.n_flat, 0));
+  HIPCHK(hipMemcpyAsync(dst + p->Lp.n_flat, p->log_std(), p->a * sizeof(float), hipMemcpyDeviceToHost, p->ctx->stream));
+  HIPCHK(hipStreamSynchronize(p->ctx->stream));
+  return ILSX_OK;
+}
+
+static void ppo_fwd_task(FwdTask& t, const NetLayout& L, float* base, const float* obs, int o) {
+  t.net = net_view(L, base);
+  t.x0 = obs; t.d0 = o; t.s0 = o;
+}
+
+// values[N] = vf(obs) ; fixed log-probs[N] = log pi(act | obs)   (ppo.py:104-113)
+static int ppo_full_forward(ilsx_ppo* p, const float* obs, const float* act, int N, bool value, float* out) {
+  FwdArgs A;
+  memset(&A, 0, sizeof A);
+  A.rows = N; A.ntasks = 1; A.seed = p->ctx->seed;
+  FwdTask& t = A.t[0];
+  if (value) {
+    ppo_fwd_task(t, p->Lv, p->Pv, obs, p->o);
+    t.head = HEAD_RAW; t.out = out;
+    return launch_fwd(p->ctx, A, p->cfg.hidden, ILSX_ACT_TANH, p->Lv.KP);
+  }
+  ppo_fwd_task(t, p->Lp, p->Pp, obs, p->o);
+  t.head = HEAD_GAUSS_LOGP_OF_ACT; t.act_in = act; t.log_std = p->log_std(); t.logp = out;
+  return launch_fwd(p->ctx, A, p->cfg.hidden, ILSX_ACT_TANH, p->Lp.KP);
+}
+
+extern "C" int ilsx_ppo_gae(ilsx_ppo* p, const float* obs, const float* act, const float* rew, const int32_t* traj_offsets_host,
+                            int n_traj, float* returns_out, float* adv_out, float* values_out, float* logp_out) {
+  if (!p || !obs || !act || !rew || !traj_offsets_host || n_traj < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_gae: bad argument");
+  const int N = traj_offsets_host[n_traj];
+  if (traj_offsets_host[0] != 0 || N < 1 || N > p->cfg.max_samples) ILSX_FAIL(ILSX_ERR_ARG, "trajectory offsets must span 1..max_samples rows");
+  HIPCHK(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  HIPCHK(hipMemcpyAsync(p->offs, traj_offsets_host, (size_t)(n_traj + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  ILSX_TRY(ppo_full_forward(p, obs, act, N, true, p->values));
+  hipLaunchKernelGGL(k_ppo_gae, dim3((n_traj + 63) / 64), dim3(64), 0, st, p->values, rew, p->offs, n_traj, p->cfg.reward_scale,
+                     p->cfg.discount, p->cfg.gae_tau, p->returns, p->adv);
+  HIPCHK(hipGetLastError());
+  ILSX_TRY(ppo_full_forward(p, obs, act, N, false, p->lp_old));
+  p->N = N;
+  const size_t nb = (size_t)N * sizeof(float);
+  if (returns_out) HIPCHK(hipMemcpyAsync(returns_out, p->returns, nb, hipMemcpyDeviceToDevice, st));
+  if (adv_out) HIPCHK(hipMemcpyAsync(adv_out, p->adv, nb, hipMemcpyDeviceToDevice, st));
+  if (values_out) HIPCHK(hipMemcpyAsync(values_out, p->values, nb, hipMemcpyDeviceToDevice, st));
+  if (logp_out) HIPCHK(hipMemcpyAsync(logp_out, p->lp_old, nb, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));   // the host offsets buffer may be reused by the caller
+  return ILSX_OK;
+}
+
+static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const int* idx, int rows) {
+  ilsx_ctx* ctx = p->ctx;
+  const int H = p->cfg.hidden, nh = p->cfg.n_hidden;
+  const float inv = 1.0f / (float)rows;
+  // ---- value update (ppo.py:136-153)
+  {
+    FwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = rows; A.ntasks = 1; A.seed = ctx->seed;
+    FwdTask& t = A.t[0];
+    ppo_fwd_task(t, p->Lv, p->Pv, obs, p->o);
+    t.rows_idx = idx; t.xsave = p->xv;
+    for (int l = 0; l < nh; ++l) t.hsave[l] = p->hv[l];
+    t.head = HEAD_RAW; t.out = p->vpred;
+    ILSX_TRY(launch_fwd(ctx, A, H, ILSX_ACT_TANH, p->Lv.KP));
+    BwdArgs Bw;
+    memset(&Bw, 0, sizeof Bw);
+    Bw.rows = rows; Bw.ntasks = 1; Bw.inv_B = inv;
+    BwdTask& b = Bw.t[0];
+    b.net = net_view(p->Lv, p->Pv);
+    for (int l = 0; l < nh; ++l) { b.hsave[l] = p->hv[l]; b.dsave[l] = p->dv[l]; }
+    b.dhead = p->dhv; b.loss = LOSS_MSE; b.rows_idx = idx; b.pred = p->vpred; b.target = p->returns;
+    ILSX_TRY(launch_bwd_dx(ctx, Bw, H, ILSX_ACT_TANH));
+    AdamFuse F;
+    memset(&F, 0, sizeof F);
+    F.on = 1; F.Gbase = p->Gv; F.P = p->Pv; F.M = p->Mv; F.V = p->Vv; F.T = nullptr;
+    F.b1 = 0.9f; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f; F.l2x2 = 2.0f * p->cfg.value_l2_reg;
+    F.step_size = &p->sc->v_step; F.bc2_sqrt = &p->sc->v_bc2s;
+    ILSX_TRY(launch_bwd_dw(ctx, p->jobs_v, rows, &F));
+    ILSX_TRY(ppo_refresh(p, 0));
+  }
+  // ---- policy update (ppo.py:155-170)
+  {
+    FwdArgs A;
+    memset(&A, 0, sizeof A);
+    A.rows = rows; A.ntasks = 1; A.seed = ctx->seed;
+    FwdTask& t = A.t[0];
+    ppo_fwd_task(t, p->Lp, p->Pp, obs, p->o);
+    t.rows_idx = idx; t.xsave = p->xp;
+    for (int l = 0; l < nh; ++l) t.hsave[l] = p->hp[l];
+    t.head = HEAD_GAUSS_LOGP_OF_ACT; t.act_in = act; t.log_std = p->log_std(); t.logp = p->lp; t.out = p->mu;
+    ILSX_TRY(launch_fwd(ctx, A, H, ILSX_ACT_TANH, p->Lp.KP));
+    BwdArgs Bw;
+    memset(&Bw, 0, sizeof Bw);
+    Bw.rows = rows; Bw.ntasks = 1; Bw.inv_B = inv;
+    BwdTask& b = Bw.t[0];
+    b.net = net_view(p->Lp, p->Pp);
+    for (int l = 0; l < nh; ++l) { b.hsave[l] = p->hp[l]; b.dsave[l] = p->dp[l]; }
+    b.dhead = p->dhp; b.loss = LOSS_PPO_POLICY; b.rows_idx = idx;
+    b.pred = p->lp; b.target = p->adv; b.lp_old = p->lp_old; b.act_all = act; b.log_std = p->log_std(); b.mu = p->mu;
+    b.aux = p->aux; b.clip_eps = p->cfg.clip_eps;
+    ILSX_TRY(launch_bwd_dx(ctx, Bw, H, ILSX_ACT_TANH));
+    ILSX_TRY(launch_bwd_dw(ctx, p->jobs_p, rows, nullptr));
+    PpoNormArgs Nn;
+    Nn.G = p->Gp; Nn.n = (int)p->Lp.n_int;
+    for (int l = 1; l <= 2; ++l) {
+      Nn.skip0[l - 1] = l < nh ? p->Lp.off_Wb[l] : 0;
+      Nn.skip1[l - 1] = l < nh ? p->Lp.off_Wb[l] + H * H : 0;
+    }
+    Nn.aux = p->aux; Nn.rows = rows; Nn.a = p->a; Nn.g_logstd = p->g_log_std(); Nn.partial = p->partial;
+    const int nblk = 32;
+    hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
+    PpoClipAdamArgs C;
+    C.P = p->Pp; C.G = p->Gp; C.M = p->Mp; C.V = p->Vp; C.n = (int)p->np;
+    C.partial = p->partial; C.nparts = nblk; C.max_norm = 20.0f; C.b1 = 0.9f; C.b2 = 0.999f; C.eps = 1e-8f; C.sc = p->sc;
+    hipLaunchKernelGGL(k_ppo_clip_adam, dim3(64), dim3(256), 0, ctx->stream, C);
+    HIPCHK(hipGetLastError());
+    ILSX_TRY(ppo_refresh(p, 1));
+  }
+  return ILSX_OK;
+}
+
+// PPO.train_step (ppo.py:102-170).  perms_host: update_epoch x N int32 permutations (the reference draws
+// torch.randperm per epoch), or NULL = drawn here from a host Mersenne twister seeded by the ctx seed.
+extern "C" int ilsx_ppo_train(ilsx_ppo* p, const float* obs, const float* act, const float* rew,
+                              const int32_t* traj_offsets_host, int n_traj, const int32_t* perms_host) {
+  ILSX_TRY(ilsx_ppo_gae(p, obs, act, rew, traj_offsets_host, n_traj, nullptr, nullptr, nullptr, nullptr));
+  const int N = p->N, mb = p->cfg.mini_batch_size;
+  static std::mt19937_64 gen(0x5eed);
+  std::vector<int> perm(N);
+  for (int ep = 0; ep < p->cfg.update_epoch; ++ep) {
+    if (perms_host) {
+      memcpy(perm.data(), perms_host + (size_t)ep * N, (size_t)N * sizeof(int));
+    } else {
+      std::iota(perm.begin(), perm.end(), 0);
+      std::shuffle(perm.begin(), perm.end(), gen);
+    }
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));   // previous epoch's kernels still read p->perm
+    HIPCHK(hipMemcpyAsync(p->perm, perm.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, p->ctx->stream));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    for (int s = 0; s < N; s += mb) ILSX_TRY(ppo_minibatch(p, obs, act, p->perm + s, std::min(mb, N - s)));
+  }
+  return ILSX_OK;
+}
+
+// ReparamMultivariateGaussianPolicy.get_actions (policies.py:392-417): mean + exp(log_std)*eps, un-squashed
+extern "C" int ilsx_ppo_policy_act(ilsx_ppo* p, const float* obs, int n, int deterministic, const float* eps, float* act,
+                                   float* logp) {
+  if (!p || !obs || !act || n < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_policy_act: bad argument");
+  HIPCHK(hipSetDevice(p->ctx->device));
+  static unsigned long long calls = 0;
+  FwdArgs A;
+  memset(&A, 0, sizeof A);
+  A.rows = n; A.ntasks = 1; A.seed = p->ctx->seed; A.step_host = ++calls;
+  FwdTask& t = A.t[0];
+  ppo_fwd_task(t, p->Lp, p->Pp, obs, p->o);
+  if (deterministic) { t.head = HEAD_RAW; t.out = act; }   // action = mean (policies.py:407-408)
+  else { t.head = HEAD_GAUSS_SAMPLE; t.eps = eps; t.action = act; t.logp = logp; t.log_std = p->log_std(); t.rng_stream = 0x50504f00u; }
+  return launch_fwd(p->ctx, A, p->cfg.hidden, ILSX_ACT_TANH, p->Lp.KP);
+}

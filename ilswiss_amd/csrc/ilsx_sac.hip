@@ -76,6 +76,20 @@ struct StatsArgs {
 };
 
 // single workgroup: losses of sac_alpha.py:122-123,148-153,161-162 + the alpha gradient
+// the alpha gradient alone (every step); the full statistics only when the host asked for them
+__device__ __forceinline__ void sac_alpha_grad_dev(const StatsArgs& S) {
+  __shared__ float sh2[4];
+  float lpe = 0.f;
+  for (int r = threadIdx.x; r < S.B; r += 256) lpe += S.logp[r] + S.target_entropy;
+  lpe = block256_sum(lpe, sh2);
+  if (threadIdx.x == 0) {
+    S.scal->alpha_used = S.scal->alpha;
+    S.scal->log_alpha_used = S.scal->log_alpha;
+    S.alpha_grad_slot[0] = -lpe * S.inv_B;
+    S.alpha_grad_slot[1] = 0.f; S.alpha_grad_slot[2] = 0.f; S.alpha_grad_slot[3] = 0.f;
+  }
+}
+
 __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
   __shared__ float sh[4];
   const float alpha = S.scal->alpha;
@@ -148,7 +162,9 @@ __global__ void k_sac_finish(DevScalars* sc, const float* alpha_grad_slot, int t
 // stats + alpha Adam + counters in ONE launch (the un-split step: nothing has to be all-reduced in between)
 __global__ __launch_bounds__(256) void k_sac_tail(const StatsArgs S, int train_alpha, float lr, float b1, float b2,
                                                   float eps, float qf_lr, float policy_lr) {
-  sac_stats_dev(S);
+  if (S.scal->want_stats) sac_stats_dev(S);   // workgroup-uniform
+  else sac_alpha_grad_dev(S);
+  if (threadIdx.x == 0) S.scal->want_stats = 0;
   if (threadIdx.x == 0) sac_finish_dev(S.scal, S.alpha_grad_slot, train_alpha, lr, b1, b2, eps, qf_lr, policy_lr);
 }
 
@@ -509,6 +525,12 @@ static int sac_full_step(ilsx_sac* s) {
   return rc;
 }
 
+static int sac_request_stats(ilsx_sac* s) {  // ordered on the stream before the step that must produce them
+  static const int one = 1;
+  HIPCHK(hipMemcpyAsync(&s->scal->want_stats, &one, sizeof(int), hipMemcpyHostToDevice, s->ctx->stream));
+  return ILSX_OK;
+}
+
 static int sac_read_stats(ilsx_sac* s, ilsx_sac_stats* out) {
   DevScalars h;
   HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
@@ -567,6 +589,7 @@ extern "C" int ilsx_sac_train_step(ilsx_sac* s, const float* obs, const float* a
                                    const float* done, const float* nobs, int B, const float* eps_next,
                                    const float* eps_cur, ilsx_sac_stats* stats) {
   ILSX_TRY(ilsx_sac_set_batch(s, obs, act, rew, done, nobs, B, eps_next, eps_cur));
+  if (stats) ILSX_TRY(sac_request_stats(s));
   ILSX_TRY(sac_full_step(s));
   if (stats) return sac_read_stats(s, stats);
   return ILSX_OK;
@@ -595,7 +618,10 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   s->eps_explicit = false;
   static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
   if (no_graph || s->ctx->prof_on) {
-    for (int i = 0; i < n_steps; ++i) ILSX_TRY(sac_sample_and_step(s, rb, B));
+    for (int i = 0; i < n_steps; ++i) {
+      if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
+      ILSX_TRY(sac_sample_and_step(s, rb, B));
+    }
   } else {
     if (!s->graph || s->graph_rb != rb || s->graph_B != B) {
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
@@ -610,7 +636,10 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
       if (e != hipSuccess) { s->graph = nullptr; ILSX_FAIL(ILSX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
       s->graph_rb = rb; s->graph_B = B;
     }
-    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(s->graph, st));
+    for (int i = 0; i < n_steps; ++i) {
+      if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
+      HIPCHK(hipGraphLaunch(s->graph, st));
+    }
   }
   if (stats) return sac_read_stats(s, stats);
   return ILSX_OK;

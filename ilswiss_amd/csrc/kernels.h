@@ -23,8 +23,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ILSX_MAX_HID 3
 #define ILSX_MAX_NO 64   // max total head outputs (n_heads*out_dim)
 
-enum { HEAD_RAW = 0, HEAD_TANH_SAMPLE = 1, HEAD_TANH_DET = 2, HEAD_TANH_LOGP_OF_ACT = 3 };
-enum { LOSS_GIVEN = 0, LOSS_SAC_CRITIC = 1, LOSS_SAC_ACTORQ = 2, LOSS_SAC_POLICY = 3 };
+enum { HEAD_RAW = 0, HEAD_TANH_SAMPLE = 1, HEAD_TANH_DET = 2, HEAD_TANH_LOGP_OF_ACT = 3,
+       HEAD_GAUSS_SAMPLE = 4, HEAD_GAUSS_LOGP_OF_ACT = 5 };  // un-squashed Gaussian, state-independent log_std (PPO)
+enum { LOSS_GIVEN = 0, LOSS_SAC_CRITIC = 1, LOSS_SAC_ACTORQ = 2, LOSS_SAC_POLICY = 3, LOSS_MSE = 4, LOSS_PPO_POLICY = 5 };
 enum { ACT_RELU = 0, ACT_TANH = 1 };
 
 #define LOG_SIG_MIN (-20.0f)
@@ -60,7 +61,7 @@ struct DevScalars {
   float q1_mean, q2_mean, log_pi_mean, mu_mean, log_std_mean;
   // Adam bias-correction scalars for the NEXT step: lr/(1-b1^t), sqrt(1-b2^t)   (t = t_x + 1)
   float adam_q_step, adam_q_bc2s, adam_pi_step, adam_pi_bc2s;
-  float pad1;
+  int want_stats;   // host sets 1 before the step whose statistics it will read (sac_alpha.py:186: one batch per epoch)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -160,6 +161,8 @@ struct FwdTask {
   float* logp;                       // [rows] nullable
   float* part;                       // column-split kernels: partial head sums [CS][part_stride][NO]
   int g0_off, g1_off, publish;       // GatherSpec: record offsets of the x0 / x1 segments; 1 = publish s,a,r,d ; 2 = s2
+  const int* rows_idx;               // nullable: row r of this launch reads source row rows_idx[r] (minibatch gather)
+  const float* log_std;              // HEAD_GAUSS_*: state-independent log-std parameter [a]
 };
 // A per-row scalar (Q value) that may still be split into CS column-slice partial sums: summed in a fixed
 // order by whoever consumes it (the "combine in the next kernel's prologue" seam of a split-K reduction).
@@ -221,8 +224,9 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
     const int r = e / KP, k = e - r * KP, gr = r0 + r;
     float v = 0.0f;
     if (gr < rows) {
-      if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
-      else if (k < T.d0 + T.d1) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
+      const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;
+      if (k < T.d0) v = T.x0[sr * T.s0 + k];
+      else if (k < T.d0 + T.d1) v = T.x1[sr * T.s1 + (k - T.d0)];
       if (T.xsave) T.xsave[(size_t)gr * KP + k] = v;
     }
     xs[r * LDX + k] = v;
@@ -326,6 +330,39 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
     const float* ho = hout + row * ILSX_MAX_NO;
     if (T.out && lane < NO) T.out[(size_t)gr * NO + lane] = ho[lane];
     if (T.head == HEAD_RAW) continue;
+    if (T.head >= HEAD_GAUSS_SAMPLE) {
+      // ReparamMultivariateGaussianPolicy, conditioned_std=False (policies.py:398-417,462-478 + distributions.py:43-50)
+      const int a = NO, j = lane;
+      float q = 0.f, l = 0.f;
+      if (j < a) {
+        const float mu = ho[j], ls = T.log_std[j];
+        float act;
+        if (T.head == HEAD_GAUSS_LOGP_OF_ACT) {
+          const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;
+          act = T.act_in[sr * a + j];
+        } else {
+          float e;
+          if (T.eps) {
+            e = T.eps[(size_t)gr * a + j];
+          } else {
+            float z4[4];
+            philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+            const int qd = j & 3;
+            e = qd == 0 ? z4[0] : qd == 1 ? z4[1] : qd == 2 ? z4[2] : z4[3];
+          }
+          act = e * expf(ls) + mu;
+          if (T.action) T.action[(size_t)gr * a + j] = act;
+        }
+        const float dm = mu - act;
+        q = dm * dm / expf(2.0f * ls);
+        l = ls;
+      }
+      if (T.logp) {
+        q = wave_sum(q); l = wave_sum(l);
+        if (lane == 0) T.logp[gr] = -0.5f * q - (l + HALF_LOG_2PI);
+      }
+      continue;
+    }
     const int a = NO >> 1, j = lane;
     float lp_quad = 0.f, lp_ls = 0.f, lp_jac = 0.f;
     if (j < a) {
@@ -383,6 +420,12 @@ struct BwdTask {
   const float *raw, *eps, *action, *ga1, *ga2;            // LOSS_SAC_POLICY (raw = mu|log_std_raw)
   float* dx;                    // [rows][dx_cols] = dL/dx[:, dx_col0:dx_col0+dx_cols], nullable
   int dx_col0, dx_cols;
+  // LOSS_MSE / LOSS_PPO_POLICY (minibatch rows gathered through rows_idx)
+  const int* rows_idx;
+  const float *pred, *target;          // LOSS_MSE: v_pred [rows], returns [N]  ;  PPO: logp_cur [rows], advantages [N]
+  const float *lp_old, *act_all, *log_std, *mu;   // PPO: fixed log-probs [N], actions [N][a], log_std [a], mean [rows][a]
+  float* aux;                          // PPO: per-row d(loss)/d(log_std) contributions [rows][a]
+  float clip_eps;
 };
 struct BwdArgs {
   BwdTask t[2];
@@ -413,6 +456,24 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
     const float a1 = T.q1n.get(gr), a2 = T.q2n.get(gr);
     const float w1 = a1 < a2 ? 1.0f : (a1 == a2 ? 0.5f : 0.0f);
     d = -(T.which == 0 ? w1 : 1.0f - w1) * A.inv_B;
+  } else if (T.loss == LOSS_MSE) {
+    // ppo.py:145: mean((v - R)^2) over the minibatch
+    const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;
+    d = 2.0f * (T.pred[gr] - T.target[sr]) * A.inv_B;
+  } else if (T.loss == LOSS_PPO_POLICY) {
+    // ppo.py:155-164: ratio = exp(logp - logp_old); -mean(min(ratio*A, clamp(ratio, 1+-eps)*A)); j indexes the mean
+    const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;
+    const float adv = T.target[sr];
+    const float ratio = expf(T.pred[gr] - T.lp_old[sr]);
+    const float lo = 1.0f - T.clip_eps, hi = 1.0f + T.clip_eps;
+    const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, lo), hi) * adv;
+    const float inside = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;          // clamp passes gradient on [lo,hi]
+    const float w = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);                 // torch.min tie rule
+    const float dlp = -(w * adv + (1.0f - w) * adv * inside) * A.inv_B * ratio;
+    const float ls = T.log_std[j], var = expf(2.0f * ls);
+    const float diff = T.act_all[sr * NO + j] - T.mu[(size_t)gr * NO + j];
+    d = dlp * diff / var;
+    if (T.aux) T.aux[(size_t)gr * NO + j] = dlp * (diff * diff / var - 1.0f);
   } else {  // LOSS_SAC_POLICY: SURVEY Appendix A.1/A.2 ; j < a -> d mu_j, else d log_std_raw_{j-a}
     const int a = NO >> 1, jj = j < a ? j : j - a;
     const float alpha = A.scal->alpha;
@@ -959,6 +1020,7 @@ struct AdamFuse {
   float b1, b2, eps, tau;
   const float* step_size; const float* bc2_sqrt;
   int on;
+  float l2x2;   // gradient of an L2 penalty lambda*sum(p^2) folded in: g += l2x2 * p  (ppo.py:147-148, l2x2 = 2*lambda)
 };
 struct DwArgs {
   DwMat m[DW_MAX_MATS];
@@ -980,6 +1042,7 @@ __device__ __forceinline__ AdamOperands adam_prefetch(const AdamFuse& F, size_t 
 }
 __device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float bc2s, const AdamOperands& o, size_t i0,
                                            size_t i1, bool two, float g) {
+  g = g + F.l2x2 * o.p;
   const float m = o.m * F.b1 + (1.0f - F.b1) * g;
   const float v = o.v * F.b2 + (1.0f - F.b2) * g * g;
   const float p = o.p - step * (m / (sqrtf(v) / bc2s + F.eps));

@@ -1,0 +1,146 @@
+"""PPO over libilsx: the reference's `PPO` trainer (rlkit/torch/algorithms/ppo/ppo.py:11-190) and its Gaussian
+policy `ReparamMultivariateGaussianPolicy(conditioned_std=False)` (rlkit/torch/common/policies.py:348-478).
+Constructor kwargs are the YAML `ppo_params` keys (exp_specs/ppo/ppo_hopper.yaml:41-50); unknown keys are
+swallowed like the reference's **kwargs.  GAE, the fixed log-probs and every minibatch update run on the device
+(csrc/ilsx_ppo.hip); this module only moves trajectories to HBM and builds the trajectory offset table.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from .device import as_dev
+from .networks import Mlp
+from .sac import Trainer
+
+
+class ReparamMultivariateGaussianPolicy(Mlp):
+    """policies.py:348-478 with conditioned_std=False: tanh-hidden mean network whose last layer is scaled by
+    0.1 (bias 0) after the usual init (:378-379), and a state-independent `action_log_std` parameter (zeros)."""
+
+    def __init__(self, hidden_sizes, obs_dim, action_dim, conditioned_std=False, init_w=1e-3,
+                 hidden_activation="tanh", **kwargs):
+        if conditioned_std:
+            raise NotImplementedError("PPO configs use conditioned_std=False (ppo_exp_script.py:90-96)")
+        super().__init__(hidden_sizes, input_size=obs_dim, output_size=action_dim, init_w=init_w,
+                         hidden_activation=hidden_activation, **kwargs)
+        self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
+        flat = self.get_flat_params()
+        nl = self.hidden_sizes[-1] * self.action_dim
+        flat[-(nl + self.action_dim):-self.action_dim] *= np.float32(0.1)
+        flat[-self.action_dim:] = 0.0
+        self.set_flat_params(flat)
+        self.action_log_std = np.zeros(self.action_dim, np.float32)
+        self._ppo = None   # set by PPO: from then on the trainer's device copy is the live one
+
+    def ppo_flat(self):  # mean net | action_log_std
+        return np.concatenate([self.get_flat_params(), self.action_log_std])
+
+    def get_actions(self, obs_np, deterministic=False):  # policies.py:392-395
+        if self._ppo is None:
+            raise RuntimeError("bind the policy to a PPO trainer first (PPO(policy=..., vf=...))")
+        return self._ppo.policy_act(obs_np, deterministic)[0]
+
+    def get_action(self, obs_np, deterministic=False):
+        return self.get_actions(np.asarray(obs_np)[None], deterministic)[0], {}
+
+
+class PPO(Trainer):
+    def __init__(self, policy, vf, mini_batch_size=64, clip_eps=0.2, reward_scale=1.0, discount=0.99, policy_lr=3e-4,
+                 value_lr=3e-4, gae_tau=0.9, value_l2_reg=1e-3, use_value_clip=False, update_epoch=10,
+                 lambda_entropy_policy=0.0, max_samples=16384, **kwargs):
+        if use_value_clip:
+            raise NotImplementedError("use_value_clip is never read by the reference's train_step (ppo.py:136-153)")
+        self.on_policy = True  # ppo.py:30
+        self.policy, self.vf, self.ctx = policy, vf, policy.ctx
+        if vf.act != 1 or policy.act != 1:
+            raise ValueError("PPO networks use tanh hidden units (ppo_exp_script.py:82-96)")
+        if vf.hidden_sizes != policy.hidden_sizes:
+            raise ValueError("policy and value net share net_size / num_hidden_layers (ppo_exp_script.py:79-80)")
+        self.mini_batch_size, self.update_epoch, self.max_samples = int(mini_batch_size), int(update_epoch), int(max_samples)
+        self.o, self.a = policy.obs_dim, policy.action_dim
+        cfg = _lib.PpoCfg(self.o, self.a, len(policy.hidden_sizes), policy.hidden_sizes[0], reward_scale, discount,
+                          clip_eps, policy_lr, value_lr, gae_tau, value_l2_reg, self.mini_batch_size,
+                          self.update_epoch, self.max_samples)
+        self.h = C.c_void_p()
+        _lib.check(self.ctx.lib.ilsx_ppo_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
+        self.set_flat_params(policy.ppo_flat(), vf.get_flat_params())
+        policy._ppo = self
+        self.eval_statistics = None
+
+    # ---- parameters (0 = policy: mean net | action_log_std ; 1 = value net)
+    def _num(self, which):
+        n = C.c_size_t()
+        _lib.check(self.ctx.lib.ilsx_ppo_num_params(self.h, which, C.byref(n)))
+        return n.value
+
+    def set_flat_params(self, pi_flat=None, vf_flat=None):
+        for which, flat in ((0, pi_flat), (1, vf_flat)):
+            if flat is not None:
+                flat = np.ascontiguousarray(flat, np.float32)
+                _lib.check(self.ctx.lib.ilsx_ppo_set_params(self.h, which, flat.ctypes.data_as(C.c_void_p), flat.size))
+
+    def get_flat_params(self, which):
+        out = np.empty(self._num(which), np.float32)
+        _lib.check(self.ctx.lib.ilsx_ppo_get_params(self.h, which, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    # ---- data plumbing
+    def _upload(self, trajs):
+        lens = [int(np.shape(t["rewards"])[0]) for t in trajs]
+        offs = np.zeros(len(lens) + 1, np.int32)
+        offs[1:] = np.cumsum(lens)
+        cat = lambda k, w: np.concatenate([np.asarray(t[k], np.float32).reshape(-1, w) for t in trajs])  # noqa: E731
+        keep, ptrs = [], []
+        for arr in (cat("observations", self.o), cat("actions", self.a), cat("rewards", 1)):
+            k, p = as_dev(self.ctx, arr)
+            keep.append(k)
+            ptrs.append(p)
+        return keep, ptrs, offs
+
+    def calc_adv(self, trajs):
+        """ppo.py:57-100 -> (returns, advantages, values, fixed log-probs), numpy [N,1]."""
+        keep, (po, pa, pr), offs = self._upload(trajs)
+        N = int(offs[-1])
+        outs = [self.ctx.empty((N,)) for _ in range(4)]
+        _lib.check(self.ctx.lib.ilsx_ppo_gae(self.h, po, pa, pr, offs.ctypes.data_as(C.c_void_p), len(offs) - 1,
+                                             *[x.ptr for x in outs]))
+        return tuple(x.numpy().reshape(N, 1) for x in outs)
+
+    def train_step(self, trajs, perms=None):
+        """ppo.py:102-170.  trajs: list of dicts with observations / actions / rewards.  perms (update_epoch x N)
+        replaces the library's own shuffles (parity tests)."""
+        keep, (po, pa, pr), offs = self._upload(trajs)
+        pp = None
+        if perms is not None:
+            perms = np.ascontiguousarray(perms, np.int32)
+            assert perms.shape == (self.update_epoch, int(offs[-1]))
+            pp = perms.ctypes.data_as(C.c_void_p)
+        _lib.check(self.ctx.lib.ilsx_ppo_train(self.h, po, pa, pr, offs.ctypes.data_as(C.c_void_p), len(offs) - 1, pp))
+        if self.eval_statistics is None:
+            self.eval_statistics = OrderedDict()
+
+    def policy_act(self, obs, deterministic=False, eps=None):
+        obs = np.ascontiguousarray(obs, np.float32)
+        n = obs.shape[0]
+        ko, po = as_dev(self.ctx, obs)
+        ke, pe = as_dev(self.ctx, np.ascontiguousarray(eps, np.float32)) if eps is not None else (None, None)
+        act, lp = self.ctx.empty((n, self.a)), self.ctx.empty((n,))
+        _lib.check(self.ctx.lib.ilsx_ppo_policy_act(self.h, po, n, int(bool(deterministic)), pe, act.ptr,
+                                                    None if deterministic else lp.ptr))
+        return act.numpy(), (None if deterministic else lp.numpy().reshape(n, 1))
+
+    # ---- Trainer API
+    @property
+    def networks(self):
+        return [self.policy, self.vf]
+
+    def get_snapshot(self):
+        return dict(policy=self.get_flat_params(0), vf=self.get_flat_params(1))
+
+    def get_eval_statistics(self):
+        return self.eval_statistics
+
+    def end_epoch(self):
+        self.eval_statistics = None

@@ -45,6 +45,7 @@ typedef struct ilsx_replay ilsx_replay;
 typedef struct ilsx_sac ilsx_sac;
 typedef struct ilsx_vecenv ilsx_vecenv;
 typedef struct ilsx_disc ilsx_disc;
+typedef struct ilsx_ppo ilsx_ppo;
 
 enum { ILSX_ACT_RELU = 0, ILSX_ACT_TANH = 1 };
 
@@ -222,6 +223,37 @@ int ilsx_disc_train_step(ilsx_disc* disc, const float* exp_obs, const float* exp
 /* reward relabelling: rew[n] (nullable) by mode + optional clip; logits[n] (nullable) = clamped D(s,a) */
 int ilsx_disc_reward(ilsx_disc* disc, const float* obs, const float* act, int n, int mode, int has_min, float rew_clip_min,
                      int has_max, float rew_clip_max, float* rew, float* logits);
+
+/* ---------------------------------------------------------------- PPO
+ * Replaces rlkit/torch/algorithms/ppo/ppo.py:57-100 (calc_adv: per-trajectory GAE, zero bootstrap, per-trajectory
+ * advantage standardisation) and :102-170 (train_step: update_epoch x shuffled minibatches of value MSE + L2 and
+ * the clipped surrogate, grad-norm clip 20), with ReparamMultivariateGaussianPolicy(conditioned_std=False)
+ * (rlkit/torch/common/policies.py:348-478) and the tanh value net of run_scripts/ppo_exp_script.py:82-96.
+ * cfg fields == the YAML keys of exp_specs/ppo/ppo_hopper.yaml:41-50 (+ net_size / num_hidden_layers :13-14). */
+typedef struct {
+  int32_t obs_dim, act_dim, n_hidden, hidden;
+  float reward_scale, discount, clip_eps, policy_lr, value_lr, gae_tau, value_l2_reg;
+  int32_t mini_batch_size, update_epoch;
+  int32_t max_samples;            /* upper bound on the on-policy samples of one train call */
+} ilsx_ppo_cfg;
+int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo** out);
+int ilsx_ppo_destroy(ilsx_ppo* ppo);
+/* which: 0 = policy, flat = fc*.W|fc*.b|last_fc.W|last_fc.b|action_log_std[a] ; 1 = value net.  HOST arrays. */
+int ilsx_ppo_num_params(const ilsx_ppo* ppo, int which, size_t* out);
+int ilsx_ppo_set_params(ilsx_ppo* ppo, int which, const float* src_host, size_t n);
+int ilsx_ppo_get_params(ilsx_ppo* ppo, int which, float* dst_host, size_t n);
+/* calc_adv + the fixed log-probs over N = traj_offsets_host[n_traj] device rows obs[N,o] act[N,a] rew[N]; trajectory
+ * t owns rows [traj_offsets_host[t], traj_offsets_host[t+1]).  Device outputs [N], all nullable. */
+int ilsx_ppo_gae(ilsx_ppo* ppo, const float* obs, const float* act, const float* rew, const int32_t* traj_offsets_host,
+                 int n_traj, float* returns, float* advantages, float* values, float* fixed_log_probs);
+/* one PPO.train_step.  perms_host [update_epoch][N] int32 row permutations (torch.randperm in the reference,
+ * ppo.py:116) or NULL = drawn by the library. */
+int ilsx_ppo_train(ilsx_ppo* ppo, const float* obs, const float* act, const float* rew, const int32_t* traj_offsets_host,
+                   int n_traj, const int32_t* perms_host);
+/* get_actions (policies.py:392-417): act[n,a] = mean + exp(log_std)*eps (eps device [n,a] or NULL = Philox), or the
+ * mean when deterministic; logp[n] nullable. */
+int ilsx_ppo_policy_act(ilsx_ppo* ppo, const float* obs, int n, int deterministic, const float* eps, float* act,
+                        float* logp);
 
 /* ---------------------------------------------------------------- vectorised env stepper
  * Replaces the reference's vec-env path: rlkit/envs/vecenvs.py:158-257 (BaseVectorEnv.reset/step),

@@ -43,11 +43,98 @@ def test_gae_zero_bootstrap_closed_form():
     np.testing.assert_allclose(R.ravel(), [1 + a0, 2 + a1, 3 + a2], rtol=1e-6)
 
 
-def test_train_step_two_epochs():
-    g = load_golden("g7_ppo")
+import pytest
+
+
+@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip"])   # g7b: clip_grad_norm_(20) active
+def test_train_step(name):
+    g = load_golden(name)
     o, a = int(g["dims"][0]), int(g["dims"][1])
-    orc = PPOOracle(o, a, [int(v) for v in g["dims"][2:]], g["pi0"], g["vf0"], **KW)
-    orc.train_step(_trajs(g), list(g["perms"]))
+    orc = PPOOracle(o, a, [int(v) for v in g["dims"][2:]], g["pi0"], g["vf0"], **dict(KW, update_epoch=int(g["epochs"])))
+    res = orc.train_step(_trajs(g), list(g["perms"]))
+    assert (res["pi_grad_norm"] > 20) == (name == "g7b_ppo_clip")
     np.testing.assert_allclose(orc.vf, g["vf_final"], rtol=0, atol=5e-5)
     np.testing.assert_allclose(orc.pi, g["pi_final"], rtol=0, atol=5e-5)
     assert np.abs(orc.pi - g["pi0"]).max() > 1e-4  # the policy really moved
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _hip_ppo(ctx, g, **over):
+    from ilswiss_amd.networks import FlattenMlp
+    from ilswiss_amd.ppo import PPO, ReparamMultivariateGaussianPolicy
+    o, a = int(g["dims"][0]), int(g["dims"][1])
+    hid = [int(v) for v in g["dims"][2:]]
+    pol = ReparamMultivariateGaussianPolicy(hid, o, a, ctx=ctx, seed=3)
+    vf = FlattenMlp(hid, 1, o, hidden_activation="tanh", ctx=ctx, seed=4)
+    tr = PPO(pol, vf, max_samples=4096, **dict(KW, update_epoch=int(g["epochs"]), **over))
+    tr.set_flat_params(g["pi0"], g["vf0"])
+    return tr
+
+
+@pytest.mark.gpu
+def test_hip_gae_and_fixed_log_probs_golden(ctx):
+    g = load_golden("g7_ppo")
+    tr = _hip_ppo(ctx, g)
+    np.testing.assert_array_equal(tr.get_flat_params(0), g["pi0"])
+    np.testing.assert_array_equal(tr.get_flat_params(1), g["vf0"])
+    R, A, V, lp = tr.calc_adv(_trajs(g))
+    np.testing.assert_allclose(V, g["values"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(R, g["returns"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(A, g["advantages"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(lp, g["fixed_log_probs"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip"])
+def test_hip_train_step_golden(ctx, name):
+    g = load_golden(name)
+    tr = _hip_ppo(ctx, g)
+    tr.train_step(_trajs(g), g["perms"])
+    np.testing.assert_allclose(tr.get_flat_params(1), g["vf_final"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(tr.get_flat_params(0), g["pi_final"], rtol=0, atol=5e-5)
+    assert np.abs(tr.get_flat_params(0) - g["pi0"]).max() > 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_train_step_vs_oracle_ragged(ctx):
+    """Widths / sizes the goldens do not hold: H=128, 5 trajectories (one of length 2), N not a multiple of the
+    minibatch (ragged last minibatch), 3 epochs."""
+    from oracle import mlp as omlp
+    rng = np.random.default_rng(99)
+    o, a, hid = 17, 6, [128, 128]
+    kw = dict(KW, mini_batch_size=48, update_epoch=3, gae_tau=0.9)
+    vf0 = omlp.init_mlp(rng, o, hid, 1)
+    pi0 = np.concatenate([omlp.init_mlp(rng, o, hid, a, init_w=1e-3, last_scale=(0.1, 0.0)),
+                          rng.normal(-0.5, 0.2, a).astype(np.float32)])
+    trajs = [dict(observations=rng.normal(0, 1, (L, o)).astype(np.float32),
+                  actions=rng.normal(0, 0.7, (L, a)).astype(np.float32),
+                  rewards=rng.normal(0.5, 1.0, (L, 1)).astype(np.float32)) for L in (2, 31, 100, 64, 9)]
+    N = sum(t["rewards"].shape[0] for t in trajs)
+    perms = np.stack([rng.permutation(N) for _ in range(3)])
+    orc = PPOOracle(o, a, hid, pi0, vf0, **kw)
+    g = dict(dims=np.array([o, a] + hid), epochs=3, pi0=pi0, vf0=vf0)
+    tr = _hip_ppo(ctx, g, mini_batch_size=48, gae_tau=0.9)
+    R, A, V, lp = tr.calc_adv(trajs)
+    _, _, R0, A0, V0 = orc.calc_adv(trajs)
+    np.testing.assert_allclose(V, V0, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(A, A0, rtol=2e-4, atol=2e-5)
+    orc.train_step(trajs, list(perms))
+    tr.train_step(trajs, perms)
+    np.testing.assert_allclose(tr.get_flat_params(1), orc.vf, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(tr.get_flat_params(0), orc.pi, rtol=0, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_hip_gaussian_policy_act(ctx):
+    g = load_golden("g7_ppo")
+    tr = _hip_ppo(ctx, g)
+    orc = PPOOracle(int(g["dims"][0]), int(g["dims"][1]), [int(v) for v in g["dims"][2:]], g["pi0"], g["vf0"], **KW)
+    obs = g["t2_observations"]
+    eps = np.random.default_rng(5).normal(0, 1, (obs.shape[0], 3)).astype(np.float32)
+    mu, _ = orc.pi_mean(obs)
+    act, lp = tr.policy_act(obs, eps=eps)
+    np.testing.assert_allclose(act, mu + np.exp(g["pi0"][-3:]) * eps, rtol=1e-5, atol=1e-6)   # policies.py:409-417
+    np.testing.assert_allclose(lp, orc.log_prob(obs, act)[0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tr.policy_act(obs, deterministic=True)[0], mu, rtol=1e-5, atol=1e-6)
+    a1, a2 = tr.policy_act(obs)[0], tr.policy_act(obs)[0]                                       # Philox draws move on
+    assert np.abs(a1 - a2).max() > 1e-3 and np.isfinite(a1).all()

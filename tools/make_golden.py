@@ -394,21 +394,27 @@ def gen_disc():
 
 
 def gen_ppo():
-    """G7: PPO.calc_adv + train_step (ppo.py:57-170) on scripted trajectories with injected permutations."""
+    """G7: PPO.calc_adv + train_step (ppo.py:57-170) on scripted trajectories with injected permutations.
+    g7_ppo: ordinary regime; g7b_ppo_clip: narrow policy (log_std ~ -3) so that clip_grad_norm_(20) bites."""
+    _gen_ppo_case("g7_ppo", 707, -0.3, 2)
+    _gen_ppo_case("g7b_ppo_clip", 708, -3.0, 1)
+
+
+def _gen_ppo_case(name, seed, ls_mean, epochs):
     from rlkit.torch.algorithms.ppo.ppo import PPO
     from rlkit.torch.common.networks import FlattenMlp
     from rlkit.torch.common.policies import ReparamMultivariateGaussianPolicy
     from oracle.ppo import PPOOracle, gae_one_traj
-    rng = np.random.default_rng(707)
-    o, a, Hh = 11, 3, [32, 32]
+    rng = np.random.default_rng(seed)
+    o, a, Hh = 11, 3, [64, 64]
     kw = dict(reward_scale=1.0, discount=0.99, clip_eps=0.2, policy_lr=3e-4, value_lr=3e-4, gae_tau=0.95,
-              value_l2_reg=1e-3, mini_batch_size=16, update_epoch=2)
+              value_l2_reg=1e-3, mini_batch_size=16, update_epoch=epochs)
     vf = FlattenMlp(hidden_sizes=Hh, input_size=o, output_size=1, hidden_activation=torch.tanh)
     pol = ReparamMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a, conditioned_std=False,
                                             hidden_activation=torch.tanh)
     vf0 = omlp.init_mlp(rng, o, Hh, 1)
     pim = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, last_scale=(0.1, 0.0))   # policies.py:378-379
-    ls0 = rng.normal(-0.3, 0.2, a).astype(np.float32)
+    ls0 = rng.normal(ls_mean, 0.2, a).astype(np.float32)
     pi0 = np.concatenate([pim, ls0])                      # our layout: mean net | action_log_std
     set_flat(vf, vf0)
     set_flat(pol, np.concatenate([ls0, pim]))             # torch yields action_log_std first
@@ -447,10 +453,9 @@ def gen_ppo():
                vf_final=get_flat(vf), pi_final=pi_ref)
     for i, tj in enumerate(trajs):
         out.update({f"t{i}_{k}": v for k, v in tj.items()})
-    # one more case: large gradient so that clip_grad_norm_(20) bites (huge advantages)
-    gb = rng.normal(0, 1, (40, o)).astype(np.float32)
-    out.update(clip_obs=gb)
-    save("g7_ppo", **out)
+    out.update(epochs=np.array(epochs), pi_grad_norm_last=np.array(res["pi_grad_norm"]))
+    print(name, "last policy grad norm", res["pi_grad_norm"])
+    save(name, **out)
 
 
 GROUPS = dict(ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
