@@ -54,6 +54,32 @@ class PlanarModel(C.Structure):  # ilsx_planar_model
                 ("ang_max", C.c_double), ("state_max", C.c_double), ("init_qpos", C.c_double * (_MB + 2))]
 
 
+class Td3Cfg(C.Structure):  # ilsx_td3_cfg
+    _fields_ = [("reward_scale", C.c_float), ("discount", C.c_float), ("policy_lr", C.c_float), ("qf_lr", C.c_float),
+                ("policy_and_target_update_period", C.c_int32), ("soft_target_tau", C.c_float),
+                ("policy_noise", C.c_float), ("policy_noise_clip", C.c_float), ("max_act", C.c_float),
+                ("max_batch", C.c_int32)]
+
+
+class Td3Stats(C.Structure):  # ilsx_td3_stats
+    _fields_ = [("qf1_loss", C.c_float), ("qf2_loss", C.c_float), ("policy_loss", C.c_float),
+                ("q1_pred", C.c_float * 4), ("q2_pred", C.c_float * 4), ("q_target", C.c_float * 4),
+                ("bellman1", C.c_float * 4), ("bellman2", C.c_float * 4), ("policy_action", C.c_float * 4)]
+
+
+class SacvCfg(C.Structure):  # ilsx_sacv_cfg
+    _fields_ = [("reward_scale", C.c_float), ("discount", C.c_float), ("alpha", C.c_float), ("policy_lr", C.c_float),
+                ("qf_lr", C.c_float), ("vf_lr", C.c_float), ("soft_target_tau", C.c_float),
+                ("policy_mean_reg_weight", C.c_float), ("policy_std_reg_weight", C.c_float), ("beta_1", C.c_float),
+                ("max_batch", C.c_int32)]
+
+
+class SacvStats(C.Structure):  # ilsx_sacv_stats
+    _fields_ = [("qf1_loss", C.c_float), ("qf2_loss", C.c_float), ("vf_loss", C.c_float), ("policy_loss", C.c_float),
+                ("q1_pred", C.c_float * 4), ("q2_pred", C.c_float * 4), ("v_pred", C.c_float * 4),
+                ("log_pi", C.c_float * 4), ("policy_mu", C.c_float * 4), ("policy_log_std", C.c_float * 4)]
+
+
 class PpoCfg(C.Structure):  # ilsx_ppo_cfg
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32),
                 ("reward_scale", C.c_float), ("discount", C.c_float), ("clip_eps", C.c_float),
@@ -74,6 +100,19 @@ class DiscStats(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/ilsx.h declares
 PROTOTYPES = {
+    "ilsx_net_set_noise_policy": (C.c_int, [vp, C.c_float, C.c_float, C.c_float]),
+    "ilsx_td3_create": (C.c_int, [vp, C.POINTER(Td3Cfg), vp, vp, vp, C.POINTER(vp)]),
+    "ilsx_td3_destroy": (C.c_int, [vp]),
+    "ilsx_td3_train_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(Td3Stats)]),
+    "ilsx_td3_train_from_replay": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(Td3Stats)]),
+    "ilsx_td3_get_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "ilsx_td3_set_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "ilsx_sacv_create": (C.c_int, [vp, C.POINTER(SacvCfg), vp, vp, vp, vp, C.POINTER(vp)]),
+    "ilsx_sacv_destroy": (C.c_int, [vp]),
+    "ilsx_sacv_train_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(SacvStats)]),
+    "ilsx_sacv_train_from_replay": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(SacvStats)]),
+    "ilsx_sacv_get_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "ilsx_sacv_set_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "ilsx_ppo_create": (C.c_int, [vp, C.POINTER(PpoCfg), C.POINTER(vp)]),
     "ilsx_ppo_destroy": (C.c_int, [vp]),
     "ilsx_ppo_num_params": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),

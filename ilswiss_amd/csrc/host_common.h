@@ -91,6 +91,9 @@ struct ilsx_net {
   // lazily sized workspace for the standalone forward / act entry points
   float* ws_out = nullptr;
   int ws_rows = 0;
+  // MlpGaussianNoisePolicy (policies.py:130-188): single head, tanh output, clipped Gaussian exploration noise
+  bool noise_policy = false;
+  float noise = 0.f, noise_clip = 0.f, max_act = 1.f;
 };
 
 int net_upload_flat(ilsx_ctx* ctx, const NetLayout& L, float* dev_base, const float* src, size_t n, int src_is_device);

@@ -565,7 +565,8 @@ extern "C" int ilsx_mlp_forward(ilsx_net* n, const float* x, int rows, float* y)
 extern "C" int ilsx_policy_act(ilsx_net* pi, const float* obs, int nrows, int deterministic, const float* eps,
                                float* act, float* logp) {
   if (!pi || !obs || !act || nrows < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_act: bad argument");
-  if (pi->lay.cfg.n_heads != 2) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_act: network has %d heads (need mean|log_std)", pi->lay.cfg.n_heads);
+  if (pi->lay.cfg.n_heads != 2 && !pi->noise_policy)
+    ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_act: network has %d heads (need mean|log_std, or a noise policy)", pi->lay.cfg.n_heads);
   HIPCHK(hipSetDevice(pi->ctx->device));
   static unsigned long long act_calls = 0;
   FwdArgs A;
@@ -574,6 +575,11 @@ extern "C" int ilsx_policy_act(ilsx_net* pi, const float* obs, int nrows, int de
   t.net = net_view(pi->lay, pi->base);
   t.x0 = obs; t.d0 = pi->lay.cfg.in_dim; t.s0 = pi->lay.cfg.in_dim;
   t.head = deterministic ? HEAD_TANH_DET : HEAD_TANH_SAMPLE;
+  if (pi->noise_policy) {
+    if (logp) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_act: a noise policy has no log-probability");
+    t.head = HEAD_DET_TANH_NOISE;
+    t.noise = deterministic ? 0.0f : pi->noise; t.noise_clip = pi->noise_clip; t.max_act = pi->max_act;
+  }
   t.eps = eps;
   t.action = act;
   t.logp = logp;
@@ -582,6 +588,13 @@ extern "C" int ilsx_policy_act(ilsx_net* pi, const float* obs, int nrows, int de
   A.scal = nullptr;
   A.step_host = ++act_calls;
   return launch_fwd(pi->ctx, A, pi->lay.cfg.hidden, pi->lay.cfg.act, pi->lay.KP);
+}
+
+extern "C" int ilsx_net_set_noise_policy(ilsx_net* pi, float policy_noise, float policy_noise_clip, float max_act) {
+  if (!pi) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_net_set_noise_policy: NULL network");
+  if (pi->lay.cfg.n_heads != 1) ILSX_FAIL(ILSX_ERR_ARG, "a noise policy is a single-head Mlp (policies.py:130-188)");
+  pi->noise_policy = true; pi->noise = policy_noise; pi->noise_clip = policy_noise_clip; pi->max_act = max_act;
+  return ILSX_OK;
 }
 
 extern "C" int ilsx_policy_log_prob(ilsx_net* pi, const float* obs, const float* act, int nrows, float* logp) {

@@ -24,8 +24,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ILSX_MAX_NO 64   // max total head outputs (n_heads*out_dim)
 
 enum { HEAD_RAW = 0, HEAD_TANH_SAMPLE = 1, HEAD_TANH_DET = 2, HEAD_TANH_LOGP_OF_ACT = 3,
-       HEAD_GAUSS_SAMPLE = 4, HEAD_GAUSS_LOGP_OF_ACT = 5 };  // un-squashed Gaussian, state-independent log_std (PPO)
-enum { LOSS_GIVEN = 0, LOSS_SAC_CRITIC = 1, LOSS_SAC_ACTORQ = 2, LOSS_SAC_POLICY = 3, LOSS_MSE = 4, LOSS_PPO_POLICY = 5 };
+       HEAD_GAUSS_SAMPLE = 4, HEAD_GAUSS_LOGP_OF_ACT = 5,    // un-squashed Gaussian, state-independent log_std (PPO)
+       HEAD_DET_TANH_NOISE = 6 };                            // max_act*tanh(out) + clip(noise*eps) (TD3, policies.py:166-188)
+enum { LOSS_GIVEN = 0, LOSS_SAC_CRITIC = 1, LOSS_SAC_ACTORQ = 2, LOSS_SAC_POLICY = 3, LOSS_MSE = 4, LOSS_PPO_POLICY = 5,
+       LOSS_TD_CRITIC = 6, LOSS_SACV_VALUE = 7, LOSS_CONST = 8, LOSS_TD3_POLICY = 9 };
 enum { ACT_RELU = 0, ACT_TANH = 1 };
 
 #define LOG_SIG_MIN (-20.0f)
@@ -163,6 +165,7 @@ struct FwdTask {
   int g0_off, g1_off, publish;       // GatherSpec: record offsets of the x0 / x1 segments; 1 = publish s,a,r,d ; 2 = s2
   const int* rows_idx;               // nullable: row r of this launch reads source row rows_idx[r] (minibatch gather)
   const float* log_std;              // HEAD_GAUSS_*: state-independent log-std parameter [a]
+  float noise, noise_clip, max_act;  // HEAD_DET_TANH_NOISE (noise == 0: deterministic)
 };
 // A per-row scalar (Q value) that may still be split into CS column-slice partial sums: summed in a fixed
 // order by whoever consumes it (the "combine in the next kernel's prologue" seam of a split-K reduction).
@@ -330,6 +333,27 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
     const float* ho = hout + row * ILSX_MAX_NO;
     if (T.out && lane < NO) T.out[(size_t)gr * NO + lane] = ho[lane];
     if (T.head == HEAD_RAW) continue;
+    if (T.head == HEAD_DET_TANH_NOISE) {
+      // MlpGaussianNoisePolicy.forward (policies.py:166-188): the result is NOT re-clipped to [-max_act, max_act]
+      const int j = lane;
+      if (j < NO && T.action) {
+        float act = T.max_act * tanhf(ho[j]);
+        if (T.noise != 0.0f) {
+          float e;
+          if (T.eps) {
+            e = T.eps[(size_t)gr * NO + j];
+          } else {
+            float z4[4];
+            philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+            const int qd = j & 3;
+            e = qd == 0 ? z4[0] : qd == 1 ? z4[1] : qd == 2 ? z4[2] : z4[3];
+          }
+          act += fminf(fmaxf(T.noise * e, -T.noise_clip), T.noise_clip);
+        }
+        T.action[(size_t)gr * NO + j] = act;
+      }
+      continue;
+    }
     if (T.head >= HEAD_GAUSS_SAMPLE) {
       // ReparamMultivariateGaussianPolicy, conditioned_std=False (policies.py:398-417,462-478 + distributions.py:43-50)
       const int a = NO, j = lane;
@@ -426,7 +450,8 @@ struct BwdTask {
   const float *lp_old, *act_all, *log_std, *mu;   // PPO: fixed log-probs [N], actions [N][a], log_std [a], mean [rows][a]
   float* aux;                          // PPO: per-row d(loss)/d(log_std) contributions [rows][a]
   float clip_eps;
-};
+  float coef;                          // LOSS_TD_CRITIC: 1 (half-MSE) or 2 (MSE); LOSS_SACV_VALUE: alpha; LOSS_CONST: value;
+};                                     //   LOSS_TD3_POLICY: max_act
 struct BwdArgs {
   BwdTask t[2];
   int rows, ntasks;
@@ -456,6 +481,20 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
     const float a1 = T.q1n.get(gr), a2 = T.q2n.get(gr);
     const float w1 = a1 < a2 ? 1.0f : (a1 == a2 ? 0.5f : 0.0f);
     d = -(T.which == 0 ? w1 : 1.0f - w1) * A.inv_B;
+  } else if (T.loss == LOSS_TD_CRITIC) {
+    // td3.py:84-99 (coef 2: plain MSE) / sac.py:93-105 (coef 1: half MSE, tq1 == tq2 == target V): no entropy term
+    const float y = A.reward_scale * T.rew[gr] + (1.0f - T.done[gr]) * A.gamma * fminf(T.tq1.get(gr), T.tq2.get(gr));
+    d = T.coef * (T.q.get(gr) - y) * A.inv_B;
+  } else if (T.loss == LOSS_SACV_VALUE) {
+    // sac.py:120-131: v_target = min(Q1,Q2)(s,a~) - alpha*log pi (detached), L = 0.5*mean((v - v_target)^2)
+    const float vt = fminf(T.q1n.get(gr), T.q2n.get(gr)) - T.coef * T.logp_next[gr];
+    d = (T.q.get(gr) - vt) * A.inv_B;
+  } else if (T.loss == LOSS_CONST) {
+    d = T.coef * A.inv_B;   // td3.py:113-114: -mean(Q1(s, pi(s)))
+  } else if (T.loss == LOSS_TD3_POLICY) {
+    // action = max_act*tanh(pre): d pre = dL/da * max_act * (1 - tanh(pre)^2)
+    const float th = tanhf(T.raw[(size_t)gr * NO + j]);
+    d = T.ga1[(size_t)gr * NO + j] * T.coef * (1.0f - th * th);
   } else if (T.loss == LOSS_MSE) {
     // ppo.py:145: mean((v - R)^2) over the minibatch
     const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;

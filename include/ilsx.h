@@ -46,6 +46,8 @@ typedef struct ilsx_sac ilsx_sac;
 typedef struct ilsx_vecenv ilsx_vecenv;
 typedef struct ilsx_disc ilsx_disc;
 typedef struct ilsx_ppo ilsx_ppo;
+typedef struct ilsx_td3 ilsx_td3;
+typedef struct ilsx_sacv ilsx_sacv;
 
 enum { ILSX_ACT_RELU = 0, ILSX_ACT_TANH = 1 };
 
@@ -107,6 +109,9 @@ int ilsx_policy_act(ilsx_net* pi, const float* obs, int n, int deterministic, co
 /* ReparamTanhMultivariateNormal.log_prob with pre_tanh_value=None (policies.py:329-345):
  * logp[n] of GIVEN actions act[n,a] under pi(.|obs). */
 int ilsx_policy_log_prob(ilsx_net* pi, const float* obs, const float* act, int n, float* logp);
+/* Marks a single-head Mlp as MlpGaussianNoisePolicy (policies.py:130-188): ilsx_policy_act / ilsx_rollout_step then
+ * return max_act*tanh(out) + clip(policy_noise*N(0,1), +-policy_noise_clip) (no noise when deterministic). */
+int ilsx_net_set_noise_policy(ilsx_net* pi, float policy_noise, float policy_noise_clip, float max_act);
 
 /* ---------------------------------------------------------------- replay buffer
  * Replaces rlkit/data_management/simple_replay_buffer.py:17-442 + env_replay_buffer.py:7-49.
@@ -223,6 +228,56 @@ int ilsx_disc_train_step(ilsx_disc* disc, const float* exp_obs, const float* exp
 /* reward relabelling: rew[n] (nullable) by mode + optional clip; logits[n] (nullable) = clamped D(s,a) */
 int ilsx_disc_reward(ilsx_disc* disc, const float* obs, const float* act, int n, int mode, int has_min, float rew_clip_min,
                      int has_max, float rew_clip_max, float* rew, float* logits);
+
+/* ---------------------------------------------------------------- TD3
+ * Replaces rlkit/torch/algorithms/td3/td3.py:21-70 (ctor), :72-124 (train_step), :180-183 (soft updates).  cfg fields ==
+ * the YAML keys of exp_specs/td3/td3_hopper.yaml:12-13,39-45 (policy_noise / policy_noise_clip are the noise of the
+ * policy MODULE, which the target policy inherits through policy.copy(); td3.py's target_policy_noise* are unused).
+ * The value list of a statistic is {Mean, Std, Max, Min} (core/eval_util.py create_stats_ordered_dict). */
+typedef struct {
+  float reward_scale, discount, policy_lr, qf_lr;
+  int32_t policy_and_target_update_period;
+  float soft_target_tau, policy_noise, policy_noise_clip, max_act;
+  int32_t max_batch;
+} ilsx_td3_cfg;
+typedef struct {
+  float qf1_loss, qf2_loss, policy_loss;
+  float q1_pred[4], q2_pred[4], q_target[4], bellman1[4], bellman2[4], policy_action[4];
+} ilsx_td3_stats;
+/* adopts the three networks' storage like ilsx_sac_create; pi: single-head Mlp (becomes a noise policy) */
+int ilsx_td3_create(ilsx_ctx* ctx, const ilsx_td3_cfg* cfg, ilsx_net* pi, ilsx_net* qf1, ilsx_net* qf2, ilsx_td3** out);
+int ilsx_td3_destroy(ilsx_td3* td3);
+/* device batch rows as in ilsx_sac_train_step; eps_target: device [B,a] N(0,1) draws of the target policy's noise
+ * (policies.py:182-184) or NULL = Philox; stats nullable (host). */
+int ilsx_td3_train_step(ilsx_td3* td3, const float* obs, const float* act, const float* rew, const float* done,
+                        const float* nobs, int B, const float* eps_target, ilsx_td3_stats* stats);
+int ilsx_td3_train_from_replay(ilsx_td3* td3, ilsx_replay* rb, int n_steps, int B, ilsx_td3_stats* stats);
+/* which: 0 qf1, 1 qf2, 2 policy, 3 target_qf1, 4 target_qf2, 5 target_policy; HOST flat arrays */
+int ilsx_td3_get_params(ilsx_td3* td3, int which, float* dst_host, size_t n);
+int ilsx_td3_set_params(ilsx_td3* td3, int which, const float* src_host, size_t n);
+
+/* ---------------------------------------------------------------- SAC with a state-value function
+ * Replaces rlkit/torch/algorithms/sac/sac.py:23-68 (ctor), :70-179 (train_step), :242-243 (soft update of V).
+ * cfg fields == the YAML `sac_params` keys (exp_specs/sac/sac_hopper.yaml:36-47 with run_scripts/sac_exp_script.py). */
+typedef struct {
+  float reward_scale, discount, alpha, policy_lr, qf_lr, vf_lr, soft_target_tau;
+  float policy_mean_reg_weight, policy_std_reg_weight, beta_1;
+  int32_t max_batch;
+} ilsx_sacv_cfg;
+typedef struct {
+  float qf1_loss, qf2_loss, vf_loss, policy_loss;
+  float q1_pred[4], q2_pred[4], v_pred[4], log_pi[4], policy_mu[4], policy_log_std[4];
+} ilsx_sacv_stats;
+int ilsx_sacv_create(ilsx_ctx* ctx, const ilsx_sacv_cfg* cfg, ilsx_net* pi, ilsx_net* qf1, ilsx_net* qf2, ilsx_net* vf,
+                     ilsx_sacv** out);
+int ilsx_sacv_destroy(ilsx_sacv* sac);
+/* eps: device [B,a] N(0,1) draws of the single policy sample of the step (sac.py:123) or NULL = Philox */
+int ilsx_sacv_train_step(ilsx_sacv* sac, const float* obs, const float* act, const float* rew, const float* done,
+                         const float* nobs, int B, const float* eps, ilsx_sacv_stats* stats);
+int ilsx_sacv_train_from_replay(ilsx_sacv* sac, ilsx_replay* rb, int n_steps, int B, ilsx_sacv_stats* stats);
+/* which: 0 qf1, 1 qf2, 2 vf, 3 policy, 6 target_vf; HOST flat arrays */
+int ilsx_sacv_get_params(ilsx_sacv* sac, int which, float* dst_host, size_t n);
+int ilsx_sacv_set_params(ilsx_sacv* sac, int which, const float* src_host, size_t n);
 
 /* ---------------------------------------------------------------- PPO
  * Replaces rlkit/torch/algorithms/ppo/ppo.py:57-100 (calc_adv: per-trajectory GAE, zero bootstrap, per-trajectory

@@ -458,7 +458,130 @@ def _gen_ppo_case(name, seed, ls_mean, epochs):
     save(name, **out)
 
 
-GROUPS = dict(ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+def _hook_grads(grads, opt, name, mod):
+    orig = opt.step
+
+    def step(*aa, **kk):
+        grads[name] = get_flat_grad(mod)
+        return orig(*aa, **kk)
+    opt.step = step
+
+
+def _rand_batch(rng, B, o, a):
+    return dict(observations=rng.normal(0, 1, (B, o)).astype(np.float32),
+                actions=np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32),
+                rewards=rng.normal(0, 1, (B, 1)).astype(np.float32),
+                terminals=(rng.random((B, 1)) < 0.1).astype(np.float32),
+                next_observations=rng.normal(0, 1, (B, o)).astype(np.float32))
+
+
+def gen_td3():
+    """G6: TD3.train_step (td3.py:72-124), 4 chained steps (delayed policy/target update at steps 0 and 2), the
+    target policy's clipped noise injected (policies.py:182-186)."""
+    from rlkit.torch.algorithms.td3.td3 import TD3
+    from rlkit.torch.common.networks import FlattenMlp
+    from rlkit.torch.common.policies import MlpGaussianNoisePolicy
+    from oracle.td3 import TD3Oracle
+    rng = np.random.default_rng(606)
+    o, a, Hh, B, steps = 11, 3, [64, 64], 32, 4
+    kw = dict(reward_scale=1.0, discount=0.99, policy_lr=3e-4, qf_lr=3e-4, policy_and_target_update_period=2,
+              soft_target_tau=0.005)
+    pi0 = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3)
+    pi0[-(Hh[-1] * a + a):] *= 300.0      # head weights up so that tanh bends (init_w=1e-3 keeps it linear)
+    q10, q20 = omlp.init_mlp(rng, o + a, Hh, 1), omlp.init_mlp(rng, o + a, Hh, 1)
+    pol = MlpGaussianNoisePolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a, output_activation=torch.tanh,
+                                 policy_noise=0.2, policy_noise_clip=0.5)
+    qf1 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1)
+    qf2 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1)
+    set_flat(pol, pi0), set_flat(qf1, q10), set_flat(qf2, q20)
+    tr = TD3(policy=pol, qf1=qf1, qf2=qf2, **kw)
+    orc = TD3Oracle(o, a, Hh, pi0, q10, q20, policy_noise=0.2, policy_noise_clip=0.5, **kw)
+    grads = {}
+    _hook_grads(grads, tr.qf1_optimizer, "q1", qf1), _hook_grads(grads, tr.qf2_optimizer, "q2", qf2)
+    _hook_grads(grads, tr.policy_optimizer, "pi", pol)
+    rec = dict(pi0=pi0, q10=q10, q20=q20, dims=np.array([o, a, B, steps] + Hh))
+    for s in range(steps):
+        batch = _rand_batch(rng, B, o, a)
+        eps = rng.normal(0, 1, (B, a)).astype(np.float32)
+        eps[0] = [4.0, -4.0, 0.1]                       # 0.2*4 = 0.8 > 0.5: the clip is active
+        tr.eval_statistics = None
+        grads.pop("pi", None)
+        with H.NoiseInjector() as inj:
+            inj.push(eps)
+            tr.train_step({k: t(v) for k, v in batch.items()})
+        st = tr.eval_statistics
+        res = orc.train_step(batch, eps)
+        for k_ref, k_or in (("QF1 Loss", "qf1_loss"), ("QF2 Loss", "qf2_loss"), ("Policy Loss", "policy_loss")):
+            assert np.allclose(st[k_ref], res[k_or], rtol=2e-4, atol=1e-6), (s, k_ref, st[k_ref], res[k_or])
+        assert ("pi" in grads) == (s % 2 == 0) == ("pi_grad" in res)
+        for nm in grads:
+            err = np.abs(grads[nm] - res[nm + "_grad"]).max() / (np.abs(grads[nm]).max() + 1e-12)
+            assert err < 2e-3, (s, nm, err)
+        rec.update({f"s{s}_{k}": v for k, v in batch.items()})
+        rec.update({f"s{s}_eps": eps, f"s{s}_qf1_loss": st["QF1 Loss"], f"s{s}_qf2_loss": st["QF2 Loss"],
+                    f"s{s}_policy_loss": st["Policy Loss"], f"s{s}_grad_q1": grads["q1"], f"s{s}_grad_q2": grads["q2"],
+                    f"s{s}_pi": get_flat(pol), f"s{s}_q1": get_flat(qf1), f"s{s}_q2": get_flat(qf2),
+                    f"s{s}_tpi": get_flat(tr.target_policy), f"s{s}_tq1": get_flat(tr.target_qf1),
+                    f"s{s}_tq2": get_flat(tr.target_qf2), f"s{s}_q_target_mean": st["Q Targets Mean"]})
+        if "pi" in grads:
+            rec[f"s{s}_grad_pi"] = grads["pi"]
+        for k, mod in (("pi", pol), ("q1", qf1), ("q2", qf2), ("tpi", tr.target_policy), ("tq1", tr.target_qf1)):
+            err = np.abs(getattr(orc, k) - get_flat(mod)).max()
+            assert err < 5e-5, (s, k, err)
+    save("g6_td3", **rec)
+
+
+def gen_sac_v():
+    """G5: SoftActorCritic (V-function variant) train_step (sac/sac.py:70-179), 3 chained steps."""
+    from rlkit.torch.algorithms.sac.sac import SoftActorCritic
+    from rlkit.torch.common.networks import FlattenMlp
+    from rlkit.torch.common.policies import ReparamTanhMultivariateGaussianPolicy
+    from oracle.sac_v import SacVOracle
+    rng = np.random.default_rng(505)
+    o, a, Hh, B, steps = 11, 3, [64, 64], 32, 3
+    kw = dict(reward_scale=1.0, discount=0.99, alpha=0.2, policy_lr=3e-4, qf_lr=3e-4, vf_lr=3e-4, soft_target_tau=0.005,
+              policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3, beta_1=0.9)
+    pi0 = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, n_heads=2)
+    q10, q20, vf0 = omlp.init_mlp(rng, o + a, Hh, 1), omlp.init_mlp(rng, o + a, Hh, 1), omlp.init_mlp(rng, o, Hh, 1)
+    pol = ReparamTanhMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a)
+    qf1 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1)
+    qf2 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1)
+    vf = FlattenMlp(hidden_sizes=Hh, input_size=o, output_size=1)
+    set_flat(pol, pi0), set_flat(qf1, q10), set_flat(qf2, q20), set_flat(vf, vf0)
+    tr = SoftActorCritic(policy=pol, qf1=qf1, qf2=qf2, vf=vf, **kw)
+    orc = SacVOracle(o, a, Hh, pi0, q10, q20, vf0, **kw)
+    grads = {}
+    _hook_grads(grads, tr.qf1_optimizer, "q1", qf1), _hook_grads(grads, tr.qf2_optimizer, "q2", qf2)
+    _hook_grads(grads, tr.vf_optimizer, "vf", vf), _hook_grads(grads, tr.policy_optimizer, "pi", pol)
+    rec = dict(pi0=pi0, q10=q10, q20=q20, vf0=vf0, dims=np.array([o, a, B, steps] + Hh))
+    for s in range(steps):
+        batch = _rand_batch(rng, B, o, a)
+        eps = rng.normal(0, 1, (B, a)).astype(np.float32)
+        tr.eval_statistics = None
+        with H.NoiseInjector() as inj:
+            inj.push(eps)
+            tr.train_step({k: t(v) for k, v in batch.items()})
+        st = tr.eval_statistics
+        res = orc.train_step(batch, eps)
+        for k_ref, k_or in (("QF1 Loss", "qf1_loss"), ("QF2 Loss", "qf2_loss"), ("VF Loss", "vf_loss"),
+                            ("Policy Loss", "policy_loss")):
+            assert np.allclose(st[k_ref], res[k_or], rtol=2e-4, atol=1e-6), (s, k_ref, st[k_ref], res[k_or])
+        for nm in ("q1", "q2", "vf", "pi"):
+            err = np.abs(grads[nm] - res[nm + "_grad"]).max() / (np.abs(grads[nm]).max() + 1e-12)
+            assert err < 2e-3, (s, nm, err)
+        rec.update({f"s{s}_{k}": v for k, v in batch.items()})
+        rec.update({f"s{s}_eps": eps, f"s{s}_qf1_loss": st["QF1 Loss"], f"s{s}_qf2_loss": st["QF2 Loss"],
+                    f"s{s}_vf_loss": st["VF Loss"], f"s{s}_policy_loss": st["Policy Loss"],
+                    f"s{s}_grad_q1": grads["q1"], f"s{s}_grad_vf": grads["vf"], f"s{s}_grad_pi": grads["pi"],
+                    f"s{s}_pi": get_flat(pol), f"s{s}_q1": get_flat(qf1), f"s{s}_q2": get_flat(qf2),
+                    f"s{s}_vf": get_flat(vf), f"s{s}_tvf": get_flat(tr.target_vf)})
+        for k, mod in (("pi", pol), ("q1", qf1), ("q2", qf2), ("vf", vf), ("tvf", tr.target_vf)):
+            err = np.abs(getattr(orc, k) - get_flat(mod)).max()
+            assert err < 5e-5, (s, k, err)
+    save("g5_sac_v", **rec)
+
+
+GROUPS = dict(td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap)
 
 if __name__ == "__main__":
