@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""Secondary benchmark lines for the other BASELINE.json configs; `bench.py` stays the headline.
+
+    python bench_aux.py ppo     # C4: PPO Hopper dims, 8192 envs x 128-step rollout = 1,048,576 samples
+    python bench_aux.py gail    # C3: GAIL Walker2d dims, 1 discriminator step + 1 SAC step per loop iteration
+    python bench_aux.py td3     # TD3 / SAC-V grad-steps/s at the SAC config's sizes
+
+Each prints one JSON line.  Synthetic inputs of the configs' shapes, random-init networks.
+"""
+import ctypes as C
+import json
+import sys
+import time
+
+import numpy as np
+
+import ilswiss_amd
+from ilswiss_amd import _lib
+
+PEAK_HBM_GBS = 8000.0
+
+
+def _kernel_time(ctx, kid, fn):
+    lib = ctx.lib
+    _lib.check(lib.ilsx_prof_reset(ctx.h))
+    _lib.check(lib.ilsx_prof_enable(ctx.h, 1))
+    fn()
+    _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
+    nl, ms = C.c_uint64(), C.c_double()
+    _lib.check(lib.ilsx_prof_read(ctx.h, kid, C.byref(nl), C.byref(ms)))
+    return nl.value, ms.value
+
+
+def bench_ppo(ctx):
+    from ilswiss_amd.networks import FlattenMlp
+    from ilswiss_amd.ppo import PPO, ReparamMultivariateGaussianPolicy
+    o, a, H, n_env, T = 11, 3, 256, 8192, 128
+    N = n_env * T
+    rng = np.random.default_rng(0)
+    pol = ReparamMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=1)
+    vf = FlattenMlp([H, H], 1, o, hidden_activation="tanh", ctx=ctx, seed=2)
+    out = {}
+    obs = ctx.from_numpy(rng.normal(0, 1, (N, o)).astype(np.float32))
+    act = ctx.from_numpy(rng.normal(0, 0.5, (N, a)).astype(np.float32))
+    rew = ctx.from_numpy(rng.normal(1, 1, (N,)).astype(np.float32))
+    offs = (np.arange(n_env + 1) * T).astype(np.int32)
+    for mb, epochs, tag in ((32768, 10, "mb32768"), (64, 1, "mb64_1epoch_64k_samples")):
+        tr = PPO(pol, vf, mini_batch_size=mb, update_epoch=epochs, gae_tau=0.95, max_samples=N)
+        n_use = N if mb > 64 else 65536
+        ntraj = n_use // T
+        call = lambda: _lib.check(ctx.lib.ilsx_ppo_train(tr.h, obs.ptr, act.ptr, rew.ptr, offs.ctypes.data_as(C.c_void_p),  # noqa: E731
+                                                         ntraj, None))
+        call(); ctx.sync()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            call()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        out[tag] = dict(samples=n_use, update_epoch=epochs, mini_batch_size=mb, train_step_s=dt,
+                        sample_updates_per_s=n_use * epochs / dt, minibatch_steps_per_s=epochs * -(-n_use // mb) / dt)
+        if mb > 64:
+            gae = lambda: _lib.check(ctx.lib.ilsx_ppo_gae(tr.h, obs.ptr, act.ptr, rew.ptr, offs.ctypes.data_as(C.c_void_p),  # noqa: E731
+                                                          n_env, None, None, None, None))
+            nl, ms = _kernel_time(ctx, 12, lambda: [gae() for _ in range(20)])
+            us = ms * 1e3 / nl
+            alg = 16.0 * N   # values + rewards in, returns + advantages out (fp32); SURVEY §8d counts 5 streams = 20 B
+            out["gae"] = dict(kernel="k_ppo_gae", avg_launch_us=us, algorithmic_bytes_per_launch=alg,
+                              achieved_GBps=alg / (us * 1e-6) / 1e9, frac_of_hbm_peak=alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                              samples=N, trajectories=n_env)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                gae()
+            ctx.sync()
+            out["calc_adv_s"] = (time.perf_counter() - t0) / 5   # vf forward + GAE + fixed log-probs over 1M rows
+    return dict(metric="PPO Hopper-v2 dims, 8192 envs x 128-step rollout, GAE + minibatch update", unit="sample-updates/s",
+                value=out["mb32768"]["sample_updates_per_s"], dtype="f32", data="synthetic",
+                config=dict(workload="o=11,a=3, tanh 256-256 policy + value net, gamma .99, lambda .95, clip .2, 10 epochs; "
+                                     "minibatch 32768 at 1,048,576 samples and the reference's 64 at 65,536 samples (ppo_hopper.yaml:41-50)"),
+                detail=out)
+
+
+def bench_gail(ctx):
+    from ilswiss_amd.adv_irl import AdvIRLTrainer, MLPDisc
+    from ilswiss_amd.networks import FlattenMlp, ReparamTanhMultivariateGaussianPolicy
+    from ilswiss_amd.replay import SimpleReplayBuffer
+    from ilswiss_amd.sac import SoftActorCritic
+    o, a, H, B = 17, 6, 256, 256
+    rng = np.random.default_rng(0)
+    pol = ReparamTanhMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=1)
+    q1, q2 = FlattenMlp([H, H], 1, o + a, ctx=ctx, seed=2), FlattenMlp([H, H], 1, o + a, ctx=ctx, seed=3)
+    sac = SoftActorCritic(pol, q1, q2, reward_scale=2.0, policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, beta_1=0.25,
+                          max_batch=B)
+    disc = MLPDisc(o, a, hid_dim=128, hid_act="tanh", clamp_magnitude=10.0, grad_pen_weight=8.0, max_batch=B, ctx=ctx, seed=4)
+
+    def fill(rb, n):
+        rb.add_rows(rng.normal(0, 1, (n, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (n, a))).astype(np.float32),
+                     rng.normal(0, 1, n).astype(np.float32), (rng.random(n) < 1e-3), rng.normal(0, 1, (n, o)).astype(np.float32))
+    exp_rb = SimpleReplayBuffer(4000, o, a, random_seed=1, ctx=ctx)   # 4 expert trajectories x 1000 rows
+    rb = SimpleReplayBuffer(20000, o, a, random_seed=2, ctx=ctx)      # gail_walker.yaml:46
+    fill(exp_rb, 4000), fill(rb, 20000)
+    alg = AdvIRLTrainer("gail2", disc, sac, exp_rb, rb, disc_optim_batch_size=B, policy_optim_batch_size=B)
+    sac.eval_statistics, alg.disc_eval_statistics = {}, {}   # steady state: no statistics read-back
+    alg.train(200); ctx.sync()
+    n = 2000
+    t0 = time.perf_counter()
+    alg.train(n)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(n):
+        alg._do_reward_training()
+    ctx.sync()
+    dtd = time.perf_counter() - t0
+    return dict(metric="GAIL Walker2d-v2 dims: discriminator step + SAC step", unit="loop-iterations/s", value=n / dt,
+                dtype="f32", data="synthetic",
+                config=dict(workload="o=17,a=6; disc 23-128-128-1 tanh, B=256+256, WGAN-GP weight 8; SAC 256-256, B=256, "
+                                     "reward_scale 2, beta_1 0.25; expert buffer 4x1000 rows (gail_walker.yaml)"),
+                detail=dict(loop_iterations_per_s=n / dt, disc_steps_per_s_alone=n / dtd, us_per_iteration=1e6 * dt / n))
+
+
+def bench_td3(ctx):
+    from ilswiss_amd.networks import FlattenMlp, ReparamTanhMultivariateGaussianPolicy
+    from ilswiss_amd.replay import SimpleReplayBuffer
+    from ilswiss_amd.sac_v import SoftActorCriticV
+    from ilswiss_amd.td3 import TD3, MlpGaussianNoisePolicy
+    o, a, H, B = 11, 3, 256, 256
+    rng = np.random.default_rng(0)
+    rb = SimpleReplayBuffer(100000, o, a, random_seed=2, ctx=ctx)
+    n = 100000
+    rb.add_rows(rng.normal(0, 1, (n, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (n, a))).astype(np.float32),
+                 rng.normal(0, 1, n).astype(np.float32), (rng.random(n) < 1e-3), rng.normal(0, 1, (n, o)).astype(np.float32))
+    mk = lambda i, s: FlattenMlp([H, H], 1, i, ctx=ctx, seed=s)  # noqa: E731
+    td3 = TD3(MlpGaussianNoisePolicy([H, H], o, a, policy_noise=0.2, ctx=ctx, seed=1), mk(o + a, 2), mk(o + a, 3),
+              policy_lr=3e-4, qf_lr=3e-4, max_batch=B)
+    sv = SoftActorCriticV(ReparamTanhMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=4), mk(o + a, 5), mk(o + a, 6), mk(o, 7),
+                          alpha=0.2, policy_lr=3e-4, qf_lr=3e-4, vf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+    res = {}
+    for name, tr in (("td3", td3), ("sac_v", sv)):
+        tr.eval_statistics = {}
+        tr.train_from_replay(rb, 200, B); ctx.sync()
+        t0 = time.perf_counter()
+        tr.train_from_replay(rb, 2000, B)
+        ctx.sync()
+        res[name + "_grad_steps_per_s"] = 2000 / (time.perf_counter() - t0)
+    return dict(metric="TD3 / SAC-V grad-steps/s, Hopper dims, 256-256 MLP, batch 256", unit="grad-steps/s",
+                value=res["td3_grad_steps_per_s"], dtype="f32", data="synthetic", detail=res)
+
+
+if __name__ == "__main__":
+    ctx = ilswiss_amd.Context(0, seed=0)
+    which = sys.argv[1:] or ["ppo", "gail", "td3"]
+    for w in which:
+        print(json.dumps(dict(ppo=bench_ppo, gail=bench_gail, td3=bench_td3)[w](ctx)), flush=True)

@@ -120,6 +120,7 @@ PROTOTYPES = {
     "ilsx_ppo_get_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "ilsx_ppo_gae": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
     "ilsx_ppo_train": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp]),
+    "ilsx_ppo_debug_perm": (C.c_int, [vp, C.c_int, C.c_uint32, vp]),
     "ilsx_ppo_policy_act": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "ilsx_disc_create": (C.c_int, [vp, C.POINTER(DiscCfg), C.POINTER(vp)]),
     "ilsx_disc_destroy": (C.c_int, [vp]),

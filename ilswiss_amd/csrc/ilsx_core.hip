@@ -172,7 +172,7 @@ extern "C" int ilsx_prof_read(ilsx_ctx* c, int kid, uint64_t* launches, double* 
 extern "C" const char* ilsx_kernel_name(int kid) {
   static const char* names[ILSX_K_COUNT] = {"k_mlp_fwd", "k_mlp_bwd_dx", "k_mlp_bwd_dw", "k_adam_polyak",
       "k_replay_sample", "k_replay_add", "k_replay_sample_many", "k_sac_stats", "k_sac_finish", "k_env_step",
-      "k_policy_finish", "k_disc_bwd", "", "", "", ""};
+      "k_policy_finish", "k_disc_bwd", "k_ppo_gae", "", "", ""};
   return (kid >= 0 && kid < ILSX_K_COUNT) ? names[kid] : "";
 }
 

@@ -14,8 +14,6 @@
 //             k_ppo_clip_adam (clip_grad_norm_(20) scale + Adam over the policy arena)
 // HBM-bound pieces: k_ppo_gae streams 5 fp32 arrays once (20 B per sample).
 #include <cmath>
-#include <numeric>
-#include <random>
 
 #include "host_common.h"
 
@@ -25,28 +23,85 @@ struct PpoScalars {
   int t_v, t_p, pad2[2];
 };
 
-// ---- GAE: one lane per trajectory (ppo.py:73-86)
-__global__ void k_ppo_gae(const float* __restrict__ values, const float* __restrict__ rewards, const int* __restrict__ offs,
-                          int n_traj, float reward_scale, float gamma, float tau, float* __restrict__ returns,
-                          float* __restrict__ adv) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_traj) return;
+// ---- GAE: one wavefront per trajectory (ppo.py:73-86).  The trajectory is walked from its end in 64-sample chunks:
+// every lane loads one sample (coalesced 256-B rows of values / rewards); delta_t = r_t + g*V_{t+1} - V_t takes V_{t+1}
+// from the neighbouring lane; the recurrence A_t = delta_t + (g*l)*A_{t+1} is a 6-step Kogge-Stone suffix scan with the
+// constant ratio g*l (a lane-serial walk in the reference's exact order costs 64 dependent VALU steps per chunk with all
+// lanes computing the same scalar and ran 5x slower); chunks chain through (A, V) of their first sample.  The raw
+// advantages stay in registers (up to 1024 samples = max_path_length of every config; longer trajectories park them
+// in `adv`), then mean / unbiased std and the normalised write.  HBM traffic: values + rewards in, returns + advantages
+// out = 16 B per sample.  Differences to the sequential fp32 order are a few ulp (tests: rtol 1e-5 on returns).
+#define GAE_KEEP 16
+__global__ __launch_bounds__(256) void k_ppo_gae(const float* __restrict__ values, const float* __restrict__ rewards,
+                                                 const int* __restrict__ offs, int n_traj, float reward_scale, float gamma,
+                                                 float tau, float* __restrict__ returns, float* __restrict__ adv) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_traj) return;   // wave-uniform
   const int b = offs[t], e = offs[t + 1], T = e - b;
-  float prev_v = 0.0f, prev_a = 0.0f, sum = 0.0f;
-  for (int i = e - 1; i >= b; --i) {
-    const float v = values[i];
-    const float delta = reward_scale * rewards[i] + gamma * prev_v - v;
-    const float a = delta + gamma * tau * prev_a;
-    adv[i] = a;
-    returns[i] = v + a;
-    prev_v = v; prev_a = a;
-    sum += a;
+  const int nchunk = (T + 63) >> 6;
+  const float c = gamma * tau;
+  float cp[7];   // c^(2^s)
+  cp[0] = c;
+#pragma unroll
+  for (int s = 1; s < 7; ++s) cp[s] = cp[s - 1] * cp[s - 1];
+  float keep[GAE_KEEP];
+#pragma unroll
+  for (int k = 0; k < GAE_KEEP; ++k) keep[k] = 0.0f;
+  float carry_v = 0.0f, carry_a = 0.0f, sum = 0.0f;
+  for (int ch = nchunk - 1, k = 0; ch >= 0; --ch, ++k) {
+    const int i0 = b + 64 * ch, idx = i0 + lane;
+    const int last = min(63, e - 1 - i0);
+    const bool ok = lane <= last;
+    const float v = ok ? values[idx] : 0.0f;
+    const float r = ok ? reward_scale * rewards[idx] : 0.0f;
+    float vn = __shfl_down(v, 1);
+    if (lane == last) vn = carry_v;
+    float a = ok ? r + gamma * vn - v : 0.0f;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const float up = __shfl_down(a, 1 << s);
+      if (lane + (1 << s) <= last) a = a + cp[s] * up;
+    }
+    // carry from the later chunk: c^(last - lane + 1) * A_first(later chunk)
+    const int m = last - lane + 1;
+    float pw = 1.0f;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) if (m & (1 << s)) pw *= cp[s];
+    if (ok) a = a + pw * carry_a;
+    carry_a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a)));
+    carry_v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+    if (ok) { returns[idx] = v + a; sum += a; }
+    bool kept = false;
+#pragma unroll
+    for (int q = 0; q < GAE_KEEP; ++q)
+      if (q == k) { keep[q] = a; kept = true; }
+    if (!kept && ok) adv[idx] = a;   // long trajectory: park the raw advantage, normalised in place below
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
   const float mean = sum / (float)T;
   double ss = 0.0;
-  for (int i = b; i < e; ++i) { const double d = (double)adv[i] - (double)mean; ss += d * d; }
+  for (int ch = nchunk - 1, k = 0; ch >= 0; --ch, ++k) {
+    const int idx = b + 64 * ch + lane;
+    float a = 0.0f;
+#pragma unroll
+    for (int q = 0; q < GAE_KEEP; ++q) if (q == k) a = keep[q];
+    if (k >= GAE_KEEP && idx < e) a = adv[idx];
+    const double dd = idx < e ? (double)a - (double)mean : 0.0;
+    ss += dd * dd;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   const float sd = (float)sqrt(ss / (double)(T - 1));   // torch.std(): unbiased; T == 1 -> nan like the reference
-  for (int i = b; i < e; ++i) adv[i] = (adv[i] - mean) / sd;
+  for (int ch = nchunk - 1, k = 0; ch >= 0; --ch, ++k) {
+    const int idx = b + 64 * ch + lane;
+    float a = 0.0f;
+#pragma unroll
+    for (int q = 0; q < GAE_KEEP; ++q) if (q == k) a = keep[q];
+    if (k >= GAE_KEEP && idx < e) a = adv[idx];
+    if (idx < e) adv[idx] = (a - mean) / sd;
+  }
 }
 
 // ---- sum of squares of the policy gradient (every parameter once) + d/d log_std = column sums of the aux rows
@@ -70,6 +125,28 @@ __global__ __launch_bounds__(256) void k_ppo_norm(const PpoNormArgs P) {
   }
   s = block256_sum(s, sh);
   if (threadIdx.x == 0) P.partial[blockIdx.x] = s;
+}
+
+// torch.randperm stand-in (ppo.py:116) without a host shuffle: a keyed 4-round Feistel network over the 2^k >= N index
+// space with cycle-walking is a bijection of [0, N); one thread per output slot.
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, int half_bits, uint32_t k0, uint32_t k1) {
+  const uint32_t mask = (1u << half_bits) - 1u;
+  uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+  for (int rd = 0; rd < 4; ++rd) {
+    uint32_t c[4] = {r, (uint32_t)rd, k1, 0x9E3779B9u};
+    philox4x32_10(c, k0, k1 ^ (uint32_t)rd);
+    const uint32_t nl = r, nr = l ^ (c[0] & mask);
+    l = nl; r = nr;
+  }
+  return (l << half_bits) | r;
+}
+__global__ __launch_bounds__(256) void k_ppo_perm(int* __restrict__ perm, int n, int half_bits, uint32_t k0, uint32_t k1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x = (uint32_t)i;
+  do { x = feistel_perm(x, half_bits, k0, k1); } while (x >= (uint32_t)n);   // cycle-walk back into [0, n)
+  perm[i] = (int)x;
 }
 
 struct PpoClipAdamArgs {
@@ -258,8 +335,11 @@ extern "C" int ilsx_ppo_gae(ilsx_ppo* p, const float* obs, const float* act, con
   hipStream_t st = p->ctx->stream;
   HIPCHK(hipMemcpyAsync(p->offs, traj_offsets_host, (size_t)(n_traj + 1) * sizeof(int), hipMemcpyHostToDevice, st));
   ILSX_TRY(ppo_full_forward(p, obs, act, N, true, p->values));
-  hipLaunchKernelGGL(k_ppo_gae, dim3((n_traj + 63) / 64), dim3(64), 0, st, p->values, rew, p->offs, n_traj, p->cfg.reward_scale,
-                     p->cfg.discount, p->cfg.gae_tau, p->returns, p->adv);
+  {
+    ProfScope ps(p->ctx, ILSX_K_PPO_GAE);
+    hipLaunchKernelGGL(k_ppo_gae, dim3((n_traj + 3) / 4), dim3(256), 0, st, p->values, rew, p->offs, n_traj, p->cfg.reward_scale,
+                       p->cfg.discount, p->cfg.gae_tau, p->returns, p->adv);
+  }
   HIPCHK(hipGetLastError());
   ILSX_TRY(ppo_full_forward(p, obs, act, N, false, p->lp_old));
   p->N = N;
@@ -350,20 +430,36 @@ extern "C" int ilsx_ppo_train(ilsx_ppo* p, const float* obs, const float* act, c
                               const int32_t* traj_offsets_host, int n_traj, const int32_t* perms_host) {
   ILSX_TRY(ilsx_ppo_gae(p, obs, act, rew, traj_offsets_host, n_traj, nullptr, nullptr, nullptr, nullptr));
   const int N = p->N, mb = p->cfg.mini_batch_size;
-  static std::mt19937_64 gen(0x5eed);
-  std::vector<int> perm(N);
+  static unsigned long long shuffles = 0;
+  int half_bits = 1;
+  while ((1ll << (2 * half_bits)) < (long long)N) ++half_bits;
   for (int ep = 0; ep < p->cfg.update_epoch; ++ep) {
     if (perms_host) {
-      memcpy(perm.data(), perms_host + (size_t)ep * N, (size_t)N * sizeof(int));
+      HIPCHK(hipStreamSynchronize(p->ctx->stream));   // previous epoch's kernels still read p->perm
+      HIPCHK(hipMemcpyAsync(p->perm, perms_host + (size_t)ep * N, (size_t)N * sizeof(int), hipMemcpyHostToDevice, p->ctx->stream));
+      HIPCHK(hipStreamSynchronize(p->ctx->stream));
     } else {
-      std::iota(perm.begin(), perm.end(), 0);
-      std::shuffle(perm.begin(), perm.end(), gen);
+      ++shuffles;
+      hipLaunchKernelGGL(k_ppo_perm, dim3((N + 255) / 256), dim3(256), 0, p->ctx->stream, p->perm, N, half_bits,
+                         (uint32_t)(p->ctx->seed ^ 0x70657261u), (uint32_t)shuffles);
+      HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(p->ctx->stream));   // previous epoch's kernels still read p->perm
-    HIPCHK(hipMemcpyAsync(p->perm, perm.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, p->ctx->stream));
-    HIPCHK(hipStreamSynchronize(p->ctx->stream));
     for (int s = 0; s < N; s += mb) ILSX_TRY(ppo_minibatch(p, obs, act, p->perm + s, std::min(mb, N - s)));
   }
+  return ILSX_OK;
+}
+
+// one library-drawn shuffle of [0, n) (what ilsx_ppo_train uses when perms_host == NULL), for tests
+extern "C" int ilsx_ppo_debug_perm(ilsx_ppo* p, int n, uint32_t key, int32_t* perm_host) {
+  if (!p || !perm_host || n < 1 || n > p->cfg.max_samples) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_debug_perm: bad argument");
+  HIPCHK(hipSetDevice(p->ctx->device));
+  int half_bits = 1;
+  while ((1ll << (2 * half_bits)) < (long long)n) ++half_bits;
+  hipLaunchKernelGGL(k_ppo_perm, dim3((n + 255) / 256), dim3(256), 0, p->ctx->stream, p->perm, n, half_bits,
+                     (uint32_t)(p->ctx->seed ^ 0x70657261u), key);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(perm_host, p->perm, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, p->ctx->stream));
+  HIPCHK(hipStreamSynchronize(p->ctx->stream));
   return ILSX_OK;
 }
 

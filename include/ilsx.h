@@ -70,7 +70,8 @@ int ilsx_memcpy_d2h(ilsx_ctx* ctx, void* dst_host, const void* src_dev, size_t b
  * path is bypassed while profiling); ilsx_prof_read synchronises and returns launches + summed ms. */
 enum { ILSX_K_MLP_FWD = 0, ILSX_K_MLP_BWD_DX = 1, ILSX_K_MLP_BWD_DW = 2, ILSX_K_ADAM = 3,
        ILSX_K_REPLAY_SAMPLE = 4, ILSX_K_REPLAY_ADD = 5, ILSX_K_REPLAY_SAMPLE_MANY = 6, ILSX_K_SAC_STATS = 7,
-       ILSX_K_SAC_FINISH = 8, ILSX_K_ENV_STEP = 9, ILSX_K_POLICY_FINISH = 10, ILSX_K_DISC_BWD = 11, ILSX_K_COUNT = 16 };
+       ILSX_K_SAC_FINISH = 8, ILSX_K_ENV_STEP = 9, ILSX_K_POLICY_FINISH = 10, ILSX_K_DISC_BWD = 11, ILSX_K_PPO_GAE = 12,
+       ILSX_K_COUNT = 16 };
 int ilsx_prof_enable(ilsx_ctx* ctx, int on);
 int ilsx_prof_reset(ilsx_ctx* ctx);
 int ilsx_prof_read(ilsx_ctx* ctx, int kernel_id, uint64_t* launches, double* total_ms);
@@ -305,6 +306,8 @@ int ilsx_ppo_gae(ilsx_ppo* ppo, const float* obs, const float* act, const float*
  * ppo.py:116) or NULL = drawn by the library. */
 int ilsx_ppo_train(ilsx_ppo* ppo, const float* obs, const float* act, const float* rew, const int32_t* traj_offsets_host,
                    int n_traj, const int32_t* perms_host);
+/* debug: one library-drawn shuffle of [0,n) (keyed Feistel bijection; the NULL-perms path of ilsx_ppo_train) -> HOST */
+int ilsx_ppo_debug_perm(ilsx_ppo* ppo, int n, uint32_t key, int32_t* perm_host);
 /* get_actions (policies.py:392-417): act[n,a] = mean + exp(log_std)*eps (eps device [n,a] or NULL = Philox), or the
  * mean when deterministic; logp[n] nullable. */
 int ilsx_ppo_policy_act(ilsx_ppo* ppo, const float* obs, int n, int deterministic, const float* eps, float* act,

@@ -138,3 +138,43 @@ def test_hip_gaussian_policy_act(ctx):
     np.testing.assert_allclose(tr.policy_act(obs, deterministic=True)[0], mu, rtol=1e-5, atol=1e-6)
     a1, a2 = tr.policy_act(obs)[0], tr.policy_act(obs)[0]                                       # Philox draws move on
     assert np.abs(a1 - a2).max() > 1e-3 and np.isfinite(a1).all()
+
+
+@pytest.mark.gpu
+def test_hip_library_shuffle_is_a_permutation(ctx):
+    import ctypes as C
+    from ilswiss_amd import _lib
+    g = load_golden("g7_ppo")
+    tr = _hip_ppo(ctx, g)
+    seen = []
+    for n, key in ((1, 1), (2, 1), (72, 1), (72, 2), (4096, 7), (4095, 7), (3001, 9)):
+        perm = np.empty(n, np.int32)
+        _lib.check(ctx.lib.ilsx_ppo_debug_perm(tr.h, n, key, perm.ctypes.data_as(C.c_void_p)))
+        np.testing.assert_array_equal(np.sort(perm), np.arange(n))
+        seen.append(perm)
+    assert (seen[2] != seen[3]).any()                       # a new key reshuffles
+    assert np.abs(np.corrcoef(seen[4], np.arange(4096))[0, 1]) < 0.1   # and looks nothing like the identity
+    # the NULL-perms train path runs and moves both networks
+    p0, v0 = tr.get_flat_params(0), tr.get_flat_params(1)
+    tr.train_step(_trajs(g))
+    assert np.abs(tr.get_flat_params(0) - p0).max() > 1e-5 and np.abs(tr.get_flat_params(1) - v0).max() > 1e-5
+    assert np.isfinite(tr.get_flat_params(0)).all()
+
+
+@pytest.mark.gpu
+def test_hip_gae_chunk_edges_and_long_trajectories(ctx):
+    """Trajectory lengths around the 64-sample chunking and the 1024-sample register window of k_ppo_gae; a
+    single-sample trajectory standardises to nan exactly like torch.std (ppo.py:86)."""
+    rng = np.random.default_rng(17)
+    g = load_golden("g7_ppo")
+    o, a = int(g["dims"][0]), int(g["dims"][1])
+    orc = PPOOracle(o, a, [int(v) for v in g["dims"][2:]], g["pi0"], g["vf0"], **dict(KW, reward_scale=0.7))
+    tr = _hip_ppo(ctx, g, reward_scale=0.7)
+    trajs = [dict(observations=rng.normal(0, 1, (L, o)).astype(np.float32), actions=rng.normal(0, 0.7, (L, a)).astype(np.float32),
+                  rewards=rng.normal(0.5, 1.0, (L, 1)).astype(np.float32)) for L in (1500, 64, 65, 128, 1, 1024, 1025, 63, 2)]
+    R, A, V, lp = tr.calc_adv(trajs)
+    _, _, R0, A0, V0 = orc.calc_adv(trajs)
+    np.testing.assert_allclose(V, V0, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(R, R0, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(A, A0, rtol=2e-4, atol=5e-5, equal_nan=True)
+    assert np.isnan(A).sum() == 1
