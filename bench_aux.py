@@ -49,7 +49,7 @@ def bench_ppo(ctx):
         n_use = N if mb > 64 else 65536
         ntraj = n_use // T
         call = lambda: _lib.check(ctx.lib.ilsx_ppo_train(tr.h, obs.ptr, act.ptr, rew.ptr, offs.ctypes.data_as(C.c_void_p),  # noqa: E731
-                                                         ntraj, None))
+                                                         ntraj, None, None))
         call(); ctx.sync()
         t0 = time.perf_counter()
         reps = 2
@@ -61,7 +61,7 @@ def bench_ppo(ctx):
                         sample_updates_per_s=n_use * epochs / dt, minibatch_steps_per_s=epochs * -(-n_use // mb) / dt)
         if mb > 64:
             gae = lambda: _lib.check(ctx.lib.ilsx_ppo_gae(tr.h, obs.ptr, act.ptr, rew.ptr, offs.ctypes.data_as(C.c_void_p),  # noqa: E731
-                                                          n_env, None, None, None, None))
+                                                          n_env, None, None, None, None, None))
             nl, ms = _kernel_time(ctx, 12, lambda: [gae() for _ in range(20)])
             us = ms * 1e3 / nl
             alg = 16.0 * N   # values + rewards in, returns + advantages out (fp32); SURVEY §8d counts 5 streams = 20 B

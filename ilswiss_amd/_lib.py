@@ -118,8 +118,13 @@ PROTOTYPES = {
     "ilsx_ppo_num_params": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),
     "ilsx_ppo_set_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "ilsx_ppo_get_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
-    "ilsx_ppo_gae": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
-    "ilsx_ppo_train": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp]),
+    "ilsx_ppo_gae": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "ilsx_ppo_values": (C.c_int, [vp, vp, C.c_int, vp]),
+    "ilsx_ppo_train": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "ilsx_ppo_rollout": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "ilsx_vecenv_obs_norm": (C.c_int, [vp, C.c_int, C.c_int]),
+    "ilsx_vecenv_get_obs_rms": (C.c_int, [vp, vp, vp, C.POINTER(C.c_double)]),
+    "ilsx_vecenv_set_obs_rms": (C.c_int, [vp, vp, vp, C.c_double]),
     "ilsx_ppo_debug_perm": (C.c_int, [vp, C.c_int, C.c_uint32, vp]),
     "ilsx_ppo_policy_act": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "ilsx_disc_create": (C.c_int, [vp, C.POINTER(DiscCfg), C.POINTER(vp)]),
@@ -138,7 +143,7 @@ PROTOTYPES = {
     "ilsx_vecenv_get_state": (C.c_int, [vp, vp, vp]),
     "ilsx_vecenv_set_state": (C.c_int, [vp, vp, vp]),
     "ilsx_vecenv_cur_obs": (C.c_int, [vp, C.POINTER(vp)]),
-    "ilsx_rollout_step": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+    "ilsx_rollout_step": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ilsx_rollout_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "ilsx_abi_version": (C.c_int, []),
     "ilsx_last_error": (C.c_char_p, []),

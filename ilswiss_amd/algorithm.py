@@ -64,9 +64,11 @@ class DeviceRLAlgorithm:
                  num_steps_per_epoch=10000, num_steps_between_train_calls=1000, num_train_steps_per_train_call=1000,
                  num_steps_per_eval=1000, max_path_length=1000, min_steps_before_training=0, batch_size=256,
                  replay_buffer_size=1000000, no_terminal=False, eval_deterministic=True, freq_saving=1, save_best=True,
-                 save_replay_buffer=False, replay_buffer=None, log_dir=None, best_key="AverageReturn", **kwargs):
-        if no_terminal:
-            raise NotImplementedError("no_terminal (used by the adv-IRL configs) arrives with the discriminator row")
+                 save_replay_buffer=False, replay_buffer=None, log_dir=None, best_key="AverageReturn", bootstrap_open_segments=True,
+                 **kwargs):
+        self.no_terminal = bool(no_terminal)   # base_algorithm.py:195-196,208-210: stored terminal flags forced to False
+        self.on_policy = bool(getattr(trainer, "on_policy", False))   # torch_rl_algorithm.py:30-32
+        self.bootstrap_open_segments = bootstrap_open_segments
         self.trainer, self.env, self.training_env, self.eval_env = trainer, env, training_env, eval_env
         self.exploration_policy = exploration_policy
         self.num_epochs, self.num_env_steps_per_epoch = num_epochs, num_steps_per_epoch
@@ -76,7 +78,7 @@ class DeviceRLAlgorithm:
         self.min_steps_before_training, self.batch_size = min_steps_before_training, batch_size
         self.freq_saving, self.save_best, self.best_key = freq_saving, save_best, best_key
         self.env_num = len(training_env)
-        if replay_buffer is None:
+        if replay_buffer is None and not self.on_policy:
             seed = int(np.random.randint(10000))  # base_algorithm.py:118-120
             replay_buffer = EnvReplayBuffer(replay_buffer_size, env, random_seed=seed, ctx=trainer.ctx)
         self.replay_buffer = replay_buffer
@@ -91,7 +93,35 @@ class DeviceRLAlgorithm:
     def _can_train(self):
         return self.replay_buffer.num_steps_can_sample() >= max(self.min_steps_before_training, 1)
 
+    def _train_on_policy(self, start_epoch):
+        """The on-policy branch (torch_rl_algorithm.py:30-32): every `num_steps_between_train_calls` env steps the trainer
+        consumes ALL samples collected since the last call and the buffer is cleared.  Here the samples never leave the
+        device: trainer.train_from_rollout runs the vec steps, GAE and the minibatch epochs."""
+        ctx = self.trainer.ctx
+        horizon = max(1, self.num_steps_between_train_calls // self.env_num)
+        t_start = time.perf_counter()
+        for epoch in range(start_epoch, self.num_epochs + 1):
+            t_epoch = time.perf_counter()
+            self.training_env.rollout_stats(reset=True)
+            steps = 0
+            while steps < self.num_env_steps_per_epoch:
+                steps += self.trainer.train_from_rollout(self.training_env, horizon, self.max_path_length,
+                                                         bootstrap=self.bootstrap_open_segments)
+                self._n_train_steps_total += self.num_train_steps_per_train_call
+            ctx.sync()
+            self._n_env_steps_total += steps
+            self._t_train = time.perf_counter() - t_epoch   # rollout + update are one device pipeline here
+            self._t_sample = 0.0
+            if hasattr(self.eval_env, "sync_obs_rms"):
+                self.eval_env.sync_obs_rms()
+            t0 = time.perf_counter()
+            self.evaluate(epoch, time.perf_counter() - t_epoch, time.perf_counter() - t_start)
+            self._t_eval = time.perf_counter() - t0
+            self.trainer.end_epoch()
+
     def train(self, start_epoch=0):
+        if self.on_policy:
+            return self._train_on_policy(start_epoch)
         ctx = self.trainer.ctx
         t_start = time.perf_counter()
         for epoch in range(start_epoch, self.num_epochs + 1):  # num_epochs + 1 (base_algorithm.py:64)
@@ -102,7 +132,7 @@ class DeviceRLAlgorithm:
                 t0 = time.perf_counter()
                 random_actions = self.replay_buffer.num_steps_can_sample() < self.min_steps_before_training
                 self.training_env.rollout_step(self.exploration_policy, self.replay_buffer, self.max_path_length,
-                                               random_actions=random_actions)
+                                               random_actions=random_actions, no_terminal=self.no_terminal)
                 self._n_env_steps_total += self.env_num
                 if self._n_env_steps_total - self._n_prev_train_env_steps >= self.num_steps_between_train_calls:
                     ctx.sync()

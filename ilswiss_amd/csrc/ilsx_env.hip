@@ -44,7 +44,61 @@ struct ilsx_vecenv {
   uint64_t seed = 0;
   uint32_t rng_stream = 0;
   unsigned long long step_ctr = 0;
+  // running observation statistics (vecenvs.py:299-327, normalizer.py:128-152)
+  struct ObsRms* rms = nullptr;
+  float* obs_n = nullptr;   // [n_env][o] normalised policy input (norm_obs)
+  bool norm_obs = false, update_rms = false;
+  const float* policy_obs() const { return norm_obs ? obs_n : obs_cur; }
 };
+
+// RunningMeanStd (normalizer.py:128-152): float64, one owner workgroup per observation dimension (count is kept per
+// dimension so that no workgroup depends on another's update).
+#define ENV_MAX_OBS 64
+struct ObsRms { double mean[ENV_MAX_OBS], var[ENV_MAX_OBS], count[ENV_MAX_OBS]; };
+
+// update(x) with x = the selected rows of src[n_rows][o]: batch mean / population variance in two passes (np.mean,
+// np.var), then the parallel-variance merge.  flag != null: only rows whose flag is 0 (episodes that just ended).
+__global__ __launch_bounds__(256) void k_obs_rms_update(const float* __restrict__ src, int n_rows, int o, const int* __restrict__ flag,
+                                                        ObsRms* rms) {
+  __shared__ double sh[4];
+  __shared__ double bc;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  auto bsum = [&](double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+  };
+  double s = 0.0, n = 0.0;
+  for (int r = tid; r < n_rows; r += 256)
+    if (!flag || flag[r] == 0) { s += (double)src[(size_t)r * o + i]; n += 1.0; }
+  s = bsum(s); n = bsum(n);
+  if (n == 0.0) return;   // block-uniform
+  const double bm = s / n;
+  double ss = 0.0;
+  for (int r = tid; r < n_rows; r += 256)
+    if (!flag || flag[r] == 0) { const double d = (double)src[(size_t)r * o + i] - bm; ss += d * d; }
+  ss = bsum(ss);
+  if (tid == 0) {
+    const double bv = ss / n, c = rms->count[i], mean = rms->mean[i], var = rms->var[i];
+    const double delta = bm - mean, tot = c + n;
+    const double m2 = var * c + bv * n + delta * delta * c * n / tot;
+    rms->mean[i] = mean + delta * n / tot;
+    rms->var[i] = m2 / tot;
+    rms->count[i] = tot;
+  }
+  (void)bc;
+}
+// normalize_obs (vecenvs.py:299-327): clip((x - mean) / sqrt(var + eps), +-10), eps = np.finfo(float32).eps
+__global__ __launch_bounds__(256) void k_obs_normalize(const float* src, float* dst, int n, int o, const ObsRms* __restrict__ rms) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int i = t % o;
+  const double z = ((double)src[t] - rms->mean[i]) / sqrt(rms->var[i] + 1.1920928955078125e-07);
+  dst[t] = (float)fmin(fmax(z, -10.0), 10.0);
+}
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double impedance_d(double r_abs, const double* solimp) {
@@ -322,7 +376,7 @@ struct EnvStepArgs {
   unsigned char* done;    // [n_ids]
   // fused-rollout extras (all nullable / 0)
   float* obs_cur;         // [n_env][o]: the policy's next input (post auto-reset)
-  int auto_reset, max_path_length;
+  int auto_reset, max_path_length, no_terminal;
   int* ep_len; double* ep_ret; double* stats;
   float* replay; int rec; long long cap, top;   // transition record written at slot (top + env) % cap
   uint64_t seed; uint32_t stream; unsigned long long step;
@@ -404,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
     for (int i = 0; i < o; ++i) rec[i] = obs_before[i];
     for (int k = 0; k < na; ++k) rec[o + k] = A.act[(size_t)t * na + k];
     rec[o + na] = (float)reward;
-    rec[o + na + 1] = done ? 1.0f : 0.0f;
+    rec[o + na + 1] = (done && !A.no_terminal) ? 1.0f : 0.0f;   // base_algorithm.py:195-196,208-210
     for (int i = 0; i < o; ++i) rec[o + na + 2 + i] = ob[i];
   }
   if (A.auto_reset) {
@@ -490,6 +544,19 @@ static int launch_env_reset(ilsx_vecenv* e, const int* ids_dev, int n_ids, float
   return ILSX_OK;
 }
 
+// RunningMeanStd update with rows of `src` (all, or those whose flag is 0) then normalise src -> dst
+static int env_obs_norm(ilsx_vecenv* e, const float* upd_src, int upd_rows, const int* flag, const float* src, float* dst, int rows) {
+  if (!e->norm_obs) return ILSX_OK;
+  hipStream_t st = e->ctx->stream;
+  if (e->update_rms && upd_src && upd_rows > 0)
+    hipLaunchKernelGGL(k_obs_rms_update, dim3(e->o), dim3(256), 0, st, upd_src, upd_rows, e->o, flag, e->rms);
+  if (src && rows > 0)
+    hipLaunchKernelGGL(k_obs_normalize, dim3((rows * e->o + 255) / 256), dim3(256), 0, st, src, dst, rows * e->o, e->o,
+                       (const ObsRms*)e->rms);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
 extern "C" int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* pm, int n_env, uint64_t seed, ilsx_vecenv** out) {
   if (!ctx || !pm || !out || n_env < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_vecenv_create: bad argument");
   if (pm->n_body != 4 && pm->n_body != 7)
@@ -541,11 +608,18 @@ extern "C" int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* pm, in
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->rew);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, N, (void**)&e->done);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->ep_len);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->o * 4, (void**)&e->obs_n);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(ObsRms), (void**)&e->rms);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 8, (void**)&e->ep_ret);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, 4 * 8, (void**)&e->stats);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->ids);
   if (rc != ILSX_OK) { delete e; return rc; }
   HIPCHK(hipMemcpyAsync(e->dm, &m, sizeof m, hipMemcpyHostToDevice, ctx->stream));
+  {
+    ObsRms h;   // RunningMeanStd(): mean 0, var 1, count 0 (normalizer.py:133-136)
+    for (int i = 0; i < ENV_MAX_OBS; ++i) { h.mean[i] = 0.0; h.var[i] = 1.0; h.count[i] = 0.0; }
+    HIPCHK(hipMemcpyAsync(e->rms, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ILSX_TRY(launch_env_reset(e, nullptr, n_env, nullptr));
   *out = e;
@@ -587,7 +661,12 @@ extern "C" int ilsx_vecenv_reset(ilsx_vecenv* e, const int32_t* ids_host, int n_
   if (n_ids < 0 || n_ids > e->n_env) ILSX_FAIL(ILSX_ERR_ARG, "n_ids=%d out of range", n_ids);
   const int* dev = nullptr;
   ILSX_TRY(env_upload_ids(e, ids_host, n_ids, &dev));
-  return launch_env_reset(e, dev, n_ids, obs);
+  if (!e->norm_obs) return launch_env_reset(e, dev, n_ids, obs);
+  // reset(id) returns normalised observations and feeds the running statistics (vecenvs.py:173-181)
+  float* raw = obs ? obs : e->nobs;   // compact [n_ids][o]
+  ILSX_TRY(launch_env_reset(e, dev, n_ids, raw));
+  ILSX_TRY(env_obs_norm(e, raw, n_ids, nullptr, obs, obs, obs ? n_ids : 0));
+  return env_obs_norm(e, nullptr, 0, nullptr, e->obs_cur, e->obs_n, e->n_env);
 }
 
 extern "C" int ilsx_vecenv_step(ilsx_vecenv* e, const float* act, const int32_t* ids_host, int n_ids, float* obs,
@@ -603,7 +682,11 @@ extern "C" int ilsx_vecenv_step(ilsx_vecenv* e, const float* act, const int32_t*
   A.m = e->dm; A.qpos = e->qpos; A.qvel = e->qvel; A.n_env = e->n_env;
   A.ids = dev; A.n_ids = n_ids; A.act = act; A.obs = obs; A.rew = rew; A.done = done;
   A.obs_cur = e->obs_cur;
-  return launch_env_step(e, A);
+  if (!e->norm_obs) return launch_env_step(e, A);
+  if (!obs) A.obs = e->nobs;
+  ILSX_TRY(launch_env_step(e, A));   // step() returns normalised observations (vecenvs.py:251-257)
+  ILSX_TRY(env_obs_norm(e, A.obs, n_ids, nullptr, obs, obs, obs ? n_ids : 0));
+  return env_obs_norm(e, nullptr, 0, nullptr, e->obs_cur, e->obs_n, e->n_env);
 }
 
 extern "C" int ilsx_vecenv_get_state(ilsx_vecenv* e, double* qpos_host, double* qvel_host) {
@@ -634,14 +717,51 @@ extern "C" int ilsx_vecenv_set_state(ilsx_vecenv* e, const double* qpos_host, co
 
 extern "C" int ilsx_vecenv_cur_obs(ilsx_vecenv* e, float** dev_ptr) {
   if (!e || !dev_ptr) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
-  *dev_ptr = e->obs_cur;
+  *dev_ptr = const_cast<float*>(e->policy_obs());
   return ILSX_OK;
+}
+
+// vecenvs.py:104-113 (obs_rms / norm_obs / update_obs_rms attributes of BaseVectorEnv)
+extern "C" int ilsx_vecenv_obs_norm(ilsx_vecenv* e, int norm_obs, int update_obs_rms) {
+  if (!e) ILSX_FAIL(ILSX_ERR_ARG, "env is NULL");
+  if (e->o > ENV_MAX_OBS) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "obs_dim %d > %d", e->o, ENV_MAX_OBS);
+  HIPCHK(hipSetDevice(e->ctx->device));
+  e->norm_obs = norm_obs != 0; e->update_rms = update_obs_rms != 0;
+  // the observations the envs currently show become the first batch, like the reset() that follows construction
+  return env_obs_norm(e, e->obs_cur, e->n_env, nullptr, e->obs_cur, e->obs_n, e->n_env);
+}
+extern "C" int ilsx_vecenv_get_obs_rms(ilsx_vecenv* e, double* mean, double* var, double* count) {
+  if (!e || !mean || !var || !count) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  ObsRms h;
+  HIPCHK(hipMemcpyAsync(&h, e->rms, sizeof h, hipMemcpyDeviceToHost, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  for (int i = 0; i < e->o; ++i) { mean[i] = h.mean[i]; var[i] = h.var[i]; }
+  *count = h.count[0];
+  return ILSX_OK;
+}
+extern "C" int ilsx_vecenv_set_obs_rms(ilsx_vecenv* e, const double* mean, const double* var, double count) {
+  if (!e || !mean || !var) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  ObsRms h;
+  for (int i = 0; i < ENV_MAX_OBS; ++i) { h.mean[i] = i < e->o ? mean[i] : 0.0; h.var[i] = i < e->o ? var[i] : 1.0; h.count[i] = count; }
+  HIPCHK(hipMemcpyAsync(e->rms, &h, sizeof h, hipMemcpyHostToDevice, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  return env_obs_norm(e, nullptr, 0, nullptr, e->obs_cur, e->obs_n, e->n_env);
+}
+
+// after an auto-resetting step: statistics see the step's observations, then the reset observations of the envs whose
+// episode just ended (the reference's step() followed by reset(ids)), and the policy input is re-normalised
+static int env_after_step_norm(ilsx_vecenv* e) {
+  if (!e->norm_obs) return ILSX_OK;
+  ILSX_TRY(env_obs_norm(e, e->nobs, e->n_env, nullptr, nullptr, nullptr, 0));
+  return env_obs_norm(e, e->obs_cur, e->n_env, e->ep_len, e->obs_cur, e->obs_n, e->n_env);
 }
 
 // One iteration of BaseAlgorithm's sampling loop (base_algorithm.py:183-277) for ALL envs, on the device:
 // actions (policy or uniform random) -> physics -> transition record into the replay ring -> auto-reset.
 extern "C" int ilsx_rollout_step(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
-                                 int deterministic) {
+                                 int deterministic, int no_terminal) {
   if (!e || (!pi && !random_actions)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_step: need a policy or random_actions");
   ilsx_ctx* ctx = e->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -654,7 +774,7 @@ extern "C" int ilsx_rollout_step(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, 
                        e->rng_stream ^ 0x5A5A5A5Au, step, e->a);
     HIPCHK(hipGetLastError());
   } else {
-    ILSX_TRY(ilsx_policy_act(pi, e->obs_cur, e->n_env, deterministic, nullptr, e->act, nullptr));
+    ILSX_TRY(ilsx_policy_act(pi, e->policy_obs(), e->n_env, deterministic, nullptr, e->act, nullptr));
   }
   EnvStepArgs A;
   memset(&A, 0, sizeof A);
@@ -664,9 +784,61 @@ extern "C" int ilsx_rollout_step(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, 
   A.obs_cur = e->obs_cur; A.auto_reset = 1; A.max_path_length = max_path_length;
   A.ep_len = e->ep_len; A.ep_ret = e->ep_ret; A.stats = e->stats;
   if (rb) { A.replay = rb->data; A.rec = rb->rec; A.cap = rb->cap; A.top = rb->top; }
-  A.seed = e->seed; A.stream = e->rng_stream; A.step = step;
+  A.seed = e->seed; A.stream = e->rng_stream; A.step = step; A.no_terminal = no_terminal;
   ILSX_TRY(launch_env_step(e, A));
   if (rb) ILSX_TRY(replay_advance_device_rows(rb, e->n_env));
+  return env_after_step_norm(e);
+}
+
+// ---- on-policy rollout into env-major buffers (sample (env, t) lives at row env*T + t)
+__global__ void k_onpolicy_record_pre(const float* __restrict__ obs, const float* __restrict__ act, int n_env, int o, int a, int t,
+                                      int T, float* __restrict__ obs_buf, float* __restrict__ act_buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, w = o + a;
+  if (i >= n_env * w) return;
+  const int env = i / w, j = i - env * w;
+  const size_t row = (size_t)env * T + t;
+  if (j < o) obs_buf[row * o + j] = obs[(size_t)env * o + j];
+  else act_buf[row * a + (j - o)] = act[(size_t)env * a + (j - o)];
+}
+__global__ void k_onpolicy_record_post(const float* __restrict__ rew, const int* __restrict__ ep_len, int n_env, int t, int T,
+                                       float* __restrict__ rew_buf, uint8_t* __restrict__ ends_buf) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n_env) return;
+  const size_t row = (size_t)env * T + t;
+  rew_buf[row] = rew[env];
+  ends_buf[row] = ep_len[env] == 0 ? 1 : 0;   // the env was just reset: terminal or time limit
+}
+
+// PPO's sampling phase (torch_rl_algorithm.py:30-32 over base_algorithm.py:183-277) for ALL envs on the device: T vec steps
+// with the Gaussian policy of `ppo`; env-major buffers obs[n_env*T,o] (what the policy saw: normalised when norm_obs),
+// act[n_env*T,a] (un-clipped policy output; the env clips), rew[n_env*T], ends[n_env*T] (1 = episode ended after this
+// sample).  last_values[n_env] (nullable) = V(observation after the last step) for bootstrapping unfinished segments.
+extern "C" int ilsx_ppo_rollout(ilsx_ppo* ppo, ilsx_vecenv* e, int T, int max_path_length, float* obs, float* act, float* rew,
+                                uint8_t* ends, float* last_values) {
+  if (!ppo || !e || !obs || !act || !rew || !ends || T < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_rollout: bad argument");
+  ilsx_ctx* ctx = e->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = e->n_env, w = e->o + e->a;
+  for (int t = 0; t < T; ++t) {
+    const unsigned long long step = ++e->step_ctr;
+    ILSX_TRY(ilsx_ppo_policy_act(ppo, e->policy_obs(), n, 0, nullptr, e->act, nullptr));
+    hipLaunchKernelGGL(k_onpolicy_record_pre, dim3((n * w + 255) / 256), dim3(256), 0, ctx->stream, e->policy_obs(), (const float*)e->act,
+                       n, e->o, e->a, t, T, obs, act);
+    EnvStepArgs A;
+    memset(&A, 0, sizeof A);
+    A.m = e->dm; A.qpos = e->qpos; A.qvel = e->qvel; A.n_env = n;
+    A.ids = nullptr; A.n_ids = n; A.act = e->act;
+    A.obs = e->nobs; A.rew = e->rew; A.done = e->done;
+    A.obs_cur = e->obs_cur; A.auto_reset = 1; A.max_path_length = max_path_length;
+    A.ep_len = e->ep_len; A.ep_ret = e->ep_ret; A.stats = e->stats;
+    A.seed = e->seed; A.stream = e->rng_stream; A.step = step;
+    ILSX_TRY(launch_env_step(e, A));
+    hipLaunchKernelGGL(k_onpolicy_record_post, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float*)e->rew,
+                       (const int*)e->ep_len, n, t, T, rew, ends);
+    HIPCHK(hipGetLastError());
+    ILSX_TRY(env_after_step_norm(e));
+  }
+  if (last_values) ILSX_TRY(ilsx_ppo_values(ppo, e->policy_obs(), n, last_values));
   return ILSX_OK;
 }
 

@@ -33,8 +33,9 @@ struct PpoScalars {
 // out = 16 B per sample.  Differences to the sequential fp32 order are a few ulp (tests: rtol 1e-5 on returns).
 #define GAE_KEEP 16
 __global__ __launch_bounds__(256) void k_ppo_gae(const float* __restrict__ values, const float* __restrict__ rewards,
-                                                 const int* __restrict__ offs, int n_traj, float reward_scale, float gamma,
-                                                 float tau, float* __restrict__ returns, float* __restrict__ adv) {
+                                                 const int* __restrict__ offs, const float* __restrict__ boot, int n_traj,
+                                                 float reward_scale, float gamma, float tau, float* __restrict__ returns,
+                                                 float* __restrict__ adv) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_traj) return;   // wave-uniform
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_ppo_gae(const float* __restrict__ value
   float keep[GAE_KEEP];
 #pragma unroll
   for (int k = 0; k < GAE_KEEP; ++k) keep[k] = 0.0f;
-  float carry_v = 0.0f, carry_a = 0.0f, sum = 0.0f;
+  float carry_v = boot ? boot[t] : 0.0f, carry_a = 0.0f, sum = 0.0f;   // V after the last sample: 0 = the reference (ppo.py:74)
   for (int ch = nchunk - 1, k = 0; ch >= 0; --ch, ++k) {
     const int i0 = b + 64 * ch, idx = i0 + lane;
     const int last = min(63, e - 1 - i0);
@@ -93,7 +94,10 @@ __global__ __launch_bounds__(256) void k_ppo_gae(const float* __restrict__ value
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float sd = (float)sqrt(ss / (double)(T - 1));   // torch.std(): unbiased; T == 1 -> nan like the reference
+  float sd = (float)sqrt(ss / (double)(T - 1));   // torch.std(): unbiased; T == 1 -> nan like the reference
+  // segment mode (bootstrap values given; not a reference code path): a rollout boundary can leave a one-sample segment,
+  // whose standardised advantage is undefined -> 0 (no policy gradient from it) instead of poisoning the minibatch
+  if (boot && T == 1) sd = INFINITY;
   for (int ch = nchunk - 1, k = 0; ch >= 0; --ch, ++k) {
     const int idx = b + 64 * ch + lane;
     float a = 0.0f;
@@ -326,8 +330,15 @@ static int ppo_full_forward(ilsx_ppo* p, const float* obs, const float* act, int
   return launch_fwd(p->ctx, A, p->cfg.hidden, ILSX_ACT_TANH, p->Lp.KP);
 }
 
+extern "C" int ilsx_ppo_values(ilsx_ppo* p, const float* obs, int n, float* values) {
+  if (!p || !obs || !values || n < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_values: bad argument");
+  HIPCHK(hipSetDevice(p->ctx->device));
+  return ppo_full_forward(p, obs, nullptr, n, true, values);
+}
+
 extern "C" int ilsx_ppo_gae(ilsx_ppo* p, const float* obs, const float* act, const float* rew, const int32_t* traj_offsets_host,
-                            int n_traj, float* returns_out, float* adv_out, float* values_out, float* logp_out) {
+                            int n_traj, const float* bootstrap_values, float* returns_out, float* adv_out, float* values_out,
+                            float* logp_out) {
   if (!p || !obs || !act || !rew || !traj_offsets_host || n_traj < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_gae: bad argument");
   const int N = traj_offsets_host[n_traj];
   if (traj_offsets_host[0] != 0 || N < 1 || N > p->cfg.max_samples) ILSX_FAIL(ILSX_ERR_ARG, "trajectory offsets must span 1..max_samples rows");
@@ -337,7 +348,7 @@ extern "C" int ilsx_ppo_gae(ilsx_ppo* p, const float* obs, const float* act, con
   ILSX_TRY(ppo_full_forward(p, obs, act, N, true, p->values));
   {
     ProfScope ps(p->ctx, ILSX_K_PPO_GAE);
-    hipLaunchKernelGGL(k_ppo_gae, dim3((n_traj + 3) / 4), dim3(256), 0, st, p->values, rew, p->offs, n_traj, p->cfg.reward_scale,
+    hipLaunchKernelGGL(k_ppo_gae, dim3((n_traj + 3) / 4), dim3(256), 0, st, p->values, rew, p->offs, bootstrap_values, n_traj, p->cfg.reward_scale,
                        p->cfg.discount, p->cfg.gae_tau, p->returns, p->adv);
   }
   HIPCHK(hipGetLastError());
@@ -427,8 +438,9 @@ static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const 
 // PPO.train_step (ppo.py:102-170).  perms_host: update_epoch x N int32 permutations (the reference draws
 // torch.randperm per epoch), or NULL = drawn here from a host Mersenne twister seeded by the ctx seed.
 extern "C" int ilsx_ppo_train(ilsx_ppo* p, const float* obs, const float* act, const float* rew,
-                              const int32_t* traj_offsets_host, int n_traj, const int32_t* perms_host) {
-  ILSX_TRY(ilsx_ppo_gae(p, obs, act, rew, traj_offsets_host, n_traj, nullptr, nullptr, nullptr, nullptr));
+                              const int32_t* traj_offsets_host, int n_traj, const float* bootstrap_values,
+                              const int32_t* perms_host) {
+  ILSX_TRY(ilsx_ppo_gae(p, obs, act, rew, traj_offsets_host, n_traj, bootstrap_values, nullptr, nullptr, nullptr, nullptr));
   const int N = p->N, mb = p->cfg.mini_batch_size;
   static unsigned long long shuffles = 0;
   int half_bits = 1;

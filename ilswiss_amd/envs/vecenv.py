@@ -50,8 +50,32 @@ def model_struct(m):
     return s
 
 
+class DeviceObsRms:
+    """`env.obs_rms` (RunningMeanStd, normalizer.py:128-152) living on the device inside a HipVectorEnv: float64
+    mean / var / count, read back on attribute access.  Passing one env's obs_rms to another env's constructor
+    (ppo_exp_script.py:68-75) copies the statistics at every `sync_from()`."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def _get(self):
+        e = self.env
+        m, v, c = np.empty(e.obs_dim), np.empty(e.obs_dim), C.c_double()
+        _lib.check(e.ctx.lib.ilsx_vecenv_get_obs_rms(e.h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.byref(c)))
+        return m, v, c.value
+
+    mean = property(lambda self: self._get()[0])
+    var = property(lambda self: self._get()[1])
+    count = property(lambda self: self._get()[2])
+
+    def set(self, mean, var, count):
+        e = self.env
+        m, v = np.ascontiguousarray(mean, np.float64), np.ascontiguousarray(var, np.float64)
+        _lib.check(e.ctx.lib.ilsx_vecenv_set_obs_rms(e.h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), float(count)))
+
+
 class HipVectorEnv:
-    def __init__(self, env_name, env_num, seed=0, ctx=None, model=None):
+    def __init__(self, env_name, env_num, seed=0, ctx=None, model=None, norm_obs=False, obs_rms=None, update_obs_rms=True):
         self.ctx = ctx or get_context()
         self.model = model or MODELS[env_name]()
         self.env_num = int(env_num)
@@ -65,7 +89,31 @@ class HipVectorEnv:
         ac = Box(-np.ones(self.act_dim), np.ones(self.act_dim))
         self.observation_space, self.action_space = [ob] * self.env_num, [ac] * self.env_num  # vecenvs.py:118-140
         self.single_observation_space, self.single_action_space = ob, ac
-        self.norm_obs, self.obs_rms, self.update_obs_rms = False, None, False
+        # vecenvs.py:104-113
+        self.norm_obs, self.update_obs_rms = bool(norm_obs), bool(update_obs_rms) and bool(norm_obs)
+        self.obs_rms = DeviceObsRms(self) if norm_obs else None
+        self._shared_rms = obs_rms if norm_obs else None    # another env's statistics (eval env of ppo_exp_script.py:68-75)
+        if norm_obs:
+            if self._shared_rms is not None:
+                self.sync_obs_rms()
+            _lib.check(self.ctx.lib.ilsx_vecenv_obs_norm(self.h, 1, int(self.update_obs_rms)))
+
+    def sync_obs_rms(self):
+        """Pull the statistics of the env this one shares its obs_rms with (same object in the reference)."""
+        if self._shared_rms is not None:
+            self.obs_rms.set(*self._shared_rms._get())
+
+    def normalize_obs(self, obs):  # vecenvs.py:299-327
+        if not self.norm_obs:
+            return obs
+        m, v, _ = self.obs_rms._get()
+        return np.clip((obs - m) / np.sqrt(v + np.finfo(np.float32).eps.item()), -10.0, 10.0)
+
+    def unnormalize_obs(self, obs):  # vecenvs.py:329-349
+        if not self.norm_obs:
+            return obs
+        m, v, _ = self.obs_rms._get()
+        return obs * np.sqrt(v + np.finfo(np.float32).eps.item()) + m
 
     def __len__(self):
         return self.env_num
@@ -113,10 +161,11 @@ class HipVectorEnv:
         _lib.check(self.ctx.lib.ilsx_vecenv_set_state(self.h, q.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
 
     # ---- fused device loop (BaseAlgorithm's sampling iteration, base_algorithm.py:183-277)
-    def rollout_step(self, policy=None, replay=None, max_path_length=1000, random_actions=False, deterministic=False):
+    def rollout_step(self, policy=None, replay=None, max_path_length=1000, random_actions=False, deterministic=False,
+                     no_terminal=False):
         _lib.check(self.ctx.lib.ilsx_rollout_step(self.h, policy.h if policy is not None else None,
                                                   replay.h if replay is not None else None, int(max_path_length),
-                                                  int(bool(random_actions)), int(bool(deterministic))))
+                                                  int(bool(random_actions)), int(bool(deterministic)), int(bool(no_terminal))))
 
     def rollout_stats(self, reset=True):
         e, r = C.c_double(), C.c_double()
@@ -129,8 +178,11 @@ class HipVectorEnv:
             self.h = None
 
 
-def get_envs(env_specs, env_wrapper=None, wrapper_kwargs=None, ctx=None, **kwargs):
+def get_envs(env_specs, env_wrapper=None, wrapper_kwargs=None, ctx=None, norm_obs=False, obs_rms=None, update_obs_rms=True,
+             **kwargs):
     """rlkit/envs/__init__.py:72-132: env_specs{env_name, env_num, training_env_seed, ...} -> vec env.
-    NormalizedBoxEnv (the only wrapper on the hot path) is folded into the stepper."""
+    NormalizedBoxEnv (the only wrapper on the hot path) is folded into the stepper; norm_obs / obs_rms /
+    update_obs_rms are BaseVectorEnv's (vecenvs.py:84-113)."""
     return HipVectorEnv(env_specs["env_name"], env_specs.get("env_num", 1),
-                        seed=env_specs.get("training_env_seed", env_specs.get("seed", 0)), ctx=ctx)
+                        seed=env_specs.get("training_env_seed", env_specs.get("seed", 0)), ctx=ctx, norm_obs=norm_obs,
+                        obs_rms=obs_rms, update_obs_rms=update_obs_rms)

@@ -104,7 +104,7 @@ class PPO(Trainer):
         keep, (po, pa, pr), offs = self._upload(trajs)
         N = int(offs[-1])
         outs = [self.ctx.empty((N,)) for _ in range(4)]
-        _lib.check(self.ctx.lib.ilsx_ppo_gae(self.h, po, pa, pr, offs.ctypes.data_as(C.c_void_p), len(offs) - 1,
+        _lib.check(self.ctx.lib.ilsx_ppo_gae(self.h, po, pa, pr, offs.ctypes.data_as(C.c_void_p), len(offs) - 1, None,
                                              *[x.ptr for x in outs]))
         return tuple(x.numpy().reshape(N, 1) for x in outs)
 
@@ -117,9 +117,40 @@ class PPO(Trainer):
             perms = np.ascontiguousarray(perms, np.int32)
             assert perms.shape == (self.update_epoch, int(offs[-1]))
             pp = perms.ctypes.data_as(C.c_void_p)
-        _lib.check(self.ctx.lib.ilsx_ppo_train(self.h, po, pa, pr, offs.ctypes.data_as(C.c_void_p), len(offs) - 1, pp))
+        _lib.check(self.ctx.lib.ilsx_ppo_train(self.h, po, pa, pr, offs.ctypes.data_as(C.c_void_p), len(offs) - 1, None, pp))
         if self.eval_statistics is None:
             self.eval_statistics = OrderedDict()
+
+    def train_from_rollout(self, env, horizon, max_path_length=1000, bootstrap=True):
+        """One on-policy iteration on the device: `horizon` vec steps of all envs (ilsx_ppo_rollout), then train_step on
+        the collected segments.  A segment is one env's samples up to an episode end or the end of the rollout.
+        bootstrap=False is the reference: V after a segment's last sample is 0 everywhere (ppo.py:74; it only ever sees
+        whole episodes).  bootstrap=True uses vf(next observation) for segments cut by the end of the rollout
+        (fixed 8192 x 128 rollouts need it)."""
+        ctx, n, T = self.ctx, len(env), int(horizon)
+        N = n * T
+        if N > self.max_samples:
+            raise ValueError(f"{n} envs x {T} steps exceed max_samples={self.max_samples}")
+        if getattr(self, "_roll", None) is None or self._roll[0] != (n, T):
+            self._roll = ((n, T), ctx.empty((N, self.o)), ctx.empty((N, self.a)), ctx.empty((N,)), ctx.empty((N,), np.uint8),
+                          ctx.empty((n,)))
+        _, obs, act, rew, ends, lastv = self._roll
+        _lib.check(ctx.lib.ilsx_ppo_rollout(self.h, env.h, T, int(max_path_length), obs.ptr, act.ptr, rew.ptr, ends.ptr, lastv.ptr))
+        e = ends.numpy().reshape(n, T).astype(bool)
+        cut = e.copy()
+        cut[:, -1] = True                                   # the rollout's end closes every env's last segment
+        offs = np.concatenate([[0], np.flatnonzero(cut.ravel()) + 1]).astype(np.int32)
+        b = np.zeros(offs.size - 1, np.float32)   # always given: also arms the one-sample-segment guard of k_ppo_gae
+        if bootstrap:
+            open_env = np.flatnonzero(~e[:, -1])            # last segment still running: bootstrap with V(s_T)
+            seg_of_last = np.searchsorted(offs, (open_env + 1) * T, side="left") - 1
+            b[seg_of_last] = lastv.numpy()[open_env]
+        boot = ctx.from_numpy(b)
+        _lib.check(ctx.lib.ilsx_ppo_train(self.h, obs.ptr, act.ptr, rew.ptr, offs.ctypes.data_as(C.c_void_p), offs.size - 1,
+                                          boot.ptr, None))
+        if self.eval_statistics is None:
+            self.eval_statistics = OrderedDict([("PPO Segments", float(offs.size - 1)), ("PPO Samples", float(N))])
+        return N
 
     def policy_act(self, obs, deterministic=False, eps=None):
         obs = np.ascontiguousarray(obs, np.float32)

@@ -299,13 +299,18 @@ int ilsx_ppo_num_params(const ilsx_ppo* ppo, int which, size_t* out);
 int ilsx_ppo_set_params(ilsx_ppo* ppo, int which, const float* src_host, size_t n);
 int ilsx_ppo_get_params(ilsx_ppo* ppo, int which, float* dst_host, size_t n);
 /* calc_adv + the fixed log-probs over N = traj_offsets_host[n_traj] device rows obs[N,o] act[N,a] rew[N]; trajectory
- * t owns rows [traj_offsets_host[t], traj_offsets_host[t+1]).  Device outputs [N], all nullable. */
+ * t owns rows [traj_offsets_host[t], traj_offsets_host[t+1]).  bootstrap_values (device [n_traj], nullable): V of the
+ * observation that follows each trajectory's last sample; NULL = 0 everywhere = the reference, which also zeroes it at
+ * time-limit ends (ppo.py:74).  Device outputs [N], all nullable. */
 int ilsx_ppo_gae(ilsx_ppo* ppo, const float* obs, const float* act, const float* rew, const int32_t* traj_offsets_host,
-                 int n_traj, float* returns, float* advantages, float* values, float* fixed_log_probs);
+                 int n_traj, const float* bootstrap_values, float* returns, float* advantages, float* values,
+                 float* fixed_log_probs);
+/* values[n] = vf(obs[n,o]) (device) */
+int ilsx_ppo_values(ilsx_ppo* ppo, const float* obs, int n, float* values);
 /* one PPO.train_step.  perms_host [update_epoch][N] int32 row permutations (torch.randperm in the reference,
  * ppo.py:116) or NULL = drawn by the library. */
 int ilsx_ppo_train(ilsx_ppo* ppo, const float* obs, const float* act, const float* rew, const int32_t* traj_offsets_host,
-                   int n_traj, const int32_t* perms_host);
+                   int n_traj, const float* bootstrap_values, const int32_t* perms_host);
 /* debug: one library-drawn shuffle of [0,n) (keyed Feistel bijection; the NULL-perms path of ilsx_ppo_train) -> HOST */
 int ilsx_ppo_debug_perm(ilsx_ppo* ppo, int n, uint32_t key, int32_t* perm_host);
 /* get_actions (policies.py:392-417): act[n,a] = mean + exp(log_std)*eps (eps device [n,a] or NULL = Philox), or the
@@ -351,12 +356,26 @@ int ilsx_vecenv_step(ilsx_vecenv* env, const float* act, const int32_t* ids_host
 /* simulator state, HOST float64 [n_env, n_dof] (tests / snapshots) */
 int ilsx_vecenv_get_state(ilsx_vecenv* env, double* qpos_host, double* qvel_host);
 int ilsx_vecenv_set_state(ilsx_vecenv* env, const double* qpos_host, const double* qvel_host);
-int ilsx_vecenv_cur_obs(ilsx_vecenv* env, float** dev_ptr);  /* [n_env,o] current observations (device) */
+int ilsx_vecenv_cur_obs(ilsx_vecenv* env, float** dev_ptr);  /* [n_env,o] current (normalised if norm_obs) observations (device) */
+/* Running observation statistics of BaseVectorEnv (vecenvs.py:104-113,299-327; RunningMeanStd normalizer.py:128-152):
+ * norm_obs: reset/step/cur_obs/rollouts return clip((obs-mean)/sqrt(var+eps), +-10); update_obs_rms: every batch of
+ * observations returned by reset/step updates (mean, var, count) first.  Statistics are float64; get/set use HOST arrays
+ * [obs_dim] (an eval env shares the training env's statistics by set after get, ppo_exp_script.py:68-75). */
+int ilsx_vecenv_obs_norm(ilsx_vecenv* env, int norm_obs, int update_obs_rms);
+int ilsx_vecenv_get_obs_rms(ilsx_vecenv* env, double* mean_host, double* var_host, double* count);
+int ilsx_vecenv_set_obs_rms(ilsx_vecenv* env, const double* mean_host, const double* var_host, double count);
+/* PPO's sampling phase for ALL envs on the device (torch_rl_algorithm.py:30-32 over base_algorithm.py:183-277): T vec
+ * steps with ppo's Gaussian policy, auto-reset on done / max_path_length, into env-major device buffers (sample (env,t) at
+ * row env*T+t): obs[n_env*T,o] as the policy saw it, act[n_env*T,a], rew[n_env*T], ends[n_env*T] (1 = the episode ended
+ * after this sample); last_values[n_env] (nullable) = vf(observation after the last step). */
+int ilsx_ppo_rollout(ilsx_ppo* ppo, ilsx_vecenv* env, int T, int max_path_length, float* obs, float* act, float* rew,
+                     uint8_t* ends, float* last_values);
 /* One iteration of BaseAlgorithm's sampling loop for ALL envs on the device (base_algorithm.py:183-277):
  * actions (policy, or env.action_space.sample() when random_actions) -> physics -> one transition record per
- * env written straight into the replay ring (nullable) -> auto-reset on done or max_path_length. */
+ * env written straight into the replay ring (nullable) -> auto-reset on done or max_path_length.  no_terminal: the
+ * stored terminal flag is forced to 0 (base_algorithm.py:195-196,208-210; the adv-IRL configs). */
 int ilsx_rollout_step(ilsx_vecenv* env, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
-                      int deterministic);
+                      int deterministic, int no_terminal);
 /* finished episodes and the sum of their returns since the last reset of the counters */
 int ilsx_rollout_stats(ilsx_vecenv* env, double* episodes, double* return_sum, int reset);
 

@@ -46,6 +46,6 @@ act = ctx.from_numpy(rng.normal(0, 0.5, (N, a)).astype(np.float32))
 rew = ctx.from_numpy(rng.normal(1, 1, (N,)).astype(np.float32))
 offs = (np.arange(n_env + 1) * T).astype(np.int32)
 for _ in range(3):
-    _lib.check(ctx.lib.ilsx_ppo_gae(ppo.h, obs.ptr, act.ptr, rew.ptr, offs.ctypes.data_as(C.c_void_p), n_env, None, None, None, None))
+    _lib.check(ctx.lib.ilsx_ppo_gae(ppo.h, obs.ptr, act.ptr, rew.ptr, offs.ctypes.data_as(C.c_void_p), n_env, None, None, None, None, None))
 ctx.sync()
 print("pmc workload done")
