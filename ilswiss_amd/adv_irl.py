@@ -149,11 +149,47 @@ class AdvIRLTrainer:
                                               "Disc Rew Max": float(r.max()), "Disc Rew Min": float(r.min())})
 
     def train(self, n_calls=1):
-        for _ in range(n_calls * self.loops):
-            for _ in range(self.k):
-                self._do_reward_training()
-            for _ in range(self.m):
-                self._do_policy_training()
+        """n_calls x `num_update_loops_per_train_call` loop iterations in ONE library call (ilsx_advirl_train)."""
+        want_d, tr = self.disc_eval_statistics is None, self.policy_trainer
+        want_p = tr.eval_statistics is None
+        rs = (C.c_float * 4)()
+        _lib.check(self.ctx.lib.ilsx_advirl_train(
+            self.disc.h, tr.h, self.expert_rb.h, self.rb.h, int(n_calls * self.loops), int(self.k), int(self.m), self.Bd, self.Bp,
+            _MODES[self.mode], int(self.rew_clip_min is not None), float(self.rew_clip_min or 0.0),
+            int(self.rew_clip_max is not None), float(self.rew_clip_max or 0.0),
+            C.byref(self.disc._stats) if want_d else None, C.byref(tr._stats) if want_p else None, rs if want_d else None))
+        if want_d:
+            s = self.disc._stats
+            self.disc_eval_statistics = OrderedDict([("Disc CE Loss", s.ce_loss), ("Disc Acc", s.accuracy)])
+            if self.disc.use_grad_pen:
+                self.disc_eval_statistics.update({"Grad Pen": s.grad_pen, "Grad Pen W": self.disc.grad_pen_weight})
+            self.disc_eval_statistics.update({"Disc Rew Mean": rs[0], "Disc Rew Std": rs[1], "Disc Rew Max": rs[2],
+                                              "Disc Rew Min": rs[3]})
+        if want_p:
+            tr._fill_stats()
+
+    # ---- what DeviceRLAlgorithm asks of a trainer
+    def train_from_replay(self, replay_buffer, n_loops, batch_size):
+        """One train call of AdvIRL (adv_irl.py:126-131): n_loops = num_update_loops_per_train_call."""
+        self.rb, loops = replay_buffer, self.loops
+        self.loops = int(n_loops)
+        try:
+            self.train(1)
+        finally:
+            self.loops = loops
+
+    @property
+    def policy(self):
+        return self.policy_trainer.policy
+
+    @property
+    def networks(self):
+        return self.policy_trainer.networks + [self.disc]
+
+    def get_snapshot(self):  # adv_irl.py:316-326, as plain arrays
+        snap = dict(self.policy_trainer.get_snapshot())
+        snap["disc"] = self.disc.get_flat_params()
+        return snap
 
     def get_eval_statistics(self):
         st = OrderedDict()

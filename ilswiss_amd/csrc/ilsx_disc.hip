@@ -307,10 +307,12 @@ __global__ void k_disc_reward(PartVal raw, int n, float clamp, int mode, int has
 }
 
 // ------------------------------------------------------------------------------------------------ host
+struct AdvIrlWs { float *eo, *ea, *er, *ed, *en, *po, *pa, *pr, *pd, *pn; int B; };
 struct ilsx_disc {
   ilsx_ctx* ctx = nullptr;
   ilsx_disc_cfg cfg;
   NetLayout L;
+  AdvIrlWs airl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};  // ilsx_advirl_train batches
   int cs = 1, D = 0, o = 0, a = 0;
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
   DiscScalars* scal = nullptr;
@@ -493,5 +495,55 @@ extern "C" int ilsx_disc_reward(ilsx_disc* d, const float* obs, const float* act
   hipLaunchKernelGGL(k_disc_reward, dim3((n + 255) / 256), dim3(256), 0, d->ctx->stream, d->pv(), n, d->cfg.clamp_magnitude,
                      mode, has_min, rmin, has_max, rmax, rew, logits);
   HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdvIRL._do_training (adv_irl.py:126-131): `loops` x { k discriminator steps ; m policy steps whose rewards are
+// relabelled by the discriminator (:256-301) }, with every batch drawn on the device from the two HBM replay rings
+// (get_batch, :106-113).  One C call per train call instead of ~6 per loop iteration from the host language.
+extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* expert_rb, ilsx_replay* policy_rb, int loops,
+                                 int disc_updates, int policy_updates, int disc_batch, int policy_batch, int mode, int has_min,
+                                 float rew_clip_min, int has_max, float rew_clip_max, ilsx_disc_stats* disc_stats,
+                                 ilsx_sac_stats* sac_stats, float* rew_stats4) {
+  if (!d || !sac || !expert_rb || !policy_rb || loops < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_advirl_train: bad argument");
+  const int B = std::max(disc_batch, policy_batch);
+  if (disc_batch < 1 || disc_batch > d->cfg.max_batch || policy_batch < 1) ILSX_FAIL(ILSX_ERR_ARG, "batch sizes out of range");
+  HIPCHK(hipSetDevice(d->ctx->device));
+  AdvIrlWs& ws = d->airl;
+  const int o = d->cfg.obs_dim, a = d->cfg.act_dim;
+  if (ws.B < B) {
+    float** ps[] = {&ws.eo, &ws.ea, &ws.er, &ws.ed, &ws.en, &ws.po, &ws.pa, &ws.pr, &ws.pd, &ws.pn};
+    const size_t w[] = {(size_t)o, (size_t)a, 1, 1, (size_t)o, (size_t)o, (size_t)a, 1, 1, (size_t)o};
+    for (int i = 0; i < 10; ++i) ILSX_TRY(ctx_alloc(d->ctx, (size_t)B * w[i] * 4, (void**)ps[i], true));
+    ws.B = B;
+  }
+  bool first_disc = true, first_pol = true;
+  for (int it = 0; it < loops; ++it) {
+    for (int k = 0; k < disc_updates; ++k) {   // adv_irl.py:133-216
+      ILSX_TRY(ilsx_replay_sample(expert_rb, disc_batch, nullptr, ws.eo, ws.ea, ws.er, ws.ed, ws.en, nullptr));
+      ILSX_TRY(ilsx_replay_sample(policy_rb, disc_batch, nullptr, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, nullptr));
+      ILSX_TRY(ilsx_disc_train_step(d, ws.eo, ws.ea, ws.po, ws.pa, disc_batch, nullptr, first_disc ? disc_stats : nullptr));
+      first_disc = false;
+    }
+    for (int m = 0; m < policy_updates; ++m) {   // adv_irl.py:238-314
+      ILSX_TRY(ilsx_replay_sample(policy_rb, policy_batch, nullptr, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, nullptr));
+      ILSX_TRY(ilsx_disc_reward(d, ws.po, ws.pa, policy_batch, mode, has_min, rew_clip_min, has_max, rew_clip_max, ws.pr, nullptr));
+      const bool want = first_pol && sac_stats;
+      ILSX_TRY(ilsx_sac_train_step(sac, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, policy_batch, nullptr, nullptr, want ? sac_stats : nullptr));
+      if (first_pol && rew_stats4) {   // "Disc Rew Mean/Std/Max/Min" of the first relabelled batch (adv_irl.py:303-314)
+        std::vector<float> r(policy_batch);
+        HIPCHK(hipMemcpyAsync(r.data(), ws.pr, (size_t)policy_batch * 4, hipMemcpyDeviceToHost, d->ctx->stream));
+        HIPCHK(hipStreamSynchronize(d->ctx->stream));
+        double s = 0, ss = 0;
+        float mx = r[0], mn = r[0];
+        for (float v : r) { s += v; mx = std::max(mx, v); mn = std::min(mn, v); }
+        const double mean = s / policy_batch;
+        for (float v : r) ss += (v - mean) * (v - mean);
+        rew_stats4[0] = (float)mean; rew_stats4[1] = (float)std::sqrt(ss / policy_batch); rew_stats4[2] = mx; rew_stats4[3] = mn;
+      }
+      first_pol = false;
+    }
+  }
   return ILSX_OK;
 }

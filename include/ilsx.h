@@ -230,6 +230,15 @@ int ilsx_disc_train_step(ilsx_disc* disc, const float* exp_obs, const float* exp
 int ilsx_disc_reward(ilsx_disc* disc, const float* obs, const float* act, int n, int mode, int has_min, float rew_clip_min,
                      int has_max, float rew_clip_max, float* rew, float* logits);
 
+/* AdvIRL._do_training (adv_irl.py:126-131) for one train call: `loops` x { disc_updates discriminator steps ;
+ * policy_updates SAC steps on rewards relabelled by the discriminator (mode / clips as ilsx_disc_reward) }, every batch
+ * drawn on the device from the expert / policy replay rings (get_batch, :106-113).  Statistics (all nullable, host) are
+ * those of the first discriminator / policy batch of the call; rew_stats4 = {Mean, Std, Max, Min} of its rewards. */
+int ilsx_advirl_train(ilsx_disc* disc, ilsx_sac* policy_trainer, ilsx_replay* expert_rb, ilsx_replay* policy_rb, int loops,
+                      int disc_updates, int policy_updates, int disc_batch, int policy_batch, int mode, int has_min,
+                      float rew_clip_min, int has_max, float rew_clip_max, ilsx_disc_stats* disc_stats,
+                      ilsx_sac_stats* sac_stats, float* rew_stats4);
+
 /* ---------------------------------------------------------------- TD3
  * Replaces rlkit/torch/algorithms/td3/td3.py:21-70 (ctor), :72-124 (train_step), :180-183 (soft updates).  cfg fields ==
  * the YAML keys of exp_specs/td3/td3_hopper.yaml:12-13,39-45 (policy_noise / policy_noise_clip are the noise of the

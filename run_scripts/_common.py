@@ -14,17 +14,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ilswiss_amd as ia  # noqa: E402
 from ilswiss_amd.algorithm import setup_log_dir  # noqa: E402
 from ilswiss_amd.envs.vecenv import get_envs  # noqa: E402
+from ilswiss_amd.launcher import variants  # noqa: E402
 
 
 def flatten_spec(spec):
+    """A flat variant passes through; a full exp_spec yields its first grid point."""
     if "constants" not in spec:
         return spec
-    v = dict(spec["constants"])
-    for k, vals in (spec.get("variables") or {}).items():
-        v[k] = vals[0] if isinstance(vals, list) else vals
-    v.update(spec.get("meta_data") or {})
-    v.setdefault("exp_id", 0)
-    return v
+    return next(variants(spec))
 
 
 def make_envs(variant, ctx, **vec_kwargs):

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Adversarial IRL (GAIL / AIRL / FAIRL / gail2) experiment script on the MI355X engine — same contract as the reference's
+run_scripts/adv_irl_exp_script.py:30-201: expert demonstrations are looked up in `demos_listing.yaml`
+(expert_name / expert_idx), a pickled `list[dict]` of trajectories with keys observations / actions / rewards /
+next_observations / terminals (what run_scripts/gen_expert_demos.py writes); `traj_num` of them are drawn with
+random.sample and loaded with `add_path` into the expert replay buffer; variant keys disc_* / policy_net_size /
+policy_num_hidden_layers / adv_irl_params / sac_params / env_specs."""
+import os
+import pickle
+import random
+
+import numpy as np
+import yaml
+from _common import ia, main, make_envs, start
+
+from ilswiss_amd.adv_irl import AdvIRLTrainer, MLPDisc
+from ilswiss_amd.algorithm import DeviceRLAlgorithm
+from ilswiss_amd.replay import EnvReplayBuffer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_demos(variant):
+    listing = variant.get("demos_listing", os.path.join(ROOT, "demos_listing.yaml"))
+    with open(listing) as f:
+        listings = yaml.safe_load(f)
+    path = listings[variant["expert_name"]]["file_paths"][variant["expert_idx"]]
+    if not os.path.isabs(path):
+        path = os.path.join(os.path.dirname(os.path.abspath(listing)), path)
+    with open(path, "rb") as f:
+        traj_list = pickle.load(f)
+    return random.sample(traj_list, variant["traj_num"])          # adv_irl_exp_script.py:51-53
+
+
+def experiment(variant, gpu=0, log_dir=None):
+    ctx = start(variant, gpu)
+    random.seed(int(variant.get("seed", 0)))
+    if variant.get("scale_env_with_demo_stats") or variant.get("minmax_env_with_demo_stats"):
+        raise NotImplementedError("ScaledEnv / MinmaxEnv wrappers are off in the hot-path config (gail_walker.yaml:20-21)")
+    traj_list = load_demos(variant)
+    training_env, eval_env, env = make_envs(variant, ctx)
+    obs_dim, action_dim = training_env.obs_dim, training_env.act_dim
+    p = dict(variant["adv_irl_params"])
+    if p.get("wrap_absorbing") or p.get("state_only"):
+        raise NotImplementedError("wrap_absorbing / state_only are off in the hot-path config (gail_walker.yaml:35,49)")
+    expert_rb = EnvReplayBuffer(p["replay_buffer_size"], env, random_seed=int(np.random.randint(10000)), ctx=ctx)
+    for tj in traj_list:                                           # adv_irl_exp_script.py:135-138
+        expert_rb.add_path(tj, absorbing=False, env=env)
+    hid = variant["policy_num_hidden_layers"] * [variant["policy_net_size"]]
+    qf1 = ia.FlattenMlp(hidden_sizes=hid, input_size=obs_dim + action_dim, output_size=1, ctx=ctx)
+    qf2 = ia.FlattenMlp(hidden_sizes=hid, input_size=obs_dim + action_dim, output_size=1, ctx=ctx)
+    policy = ia.ReparamTanhMultivariateGaussianPolicy(hidden_sizes=hid, obs_dim=obs_dim, action_dim=action_dim, ctx=ctx)
+    Bd, Bp = p.get("disc_optim_batch_size", 1024), p.get("policy_optim_batch_size", 1024)
+    disc = MLPDisc(obs_dim, action_dim, num_layer_blocks=variant["disc_num_blocks"], hid_dim=variant["disc_hid_dim"],
+                   hid_act=variant["disc_hid_act"], use_bn=variant["disc_use_bn"], clamp_magnitude=variant["disc_clamp_magnitude"],
+                   disc_lr=p.get("disc_lr", 1e-3), disc_momentum=p.get("disc_momentum", 0.0),
+                   use_grad_pen=p.get("use_grad_pen", True), grad_pen_weight=p.get("grad_pen_weight", 10.0), max_batch=Bd, ctx=ctx)
+    sac = ia.SoftActorCritic(policy=policy, qf1=qf1, qf2=qf2, env=env, max_batch=Bp, **variant["sac_params"])
+    trainer = AdvIRLTrainer(p["mode"], disc, sac, expert_rb, None, disc_optim_batch_size=Bd, policy_optim_batch_size=Bp,
+                            num_update_loops_per_train_call=p.get("num_update_loops_per_train_call", 1),
+                            num_disc_updates_per_loop_iter=p.get("num_disc_updates_per_loop_iter", 1),
+                            num_policy_updates_per_loop_iter=p.get("num_policy_updates_per_loop_iter", 1),
+                            rew_clip_min=p.get("rew_clip_min"), rew_clip_max=p.get("rew_clip_max"))
+    loop_keys = ("num_epochs", "num_steps_per_epoch", "num_steps_between_train_calls", "max_path_length", "min_steps_before_training",
+                 "eval_deterministic", "num_steps_per_eval", "replay_buffer_size", "no_terminal", "save_best", "freq_saving")
+    alg = {k: p[k] for k in loop_keys if k in p}
+    algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env, exploration_policy=policy,
+                                  log_dir=log_dir, num_train_steps_per_train_call=p.get("num_update_loops_per_train_call", 1),
+                                  batch_size=Bp, **alg)
+    algorithm.train()
+    return algorithm
+
+
+if __name__ == "__main__":
+    main(experiment, "adv_irl")

@@ -161,3 +161,50 @@ def test_ppo_learns_on_hip_hopper():
         rets.append(rs / max(ep, 1))
     ctx.close()
     assert np.isfinite(rets).all() and rets[-1] > 4.0 * rets[0] and rets[-1] > 80, rets
+
+
+def test_gail_run_script_with_generated_demos(tmp_path, ctx):
+    """Config 3 plumbing end to end: demonstrations in the reference's pickle format (gen_expert_demos) -> demos listing ->
+    adv_irl_exp_script with the gail_walker keys (no_terminal, gail2 rewards, WGAN-GP) for one tiny epoch."""
+    import pickle
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "run_scripts"))
+    import adv_irl_exp_script as script
+    import gen_expert_demos as gen
+    import ilswiss_amd as ia
+    from _common import flatten_spec
+    from ilswiss_amd.envs.vecenv import HipVectorEnv
+    env = HipVectorEnv("walker", 6, seed=3, ctx=ctx)
+    pol = ia.ReparamTanhMultivariateGaussianPolicy([64, 64], env.obs_dim, env.act_dim, ctx=ctx, seed=5)
+    demos = gen.generate(pol, env, 6, max_path_length=60)
+    assert len(demos) == 6 and demos[0]["observations"].shape[1] == 17 and demos[0]["rewards"].shape[1] == 1
+    for d in demos:   # wire format of adv_irl_exp_script.py:51-60
+        T = len(d["rewards"])
+        assert d["actions"].shape == (T, 6) and d["next_observations"].shape == (T, 17) and d["terminals"].shape == (T, 1)
+        np.testing.assert_array_equal(d["observations"][1:], d["next_observations"][:-1])
+    (tmp_path / "demos").mkdir()
+    with open(tmp_path / "demos" / "walker.pkl", "wb") as f:
+        pickle.dump(demos, f)
+    with open(tmp_path / "listing.yaml", "w") as f:
+        yaml.dump(dict(walker_sac=dict(description="test", file_paths=["./demos/walker.pkl"])), f)
+    v = flatten_spec(yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "gail", "gail_walker_hip.yaml"))))
+    v["demos_listing"] = str(tmp_path / "listing.yaml")
+    v["env_specs"].update(env_num=8, eval_env_num=4)
+    v["adv_irl_params"].update(num_epochs=1, num_steps_per_epoch=800, num_steps_between_train_calls=400, max_path_length=100,
+                               min_steps_before_training=200, num_steps_per_eval=100, replay_buffer_size=5000,
+                               num_update_loops_per_train_call=10, disc_optim_batch_size=64, policy_optim_batch_size=64, freq_saving=1)
+    alg = script.experiment(v, 0, str(tmp_path / "log"))
+    rows = list(csv.DictReader(open(tmp_path / "log" / "progress.csv")))
+    assert len(rows) == 2
+    for k in ("Disc CE Loss", "Disc Acc", "Grad Pen", "Grad Pen W", "Disc Rew Mean", "Disc Rew Max", "QF1 Loss", "Policy Loss",
+              "AverageReturn", "Test Returns Mean"):
+        assert k in rows[-1] and np.isfinite(float(rows[-1][k])), k
+    assert float(rows[-1]["Disc Rew Max"]) <= 0.0            # gail2: log D <= 0 (adv_irl.py:283-286)
+    assert float(rows[-1]["Grad Pen W"]) == 8.0
+    assert alg.trainer.expert_rb.num_steps_can_sample() <= sum(len(d["rewards"]) for d in demos)   # 4 of the 6 (traj_num)
+    # no_terminal: nothing stored in the policy buffer is flagged terminal (base_algorithm.py:195-196)
+    batch = alg.replay_buffer.random_batch(512)
+    assert batch["terminals"].sum() == 0
+    with open(tmp_path / "log" / "params.pkl", "rb") as f:
+        snap = pickle.load(f)
+    assert "disc" in snap and "policy" in snap
