@@ -34,6 +34,27 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix p
 PEAK_HBM_GBS = 8000.0
 
 
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_summary.json")
+PMC_NAMES = {0: ("k_mlp2_fwd_split", "k_mlp_fwd"), 1: ("k_mlp2_bwd_split", "k_mlp_bwd_dx"), 2: ("k_mlp_bwd_dw",),
+             6: ("k_replay_sample_many",)}
+
+
+def pmc_traffic(kid):
+    """HBM bytes per launch of profiling id `kid` from the committed rocprofv3 counter passes (tools/pmc_collect.sh ->
+    profiles/r01_d_pmc_summary.json): FETCH_SIZE x 1024 x 2 (gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE x
+    1024, each collected in its own --pmc pass over the same kernels at the same sizes.  None if the file is absent."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            d = json.load(f)
+    except OSError:
+        return None
+    for name in PMC_NAMES.get(kid, ()):
+        k = d.get(name)
+        if k and "hbm_read_bytes_corrected" in k and "hbm_write_bytes_raw" in k:
+            return k["hbm_read_bytes_corrected"] + k["hbm_write_bytes_raw"]
+    return None
+
+
 def flops_per_step():
     """ALGORITHMIC FLOPs of one SAC-alpha gradient step, split by kernel."""
     Wq, Wp = (O + A) * H + H * H + H, O * H + H * H + 2 * H * A
@@ -185,7 +206,7 @@ def main():
         avg_s = ms * 1e-3 / nl
         achieved = flops_per_launch / avg_s / 1e12
         roofline = dict(bound="mfma", kernel=name, achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_us=avg_s * 1e6,
+                        frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=pmc_traffic(dom), avg_launch_us=avg_s * 1e6,
                         algorithmic_flop_per_launch=flops_per_launch,
                         kernel_ms_per_grad_step={prof[k][0]: prof[k][2] / 200.0 for k in prof if k not in (5, 9)})
         # ---- HBM-bound kernel: replay sample (4096 batches x 256 rows per launch)
@@ -204,7 +225,7 @@ def main():
         alg_bytes = 2.0 * nb * B * (2 * O + A + 2) * 4
         gbs = alg_bytes / (ms.value * 1e-3 / nl.value) / 1e9
         roofline_replay = dict(bound="hbm", kernel="k_replay_sample_many", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
-                               frac=gbs / PEAK_HBM_GBS, traffic=None, avg_launch_us=ms.value * 1e3 / nl.value,
+                               frac=gbs / PEAK_HBM_GBS, traffic=pmc_traffic(6), avg_launch_us=ms.value * 1e3 / nl.value,
                                algorithmic_bytes_per_launch=alg_bytes)
         result = dict(
             metric="env-steps/s + SAC grad-steps/s, Hopper-v2 4096 envs", value=grad_total / dt, unit="grad-steps/s",

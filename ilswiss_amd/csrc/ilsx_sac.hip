@@ -26,7 +26,8 @@ struct SacWs {  // device workspace for B <= max_batch rows
   float *xq[2], *hq[2][ILSX_MAX_HID], *dq[2][ILSX_MAX_HID], *dhq[2];
   float *raw, *an, *logp, *epss, *q1n, *q2n, *ga[2];
   float *xp, *hp[ILSX_MAX_HID], *dp[ILSX_MAX_HID], *dhp;
-  float* ppart;  // policy head partials [cs][max_batch][2a] (column-split path)
+  float* ppart;  // policy head partials [cs][max_batch][2a] (column-split path): pi(s')
+  float* ppart2; //   and pi(s), whose trunk runs in the step's first launch
 };
 
 struct ilsx_sac {
@@ -187,6 +188,7 @@ static int sac_alloc_ws(ilsx_sac* s) {
   const size_t CS = (size_t)s->cs;
   ILSX_TRY(A(&w.a2, B * a)); ILSX_TRY(A(&w.logp2, B)); ILSX_TRY(A(&w.q1, CS * B)); ILSX_TRY(A(&w.q2, CS * B));
   ILSX_TRY(A(&w.tq1, CS * B)); ILSX_TRY(A(&w.tq2, CS * B)); ILSX_TRY(A(&w.ppart, CS * B * 2 * a));
+  ILSX_TRY(A(&w.ppart2, CS * B * 2 * a));
   for (int i = 0; i < 2; ++i) {
     ILSX_TRY(A(&w.xq[i], B * s->Lq.KP));
     for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) { ILSX_TRY(A(&w.hq[i][l], B * H)); ILSX_TRY(A(&w.dq[i][l], B * H)); }
@@ -296,7 +298,7 @@ static float sac_inv_B(const ilsx_sac* s) { return 1.0f / ((float)s->B * (float)
 // forward of the policy on `obs` (+ its tanh-Gaussian epilogue) as task `slot` of a forward launch; when the
 // column-split path is on, the epilogue runs in k_policy_finish right after the launch (sac_policy_finish).
 static void sac_policy_task(ilsx_sac* s, FwdTask& t, const float* obs, const float* eps, uint32_t stream, bool save,
-                            float* action, float* logp) {
+                            float* action, float* logp, float* part) {
   const SacWs& w = s->ws;
   t.net = net_view(s->Lp, s->base(W_PI));
   t.x0 = obs; t.d0 = s->o; t.s0 = s->o;
@@ -306,19 +308,20 @@ static void sac_policy_task(ilsx_sac* s, FwdTask& t, const float* obs, const flo
   }
   t.head = HEAD_TANH_SAMPLE; t.rng_stream = stream;
   if (s->cs > 1) {
-    t.part = w.ppart;
+    t.part = part;
   } else {
     t.eps = eps; t.action = action; t.logp = logp;
     if (save) { t.out = w.raw; t.eps_save = w.epss; }
   }
 }
 // the policy's tanh-Gaussian epilogue runs in the prologue of the launch that consumes its actions (column-split path)
-static void sac_policy_fin(ilsx_sac* s, FwdArgs& A, const float* eps, uint32_t stream, bool save, float* action, float* logp) {
+static void sac_policy_fin(ilsx_sac* s, FwdArgs& A, const float* eps, uint32_t stream, bool save, float* action, float* logp,
+                           const float* part) {
   if (s->cs == 1) return;
   const SacWs& w = s->ws;
   PolicyFinishArgs& P = A.fin;
   memset(&P, 0, sizeof P);
-  P.part = w.ppart; P.cs = s->cs; P.part_stride = s->cfg.max_batch; P.rows = s->B; P.a = s->a;
+  P.part = part; P.cs = s->cs; P.part_stride = s->cfg.max_batch; P.rows = s->B; P.a = s->a;
   P.head = HEAD_TANH_SAMPLE; P.rng_stream = stream; P.seed = s->ctx->seed; P.scal = s->scal;
   P.eps = eps; P.action = action; P.logp = logp;
   if (save) { P.raw = w.raw; P.eps_save = w.epss; }
@@ -339,11 +342,14 @@ static int sac_critic_backward(ilsx_sac* s) {
   const SacWs& w = s->ws;
   const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
   const float* eps1 = s->eps_explicit ? w.eps1 : nullptr;
-  {  // fwd: pi(s') with eps_next ; Q1(s,a) ; Q2(s,a)
+  const float* eps2 = s->eps_explicit ? w.eps2 : nullptr;
+  {  // fwd: pi(s') with eps_next ; Q1(s,a) ; Q2(s,a) ; pi(s) with eps_cur (its weights do not change before the actor
+     // phase reads it, so its trunk rides along here and one dependent launch disappears from the step)
     FwdArgs A;
     memset(&A, 0, sizeof A);
-    A.rows = B; A.ntasks = 3; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
-    sac_policy_task(s, A.t[0], w.s2, eps1, s->rng_stream, false, w.a2, w.logp2);
+    A.rows = B; A.ntasks = 4; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
+    sac_policy_task(s, A.t[0], w.s2, eps1, s->rng_stream, false, w.a2, w.logp2, w.ppart);
+    sac_policy_task(s, A.t[3], w.s, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
     sac_q_task(s, A.t[1], W_Q1, w.s, w.a, w.q1, true, true, 0);
     sac_q_task(s, A.t[2], W_Q2, w.s, w.a, w.q2, true, true, 1);
     if (s->gather_rb && cs > 1) {  // fused sample+index: rows are drawn from the ring inside this launch
@@ -355,6 +361,7 @@ static int sac_critic_backward(ilsx_sac* s) {
       A.t[0].g0_off = s->o + s->a + 2; A.t[0].publish = 2;               // pi reads next_obs
       A.t[1].g0_off = 0; A.t[1].g1_off = s->o; A.t[1].publish = 1;      // Q1 reads (obs, act) and publishes s,a,r,d
       A.t[2].g0_off = 0; A.t[2].g1_off = s->o; A.t[2].publish = 0;
+      A.t[3].g0_off = 0; A.t[3].publish = 0;                              // pi reads obs
     }
     ILSX_TRY(launch_fwd(s->ctx, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
   }
@@ -364,7 +371,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
     sac_q_task(s, A.t[0], W_TQ1, w.s2, w.a2, w.tq1, false, false, 0);
     sac_q_task(s, A.t[1], W_TQ2, w.s2, w.a2, w.tq2, false, false, 1);
-    sac_policy_fin(s, A, eps1, s->rng_stream, false, w.a2, w.logp2);
+    sac_policy_fin(s, A, eps1, s->rng_stream, false, w.a2, w.logp2, w.ppart);
     ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx with the TD-target loss head
@@ -409,20 +416,14 @@ static int sac_actor_backward(ilsx_sac* s) {
   const SacWs& w = s->ws;
   const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
   const float* eps2 = s->eps_explicit ? w.eps2 : nullptr;
-  {  // fwd pi(s) with eps_cur
-    FwdArgs A;
-    memset(&A, 0, sizeof A);
-    A.rows = B; A.ntasks = 1; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
-    sac_policy_task(s, A.t[0], w.s, eps2, s->rng_stream + 1, true, w.an, w.logp);
-    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lp.KP, cs));
-  }
+  // (pi(s) with eps_cur ran as the 4th task of the step's first forward launch, sac_critic_backward)
   {  // fwd Q1(s,a~), Q2(s,a~) with the just-updated critics (sac_alpha.py:144-146)
     FwdArgs A;
     memset(&A, 0, sizeof A);
     A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
     sac_q_task(s, A.t[0], W_Q1, w.s, w.an, w.q1n, false, true, 0);
     sac_q_task(s, A.t[1], W_Q2, w.s, w.an, w.q2n, false, true, 1);
-    sac_policy_fin(s, A, eps2, s->rng_stream + 1, true, w.an, w.logp);
+    sac_policy_fin(s, A, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
     ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx through both critics to the action columns
