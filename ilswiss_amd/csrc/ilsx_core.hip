@@ -417,8 +417,40 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
   memset(&D.F, 0, sizeof D.F);
   if (fuse) D.F = *fuse;
   D.dbg = ctx->dbg_stamps ? ctx->dbg_stamps + 4 : nullptr;
-  ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
   D.xs = ctx->xcd_shift;
+  D.splits = 1; D.rows_per_split = rows; D.scratch = nullptr; D.span = 0;
+  bool stacked = false;
+  for (int i = 0; i < D.nmat; ++i) stacked = stacked || D.m[i].rows > 0;
+  if (rows >= DW_SPLIT_MIN_ROWS && D.g_lo && !stacked) {   // large batch: split the contraction over row ranges
+    int splits = rows / 512;
+    if (splits > 32) splits = 32;
+    const size_t span = (size_t)(D.g_hi - D.g_lo);
+    const size_t need = (size_t)splits * span * sizeof(float);
+    if (ctx->dw_scratch_bytes < need) {
+      if (ctx->dw_scratch) ILSX_TRY(ctx_free(ctx, ctx->dw_scratch));
+      ctx->dw_scratch = nullptr; ctx->dw_scratch_bytes = 0;
+      ILSX_TRY(ctx_alloc(ctx, need, (void**)&ctx->dw_scratch, true));   // zeroed: padding words are never written
+      ctx->dw_scratch_bytes = need;
+    }
+    D.splits = splits; D.rows_per_split = ((rows + splits - 1) / splits + 127) / 128 * 128;
+    D.scratch = (float*)ctx->dw_scratch; D.span = span; D.xs = 0;
+    const AdamFuse keep = D.F;
+    D.F.on = 0;
+    {
+      ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
+      hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(D.ntiles, splits), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+    }
+    DwReduceArgs R;
+    R.scratch = D.scratch; R.splits = splits; R.span = span; R.g_lo = D.g_lo; R.F = keep;
+    R.off0 = keep.on ? (size_t)(D.g_lo - keep.Gbase) : 0;
+    int blocks = (int)((span / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    ProfScope ps(ctx, ILSX_K_ADAM);
+    hipLaunchKernelGGL(k_dw_reduce, dim3(blocks), dim3(256), 0, ctx->stream, R);
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
+  ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
   hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
@@ -450,6 +482,8 @@ int launch_adam(ilsx_ctx* ctx, const AdamArgs& A) {
 int build_dw_jobs(const NetLayout& L, float* gbase, const float* xsave, float* const* hsave,
                   float* const* dsave, const float* dhead, DwArgs* table) {
   const int H = L.cfg.hidden;
+  if (!table->g_lo || gbase < table->g_lo) table->g_lo = gbase;
+  if (!table->g_hi || gbase + L.n_int > table->g_hi) table->g_hi = gbase + L.n_int;
   for (int l = 0; l < L.cfg.n_hidden; ++l) {
     const float* Bm = l == 0 ? xsave : hsave[l - 1];
     const int ldb = l == 0 ? L.KP : H;

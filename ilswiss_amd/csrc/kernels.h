@@ -120,8 +120,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 template <int N> __device__ __forceinline__ void load_vec(const float* p, float (&v)[N]) {
-  if (N == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-  else if (N == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+  if constexpr (N == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  else if constexpr (N == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
   else { v[0] = p[0]; }
 }
 
@@ -1067,7 +1067,13 @@ struct DwArgs {
   AdamFuse F;
   unsigned long long* dbg;
   int xs;
+  // large batches: the contraction is split over blockIdx.y row ranges; each range writes its partial gradient arena
+  // slab (same layout as G) and k_dw_reduce sums the slabs in a fixed order (+ Adam): deterministic, no atomics
+  int splits, rows_per_split;
+  float* g_lo; float* g_hi;   // extent of the gradient arena the table's matrices live in (set by build_dw_jobs)
+  float* scratch; size_t span;
 };
+#define DW_SPLIT_MIN_ROWS 1024
 #define DW_TILE_N 32
 #define DW_TILE_K 64
 #define DW_LDS_BYTES ((16 * 16 * 64 + 16 * 16) * 4)
@@ -1108,7 +1114,15 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   const AdamFuse& F = D.F;
   const int local = bx - J.tile0;
   const int n0 = (local / J.ktiles) * DW_TILE_N, k0 = (local % J.ktiles) * DW_TILE_K;
-  const int rows = J.rows > 0 ? J.rows : D.rows_all, brows = J.rows > 0 ? J.bias_rows : D.rows_all;
+  int rows = J.rows > 0 ? J.rows : D.rows_all, brows = J.rows > 0 ? J.bias_rows : D.rows_all;
+  int r_begin = 0;
+  float* out_shift = nullptr;   // split mode: outputs land in this row range's slab
+  if (D.splits > 1) {
+    r_begin = blockIdx.y * D.rows_per_split;
+    rows = min(rows, r_begin + D.rows_per_split);
+    brows = rows;
+    out_shift = D.scratch + (size_t)blockIdx.y * D.span;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int wn = wave & 1, wr = wave >> 1;
   const int nsub = n0 + 16 * wn;
@@ -1131,11 +1145,16 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
     if (live[h]) {
       g0p[h] = J.mode == DW_OUT_NATURAL ? J.dW + (size_t)n * J.ldw + k : J.dW + pack_f(n, k, J.ldw);
       g1p[h] = J.mode == DW_OUT_PACK_FB ? J.dWb + pack_b(n, k, J.NA) : nullptr;
+      if (out_shift) {
+        g0p[h] = out_shift + (g0p[h] - D.g_lo);
+        if (g1p[h]) g1p[h] = out_shift + (g1p[h] - D.g_lo);
+      }
       if (F.on) ao[h] = adam_prefetch(F, (size_t)(g0p[h] - F.Gbase));
     }
   }
   const bool bias_thread = J.db && k0 == 0 && tid < 32 && n0 + 16 * (tid >> 4) + (tid & 15) < J.NA;
   float* gbp = bias_thread ? J.db + n0 + 16 * (tid >> 4) + (tid & 15) : nullptr;
+  if (gbp && out_shift) gbp = out_shift + (gbp - D.g_lo);
   AdamOperands aob;
   if (bias_thread && F.on) aob = adam_prefetch(F, (size_t)(gbp - F.Gbase));
 
@@ -1146,7 +1165,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   bool k_ok[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) k_ok[t] = k0 + 16 * t + li < J.NB;
-  for (int rc = 16 * wr; rc < rows; rc += 128) {
+  for (int rc = r_begin + 16 * wr; rc < rows; rc += 128) {
     float a[4], b[4][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1200,6 +1219,35 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
     if (F.on) adam_apply(F, ad_step, ad_bc2s, aob, (size_t)(gbp - F.Gbase), 0, false, s);
   }
   if (D.dbg && bx == 5 && tid == 0) D.dbg[3] = __builtin_amdgcn_s_memtime();
+}
+
+// Sum the row-range slabs of a split weight-gradient launch in slab order, store the gradient, and apply the optimiser
+// epilogue (Adam + L2 + Polyak) elementwise: the arena is a flat vector, both packings of a matrix carry identical
+// gradients and moments, so they stay identical.
+struct DwReduceArgs { const float* scratch; int splits; size_t span; float* g_lo; AdamFuse F; size_t off0; };
+__global__ __launch_bounds__(256) void k_dw_reduce(const DwReduceArgs R) {
+  const AdamFuse& F = R.F;
+  float step = 0.f, bc2s = 1.f;
+  if (F.on) { step = *F.step_size; bc2s = *F.bc2_sqrt; }
+  const size_t n4 = R.span >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 s = reinterpret_cast<const float4*>(R.scratch)[i];
+    for (int y = 1; y < R.splits; ++y) {
+      const float4 v = reinterpret_cast<const float4*>(R.scratch + (size_t)y * R.span)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(R.g_lo)[i] = s;
+    if (F.on) {
+      const float gs[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t j = R.off0 + 4 * i + c;
+        AdamOperands o;
+        o.p = F.P[j]; o.m = F.M[j]; o.v = F.V[j]; o.t = F.T ? F.T[j] : 0.0f;
+        adam_apply(F, step, bc2s, o, j, 0, false, gs[c]);
+      }
+    }
+  }
 }
 #endif  // ILSX_KERNEL_IMPL
 

@@ -178,3 +178,24 @@ def test_hip_gae_chunk_edges_and_long_trajectories(ctx):
     np.testing.assert_allclose(R, R0, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(A, A0, rtol=2e-4, atol=5e-5, equal_nan=True)
     assert np.isnan(A).sum() == 1
+
+
+@pytest.mark.gpu
+def test_hip_train_step_large_minibatch_row_split_dw(ctx):
+    """Minibatches >= 1024 rows take the row-split weight-gradient path (slabs + k_dw_reduce, Adam in the reduce)."""
+    from oracle import mlp as omlp
+    rng = np.random.default_rng(123)
+    o, a, hid = 11, 3, [64, 64]
+    kw = dict(KW, mini_batch_size=1500, update_epoch=2)
+    vf0 = omlp.init_mlp(rng, o, hid, 1)
+    pi0 = np.concatenate([omlp.init_mlp(rng, o, hid, a, init_w=1e-3, last_scale=(0.1, 0.0)), rng.normal(-0.5, 0.2, a).astype(np.float32)])
+    trajs = [dict(observations=rng.normal(0, 1, (L, o)).astype(np.float32), actions=rng.normal(0, 0.7, (L, a)).astype(np.float32),
+                  rewards=rng.normal(0.5, 1.0, (L, 1)).astype(np.float32)) for L in (700, 900, 1000, 650)]
+    N = sum(t["rewards"].shape[0] for t in trajs)     # 3250 = 1500 + 1500 + 250 (the last minibatch is NOT split)
+    perms = np.stack([rng.permutation(N) for _ in range(2)])
+    orc = PPOOracle(o, a, hid, pi0, vf0, **kw)
+    tr = _hip_ppo(ctx, dict(dims=np.array([o, a] + hid), epochs=2, pi0=pi0, vf0=vf0), mini_batch_size=1500)
+    orc.train_step(trajs, list(perms))
+    tr.train_step(trajs, perms)
+    np.testing.assert_allclose(tr.get_flat_params(1), orc.vf, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(tr.get_flat_params(0), orc.pi, rtol=0, atol=5e-5)

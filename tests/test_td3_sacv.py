@@ -128,3 +128,30 @@ def test_hip_sac_v_golden(ctx):
             np.testing.assert_allclose(st[ref], g[f"s{s}_{k}"], rtol=2e-4, atol=1e-6, err_msg=f"step {s} {ref}")
         for k in ("pi", "q1", "q2", "vf", "tvf"):
             np.testing.assert_allclose(tr.get_flat_params(k), g[f"s{s}_{k}"], rtol=0, atol=5e-5, err_msg=f"step {s} {k}")
+
+
+@pytest.mark.gpu
+def test_hip_sac_v_large_batch_row_split_dw(ctx):
+    """B = 2048 rows: row-split weight gradients with Adam (+ the Polyak write of target V) in k_dw_reduce."""
+    from ilswiss_amd.networks import FlattenMlp, ReparamTanhMultivariateGaussianPolicy
+    from ilswiss_amd.sac_v import SoftActorCriticV
+    from oracle import mlp as omlp
+    rng = np.random.default_rng(88)
+    o, a, hid, B = 11, 3, [64, 64], 2048
+    pi0 = omlp.init_mlp(rng, o, hid, a, init_w=1e-3, n_heads=2)
+    q10, q20, vf0 = omlp.init_mlp(rng, o + a, hid, 1), omlp.init_mlp(rng, o + a, hid, 1), omlp.init_mlp(rng, o, hid, 1)
+    orc = SacVOracle(o, a, hid, pi0, q10, q20, vf0, **SACV_KW)
+    pol = ReparamTanhMultivariateGaussianPolicy(hid, o, a, ctx=ctx, seed=1)
+    q1, q2, vf = FlattenMlp(hid, 1, o + a, ctx=ctx, seed=2), FlattenMlp(hid, 1, o + a, ctx=ctx, seed=3), FlattenMlp(hid, 1, o, ctx=ctx, seed=4)
+    for net, p0 in ((pol, pi0), (q1, q10), (q2, q20), (vf, vf0)):
+        net.set_flat_params(p0)
+    tr = SoftActorCriticV(pol, q1, q2, vf, max_batch=B, **SACV_KW)
+    for s in range(3):
+        batch = dict(observations=rng.normal(0, 1, (B, o)).astype(np.float32), actions=np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32),
+                     rewards=rng.normal(0, 1, (B, 1)).astype(np.float32), terminals=(rng.random((B, 1)) < 0.1).astype(np.float32),
+                     next_observations=rng.normal(0, 1, (B, o)).astype(np.float32))
+        eps = rng.normal(0, 1, (B, a)).astype(np.float32)
+        orc.train_step(batch, eps)
+        tr.train_step(batch, eps=eps)
+    for k in ("pi", "q1", "q2", "vf", "tvf"):
+        np.testing.assert_allclose(tr.get_flat_params(k), getattr(orc, k), rtol=0, atol=5e-5, err_msg=k)
