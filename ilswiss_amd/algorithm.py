@@ -19,7 +19,7 @@ import numpy as np
 
 from .networks import MakeDeterministic
 from .replay import EnvReplayBuffer
-from .samplers import VecPathSampler, get_average_returns, get_generic_path_information
+from .samplers import DeviceEvalSampler, VecPathSampler, get_average_returns, get_generic_path_information
 
 
 class TabularLogger:
@@ -65,7 +65,7 @@ class DeviceRLAlgorithm:
                  num_steps_per_eval=1000, max_path_length=1000, min_steps_before_training=0, batch_size=256,
                  replay_buffer_size=1000000, no_terminal=False, eval_deterministic=True, freq_saving=1, save_best=True,
                  save_replay_buffer=False, replay_buffer=None, log_dir=None, best_key="AverageReturn", bootstrap_open_segments=True,
-                 **kwargs):
+                 eval_on_device=True, **kwargs):
         self.no_terminal = bool(no_terminal)   # base_algorithm.py:195-196,208-210: stored terminal flags forced to False
         self.on_policy = bool(getattr(trainer, "on_policy", False))   # torch_rl_algorithm.py:30-32
         self.bootstrap_open_segments = bootstrap_open_segments
@@ -83,7 +83,9 @@ class DeviceRLAlgorithm:
             replay_buffer = EnvReplayBuffer(replay_buffer_size, env, random_seed=seed, ctx=trainer.ctx)
         self.replay_buffer = replay_buffer
         eval_policy = MakeDeterministic(exploration_policy) if eval_deterministic else exploration_policy
-        self.eval_sampler = VecPathSampler(eval_env, eval_policy, num_steps_per_eval, max_path_length)
+        # evaluation runs on the device unless asked otherwise (the host-walked VecPathSampler is the reference's own loop)
+        sampler_cls = DeviceEvalSampler if (eval_on_device and hasattr(eval_env, "h")) else VecPathSampler
+        self.eval_sampler = sampler_cls(eval_env, eval_policy, num_steps_per_eval, max_path_length)
         self.logger = TabularLogger(log_dir)
         self._n_env_steps_total = self._n_train_steps_total = self._n_prev_train_env_steps = 0
         self._n_rollouts_total, self.best_statistic_so_far = 0, -np.inf
@@ -157,14 +159,20 @@ class DeviceRLAlgorithm:
         ts = self.trainer.get_eval_statistics()
         if ts:
             st.update(ts)
-        test_paths = self.eval_sampler.obtain_samples()
-        st.update(get_generic_path_information(test_paths, stat_prefix="Test"))
+        if isinstance(self.eval_sampler, DeviceEvalSampler):
+            dev_stats = self.eval_sampler.obtain_statistics(stat_prefix="Test")
+            average_return = dev_stats.pop("AverageReturn")
+            st.update(dev_stats)
+        else:
+            test_paths = self.eval_sampler.obtain_samples()
+            st.update(get_generic_path_information(test_paths, stat_prefix="Test"))
+            average_return = get_average_returns(test_paths)
         episodes, ret_sum = self.training_env.rollout_stats(reset=True)
         self._n_rollouts_total += int(episodes)
         if episodes > 0:
             st["Exploration Returns Mean"] = ret_sum / episodes
             st["Exploration Num Paths"] = episodes
-        st["AverageReturn"] = get_average_returns(test_paths)
+        st["AverageReturn"] = average_return
         lg = self.logger
         for k, v in st.items():
             lg.record_tabular(k, float(np.mean(v)))

@@ -47,6 +47,8 @@ struct ilsx_vecenv {
   // running observation statistics (vecenvs.py:299-327, normalizer.py:128-152)
   struct ObsRms* rms = nullptr;
   float* obs_n = nullptr;   // [n_env][o] normalised policy input (norm_obs)
+  // evaluation rollouts (ilsx_eval_rollout)
+  unsigned char* ev_frozen = nullptr; double* ev_ret = nullptr; int* ev_len = nullptr; double* ev_stats = nullptr; int* ev_alive = nullptr;
   bool norm_obs = false, update_rms = false;
   const float* policy_obs() const { return norm_obs ? obs_n : obs_cur; }
 };
@@ -377,6 +379,7 @@ struct EnvStepArgs {
   // fused-rollout extras (all nullable / 0)
   float* obs_cur;         // [n_env][o]: the policy's next input (post auto-reset)
   int auto_reset, max_path_length, no_terminal;
+  const unsigned char* frozen;   // nullable: envs whose flag is set do not step (evaluation: one episode per env)
   int* ep_len; double* ep_ret; double* stats;
   float* replay; int rec; long long cap, top;   // transition record written at slot (top + env) % cap
   uint64_t seed; uint32_t stream; unsigned long long step;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
   const int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t >= A.n_ids) return;
   const int env = A.ids ? A.ids[t] : t;
+  if (A.frozen && A.frozen[env]) return;
   const int o = m.obs_dim, na = m.n_act;
   double q[N], v[N];
 #pragma unroll
@@ -839,6 +843,111 @@ extern "C" int ilsx_ppo_rollout(ilsx_ppo* ppo, ilsx_vecenv* e, int T, int max_pa
     ILSX_TRY(env_after_step_norm(e));
   }
   if (last_values) ILSX_TRY(ilsx_ppo_values(ppo, e->policy_obs(), n, last_values));
+  return ILSX_OK;
+}
+
+// ---- evaluation: VecPathSampler.obtain_samples / rollout (samplers/vec_sampler.py:5-93,124-142) on the device.
+// Every env plays ONE episode (envs that end are frozen, not reset); the statistics of
+// eval_util.get_generic_path_information (:15-80) are accumulated as sums / extrema.
+enum { EV_PATHS = 0, EV_STEPS, EV_RET_S, EV_RET_SS, EV_RET_MAX, EV_RET_MIN, EV_LEN_S, EV_LEN_SS, EV_LEN_MAX, EV_LEN_MIN, EV_REW_S,
+       EV_REW_SS, EV_REW_MAX, EV_REW_MIN, EV_ACT_S, EV_ACT_SS, EV_ACT_MAX, EV_ACT_MIN, EV_N };
+__device__ __forceinline__ void atomic_max_d(double* p, double v) {
+  unsigned long long old = __double_as_longlong(*p);
+  while (v > __longlong_as_double(old)) {
+    const unsigned long long prev = atomicCAS((unsigned long long*)p, old, (unsigned long long)__double_as_longlong(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+__device__ __forceinline__ void atomic_min_d(double* p, double v) {
+  unsigned long long old = __double_as_longlong(*p);
+  while (v < __longlong_as_double(old)) {
+    const unsigned long long prev = atomicCAS((unsigned long long*)p, old, (unsigned long long)__double_as_longlong(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+__global__ void k_eval_begin(unsigned char* frozen, double* ret, int* len, int n, int* alive) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) { frozen[e] = 0; ret[e] = 0.0; len[e] = 0; }
+  if (e == 0) *alive = n;
+}
+__global__ void k_eval_accum(const float* __restrict__ rew, const unsigned char* __restrict__ done, const float* __restrict__ act,
+                             int n, int a, int max_path_length, unsigned char* frozen, double* ret, int* len, double* st, int* alive) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n || frozen[e]) return;
+  const double r = (double)rew[e];
+  const double R = ret[e] + r;
+  const int L = len[e] + 1;
+  ret[e] = R; len[e] = L;
+  atomicAdd(&st[EV_STEPS], 1.0);
+  atomicAdd(&st[EV_REW_S], r); atomicAdd(&st[EV_REW_SS], r * r); atomic_max_d(&st[EV_REW_MAX], r); atomic_min_d(&st[EV_REW_MIN], r);
+  for (int k = 0; k < a; ++k) {
+    const double x = (double)act[(size_t)e * a + k];
+    atomicAdd(&st[EV_ACT_S], x); atomicAdd(&st[EV_ACT_SS], x * x); atomic_max_d(&st[EV_ACT_MAX], x); atomic_min_d(&st[EV_ACT_MIN], x);
+  }
+  if (done[e] || L >= max_path_length) {   // the path ends at its first terminal or at the horizon (vec_sampler.py:61-77)
+    frozen[e] = 1;
+    atomicAdd(&st[EV_PATHS], 1.0);
+    atomicAdd(&st[EV_RET_S], R); atomicAdd(&st[EV_RET_SS], R * R); atomic_max_d(&st[EV_RET_MAX], R); atomic_min_d(&st[EV_RET_MIN], R);
+    const double l = (double)L;
+    atomicAdd(&st[EV_LEN_S], l); atomicAdd(&st[EV_LEN_SS], l * l); atomic_max_d(&st[EV_LEN_MAX], l); atomic_min_d(&st[EV_LEN_MIN], l);
+    atomicSub(alive, 1);
+  }
+}
+
+extern "C" int ilsx_eval_rollout(ilsx_vecenv* e, ilsx_net* pi, ilsx_ppo* ppo, int max_path_length, int deterministic, int reset_stats,
+                                 double* stats_host) {
+  if (!e || (!pi && !ppo) || max_path_length < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_eval_rollout: bad argument");
+  ilsx_ctx* ctx = e->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = e->n_env;
+  if (!e->ev_frozen) {
+    ILSX_TRY(ctx_alloc(ctx, n, (void**)&e->ev_frozen)); ILSX_TRY(ctx_alloc(ctx, (size_t)n * 8, (void**)&e->ev_ret));
+    ILSX_TRY(ctx_alloc(ctx, (size_t)n * 4, (void**)&e->ev_len)); ILSX_TRY(ctx_alloc(ctx, EV_N * 8, (void**)&e->ev_stats));
+    ILSX_TRY(ctx_alloc(ctx, 4, (void**)&e->ev_alive));
+    reset_stats = 1;
+  }
+  hipStream_t st = ctx->stream;
+  if (reset_stats) {
+    double h[EV_N];
+    for (int i = 0; i < EV_N; ++i) h[i] = 0.0;
+    h[EV_RET_MAX] = h[EV_LEN_MAX] = h[EV_REW_MAX] = h[EV_ACT_MAX] = -INFINITY;
+    h[EV_RET_MIN] = h[EV_LEN_MIN] = h[EV_REW_MIN] = h[EV_ACT_MIN] = INFINITY;
+    HIPCHK(hipMemcpyAsync(e->ev_stats, h, sizeof h, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  ILSX_TRY(ilsx_vecenv_reset(e, nullptr, n, nullptr));   // rollout() starts with env.reset(ready_env_ids) (vec_sampler.py:33)
+  hipLaunchKernelGGL(k_eval_begin, dim3((n + 255) / 256), dim3(256), 0, st, e->ev_frozen, e->ev_ret, e->ev_len, n, e->ev_alive);
+  for (int t = 0; t < max_path_length; ++t) {
+    const unsigned long long step = ++e->step_ctr;
+    if (pi) ILSX_TRY(ilsx_policy_act(pi, e->policy_obs(), n, deterministic, nullptr, e->act, nullptr));
+    else ILSX_TRY(ilsx_ppo_policy_act(ppo, e->policy_obs(), n, deterministic, nullptr, e->act, nullptr));
+    EnvStepArgs A;
+    memset(&A, 0, sizeof A);
+    A.m = e->dm; A.qpos = e->qpos; A.qvel = e->qvel; A.n_env = n;
+    A.ids = nullptr; A.n_ids = n; A.act = e->act;
+    A.obs = e->nobs; A.rew = e->rew; A.done = e->done; A.obs_cur = e->obs_cur; A.frozen = e->ev_frozen;
+    A.seed = e->seed; A.stream = e->rng_stream; A.step = step;
+    ILSX_TRY(launch_env_step(e, A));
+    hipLaunchKernelGGL(k_eval_accum, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)e->rew, (const unsigned char*)e->done,
+                       (const float*)e->act, n, e->a, max_path_length, e->ev_frozen, e->ev_ret, e->ev_len, e->ev_stats, e->ev_alive);
+    HIPCHK(hipGetLastError());
+    if (e->norm_obs) {   // step() hands out normalised observations and (training envs only) feeds the statistics
+      ILSX_TRY(env_obs_norm(e, e->nobs, n, nullptr, nullptr, nullptr, 0));
+      ILSX_TRY(env_obs_norm(e, nullptr, 0, nullptr, e->obs_cur, e->obs_n, n));
+    }
+    if ((t & 31) == 31) {   // every env done? (one 4-byte read-back per 32 vec steps)
+      int alive = 0;
+      HIPCHK(hipMemcpyAsync(&alive, e->ev_alive, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (alive <= 0) break;
+    }
+  }
+  if (stats_host) {
+    HIPCHK(hipMemcpyAsync(stats_host, e->ev_stats, EV_N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
   return ILSX_OK;
 }
 

@@ -91,3 +91,45 @@ def get_generic_path_information(paths, stat_prefix=""):
 
 def get_average_returns(paths):
     return float(np.mean([np.sum(p["rewards"]) for p in paths]))
+
+
+class DeviceEvalSampler:
+    """VecPathSampler.obtain_samples + get_generic_path_information without leaving the device (ilsx_eval_rollout): every
+    call of the library plays one episode per env; calls repeat until `num_steps` samples are in (vec_sampler.py:124-142).
+    Returns the statistics dict directly (there are no host-side paths)."""
+
+    def __init__(self, env, policy, num_steps, max_path_length, **kwargs):
+        self.env, self.policy, self.num_steps, self.max_path_length = env, policy, num_steps, max_path_length
+
+    def _handles(self):
+        pol, det = self.policy, False
+        if hasattr(pol, "stochastic_policy"):        # MakeDeterministic (policies.py:19-36)
+            pol, det = pol.stochastic_policy, True
+        ppo = getattr(pol, "_ppo", None)
+        return (None, ppo.h, det) if ppo is not None else (pol.h, None, det)
+
+    def obtain_statistics(self, stat_prefix="Test"):
+        import ctypes as C
+
+        from . import _lib
+        pi, ppo, det = self._handles()
+        st = (C.c_double * 18)()
+        first = True
+        while first or st[1] < self.num_steps:
+            _lib.check(self.env.ctx.lib.ilsx_eval_rollout(self.env.h, pi, ppo, int(self.max_path_length), int(det), int(first), st))
+            first = False
+        n_paths, n_steps = st[0], st[1]
+        out = OrderedDict()
+
+        def block(name, i, n):
+            mean = st[i] / n
+            out[f"{stat_prefix} {name} Mean"] = mean
+            out[f"{stat_prefix} {name} Std"] = float(np.sqrt(max(st[i + 1] / n - mean * mean, 0.0)))
+            out[f"{stat_prefix} {name} Max"], out[f"{stat_prefix} {name} Min"] = st[i + 2], st[i + 3]
+        block("Rewards", 10, n_steps)
+        block("Returns", 2, n_paths)
+        block("Actions", 14, n_steps * self.env.act_dim)
+        block("Ep. Len.", 6, n_paths)
+        out["Num Paths"] = int(n_paths)
+        out["AverageReturn"] = st[2] / n_paths
+        return out

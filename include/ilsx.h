@@ -385,6 +385,14 @@ int ilsx_ppo_rollout(ilsx_ppo* ppo, ilsx_vecenv* env, int T, int max_path_length
  * stored terminal flag is forced to 0 (base_algorithm.py:195-196,208-210; the adv-IRL configs). */
 int ilsx_rollout_step(ilsx_vecenv* env, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
                       int deterministic, int no_terminal);
+/* Evaluation on the device — VecPathSampler.obtain_samples / rollout (samplers/vec_sampler.py:5-93,124-142): reset all envs,
+ * then every env plays ONE episode with `pi` (ilsx_net: tanh-Gaussian or noise policy) or `ppo`'s Gaussian policy; envs that
+ * end (terminal or max_path_length) are frozen, not reset.  stats_host[18] (nullable, float64) accumulates what
+ * eval_util.get_generic_path_information (:15-80) needs: {paths, steps, returns sum/sumsq/max/min, lengths
+ * sum/sumsq/max/min, rewards sum/sumsq/max/min, actions sum/sumsq/max/min}; reset_stats = 0 keeps accumulating over calls. */
+#define ILSX_EVAL_NSTATS 18
+int ilsx_eval_rollout(ilsx_vecenv* env, ilsx_net* pi, ilsx_ppo* ppo, int max_path_length, int deterministic, int reset_stats,
+                      double* stats_host);
 /* finished episodes and the sum of their returns since the last reset of the counters */
 int ilsx_rollout_stats(ilsx_vecenv* env, double* episodes, double* return_sum, int reset);
 
