@@ -4,6 +4,7 @@
     python bench_aux.py ppo     # C4: PPO Hopper dims, 8192 envs x 128-step rollout = 1,048,576 samples
     python bench_aux.py gail    # C3: GAIL Walker2d dims, 1 discriminator step + 1 SAC step per loop iteration
     python bench_aux.py td3     # TD3 / SAC-V grad-steps/s at the SAC config's sizes
+    python bench_aux.py seeds   # K co-resident SAC seeds on one GPU (multi-stream), aggregate grad-steps/s
 
 Each prints one JSON line.  Synthetic inputs of the configs' shapes, random-init networks.
 """
@@ -147,8 +148,76 @@ def bench_td3(ctx):
                 value=res["td3_grad_steps_per_s"], dtype="f32", data="synthetic", detail=res)
 
 
+def bench_seeds(_ctx):
+    """Co-resident seeds on one GPU (SURVEY config 5's "4 seeds per GPU"): K independent SAC runs, each with its own
+    context = HIP stream, replay ring and captured step graph, issued round-robin from one host thread."""
+    from ilswiss_amd.networks import FlattenMlp, ReparamTanhMultivariateGaussianPolicy
+    from ilswiss_amd.replay import SimpleReplayBuffer
+    from ilswiss_amd.sac import SoftActorCritic
+    o, a, H, B, CAP = 11, 3, 256, 256, 200_000
+    rng = np.random.default_rng(0)
+    data = (rng.normal(0, 1, (CAP, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (CAP, a))).astype(np.float32),
+            rng.normal(0, 1, CAP).astype(np.float32), rng.random(CAP) < 1e-3, rng.normal(0, 1, (CAP, o)).astype(np.float32))
+    res = {}
+    for K in (1, 2, 4, 8):
+        runs = []
+        for k in range(K):
+            c = ilswiss_amd.Context(0, seed=100 * k)
+            rb = SimpleReplayBuffer(CAP, o, a, random_seed=k, ctx=c)
+            rb.add_rows(*data)
+            tr = SoftActorCritic(ReparamTanhMultivariateGaussianPolicy([H, H], o, a, ctx=c, seed=k),
+                                 FlattenMlp([H, H], 1, o + a, ctx=c, seed=k + 1), FlattenMlp([H, H], 1, o + a, ctx=c, seed=k + 2),
+                                 policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+            tr.eval_statistics = {}
+            runs.append((c, rb, tr))
+        for c, rb, tr in runs:
+            tr.train_from_replay(rb, 300, B)
+        for c, rb, tr in runs:
+            c.sync()
+        n, chunk = 4000, 500
+        t0 = time.perf_counter()
+        for _ in range(n // chunk):
+            for c, rb, tr in runs:
+                tr.train_from_replay(rb, chunk, B)
+        for c, rb, tr in runs:
+            c.sync()
+        dt = time.perf_counter() - t0
+        res[f"streams_K{K}"] = dict(aggregate_grad_steps_per_s=K * n / dt, per_run=n / dt)
+        for c, rb, tr in runs:
+            c.close()
+    # grouped launches: ONE context, every stage of the step is one launch for all K agents (ilsx_sac_group)
+    from ilswiss_amd.sac import SoftActorCriticGroup
+    for K in (1, 2, 4, 8, 16):
+        c = ilswiss_amd.Context(0, seed=7)
+        rbs, trs = [], []
+        for k in range(K):
+            rb = SimpleReplayBuffer(CAP, o, a, random_seed=k, ctx=c)
+            rb.add_rows(*data)
+            tr = SoftActorCritic(ReparamTanhMultivariateGaussianPolicy([H, H], o, a, ctx=c, seed=k),
+                                 FlattenMlp([H, H], 1, o + a, ctx=c, seed=k + 1), FlattenMlp([H, H], 1, o + a, ctx=c, seed=k + 2),
+                                 policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+            tr.eval_statistics = {}
+            rbs.append(rb), trs.append(tr)
+        grp = SoftActorCriticGroup(trs)
+        grp.train_from_replay(rbs, 300, B)
+        c.sync()
+        n = 3000
+        t0 = time.perf_counter()
+        grp.train_from_replay(rbs, n, B)
+        c.sync()
+        dt = time.perf_counter() - t0
+        res[f"grouped_K{K}"] = dict(aggregate_grad_steps_per_s=K * n / dt, per_run=n / dt, us_per_lockstep=1e6 * dt / n)
+        grp.close()
+        c.close()
+    return dict(metric="co-resident SAC seeds on one GPU: aggregate grad-steps/s", unit="grad-steps/s (aggregate)",
+                value=res["grouped_K8"]["aggregate_grad_steps_per_s"], dtype="f32", data="synthetic",
+                config=dict(workload="K independent SAC runs, Hopper dims, 256-256 MLP, batch 256 each; 'streams' = one HIP stream + "
+                                     "step graph per run, 'grouped' = ilsx_sac_group (one launch per stage for all runs)"),
+                detail=res)
+
+
 if __name__ == "__main__":
     ctx = ilswiss_amd.Context(0, seed=0)
-    which = sys.argv[1:] or ["ppo", "gail", "td3"]
+    which = sys.argv[1:] or ["ppo", "gail", "td3", "seeds"]
     for w in which:
-        print(json.dumps(dict(ppo=bench_ppo, gail=bench_gail, td3=bench_td3)[w](ctx)), flush=True)
+        print(json.dumps(dict(ppo=bench_ppo, gail=bench_gail, td3=bench_td3, seeds=bench_seeds)[w](ctx)), flush=True)

@@ -9,4 +9,4 @@ from .device import Context, DevArray, get_context, set_gpu_mode  # noqa: F401
 from .networks import (FlattenMlp, MakeDeterministic, Mlp,  # noqa: F401
                        ReparamTanhMultivariateGaussianPolicy)
 from .replay import EnvReplayBuffer, SimpleReplayBuffer  # noqa: F401
-from .sac import SoftActorCritic, Trainer  # noqa: F401
+from .sac import SoftActorCritic, SoftActorCriticGroup, Trainer  # noqa: F401

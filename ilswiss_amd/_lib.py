@@ -100,6 +100,9 @@ class DiscStats(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/ilsx.h declares
 PROTOTYPES = {
+    "ilsx_sac_group_create": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.POINTER(vp)]),
+    "ilsx_sac_group_destroy": (C.c_int, [vp]),
+    "ilsx_sac_group_train_from_replay": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int]),
     "ilsx_advirl_train": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_int, C.c_float, C.POINTER(DiscStats), C.POINTER(SacStats), vp]),
     "ilsx_net_set_noise_policy": (C.c_int, [vp, C.c_float, C.c_float, C.c_float]),

@@ -298,11 +298,16 @@ static int kernels_init_once() {
   SET_FWD(64, ACT_RELU); SET_FWD(128, ACT_RELU); SET_FWD(256, ACT_RELU);
   SET_FWD(64, ACT_TANH); SET_FWD(128, ACT_TANH); SET_FWD(256, ACT_TANH);
 #undef SET_FWD
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   done = true;
   return ILSX_OK;
 }
@@ -350,11 +355,11 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
     A.xs = ctx->xcd_shift;
     dim3 grid(((A.rows + 15) / 16) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (H == 256 && cs == 4) {
-      if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, A);
-      else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, A);
+      if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
+      else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
     } else if (H == 128 && cs == 2) {
-      if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, A);
-      else hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_TANH, 2>), grid, block, lds, ctx->stream, A);
+      if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_RELU, 2, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_RELU, 2, false>), grid, block, lds, ctx->stream, A); }
+      else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_TANH, 2, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_TANH, 2, false>), grid, block, lds, ctx->stream, A); }
     } else {
       ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "no column-split forward kernel for H=%d cs=%d", H, cs);
     }
@@ -382,11 +387,11 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
     A.xs = ctx->xcd_shift;
     dim3 grid(((A.rows + 15) / 16) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (H == 256 && cs == 4) {
-      if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, A);
-      else hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, A);
+      if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
+      else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
     } else if (H == 128 && cs == 2) {
-      if (act == ILSX_ACT_RELU) hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, A);
-      else hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_TANH, 2>), grid, block, lds, ctx->stream, A);
+      if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_RELU, 2, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_RELU, 2, false>), grid, block, lds, ctx->stream, A); }
+      else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_TANH, 2, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_TANH, 2, false>), grid, block, lds, ctx->stream, A); }
     } else {
       ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "no column-split backward kernel for H=%d cs=%d", H, cs);
     }
@@ -420,7 +425,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
   D.xs = ctx->xcd_shift;
   D.splits = 1; D.rows_per_split = rows; D.scratch = nullptr; D.span = 0;
   bool stacked = false;
-  for (int i = 0; i < D.nmat; ++i) stacked = stacked || D.m[i].rows > 0;
+  for (int i = 0; i < D.nmat && !D.mats; ++i) stacked = stacked || D.m[i].rows > 0;
   if (rows >= DW_SPLIT_MIN_ROWS && D.g_lo && !stacked) {   // large batch: split the contraction over row ranges
     int splits = rows / 512;
     if (splits > 32) splits = 32;
@@ -438,7 +443,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     D.F.on = 0;
     {
       ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-      hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(D.ntiles, splits), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+      hipLaunchKernelGGL(k_mlp_bwd_dw<false>, dim3(D.ntiles, splits), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
     }
     DwReduceArgs R;
     R.scratch = D.scratch; R.splits = splits; R.span = span; R.g_lo = D.g_lo; R.F = keep;
@@ -451,7 +456,8 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     return ILSX_OK;
   }
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-  hipLaunchKernelGGL(k_mlp_bwd_dw, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+  if (D.mats) hipLaunchKernelGGL(k_mlp_bwd_dw<true>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+  else hipLaunchKernelGGL(k_mlp_bwd_dw<false>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

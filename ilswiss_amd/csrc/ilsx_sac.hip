@@ -30,8 +30,27 @@ struct SacWs {  // device workspace for B <= max_batch rows
   float* ppart2; //   and pi(s), whose trunk runs in the step's first launch
 };
 
+struct StatsArgs {
+  PartVal q1, q2, tq1, tq2, q1n, q2n;
+  const float *logp2, *r, *d, *logp, *raw;
+  int B, a;
+  float gamma, reward_scale, w_mu, w_std, target_entropy, inv_B;
+  DevScalars* scal;
+  float* alpha_grad_slot;  // G arena slot: -(sum(logp + target_entropy)) * inv_B
+};
+
+// A grouped step (ilsx_sac_group) is assembled by running every agent's ordinary step in "collect" mode: the launch sites
+// below hand their descriptors to this list instead of launching.
+struct SacTailItem { StatsArgs S; int train_alpha; float lr, b1, b2, eps, qf_lr, policy_lr; };
+struct SacLaunch {
+  int kind;   // 0 forward, 1 backward-to-activations, 2 weight gradients (+ Adam), 3 tail
+  FwdArgs f; int KP; BwdArgs b; DwArgs d; AdamFuse F; SacTailItem t;
+};
+struct SacCollector { std::vector<SacLaunch> L; };
+
 struct ilsx_sac {
   ilsx_ctx* ctx = nullptr;
+  SacCollector* col = nullptr;
   ilsx_sac_cfg cfg;
   ilsx_net *pi = nullptr, *q1 = nullptr, *q2 = nullptr;
   NetLayout Lq, Lp;
@@ -67,14 +86,6 @@ struct ilsx_sac {
 };
 
 // ------------------------------------------------------------------------------------------------
-struct StatsArgs {
-  PartVal q1, q2, tq1, tq2, q1n, q2n;
-  const float *logp2, *r, *d, *logp, *raw;
-  int B, a;
-  float gamma, reward_scale, w_mu, w_std, target_entropy, inv_B;
-  DevScalars* scal;
-  float* alpha_grad_slot;  // G arena slot: -(sum(logp + target_entropy)) * inv_B
-};
 
 // single workgroup: losses of sac_alpha.py:122-123,148-153,161-162 + the alpha gradient
 // the alpha gradient alone (every step); the full statistics only when the host asked for them
@@ -167,6 +178,17 @@ __global__ __launch_bounds__(256) void k_sac_tail(const StatsArgs S, int train_a
   else sac_alpha_grad_dev(S);
   if (threadIdx.x == 0) S.scal->want_stats = 0;
   if (threadIdx.x == 0) sac_finish_dev(S.scal, S.alpha_grad_slot, train_alpha, lr, b1, b2, eps, qf_lr, policy_lr);
+}
+
+// grouped step: one workgroup per agent
+__global__ __launch_bounds__(256) void k_sac_tail_group(const SacTailItem* items) {
+  const SacTailItem& T = items[blockIdx.x];
+  if (T.S.scal->want_stats) sac_stats_dev(T.S);   // workgroup-uniform
+  else sac_alpha_grad_dev(T.S);
+  if (threadIdx.x == 0) {
+    T.S.scal->want_stats = 0;
+    sac_finish_dev(T.S.scal, T.S.alpha_grad_slot, T.train_alpha, T.lr, T.b1, T.b2, T.eps, T.qf_lr, T.policy_lr);
+  }
 }
 
 // device-side (re)computation of the Adam scalars so every path uses the same pow()
@@ -338,6 +360,25 @@ static void sac_q_task(ilsx_sac* s, FwdTask& q, int which, const float* obs, con
   if (s->cs > 1) q.part = out; else q.out = out;
 }
 
+static int sac_fwd(ilsx_sac* s, const FwdArgs& A, int H, int act, int KP, int cs) {
+  if (!s->col) return launch_fwd(s->ctx, A, H, act, KP, cs);
+  SacLaunch l; memset(&l, 0, sizeof l); l.kind = 0; l.f = A; l.KP = KP;
+  s->col->L.push_back(l);
+  return ILSX_OK;
+}
+static int sac_bwd(ilsx_sac* s, const BwdArgs& A, int H, int act, int cs) {
+  if (!s->col) return launch_bwd_dx(s->ctx, A, H, act, cs);
+  SacLaunch l; memset(&l, 0, sizeof l); l.kind = 1; l.b = A;
+  s->col->L.push_back(l);
+  return ILSX_OK;
+}
+static int sac_dw(ilsx_sac* s, const DwArgs& table, int rows, const AdamFuse* F) {
+  if (!s->col) return launch_bwd_dw(s->ctx, table, rows, F);
+  SacLaunch l; memset(&l, 0, sizeof l); l.kind = 2; l.d = table; l.F = *F;
+  s->col->L.push_back(l);
+  return ILSX_OK;
+}
+
 static int sac_critic_backward(ilsx_sac* s) {
   const SacWs& w = s->ws;
   const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
@@ -363,7 +404,7 @@ static int sac_critic_backward(ilsx_sac* s) {
       A.t[2].g0_off = 0; A.t[2].g1_off = s->o; A.t[2].publish = 0;
       A.t[3].g0_off = 0; A.t[3].publish = 0;                              // pi reads obs
     }
-    ILSX_TRY(launch_fwd(s->ctx, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
+    ILSX_TRY(sac_fwd(s, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
   }
   {  // fwd: TQ1(s',a'), TQ2(s',a')
     FwdArgs A;
@@ -372,7 +413,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     sac_q_task(s, A.t[0], W_TQ1, w.s2, w.a2, w.tq1, false, false, 0);
     sac_q_task(s, A.t[1], W_TQ2, w.s2, w.a2, w.tq2, false, false, 1);
     sac_policy_fin(s, A, eps1, s->rng_stream, false, w.a2, w.logp2, w.ppart);
-    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP, cs));
+    ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx with the TD-target loss head
     BwdArgs A;
@@ -389,7 +430,7 @@ static int sac_critic_backward(ilsx_sac* s) {
       t.q = s->pv(i == 0 ? w.q1 : w.q2); t.tq1 = s->pv(w.tq1); t.tq2 = s->pv(w.tq2);
       t.logp_next = w.logp2; t.rew = w.r; t.done = w.d;
     }
-    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act, cs));
+    ILSX_TRY(sac_bwd(s, A, H, act, cs));
   }
   AdamFuse F;
   memset(&F, 0, sizeof F);
@@ -398,7 +439,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     F.b1 = s->cfg.beta_1; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = s->cfg.soft_target_tau;
     F.step_size = &s->scal->adam_q_step; F.bc2_sqrt = &s->scal->adam_q_bc2s;
   }
-  return launch_bwd_dw(s->ctx, s->jobs_q, B, &F);
+  return sac_dw(s, s->jobs_q, B, &F);
 }
 
 static int sac_critic_update(ilsx_sac* s) {
@@ -424,7 +465,7 @@ static int sac_actor_backward(ilsx_sac* s) {
     sac_q_task(s, A.t[0], W_Q1, w.s, w.an, w.q1n, false, true, 0);
     sac_q_task(s, A.t[1], W_Q2, w.s, w.an, w.q2n, false, true, 1);
     sac_policy_fin(s, A, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
-    ILSX_TRY(launch_fwd(s->ctx, A, H, act, s->Lq.KP, cs));
+    ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx through both critics to the action columns
     BwdArgs A;
@@ -437,7 +478,7 @@ static int sac_actor_backward(ilsx_sac* s) {
       t.loss = LOSS_SAC_ACTORQ; t.which = i; t.q1n = s->pv(w.q1n); t.q2n = s->pv(w.q2n);
       t.dx = w.ga[i]; t.dx_col0 = s->o; t.dx_cols = s->a;
     }
-    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act, cs));
+    ILSX_TRY(sac_bwd(s, A, H, act, cs));
   }
   {  // bwd_dx of the policy with the tanh-Gaussian loss head
     BwdArgs A;
@@ -451,7 +492,7 @@ static int sac_actor_backward(ilsx_sac* s) {
     t.dhead = w.dhp;
     t.loss = LOSS_SAC_POLICY;
     t.raw = w.raw; t.eps = w.epss; t.action = w.an; t.ga1 = w.ga[0]; t.ga2 = w.ga[1];
-    ILSX_TRY(launch_bwd_dx(s->ctx, A, H, act, cs));
+    ILSX_TRY(sac_bwd(s, A, H, act, cs));
   }
   {
     AdamFuse F;
@@ -461,7 +502,7 @@ static int sac_actor_backward(ilsx_sac* s) {
       F.b1 = s->cfg.beta_1; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
       F.step_size = &s->scal->adam_pi_step; F.bc2_sqrt = &s->scal->adam_pi_bc2s;
     }
-    ILSX_TRY(launch_bwd_dw(s->ctx, s->jobs_p, B, &F));
+    ILSX_TRY(sac_dw(s, s->jobs_p, B, &F));
   }
   if (s->fuse_now) return ILSX_OK;  // stats run inside k_sac_tail (sac_actor_update)
   StatsArgs S = sac_stats_args(s);
@@ -493,6 +534,13 @@ static int sac_actor_update(ilsx_sac* s) {
   A.n = (int)s->np;
   A.b1 = s->cfg.beta_1; A.b2 = 0.999f; A.eps = 1e-8f; A.tau = 0.f;
   A.step_size = &s->scal->adam_pi_step; A.bc2_sqrt = &s->scal->adam_pi_bc2s;
+  if (s->fuse_now && s->col) {
+    SacLaunch l; memset(&l, 0, sizeof l); l.kind = 3;
+    l.t.S = sac_stats_args(s); l.t.train_alpha = s->cfg.train_alpha; l.t.lr = s->cfg.alpha_lr; l.t.b1 = s->cfg.beta_1;
+    l.t.b2 = 0.999f; l.t.eps = 1e-8f; l.t.qf_lr = s->cfg.qf_lr; l.t.policy_lr = s->cfg.policy_lr;
+    s->col->L.push_back(l);
+    return ILSX_OK;
+  }
   if (s->fuse_now) {
     ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
     hipLaunchKernelGGL(k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, sac_stats_args(s), s->cfg.train_alpha,
@@ -740,5 +788,199 @@ extern "C" int ilsx_sac_set_alpha_opt(ilsx_sac* s, double m, double v, int64_t t
   h.m_alpha = m; h.v_alpha = v; h.t_alpha = (int)t; h.step = rng_step;
   HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, s->ctx->stream));
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  return ILSX_OK;
+}
+
+// ================================================================================================ grouped agents
+// "within a GPU, the co-resident seeds are batched as grouped GEMMs (weights differ per seed)".  K independent
+// agents of identical shape step in lock-step: every stage of the fused step is ONE launch whose grid carries all agents'
+// tasks (descriptor tables in device memory, built once), so the step costs 9 dependent launches for K agents instead of
+// 9K, and each launch brings K times the workgroups to hide the dependent-load latency that bounds the single step.
+struct ilsx_sac_group {
+  ilsx_ctx* ctx = nullptr;
+  std::vector<ilsx_sac*> agents;
+  std::vector<ilsx_replay*> rbs;
+  int B = 0;
+  hipGraphExec_t graph = nullptr;
+  struct Stage {
+    int kind = 0, KP = 0, ntasks = 0;
+    FwdArgs f; BwdArgs b; DwArgs d;
+    void *tasks = nullptr, *groups = nullptr, *mats = nullptr, *tile_mat = nullptr, *fuses = nullptr, *tails = nullptr;
+  };
+  std::vector<Stage> stages;
+};
+
+template <class T>
+static int upload_table(ilsx_ctx* ctx, const std::vector<T>& v, void** dev) {
+  ILSX_TRY(ctx_alloc(ctx, v.size() * sizeof(T), dev, false));
+  HIPCHK(hipMemcpyAsync(*dev, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return ILSX_OK;
+}
+
+static void group_release_tables(ilsx_sac_group* g) {
+  for (auto& st : g->stages)
+    for (void* p : {st.tasks, st.groups, st.mats, st.tile_mat, st.fuses, st.tails})
+      if (p) ctx_free(g->ctx, p);
+  g->stages.clear();
+  if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+}
+
+// collect every agent's launch list for one fused step on (rbs, B) and merge stage by stage
+static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
+  const int K = (int)g->agents.size();
+  std::vector<SacCollector> cols(K);
+  for (int k = 0; k < K; ++k) {
+    ilsx_sac* s = g->agents[k];
+    s->B = B; s->eps_explicit = false; s->col = &cols[k]; s->gather_rb = rbs[k];
+    const int rc = sac_full_step(s);
+    s->col = nullptr; s->gather_rb = nullptr;
+    if (rc != ILSX_OK) return rc;
+    if (cols[k].L.size() != cols[0].L.size()) ILSX_FAIL(ILSX_ERR_STATE, "agents of a group must produce the same launch sequence");
+  }
+  group_release_tables(g);
+  const size_t nst = cols[0].L.size();
+  g->stages.resize(nst);
+  for (size_t i = 0; i < nst; ++i) {
+    ilsx_sac_group::Stage& st = g->stages[i];
+    st.kind = cols[0].L[i].kind;
+    for (int k = 0; k < K; ++k)
+      if (cols[k].L[i].kind != st.kind) ILSX_FAIL(ILSX_ERR_STATE, "agents of a group must produce the same launch sequence");
+    if (st.kind == 0) {
+      std::vector<FwdTask> tasks; std::vector<FwdGroup> groups;
+      st.f = cols[0].L[i].f; st.KP = cols[0].L[i].KP;
+      for (int k = 0; k < K; ++k) {
+        const FwdArgs& A = cols[k].L[i].f;
+        FwdGroup G; memset(&G, 0, sizeof G);
+        G.fin = A.fin; G.gather = A.gather; G.scal = A.scal; G.fin_on = A.fin_on;
+        groups.push_back(G);
+        for (int t = 0; t < A.ntasks; ++t) { FwdTask T = A.t[t]; T.agent = k; T.first = t == 0; tasks.push_back(T); }
+      }
+      st.ntasks = (int)tasks.size();
+      ILSX_TRY(upload_table(g->ctx, tasks, &st.tasks)); ILSX_TRY(upload_table(g->ctx, groups, &st.groups));
+      st.f.tasks = (const FwdTask*)st.tasks; st.f.groups = (const FwdGroup*)st.groups; st.f.ntasks = st.ntasks;
+    } else if (st.kind == 1) {
+      std::vector<BwdTask> tasks;
+      st.b = cols[0].L[i].b;
+      for (int k = 0; k < K; ++k) {
+        const BwdArgs& A = cols[k].L[i].b;
+        if (A.inv_B != st.b.inv_B || A.gamma != st.b.gamma || A.reward_scale != st.b.reward_scale || A.w_mu != st.b.w_mu ||
+            A.w_std != st.b.w_std)
+          ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "agents of a group must share discount / reward_scale / regulariser weights");
+        for (int t = 0; t < A.ntasks; ++t) { BwdTask T = A.t[t]; T.scal = A.scal; tasks.push_back(T); }
+      }
+      st.ntasks = (int)tasks.size();
+      ILSX_TRY(upload_table(g->ctx, tasks, &st.tasks));
+      st.b.tasks = (const BwdTask*)st.tasks; st.b.ntasks = st.ntasks;
+    } else if (st.kind == 2) {
+      std::vector<DwMat> mats; std::vector<int> tile_mat; std::vector<AdamFuse> fuses;
+      st.d = cols[0].L[i].d;
+      int tiles = 0;
+      for (int k = 0; k < K; ++k) {
+        const DwArgs& D = cols[k].L[i].d;
+        fuses.push_back(cols[k].L[i].F);
+        for (int m = 0; m < D.nmat; ++m) {
+          DwMat J = D.m[m];
+          const int n = (m + 1 < D.nmat ? D.m[m + 1].tile0 : D.ntiles) - J.tile0;
+          J.tile0 = tiles; J.agent = k;
+          for (int t = 0; t < n; ++t) tile_mat.push_back((int)mats.size());
+          mats.push_back(J);
+          tiles += n;
+        }
+      }
+      st.d.ntiles = tiles; st.d.nmat = (int)mats.size();
+      ILSX_TRY(upload_table(g->ctx, mats, &st.mats)); ILSX_TRY(upload_table(g->ctx, tile_mat, &st.tile_mat));
+      ILSX_TRY(upload_table(g->ctx, fuses, &st.fuses));
+      st.d.mats = (const DwMat*)st.mats; st.d.tile_mat = (const int*)st.tile_mat; st.d.fuses = (const AdamFuse*)st.fuses;
+      st.d.g_lo = nullptr;   // never the row-split path (B is the SAC batch)
+    } else {
+      std::vector<SacTailItem> items;
+      for (int k = 0; k < K; ++k) items.push_back(cols[k].L[i].t);
+      ILSX_TRY(upload_table(g->ctx, items, &st.tails));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  g->rbs.assign(rbs, rbs + K);
+  g->B = B;
+  return ILSX_OK;
+}
+
+static int group_launch_step(ilsx_sac_group* g) {
+  ilsx_sac* s0 = g->agents[0];
+  const int H = s0->Lq.cfg.hidden, act = s0->Lq.cfg.act, cs = s0->cs;
+  for (auto& st : g->stages) {
+    if (st.kind == 0) ILSX_TRY(launch_fwd(g->ctx, st.f, H, act, st.KP, cs));
+    else if (st.kind == 1) ILSX_TRY(launch_bwd_dx(g->ctx, st.b, H, act, cs));
+    else if (st.kind == 2) { AdamFuse on; memset(&on, 0, sizeof on); on.on = 1; ILSX_TRY(launch_bwd_dw(g->ctx, st.d, g->B, &on)); }
+    else {
+      ProfScope ps(g->ctx, ILSX_K_SAC_FINISH);
+      hipLaunchKernelGGL(k_sac_tail_group, dim3((unsigned)g->agents.size()), dim3(256), 0, g->ctx->stream, (const SacTailItem*)st.tails);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_sac_group_create(ilsx_ctx* ctx, ilsx_sac* const* agents, int n_agents, ilsx_sac_group** out) {
+  if (!ctx || !agents || !out || n_agents < 1 || n_agents > 64) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_group_create: bad argument");
+  for (int k = 0; k < n_agents; ++k) {
+    ilsx_sac* s = agents[k];
+    if (!s || s->ctx != ctx) ILSX_FAIL(ILSX_ERR_ARG, "every agent of a group must live in the group's ctx");
+    if (s->cs <= 1) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "grouped steps use the column-split kernels (2 hidden layers of 128 or 256)");
+    if (s->cfg.grad_world != 1) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "grouped agents are whole runs (grad_world == 1)");
+    if (memcmp(&s->Lq.cfg, &agents[0]->Lq.cfg, sizeof s->Lq.cfg) || memcmp(&s->Lp.cfg, &agents[0]->Lp.cfg, sizeof s->Lp.cfg) ||
+        s->cfg.max_batch != agents[0]->cfg.max_batch)
+      ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "agents of a group must have identical network shapes and max_batch");
+  }
+  ilsx_sac_group* g = new ilsx_sac_group();
+  g->ctx = ctx;
+  g->agents.assign(agents, agents + n_agents);
+  *out = g;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_sac_group_destroy(ilsx_sac_group* g) {
+  if (!g) return ILSX_OK;
+  hipSetDevice(g->ctx->device);
+  hipStreamSynchronize(g->ctx->stream);
+  group_release_tables(g);
+  delete g;
+  return ILSX_OK;
+}
+
+// n_steps lock-step gradient steps of every agent, agent k sampling from rbs[k] (TorchRLAlgorithm._do_training of K
+// independent runs).  want_stats: the last step also computes every agent's statistics (read with ilsx_sac_last_stats).
+extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* const* rbs, int n_steps, int B, int want_stats) {
+  if (!g || !rbs || n_steps < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_group_train_from_replay: bad argument");
+  const int K = (int)g->agents.size();
+  HIPCHK(hipSetDevice(g->ctx->device));
+  for (int k = 0; k < K; ++k) {
+    ilsx_sac* s = g->agents[k];
+    if (!rbs[k] || rbs[k]->o != s->o || rbs[k]->a != s->a) ILSX_FAIL(ILSX_ERR_ARG, "replay %d does not match its agent", k);
+    if (rbs[k]->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "replay buffer %d is empty", k);
+  }
+  if (B < 1 || B > g->agents[0]->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch", B);
+  bool rebuild = g->stages.empty() || g->B != B || (int)g->rbs.size() != K;
+  for (int k = 0; k < K && !rebuild; ++k) rebuild = g->rbs[k] != rbs[k];
+  if (rebuild) ILSX_TRY(group_build(g, rbs, B));
+  hipStream_t st = g->ctx->stream;
+  static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
+  const bool use_graph = !(no_graph || g->ctx->prof_on);
+  if (use_graph && !g->graph) {
+    hipGraph_t gr = nullptr;
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = group_launch_step(g);
+    hipError_t e = hipStreamEndCapture(st, &gr);
+    if (rc != ILSX_OK) { if (gr) hipGraphDestroy(gr); return rc; }
+    if (e != hipSuccess) ILSX_FAIL(ILSX_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&g->graph, gr, nullptr, nullptr, 0);
+    hipGraphDestroy(gr);
+    if (e != hipSuccess) { g->graph = nullptr; ILSX_FAIL(ILSX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+  }
+  for (int i = 0; i < n_steps; ++i) {
+    if (want_stats && i == n_steps - 1)
+      for (int k = 0; k < K; ++k) ILSX_TRY(sac_request_stats(g->agents[k]));
+    if (use_graph) HIPCHK(hipGraphLaunch(g->graph, st));
+    else ILSX_TRY(group_launch_step(g));
+  }
   return ILSX_OK;
 }

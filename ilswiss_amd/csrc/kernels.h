@@ -166,6 +166,7 @@ struct FwdTask {
   const int* rows_idx;               // nullable: row r of this launch reads source row rows_idx[r] (minibatch gather)
   const float* log_std;              // HEAD_GAUSS_*: state-independent log-std parameter [a]
   float noise, noise_clip, max_act;  // HEAD_DET_TANH_NOISE (noise == 0: deterministic)
+  int agent, first;                  // grouped launches (FwdArgs::tasks): owning agent, 1 = the agent's publishing task
 };
 // A per-row scalar (Q value) that may still be split into CS column-slice partial sums: summed in a fixed
 // order by whoever consumes it (the "combine in the next kernel's prologue" seam of a split-K reduction).
@@ -191,6 +192,7 @@ struct PolicyFinishArgs {
   const float* eps; const float* act_in;
   float *raw, *eps_save, *action, *logp;
 };
+struct FwdGroup;
 struct FwdArgs {
   FwdTask t[4];
   int rows, ntasks;
@@ -203,7 +205,11 @@ struct FwdArgs {
   PolicyFinishArgs fin;    //   policy whose head partials are combined + squashed here, in the consumer
   GatherSpec gather;       // rows drawn from the replay ring in-kernel (first launch of a SAC step)
   int xs;                  // XCD confinement: only workgroups with (blockIdx.x & ((1<<xs)-1)) == 0 work (grid.x <<= xs)
+  // grouped launch (several agents' tasks in one grid, SURVEY §8e "co-resident seeds as grouped GEMMs"): descriptor
+  // tables in device memory, built once per group; blockIdx.y indexes `tasks`, FwdTask::agent indexes `groups`
+  const FwdTask* tasks; const FwdGroup* groups;
 };
+struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
 
 #ifdef ILSX_KERNEL_IMPL
 template <int H, int ACT>
@@ -450,6 +456,7 @@ struct BwdTask {
   const float *lp_old, *act_all, *log_std, *mu;   // PPO: fixed log-probs [N], actions [N][a], log_std [a], mean [rows][a]
   float* aux;                          // PPO: per-row d(loss)/d(log_std) contributions [rows][a]
   float clip_eps;
+  const DevScalars* scal;              // grouped launches: this task's agent scalars (else BwdArgs::scal)
   float coef;                          // LOSS_TD_CRITIC: 1 (half-MSE) or 2 (MSE); LOSS_SACV_VALUE: alpha; LOSS_CONST: value;
 };                                     //   LOSS_TD3_POLICY: max_act
 struct BwdArgs {
@@ -462,17 +469,19 @@ struct BwdArgs {
   int ga_parts, ga_stride;  // LOSS_SAC_POLICY: ga1/ga2 hold ga_parts partial slabs of ga_stride rows each
   int part_stride;          // column-split kernels: rows of one dx partial slab
   int xs;                   // XCD confinement (see FwdArgs)
+  const BwdTask* tasks;     // grouped launch: descriptor table in device memory, indexed by blockIdx.y
 };
 
 // dL/d(head output j) of row gr for the loss functor of task T (shared by the generic and the column-split
 // backward kernels).
 __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& A, int gr, int j, int NO) {
   float d = 0.0f;
+  const DevScalars* scal = T.scal ? T.scal : A.scal;
   if (T.loss == LOSS_GIVEN) {
     d = T.given[(size_t)gr * NO + j];
   } else if (T.loss == LOSS_SAC_CRITIC) {
     // sac_alpha.py:110-123: y = r + (1-d)*gamma*(min(TQ1,TQ2) - alpha*logpi'); dL/dq = (q-y)/B
-    const float alpha = A.scal->alpha;
+    const float alpha = scal->alpha;
     const float r = A.reward_scale * T.rew[gr];
     const float y = r + (1.0f - T.done[gr]) * A.gamma * (fminf(T.tq1.get(gr), T.tq2.get(gr)) - alpha * T.logp_next[gr]);
     d = (T.q.get(gr) - y) * A.inv_B;
@@ -515,7 +524,7 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
     if (T.aux) T.aux[(size_t)gr * NO + j] = dlp * (diff * diff / var - 1.0f);
   } else {  // LOSS_SAC_POLICY: SURVEY Appendix A.1/A.2 ; j < a -> d mu_j, else d log_std_raw_{j-a}
     const int a = NO >> 1, jj = j < a ? j : j - a;
-    const float alpha = A.scal->alpha;
+    const float alpha = scal->alpha;
     const float glp = alpha * A.inv_B;
     const float inv_Ba = A.inv_B / (float)a;
     const float mu = T.raw[(size_t)gr * NO + jj], lsr = T.raw[(size_t)gr * NO + a + jj];
@@ -655,13 +664,15 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
 // prologue (PartVal) or by k_policy_finish; backward input-gradients leave as CS partial slabs likewise.
 // block = 4*H/CS threads; wave w owns column tile(s) [w*CS, (w+1)*CS) of layer 0 and tile cs*NWV+w of layer 1.
 #ifdef ILSX_KERNEL_IMPL
-template <int H, int ACT, int CS>
+template <int H, int ACT, int CS, bool GRP>
 __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) {
   constexpr int NTH = 4 * H / CS, NWV = NTH / 64, NC = H / 16, SLW = H / CS, NCS = SLW / 16;
   constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
   static_assert(NCS == NWV, "one k16 chunk of the slice per wave in the head phase");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const FwdTask& T = A.t[blockIdx.y];
+  const FwdTask& T = GRP ? A.tasks[blockIdx.y] : A.t[blockIdx.y];   // GRP: descriptor tables in device memory
+  const FwdGroup* GP = GRP ? A.groups + T.agent : nullptr;
+  const DevScalars* scal = GRP ? GP->scal : A.scal;
   const NetView& N = T.net;
   const int KP = N.KP, LDX = KP + ILSX_LDS_PAD, NO = N.NO, NCH0 = KP >> 4, NOT = (NO + 15) >> 4;
   float* xs = smem;                 // [16][LDX]
@@ -679,16 +690,16 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   float4 b0[CS];
 #pragma unroll
   for (int i = 0; i < CS; ++i) b0[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256);
-  const bool fin = A.fin_on != 0;
+  const bool fin = (GRP ? GP->fin_on : A.fin_on) != 0;
+  const GatherSpec& G = GRP ? GP->gather : A.gather;
   for (int e = tid; e < 16 * KP; e += NTH) {
     const int r = e / KP, k = e - r * KP, gr = r0 + r;
     const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
     if (fin && act_col) continue;   // filled by the policy epilogue below
     float v = 0.0f;
     if (gr < rows) {
-      if (A.gather.on) {   // fused sample+index (simple_replay_buffer.py:239-293): row gr of the batch is record idx
-        const GatherSpec& G = A.gather;
-        const long long idx = replay_draw(G.seed, A.scal->step, G.stream, (uint32_t)gr, G.st->size);
+      if (G.on) {   // fused sample+index (simple_replay_buffer.py:239-293): row gr of the batch is record idx
+        const long long idx = replay_draw(G.seed, scal->step, G.stream, (uint32_t)gr, G.st->size);
         const float* rec = G.records + (size_t)idx * G.rec;
         if (k < T.d0) v = rec[T.g0_off + k];
         else if (act_col) v = rec[T.g1_off + (k - T.d0)];
@@ -710,9 +721,9 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   if (fin) {
     // the action columns are pi's output: combine its CS head partials, squash (policies.py:262-283,
     // distributions.py:23-28,43-50,74-97); slice 0 of task 0 publishes action / logp / raw / eps for later kernels
-    const PolicyFinishArgs& P = A.fin;
+    const PolicyFinishArgs& P = GRP ? GP->fin : A.fin;
     const int a = P.a, NOp = 2 * a;
-    const bool pub = lead && blockIdx.y == 0;
+    const bool pub = lead && (GRP ? T.first != 0 : blockIdx.y == 0);
     float* lp3 = red;   // [16][32][3] log-prob contributions (quad, log_std, jacobian)
     for (int e = tid; e < 16 * a; e += NTH) {
       const int row = e / a, j = e - row * a, gr = r0 + row;
@@ -910,14 +921,14 @@ __global__ __launch_bounds__(64) void k_policy_finish(const PolicyFinishArgs P) 
   if (P.logp) P.logp[gr] = -0.5f * lp_quad - (lp_ls + HALF_LOG_2PI) - lp_jac;
 }
 
-template <int H, int ACT, int CS>
+template <int H, int ACT, int CS, bool GRP>
 __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) {
   constexpr int NTH = 4 * H / CS, NWV = NTH / 64, NC = H / 16, SLW = H / CS, RPW = 16 / NWV, KPL = SLW / 64;
   constexpr int RPT = 16 * H / NTH, RSTEP = NTH / H;   // delta_1: thread <-> one column, RPT rows RSTEP apart
   constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
   static_assert(NTH % H == 0 && RPW >= 1 && KPL >= 1, "unsupported split geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const BwdTask& T = A.t[blockIdx.y];
+  const BwdTask& T = GRP ? A.tasks[blockIdx.y] : A.t[blockIdx.y];
   const NetView& N = T.net;
   const int NO = N.NO;
   float* d1 = smem;                      // [16][LDH]  delta_1, all H columns
@@ -1049,6 +1060,7 @@ struct DwMat {
   int lda, NA, ldb, NB, ldw, mode;   // ldw: natural row stride, or K (PACK_F); NA rows for PACK_B
   int rows, bias_rows;               // > 0: contract over `rows` (row-stacked jobs); only the first bias_rows feed db
   int tile0, ktiles;                 // first workgroup of this matrix, number of 64-wide k tiles
+  int agent;                         // grouped launches: index into DwArgs::fuses
 };
 #define DW_MAX_MATS 10
 // Optional optimiser epilogue of the dW kernel: every workgroup owns its output tile completely (the batch
@@ -1072,6 +1084,8 @@ struct DwArgs {
   int splits, rows_per_split;
   float* g_lo; float* g_hi;   // extent of the gradient arena the table's matrices live in (set by build_dw_jobs)
   float* scratch; size_t span;
+  // grouped launch: matrix / optimiser tables in device memory, tile -> matrix map
+  const DwMat* mats; const int* tile_mat; const AdamFuse* fuses;
 };
 #define DW_SPLIT_MIN_ROWS 1024
 #define DW_TILE_N 32
@@ -1100,6 +1114,7 @@ __device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float 
   }
 }
 
+template <bool GRP>
 __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* part = smem;                    // [16 waves][16 acc regs][64 lanes]
@@ -1107,11 +1122,15 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   if (blockIdx.x & ((1u << D.xs) - 1u)) return;
   const int bx = blockIdx.x >> D.xs;
   int mi = 0;
+  if (GRP) {
+    mi = D.tile_mat[bx];
+  } else {
 #pragma unroll
-  for (int i = 1; i < DW_MAX_MATS; ++i)
-    if (i < D.nmat && bx >= D.m[i].tile0) mi = i;
-  const DwMat& J = D.m[mi];
-  const AdamFuse& F = D.F;
+    for (int i = 1; i < DW_MAX_MATS; ++i)
+      if (i < D.nmat && bx >= D.m[i].tile0) mi = i;
+  }
+  const DwMat& J = GRP ? D.mats[mi] : D.m[mi];
+  const AdamFuse& F = GRP ? D.fuses[J.agent] : D.F;
   const int local = bx - J.tile0;
   const int n0 = (local / J.ktiles) * DW_TILE_N, k0 = (local % J.ktiles) * DW_TILE_K;
   int rows = J.rows > 0 ? J.rows : D.rows_all, brows = J.rows > 0 ? J.bias_rows : D.rows_all;

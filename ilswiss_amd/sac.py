@@ -220,3 +220,28 @@ class SoftActorCritic(Trainer):
 
     def actor_update(self):
         _lib.check(self.ctx.lib.ilsx_sac_actor_update(self.h))
+
+
+class SoftActorCriticGroup:
+    """K independent SoftActorCritic runs (seeds) of identical shape stepped in lock-step on one GPU, every stage of the
+    step being ONE launch for all of them (ilsx_sac_group).  The trainers stay ordinary objects."""
+
+    def __init__(self, trainers):
+        self.trainers, self.ctx = list(trainers), trainers[0].ctx
+        arr = (C.c_void_p * len(self.trainers))(*[t.h for t in self.trainers])
+        self.h = C.c_void_p()
+        _lib.check(self.ctx.lib.ilsx_sac_group_create(self.ctx.h, arr, len(self.trainers), C.byref(self.h)))
+
+    def train_from_replay(self, replay_buffers, n_steps, batch_size):
+        want = any(t.eval_statistics is None for t in self.trainers)
+        arr = (C.c_void_p * len(self.trainers))(*[rb.h for rb in replay_buffers])
+        _lib.check(self.ctx.lib.ilsx_sac_group_train_from_replay(self.h, arr, int(n_steps), int(batch_size), int(want)))
+        if want:
+            for t in self.trainers:
+                _lib.check(self.ctx.lib.ilsx_sac_last_stats(t.h, C.byref(t._stats)))
+                t._fill_stats()
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.ilsx_sac_group_destroy(self.h)
+            self.h = None

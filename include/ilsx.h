@@ -43,6 +43,7 @@ typedef struct ilsx_ctx ilsx_ctx;
 typedef struct ilsx_net ilsx_net;
 typedef struct ilsx_replay ilsx_replay;
 typedef struct ilsx_sac ilsx_sac;
+typedef struct ilsx_sac_group ilsx_sac_group;
 typedef struct ilsx_vecenv ilsx_vecenv;
 typedef struct ilsx_disc ilsx_disc;
 typedef struct ilsx_ppo ilsx_ppo;
@@ -229,6 +230,18 @@ int ilsx_disc_train_step(ilsx_disc* disc, const float* exp_obs, const float* exp
 /* reward relabelling: rew[n] (nullable) by mode + optional clip; logits[n] (nullable) = clamped D(s,a) */
 int ilsx_disc_reward(ilsx_disc* disc, const float* obs, const float* act, int n, int mode, int has_min, float rew_clip_min,
                      int has_max, float rew_clip_max, float* rew, float* logits);
+
+/* ---------------------------------------------------------------- co-resident seeds
+ * The reference runs a seed sweep as independent processes (run_experiment.py:57-78).  A group steps K independent
+ * SoftActorCritic agents of identical shape in lock-step on ONE GPU: every stage of the fused step is one launch whose grid
+ * carries all agents' tasks ("grouped GEMMs, weights differ per seed"), so K runs cost 9 dependent launches per step
+ * instead of 9K.  The agents stay ordinary ilsx_sac objects (parameters, statistics, snapshots through their own entry
+ * points); results are bit-identical to stepping each agent alone with ilsx_sac_train_from_replay. */
+int ilsx_sac_group_create(ilsx_ctx* ctx, ilsx_sac* const* agents, int n_agents, ilsx_sac_group** out);
+int ilsx_sac_group_destroy(ilsx_sac_group* group);
+/* n_steps gradient steps of every agent; agent k samples its batch from rbs[k].  want_stats: the last step also
+ * computes every agent's statistics (read them with ilsx_sac_last_stats). */
+int ilsx_sac_group_train_from_replay(ilsx_sac_group* group, ilsx_replay* const* rbs, int n_steps, int B, int want_stats);
 
 /* AdvIRL._do_training (adv_irl.py:126-131) for one train call: `loops` x { disc_updates discriminator steps ;
  * policy_updates SAC steps on rewards relabelled by the discriminator (mode / clips as ilsx_disc_reward) }, every batch

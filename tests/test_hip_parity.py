@@ -469,3 +469,45 @@ def test_train_from_replay_graph_equals_direct_and_learns(ctx, monkeypatch):
         finals.append(tr.get_params("qf1"))
         c2.close()
     np.testing.assert_array_equal(finals[0], finals[1])
+
+
+@pytest.mark.gpu
+def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx):
+    """K=3 co-resident seeds stepped by ONE launch per stage (ilsx_sac_group) == each agent stepped alone with
+    ilsx_sac_train_from_replay: same kernels, same per-agent Philox streams, so every parameter is bit-identical."""
+    import ilswiss_amd as ia
+    from ilswiss_amd.replay import SimpleReplayBuffer
+    o, a, hid, B, K, n = 11, 3, [256, 256], 256, 3, 7
+    rng = np.random.default_rng(5)
+    N = 5000
+    data = [(rng.normal(0, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),
+             rng.normal(0, 1, N).astype(np.float32), rng.random(N) < 0.01, rng.normal(0, 1, (N, o)).astype(np.float32)) for _ in range(K)]
+
+    def make(k, ctx_k):
+        rb = SimpleReplayBuffer(8192, o, a, random_seed=k, ctx=ctx_k)
+        rb.add_rows(*data[k])
+        pol = ia.ReparamTanhMultivariateGaussianPolicy(hid, o, a, ctx=ctx_k, seed=10 + k)
+        q1, q2 = ia.FlattenMlp(hid, 1, o + a, ctx=ctx_k, seed=20 + k), ia.FlattenMlp(hid, 1, o + a, ctx=ctx_k, seed=30 + k)
+        tr = ia.SoftActorCritic(pol, q1, q2, policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+        return rb, tr
+    # the per-object Philox stream ids come from the ctx's allocation counter: build both worlds in fresh, identically
+    # ordered contexts so that agent k gets the same streams in both
+    c1, c2 = ia.Context(0, seed=77), ia.Context(0, seed=77)
+    solo, grouped = [make(k, c1) for k in range(K)], [make(k, c2) for k in range(K)]
+    for rb, tr in solo:
+        tr.eval_statistics = {}
+        tr.train_from_replay(rb, n, B)
+    grp = ia.SoftActorCriticGroup([tr for _, tr in grouped])
+    for _, tr in grouped:
+        tr.eval_statistics = {}
+    grp.train_from_replay([rb for rb, _ in grouped], n - 1, B)
+    for _, tr in grouped:
+        tr.eval_statistics = None          # ask for statistics on the last step
+    grp.train_from_replay([rb for rb, _ in grouped], 1, B)
+    for (_, t1), (_, t2) in zip(solo, grouped):
+        for name in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+            np.testing.assert_array_equal(t1.get_params(name), t2.get_params(name), err_msg=name)
+        assert t1.log_alpha == t2.log_alpha
+        assert np.isfinite(t2.eval_statistics["QF1 Loss"]) and t2.eval_statistics["QF1 Loss"] > 0
+    assert np.abs(solo[0][1].get_params("policy") - solo[1][1].get_params("policy")).max() > 1e-4   # the seeds differ
+    grp.close(); c1.close(); c2.close()
