@@ -109,26 +109,28 @@ __global__ __launch_bounds__(256) void k_ppo_gae(const float* __restrict__ value
 }
 
 // ---- sum of squares of the policy gradient (every parameter once) + d/d log_std = column sums of the aux rows
+#define PPO_MAX_A 32
 struct PpoNormArgs {
   const float* G; int n;
   int skip0[2], skip1[2];                    // [skip0, skip1): second packings of hidden->hidden matrices (not parameters)
   const float* aux; int rows, a;
-  float* g_logstd;                           // [a] (part of the gradient arena)
-  float* partial;                            // [gridDim.x]
+  float* partial;                            // [gridDim.x] sum of squares of this block's share of the mean-net gradient
+  float* partial_ls;                         // [gridDim.x][a] this block's share of the log_std gradient (column sums of aux)
 };
 __global__ __launch_bounds__(256) void k_ppo_norm(const PpoNormArgs P) {
   __shared__ float sh[4];
   float s = 0.0f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < P.n; i += gridDim.x * 256)
     if ((i < P.skip0[0] || i >= P.skip1[0]) && (i < P.skip0[1] || i >= P.skip1[1])) { const float g = P.G[i]; s += g * g; }
-  if (blockIdx.x == 0 && threadIdx.x < P.a) {   // log_std gradient, fixed summation order
-    float c = 0.0f;
-    for (int r = 0; r < P.rows; ++r) c += P.aux[(size_t)r * P.a + threadIdx.x];
-    P.g_logstd[threadIdx.x] = c;
-    s += c * c;
-  }
   s = block256_sum(s, sh);
   if (threadIdx.x == 0) P.partial[blockIdx.x] = s;
+  // log_std gradient: rows strided over (block, thread), summed per column in a fixed order
+  for (int j = 0; j < P.a; ++j) {
+    float c = 0.0f;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < P.rows; r += gridDim.x * 256) c += P.aux[(size_t)r * P.a + j];
+    c = block256_sum(c, sh);
+    if (threadIdx.x == 0) P.partial_ls[blockIdx.x * P.a + j] = c;
+  }
 }
 
 // torch.randperm stand-in (ppo.py:116) without a host shuffle: a keyed 4-round Feistel network over the 2^k >= N index
@@ -154,16 +156,26 @@ __global__ __launch_bounds__(256) void k_ppo_perm(int* __restrict__ perm, int n,
 }
 
 struct PpoClipAdamArgs {
-  float* P; const float* G; float* M; float* V; int n;   // whole policy arena incl. log_std (and both W1 packings)
-  const float* partial; int nparts;
+  float* P; float* G; float* M; float* V; int n;   // whole policy arena incl. log_std (and both W1 packings)
+  int n_mean, a;                                    // log_std lives at [n_mean, n_mean + a)
+  const float* partial; const float* partial_ls; int nparts;
   float max_norm, b1, b2, eps;
   PpoScalars* sc;
 };
 __global__ __launch_bounds__(256) void k_ppo_clip_adam(const PpoClipAdamArgs A) {
   __shared__ float s_coef;
+  __shared__ float s_gls[PPO_MAX_A];
+  if (threadIdx.x < A.a) {   // every block rebuilds the log_std gradient from the per-block column sums (fixed order)
+    float c = 0.0f;
+    for (int i = 0; i < A.nparts; ++i) c += A.partial_ls[i * A.a + threadIdx.x];
+    s_gls[threadIdx.x] = c;
+    if (blockIdx.x == 0) A.G[A.n_mean + threadIdx.x] = c;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int i = 0; i < A.nparts; ++i) tot += (double)A.partial[i];
+    for (int j = 0; j < A.a; ++j) tot += (double)s_gls[j] * (double)s_gls[j];
     const double norm = sqrt(tot);
     const double coef = (double)A.max_norm / (norm + 1e-6);   // torch.nn.utils.clip_grad_norm_
     s_coef = coef < 1.0 ? (float)coef : 1.0f;
@@ -172,7 +184,8 @@ __global__ __launch_bounds__(256) void k_ppo_clip_adam(const PpoClipAdamArgs A) 
   __syncthreads();
   const float coef = s_coef, step = A.sc->p_step, bc2s = A.sc->p_bc2s;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < A.n; i += gridDim.x * 256) {
-    const float g = A.G[i] * coef;
+    const float graw = (i >= A.n_mean && i < A.n_mean + A.a) ? s_gls[i - A.n_mean] : (i >= A.n_mean ? 0.0f : A.G[i]);
+    const float g = graw * coef;
     const float m = A.M[i] * A.b1 + (1.0f - A.b1) * g;
     const float v = A.V[i] * A.b2 + (1.0f - A.b2) * g * g;
     A.M[i] = m; A.V[i] = v;
@@ -221,6 +234,7 @@ static int ppo_refresh(ilsx_ppo* p, int which) {
 extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo** out) {
   if (!ctx || !cfg || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_create: NULL argument");
   if (cfg->max_samples < 1 || cfg->mini_batch_size < 1) ILSX_FAIL(ILSX_ERR_ARG, "max_samples / mini_batch_size must be >= 1");
+  if (cfg->act_dim > PPO_MAX_A) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "act_dim %d > %d", cfg->act_dim, PPO_MAX_A);
   HIPCHK(hipSetDevice(ctx->device));
   ilsx_ppo* p = new ilsx_ppo();
   p->ctx = ctx; p->cfg = *cfg; p->o = cfg->obs_dim; p->a = cfg->act_dim;
@@ -260,7 +274,7 @@ extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo*
   if (rc == ILSX_OK) rc = A(&p->mu, mb * p->a);
   if (rc == ILSX_OK) rc = A(&p->lp, mb);
   if (rc == ILSX_OK) rc = A(&p->aux, mb * p->a);
-  if (rc == ILSX_OK) rc = A(&p->partial, 64);
+  if (rc == ILSX_OK) rc = A(&p->partial, 64 + 64 * PPO_MAX_A);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, (N + 1) * sizeof(int), (void**)&p->offs);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * sizeof(int), (void**)&p->perm);
   if (rc != ILSX_OK) { delete p; return rc; }
@@ -422,12 +436,12 @@ static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const 
       Nn.skip0[l - 1] = l < nh ? p->Lp.off_Wb[l] : 0;
       Nn.skip1[l - 1] = l < nh ? p->Lp.off_Wb[l] + H * H : 0;
     }
-    Nn.aux = p->aux; Nn.rows = rows; Nn.a = p->a; Nn.g_logstd = p->g_log_std(); Nn.partial = p->partial;
+    Nn.aux = p->aux; Nn.rows = rows; Nn.a = p->a; Nn.partial = p->partial; Nn.partial_ls = p->partial + 64;
     const int nblk = 32;
     hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
     PpoClipAdamArgs C;
     C.P = p->Pp; C.G = p->Gp; C.M = p->Mp; C.V = p->Vp; C.n = (int)p->np;
-    C.partial = p->partial; C.nparts = nblk; C.max_norm = 20.0f; C.b1 = 0.9f; C.b2 = 0.999f; C.eps = 1e-8f; C.sc = p->sc;
+    C.partial = p->partial; C.partial_ls = p->partial + 64; C.nparts = nblk; C.n_mean = (int)p->Lp.n_int; C.a = p->a; C.max_norm = 20.0f; C.b1 = 0.9f; C.b2 = 0.999f; C.eps = 1e-8f; C.sc = p->sc;
     hipLaunchKernelGGL(k_ppo_clip_adam, dim3(64), dim3(256), 0, ctx->stream, C);
     HIPCHK(hipGetLastError());
     ILSX_TRY(ppo_refresh(p, 1));
