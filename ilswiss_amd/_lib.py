@@ -31,7 +31,8 @@ class SacStats(C.Structure):
     _fields_ = [("qf1_loss", C.c_float), ("qf2_loss", C.c_float), ("policy_loss", C.c_float),
                 ("alpha_loss", C.c_float), ("alpha", C.c_float), ("q1_mean", C.c_float),
                 ("q2_mean", C.c_float), ("log_pi_mean", C.c_float), ("policy_mu_mean", C.c_float),
-                ("policy_log_std_mean", C.c_float), ("log_alpha", C.c_double)]
+                ("policy_log_std_mean", C.c_float), ("log_alpha", C.c_double),
+                ("ext_std", C.c_float * 5), ("ext_max", C.c_float * 5), ("ext_min", C.c_float * 5)]
 
 
 _MB, _MG = 8, 8

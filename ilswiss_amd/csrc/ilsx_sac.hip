@@ -106,12 +106,17 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
   __shared__ float sh[4];
   const float alpha = S.scal->alpha;
   float l1 = 0, l2 = 0, pl = 0, lp = 0, mu2 = 0, ls2 = 0, mus = 0, lss = 0, q1s = 0, q2s = 0, lpe = 0;
+  float sq[3] = {0.f, 0.f, 0.f};                                   // sums of squares of q1, q2, log pi (mu / log std: mu2, ls2)
+  float mx[5] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
   for (int r = threadIdx.x; r < S.B; r += 256) {
     const float y = S.reward_scale * S.r[r] +
                     (1.0f - S.d[r]) * S.gamma * (fminf(S.tq1.get(r), S.tq2.get(r)) - alpha * S.logp2[r]);
     const float q1v = S.q1.get(r), q2v = S.q2.get(r);
     const float e1 = q1v - y, e2 = q2v - y;
     l1 += e1 * e1; l2 += e2 * e2; q1s += q1v; q2s += q2v;
+    sq[0] += q1v * q1v; sq[1] += q2v * q2v; sq[2] += S.logp[r] * S.logp[r];
+    mx[0] = fmaxf(mx[0], q1v); mn[0] = fminf(mn[0], q1v); mx[1] = fmaxf(mx[1], q2v); mn[1] = fminf(mn[1], q2v);
+    mx[2] = fmaxf(mx[2], S.logp[r]); mn[2] = fminf(mn[2], S.logp[r]);
     pl += alpha * S.logp[r] - fminf(S.q1n.get(r), S.q2n.get(r));
     lp += S.logp[r];
     lpe += S.logp[r] + S.target_entropy;
@@ -119,11 +124,27 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
       const float mu = S.raw[(size_t)r * 2 * S.a + j];
       const float ls = fminf(fmaxf(S.raw[(size_t)r * 2 * S.a + S.a + j], LOG_SIG_MIN), LOG_SIG_MAX);
       mu2 += mu * mu; ls2 += ls * ls; mus += mu; lss += ls;
+      mx[3] = fmaxf(mx[3], mu); mn[3] = fminf(mn[3], mu); mx[4] = fmaxf(mx[4], ls); mn[4] = fminf(mn[4], ls);
     }
   }
   l1 = block256_sum(l1, sh); l2 = block256_sum(l2, sh); pl = block256_sum(pl, sh); lp = block256_sum(lp, sh);
   mu2 = block256_sum(mu2, sh); ls2 = block256_sum(ls2, sh); mus = block256_sum(mus, sh); lss = block256_sum(lss, sh);
   q1s = block256_sum(q1s, sh); q2s = block256_sum(q2s, sh); lpe = block256_sum(lpe, sh);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sq[i] = block256_sum(sq[i], sh);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {   // block extrema: wave butterflies, then the 4 wave results through LDS
+    float a = mx[i], b = mn[i];
+    for (int o = 32; o >= 1; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); b = fminf(b, __shfl_xor(b, o, 64)); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    mx[i] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = b;
+    __syncthreads();
+    mn[i] = fminf(fminf(sh[0], sh[1]), fminf(sh[2], sh[3]));
+  }
   if (threadIdx.x == 0) {
     const float iB = 1.0f / (float)S.B, iBa = iB / (float)S.a;
     DevScalars* sc = S.scal;
@@ -133,6 +154,12 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
     sc->alpha_loss = -(float)sc->log_alpha * (lpe * iB);
     sc->q1_mean = q1s * iB; sc->q2_mean = q2s * iB; sc->log_pi_mean = lp * iB;
     sc->mu_mean = mus * iBa; sc->log_std_mean = lss * iBa;
+    const float means[5] = {sc->q1_mean, sc->q2_mean, sc->log_pi_mean, sc->mu_mean, sc->log_std_mean};
+    const float msq[5] = {sq[0] * iB, sq[1] * iB, sq[2] * iB, mu2 * iBa, ls2 * iBa};
+    for (int i = 0; i < 5; ++i) {   // np.std: population standard deviation
+      sc->ext_std[i] = sqrtf(fmaxf(msq[i] - means[i] * means[i], 0.0f));
+      sc->ext_max[i] = mx[i]; sc->ext_min[i] = mn[i];
+    }
     sc->alpha_used = alpha;
     sc->log_alpha_used = sc->log_alpha;
     S.alpha_grad_slot[0] = -lpe * S.inv_B;  // d(alpha_loss)/d(log_alpha), summed over ranks by the all-reduce
@@ -589,6 +616,7 @@ static int sac_read_stats(ilsx_sac* s, ilsx_sac_stats* out) {
   out->q1_mean = h.q1_mean; out->q2_mean = h.q2_mean; out->log_pi_mean = h.log_pi_mean;
   out->policy_mu_mean = h.mu_mean; out->policy_log_std_mean = h.log_std_mean;
   out->log_alpha = h.log_alpha;
+  for (int i = 0; i < 5; ++i) { out->ext_std[i] = h.ext_std[i]; out->ext_max[i] = h.ext_max[i]; out->ext_min[i] = h.ext_min[i]; }
   return ILSX_OK;
 }
 

@@ -63,6 +63,8 @@ struct DevScalars {
   float q1_mean, q2_mean, log_pi_mean, mu_mean, log_std_mean;
   // Adam bias-correction scalars for the NEXT step: lr/(1-b1^t), sqrt(1-b2^t)   (t = t_x + 1)
   float adam_q_step, adam_q_bc2s, adam_pi_step, adam_pi_bc2s;
+  // Std / Max / Min of the five batch quantities of create_stats_ordered_dict (sac_alpha.py:202-233): q1, q2, log pi, mu, log std
+  float ext_std[5], ext_max[5], ext_min[5];
   int want_stats;   // host sets 1 before the step whose statistics it will read (sac_alpha.py:186: one batch per epoch)
 };
 

@@ -97,17 +97,22 @@ class SoftActorCritic(Trainer):
         if want:
             self._fill_stats()
 
-    def _fill_stats(self):  # sac_alpha.py:186-233 (scalar part; Std/Max/Min of the batch are not tracked)
+    def _fill_stats(self):  # sac_alpha.py:186-233
         s, st = self._stats, OrderedDict()
         st["Reward Scale"] = self.reward_scale
         st["QF1 Loss"], st["QF2 Loss"] = s.qf1_loss, s.qf2_loss
         if self.train_alpha:
             st["Alpha Loss"] = s.alpha_loss
         st["Policy Loss"] = s.policy_loss
-        st["Q1 Predictions Mean"], st["Q2 Predictions Mean"] = s.q1_mean, s.q2_mean
+
+        def block(name, mean, i):  # create_stats_ordered_dict: Mean / Std / Max / Min
+            st[name + " Mean"], st[name + " Std"], st[name + " Max"], st[name + " Min"] = mean, s.ext_std[i], s.ext_max[i], s.ext_min[i]
+        block("Q1 Predictions", s.q1_mean, 0)
+        block("Q2 Predictions", s.q2_mean, 1)
         st["Alpha"] = s.alpha
-        st["Log Pis Mean"] = s.log_pi_mean
-        st["Policy mu Mean"], st["Policy log std Mean"] = s.policy_mu_mean, s.policy_log_std_mean
+        block("Log Pis", s.log_pi_mean, 2)
+        block("Policy mu", s.policy_mu_mean, 3)
+        block("Policy log std", s.policy_log_std_mean, 4)
         self.eval_statistics = st
 
     def get_eval_statistics(self):

@@ -161,6 +161,8 @@ typedef struct {              /* scalars of sac_alpha.py:186-233 for the step ju
   float qf1_loss, qf2_loss, policy_loss, alpha_loss, alpha;
   float q1_mean, q2_mean, log_pi_mean, policy_mu_mean, policy_log_std_mean;
   double log_alpha;
+  /* Std / Max / Min of {Q1 Predictions, Q2 Predictions, Log Pis, Policy mu, Policy log std} (sac_alpha.py:202-233) */
+  float ext_std[5], ext_max[5], ext_min[5];
 } ilsx_sac_stats;
 
 /* Takes over the storage of pi/q1/q2 (they become views into the agent's parameter arena and stay

@@ -168,6 +168,11 @@ def test_sac_steps_vs_oracle(ctx, o, a, H, nhid, B, kw):
             np.testing.assert_allclose(st[k_ref], res[k_or], rtol=2e-4, atol=2e-6, err_msg=f"{k_ref} step {s}")
         np.testing.assert_allclose(st["Q1 Predictions Mean"], res["q1_pred"].mean(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(st["Log Pis Mean"], res["log_pi"].mean(), rtol=1e-4, atol=1e-5)
+        for name, arr in (("Q1 Predictions", res["q1_pred"]), ("Q2 Predictions", res["q2_pred"]), ("Log Pis", res["log_pi"]),
+                          ("Policy mu", res["policy_mean"]), ("Policy log std", res["policy_log_std"])):   # create_stats_ordered_dict
+            np.testing.assert_allclose(st[name + " Std"], arr.std(), rtol=2e-3, atol=2e-4, err_msg=name)
+            np.testing.assert_allclose(st[name + " Max"], arr.max(), rtol=1e-4, atol=1e-5, err_msg=name)
+            np.testing.assert_allclose(st[name + " Min"], arr.min(), rtol=1e-4, atol=1e-5, err_msg=name)
         for nm, key in (("qf1", "q1_grad"), ("qf2", "q2_grad"), ("policy", "pi_grad")):
             got, ref = tr.get_grads(nm), res[key]
             assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, (s, nm, np.abs(got - ref).max(), np.abs(ref).max())
