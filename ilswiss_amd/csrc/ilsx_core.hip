@@ -425,7 +425,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
   D.xs = ctx->xcd_shift;
   D.splits = 1; D.rows_per_split = rows; D.scratch = nullptr; D.span = 0;
   bool stacked = false;
-  for (int i = 0; i < D.nmat && !D.mats; ++i) stacked = stacked || D.m[i].rows > 0;
+  for (int i = 0; i < D.nmat && !D.gtiles; ++i) stacked = stacked || D.m[i].rows > 0;
   if (rows >= DW_SPLIT_MIN_ROWS && D.g_lo && !stacked) {   // large batch: split the contraction over row ranges
     int splits = rows / 512;
     if (splits > 32) splits = 32;
@@ -456,7 +456,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     return ILSX_OK;
   }
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-  if (D.mats) hipLaunchKernelGGL(k_mlp_bwd_dw<true>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+  if (D.gtiles) hipLaunchKernelGGL(k_mlp_bwd_dw<true>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
   else hipLaunchKernelGGL(k_mlp_bwd_dw<false>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
   HIPCHK(hipGetLastError());
   return ILSX_OK;

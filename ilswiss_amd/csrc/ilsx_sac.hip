@@ -833,7 +833,7 @@ struct ilsx_sac_group {
   struct Stage {
     int kind = 0, KP = 0, ntasks = 0;
     FwdArgs f; BwdArgs b; DwArgs d;
-    void *tasks = nullptr, *groups = nullptr, *mats = nullptr, *tile_mat = nullptr, *fuses = nullptr, *tails = nullptr;
+    void *tasks = nullptr, *gtiles = nullptr, *tails = nullptr;
   };
   std::vector<Stage> stages;
 };
@@ -847,7 +847,7 @@ static int upload_table(ilsx_ctx* ctx, const std::vector<T>& v, void** dev) {
 
 static void group_release_tables(ilsx_sac_group* g) {
   for (auto& st : g->stages)
-    for (void* p : {st.tasks, st.groups, st.mats, st.tile_mat, st.fuses, st.tails})
+    for (void* p : {st.tasks, st.gtiles, st.tails})
       if (p) ctx_free(g->ctx, p);
   g->stages.clear();
   if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
@@ -874,18 +874,21 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
     for (int k = 0; k < K; ++k)
       if (cols[k].L[i].kind != st.kind) ILSX_FAIL(ILSX_ERR_STATE, "agents of a group must produce the same launch sequence");
     if (st.kind == 0) {
-      std::vector<FwdTask> tasks; std::vector<FwdGroup> groups;
+      std::vector<FwdTaskG> tasks;
       st.f = cols[0].L[i].f; st.KP = cols[0].L[i].KP;
       for (int k = 0; k < K; ++k) {
         const FwdArgs& A = cols[k].L[i].f;
         FwdGroup G; memset(&G, 0, sizeof G);
         G.fin = A.fin; G.gather = A.gather; G.scal = A.scal; G.fin_on = A.fin_on;
-        groups.push_back(G);
-        for (int t = 0; t < A.ntasks; ++t) { FwdTask T = A.t[t]; T.agent = k; T.first = t == 0; tasks.push_back(T); }
+        for (int t = 0; t < A.ntasks; ++t) {
+          FwdTaskG R; memset(&R, 0, sizeof R);
+          R.t = A.t[t]; R.t.agent = k; R.t.first = t == 0; R.g = G;
+          tasks.push_back(R);
+        }
       }
       st.ntasks = (int)tasks.size();
-      ILSX_TRY(upload_table(g->ctx, tasks, &st.tasks)); ILSX_TRY(upload_table(g->ctx, groups, &st.groups));
-      st.f.tasks = (const FwdTask*)st.tasks; st.f.groups = (const FwdGroup*)st.groups; st.f.ntasks = st.ntasks;
+      ILSX_TRY(upload_table(g->ctx, tasks, &st.tasks));
+      st.f.tasks = (const FwdTaskG*)st.tasks; st.f.ntasks = st.ntasks;
     } else if (st.kind == 1) {
       std::vector<BwdTask> tasks;
       st.b = cols[0].L[i].b;
@@ -900,25 +903,23 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
       ILSX_TRY(upload_table(g->ctx, tasks, &st.tasks));
       st.b.tasks = (const BwdTask*)st.tasks; st.b.ntasks = st.ntasks;
     } else if (st.kind == 2) {
-      std::vector<DwMat> mats; std::vector<int> tile_mat; std::vector<AdamFuse> fuses;
+      std::vector<DwTileG> gt;
       st.d = cols[0].L[i].d;
-      int tiles = 0;
+      int tiles = 0, nmat = 0;
       for (int k = 0; k < K; ++k) {
         const DwArgs& D = cols[k].L[i].d;
-        fuses.push_back(cols[k].L[i].F);
-        for (int m = 0; m < D.nmat; ++m) {
-          DwMat J = D.m[m];
-          const int n = (m + 1 < D.nmat ? D.m[m + 1].tile0 : D.ntiles) - J.tile0;
-          J.tile0 = tiles; J.agent = k;
-          for (int t = 0; t < n; ++t) tile_mat.push_back((int)mats.size());
-          mats.push_back(J);
+        for (int m = 0; m < D.nmat; ++m, ++nmat) {
+          DwTileG R; memset(&R, 0, sizeof R);
+          R.J = D.m[m]; R.F = cols[k].L[i].F;
+          const int n = (m + 1 < D.nmat ? D.m[m + 1].tile0 : D.ntiles) - R.J.tile0;
+          R.J.tile0 = tiles; R.J.agent = k;
+          for (int t = 0; t < n; ++t) gt.push_back(R);
           tiles += n;
         }
       }
-      st.d.ntiles = tiles; st.d.nmat = (int)mats.size();
-      ILSX_TRY(upload_table(g->ctx, mats, &st.mats)); ILSX_TRY(upload_table(g->ctx, tile_mat, &st.tile_mat));
-      ILSX_TRY(upload_table(g->ctx, fuses, &st.fuses));
-      st.d.mats = (const DwMat*)st.mats; st.d.tile_mat = (const int*)st.tile_mat; st.d.fuses = (const AdamFuse*)st.fuses;
+      st.d.ntiles = tiles; st.d.nmat = nmat;
+      ILSX_TRY(upload_table(g->ctx, gt, &st.gtiles));
+      st.d.gtiles = (const DwTileG*)st.gtiles;
       st.d.g_lo = nullptr;   // never the row-split path (B is the SAC batch)
     } else {
       std::vector<SacTailItem> items;

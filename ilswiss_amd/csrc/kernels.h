@@ -208,10 +208,13 @@ struct FwdArgs {
   GatherSpec gather;       // rows drawn from the replay ring in-kernel (first launch of a SAC step)
   int xs;                  // XCD confinement: only workgroups with (blockIdx.x & ((1<<xs)-1)) == 0 work (grid.x <<= xs)
   // grouped launch (several agents' tasks in one grid, SURVEY §8e "co-resident seeds as grouped GEMMs"): descriptor
-  // tables in device memory, built once per group; blockIdx.y indexes `tasks`, FwdTask::agent indexes `groups`
-  const FwdTask* tasks; const FwdGroup* groups;
+  // tables in device memory, built once per group; blockIdx.y indexes `tasks`
+  const struct FwdTaskG* tasks;
 };
 struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
+// one self-contained record per grid row: the task and its agent's per-launch state side by side, so a workgroup reaches
+// every pointer it needs with ONE dependent load level (a task -> group -> scalars chain cost ~2 us per level)
+struct FwdTaskG { FwdTask t; FwdGroup g; };
 
 #ifdef ILSX_KERNEL_IMPL
 template <int H, int ACT>
@@ -672,8 +675,13 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
   static_assert(NCS == NWV, "one k16 chunk of the slice per wave in the head phase");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const FwdTask& T = GRP ? A.tasks[blockIdx.y] : A.t[blockIdx.y];   // GRP: descriptor tables in device memory
-  const FwdGroup* GP = GRP ? A.groups + T.agent : nullptr;
+  // GRP: descriptor records in device memory, copied by value at entry (before any store) so that their fields are
+  // loaded once with scalar loads; a reference would be re-read with vector loads after every store
+  FwdTaskG Rg;
+  if (GRP) Rg = A.tasks[blockIdx.y];
+  else Rg.t = A.t[blockIdx.y];
+  const FwdTask& T = Rg.t;
+  const FwdGroup* GP = GRP ? &Rg.g : nullptr;
   const DevScalars* scal = GRP ? GP->scal : A.scal;
   const NetView& N = T.net;
   const int KP = N.KP, LDX = KP + ILSX_LDS_PAD, NO = N.NO, NCH0 = KP >> 4, NOT = (NO + 15) >> 4;
@@ -930,7 +938,10 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
   constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
   static_assert(NTH % H == 0 && RPW >= 1 && KPL >= 1, "unsupported split geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const BwdTask& T = GRP ? A.tasks[blockIdx.y] : A.t[blockIdx.y];
+  BwdTask Tg;
+  if (GRP) Tg = A.tasks[blockIdx.y];   // by value at entry (see k_mlp2_fwd_split)
+  else Tg = A.t[blockIdx.y];
+  const BwdTask& T = Tg;
   const NetView& N = T.net;
   const int NO = N.NO;
   float* d1 = smem;                      // [16][LDH]  delta_1, all H columns
@@ -1086,9 +1097,10 @@ struct DwArgs {
   int splits, rows_per_split;
   float* g_lo; float* g_hi;   // extent of the gradient arena the table's matrices live in (set by build_dw_jobs)
   float* scratch; size_t span;
-  // grouped launch: matrix / optimiser tables in device memory, tile -> matrix map
-  const DwMat* mats; const int* tile_mat; const AdamFuse* fuses;
+  // grouped launch: one self-contained record per output tile (its matrix and its agent's optimiser) in device memory
+  const struct DwTileG* gtiles;
 };
+struct DwTileG { DwMat J; AdamFuse F; };
 #define DW_SPLIT_MIN_ROWS 1024
 #define DW_TILE_N 32
 #define DW_TILE_K 64
@@ -1124,15 +1136,16 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   if (blockIdx.x & ((1u << D.xs) - 1u)) return;
   const int bx = blockIdx.x >> D.xs;
   int mi = 0;
-  if (GRP) {
-    mi = D.tile_mat[bx];
-  } else {
+  if (!GRP) {
 #pragma unroll
     for (int i = 1; i < DW_MAX_MATS; ++i)
       if (i < D.nmat && bx >= D.m[i].tile0) mi = i;
   }
-  const DwMat& J = GRP ? D.mats[mi] : D.m[mi];
-  const AdamFuse& F = GRP ? D.fuses[J.agent] : D.F;
+  DwTileG Rg;
+  if (GRP) Rg = D.gtiles[bx];   // by value at entry (see k_mlp2_fwd_split)
+  else { Rg.J = D.m[mi]; Rg.F = D.F; }
+  const DwMat& J = Rg.J;
+  const AdamFuse& F = Rg.F;
   const int local = bx - J.tile0;
   const int n0 = (local / J.ktiles) * DW_TILE_N, k0 = (local % J.ktiles) * DW_TILE_K;
   int rows = J.rows > 0 ? J.rows : D.rows_all, brows = J.rows > 0 ? J.bias_rows : D.rows_all;
