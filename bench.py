@@ -55,6 +55,51 @@ def pmc_traffic(kid):
     return None
 
 
+def co_resident_seeds(K=8, n=1500):
+    """SURVEY config 5's per-GPU shape ("several seeds per GPU"): K independent SAC runs of the same config stepped in
+    lock-step by ilsx_sac_group (one launch per stage for all of them).  Reported beside the headline, never as `value`.
+    The MFMA roofline entry is the grouped forward launch (K x 4 tasks x 16 row tiles x 4 column slices workgroups)."""
+    import ctypes as C
+
+    import ilswiss_amd as ia
+    from ilswiss_amd import _lib
+    c = ia.Context(0, seed=4242)
+    rng = np.random.default_rng(7)
+    cap = 200_000
+    rows = synth_rows(rng, cap)
+    rbs, trs = [], []
+    for k in range(K):
+        rb = ia.SimpleReplayBuffer(cap, O, A, random_seed=k, ctx=c)
+        rb.add_rows(*rows)
+        tr = ia.SoftActorCritic(ia.ReparamTanhMultivariateGaussianPolicy([H, H], O, A, ctx=c, seed=3 * k),
+                                ia.FlattenMlp([H, H], 1, O + A, ctx=c, seed=3 * k + 1),
+                                ia.FlattenMlp([H, H], 1, O + A, ctx=c, seed=3 * k + 2), max_batch=B, **SAC_KW)
+        tr.eval_statistics = {}
+        rbs.append(rb), trs.append(tr)
+    grp = ia.SoftActorCriticGroup(trs)
+    grp.train_from_replay(rbs, 200, B)
+    c.sync()
+    t0 = time.perf_counter()
+    grp.train_from_replay(rbs, n, B)
+    c.sync()
+    dt = time.perf_counter() - t0
+    _lib.check(c.lib.ilsx_prof_reset(c.h))
+    _lib.check(c.lib.ilsx_prof_enable(c.h, 1))
+    grp.train_from_replay(rbs, 100, B)
+    _lib.check(c.lib.ilsx_prof_enable(c.h, 0))
+    nl, ms = C.c_uint64(), C.c_double()
+    _lib.check(c.lib.ilsx_prof_read(c.h, 0, C.byref(nl), C.byref(ms)))
+    fl = K * flops_per_step()[0] / (nl.value / 100.0)
+    avg_s = ms.value * 1e-3 / nl.value
+    out = dict(K=K, aggregate_grad_steps_per_s=K * n / dt, per_run_grad_steps_per_s=n / dt, us_per_lockstep=1e6 * dt / n,
+               roofline=dict(bound="mfma", kernel="k_mlp2_fwd_split (grouped)", achieved=fl / avg_s / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
+                             unit="TFLOP/s", frac=fl / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_us=avg_s * 1e6,
+                             algorithmic_flop_per_launch=fl))
+    grp.close()
+    c.close()
+    return out
+
+
 def flops_per_step():
     """ALGORITHMIC FLOPs of one SAC-alpha gradient step, split by kernel."""
     Wq, Wp = (O + A) * H + H * H + H, O * H + H * H + 2 * H * A
@@ -115,6 +160,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-seeds", action="store_true", help="skip the co-resident seeds leg")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -237,6 +283,8 @@ def main():
                         parallelism=f"{world} independent replicas (seed sharding, no collective)"),
             env_steps_per_s=env_total / dt, env_steps_per_s_sample_phase=env_total / t_sample,
             grad_steps_per_s_train_phase=grad_total / t_train, roofline=roofline, roofline_replay=roofline_replay)
+        if world == 1 and not args.no_seeds:
+            result["co_resident_seeds"] = co_resident_seeds()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
