@@ -74,6 +74,23 @@ def bench_ppo(ctx):
                 gae()
             ctx.sync()
             out["calc_adv_s"] = (time.perf_counter() - t0) / 5   # vf forward + GAE + fixed log-probs over 1M rows
+    # end to end on the HIP Hopper stepper: rollout (policy -> physics -> record -> running obs statistics) + calc_adv + update
+    from ilswiss_amd.envs.vecenv import HipVectorEnv
+    env = HipVectorEnv("hopper", n_env, seed=0, ctx=ctx, norm_obs=True)
+    tr = PPO(pol, vf, mini_batch_size=32768, update_epoch=10, gae_tau=0.95, max_samples=N)
+    tr.train_from_rollout(env, T, max_path_length=1000)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        tr.train_from_rollout(env, T, max_path_length=1000)
+    ctx.sync()
+    it = (time.perf_counter() - t0) / 3
+    obs_b, act_b, rew_b, ends_b, lastv = tr._roll[1:]
+    t0 = time.perf_counter()
+    _lib.check(ctx.lib.ilsx_ppo_rollout(tr.h, env.h, T, 1000, obs_b.ptr, act_b.ptr, rew_b.ptr, ends_b.ptr, lastv.ptr))
+    ctx.sync()
+    roll = time.perf_counter() - t0
+    out["end_to_end"] = dict(iteration_s=it, rollout_s=roll, env_steps_per_s_rollout=N / roll, samples_per_s_whole_iteration=N / it)
     return dict(metric="PPO Hopper-v2 dims, 8192 envs x 128-step rollout, GAE + minibatch update", unit="sample-updates/s",
                 value=out["mb32768"]["sample_updates_per_s"], dtype="f32", data="synthetic",
                 config=dict(workload="o=11,a=3, tanh 256-256 policy + value net, gamma .99, lambda .95, clip .2, 10 epochs; "

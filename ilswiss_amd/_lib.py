@@ -81,6 +81,10 @@ class SacvStats(C.Structure):  # ilsx_sacv_stats
                 ("log_pi", C.c_float * 4), ("policy_mu", C.c_float * 4), ("policy_log_std", C.c_float * 4)]
 
 
+class BcCfg(C.Structure):  # ilsx_bc_cfg
+    _fields_ = [("mode", C.c_int32), ("lr", C.c_float), ("momentum", C.c_float), ("max_batch", C.c_int32)]
+
+
 class PpoCfg(C.Structure):  # ilsx_ppo_cfg
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32),
                 ("reward_scale", C.c_float), ("discount", C.c_float), ("clip_eps", C.c_float),
@@ -119,6 +123,10 @@ PROTOTYPES = {
     "ilsx_sacv_train_from_replay": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(SacvStats)]),
     "ilsx_sacv_get_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "ilsx_sacv_set_params": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "ilsx_bc_create": (C.c_int, [vp, C.POINTER(BcCfg), vp, C.POINTER(vp)]),
+    "ilsx_bc_destroy": (C.c_int, [vp]),
+    "ilsx_bc_train_step": (C.c_int, [vp, vp, vp, C.c_int, vp, C.POINTER(C.c_float)]),
+    "ilsx_bc_train_from_replay": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ilsx_ppo_create": (C.c_int, [vp, C.POINTER(PpoCfg), C.POINTER(vp)]),
     "ilsx_ppo_destroy": (C.c_int, [vp]),
     "ilsx_ppo_num_params": (C.c_int, [vp, C.c_int, C.POINTER(C.c_size_t)]),

@@ -580,3 +580,108 @@ extern "C" int ilsx_sacv_set_params(ilsx_sacv* s, int which, const float* src_ho
   if (!s) ILSX_FAIL(ILSX_ERR_ARG, "NULL handle");
   return ac_params(&s->g, which, true, const_cast<float*>(src_host), n);
 }
+
+// ================================================================================================ behaviour cloning
+// rlkit/torch/algorithms/bc/bc.py:14-41,81-106: one Adam(lr, betas=(momentum, 0.999)) over a tanh-Gaussian policy;
+// mode MLE = -mean(get_log_prob(obs, acts)), mode MSE = mean_rows(sum_j (sampled action - acts)^2).
+struct ilsx_bc {
+  AcAgent g;
+  ilsx_bc_cfg cfg;
+  float *raw = nullptr, *pred = nullptr, *logp = nullptr, *epss = nullptr;
+};
+
+extern "C" int ilsx_bc_create(ilsx_ctx* ctx, const ilsx_bc_cfg* cfg, ilsx_net* pi, ilsx_bc** out) {
+  if (!ctx || !cfg || !pi || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_bc_create: NULL argument");
+  if (pi->lay.cfg.n_heads != 2) ILSX_FAIL(ILSX_ERR_ARG, "policy must have 2 heads (mean | log_std), policies.py:231-239");
+  if (cfg->mode != ILSX_BC_MLE && cfg->mode != ILSX_BC_MSE) ILSX_FAIL(ILSX_ERR_ARG, "mode must be ILSX_BC_MLE or ILSX_BC_MSE");
+  if (cfg->max_batch < 1 || cfg->max_batch > (1 << 20)) ILSX_FAIL(ILSX_ERR_ARG, "max_batch=%d out of range", cfg->max_batch);
+  HIPCHK(hipSetDevice(ctx->device));
+  ilsx_bc* b = new ilsx_bc();
+  b->cfg = *cfg;
+  ilsx_net* nets[1] = {pi};
+  const int opt_of[1] = {0};
+  AcAgent* g = &b->g;
+  g->lr[0] = cfg->lr; g->beta_1 = cfg->momentum;
+  int rc = ac_init(g, ctx, nets, 1, opt_of, cfg->max_batch, pi->lay.cfg.in_dim, pi->lay.cfg.out_dim);
+  const size_t B = (size_t)cfg->max_batch, a = (size_t)pi->lay.cfg.out_dim;
+  if (rc == ILSX_OK) rc = ac_alloc(g, &b->raw, B * 2 * a);
+  if (rc == ILSX_OK) rc = ac_alloc(g, &b->pred, B * a);
+  if (rc == ILSX_OK) rc = ac_alloc(g, &b->epss, B * a);
+  if (rc == ILSX_OK) rc = ac_alloc(g, &b->logp, B);
+  if (rc == ILSX_OK) rc = ac_tick(g, 0, 0);
+  if (rc != ILSX_OK) { delete b; return rc; }
+  *out = b;
+  return ILSX_OK;
+}
+extern "C" int ilsx_bc_destroy(ilsx_bc* b) {
+  if (!b) return ILSX_OK;
+  ac_release(&b->g);
+  delete b;
+  return ILSX_OK;
+}
+
+static int bc_step(ilsx_bc* b, float* stat) {
+  AcAgent* g = &b->g;
+  const bool mle = b->cfg.mode == ILSX_BC_MLE;
+  {
+    FwdArgs A = ac_fwd_args(g, 1);
+    FwdTask& f = A.t[0];
+    ac_fwd(g, f, 0, false, g->s, g->o, nullptr, 0, true);
+    f.out = b->raw; f.logp = b->logp; f.rng_stream = g->rng_stream;
+    if (mle) { f.head = HEAD_TANH_LOGP_OF_ACT; f.act_in = g->ac; }
+    else { f.head = HEAD_TANH_SAMPLE; f.eps = g->eps_explicit ? g->eps : nullptr; f.action = b->pred; f.eps_save = b->epss; }
+    ILSX_TRY(launch_fwd(g->ctx, A, g->H, g->act, g->L[0].KP));
+  }
+  {
+    BwdArgs A = ac_bwd_args(g, 1, 0.f, 0.f);
+    BwdTask& t = A.t[0];
+    ac_bwd(g, t, 0, true);
+    t.loss = mle ? LOSS_BC_MLE : LOSS_BC_MSE; t.raw = b->raw; t.act_all = g->ac; t.action = b->pred; t.eps = b->epss;
+    ILSX_TRY(launch_bwd_dx(g->ctx, A, g->H, g->act));
+  }
+  ILSX_TRY(ac_dw_adam(g, 0, 1, false, 0.f));
+  ILSX_TRY(ac_tick(g, 1, 1));
+  if (stat) {   // "Log-Likelihood" / "MSE" of this batch (bc.py:92-102)
+    const size_t B = (size_t)g->B, a = (size_t)g->a;
+    if (mle) {
+      std::vector<float> lp;
+      ILSX_TRY(ac_fetch(g, b->logp, B, lp));
+      HIPCHK(hipStreamSynchronize(g->ctx->stream));
+      double s = 0;
+      for (float v : lp) s += v;
+      *stat = (float)(s / (double)B);
+    } else {
+      std::vector<float> p, t;
+      ILSX_TRY(ac_fetch(g, b->pred, B * a, p)); ILSX_TRY(ac_fetch(g, g->ac, B * a, t));
+      HIPCHK(hipStreamSynchronize(g->ctx->stream));
+      double s = 0;
+      for (size_t i = 0; i < B * a; ++i) s += (double)(p[i] - t[i]) * (p[i] - t[i]);
+      *stat = (float)(s / (double)B);
+    }
+  }
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_bc_train_step(ilsx_bc* b, const float* obs, const float* act, int B, const float* eps, float* stat) {
+  if (!b || !obs || !act) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_bc_train_step: NULL argument");
+  AcAgent* g = &b->g;
+  if (B < 1 || B > g->max_batch) ILSX_FAIL(ILSX_ERR_ARG, "B=%d not in 1..max_batch=%d", B, g->max_batch);
+  HIPCHK(hipSetDevice(g->ctx->device));
+  hipStream_t st = g->ctx->stream;
+  HIPCHK(hipMemcpyAsync(g->s, obs, (size_t)B * g->o * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(g->ac, act, (size_t)B * g->a * 4, hipMemcpyDeviceToDevice, st));
+  g->eps_explicit = eps != nullptr;
+  if (eps) HIPCHK(hipMemcpyAsync(g->eps, eps, (size_t)B * g->a * 4, hipMemcpyDeviceToDevice, st));
+  g->B = B;
+  return bc_step(b, stat);
+}
+// BC._do_training (bc.py:77-79): n_updates x (expert batch with keys observations / actions -> update)
+extern "C" int ilsx_bc_train_from_replay(ilsx_bc* b, ilsx_replay* expert_rb, int n_updates, int B, float* stat) {
+  if (!b || n_updates < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_bc_train_from_replay: bad argument");
+  HIPCHK(hipSetDevice(b->g.ctx->device));
+  for (int i = 0; i < n_updates; ++i) {
+    ILSX_TRY(ac_sample(&b->g, expert_rb, B));
+    ILSX_TRY(bc_step(b, i == 0 ? stat : nullptr));
+  }
+  return ILSX_OK;
+}

@@ -27,7 +27,7 @@ enum { HEAD_RAW = 0, HEAD_TANH_SAMPLE = 1, HEAD_TANH_DET = 2, HEAD_TANH_LOGP_OF_
        HEAD_GAUSS_SAMPLE = 4, HEAD_GAUSS_LOGP_OF_ACT = 5,    // un-squashed Gaussian, state-independent log_std (PPO)
        HEAD_DET_TANH_NOISE = 6 };                            // max_act*tanh(out) + clip(noise*eps) (TD3, policies.py:166-188)
 enum { LOSS_GIVEN = 0, LOSS_SAC_CRITIC = 1, LOSS_SAC_ACTORQ = 2, LOSS_SAC_POLICY = 3, LOSS_MSE = 4, LOSS_PPO_POLICY = 5,
-       LOSS_TD_CRITIC = 6, LOSS_SACV_VALUE = 7, LOSS_CONST = 8, LOSS_TD3_POLICY = 9 };
+       LOSS_TD_CRITIC = 6, LOSS_SACV_VALUE = 7, LOSS_CONST = 8, LOSS_TD3_POLICY = 9, LOSS_BC_MLE = 10, LOSS_BC_MSE = 11 };
 enum { ACT_RELU = 0, ACT_TANH = 1 };
 
 #define LOG_SIG_MIN (-20.0f)
@@ -509,6 +509,22 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
     // action = max_act*tanh(pre): d pre = dL/da * max_act * (1 - tanh(pre)^2)
     const float th = tanhf(T.raw[(size_t)gr * NO + j]);
     d = T.ga1[(size_t)gr * NO + j] * T.coef * (1.0f - th * th);
+  } else if (T.loss == LOSS_BC_MLE || T.loss == LOSS_BC_MSE) {
+    // bc.py:88-101.  raw = mean | log_std_raw [rows][2a]; act_all = expert actions [rows][a]
+    const int a = NO >> 1, jj = j < a ? j : j - a;
+    const float mu = T.raw[(size_t)gr * NO + jj], lsr = T.raw[(size_t)gr * NO + a + jj];
+    const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
+    const bool gate = lsr >= LOG_SIG_MIN && lsr <= LOG_SIG_MAX;
+    const float tgt = T.act_all[(size_t)gr * a + jj];
+    if (T.loss == LOSS_BC_MLE) {   // -mean(log_prob(acts)): z = atanh-with-epsilon of the expert action (distributions.py:85-88)
+      const float z = 0.5f * (logf(1.0f + tgt + TANH_EPS) - logf(1.0f - tgt + TANH_EPS));
+      const float var = expf(2.0f * ls), dm = mu - z;
+      d = j < a ? dm / var * A.inv_B : (gate ? -(dm * dm / var - 1.0f) * A.inv_B : 0.0f);
+    } else {                        // mean_rows(sum_j (sampled action - acts)^2): action = tanh(mu + sigma*eps)
+      const float pred = T.action[(size_t)gr * a + jj];
+      const float dz = 2.0f * (pred - tgt) * A.inv_B * (1.0f - pred * pred);
+      d = j < a ? dz : (gate ? dz * expf(ls) * T.eps[(size_t)gr * a + jj] : 0.0f);
+    }
   } else if (T.loss == LOSS_MSE) {
     // ppo.py:145: mean((v - R)^2) over the minibatch
     const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;

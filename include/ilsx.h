@@ -49,6 +49,7 @@ typedef struct ilsx_disc ilsx_disc;
 typedef struct ilsx_ppo ilsx_ppo;
 typedef struct ilsx_td3 ilsx_td3;
 typedef struct ilsx_sacv ilsx_sacv;
+typedef struct ilsx_bc ilsx_bc;
 
 enum { ILSX_ACT_RELU = 0, ILSX_ACT_TANH = 1 };
 
@@ -303,6 +304,19 @@ int ilsx_sacv_train_from_replay(ilsx_sacv* sac, ilsx_replay* rb, int n_steps, in
 /* which: 0 qf1, 1 qf2, 2 vf, 3 policy, 6 target_vf; HOST flat arrays */
 int ilsx_sacv_get_params(ilsx_sacv* sac, int which, float* dst_host, size_t n);
 int ilsx_sacv_set_params(ilsx_sacv* sac, int which, const float* src_host, size_t n);
+
+/* ---------------------------------------------------------------- behaviour cloning
+ * Replaces rlkit/torch/algorithms/bc/bc.py:14-41 (ctor: Adam(lr, betas=(momentum, 0.999)) over the policy) and :77-106
+ * (_do_training / _do_update_step).  MLE: loss = -mean(policy.get_log_prob(obs, acts)); MSE: loss = mean over rows of
+ * sum_j (policy(obs)[0] - acts)^2 with policy(obs)[0] a SAMPLED action, like the reference. */
+enum { ILSX_BC_MLE = 0, ILSX_BC_MSE = 1 };
+typedef struct { int32_t mode; float lr, momentum; int32_t max_batch; } ilsx_bc_cfg;
+int ilsx_bc_create(ilsx_ctx* ctx, const ilsx_bc_cfg* cfg, ilsx_net* pi, ilsx_bc** out);   /* adopts pi like ilsx_sac_create */
+int ilsx_bc_destroy(ilsx_bc* bc);
+/* device rows obs[B,o], act[B,a]; eps (device [B,a], MSE mode's N(0,1) draws) or NULL = Philox; stat (host, nullable) =
+ * "Log-Likelihood" (MLE) or "MSE" of this batch (bc.py:92-102) */
+int ilsx_bc_train_step(ilsx_bc* bc, const float* obs, const float* act, int B, const float* eps, float* stat);
+int ilsx_bc_train_from_replay(ilsx_bc* bc, ilsx_replay* expert_rb, int n_updates, int B, float* stat);
 
 /* ---------------------------------------------------------------- PPO
  * Replaces rlkit/torch/algorithms/ppo/ppo.py:57-100 (calc_adv: per-trajectory GAE, zero bootstrap, per-trajectory

@@ -41,11 +41,21 @@ def test_ctypes_table_matches_header(built):
     assert lib.ilsx_abi_version() == 1
 
 
-def test_struct_sizes_match_header(built):
-    # ilsx_mlp_cfg: 6 x int32 ; ilsx_sac_cfg: 15 x 4 bytes ; ilsx_sac_stats: 10 floats + double
-    assert ctypes.sizeof(built.MlpCfg) == 24
-    assert ctypes.sizeof(built.SacCfg) == 60
-    assert ctypes.sizeof(built.SacStats) == 48
+def test_struct_sizes_match_header(built, tmp_path):
+    """Every struct that crosses the ABI: sizeof() as gcc lays include/ilsx.h out == the ctypes mirror in _lib.py."""
+    import subprocess
+    pairs = dict(ilsx_mlp_cfg="MlpCfg", ilsx_sac_cfg="SacCfg", ilsx_sac_stats="SacStats", ilsx_disc_cfg="DiscCfg",
+                 ilsx_disc_stats="DiscStats", ilsx_ppo_cfg="PpoCfg", ilsx_td3_cfg="Td3Cfg", ilsx_td3_stats="Td3Stats",
+                 ilsx_sacv_cfg="SacvCfg", ilsx_sacv_stats="SacvStats", ilsx_bc_cfg="BcCfg", ilsx_planar_model="PlanarModel")
+    src = tmp_path / "sizes.c"
+    body = "".join(f'  printf("{c} %zu\\n", sizeof({c}));\n' for c in pairs)
+    src.write_text('#include <stdio.h>\n#include "ilsx.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    sizes = dict(zip(out[::2], map(int, out[1::2])))
+    for c, py in pairs.items():
+        assert ctypes.sizeof(getattr(built, py)) == sizes[c], (c, ctypes.sizeof(getattr(built, py)), sizes[c])
 
 
 def test_no_gpu_means_loud_failure(built):

@@ -243,3 +243,33 @@ def test_device_eval_sampler_matches_host_walked_sampler(ctx):
     s1 = DeviceEvalSampler(env1, det, num_steps=1, max_path_length=60).obtain_statistics("Test")
     assert s1["Num Paths"] == 5 and 1 <= s1["Test Ep. Len. Min"] <= s1["Test Ep. Len. Max"] <= 60
     assert abs(s1["Test Rewards Mean"] * s1["Test Ep. Len. Mean"] - s1["Test Returns Mean"]) < 1e-6 * max(1, abs(s1["Test Returns Mean"]))
+
+
+def test_bc_run_script_with_generated_demos(tmp_path, ctx):
+    import pickle
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "run_scripts"))
+    import bc_exp_script as script
+    import gen_expert_demos as gen
+    import ilswiss_amd as ia
+    from _common import flatten_spec
+    from ilswiss_amd.envs.vecenv import HipVectorEnv
+    env = HipVectorEnv("hopper", 6, seed=3, ctx=ctx)
+    expert = ia.ReparamTanhMultivariateGaussianPolicy([64, 64], 11, 3, ctx=ctx, seed=5)
+    demos = gen.generate(expert, env, 6, max_path_length=80)
+    (tmp_path / "demos").mkdir()
+    with open(tmp_path / "demos" / "hopper.pkl", "wb") as f:
+        pickle.dump(demos, f)
+    with open(tmp_path / "listing.yaml", "w") as f:
+        yaml.dump(dict(hopper_sac=dict(description="test", file_paths=["./demos/hopper.pkl"])), f)
+    v = flatten_spec(yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "bc", "bc_hopper_hip.yaml"))))
+    v["demos_listing"] = str(tmp_path / "listing.yaml")
+    v["env_specs"].update(env_num=4, eval_env_num=4)
+    v["policy_net_size"] = 64
+    v["bc_params"].update(num_epochs=2, num_steps_per_epoch=100, num_steps_between_train_calls=50, max_path_length=60,
+                          num_steps_per_eval=100, num_updates_per_train_call=20, batch_size=64, freq_saving=1)
+    script.experiment(v, 0, str(tmp_path / "log"))
+    rows = list(csv.DictReader(open(tmp_path / "log" / "progress.csv")))
+    assert len(rows) == 2 and float(rows[-1]["Number of train steps total"]) == 80
+    assert float(rows[-1]["Log-Likelihood"]) > float(rows[0]["Log-Likelihood"])      # the clone's likelihood of the demos rises
+    assert np.isfinite(float(rows[-1]["AverageReturn"])) and os.path.exists(tmp_path / "log" / "best.pkl")

@@ -581,7 +581,51 @@ def gen_sac_v():
     save("g5_sac_v", **rec)
 
 
-GROUPS = dict(td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+def gen_bc():
+    """G13: BC._do_update_step (bc/bc.py:81-106) driven as an unbound function on a namespace carrying the attributes it
+    touches; modes MLE and MSE (the MSE mode samples its action: torch.randn injected), 3 chained Adam steps each."""
+    import types
+    import torch.optim as optim
+    from rlkit.torch.algorithms.bc.bc import BC
+    from rlkit.torch.common.policies import ReparamTanhMultivariateGaussianPolicy
+    from oracle.bc import BCOracle
+    out = {}
+    for mode, seed in (("MLE", 1301), ("MSE", 1302)):
+        rng = np.random.default_rng(seed)
+        o, a, Hh, B, steps = 11, 3, [64, 64], 32, 3
+        pi0 = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, n_heads=2)
+        pi0[-(2 * (Hh[-1] * a + a)):] *= 200.0            # heads up so that tanh / log_std matter
+        pol = ReparamTanhMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a)
+        set_flat(pol, pi0)
+        opt = optim.Adam(pol.parameters(), lr=1e-3, betas=(0.5, 0.999))
+        grads = {}
+        _hook_grads(grads, opt, "pi", pol)
+        orc = BCOracle(o, a, Hh, pi0, mode=mode, lr=1e-3, momentum=0.5)
+        out[f"{mode}_dims"] = np.array([o, a, B, steps] + Hh)
+        out[f"{mode}_pi0"] = pi0
+        for s in range(steps):
+            obs = rng.normal(0, 1, (B, o)).astype(np.float32)
+            acts = np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32)
+            acts[0, 0] = 0.999999                          # near-saturated expert action: the atanh epsilon matters
+            eps = rng.normal(0, 1, (B, a)).astype(np.float32)
+            ns = types.SimpleNamespace(mode=mode, batch_size=B, exploration_policy=pol, optimizer=opt, eval_statistics=None,
+                                       get_batch=lambda *aa, **kk: dict(observations=t(obs), actions=t(acts)))
+            with H.NoiseInjector() as inj:
+                if mode == "MSE":
+                    inj.push(eps)
+                BC._do_update_step(ns, 0, use_expert_buffer=True)
+            stat = float(ns.eval_statistics["Log-Likelihood" if mode == "MLE" else "MSE"])
+            res = orc.update(obs, acts, eps)
+            assert np.allclose(stat, res["stat"], rtol=2e-4, atol=1e-5), (mode, s, stat, res["stat"])
+            err = np.abs(grads["pi"] - res["grad"]).max() / (np.abs(grads["pi"]).max() + 1e-12)
+            assert err < 2e-3, (mode, s, err)
+            assert np.abs(orc.pi - get_flat(pol)).max() < 5e-5
+            out.update({f"{mode}_s{s}_obs": obs, f"{mode}_s{s}_acts": acts, f"{mode}_s{s}_eps": eps, f"{mode}_s{s}_stat": stat,
+                        f"{mode}_s{s}_grad": grads["pi"], f"{mode}_s{s}_pi": get_flat(pol)})
+    save("g13_bc", **out)
+
+
+GROUPS = dict(bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap)
 
 if __name__ == "__main__":
