@@ -135,6 +135,7 @@ PROTOTYPES = {
     "ilsx_ppo_gae": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]),
     "ilsx_ppo_values": (C.c_int, [vp, vp, C.c_int, vp]),
     "ilsx_ppo_train": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "ilsx_rollout_step_relabel": (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]),
     "ilsx_eval_rollout": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "ilsx_ppo_rollout": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "ilsx_vecenv_obs_norm": (C.c_int, [vp, C.c_int, C.c_int]),

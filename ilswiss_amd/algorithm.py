@@ -134,7 +134,8 @@ class DeviceRLAlgorithm:
                 t0 = time.perf_counter()
                 random_actions = self.replay_buffer.num_steps_can_sample() < self.min_steps_before_training
                 self.training_env.rollout_step(self.exploration_policy, self.replay_buffer, self.max_path_length,
-                                               random_actions=random_actions, no_terminal=self.no_terminal)
+                                               random_actions=random_actions, no_terminal=self.no_terminal,
+                                               label_policy=getattr(self.trainer, "expert_policy", None))
                 self._n_env_steps_total += self.env_num
                 if self._n_env_steps_total - self._n_prev_train_env_steps >= self.num_steps_between_train_calls:
                     ctx.sync()

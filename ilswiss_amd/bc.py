@@ -63,3 +63,36 @@ class BC(Trainer):
 
     def get_snapshot(self):
         return dict(policy=self.policy.get_flat_params())
+
+
+class DAgger(BC):
+    """rlkit/torch/algorithms/dagger/dagger.py:4-82: BC whose batches come from the policy's own rollouts relabelled with
+    the expert's actions.  The expert demonstrations are copied into the replay buffer at construction (:27-35); the first
+    train call spends `num_initial_train_steps` updates on the expert buffer alone (:37-40); the sampling loop stores the
+    expert's action for every visited observation (`HipVectorEnv.rollout_step(label_policy=...)`, :45-71).
+    `unscale_for_expert` concerns ScaledEnv wrappers, which libilsx does not have (observations are raw)."""
+
+    def __init__(self, expert_policy, mode, policy, expert_replay_buffer, replay_buffer, num_initial_train_steps=100, **kwargs):
+        kwargs.pop("unscale_for_expert", None)
+        super().__init__(mode, policy, expert_replay_buffer=expert_replay_buffer, **kwargs)
+        self.expert_policy, self.replay_buffer = expert_policy, replay_buffer
+        self.num_initial_train_steps, self._first_call = int(num_initial_train_steps), True
+        n = expert_replay_buffer.num_steps_can_sample()
+        b = expert_replay_buffer._gather(np.arange(n))
+        replay_buffer.add_rows(b["observations"], b["actions"], b["rewards"], b["terminals"], b["next_observations"])
+
+    def train_from_replay(self, replay_buffer=None, n_updates=None, batch_size=None):
+        n = int(n_updates or self.num_updates_per_train_call)
+        B = int(batch_size or self.batch_size)
+        if self._first_call:          # `epoch == 0` in the reference
+            self._first_call = False
+            _lib.check(self.ctx.lib.ilsx_bc_train_from_replay(self.h, self.expert_replay_buffer.h, self.num_initial_train_steps, B, None))
+        rb = replay_buffer if replay_buffer is not None else self.replay_buffer
+        want, st = self.eval_statistics is None, C.c_float()
+        _lib.check(self.ctx.lib.ilsx_bc_train_from_replay(self.h, rb.h, n, B, C.byref(st) if want else None))
+        if want:
+            self._record(st.value)
+
+    @property
+    def networks(self):
+        return [self.policy, self.expert_policy]

@@ -48,6 +48,7 @@ struct ilsx_vecenv {
   struct ObsRms* rms = nullptr;
   float* obs_n = nullptr;   // [n_env][o] normalised policy input (norm_obs)
   // evaluation rollouts (ilsx_eval_rollout)
+  float* act_label = nullptr;   // [n_env][a] expert labels (ilsx_rollout_step_relabel)
   unsigned char* ev_frozen = nullptr; double* ev_ret = nullptr; int* ev_len = nullptr; double* ev_stats = nullptr; int* ev_alive = nullptr;
   bool norm_obs = false, update_rms = false;
   const float* policy_obs() const { return norm_obs ? obs_n : obs_cur; }
@@ -379,6 +380,7 @@ struct EnvStepArgs {
   // fused-rollout extras (all nullable / 0)
   float* obs_cur;         // [n_env][o]: the policy's next input (post auto-reset)
   int auto_reset, max_path_length, no_terminal;
+  const float* rec_act;          // nullable: [n_ids][a] action written into the replay record instead of `act`
   const unsigned char* frozen;   // nullable: envs whose flag is set do not step (evaluation: one episode per env)
   int* ep_len; double* ep_ret; double* stats;
   float* replay; int rec; long long cap, top;   // transition record written at slot (top + env) % cap
@@ -460,7 +462,8 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
     if (slot >= A.cap) slot -= A.cap;
     float* rec = A.replay + (size_t)slot * A.rec;
     for (int i = 0; i < o; ++i) rec[i] = obs_before[i];
-    for (int k = 0; k < na; ++k) rec[o + k] = A.act[(size_t)t * na + k];
+    const float* ra = A.rec_act ? A.rec_act : A.act;   // DAgger stores the expert's label, not the executed action
+    for (int k = 0; k < na; ++k) rec[o + k] = ra[(size_t)t * na + k];
     rec[o + na] = (float)reward;
     rec[o + na + 1] = (done && !A.no_terminal) ? 1.0f : 0.0f;   // base_algorithm.py:195-196,208-210
     for (int i = 0; i < o; ++i) rec[o + na + 2 + i] = ob[i];
@@ -764,8 +767,8 @@ static int env_after_step_norm(ilsx_vecenv* e) {
 
 // One iteration of BaseAlgorithm's sampling loop (base_algorithm.py:183-277) for ALL envs, on the device:
 // actions (policy or uniform random) -> physics -> transition record into the replay ring -> auto-reset.
-extern "C" int ilsx_rollout_step(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
-                                 int deterministic, int no_terminal) {
+static int rollout_step_impl(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* label_pi, int label_deterministic, ilsx_replay* rb,
+                             int max_path_length, int random_actions, int deterministic, int no_terminal) {
   if (!e || (!pi && !random_actions)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_step: need a policy or random_actions");
   ilsx_ctx* ctx = e->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -789,9 +792,24 @@ extern "C" int ilsx_rollout_step(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, 
   A.ep_len = e->ep_len; A.ep_ret = e->ep_ret; A.stats = e->stats;
   if (rb) { A.replay = rb->data; A.rec = rb->rec; A.cap = rb->cap; A.top = rb->top; }
   A.seed = e->seed; A.stream = e->rng_stream; A.step = step; A.no_terminal = no_terminal;
+  if (label_pi) {   // DAgger._handle_step (dagger.py:45-71): the stored action is the expert's for the observation acted on
+    if (!e->act_label) ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * e->a * 4, (void**)&e->act_label));
+    ILSX_TRY(ilsx_policy_act(label_pi, e->policy_obs(), e->n_env, label_deterministic, nullptr, e->act_label, nullptr));
+    A.rec_act = e->act_label;
+  }
   ILSX_TRY(launch_env_step(e, A));
   if (rb) ILSX_TRY(replay_advance_device_rows(rb, e->n_env));
   return env_after_step_norm(e);
+}
+
+extern "C" int ilsx_rollout_step(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
+                                 int deterministic, int no_terminal) {
+  return rollout_step_impl(e, pi, nullptr, 0, rb, max_path_length, random_actions, deterministic, no_terminal);
+}
+extern "C" int ilsx_rollout_step_relabel(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* expert, int expert_deterministic, ilsx_replay* rb,
+                                         int max_path_length, int no_terminal) {
+  if (!expert) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_step_relabel: NULL expert policy");
+  return rollout_step_impl(e, pi, expert, expert_deterministic, rb, max_path_length, 0, 0, no_terminal);
 }
 
 // ---- on-policy rollout into env-major buffers (sample (env, t) lives at row env*T + t)

@@ -422,6 +422,10 @@ int ilsx_rollout_step(ilsx_vecenv* env, ilsx_net* pi, ilsx_replay* rb, int max_p
 #define ILSX_EVAL_NSTATS 18
 int ilsx_eval_rollout(ilsx_vecenv* env, ilsx_net* pi, ilsx_ppo* ppo, int max_path_length, int deterministic, int reset_stats,
                       double* stats_host);
+/* DAgger's sampling iteration (dagger/dagger.py:45-71): the envs are driven by `pi`, the action stored in the replay record is
+ * `expert`'s action for the observation acted on. */
+int ilsx_rollout_step_relabel(ilsx_vecenv* env, ilsx_net* pi, ilsx_net* expert, int expert_deterministic, ilsx_replay* rb,
+                              int max_path_length, int no_terminal);
 /* finished episodes and the sum of their returns since the last reset of the counters */
 int ilsx_rollout_stats(ilsx_vecenv* env, double* episodes, double* return_sum, int reset);
 

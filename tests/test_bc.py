@@ -66,3 +66,39 @@ def test_hip_bc_clones_an_expert_from_the_replay(ctx):
         tr.train_from_replay()
     err1 = np.abs(pol.get_actions(obs[:512], deterministic=True) - act[:512]).mean()
     assert tr.get_eval_statistics()["Log-Likelihood"] > ll0 + 1.0 and err1 < 0.35 * err0, (ll0, tr.get_eval_statistics(), err0, err1)
+
+
+@pytest.mark.gpu
+def test_hip_dagger_relabels_rollouts_with_the_expert(ctx):
+    """dagger.py:27-71: demos copied into the replay buffer; the sampling loop stores the EXPERT's action for the observations
+    the learner visits; after training on those labels the learner imitates the expert on its own state distribution."""
+    import ilswiss_amd as ia
+    from ilswiss_amd.bc import DAgger
+    from ilswiss_amd.envs.vecenv import HipVectorEnv
+    from ilswiss_amd.replay import SimpleReplayBuffer
+    o, a = 11, 3
+    expert = ia.ReparamTanhMultivariateGaussianPolicy([64, 64], o, a, ctx=ctx, seed=11)
+    flat = expert.get_flat_params()
+    flat[-(2 * (64 * a + a)):-(64 * a + a)] *= 300.0          # a mean head with real structure
+    expert.set_flat_params(flat)
+    learner = ia.ReparamTanhMultivariateGaussianPolicy([64, 64], o, a, ctx=ctx, seed=12)
+    env = HipVectorEnv("hopper", 256, seed=4, ctx=ctx)
+    rng = np.random.default_rng(0)
+    demo_obs = rng.normal(0, 1, (500, o)).astype(np.float32)
+    exp_rb = SimpleReplayBuffer(1000, o, a, random_seed=1, ctx=ctx)
+    exp_rb.add_rows(demo_obs, expert.get_actions(demo_obs, deterministic=True), np.zeros(500, np.float32), np.zeros(500, bool), demo_obs)
+    rb = SimpleReplayBuffer(100000, o, a, random_seed=2, ctx=ctx)
+    tr = DAgger(ia.MakeDeterministic(expert), "MLE", learner, exp_rb, rb, num_initial_train_steps=50, batch_size=256, lr=1e-3,
+                num_updates_per_train_call=100)
+    assert rb.num_steps_can_sample() == 500                      # the demonstrations were copied in (dagger.py:27-35)
+    for _ in range(20):
+        env.rollout_step(policy=learner, replay=rb, max_path_length=200, label_policy=tr.expert_policy)
+    assert rb.num_steps_can_sample() == 500 + 20 * 256
+    batch = rb._gather(np.arange(500, 500 + 20 * 256))
+    np.testing.assert_allclose(batch["actions"], expert.get_actions(batch["observations"], deterministic=True), rtol=1e-5, atol=1e-6)
+    err0 = np.abs(learner.get_actions(batch["observations"], deterministic=True) - batch["actions"]).mean()
+    for _ in range(6):
+        tr.end_epoch()
+        tr.train_from_replay(rb)
+    err1 = np.abs(learner.get_actions(batch["observations"], deterministic=True) - batch["actions"]).mean()
+    assert err1 < 0.4 * err0, (err0, err1)
