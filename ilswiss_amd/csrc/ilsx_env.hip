@@ -27,6 +27,8 @@ struct PlanarModelDev {
   double c_solref[2], c_solimp[3], l_solref[2], l_solimp[3];
   double ctrl_cost, alive, z_min, z_max, ang_max, state_max;
   double init_qpos[ENV_MAXB + 2];
+  // ScaledEnv / MinmaxEnv (wrappers.py:53-203): every observation the env produces is (raw - shift) * inv_scale
+  double obs_shift[2 * (ENV_MAXB + 2)], obs_inv_scale[2 * (ENV_MAXB + 2)];
 };
 
 struct ilsx_vecenv {
@@ -388,12 +390,14 @@ struct EnvStepArgs {
 };
 
 template <int NB>
-__device__ __forceinline__ void env_write_obs(const double (&q)[NB + 2], const double (&v)[NB + 2], float* dst) {
+__device__ __forceinline__ void env_write_obs(const PlanarModelDev& m, const double (&q)[NB + 2], const double (&v)[NB + 2],
+                                              float* dst) {
   constexpr int N = NB + 2;
 #pragma unroll
-  for (int i = 1; i < N; ++i) dst[i - 1] = (float)q[i];                       // qpos[1:]   (hopper.py:29-30)
+  for (int i = 1; i < N; ++i) dst[i - 1] = (float)((q[i] - m.obs_shift[i - 1]) * m.obs_inv_scale[i - 1]);   // qpos[1:] (hopper.py:29-30)
 #pragma unroll
-  for (int i = 0; i < N; ++i) dst[N - 1 + i] = (float)fmin(fmax(v[i], -10.0), 10.0);  // clip(qvel, +-10)
+  for (int i = 0; i < N; ++i)                                                                                // clip(qvel, +-10)
+    dst[N - 1 + i] = (float)((fmin(fmax(v[i], -10.0), 10.0) - m.obs_shift[N - 1 + i]) * m.obs_inv_scale[N - 1 + i]);
 }
 
 __device__ __forceinline__ double env_uniform(uint64_t seed, uint32_t stream, unsigned long long step, uint32_t env,
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
     ctrl[k] = a; ctrl_sq += a * a;
   }
   float obs_before[2 * N - 1];
-  if (A.replay) env_write_obs<NB>(q, v, obs_before);
+  if (A.replay) env_write_obs<NB>(m, q, v, obs_before);
   const double x0 = q[0];
   for (int s = 0; s < m.frame_skip; ++s) env_substep<NB, MR, BLOCK>(m, q, v, ctrl, smd, lane_in_block);
   const double dt = m.timestep * m.frame_skip;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
   }
   const bool done = !ok;
   float ob[2 * N - 1];
-  env_write_obs<NB>(q, v, ob);
+  env_write_obs<NB>(m, q, v, ob);
   if (A.obs) for (int i = 0; i < o; ++i) A.obs[(size_t)t * o + i] = ob[i];
   if (A.rew) A.rew[t] = (float)reward;
   if (A.done) A.done[t] = done ? 1 : 0;
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
       atomicAdd(&A.stats[0], 1.0);
       atomicAdd(&A.stats[1], ret);
       env_reset_state<NB>(m, A.seed, A.stream, A.step, (uint32_t)env, q, v);
-      env_write_obs<NB>(q, v, ob);
+      env_write_obs<NB>(m, q, v, ob);
     }
     A.ep_len[env] = end ? 0 : len;
     A.ep_ret[env] = end ? 0.0 : ret;
@@ -498,7 +502,7 @@ __global__ void k_env_reset(const PlanarModelDev* mp, double* qpos, double* qvel
   double q[N], v[N];
   env_reset_state<NB>(m, seed, stream, step, (uint32_t)env, q, v);
   float ob[2 * N - 1];
-  env_write_obs<NB>(q, v, ob);
+  env_write_obs<NB>(m, q, v, ob);
   for (int i = 0; i < m.obs_dim; ++i) {
     if (obs) obs[(size_t)t * m.obs_dim + i] = ob[i];
     if (obs_cur) obs_cur[(size_t)env * m.obs_dim + i] = ob[i];
@@ -605,6 +609,7 @@ extern "C" int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* pm, in
   e->n = m.nb + 2; e->o = 2 * e->n - 1; e->a = na;
   m.obs_dim = e->o;
   for (int i = 0; i < e->n; ++i) m.init_qpos[i] = pm->init_qpos[i];
+  for (int i = 0; i < 2 * (ENV_MAXB + 2); ++i) { m.obs_shift[i] = 0.0; m.obs_inv_scale[i] = 1.0; }
   const size_t N = (size_t)n_env;
   int rc = ctx_alloc(ctx, sizeof m, (void**)&e->dm);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->n * 8, (void**)&e->qpos);
@@ -726,6 +731,22 @@ extern "C" int ilsx_vecenv_cur_obs(ilsx_vecenv* e, float** dev_ptr) {
   if (!e || !dev_ptr) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
   *dev_ptr = const_cast<float*>(e->policy_obs());
   return ILSX_OK;
+}
+
+// ScaledEnv (obs - mean)/(std + EPS) and MinmaxEnv (obs - min)/(max - min + EPS) (wrappers.py:53-203): a fixed affine map of
+// every observation the env hands out or records; shift / scale are HOST float64 [obs_dim] (scale already includes EPS).
+// The envs are reset so that the observations they currently show follow the new map.
+extern "C" int ilsx_vecenv_set_obs_affine(ilsx_vecenv* e, const double* shift_host, const double* scale_host) {
+  if (!e || !shift_host || !scale_host) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_vecenv_set_obs_affine: NULL argument");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  for (int i = 0; i < e->o; ++i) {
+    if (!(scale_host[i] != 0.0)) ILSX_FAIL(ILSX_ERR_ARG, "observation scale %d is zero", i);
+    e->hm.obs_shift[i] = shift_host[i]; e->hm.obs_inv_scale[i] = 1.0 / scale_host[i];
+  }
+  HIPCHK(hipMemcpyAsync(e->dm, &e->hm, sizeof e->hm, hipMemcpyHostToDevice, e->ctx->stream));
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  ILSX_TRY(launch_env_reset(e, nullptr, e->n_env, nullptr));
+  return env_obs_norm(e, nullptr, 0, nullptr, e->obs_cur, e->obs_n, e->n_env);
 }
 
 // vecenvs.py:104-113 (obs_rms / norm_obs / update_obs_rms attributes of BaseVectorEnv)

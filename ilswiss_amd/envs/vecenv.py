@@ -50,6 +50,37 @@ def model_struct(m):
     return s
 
 
+EPS = np.finfo(np.float32).eps.item()   # rlkit/envs/wrappers.py:9
+
+
+class ProxyEnv:
+    """wrappers.py ProxyEnv: the identity wrapper the run scripts pass by default."""
+    shift = scale = None
+
+    def __init__(self, **kwargs):
+        pass
+
+
+class ScaledEnv(ProxyEnv):
+    """wrappers.py:53-131: obs -> (obs - obs_mean) / (obs_std + EPS).  (The action un-scaling half is unused by every spec:
+    acts_mean / acts_std are None in the run scripts.)"""
+
+    def __init__(self, obs_mean=None, obs_std=None, acts_mean=None, acts_std=None, **kwargs):
+        if acts_mean is not None or acts_std is not None:
+            raise NotImplementedError("action un-scaling is never enabled by the reference's scripts (adv_irl_exp_script.py:59)")
+        if obs_mean is not None:
+            self.shift, self.scale = np.asarray(obs_mean, np.float64), np.asarray(obs_std, np.float64) + EPS
+
+
+class MinmaxEnv(ProxyEnv):
+    """wrappers.py:134-203: obs -> (obs - obs_min) / (obs_max - obs_min + EPS)."""
+
+    def __init__(self, obs_min=None, obs_max=None, **kwargs):
+        if obs_min is not None:
+            self.shift = np.asarray(obs_min, np.float64)
+            self.scale = np.asarray(obs_max, np.float64) - self.shift + EPS
+
+
 class DeviceObsRms:
     """`env.obs_rms` (RunningMeanStd, normalizer.py:128-152) living on the device inside a HipVectorEnv: float64
     mean / var / count, read back on attribute access.  Passing one env's obs_rms to another env's constructor
@@ -75,7 +106,8 @@ class DeviceObsRms:
 
 
 class HipVectorEnv:
-    def __init__(self, env_name, env_num, seed=0, ctx=None, model=None, norm_obs=False, obs_rms=None, update_obs_rms=True):
+    def __init__(self, env_name, env_num, seed=0, ctx=None, model=None, norm_obs=False, obs_rms=None, update_obs_rms=True,
+                 obs_shift=None, obs_scale=None):
         self.ctx = ctx or get_context()
         self.model = model or MODELS[env_name]()
         self.env_num = int(env_num)
@@ -89,6 +121,11 @@ class HipVectorEnv:
         ac = Box(-np.ones(self.act_dim), np.ones(self.act_dim))
         self.observation_space, self.action_space = [ob] * self.env_num, [ac] * self.env_num  # vecenvs.py:118-140
         self.single_observation_space, self.single_action_space = ob, ac
+        self.obs_shift, self.obs_scale = obs_shift, obs_scale
+        if obs_shift is not None:   # ScaledEnv / MinmaxEnv folded into the stepper
+            sh, sc = np.ascontiguousarray(obs_shift, np.float64), np.ascontiguousarray(obs_scale, np.float64)
+            assert sh.shape == (self.obs_dim,) and sc.shape == (self.obs_dim,)
+            _lib.check(self.ctx.lib.ilsx_vecenv_set_obs_affine(self.h, sh.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)))
         # vecenvs.py:104-113
         self.norm_obs, self.update_obs_rms = bool(norm_obs), bool(update_obs_rms) and bool(norm_obs)
         self.obs_rms = DeviceObsRms(self) if norm_obs else None
@@ -102,6 +139,12 @@ class HipVectorEnv:
         """Pull the statistics of the env this one shares its obs_rms with (same object in the reference)."""
         if self._shared_rms is not None:
             self.obs_rms.set(*self._shared_rms._get())
+
+    def get_scaled_obs(self, obs):      # wrappers.py:101-105,176-180
+        return obs if self.obs_shift is None else (obs - self.obs_shift) / self.obs_scale
+
+    def get_unscaled_obs(self, obs):    # wrappers.py:95-99,170-174
+        return obs if self.obs_shift is None else obs * self.obs_scale + self.obs_shift
 
     def normalize_obs(self, obs):  # vecenvs.py:299-327
         if not self.norm_obs:
@@ -187,8 +230,9 @@ class HipVectorEnv:
 def get_envs(env_specs, env_wrapper=None, wrapper_kwargs=None, ctx=None, norm_obs=False, obs_rms=None, update_obs_rms=True,
              **kwargs):
     """rlkit/envs/__init__.py:72-132: env_specs{env_name, env_num, training_env_seed, ...} -> vec env.
-    NormalizedBoxEnv (the only wrapper on the hot path) is folded into the stepper; norm_obs / obs_rms /
-    update_obs_rms are BaseVectorEnv's (vecenvs.py:84-113)."""
+    NormalizedBoxEnv is folded into the stepper; env_wrapper = ProxyEnv / ScaledEnv / MinmaxEnv with wrapper_kwargs as in
+    adv_irl_exp_script.py:79-132; norm_obs / obs_rms / update_obs_rms are BaseVectorEnv's (vecenvs.py:84-113)."""
+    w = env_wrapper(**(wrapper_kwargs or {})) if env_wrapper is not None else ProxyEnv()
     return HipVectorEnv(env_specs["env_name"], env_specs.get("env_num", 1),
                         seed=env_specs.get("training_env_seed", env_specs.get("seed", 0)), ctx=ctx, norm_obs=norm_obs,
-                        obs_rms=obs_rms, update_obs_rms=update_obs_rms)
+                        obs_rms=obs_rms, update_obs_rms=update_obs_rms, obs_shift=w.shift, obs_scale=w.scale)

@@ -395,6 +395,10 @@ int ilsx_vecenv_step(ilsx_vecenv* env, const float* act, const int32_t* ids_host
 int ilsx_vecenv_get_state(ilsx_vecenv* env, double* qpos_host, double* qvel_host);
 int ilsx_vecenv_set_state(ilsx_vecenv* env, const double* qpos_host, const double* qvel_host);
 int ilsx_vecenv_cur_obs(ilsx_vecenv* env, float** dev_ptr);  /* [n_env,o] current (normalised if norm_obs) observations (device) */
+/* ScaledEnv / MinmaxEnv (rlkit/envs/wrappers.py:53-203): every observation the env hands out or records becomes
+ * (raw - shift) / scale; shift / scale are HOST float64 [obs_dim], scale already including the wrappers' EPS
+ * (std + EPS, or max - min + EPS).  Resets all envs. */
+int ilsx_vecenv_set_obs_affine(ilsx_vecenv* env, const double* shift_host, const double* scale_host);
 /* Running observation statistics of BaseVectorEnv (vecenvs.py:104-113,299-327; RunningMeanStd normalizer.py:128-152):
  * norm_obs: reset/step/cur_obs/rollouts return clip((obs-mean)/sqrt(var+eps), +-10); update_obs_rms: every batch of
  * observations returned by reset/step updates (mean, var, count) first.  Statistics are float64; get/set use HOST arrays

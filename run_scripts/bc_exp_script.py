@@ -3,14 +3,14 @@
 expert demonstrations through `demos_listing.yaml` (expert_name / expert_idx / traj_num) into an expert replay buffer, a
 tanh-Gaussian policy of policy_net_size x policy_num_hidden_layers, `bc_params` = the kwargs of BC (bc/bc.py:14-41) plus the
 loop keys.  The loop is BC.start_training (bc.py:56-75): no environment sampling, `num_updates_per_train_call` updates every
-`num_steps_between_train_calls` counted steps, evaluation every epoch.  ScaledEnv / MinmaxEnv observation wrappers
-(scale_env_with_demo_stats / minmax_env_with_demo_stats) are not implemented: the spec must leave them false."""
+`num_steps_between_train_calls` counted steps, evaluation every epoch.  scale_env_with_demo_stats /
+minmax_env_with_demo_stats wrap the envs in ScaledEnv / MinmaxEnv with the demonstrations' statistics (:56-97)."""
 import time
 from collections import OrderedDict
 
 import numpy as np
 from _common import ia, main, make_envs, start
-from adv_irl_exp_script import load_demos
+from adv_irl_exp_script import demo_stat_wrapper, load_demos
 
 from ilswiss_amd.algorithm import TabularLogger
 from ilswiss_amd.bc import BC
@@ -20,12 +20,11 @@ from ilswiss_amd.samplers import DeviceEvalSampler
 
 def experiment(variant, gpu=0, log_dir=None):
     ctx = start(variant, gpu)
-    if variant.get("scale_env_with_demo_stats") or variant.get("minmax_env_with_demo_stats"):
-        raise NotImplementedError("ScaledEnv / MinmaxEnv wrappers are not implemented; set both *_with_demo_stats to false")
     import random
     random.seed(int(variant.get("seed", 0)))
     traj_list = load_demos(variant)
-    training_env, eval_env, env = make_envs(variant, ctx)
+    wrapper, wrapper_kwargs = demo_stat_wrapper(variant, traj_list)
+    training_env, eval_env, env = make_envs(variant, ctx, env_wrapper=wrapper, wrapper_kwargs=wrapper_kwargs)
     p = dict(variant["bc_params"])
     expert_rb = EnvReplayBuffer(p["replay_buffer_size"], env, random_seed=int(np.random.randint(10000)), ctx=ctx)
     for tj in traj_list:

@@ -91,3 +91,40 @@ def test_rollout_step_fills_replay_and_auto_resets(ctx):
     q, v = env.get_state()
     assert np.isfinite(q).all() and (q[:, 1] > 0.5).all()
     env.close()
+
+
+@pytest.mark.gpu
+def test_scaled_and_minmax_env_wrappers(ctx):
+    """ScaledEnv / MinmaxEnv (wrappers.py:53-203) folded into the stepper: reset / step / replay records all carry the mapped
+    observation; rewards and dynamics are untouched."""
+    from ilswiss_amd.envs.vecenv import EPS, MinmaxEnv, ScaledEnv, get_envs
+    from ilswiss_amd.replay import SimpleReplayBuffer
+    rng = np.random.default_rng(2)
+    mean, std = rng.normal(0, 1, 11), rng.uniform(0.5, 2.0, 11)
+    lo = rng.normal(-1, 0.3, 11)
+    hi = lo + rng.uniform(1.0, 3.0, 11)
+    spec = dict(env_name="hopper", env_num=16, training_env_seed=8)
+    raw = get_envs(spec, ctx=ctx)
+    for wrapper, kw, f in ((ScaledEnv, dict(obs_mean=mean, obs_std=std), lambda x: (x - mean) / (std + EPS)),
+                           (MinmaxEnv, dict(obs_min=lo, obs_max=hi), lambda x: (x - lo) / (hi - lo + EPS))):
+        env = get_envs(spec, env_wrapper=wrapper, wrapper_kwargs=kw, ctx=ctx)
+        o0 = env.reset()
+        q, v = env.get_state()
+        raw_obs = np.concatenate([q[:, 1:], np.clip(v, -10, 10)], axis=1)
+        np.testing.assert_allclose(o0, f(raw_obs), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(env.get_unscaled_obs(o0), raw_obs, rtol=1e-5, atol=1e-5)
+        for _ in range(3):
+            act = rng.uniform(-1, 1, (16, 3)).astype(np.float32)
+            raw.set_state(*env.get_state())
+            o_r, r_r, d_r, _ = raw.step(act)
+            o_w, r_w, d_w, _ = env.step(act)
+            np.testing.assert_allclose(o_w, f(o_r), rtol=2e-6, atol=2e-6)
+            np.testing.assert_array_equal(r_w, r_r)
+            np.testing.assert_array_equal(d_w, d_r)
+        # the fused rollout records the mapped observations too
+        rb = SimpleReplayBuffer(64, 11, 3, random_seed=0, ctx=ctx)
+        q, v = env.get_state()
+        before = f(np.concatenate([q[:, 1:], np.clip(v, -10, 10)], axis=1))
+        env.rollout_step(replay=rb, random_actions=True, max_path_length=1000)
+        batch = rb._gather(np.arange(16))
+        np.testing.assert_allclose(batch["observations"], before, rtol=2e-6, atol=2e-6)
