@@ -15,6 +15,7 @@
 //                fwd{Q1,Q2(s,a~) updated} ; bwd{Q1,Q2 -> d(-min Q)/da~} ; bwd{pi: tanh-Gaussian head} ; dW+Adam{pi}
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "host_common.h"
 
@@ -57,6 +58,7 @@ struct AcAgent {
   AcScalars* sc = nullptr;
   DevScalars* dsc = nullptr;
   uint32_t rng_stream = 0;
+  int cs = 1;   // column-split factor of the 2-hidden-layer fast path (1 = generic kernels)
   // batch staging + per-net activation workspaces
   float *s = nullptr, *ac = nullptr, *r = nullptr, *d = nullptr, *s2 = nullptr, *eps = nullptr;
   bool eps_explicit = false;
@@ -74,6 +76,7 @@ static int ac_init(AcAgent* g, ilsx_ctx* ctx, ilsx_net* const* nets, int nnets, 
   g->ctx = ctx; g->nnets = nnets; g->max_batch = max_batch; g->o = o; g->a = a;
   const ilsx_mlp_cfg& c0 = nets[0]->lay.cfg;
   g->H = c0.hidden; g->act = c0.act;
+  g->cs = getenv("ILSX_NO_SPLIT") ? 1 : mlp2_split_factor(c0.n_hidden, c0.hidden);
   for (int i = 0; i < nnets; ++i) {
     const ilsx_mlp_cfg& c = nets[i]->lay.cfg;
     if (nets[i]->ctx != ctx) ILSX_FAIL(ILSX_ERR_ARG, "a network belongs to another ctx");
@@ -165,14 +168,18 @@ static void ac_fwd(AcAgent* g, FwdTask& t, int net, bool target, const float* x0
 static FwdArgs ac_fwd_args(AcAgent* g, int ntasks) {
   FwdArgs A;
   memset(&A, 0, sizeof A);
-  A.rows = g->B; A.ntasks = ntasks; A.seed = g->ctx->seed; A.scal = g->dsc;
+  A.rows = g->B; A.ntasks = ntasks; A.seed = g->ctx->seed; A.scal = g->dsc; A.part_stride = g->max_batch;
   return A;
 }
+// a network's scalar / vector output: whole (generic kernels) or as cs column-slice partial slabs (split kernels)
+static void ac_out(AcAgent* g, FwdTask& t, float* buf) { if (g->cs > 1) t.part = buf; else t.out = buf; }
+static int ac_launch_fwd(AcAgent* g, const FwdArgs& A, int KP) { return launch_fwd(g->ctx, A, g->H, g->act, KP, g->cs); }
+static int ac_launch_bwd(AcAgent* g, const BwdArgs& A) { return launch_bwd_dx(g->ctx, A, g->H, g->act, g->cs); }
 static BwdArgs ac_bwd_args(AcAgent* g, int ntasks, float gamma, float reward_scale) {
   BwdArgs A;
   memset(&A, 0, sizeof A);
   A.rows = g->B; A.ntasks = ntasks; A.inv_B = 1.0f / (float)g->B; A.gamma = gamma; A.reward_scale = reward_scale;
-  A.scal = g->dsc; A.ga_parts = 1; A.ga_stride = g->max_batch;
+  A.scal = g->dsc; A.ga_parts = g->cs; A.ga_stride = g->max_batch; A.part_stride = g->max_batch;
   return A;
 }
 static void ac_bwd(AcAgent* g, BwdTask& t, int net, bool save_d) {
@@ -193,7 +200,7 @@ static int ac_dw_adam(AcAgent* g, int net0, int nnet, bool polyak, float tau) {
   F.step_size = &g->sc->step[op]; F.bc2_sqrt = &g->sc->bc2s[op];
   return launch_bwd_dw(g->ctx, table, g->B, &F);
 }
-static PartVal pv(const float* p, int stride) { return PartVal{p, 1, stride}; }
+static PartVal pv(AcAgent* g, const float* p) { return PartVal{p, g->cs, g->max_batch}; }
 
 static int ac_params(AcAgent* g, int which, bool set, float* host, size_t n) {
   if (!host || which < 0 || which >= 2 * g->nnets) ILSX_FAIL(ILSX_ERR_ARG, "parameter block %d out of range", which);
@@ -206,6 +213,19 @@ static int ac_params(AcAgent* g, int which, bool set, float* host, size_t n) {
 static int ac_fetch(AcAgent* g, const float* dev, size_t n, std::vector<float>& out) {
   out.resize(n);
   HIPCHK(hipMemcpyAsync(out.data(), dev, n * 4, hipMemcpyDeviceToHost, g->ctx->stream));
+  return ILSX_OK;
+}
+// per-row scalar that may sit in cs partial slabs of max_batch rows: fetch and combine in slab order (synchronises)
+static int ac_fetch_pv(AcAgent* g, const float* dev, size_t B, std::vector<float>& out) {
+  std::vector<float> raw((size_t)g->cs * g->max_batch);
+  HIPCHK(hipMemcpyAsync(raw.data(), dev, raw.size() * 4, hipMemcpyDeviceToHost, g->ctx->stream));
+  HIPCHK(hipStreamSynchronize(g->ctx->stream));
+  out.assign(B, 0.0f);
+  for (size_t i = 0; i < B; ++i) {
+    float v = raw[i];
+    for (int c = 1; c < g->cs; ++c) v += raw[(size_t)c * g->max_batch + i];
+    out[i] = v;
+  }
   return ILSX_OK;
 }
 // create_stats_ordered_dict (core/eval_util.py): mean, population std, max, min
@@ -228,6 +248,18 @@ static float mean_sq_diff(const std::vector<float>& a, const std::vector<float>&
   return (float)(s / (double)a.size());
 }
 
+static void ac_policy_fin(AcAgent* g, FwdArgs& A, int head, const float* part, const float* eps, float* raw, float* action,
+                          float* logp, float* eps_save, float noise, float noise_clip, float max_act) {
+  if (g->cs == 1) return;   // generic kernels finish the head in their own epilogue
+  PolicyFinishArgs& P = A.fin;
+  memset(&P, 0, sizeof P);
+  P.part = part; P.cs = g->cs; P.part_stride = g->max_batch; P.rows = g->B; P.a = g->a; P.head = head;
+  P.rng_stream = g->rng_stream; P.seed = g->ctx->seed; P.scal = g->dsc;
+  P.eps = eps; P.raw = raw; P.action = action; P.logp = logp; P.eps_save = eps_save;
+  P.noise = noise; P.noise_clip = noise_clip; P.max_act = max_act;
+  A.fin_on = 1;
+}
+
 // ================================================================================================ TD3
 enum { T3_Q1 = 0, T3_Q2 = 1, T3_PI = 2 };
 struct ilsx_td3 {
@@ -236,6 +268,7 @@ struct ilsx_td3 {
   long long n_steps = 0;
   float *a2 = nullptr, *q1 = nullptr, *q2 = nullptr, *tq1 = nullptr, *tq2 = nullptr;   // critic phase
   float *pa = nullptr, *pre = nullptr, *qn = nullptr, *ga = nullptr;                     // actor phase
+  float *ppt = nullptr, *ppc = nullptr;   // head partials of pi_tgt(s') / pi(s) (column-split path)
 };
 
 extern "C" int ilsx_td3_create(ilsx_ctx* ctx, const ilsx_td3_cfg* cfg, ilsx_net* pi, ilsx_net* q1, ilsx_net* q2, ilsx_td3** out) {
@@ -255,12 +288,15 @@ extern "C" int ilsx_td3_create(ilsx_ctx* ctx, const ilsx_td3_cfg* cfg, ilsx_net*
   g->lr[0] = cfg->qf_lr; g->lr[1] = cfg->policy_lr; g->beta_1 = 0.9f;   // optimizer_class defaults, td3.py:56-67
   int rc = ac_init(g, ctx, nets, 3, opt_of, cfg->max_batch, cp.in_dim, cp.out_dim);
   const size_t B = (size_t)cfg->max_batch, a = (size_t)cp.out_dim;
+  const size_t CS = (size_t)g->cs;
   float** bufs[] = {&t->q1, &t->q2, &t->tq1, &t->tq2, &t->qn};
-  for (float** b : bufs) if (rc == ILSX_OK) rc = ac_alloc(g, b, B);
+  for (float** b : bufs) if (rc == ILSX_OK) rc = ac_alloc(g, b, CS * B);
   if (rc == ILSX_OK) rc = ac_alloc(g, &t->a2, B * a);
   if (rc == ILSX_OK) rc = ac_alloc(g, &t->pa, B * a);
   if (rc == ILSX_OK) rc = ac_alloc(g, &t->pre, B * a);
-  if (rc == ILSX_OK) rc = ac_alloc(g, &t->ga, B * a);
+  if (rc == ILSX_OK) rc = ac_alloc(g, &t->ga, CS * B * a);
+  if (rc == ILSX_OK) rc = ac_alloc(g, &t->ppt, CS * B * a);
+  if (rc == ILSX_OK) rc = ac_alloc(g, &t->ppc, CS * B * a);
   if (rc == ILSX_OK) rc = ac_tick(g, 0, 0);
   if (rc != ILSX_OK) { delete t; return rc; }
   pi->noise = cfg->policy_noise; pi->noise_clip = cfg->policy_noise_clip; pi->max_act = cfg->max_act; pi->noise_policy = true;
@@ -274,43 +310,54 @@ extern "C" int ilsx_td3_destroy(ilsx_td3* t) {
   return ILSX_OK;
 }
 
-static void td3_policy_task(ilsx_td3* t, FwdTask& f, bool target, const float* obs, bool noisy, bool save, float* action, float* pre) {
+// policy trunk as a forward task; generic kernels finish the head (tanh + clipped noise) in their epilogue, the column-split
+// kernels leave head partials that the consumer launch finishes (td3_policy_fin)
+static void td3_policy_task(ilsx_td3* t, FwdTask& f, bool target, const float* obs, bool noisy, bool save, float* action, float* pre,
+                            float* part) {
   AcAgent* g = &t->g;
   ac_fwd(g, f, T3_PI, target, obs, g->o, nullptr, 0, save);
-  f.head = HEAD_DET_TANH_NOISE; f.action = action; f.out = pre;
+  f.head = HEAD_DET_TANH_NOISE; f.rng_stream = g->rng_stream;
+  if (g->cs > 1) { f.part = part; return; }
+  f.action = action; f.out = pre;
   f.max_act = t->cfg.max_act; f.noise = noisy ? t->cfg.policy_noise : 0.0f; f.noise_clip = t->cfg.policy_noise_clip;
-  f.eps = (noisy && g->eps_explicit) ? g->eps : nullptr; f.rng_stream = g->rng_stream;
+  f.eps = (noisy && g->eps_explicit) ? g->eps : nullptr;
+}
+static void td3_policy_fin(ilsx_td3* t, FwdArgs& A, bool noisy, const float* part, float* action, float* pre) {
+  AcAgent* g = &t->g;
+  ac_policy_fin(g, A, HEAD_DET_TANH_NOISE, part, (noisy && g->eps_explicit) ? g->eps : nullptr, pre, action, nullptr, nullptr,
+                noisy ? t->cfg.policy_noise : 0.0f, t->cfg.policy_noise_clip, t->cfg.max_act);
 }
 
-static int td3_actor_forward(ilsx_td3* t, bool save) {
+// Q1(s, pi(s)) with the updated qf1 (td3.py:111-113); pi(s)'s trunk already ran in the step's first launch
+static int td3_actor_q(ilsx_td3* t, bool save) {
   AcAgent* g = &t->g;
-  {
-    FwdArgs A = ac_fwd_args(g, 1);
-    td3_policy_task(t, A.t[0], false, g->s, false, save, t->pa, t->pre);   // deterministic=True, td3.py:111
-    ILSX_TRY(launch_fwd(g->ctx, A, g->H, g->act, g->L[T3_PI].KP));
-  }
   FwdArgs A = ac_fwd_args(g, 1);
   ac_fwd(g, A.t[0], T3_Q1, false, g->s, g->o, t->pa, g->a, false);
   if (save) for (int l = 0; l < g->L[T3_Q1].cfg.n_hidden; ++l) A.t[0].hsave[l] = g->h[T3_Q1][l];
-  A.t[0].out = t->qn;
-  return launch_fwd(g->ctx, A, g->H, g->act, g->L[T3_Q1].KP);
+  ac_out(g, A.t[0], t->qn);
+  td3_policy_fin(t, A, false, t->ppc, t->pa, t->pre);   // deterministic=True
+  return ac_launch_fwd(g, A, g->L[T3_Q1].KP);
 }
 
 static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
   AcAgent* g = &t->g;
   const ilsx_td3_cfg& c = t->cfg;
-  {  // noisy target action (td3.py:84-85; the target is policy.copy() and keeps its noise)
-    FwdArgs A = ac_fwd_args(g, 1);
-    td3_policy_task(t, A.t[0], true, g->s2, true, false, t->a2, nullptr);
-    ILSX_TRY(launch_fwd(g->ctx, A, g->H, g->act, g->L[T3_PI].KP));
+  const bool update = t->n_steps % c.policy_and_target_update_period == 0;
+  const bool actor = update || stats != nullptr;
+  {  // noisy target action (td3.py:84-85; the target is policy.copy() and keeps its noise) ; pi(s) rides along when needed
+    FwdArgs A = ac_fwd_args(g, actor ? 2 : 1);
+    td3_policy_task(t, A.t[0], true, g->s2, true, false, t->a2, nullptr, t->ppt);
+    if (actor) td3_policy_task(t, A.t[1], false, g->s, false, update, t->pa, t->pre, t->ppc);
+    ILSX_TRY(ac_launch_fwd(g, A, g->L[T3_PI].KP));
   }
   {
     FwdArgs A = ac_fwd_args(g, 4);
-    ac_fwd(g, A.t[0], T3_Q1, true, g->s2, g->o, t->a2, g->a, false); A.t[0].out = t->tq1;
-    ac_fwd(g, A.t[1], T3_Q2, true, g->s2, g->o, t->a2, g->a, false); A.t[1].out = t->tq2;
-    ac_fwd(g, A.t[2], T3_Q1, false, g->s, g->o, g->ac, g->a, true); A.t[2].out = t->q1;
-    ac_fwd(g, A.t[3], T3_Q2, false, g->s, g->o, g->ac, g->a, true); A.t[3].out = t->q2;
-    ILSX_TRY(launch_fwd(g->ctx, A, g->H, g->act, g->L[T3_Q1].KP));
+    ac_fwd(g, A.t[0], T3_Q1, true, g->s2, g->o, t->a2, g->a, false); ac_out(g, A.t[0], t->tq1);
+    ac_fwd(g, A.t[1], T3_Q2, true, g->s2, g->o, t->a2, g->a, false); ac_out(g, A.t[1], t->tq2);
+    ac_fwd(g, A.t[2], T3_Q1, false, g->s, g->o, g->ac, g->a, true); ac_out(g, A.t[2], t->q1); A.t[2].no_fin = 1;
+    ac_fwd(g, A.t[3], T3_Q2, false, g->s, g->o, g->ac, g->a, true); ac_out(g, A.t[3], t->q2); A.t[3].no_fin = 1;
+    td3_policy_fin(t, A, true, t->ppt, t->a2, nullptr);
+    ILSX_TRY(ac_launch_fwd(g, A, g->L[T3_Q1].KP));
   }
   {
     BwdArgs A = ac_bwd_args(g, 2, c.discount, c.reward_scale);
@@ -318,14 +365,13 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
       BwdTask& b = A.t[i];
       ac_bwd(g, b, i, true);
       b.loss = LOSS_TD_CRITIC; b.coef = 2.0f;   // nn.MSELoss: no 1/2 (td3.py:36-37,92-97)
-      b.q = pv(i == 0 ? t->q1 : t->q2, g->max_batch); b.tq1 = pv(t->tq1, g->max_batch); b.tq2 = pv(t->tq2, g->max_batch);
+      b.q = pv(g, i == 0 ? t->q1 : t->q2); b.tq1 = pv(g, t->tq1); b.tq2 = pv(g, t->tq2);
       b.rew = g->r; b.done = g->d;
     }
-    ILSX_TRY(launch_bwd_dx(g->ctx, A, g->H, g->act));
+    ILSX_TRY(ac_launch_bwd(g, A));
   }
   ILSX_TRY(ac_dw_adam(g, T3_Q1, 2, false, 0.f));
-  const bool update = t->n_steps % c.policy_and_target_update_period == 0;
-  if (update || stats) ILSX_TRY(td3_actor_forward(t, update));
+  if (actor) ILSX_TRY(td3_actor_q(t, update));
   if (update) {  // td3.py:109-122
     {
       BwdArgs A = ac_bwd_args(g, 1, 0.f, 0.f);
@@ -333,14 +379,14 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
       ac_bwd(g, b, T3_Q1, false);
       b.loss = LOSS_CONST; b.coef = -1.0f;
       b.dx = t->ga; b.dx_col0 = g->o; b.dx_cols = g->a;
-      ILSX_TRY(launch_bwd_dx(g->ctx, A, g->H, g->act));
+      ILSX_TRY(ac_launch_bwd(g, A));
     }
     {
       BwdArgs A = ac_bwd_args(g, 1, 0.f, 0.f);
       BwdTask& b = A.t[0];
       ac_bwd(g, b, T3_PI, true);
       b.loss = LOSS_TD3_POLICY; b.coef = c.max_act; b.raw = t->pre; b.ga1 = t->ga;
-      ILSX_TRY(launch_bwd_dx(g->ctx, A, g->H, g->act));
+      ILSX_TRY(ac_launch_bwd(g, A));
     }
     ILSX_TRY(ac_dw_adam(g, T3_PI, 1, false, 0.f));
     hipLaunchKernelGGL(k_ac_polyak, dim3(256), dim3(256), 0, g->ctx->stream, (const float*)g->P, g->T, (int)g->off[3], c.soft_target_tau);
@@ -351,9 +397,9 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
   if (stats) {  // td3.py:124-176; the device buffers still hold this step's predictions (taken before the Adam steps)
     const size_t B = (size_t)g->B;
     std::vector<float> q1, q2, tq1, tq2, r, d, qn, pa;
-    ILSX_TRY(ac_fetch(g, t->q1, B, q1)); ILSX_TRY(ac_fetch(g, t->q2, B, q2)); ILSX_TRY(ac_fetch(g, t->tq1, B, tq1));
-    ILSX_TRY(ac_fetch(g, t->tq2, B, tq2)); ILSX_TRY(ac_fetch(g, g->r, B, r)); ILSX_TRY(ac_fetch(g, g->d, B, d));
-    ILSX_TRY(ac_fetch(g, t->qn, B, qn)); ILSX_TRY(ac_fetch(g, t->pa, B * g->a, pa));
+    ILSX_TRY(ac_fetch_pv(g, t->q1, B, q1)); ILSX_TRY(ac_fetch_pv(g, t->q2, B, q2)); ILSX_TRY(ac_fetch_pv(g, t->tq1, B, tq1));
+    ILSX_TRY(ac_fetch_pv(g, t->tq2, B, tq2)); ILSX_TRY(ac_fetch(g, g->r, B, r)); ILSX_TRY(ac_fetch(g, g->d, B, d));
+    ILSX_TRY(ac_fetch_pv(g, t->qn, B, qn)); ILSX_TRY(ac_fetch(g, t->pa, B * g->a, pa));
     HIPCHK(hipStreamSynchronize(g->ctx->stream));
     std::vector<float> y(B), e1, e2;
     for (size_t i = 0; i < B; ++i) y[i] = c.reward_scale * r[i] + (1.0f - d[i]) * c.discount * std::min(tq1[i], tq2[i]);
@@ -409,6 +455,7 @@ struct ilsx_sacv {
   ilsx_sacv_cfg cfg;
   float *q1 = nullptr, *q2 = nullptr, *tv = nullptr, *v = nullptr, *q1n0 = nullptr, *q2n0 = nullptr, *q1n = nullptr, *q2n = nullptr;
   float *raw = nullptr, *an = nullptr, *logp = nullptr, *epss = nullptr, *ga[2] = {nullptr, nullptr};
+  float* ppart = nullptr;   // head partials of pi(s) (column-split path)
 };
 
 extern "C" int ilsx_sacv_create(ilsx_ctx* ctx, const ilsx_sacv_cfg* cfg, ilsx_net* pi, ilsx_net* q1, ilsx_net* q2, ilsx_net* vf,
@@ -429,11 +476,15 @@ extern "C" int ilsx_sacv_create(ilsx_ctx* ctx, const ilsx_sacv_cfg* cfg, ilsx_ne
   g->lr[0] = cfg->qf_lr; g->lr[1] = cfg->vf_lr; g->lr[2] = cfg->policy_lr; g->beta_1 = cfg->beta_1;
   int rc = ac_init(g, ctx, nets, 4, opt_of, cfg->max_batch, cp.in_dim, cp.out_dim);
   const size_t B = (size_t)cfg->max_batch, a = (size_t)cp.out_dim;
-  float** bufs[] = {&s->q1, &s->q2, &s->tv, &s->v, &s->q1n0, &s->q2n0, &s->q1n, &s->q2n, &s->logp};
-  for (float** b : bufs) if (rc == ILSX_OK) rc = ac_alloc(g, b, B);
+  const size_t CS = (size_t)g->cs;
+  float** bufs[] = {&s->q1, &s->q2, &s->tv, &s->v, &s->q1n0, &s->q2n0, &s->q1n, &s->q2n};
+  for (float** b : bufs) if (rc == ILSX_OK) rc = ac_alloc(g, b, CS * B);
+  if (rc == ILSX_OK) rc = ac_alloc(g, &s->logp, B);
   if (rc == ILSX_OK) rc = ac_alloc(g, &s->raw, B * 2 * a);
-  float** abufs[] = {&s->an, &s->epss, &s->ga[0], &s->ga[1]};
+  if (rc == ILSX_OK) rc = ac_alloc(g, &s->ppart, CS * B * 2 * a);
+  float** abufs[] = {&s->an, &s->epss};
   for (float** b : abufs) if (rc == ILSX_OK) rc = ac_alloc(g, b, B * a);
+  for (int i = 0; i < 2; ++i) if (rc == ILSX_OK) rc = ac_alloc(g, &s->ga[i], CS * B * a);
   if (rc == ILSX_OK) {  // fixed temperature (sac.py:68): the policy loss head reads it from the device scalars
     DevScalars h;
     memset(&h, 0, sizeof h);
@@ -453,56 +504,61 @@ extern "C" int ilsx_sacv_destroy(ilsx_sacv* s) {
   return ILSX_OK;
 }
 
-static int sacv_q_pair(ilsx_sacv* s, float* o1, float* o2, bool save_h) {  // Q1, Q2 at (s, a~)
+static int sacv_q_pair(ilsx_sacv* s, float* o1, float* o2, bool save_h) {  // Q1, Q2 at (s, a~), a~ already published
   AcAgent* g = &s->g;
   FwdArgs A = ac_fwd_args(g, 2);
   for (int i = 0; i < 2; ++i) {
     ac_fwd(g, A.t[i], i, false, g->s, g->o, s->an, g->a, false);
     if (save_h) for (int l = 0; l < g->L[i].cfg.n_hidden; ++l) A.t[i].hsave[l] = g->h[i][l];
-    A.t[i].out = i == 0 ? o1 : o2;
+    ac_out(g, A.t[i], i == 0 ? o1 : o2);
   }
-  return launch_fwd(g->ctx, A, g->H, g->act, g->L[SV_Q1].KP);
+  return ac_launch_fwd(g, A, g->L[SV_Q1].KP);
 }
 
 static int sacv_step(ilsx_sacv* s, ilsx_sacv_stats* stats) {
   AcAgent* g = &s->g;
   const ilsx_sacv_cfg& c = s->cfg;
-  const int mb = g->max_batch;
-  {
+  const float* eps = g->eps_explicit ? g->eps : nullptr;
+  {  // Q1(s,a) ; Q2(s,a) ; V(s) ; pi(s): the one policy sample of the step (sac.py:123-125)
     FwdArgs A = ac_fwd_args(g, 4);
-    ac_fwd(g, A.t[0], SV_Q1, false, g->s, g->o, g->ac, g->a, true); A.t[0].out = s->q1;
-    ac_fwd(g, A.t[1], SV_Q2, false, g->s, g->o, g->ac, g->a, true); A.t[1].out = s->q2;
-    ac_fwd(g, A.t[2], SV_V, true, g->s2, g->o, nullptr, 0, false); A.t[2].out = s->tv;
-    ac_fwd(g, A.t[3], SV_V, false, g->s, g->o, nullptr, 0, true); A.t[3].out = s->v;
-    ILSX_TRY(launch_fwd(g->ctx, A, g->H, g->act, std::max(g->L[SV_Q1].KP, g->L[SV_V].KP)));
-  }
-  {  // one policy sample for the whole step (sac.py:123-125)
-    FwdArgs A = ac_fwd_args(g, 1);
-    FwdTask& f = A.t[0];
+    ac_fwd(g, A.t[0], SV_Q1, false, g->s, g->o, g->ac, g->a, true); ac_out(g, A.t[0], s->q1);
+    ac_fwd(g, A.t[1], SV_Q2, false, g->s, g->o, g->ac, g->a, true); ac_out(g, A.t[1], s->q2);
+    ac_fwd(g, A.t[2], SV_V, false, g->s, g->o, nullptr, 0, true); ac_out(g, A.t[2], s->v);
+    FwdTask& f = A.t[3];
     ac_fwd(g, f, SV_PI, false, g->s, g->o, nullptr, 0, true);
-    f.head = HEAD_TANH_SAMPLE; f.rng_stream = g->rng_stream; f.eps = g->eps_explicit ? g->eps : nullptr;
-    f.action = s->an; f.logp = s->logp; f.out = s->raw; f.eps_save = s->epss;
-    ILSX_TRY(launch_fwd(g->ctx, A, g->H, g->act, g->L[SV_PI].KP));
+    f.head = HEAD_TANH_SAMPLE; f.rng_stream = g->rng_stream;
+    if (g->cs > 1) f.part = s->ppart;
+    else { f.eps = eps; f.action = s->an; f.logp = s->logp; f.out = s->raw; f.eps_save = s->epss; }
+    ILSX_TRY(ac_launch_fwd(g, A, std::max(g->L[SV_Q1].KP, g->L[SV_V].KP)));
   }
-  ILSX_TRY(sacv_q_pair(s, s->q1n0, s->q2n0, false));   // pre-update critics -> v_target
+  {  // pre-update critics at (s, a~) -> v_target ; target V(s') ; prologue: finish pi(s) (sample, log-prob)
+    FwdArgs A = ac_fwd_args(g, 3);
+    for (int i = 0; i < 2; ++i) {
+      ac_fwd(g, A.t[i], i, false, g->s, g->o, s->an, g->a, false);
+      ac_out(g, A.t[i], i == 0 ? s->q1n0 : s->q2n0);
+    }
+    ac_fwd(g, A.t[2], SV_V, true, g->s2, g->o, nullptr, 0, false); ac_out(g, A.t[2], s->tv);
+    ac_policy_fin(g, A, HEAD_TANH_SAMPLE, s->ppart, eps, s->raw, s->an, s->logp, s->epss, 0.f, 0.f, 1.f);
+    ILSX_TRY(ac_launch_fwd(g, A, std::max(g->L[SV_Q1].KP, g->L[SV_V].KP)));
+  }
   {
     BwdArgs A = ac_bwd_args(g, 2, c.discount, c.reward_scale);
     for (int i = 0; i < 2; ++i) {
       BwdTask& b = A.t[i];
       ac_bwd(g, b, i, true);
       b.loss = LOSS_TD_CRITIC; b.coef = 1.0f;   // 0.5*mean(.)^2 (sac.py:104-105)
-      b.q = pv(i == 0 ? s->q1 : s->q2, mb); b.tq1 = pv(s->tv, mb); b.tq2 = pv(s->tv, mb);
+      b.q = pv(g, i == 0 ? s->q1 : s->q2); b.tq1 = pv(g, s->tv); b.tq2 = pv(g, s->tv);
       b.rew = g->r; b.done = g->d;
     }
-    ILSX_TRY(launch_bwd_dx(g->ctx, A, g->H, g->act));
+    ILSX_TRY(ac_launch_bwd(g, A));
   }
   {
     BwdArgs A = ac_bwd_args(g, 1, 0.f, 0.f);
     BwdTask& b = A.t[0];
     ac_bwd(g, b, SV_V, true);
     b.loss = LOSS_SACV_VALUE; b.coef = c.alpha;
-    b.q = pv(s->v, mb); b.q1n = pv(s->q1n0, mb); b.q2n = pv(s->q2n0, mb); b.logp_next = s->logp;
-    ILSX_TRY(launch_bwd_dx(g->ctx, A, g->H, g->act));
+    b.q = pv(g, s->v); b.q1n = pv(g, s->q1n0); b.q2n = pv(g, s->q2n0); b.logp_next = s->logp;
+    ILSX_TRY(ac_launch_bwd(g, A));
   }
   ILSX_TRY(ac_dw_adam(g, SV_Q1, 2, false, 0.f));
   ILSX_TRY(ac_dw_adam(g, SV_V, 1, true, c.soft_target_tau));   // target V <- post-Adam V (sac.py:179,242-243)
@@ -512,10 +568,10 @@ static int sacv_step(ilsx_sacv* s, ilsx_sacv_stats* stats) {
     for (int i = 0; i < 2; ++i) {
       BwdTask& b = A.t[i];
       ac_bwd(g, b, i, false);
-      b.loss = LOSS_SAC_ACTORQ; b.which = i; b.q1n = pv(s->q1n, mb); b.q2n = pv(s->q2n, mb);
+      b.loss = LOSS_SAC_ACTORQ; b.which = i; b.q1n = pv(g, s->q1n); b.q2n = pv(g, s->q2n);
       b.dx = s->ga[i]; b.dx_col0 = g->o; b.dx_cols = g->a;
     }
-    ILSX_TRY(launch_bwd_dx(g->ctx, A, g->H, g->act));
+    ILSX_TRY(ac_launch_bwd(g, A));
   }
   {
     BwdArgs A = ac_bwd_args(g, 1, 0.f, 0.f);
@@ -523,16 +579,16 @@ static int sacv_step(ilsx_sacv* s, ilsx_sacv_stats* stats) {
     BwdTask& b = A.t[0];
     ac_bwd(g, b, SV_PI, true);
     b.loss = LOSS_SAC_POLICY; b.raw = s->raw; b.eps = s->epss; b.action = s->an; b.ga1 = s->ga[0]; b.ga2 = s->ga[1];
-    ILSX_TRY(launch_bwd_dx(g->ctx, A, g->H, g->act));
+    ILSX_TRY(ac_launch_bwd(g, A));
   }
   ILSX_TRY(ac_dw_adam(g, SV_PI, 1, false, 0.f));
   ILSX_TRY(ac_tick(g, 7, 1));
   if (stats) {  // sac.py:181-240
     const size_t B = (size_t)g->B, a = (size_t)g->a;
     std::vector<float> q1, q2, tv, v, q1n0, q2n0, q1n, q2n, lp, raw, r, d;
-    ILSX_TRY(ac_fetch(g, s->q1, B, q1)); ILSX_TRY(ac_fetch(g, s->q2, B, q2)); ILSX_TRY(ac_fetch(g, s->tv, B, tv));
-    ILSX_TRY(ac_fetch(g, s->v, B, v)); ILSX_TRY(ac_fetch(g, s->q1n0, B, q1n0)); ILSX_TRY(ac_fetch(g, s->q2n0, B, q2n0));
-    ILSX_TRY(ac_fetch(g, s->q1n, B, q1n)); ILSX_TRY(ac_fetch(g, s->q2n, B, q2n)); ILSX_TRY(ac_fetch(g, s->logp, B, lp));
+    ILSX_TRY(ac_fetch_pv(g, s->q1, B, q1)); ILSX_TRY(ac_fetch_pv(g, s->q2, B, q2)); ILSX_TRY(ac_fetch_pv(g, s->tv, B, tv));
+    ILSX_TRY(ac_fetch_pv(g, s->v, B, v)); ILSX_TRY(ac_fetch_pv(g, s->q1n0, B, q1n0)); ILSX_TRY(ac_fetch_pv(g, s->q2n0, B, q2n0));
+    ILSX_TRY(ac_fetch_pv(g, s->q1n, B, q1n)); ILSX_TRY(ac_fetch_pv(g, s->q2n, B, q2n)); ILSX_TRY(ac_fetch(g, s->logp, B, lp));
     ILSX_TRY(ac_fetch(g, s->raw, B * 2 * a, raw)); ILSX_TRY(ac_fetch(g, g->r, B, r)); ILSX_TRY(ac_fetch(g, g->d, B, d));
     HIPCHK(hipStreamSynchronize(g->ctx->stream));
     std::vector<float> y(B), vt(B), mu(B * a), ls(B * a);

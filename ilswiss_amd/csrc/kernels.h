@@ -168,6 +168,7 @@ struct FwdTask {
   const int* rows_idx;               // nullable: row r of this launch reads source row rows_idx[r] (minibatch gather)
   const float* log_std;              // HEAD_GAUSS_*: state-independent log-std parameter [a]
   float noise, noise_clip, max_act;  // HEAD_DET_TANH_NOISE (noise == 0: deterministic)
+  int no_fin;                        // this task's action segment is NOT the launch's finished policy (FwdArgs::fin)
   int agent, first;                  // grouped launches (FwdArgs::tasks): owning agent, 1 = the agent's publishing task
 };
 // A per-row scalar (Q value) that may still be split into CS column-slice partial sums: summed in a fixed
@@ -193,6 +194,7 @@ struct PolicyFinishArgs {
   uint32_t rng_stream; uint64_t seed; const DevScalars* scal; uint64_t step_host;
   const float* eps; const float* act_in;
   float *raw, *eps_save, *action, *logp;
+  float noise, noise_clip, max_act;   // head == HEAD_DET_TANH_NOISE (TD3): raw = pre-activation [rows][a]
 };
 struct FwdGroup;
 struct FwdArgs {
@@ -508,7 +510,9 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
   } else if (T.loss == LOSS_TD3_POLICY) {
     // action = max_act*tanh(pre): d pre = dL/da * max_act * (1 - tanh(pre)^2)
     const float th = tanhf(T.raw[(size_t)gr * NO + j]);
-    d = T.ga1[(size_t)gr * NO + j] * T.coef * (1.0f - th * th);
+    float ga = 0.0f;   // dQ1/da, possibly in column-slice partial slabs
+    for (int pc = 0; pc < A.ga_parts; ++pc) ga += T.ga1[((size_t)pc * A.ga_stride + gr) * NO + j];
+    d = ga * T.coef * (1.0f - th * th);
   } else if (T.loss == LOSS_BC_MLE || T.loss == LOSS_BC_MSE) {
     // bc.py:88-101.  raw = mean | log_std_raw [rows][2a]; act_all = expert actions [rows][a]
     const int a = NO >> 1, jj = j < a ? j : j - a;
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   float4 b0[CS];
 #pragma unroll
   for (int i = 0; i < CS; ++i) b0[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256);
-  const bool fin = (GRP ? GP->fin_on : A.fin_on) != 0;
+  const bool fin = (GRP ? GP->fin_on : A.fin_on) != 0 && !T.no_fin && T.d1 > 0;
   const GatherSpec& G = GRP ? GP->gather : A.gather;
   for (int e = tid; e < 16 * KP; e += NTH) {
     const int r = e / KP, k = e - r * KP, gr = r0 + r;
@@ -748,7 +752,8 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     // the action columns are pi's output: combine its CS head partials, squash (policies.py:262-283,
     // distributions.py:23-28,43-50,74-97); slice 0 of task 0 publishes action / logp / raw / eps for later kernels
     const PolicyFinishArgs& P = GRP ? GP->fin : A.fin;
-    const int a = P.a, NOp = 2 * a;
+    const bool det = P.head == HEAD_DET_TANH_NOISE;   // TD3: max_act*tanh(pre) + clipped noise, one head (policies.py:166-188)
+    const int a = P.a, NOp = det ? a : 2 * a;
     const bool pub = lead && (GRP ? T.first != 0 : blockIdx.y == 0);
     float* lp3 = red;   // [16][32][3] log-prob contributions (quad, log_std, jacobian)
     for (int e = tid; e < 16 * a; e += NTH) {
@@ -758,26 +763,34 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
         float mu = 0.f, lsr = 0.f;
         for (int c = 0; c < P.cs; ++c) {
           mu += P.part[((size_t)c * P.part_stride + gr) * NOp + j];
-          lsr += P.part[((size_t)c * P.part_stride + gr) * NOp + a + j];
+          if (!det) lsr += P.part[((size_t)c * P.part_stride + gr) * NOp + a + j];
         }
-        const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
-        const float sd = expf(ls);
-        float ep;
-        if (P.eps) {
-          ep = P.eps[(size_t)gr * a + j];
+        float ep = 0.0f;
+        if (!det || P.noise != 0.0f) {
+          if (P.eps) {
+            ep = P.eps[(size_t)gr * a + j];
+          } else {
+            float z4[4];
+            philox_normal4(P.seed, P.scal ? P.scal->step : P.step_host, P.rng_stream, gr, j >> 2, z4);
+            const int q = j & 3;
+            ep = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
+          }
+        }
+        if (det) {
+          act = P.max_act * tanhf(mu);
+          if (P.noise != 0.0f) act += fminf(fmaxf(P.noise * ep, -P.noise_clip), P.noise_clip);
+          if (pub && P.raw) P.raw[(size_t)gr * a + j] = mu;
         } else {
-          float z4[4];
-          philox_normal4(P.seed, P.scal ? P.scal->step : P.step_host, P.rng_stream, gr, j >> 2, z4);
-          const int q = j & 3;
-          ep = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
+          const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
+          const float sd = expf(ls);
+          const float z = ep * sd + mu;
+          act = tanhf(z);
+          const float dm = mu - z;
+          c0 = dm * dm / expf(2.0f * ls); c1 = ls; c2 = logf(1.0f - act * act + TANH_EPS);
+          if (pub && P.raw) { P.raw[(size_t)gr * NOp + j] = mu; P.raw[(size_t)gr * NOp + a + j] = lsr; }
         }
-        const float z = ep * sd + mu;
-        act = tanhf(z);
-        const float dm = mu - z;
-        c0 = dm * dm / expf(2.0f * ls); c1 = ls; c2 = logf(1.0f - act * act + TANH_EPS);
         if (T.xsave && lead) T.xsave[(size_t)gr * KP + T.d0 + j] = act;
         if (pub) {
-          if (P.raw) { P.raw[(size_t)gr * NOp + j] = mu; P.raw[(size_t)gr * NOp + a + j] = lsr; }
           if (P.action) P.action[(size_t)gr * a + j] = act;
           if (P.eps_save) P.eps_save[(size_t)gr * a + j] = ep;
         }
@@ -785,7 +798,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
       xs[row * LDX + T.d0 + j] = act;
       lp3[(row * 32 + j) * 3 + 0] = c0; lp3[(row * 32 + j) * 3 + 1] = c1; lp3[(row * 32 + j) * 3 + 2] = c2;
     }
-    if (pub && P.logp) {
+    if (pub && P.logp && !det) {
       __syncthreads();
       if (tid < 16 && r0 + tid < rows) {
         float q = 0.f, l = 0.f, jc = 0.f;

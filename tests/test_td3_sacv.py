@@ -155,3 +155,38 @@ def test_hip_sac_v_large_batch_row_split_dw(ctx):
         tr.train_step(batch, eps=eps)
     for k in ("pi", "q1", "q2", "vf", "tvf"):
         np.testing.assert_allclose(tr.get_flat_params(k), getattr(orc, k), rtol=0, atol=5e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hid", [[128, 128], [256, 256]])
+def test_hip_sac_v_column_split_widths_vs_oracle(ctx, hid):
+    """H = 128 / 256 run on the column-split kernels (policy head finished in the consumer's prologue, target V riding
+    in the same launch); 4 steps against the oracle, statistics requested on every step."""
+    from ilswiss_amd.networks import FlattenMlp, ReparamTanhMultivariateGaussianPolicy
+    from ilswiss_amd.sac_v import SoftActorCriticV
+    from oracle import mlp as omlp
+    rng = np.random.default_rng(hid[0])
+    o, a, B = 17, 6, 96
+    pi0 = omlp.init_mlp(rng, o, hid, a, init_w=1e-3, n_heads=2)
+    pi0[-(2 * (hid[-1] * a + a)):] *= 100.0
+    q10, q20, vf0 = omlp.init_mlp(rng, o + a, hid, 1), omlp.init_mlp(rng, o + a, hid, 1), omlp.init_mlp(rng, o, hid, 1)
+    orc = SacVOracle(o, a, hid, pi0, q10, q20, vf0, **SACV_KW)
+    pol = ReparamTanhMultivariateGaussianPolicy(hid, o, a, ctx=ctx, seed=1)
+    q1, q2, vf = FlattenMlp(hid, 1, o + a, ctx=ctx, seed=2), FlattenMlp(hid, 1, o + a, ctx=ctx, seed=3), FlattenMlp(hid, 1, o, ctx=ctx, seed=4)
+    for net, p0 in ((pol, pi0), (q1, q10), (q2, q20), (vf, vf0)):
+        net.set_flat_params(p0)
+    tr = SoftActorCriticV(pol, q1, q2, vf, max_batch=128, **SACV_KW)
+    for s in range(4):
+        batch = dict(observations=rng.normal(0, 1, (B, o)).astype(np.float32), actions=np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32),
+                     rewards=rng.normal(0, 1, (B, 1)).astype(np.float32), terminals=(rng.random((B, 1)) < 0.1).astype(np.float32),
+                     next_observations=rng.normal(0, 1, (B, o)).astype(np.float32))
+        eps = rng.normal(0, 1, (B, a)).astype(np.float32)
+        res = orc.train_step(batch, eps)
+        tr.eval_statistics = None
+        tr.train_step(batch, eps=eps)
+        st = tr.get_eval_statistics()
+        for ref, k in (("QF1 Loss", "qf1_loss"), ("VF Loss", "vf_loss"), ("Policy Loss", "policy_loss")):
+            np.testing.assert_allclose(st[ref], res[k], rtol=3e-4, atol=2e-6, err_msg=f"step {s} {ref}")
+        np.testing.assert_allclose(st["Log Pis Mean"], res["log_pi"].mean(), rtol=1e-4, atol=1e-5)
+    for k in ("pi", "q1", "q2", "vf", "tvf"):
+        np.testing.assert_allclose(tr.get_flat_params(k), getattr(orc, k), rtol=0, atol=1e-4, err_msg=k)
