@@ -193,7 +193,9 @@ __global__ __launch_bounds__(4 * H) void k_disc_bwd(const DiscBwdArgs A) {
     float sq = wave_sum(mine * mine);
     const float n = sqrtf(sq);
     const bool gp = rowf[row * 4 + 2] > 0.5f && gr < rows;
-    const float coef = gp ? A.gp_w / (float)B * 2.0f * (n - 1.0f) / n : 0.0f;   // adv_irl.py:201-202
+    // adv_irl.py:201-202; a clamped interpolate has g == 0: torch's norm backward is 0 there (not 0/0), the row still
+    // counts (0 - 1)^2 in the penalty value
+    const float coef = (gp && n > 0.0f) ? A.gp_w / (float)B * 2.0f * (n - 1.0f) / n : 0.0f;
     const float gb = coef * mine;
     gs[row * 64 + lane] = gb;
     if (gp) {

@@ -87,7 +87,9 @@ class DiscOracle:
             n = np.sqrt(np.sum(g * g, 1, keepdims=True)).astype(F32)
             gp = np.mean((n - F32(1)) ** 2, dtype=F32)
             gp_loss = F32(gp * F32(self.gp_w))
-            gbar = (F32(self.gp_w) / F32(B) * F32(2) * (n - F32(1)) / n * g).astype(F32)   # dGP/dg
+            # dGP/dg; a clamped interpolate has g == 0 and torch's norm backward is 0 there (masked_fill), not 0/0
+            with np.errstate(divide="ignore", invalid="ignore"):
+                gbar = np.where(n > 0, F32(self.gp_w) / F32(B) * F32(2) * (n - F32(1)) / n * g, F32(0)).astype(F32)
             gW1 += (gt * u1).T @ gbar
             u1b = gt * (gbar @ W1.T)
             v1b, p1b = u1b * p1, u1b * v1

@@ -15,7 +15,7 @@ def test_oracle_disc_steps_golden():
     g = load_golden("g8_g9_disc")
     for tag, act in CASES:
         D, Hd, B, steps, _ = [int(v) for v in g[f"{tag}_dims"]]
-        orc = DiscOracle(D, Hd, g[f"{tag}_params0"], act=act, **dict(KW, use_grad_pen=tag != "tanh_sat"))
+        orc = DiscOracle(D, Hd, g[f"{tag}_params0"], act=act, **KW)
         for s in range(steps):
             res = orc.train_step(g[f"{tag}_s{s}_x_exp"], g[f"{tag}_s{s}_x_pol"], g[f"{tag}_s{s}_eps"])
             np.testing.assert_allclose(res["ce_loss"], g[f"{tag}_s{s}_ce"], rtol=1e-4, atol=1e-6)
@@ -26,6 +26,11 @@ def test_oracle_disc_steps_golden():
             np.testing.assert_allclose(orc.p, g[f"{tag}_s{s}_params"], rtol=0, atol=5e-5)
         np.testing.assert_allclose(orc.logits(g[f"{tag}_probe"]), g[f"{tag}_probe_logits"], rtol=1e-4, atol=1e-5)
     assert np.abs(g["tanh_sat_probe_logits"]).max() == 10.0  # the saturated case really exercises the clamp
+    # ... also on the gradient-penalty rows: clamped interpolates have dD/dx == 0, count (0-1)^2 in the penalty and give no
+    # gradient (torch's norm backward is 0 at 0); everything stays finite
+    orc = DiscOracle(*[int(v) for v in g["tanh_sat_dims"][:2]], g["tanh_sat_params0"], act=TANH, **KW)
+    res = orc.train_step(g["tanh_sat_s0_x_exp"], g["tanh_sat_s0_x_pol"], g["tanh_sat_s0_eps"])
+    assert (res["grad_norm"] == 0).sum() >= 1 and np.isfinite(res["grad"]).all() and np.isfinite(g["tanh_sat_s0_grad"]).all()
 
 
 def test_oracle_reward_modes_golden():
@@ -43,15 +48,14 @@ def test_hip_disc_steps_golden(ctx, tag, act):
     g = load_golden("g8_g9_disc")
     D, Hd, B, steps, o = [int(v) for v in g[f"{tag}_dims"]]
     disc = MLPDisc(o, D - o, hid_dim=Hd, hid_act=tag.split("_")[0], max_batch=B, ctx=ctx,
-                   **dict(KW, use_grad_pen=tag != "tanh_sat"))
+                   **KW)
     disc.set_flat_params(g[f"{tag}_params0"])
     np.testing.assert_array_equal(disc.get_flat_params(), g[f"{tag}_params0"])
     for s in range(steps):
         xe, xp = g[f"{tag}_s{s}_x_exp"], g[f"{tag}_s{s}_x_pol"]
         st = disc.train_step(xe[:, :o], xe[:, o:], xp[:, :o], xp[:, o:], eps=g[f"{tag}_s{s}_eps"])
         np.testing.assert_allclose(st["Disc CE Loss"], g[f"{tag}_s{s}_ce"], rtol=1e-4, atol=1e-6)
-        if tag != "tanh_sat":
-            np.testing.assert_allclose(st["Grad Pen"], g[f"{tag}_s{s}_gp"], rtol=2e-3, atol=1e-5)
+        np.testing.assert_allclose(st["Grad Pen"], g[f"{tag}_s{s}_gp"], rtol=2e-3, atol=1e-5)
         np.testing.assert_allclose(st["Disc Acc"], g[f"{tag}_s{s}_acc"])
         ref = g[f"{tag}_s{s}_grad"]
         got = disc.get_flat_grads()

@@ -338,9 +338,9 @@ def gen_disc():
             flat = omlp.pack(lay)
         disc = MLPDisc(D, num_layer_blocks=2, hid_dim=Hd, hid_act=tag.split("_")[0], use_bn=False, clamp_magnitude=10.0)
         set_flat(disc, flat)
-        # the saturated case runs WITHOUT the gradient penalty: a clamped interpolate has dD/dx = 0 and the
-        # reference's own d||g||/dg is 0/0 = NaN there, so only the BCE path can pin the clamp gate
-        use_gp = scale == 1.0
+        # the saturated case keeps the gradient penalty on: a clamped interpolate has dD/dx = 0, counts (0-1)^2 in the
+        # penalty and contributes no gradient (torch's norm backward is 0 at 0)
+        use_gp = True
         kw = dict(disc_lr=3e-4, disc_momentum=0.9, use_grad_pen=use_gp, grad_pen_weight=8.0)
         orc = DiscOracle(D, Hd, flat, act=act, **kw)
         ns = types.SimpleNamespace(
