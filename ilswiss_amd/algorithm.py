@@ -41,14 +41,19 @@ class TabularLogger:
         print("-" * (width + 18), flush=True)
         if self.log_dir:
             path = os.path.join(self.log_dir, "progress.csv")
-            new = self._header is None
-            if new:
-                self._header = list(self.row.keys())
-            with open(path, "a", newline="") as f:
-                w = csv.DictWriter(f, fieldnames=self._header, extrasaction="ignore")
-                if new:
+            if self._header is None:
+                self._header, self._rows = [], []
+            fresh = [k for k in self.row if k not in self._header]
+            self._rows.append(dict(self.row))
+            if fresh:   # a statistic that first appears in a later epoch gets its column (earlier rows stay empty there)
+                self._header += fresh
+                with open(path, "w", newline="") as f:
+                    w = csv.DictWriter(f, fieldnames=self._header, extrasaction="ignore")
                     w.writeheader()
-                w.writerow(self.row)
+                    w.writerows(self._rows)
+            else:
+                with open(path, "a", newline="") as f:
+                    csv.DictWriter(f, fieldnames=self._header, extrasaction="ignore").writerow(self.row)
         self.row = OrderedDict()
 
     def save(self, name, obj):
