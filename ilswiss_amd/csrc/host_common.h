@@ -49,6 +49,7 @@ struct ilsx_ctx {
   // optional per-kernel HIP-event timing (include/ilsx.h "kernel timing")
   void* dw_scratch = nullptr;   // row-range slabs of split weight-gradient launches (large batches)
   size_t dw_scratch_bytes = 0;
+  int rt_single = 1, rt_grouped = 1;   // 16-row tiles per workgroup in the column-split kernels (ILSX_RT / ILSX_RT_GROUPED)
   int xcd_shift = 0;  // ILSX_XCD_SHIFT: confine the split-MLP / dW kernels to every 2^k-th workgroup slot (3 = one XCD)
   unsigned long long* dbg_stamps = nullptr;  // device buffer for ILSX_STAMP (debug)
   bool prof_on = false;

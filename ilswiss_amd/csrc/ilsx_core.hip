@@ -70,6 +70,8 @@ extern "C" int ilsx_ctx_create(int hip_device, void* hip_stream, uint64_t seed, 
   c->device = hip_device;
   c->seed = seed;
   if (const char* e = getenv("ILSX_XCD_SHIFT")) c->xcd_shift = atoi(e);
+  if (const char* e = getenv("ILSX_RT")) c->rt_single = std::max(1, atoi(e));
+  if (const char* e = getenv("ILSX_RT_GROUPED")) c->rt_grouped = std::max(1, atoi(e));
   if (hip_stream) {
     c->stream = (hipStream_t)hip_stream;
   } else {
@@ -353,7 +355,9 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
     const size_t lds = fwd_split_lds_bytes(H, KPmax, cs);
     if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
     A.xs = ctx->xcd_shift;
-    dim3 grid(((A.rows + 15) / 16) << A.xs, A.ntasks, cs), block(4 * H / cs);
+    if (A.rt <= 0) A.rt = (A.tasks && ctx->rt_grouped > 0) ? ctx->rt_grouped : ctx->rt_single;
+    const int tiles = (A.rows + 15) / 16;
+    dim3 grid(((tiles + A.rt - 1) / A.rt) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (H == 256 && cs == 4) {
       if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
       else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }

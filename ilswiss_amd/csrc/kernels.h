@@ -212,6 +212,7 @@ struct FwdArgs {
   // grouped launch (several agents' tasks in one grid, SURVEY §8e "co-resident seeds as grouped GEMMs"): descriptor
   // tables in device memory, built once per group; blockIdx.y indexes `tasks`
   const struct FwdTaskG* tasks;
+  int rt;                  // column-split kernels: consecutive 16-row tiles per workgroup (0 = 1); grid.x = ceil(tiles / rt)
 };
 struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
 // one self-contained record per grid row: the task and its agent's per-launch state side by side, so a workgroup reaches
@@ -711,7 +712,8 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   float* red = hs + 16 * LDSL;      // [4 tiles][NWV][4][64] head partial tiles
   if (blockIdx.x & ((1u << A.xs) - 1u)) return;   // XCD confinement: the dispatcher deals workgroups round-robin to the 8 XCDs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int r0 = (blockIdx.x >> A.xs) * 16, rows = A.rows, cs = blockIdx.z;
+  const int rows = A.rows, cs = blockIdx.z;
+  const int RT = A.rt > 0 ? A.rt : 1;   // row tiles this workgroup walks with its weights held in registers
   const bool lead = cs == 0;
   ILSX_STAMP(A.dbg, 0);
 
@@ -720,8 +722,36 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   float4 b0[CS];
 #pragma unroll
   for (int i = 0; i < CS; ++i) b0[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256);
+  float4 b0first[CS];
+#pragma unroll
+  for (int i = 0; i < CS; ++i) b0first[i] = b0[i];
+  float bias0[CS];
+#pragma unroll
+  for (int i = 0; i < CS; ++i) bias0[i] = (N.base + N.off_b[0])[(wave * CS + i) * 16 + li];
+  const int lc = wave * 16 + li, col1 = cs * SLW + lc;
+  const float bias1 = (N.base + N.off_b[1])[col1];
+  // head weights of this slice as MFMA B fragments: wave w owns k16 chunk w of the slice, rows j = 16t + li
+  float4 whf[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = 16 * t + li;
+    whf[t] = (t < NOT && j < NO) ? *reinterpret_cast<const float4*>(N.base + N.off_Wh + (size_t)j * H + cs * SLW + 16 * wave + 4 * g)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // ---- this wave's slice of layer 1 (16 columns x H): one coalesced burst, held for every row tile
+  float4 wreg[NC];
+  {
+    const float* wp = N.base + N.off_W[1] + (size_t)(cs * NWV + wave) * NC * 256 + 4 * lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+  }
   const bool fin = (GRP ? GP->fin_on : A.fin_on) != 0 && !T.no_fin && T.d1 > 0;
   const GatherSpec& G = GRP ? GP->gather : A.gather;
+  for (int rt = 0; rt < RT; ++rt) {
+  const int r0 = ((blockIdx.x >> A.xs) * RT + rt) * 16;
+  if (r0 >= rows) break;   // workgroup-uniform
+#pragma unroll
+  for (int i = 0; i < CS; ++i) b0[i] = b0first[i];
   for (int e = tid; e < 16 * KP; e += NTH) {
     const int r = e / KP, k = e - r * KP, gr = r0 + r;
     const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
@@ -807,28 +837,8 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
       }
     }
   }
-  float bias0[CS];
-#pragma unroll
-  for (int i = 0; i < CS; ++i) bias0[i] = (N.base + N.off_b[0])[(wave * CS + i) * 16 + li];
-  const int lc = wave * 16 + li, col1 = cs * SLW + lc;
-  const float bias1 = (N.base + N.off_b[1])[col1];
-  // head weights of this slice as MFMA B fragments: wave w owns k16 chunk w of the slice, rows j = 16t + li
-  float4 whf[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int j = 16 * t + li;
-    whf[t] = (t < NOT && j < NO) ? *reinterpret_cast<const float4*>(N.base + N.off_Wh + (size_t)j * H + cs * SLW + 16 * wave + 4 * g)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   __syncthreads();
   ILSX_STAMP(A.dbg, 1);
-  // ---- this wave's slice of layer 1 (16 columns x H): one coalesced burst, lands under layer 0
-  float4 wreg[NC];
-  {
-    const float* wp = N.base + N.off_W[1] + (size_t)(cs * NWV + wave) * NC * 256 + 4 * lane;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
-  }
   // ---- layer 0, full width: CS column tiles per wave
   {
     f32x4 acc[CS];
@@ -915,6 +925,8 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     const int row = 4 * (ol >> 4) + v, j = 16 * t + (ol & 15), gr = r0 + row;
     if (j < NO && gr < rows) T.part[((size_t)cs * A.part_stride + gr) * NO + j] = sum + (lead ? bh[j] : 0.0f);
   }
+  __syncthreads();   // the next row tile reuses xs / h0 / hs / red
+  }  // rt
   ILSX_STAMP(A.dbg, 7);
 }
 #endif  // ILSX_KERNEL_IMPL
