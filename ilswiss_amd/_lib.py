@@ -52,7 +52,9 @@ class PlanarModel(C.Structure):  # ilsx_planar_model
                 ("contact_margin", C.c_double), ("contact_solref", C.c_double * 2), ("contact_solimp", C.c_double * 3),
                 ("limit_solref", C.c_double * 2), ("limit_solimp", C.c_double * 3),
                 ("ctrl_cost", C.c_double), ("alive_bonus", C.c_double), ("z_min", C.c_double), ("z_max", C.c_double),
-                ("ang_max", C.c_double), ("state_max", C.c_double), ("init_qpos", C.c_double * (_MB + 2))]
+                ("ang_max", C.c_double), ("state_max", C.c_double), ("init_qpos", C.c_double * (_MB + 2)),
+                ("stiffness", C.c_double * _MB), ("reset_noise_vel_std", C.c_double), ("qvel_clip", C.c_double),
+                ("max_rows", C.c_int32), ("pad1", C.c_int32)]
 
 
 class Td3Cfg(C.Structure):  # ilsx_td3_cfg

@@ -21,9 +21,9 @@ struct PlanarModelDev {
   int nb, ng, task, frame_skip, pgs_iters, max_rows, n_act, obs_dim;
   int parent[ENV_MAXB], limited[ENV_MAXB], act_body[ENV_MAXB], geom_body[ENV_MAXG], ancmask[ENV_MAXB];
   double anchor[ENV_MAXB][2], com[ENV_MAXB][2], mass[ENV_MAXB], inertia[ENV_MAXB], jsign[ENV_MAXB];
-  double armature[ENV_MAXB], damping[ENV_MAXB], range[ENV_MAXB][2], gear[ENV_MAXB];
+  double armature[ENV_MAXB], damping[ENV_MAXB], range[ENV_MAXB][2], gear[ENV_MAXB], stiffness[ENV_MAXB];
   double gp1[ENV_MAXG][2], gp2[ENV_MAXG][2], grad[ENV_MAXG], gfric[ENV_MAXG];
-  double timestep, gravity, reset_noise, margin;
+  double timestep, gravity, reset_noise, margin, reset_noise_vel_std, qvel_clip;
   double c_solref[2], c_solimp[3], l_solref[2], l_solimp[3];
   double ctrl_cost, alive, z_min, z_max, ang_max, state_max;
   double init_qpos[ENV_MAXB + 2];
@@ -185,7 +185,7 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     SL(S::OFF_M, (2 + b) * N + 2 + b) += m.armature[b];
-    rhs[2 + b] -= m.damping[b] * v[2 + b];
+    rhs[2 + b] -= m.damping[b] * v[2 + b] + m.stiffness[b] * q[2 + b];   // joint damper + spring towards 0
   }
   for (int k = 0; k < m.n_act; ++k) {
     const int b = m.act_body[k];
@@ -229,6 +229,8 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
   int nr = 0;
   double rr[MR], rmu[MR], rd[MR], rb_[MR], rk[MR];
   int rkind[MR];  // 0 normal, 1 tangent, 2 limit
+#pragma unroll
+  for (int t = 0; t < MR; ++t) { rr[t] = 0.0; rmu[t] = 0.0; rd[t] = 1.0; rb_[t] = 0.0; rk[t] = 0.0; rkind[t] = 0; }
   auto add_row = [&](const double (&jrow)[N], double r, int kind, double mu, double d, double bdamp, double kstiff) {
 #pragma unroll
     for (int i = 0; i < N; ++i) SL(S::OFF_J, nr * N + i) = jrow[i];
@@ -293,6 +295,8 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
   }
   // ---- Y = M^-1 J^T, A = J Y, PGS on (A + R) f = aref - J qacc0
   double rhs_c[MR], Rd[MR], f[MR];
+#pragma unroll
+  for (int t = 0; t < MR; ++t) { rhs_c[t] = 0.0; Rd[t] = 0.0; f[t] = 0.0; }
   for (int r = 0; r < nr; ++r) {
     double x[N];
 #pragma unroll
@@ -351,21 +355,30 @@ __device__ void env_substep(const PlanarModelDev& m, double (&q)[NB + 2], double
                             double* sm, int lane_in_block) {
   constexpr int N = NB + 2;
   const double h = m.timestep;
-  double a1[N], a2[N], a3[N], a4[N], q2[N], v2[N], q3[N], v3[N], q4[N], v4[N];
-  env_dynamics<NB, MR, BLOCK>(m, q, v, ctrl, a1, sm, lane_in_block);
+  // classic RK4 as ONE dynamics call site in a 4-trip loop (stage weights 1,2,2,1; stage offsets h/2, h/2, h): the sums
+  // accumulate in the order the oracle writes them, so the result is bit-identical to the unrolled form at a quarter of
+  // the code size and without the ten stage arrays
+  double qs[N], vs[N], qsum[N], vsum[N], a[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) { q2[i] = q[i] + 0.5 * h * v[i]; v2[i] = v[i] + 0.5 * h * a1[i]; }
-  env_dynamics<NB, MR, BLOCK>(m, q2, v2, ctrl, a2, sm, lane_in_block);
+  for (int i = 0; i < N; ++i) { qs[i] = q[i]; vs[i] = v[i]; qsum[i] = 0.0; vsum[i] = 0.0; }
+#pragma unroll 1
+  for (int stage = 0; stage < 4; ++stage) {
+    env_dynamics<NB, MR, BLOCK>(m, qs, vs, ctrl, a, sm, lane_in_block);
+    const double w = (stage == 1 || stage == 2) ? 2.0 : 1.0;
+    const double ch = (stage == 2) ? h : 0.5 * h;
 #pragma unroll
-  for (int i = 0; i < N; ++i) { q3[i] = q[i] + 0.5 * h * v2[i]; v3[i] = v[i] + 0.5 * h * a2[i]; }
-  env_dynamics<NB, MR, BLOCK>(m, q3, v3, ctrl, a3, sm, lane_in_block);
-#pragma unroll
-  for (int i = 0; i < N; ++i) { q4[i] = q[i] + h * v3[i]; v4[i] = v[i] + h * a3[i]; }
-  env_dynamics<NB, MR, BLOCK>(m, q4, v4, ctrl, a4, sm, lane_in_block);
+    for (int i = 0; i < N; ++i) {
+      qsum[i] = stage == 0 ? vs[i] : qsum[i] + w * vs[i];
+      vsum[i] = stage == 0 ? a[i] : vsum[i] + w * a[i];
+      const double vn = v[i] + ch * a[i];
+      qs[i] = q[i] + ch * vs[i];
+      vs[i] = vn;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const double qn = q[i] + h / 6.0 * (v[i] + 2.0 * v2[i] + 2.0 * v3[i] + v4[i]);
-    const double vn = v[i] + h / 6.0 * (a1[i] + 2.0 * a2[i] + 2.0 * a3[i] + a4[i]);
+    const double qn = q[i] + h / 6.0 * qsum[i];
+    const double vn = v[i] + h / 6.0 * vsum[i];
     q[i] = qn; v[i] = vn;
   }
 }
@@ -397,7 +410,8 @@ __device__ __forceinline__ void env_write_obs(const PlanarModelDev& m, const dou
   for (int i = 1; i < N; ++i) dst[i - 1] = (float)((q[i] - m.obs_shift[i - 1]) * m.obs_inv_scale[i - 1]);   // qpos[1:] (hopper.py:29-30)
 #pragma unroll
   for (int i = 0; i < N; ++i)                                                                                // clip(qvel, +-10)
-    dst[N - 1 + i] = (float)((fmin(fmax(v[i], -10.0), 10.0) - m.obs_shift[N - 1 + i]) * m.obs_inv_scale[N - 1 + i]);
+    dst[N - 1 + i] = (float)(((m.qvel_clip > 0.0 ? fmin(fmax(v[i], -m.qvel_clip), m.qvel_clip) : v[i]) - m.obs_shift[N - 1 + i]) *
+                             m.obs_inv_scale[N - 1 + i]);
 }
 
 __device__ __forceinline__ double env_uniform(uint64_t seed, uint32_t stream, unsigned long long step, uint32_t env,
@@ -415,7 +429,12 @@ __device__ __forceinline__ void env_reset_state(const PlanarModelDev& m, uint64_
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     q[i] = m.init_qpos[i] + m.reset_noise * (2.0 * env_uniform(seed, stream, step, env, i) - 1.0);
-    v[i] = m.reset_noise * (2.0 * env_uniform(seed, stream, step, env, N + i) - 1.0);
+    if (m.reset_noise_vel_std > 0.0) {   // HalfCheetahEnv.reset_model: qvel = init + 0.1 * randn (Box-Muller on two draws)
+      const double u1 = env_uniform(seed, stream, step, env, N + 2 * i), u2 = env_uniform(seed, stream, step, env, N + 2 * i + 1);
+      v[i] = m.reset_noise_vel_std * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    } else {
+      v[i] = m.reset_noise * (2.0 * env_uniform(seed, stream, step, env, N + i) - 1.0);
+    }
   }
 }
 
@@ -452,8 +471,10 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
     for (int i = 2; i < N; ++i) ok = ok && isfinite(q[i]) && fabs(q[i]) < m.state_max;
 #pragma unroll
     for (int i = 0; i < N; ++i) ok = ok && isfinite(v[i]) && fabs(v[i]) < m.state_max;
-  } else {            // walker2d.py:17-20
+  } else if (m.task == 1) {   // walker2d.py:17-20
     ok = q[1] > m.z_min && q[1] < m.z_max && q[2] > -m.ang_max && q[2] < m.ang_max;
+  } else {                    // HalfCheetah: done = False always
+    ok = true;
   }
   const bool done = !ok;
   float ob[2 * N - 1];
@@ -538,7 +559,7 @@ static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
 static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
   if (A.n_ids <= 0) return ILSX_OK;
   if (e->hm.nb == 4) return launch_env_step_t<4, 8, 64>(e, A);
-  if (e->hm.nb == 7) return launch_env_step_t<7, 12, 32>(e, A);
+  if (e->hm.nb == 7) return e->hm.max_rows > 12 ? launch_env_step_t<7, 16, 16>(e, A) : launch_env_step_t<7, 12, 32>(e, A);
   ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "vec-env kernels are instantiated for 4 (Hopper) and 7 (Walker2d) bodies, got %d", e->hm.nb);
 }
 static int launch_env_reset(ilsx_vecenv* e, const int* ids_dev, int n_ids, float* obs) {
@@ -579,14 +600,15 @@ extern "C" int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* pm, in
   PlanarModelDev& m = e->hm;
   memset(&m, 0, sizeof m);
   m.nb = pm->n_body; m.ng = pm->n_geom; m.task = pm->task; m.frame_skip = pm->frame_skip; m.pgs_iters = pm->pgs_iters;
-  m.max_rows = pm->n_body == 4 ? 8 : 12;
+  m.max_rows = pm->max_rows > 0 ? pm->max_rows : (pm->n_body == 4 ? 8 : 12);
+  if (m.max_rows > 16) { delete e; ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "max_rows=%d: the kernels keep at most 16 constraint rows per env", m.max_rows); }
   int na = 0;
   for (int b = 0; b < m.nb; ++b) {
     m.parent[b] = pm->parent[b]; m.limited[b] = pm->limited[b];
     m.anchor[b][0] = pm->anchor[b][0]; m.anchor[b][1] = pm->anchor[b][1];
     m.com[b][0] = pm->com[b][0]; m.com[b][1] = pm->com[b][1];
     m.mass[b] = pm->mass[b]; m.inertia[b] = pm->inertia[b]; m.jsign[b] = pm->jsign[b];
-    m.armature[b] = pm->armature[b]; m.damping[b] = pm->damping[b];
+    m.armature[b] = pm->armature[b]; m.damping[b] = pm->damping[b]; m.stiffness[b] = pm->stiffness[b];
     m.range[b][0] = pm->range[b][0]; m.range[b][1] = pm->range[b][1]; m.gear[b] = pm->gear[b];
     if (pm->gear[b] != 0.0) m.act_body[na++] = b;
     int mask = 0;
@@ -602,6 +624,7 @@ extern "C" int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* pm, in
     m.grad[g] = pm->geom_radius[g]; m.gfric[g] = pm->geom_friction[g];
   }
   m.timestep = pm->timestep; m.gravity = pm->gravity; m.reset_noise = pm->reset_noise; m.margin = pm->contact_margin;
+  m.reset_noise_vel_std = pm->reset_noise_vel_std; m.qvel_clip = pm->qvel_clip;
   for (int i = 0; i < 2; ++i) { m.c_solref[i] = pm->contact_solref[i]; m.l_solref[i] = pm->limit_solref[i]; }
   for (int i = 0; i < 3; ++i) { m.c_solimp[i] = pm->contact_solimp[i]; m.l_solimp[i] = pm->limit_solimp[i]; }
   m.ctrl_cost = pm->ctrl_cost; m.alive = pm->alive_bonus; m.z_min = pm->z_min; m.z_max = pm->z_max;

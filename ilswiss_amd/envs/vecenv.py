@@ -32,6 +32,7 @@ def model_struct(m):
             s.anchor[b][k], s.com[b][k], s.range[b][k] = m["anchor"][b][k], m["com"][b][k], m["range"][b][k]
         s.mass[b], s.inertia[b], s.jsign[b] = m["mass"][b], m["inertia"][b], m["jsign"][b]
         s.armature[b], s.damping[b], s.gear[b] = m["armature"][b], m["damping"][b], m["gear"][b]
+        s.stiffness[b] = m.get("stiffness", [0.0] * m["n_body"])[b]
     for g in range(m["n_geom"]):
         s.geom_body[g] = m["geom_body"][g]
         for k in (0, 1):
@@ -47,6 +48,7 @@ def model_struct(m):
     s.z_min, s.z_max, s.ang_max, s.state_max = hl["z_min"], hl["z_max"], hl["ang"], hl["state"]
     for i, v in enumerate(m["init_qpos"]):
         s.init_qpos[i] = v
+    s.reset_noise_vel_std, s.qvel_clip, s.max_rows = m.get("reset_noise_vel_std", 0.0), m.get("qvel_clip", 10.0), m.get("max_rows", 0)
     return s
 
 

@@ -360,13 +360,14 @@ int ilsx_ppo_policy_act(ilsx_ppo* ppo, const float* obs, int n, int deterministi
  * Replaces the reference's vec-env path: rlkit/envs/vecenvs.py:158-257 (BaseVectorEnv.reset/step),
  * rlkit/envs/worker/subproc.py:59-113 (process + pipe per env), rlkit/envs/wrappers.py:342-352
  * (NormalizedBoxEnv action map + clip) and the MuJoCo step under gym's HopperEnv / Walker2dEnv, whose
- * reward / termination / reset rules are restated in rlkit/envs/mujoco/hopper.py:11-40, walker2d.py:11-36.
+ * reward / termination / reset rules are restated in rlkit/envs/mujoco/hopper.py:11-40, walker2d.py:11-36
+ * (HalfCheetah: gym's HalfCheetahEnv — forward velocity - 0.1*|a|^2, no termination; rlkit/envs/envs_dict.py:7).
  * The dynamics model is a planar articulated-body engine (body 0: slide-x, slide-z, hinge; every other body
  * one hinge; capsule-vs-floor soft contacts + soft joint limits solved by PGS; RK4).  Model constants come
  * from the caller (ilswiss_amd/envs/models.py); physics parity with MuJoCo is UNPINNED. */
 #define ILSX_ENV_MAX_BODY 8
 #define ILSX_ENV_MAX_GEOM 8
-enum { ILSX_TASK_HOPPER = 0, ILSX_TASK_WALKER2D = 1 };
+enum { ILSX_TASK_HOPPER = 0, ILSX_TASK_WALKER2D = 1, ILSX_TASK_HALFCHEETAH = 2 /* never terminates */ };
 typedef struct {
   int32_t task, n_body, n_geom, frame_skip, pgs_iters, pad0;
   int32_t parent[ILSX_ENV_MAX_BODY], limited[ILSX_ENV_MAX_BODY], geom_body[ILSX_ENV_MAX_GEOM];
@@ -380,6 +381,10 @@ typedef struct {
   double contact_solref[2], contact_solimp[3], limit_solref[2], limit_solimp[3];
   double ctrl_cost, alive_bonus, z_min, z_max, ang_max, state_max;
   double init_qpos[ILSX_ENV_MAX_BODY + 2];
+  double stiffness[ILSX_ENV_MAX_BODY];   /* joint spring towards 0 (half_cheetah.xml) */
+  double reset_noise_vel_std;            /* > 0: reset qvel ~ N(0, std) instead of U(+-reset_noise) (HalfCheetahEnv.reset_model) */
+  double qvel_clip;                      /* > 0: observations clip qvel to +-qvel_clip (Hopper / Walker2d: 10); <= 0: none */
+  int32_t max_rows, pad1;                /* constraint rows per env the solver keeps (0 = 8 for 4 bodies, 12 otherwise; <= 16) */
 } ilsx_planar_model;
 
 int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* model, int n_env, uint64_t seed, ilsx_vecenv** out);

@@ -13,7 +13,7 @@ Model: body 0 has 3 DoF (x, z, pitch), each further body one hinge.  phi_b = abs
     M(q) qdd + c(q,qd) = tau + J^T f
     M = sum_b m_b Jc_b^T Jc_b + I_b Jphi_b^T Jphi_b + diag(armature)
     c = sum_b m_b Jc_b^T (acc_b(qdd=0) - g)
-    tau = gear*ctrl - damping*qd
+    tau = gear*ctrl - damping*qd - stiffness*q          (joint springs towards 0: half_cheetah.xml)
 Constraints (MuJoCo-style soft constraints, solved by projected Gauss-Seidel in constraint space):
     rows: per capsule end within `contact_margin` of the floor: normal (f >= 0) + tangent (|f| <= mu f_n);
           per violated joint limit: one unilateral row.
@@ -23,7 +23,7 @@ Integrator: classic RK4 on (q, qd) with the constraint solve inside every stage,
 """
 import numpy as np
 
-TASK_HOPPER, TASK_WALKER2D = 0, 1
+TASK_HOPPER, TASK_WALKER2D, TASK_HALFCHEETAH = 0, 1, 2
 
 
 def rot(phi):
@@ -87,7 +87,7 @@ class PlanarOracle:
             rhs += m["mass"][b] * Jc.T @ (g - ac)
         for b in range(nb):
             M[2 + b, 2 + b] += m["armature"][b]
-            rhs[2 + b] -= m["damping"][b] * v[2 + b]
+            rhs[2 + b] -= m["damping"][b] * v[2 + b] + m.get("stiffness", [0.0] * nb)[b] * q[2 + b]
         for k, b in enumerate(m["act_bodies"]):
             rhs[2 + b] += m["gear"][b] * ctrl[k]
         qacc0 = np.linalg.solve(M, rhs)
@@ -95,7 +95,7 @@ class PlanarOracle:
         # ---- constraint rows
         rows = []  # (J, r, kind, mu, partner)
         tc, dr = m["contact_solref"]
-        max_rows = m.get("max_rows", 8 if nb == 4 else 12)  # rows: distal geoms first (p1, p2), then limits
+        max_rows = m.get("max_rows", 0) or (8 if nb == 4 else 12)  # rows: distal geoms first (p1, p2), then limits
         for gi in range(m["n_geom"] - 1, -1, -1):
             b = m["geom_body"][gi]
             for e in (m["geom_p1"][gi], m["geom_p2"][gi]):
@@ -159,8 +159,9 @@ class PlanarOracle:
         a4 = self.dynamics(q4, v4, ctrl)
         return q + h / 6.0 * (v + 2 * v2 + 2 * v3 + v4), v + h / 6.0 * (a1 + 2 * a2 + 2 * a3 + a4)
 
-    def obs(self, q, v):  # hopper.py:29-30 / gym v2: qpos[1:], clip(qvel, +-10)
-        return np.concatenate([q[1:], np.clip(v, -10.0, 10.0)])
+    def obs(self, q, v):  # hopper.py:29-30 / gym v2: qpos[1:], clip(qvel, +-10); HalfCheetah-v2: no clip
+        c = self.m.get("qvel_clip", 10.0)
+        return np.concatenate([q[1:], np.clip(v, -c, c) if c > 0 else v])
 
     def step(self, q, v, action):
         """NormalizedBoxEnv action map (identity + clip for ctrlrange [-1,1], wrappers.py:342-346) ->
@@ -176,15 +177,18 @@ class PlanarOracle:
         s = np.concatenate([q, v])
         if m["task"] == TASK_HOPPER:
             ok = np.all(np.isfinite(s)) and np.all(np.abs(s[2:]) < hl["state"]) and q[1] > hl["z_min"] and abs(q[2]) < hl["ang"]
-        else:
+        elif m["task"] == TASK_WALKER2D:
             ok = hl["z_min"] < q[1] < hl["z_max"] and -hl["ang"] < q[2] < hl["ang"]
+        else:   # HalfCheetahEnv.step: done = False
+            ok = True
         return q, v, self.obs(q, v), reward, (not ok)
 
     def reset(self, rng):  # hopper.py:32-40: init + U(+-0.005) on qpos and qvel
         m, n = self.m, self.n
         nz = m["reset_noise"]
         q = np.asarray(m["init_qpos"], dtype=np.float64) + rng.uniform(-nz, nz, n)
-        v = rng.uniform(-nz, nz, n)
+        sd = m.get("reset_noise_vel_std", 0.0)   # HalfCheetahEnv.reset_model: qvel = 0.1 * randn
+        v = sd * rng.standard_normal(n) if sd > 0 else rng.uniform(-nz, nz, n)
         return q, v
 
     def energy(self, q, v):
@@ -198,5 +202,5 @@ class PlanarOracle:
             vc = Jc @ v
             c = o[b] + rot(phi[b]) @ r
             E += 0.5 * m["mass"][b] * vc @ vc + 0.5 * m["inertia"][b] * phid[b] ** 2 + m["mass"][b] * m["gravity"] * c[1]
-            E += 0.5 * m["armature"][b] * v[2 + b] ** 2
+            E += 0.5 * m["armature"][b] * v[2 + b] ** 2 + 0.5 * m.get("stiffness", [0.0] * nb)[b] * q[2 + b] ** 2
         return E

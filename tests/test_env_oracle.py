@@ -4,7 +4,7 @@ import copy
 
 import numpy as np
 
-from ilswiss_amd.envs.models import hopper, walker2d
+from ilswiss_amd.envs.models import halfcheetah, hopper, walker2d
 from oracle.planar_env import PlanarOracle
 
 
@@ -15,10 +15,14 @@ def test_body_masses_match_mujoco_hopper():
     assert m["obs_dim"] == 11 and m["act_dim"] == 3
     w = walker2d()
     assert w["obs_dim"] == 17 and w["act_dim"] == 6 and w["n_body"] == 7
+    # HalfCheetah-v2 (settotalmass 14): model.body_mass as MuJoCo reports it; torso = capsule + head capsule
+    c = halfcheetah()
+    np.testing.assert_allclose(c["mass"], [6.36031332, 1.53524804, 1.58093995, 1.0691906, 1.42558747, 1.17885117, 0.84986945], rtol=2e-5)
+    assert c["obs_dim"] == 17 and c["act_dim"] == 6 and c["n_geom"] == 8 and c["jsign"] == [-1.0] * 7
 
 
 def test_energy_conserved_in_free_flight():
-    for mk in (hopper, walker2d):
+    for mk in (hopper, walker2d, halfcheetah):   # the cheetah keeps its joint springs: their energy is part of the balance
         m = copy.deepcopy(mk())
         nb = m["n_body"]
         m["damping"], m["limited"] = [0.0] * nb, [0] * nb
@@ -28,9 +32,9 @@ def test_energy_conserved_in_free_flight():
         v = rng.normal(0, 1, nb + 2)
         e0 = P.energy(q, v)
         px0 = None
-        for _ in range(100):
+        for _ in range(int(round(0.2 / m["timestep"]))):   # 0.2 s of free flight from z = 3
             q, v = P.substep(q, v, np.zeros(m["act_dim"]))
-        assert abs(P.energy(q, v) - e0) < 1e-8 * abs(e0)
+        assert abs(P.energy(q, v) - e0) < (1e-8 if m["timestep"] < 0.005 else 1e-4) * abs(e0)   # RK4 at h = 0.01 with 240 N m/rad springs: omega*h ~ 0.45
 
 
 def test_momentum_and_gravity_in_free_flight():
@@ -100,3 +104,26 @@ def test_random_policy_return_is_in_the_reference_ballpark():
                 break
         rets.append(R)
     assert 8.0 < np.mean(rets) < 25.0, np.mean(rets)
+
+
+def test_halfcheetah_reward_never_done_and_reset_noise():
+    """gym HalfCheetahEnv: reward = (x_after - x_before)/dt - 0.1*|a|^2, done = False always, reset qpos + U(+-0.1) and
+    qvel = 0.1*randn, observation qpos[1:] | qvel WITHOUT clipping; dt = 5 x 0.01."""
+    m = halfcheetah()
+    P = PlanarOracle(m)
+    rng = np.random.default_rng(0)
+    q, v = P.reset(rng)
+    assert np.all(np.abs(q - np.asarray(m["init_qpos"])) <= 0.1) and 0.02 < np.std(v) < 0.3
+    v[3] = 25.0                                       # far beyond the +-10 clip of Hopper / Walker2d observations
+    assert P.obs(q, v)[8 + 3] == 25.0
+    a = np.array([0.5, -2.0, 0.3, 1.5, -0.2, 0.1])
+    q1, v1, ob, rew, done = P.step(q.copy(), v.copy(), a)
+    ac = np.clip(a, -1, 1)
+    np.testing.assert_allclose(rew, (q1[0] - q[0]) / 0.05 - 0.1 * np.sum(ac * ac), rtol=1e-12)
+    q1[1], q1[2] = -5.0, 9.0                          # absurd states still do not terminate
+    assert P.step(q1, v1, a)[4] is False
+    # resting pose: dropped from its initial height the cheetah settles on its feet, torso above the ground, nothing explodes
+    q, v = np.asarray(m["init_qpos"], float).copy(), np.zeros(9)
+    for _ in range(60):
+        q, v, ob, rew, done = P.step(q, v, np.zeros(6))
+    assert 0.3 < q[1] < 0.8 and np.all(np.isfinite(q)) and np.abs(v).max() < 1.0
