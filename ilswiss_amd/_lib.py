@@ -141,6 +141,7 @@ PROTOTYPES = {
     "ilsx_eval_rollout": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "ilsx_ppo_rollout": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "ilsx_vecenv_set_obs_affine": (C.c_int, [vp, vp, vp]),
+    "ilsx_is_terminal": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "ilsx_vecenv_obs_norm": (C.c_int, [vp, C.c_int, C.c_int]),
     "ilsx_vecenv_get_obs_rms": (C.c_int, [vp, vp, vp, C.POINTER(C.c_double)]),
     "ilsx_vecenv_set_obs_rms": (C.c_int, [vp, vp, vp, C.c_double]),

@@ -756,6 +756,50 @@ extern "C" int ilsx_vecenv_cur_obs(ilsx_vecenv* e, float** dev_ptr) {
   return ILSX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ terminals.py
+// One wave per row: lanes stride the row for the all-finite / all-below-100 scans, lane 0 applies the task's thresholds.
+__global__ __launch_bounds__(256) void k_is_terminal(int kind, const float* __restrict__ x, int n, int o, unsigned char* done) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* r = x + (size_t)row * o;
+  bool fin = true, below = true;
+  if (kind == ILSX_TERM_INVERTED_PENDULUM || kind == ILSX_TERM_HOPPER || kind == ILSX_TERM_ANT)
+    for (int i = lane; i < o; i += 64) {
+      const float v = r[i];
+      fin = fin && isfinite(v);
+      if (i >= 1) below = below && (v < 100.0f);   // terminals.py:61: abs() wraps the comparison, so only an upper bound
+    }
+  fin = __all(fin); below = __all(below);
+  if (lane != 0) return;
+  bool d = false;
+  if (kind == ILSX_TERM_INVERTED_PENDULUM) {
+    d = !(fin && fabsf(r[1]) <= 0.2f);
+  } else if (kind == ILSX_TERM_INVERTED_DOUBLE_PENDULUM) {
+    const float th1 = atan2f(r[1], r[3]), th2 = atan2f(r[2], r[4]);
+    d = 0.6f * (r[3] + cosf(th1 + th2)) <= 1.0f;
+  } else if (kind == ILSX_TERM_HOPPER) {
+    d = !(fin && below && r[0] > 0.7f && fabsf(r[1]) < 0.2f);
+  } else if (kind == ILSX_TERM_WALKER2D) {
+    d = !(r[0] > 0.8f && r[0] < 2.0f && r[1] > -1.0f && r[1] < 1.0f);
+  } else if (kind == ILSX_TERM_HUMANOID) {
+    d = r[0] < 1.0f || r[0] > 2.0f;
+  } else if (kind == ILSX_TERM_ANT) {
+    d = !(fin && r[0] >= 0.2f && r[0] <= 1.0f);
+  }
+  done[row] = d ? 1 : 0;
+}
+
+extern "C" int ilsx_is_terminal(ilsx_ctx* ctx, int kind, const float* next_obs, int n, int obs_dim, uint8_t* done) {
+  if (!ctx || !next_obs || !done || n < 0) ILSX_FAIL(ILSX_ERR_ARG, "is_terminal: null argument or n < 0");
+  static const int min_dim[7] = {2, 5, 2, 2, 1, 1, 1};
+  if (kind < 0 || kind > ILSX_TERM_ANT) ILSX_FAIL(ILSX_ERR_ARG, "is_terminal: unknown kind %d", kind);
+  if (obs_dim < min_dim[kind]) ILSX_FAIL(ILSX_ERR_ARG, "is_terminal: kind %d reads %d observation columns, got %d", kind, min_dim[kind], obs_dim);
+  if (n == 0) return ILSX_OK;
+  hipLaunchKernelGGL(k_is_terminal, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kind, next_obs, n, obs_dim, done);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
 // ScaledEnv (obs - mean)/(std + EPS) and MinmaxEnv (obs - min)/(max - min + EPS) (wrappers.py:53-203): a fixed affine map of
 // every observation the env hands out or records; shift / scale are HOST float64 [obs_dim] (scale already includes EPS).
 // The envs are reset so that the observations they currently show follow the new map.

@@ -234,6 +234,9 @@ def get_envs(env_specs, env_wrapper=None, wrapper_kwargs=None, ctx=None, norm_ob
     """rlkit/envs/__init__.py:72-132: env_specs{env_name, env_num, training_env_seed, ...} -> vec env.
     NormalizedBoxEnv is folded into the stepper; env_wrapper = ProxyEnv / ScaledEnv / MinmaxEnv with wrapper_kwargs as in
     adv_irl_exp_script.py:79-132; norm_obs / obs_rms / update_obs_rms are BaseVectorEnv's (vecenvs.py:84-113)."""
+    if env_specs.get("use_envpool"):   # rlkit/envs/__init__.py:78-84 (wrappers do not apply on this branch there either)
+        from .envpool import EnvpoolEnv
+        return EnvpoolEnv(env_specs, ctx=ctx, norm_obs=norm_obs, obs_rms=obs_rms, update_obs_rms=update_obs_rms)
     w = env_wrapper(**(wrapper_kwargs or {})) if env_wrapper is not None else ProxyEnv()
     return HipVectorEnv(env_specs["env_name"], env_specs.get("env_num", 1),
                         seed=env_specs.get("training_env_seed", env_specs.get("seed", 0)), ctx=ctx, norm_obs=norm_obs,

@@ -404,6 +404,12 @@ int ilsx_vecenv_cur_obs(ilsx_vecenv* env, float** dev_ptr);  /* [n_env,o] curren
  * (raw - shift) / scale; shift / scale are HOST float64 [obs_dim], scale already including the wrappers' EPS
  * (std + EPS, or max - min + EPS).  Resets all envs. */
 int ilsx_vecenv_set_obs_affine(ilsx_vecenv* env, const double* shift_host, const double* scale_host);
+/* Batched terminal predicates of rlkit/envs/terminals.py:14-117 (TerminalFunc.is_terminal(obs, act, next_obs), the functions
+ * MBPO's FakeEnv and model rollouts label transitions with): done[n] = f(next_obs[n,o]) on the device, NaN / inf
+ * semantics and the Hopper upper-bound-only state check (:61) as in the reference. */
+enum { ILSX_TERM_INVERTED_PENDULUM = 0, ILSX_TERM_INVERTED_DOUBLE_PENDULUM = 1, ILSX_TERM_HOPPER = 2, ILSX_TERM_WALKER2D = 3,
+       ILSX_TERM_HALFCHEETAH = 4, ILSX_TERM_HUMANOID = 5, ILSX_TERM_ANT = 6 };
+int ilsx_is_terminal(ilsx_ctx* ctx, int kind, const float* next_obs, int n, int obs_dim, uint8_t* done);
 /* Running observation statistics of BaseVectorEnv (vecenvs.py:104-113,299-327; RunningMeanStd normalizer.py:128-152):
  * norm_obs: reset/step/cur_obs/rollouts return clip((obs-mean)/sqrt(var+eps), +-10); update_obs_rms: every batch of
  * observations returned by reset/step updates (mean, var, count) first.  Statistics are float64; get/set use HOST arrays

@@ -30,12 +30,13 @@ def test_vec_path_sampler_one_episode_per_env(ctx):
         assert k in st
 
 
-def test_run_script_c1_plumbing(tmp_path):
-    """exp_specs keys of the reference's sac_hopper.yaml (env_num 4, batch 512), two tiny epochs."""
+@pytest.mark.parametrize("spec_name", ["sac_hopper_hip.yaml", "sac_hopper_envpool_hip.yaml"])
+def test_run_script_c1_plumbing(tmp_path, spec_name):
+    """exp_specs keys of the reference's sac_hopper.yaml / sac_hopper_envpool.yaml (env_num 4, batch 512), two tiny epochs."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "run_scripts"))
     import sac_alpha_exp_script as script
-    spec = yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "sac", "sac_hopper_hip.yaml")))
+    spec = yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "sac", spec_name)))
     v = script.flatten_spec(spec)
     v["env_specs"]["env_num"] = 4
     v["rl_alg_params"].update(num_epochs=1, num_steps_per_epoch=400, num_steps_between_train_calls=100,

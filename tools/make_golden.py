@@ -625,8 +625,43 @@ def gen_bc():
     save("g13_bc", **out)
 
 
+def gen_terminals():
+    """G14: the batched terminal predicates (rlkit/envs/terminals.py:6-117) on inputs that straddle every threshold and
+    carry NaN / inf / large-negative entries."""
+    # the module is loaded by path: importing the package rlkit.envs pulls in envpool / gym / dmc2gym, none installed here;
+    # terminals.py itself only needs numpy.  get_terminal_func's name rule (:6-11) is applied by hand.
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_terminals", os.path.join(H.REF, "rlkit", "envs", "terminals.py"))
+    ref_terminals = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_terminals)
+
+    def get_terminal_func(env_name):
+        cls_name = "".join(s_[0].upper() + s_[1:] for s_ in env_name.split("_")) + "TerminalFunc"
+        return getattr(ref_terminals, cls_name).is_terminal
+
+    from oracle import terminals as oterm
+    rng = np.random.default_rng(1414)
+    out = {}
+    for kind, name, o in (("inverted_pendulum", "inverted_pendulum", 4), ("inverted_double_pendulum", "inverted_double_pendulum", 11),
+                          ("hopper", "hopper", 11), ("walker2d", "walker2d", 17), ("halfcheetah", "halfcheetah", 17),
+                          ("humanoid", "humanoid", 45), ("ant", "ant", 27)):
+        nrow = 96
+        x = rng.normal(0.0, 1.0, (nrow, o)).astype(np.float32)
+        x[:, 0] = rng.uniform(0.0, 2.4, nrow)
+        x[:, 1] = rng.uniform(-1.3, 1.3, nrow) * rng.choice([0.1, 0.25, 1.0], nrow)
+        x[5, 3 % o] = np.nan; x[9, o - 1] = np.inf; x[11, 2 % o] = 150.0; x[13, 2 % o] = -150.0; x[17, 0] = np.nan
+        x[19, 0] = 0.7; x[21, 0] = 0.8; x[23, 0] = 2.0; x[25, 0] = 1.0; x[27, 0] = 0.2; x[29, 1] = 0.2; x[31, 1] = -1.0
+        f = get_terminal_func(name)
+        act = np.zeros((nrow, 1), np.float32)
+        done = np.asarray(f(x, act, x))
+        assert done.shape == (nrow, 1) and done.dtype == bool
+        assert np.array_equal(done, oterm.is_terminal(kind, x)), kind
+        out[kind + "_x"], out[kind + "_done"] = x, done
+    save("g14_terminals", **out)
+
+
 GROUPS = dict(bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
-              rms=gen_rms_actionmap)
+              rms=gen_rms_actionmap, terminals=gen_terminals)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)
