@@ -178,6 +178,7 @@ PROTOTYPES = {
     "ilsx_prof_enable": (C.c_int, [vp, C.c_int]),
     "ilsx_prof_reset": (C.c_int, [vp]),
     "ilsx_prof_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "ilsx_prof_kernel": (C.c_char_p, [vp, C.c_int]),
     "ilsx_kernel_name": (C.c_char_p, [C.c_int]),
     "ilsx_debug_set_stamp_buffer": (C.c_int, [vp, vp]),
     "ilsx_net_create": (C.c_int, [vp, C.POINTER(MlpCfg), C.POINTER(vp)]),

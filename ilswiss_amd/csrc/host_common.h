@@ -1,6 +1,7 @@
 // host_common.h — host-side objects behind the opaque handles of include/ilsx.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -58,14 +59,26 @@ struct ilsx_ctx {
   std::vector<hipEvent_t> prof_free;
   double prof_ms[ILSX_K_COUNT] = {0};
   uint64_t prof_n[ILSX_K_COUNT] = {0};
+  const char* prof_name[ILSX_K_COUNT] = {nullptr};   // source spelling of the kernel last launched under each slot
 };
 
-// RAII bracket around ONE kernel launch: records start/stop events on the ctx stream when profiling.
+// RAII bracket around ONE kernel launch.  When profiling, the launch goes through hipExtLaunchKernelGGL, which stamps the two
+// events with the dispatch's own begin / end timestamps (what rocprofv3's kernel trace reports) instead of bracketing it
+// with two extra marker packets (which adds ~3 us to a ~10 us kernel).
 struct ProfScope {
-  ilsx_ctx* c; int kid; hipEvent_t a = nullptr, b = nullptr;
+  ilsx_ctx* c; int kid; hipEvent_t a = nullptr, b = nullptr; bool launched = false;
   ProfScope(ilsx_ctx* ctx, int k);
   ~ProfScope();
 };
+#define ILSX_LAUNCH(ps, kernel, grid, block, lds, stream, ...)                                            \
+  do {                                                                                                    \
+    if ((ps).a) {                                                                                         \
+      (ps).c->prof_name[(ps).kid] = #kernel; (ps).launched = true;                                        \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, (ps).a, (ps).b, 0, __VA_ARGS__);            \
+    } else {                                                                                              \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                  \
+    }                                                                                                     \
+  } while (0)
 
 int ctx_alloc(ilsx_ctx* c, size_t bytes, void** out, bool zero = true);
 int ctx_free(ilsx_ctx* c, void* p);

@@ -135,12 +135,11 @@ static hipEvent_t prof_event(ilsx_ctx* c) {
 ProfScope::ProfScope(ilsx_ctx* ctx, int k) : c(ctx), kid(k) {
   if (!c->prof_on) return;
   a = prof_event(c); b = prof_event(c);
-  (void)hipEventRecord(a, c->stream);
 }
 ProfScope::~ProfScope() {
   if (!a) return;
-  (void)hipEventRecord(b, c->stream);
-  c->prof_pending.push_back({kid, a, b});
+  if (launched) c->prof_pending.push_back({kid, a, b});
+  else { c->prof_free.push_back(a); c->prof_free.push_back(b); }
 }
 static int prof_collect(ilsx_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -161,7 +160,7 @@ extern "C" int ilsx_prof_enable(ilsx_ctx* c, int on) {
 extern "C" int ilsx_prof_reset(ilsx_ctx* c) {
   if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
   ILSX_TRY(prof_collect(c));
-  for (int i = 0; i < ILSX_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  for (int i = 0; i < ILSX_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_name[i] = nullptr; }
   return ILSX_OK;
 }
 extern "C" int ilsx_prof_read(ilsx_ctx* c, int kid, uint64_t* launches, double* total_ms) {
@@ -170,6 +169,10 @@ extern "C" int ilsx_prof_read(ilsx_ctx* c, int kid, uint64_t* launches, double* 
   if (launches) *launches = c->prof_n[kid];
   if (total_ms) *total_ms = c->prof_ms[kid];
   return ILSX_OK;
+}
+extern "C" const char* ilsx_prof_kernel(ilsx_ctx* c, int kid) {
+  if (!c || kid < 0 || kid >= ILSX_K_COUNT || !c->prof_name[kid]) return "";
+  return c->prof_name[kid];
 }
 extern "C" const char* ilsx_kernel_name(int kid) {
   static const char* names[ILSX_K_COUNT] = {"k_mlp_fwd", "k_mlp_bwd_dx", "k_mlp_bwd_dw", "k_adam_polyak",
@@ -359,11 +362,11 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
     const int tiles = (A.rows + 15) / 16;
     dim3 grid(((tiles + A.rt - 1) / A.rt) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (H == 256 && cs == 4) {
-      if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
-      else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
+      if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
+      else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
     } else if (H == 128 && cs == 2) {
-      if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_RELU, 2, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_RELU, 2, false>), grid, block, lds, ctx->stream, A); }
-      else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_TANH, 2, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_fwd_split<128, ACT_TANH, 2, false>), grid, block, lds, ctx->stream, A); }
+      if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<128, ACT_RELU, 2, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<128, ACT_RELU, 2, false>), grid, block, lds, ctx->stream, A); }
+      else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<128, ACT_TANH, 2, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<128, ACT_TANH, 2, false>), grid, block, lds, ctx->stream, A); }
     } else {
       ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "no column-split forward kernel for H=%d cs=%d", H, cs);
     }
@@ -373,7 +376,7 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
   const size_t lds = fwd_lds_bytes(H, KPmax);
   if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
   dim3 grid((A.rows + 15) / 16, A.ntasks), block(4 * H);
-#define CALL_FWD(HH, AA) hipLaunchKernelGGL((k_mlp_fwd<HH, AA>), grid, block, lds, ctx->stream, A)
+#define CALL_FWD(HH, AA) ILSX_LAUNCH(ps, (k_mlp_fwd<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_FWD);
 #undef CALL_FWD
   HIPCHK(hipGetLastError());
@@ -391,11 +394,11 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
     A.xs = ctx->xcd_shift;
     dim3 grid(((A.rows + 15) / 16) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (H == 256 && cs == 4) {
-      if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
-      else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_bwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
+      if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
+      else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
     } else if (H == 128 && cs == 2) {
-      if (act == ILSX_ACT_RELU) { if (A.tasks) hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_RELU, 2, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_RELU, 2, false>), grid, block, lds, ctx->stream, A); }
-      else { if (A.tasks) hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_TANH, 2, true>), grid, block, lds, ctx->stream, A); else hipLaunchKernelGGL((k_mlp2_bwd_split<128, ACT_TANH, 2, false>), grid, block, lds, ctx->stream, A); }
+      if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<128, ACT_RELU, 2, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<128, ACT_RELU, 2, false>), grid, block, lds, ctx->stream, A); }
+      else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<128, ACT_TANH, 2, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<128, ACT_TANH, 2, false>), grid, block, lds, ctx->stream, A); }
     } else {
       ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "no column-split backward kernel for H=%d cs=%d", H, cs);
     }
@@ -404,7 +407,7 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
   }
   const size_t lds = bwd_lds_bytes(H);
   dim3 grid((A.rows + 15) / 16, A.ntasks), block(4 * H);
-#define CALL_BWD(HH, AA) hipLaunchKernelGGL((k_mlp_bwd_dx<HH, AA>), grid, block, lds, ctx->stream, A)
+#define CALL_BWD(HH, AA) ILSX_LAUNCH(ps, (k_mlp_bwd_dx<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_BWD);
 #undef CALL_BWD
   HIPCHK(hipGetLastError());
@@ -414,7 +417,7 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
 int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P) {
   if (P.rows <= 0) return ILSX_OK;
   ProfScope ps(ctx, ILSX_K_POLICY_FINISH);
-  hipLaunchKernelGGL(k_policy_finish, dim3((P.rows + 63) / 64), dim3(64), 0, ctx->stream, P);
+  ILSX_LAUNCH(ps, k_policy_finish, dim3((P.rows + 63) / 64), dim3(64), 0, ctx->stream, P);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
@@ -447,7 +450,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     D.F.on = 0;
     {
       ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-      hipLaunchKernelGGL(k_mlp_bwd_dw<false>, dim3(D.ntiles, splits), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+      ILSX_LAUNCH(ps, k_mlp_bwd_dw<false>, dim3(D.ntiles, splits), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
     }
     DwReduceArgs R;
     R.scratch = D.scratch; R.splits = splits; R.span = span; R.g_lo = D.g_lo; R.F = keep;
@@ -455,13 +458,13 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     int blocks = (int)((span / 4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     ProfScope ps(ctx, ILSX_K_ADAM);
-    hipLaunchKernelGGL(k_dw_reduce, dim3(blocks), dim3(256), 0, ctx->stream, R);
+    ILSX_LAUNCH(ps, k_dw_reduce, dim3(blocks), dim3(256), 0, ctx->stream, R);
     HIPCHK(hipGetLastError());
     return ILSX_OK;
   }
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-  if (D.gtiles) hipLaunchKernelGGL(k_mlp_bwd_dw<true>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
-  else hipLaunchKernelGGL(k_mlp_bwd_dw<false>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+  if (D.gtiles) ILSX_LAUNCH(ps, k_mlp_bwd_dw<true>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+  else ILSX_LAUNCH(ps, k_mlp_bwd_dw<false>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
@@ -484,7 +487,7 @@ int launch_adam(ilsx_ctx* ctx, const AdamArgs& A) {
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   ProfScope ps(ctx, ILSX_K_ADAM);
-  hipLaunchKernelGGL(k_adam_polyak, dim3(blocks), dim3(256), 0, ctx->stream, A);
+  ILSX_LAUNCH(ps, k_adam_polyak, dim3(blocks), dim3(256), 0, ctx->stream, A);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

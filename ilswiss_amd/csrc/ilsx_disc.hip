@@ -459,13 +459,13 @@ extern "C" int ilsx_disc_train_step(ilsx_disc* d, const float* exp_obs, const fl
     dim3 grid((rows + 15) / 16), block(4 * H);
     ProfScope ps(ctx, ILSX_K_DISC_BWD);
     if (d->cfg.hid_act == ILSX_ACT_TANH) {
-      if (H == 64) hipLaunchKernelGGL((k_disc_bwd<64, ACT_TANH>), grid, block, lds, ctx->stream, A);
-      else if (H == 128) hipLaunchKernelGGL((k_disc_bwd<128, ACT_TANH>), grid, block, lds, ctx->stream, A);
-      else hipLaunchKernelGGL((k_disc_bwd<256, ACT_TANH>), grid, block, lds, ctx->stream, A);
+      if (H == 64) ILSX_LAUNCH(ps, (k_disc_bwd<64, ACT_TANH>), grid, block, lds, ctx->stream, A);
+      else if (H == 128) ILSX_LAUNCH(ps, (k_disc_bwd<128, ACT_TANH>), grid, block, lds, ctx->stream, A);
+      else ILSX_LAUNCH(ps, (k_disc_bwd<256, ACT_TANH>), grid, block, lds, ctx->stream, A);
     } else {
-      if (H == 64) hipLaunchKernelGGL((k_disc_bwd<64, ACT_RELU>), grid, block, lds, ctx->stream, A);
-      else if (H == 128) hipLaunchKernelGGL((k_disc_bwd<128, ACT_RELU>), grid, block, lds, ctx->stream, A);
-      else hipLaunchKernelGGL((k_disc_bwd<256, ACT_RELU>), grid, block, lds, ctx->stream, A);
+      if (H == 64) ILSX_LAUNCH(ps, (k_disc_bwd<64, ACT_RELU>), grid, block, lds, ctx->stream, A);
+      else if (H == 128) ILSX_LAUNCH(ps, (k_disc_bwd<128, ACT_RELU>), grid, block, lds, ctx->stream, A);
+      else ILSX_LAUNCH(ps, (k_disc_bwd<256, ACT_RELU>), grid, block, lds, ctx->stream, A);
     }
     HIPCHK(hipGetLastError());
   }

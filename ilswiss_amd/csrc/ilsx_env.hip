@@ -552,7 +552,7 @@ static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
     attr_done = true;
   }
   ProfScope ps(e->ctx, ILSX_K_ENV_STEP);
-  hipLaunchKernelGGL((k_env_step<NB, MR, BLOCK>), dim3((A.n_ids + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, e->ctx->stream, A);
+  ILSX_LAUNCH(ps, (k_env_step<NB, MR, BLOCK>), dim3((A.n_ids + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, e->ctx->stream, A);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

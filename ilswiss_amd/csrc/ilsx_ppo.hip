@@ -362,7 +362,7 @@ extern "C" int ilsx_ppo_gae(ilsx_ppo* p, const float* obs, const float* act, con
   ILSX_TRY(ppo_full_forward(p, obs, act, N, true, p->values));
   {
     ProfScope ps(p->ctx, ILSX_K_PPO_GAE);
-    hipLaunchKernelGGL(k_ppo_gae, dim3((n_traj + 3) / 4), dim3(256), 0, st, p->values, rew, p->offs, bootstrap_values, n_traj, p->cfg.reward_scale,
+    ILSX_LAUNCH(ps, k_ppo_gae, dim3((n_traj + 3) / 4), dim3(256), 0, st, p->values, rew, p->offs, bootstrap_values, n_traj, p->cfg.reward_scale,
                        p->cfg.discount, p->cfg.gae_tau, p->returns, p->adv);
   }
   HIPCHK(hipGetLastError());

@@ -165,7 +165,7 @@ extern "C" int ilsx_replay_add(ilsx_replay* rb, const float* obs, const float* a
   const long long total = (long long)n * rb->rec;
   {
   ProfScope ps(ctx, ILSX_K_REPLAY_ADD);
-  hipLaunchKernelGGL(k_replay_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rb->data, rb->rec,
+  ILSX_LAUNCH(ps, k_replay_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rb->data, rb->rec,
                      (long long)rb->cap, (long long)rb->top, d_obs, d_act, d_rew, d_done, d_nobs, n, o, a);
   }
   HIPCHK(hipGetLastError());
@@ -201,7 +201,7 @@ int replay_launch_sample(ilsx_replay* rb, int B, const int64_t* idx, const DevSc
                          int64_t* idx_out) {
   const int total = B * rb->rec;
   ProfScope ps(rb->ctx, ILSX_K_REPLAY_SAMPLE);
-  hipLaunchKernelGGL(k_replay_sample, dim3((total + 255) / 256), dim3(256), 0, rb->ctx->stream, rb->data, rb->rec,
+  ILSX_LAUNCH(ps, k_replay_sample, dim3((total + 255) / 256), dim3(256), 0, rb->ctx->stream, rb->data, rb->rec,
                      rb->dstate, (const long long*)idx, rb->seed, rb->rng_stream, scal, step_host, B, rb->o, rb->a, obs,
                      act, rew, done, nobs, (long long*)idx_out);
   HIPCHK(hipGetLastError());
@@ -225,7 +225,7 @@ extern "C" int ilsx_replay_sample_many(ilsx_replay* rb, int n_batches, int B, fl
   long long blocks = (rows * rec4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // >> 256 CUs, grid-stride the rest
   ProfScope ps(rb->ctx, ILSX_K_REPLAY_SAMPLE_MANY);
-  hipLaunchKernelGGL(k_replay_sample_many, dim3((unsigned)blocks), dim3(256), 0, rb->ctx->stream,
+  ILSX_LAUNCH(ps, k_replay_sample_many, dim3((unsigned)blocks), dim3(256), 0, rb->ctx->stream,
                      (const float4*)rb->data, rec4, rb->dstate, rb->seed, rb->rng_stream, rb->sample_ctr + 1, B, rows,
                      (float4*)out_records);
   rb->sample_ctr += n_batches;

@@ -534,7 +534,7 @@ static int sac_actor_backward(ilsx_sac* s) {
   if (s->fuse_now) return ILSX_OK;  // stats run inside k_sac_tail (sac_actor_update)
   StatsArgs S = sac_stats_args(s);
   ProfScope ps(s->ctx, ILSX_K_SAC_STATS);
-  hipLaunchKernelGGL(k_sac_stats, dim3(1), dim3(256), 0, s->ctx->stream, S);
+  ILSX_LAUNCH(ps, k_sac_stats, dim3(1), dim3(256), 0, s->ctx->stream, S);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
@@ -570,14 +570,14 @@ static int sac_actor_update(ilsx_sac* s) {
   }
   if (s->fuse_now) {
     ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
-    hipLaunchKernelGGL(k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, sac_stats_args(s), s->cfg.train_alpha,
+    ILSX_LAUNCH(ps, k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, sac_stats_args(s), s->cfg.train_alpha,
                        s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr);
     HIPCHK(hipGetLastError());
     return ILSX_OK;
   }
   ILSX_TRY(launch_adam(s->ctx, A));
   ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
-  hipLaunchKernelGGL(k_sac_finish, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, (const float*)(s->G + 2 * s->nq + s->np),
+  ILSX_LAUNCH(ps, k_sac_finish, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, (const float*)(s->G + 2 * s->nq + s->np),
                      s->cfg.train_alpha, s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
@@ -942,7 +942,7 @@ static int group_launch_step(ilsx_sac_group* g) {
     else if (st.kind == 2) { AdamFuse on; memset(&on, 0, sizeof on); on.on = 1; ILSX_TRY(launch_bwd_dw(g->ctx, st.d, g->B, &on)); }
     else {
       ProfScope ps(g->ctx, ILSX_K_SAC_FINISH);
-      hipLaunchKernelGGL(k_sac_tail_group, dim3((unsigned)g->agents.size()), dim3(256), 0, g->ctx->stream, (const SacTailItem*)st.tails);
+      ILSX_LAUNCH(ps, k_sac_tail_group, dim3((unsigned)g->agents.size()), dim3(256), 0, g->ctx->stream, (const SacTailItem*)st.tails);
       HIPCHK(hipGetLastError());
     }
   }

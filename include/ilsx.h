@@ -68,8 +68,11 @@ int ilsx_memcpy_h2d(ilsx_ctx* ctx, void* dst_dev, const void* src_host, size_t b
 int ilsx_memcpy_d2h(ilsx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* syncs */
 
 /* ---------------------------------------------------------------- kernel timing (bench.py roofline leg)
- * When enabled, every launch of a library kernel is bracketed by hipEvents on the ctx stream (the graph
- * path is bypassed while profiling); ilsx_prof_read synchronises and returns launches + summed ms. */
+ * When enabled, every launch of a library kernel carries a start / stop hipEvent stamped with the dispatch's own
+ * begin / end time (hipExtLaunchKernelGGL — the interval rocprofv3's kernel trace reports; the graph path is
+ * bypassed while profiling); ilsx_prof_read synchronises and returns launches + summed ms of a slot,
+ * ilsx_prof_kernel the source spelling of the kernel last launched under it (several kernels share a slot:
+ * the column-split and the generic MLP kernels). */
 enum { ILSX_K_MLP_FWD = 0, ILSX_K_MLP_BWD_DX = 1, ILSX_K_MLP_BWD_DW = 2, ILSX_K_ADAM = 3,
        ILSX_K_REPLAY_SAMPLE = 4, ILSX_K_REPLAY_ADD = 5, ILSX_K_REPLAY_SAMPLE_MANY = 6, ILSX_K_SAC_STATS = 7,
        ILSX_K_SAC_FINISH = 8, ILSX_K_ENV_STEP = 9, ILSX_K_POLICY_FINISH = 10, ILSX_K_DISC_BWD = 11, ILSX_K_PPO_GAE = 12,
@@ -77,6 +80,7 @@ enum { ILSX_K_MLP_FWD = 0, ILSX_K_MLP_BWD_DX = 1, ILSX_K_MLP_BWD_DW = 2, ILSX_K_
 int ilsx_prof_enable(ilsx_ctx* ctx, int on);
 int ilsx_prof_reset(ilsx_ctx* ctx);
 int ilsx_prof_read(ilsx_ctx* ctx, int kernel_id, uint64_t* launches, double* total_ms);
+const char* ilsx_prof_kernel(ilsx_ctx* ctx, int kernel_id);
 const char* ilsx_kernel_name(int kernel_id);
 /* debugging aid: workgroup (0,0) of the MLP forward kernel writes shader-clock phase stamps into a
  * device uint64[16] buffer (NULL = off). */
