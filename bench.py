@@ -34,14 +34,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix p
 PEAK_HBM_GBS = 8000.0
 
 
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_summary.json")
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_pmc_summary.json")
 PMC_NAMES = {0: ("k_mlp2_fwd_split", "k_mlp_fwd"), 1: ("k_mlp2_bwd_split", "k_mlp_bwd_dx"), 2: ("k_mlp_bwd_dw",),
              6: ("k_replay_sample_many",)}
 
 
 def pmc_traffic(kid):
     """HBM bytes per launch of profiling id `kid` from the committed rocprofv3 counter passes (tools/pmc_collect.sh ->
-    profiles/r01_d_pmc_summary.json): FETCH_SIZE x 1024 x 2 (gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE x
+    profiles/r01_g_pmc_summary.json): FETCH_SIZE x 1024 x 2 (gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE x
     1024, each collected in its own --pmc pass over the same kernels at the same sizes.  None if the file is absent."""
     try:
         with open(PMC_SUMMARY) as f:
