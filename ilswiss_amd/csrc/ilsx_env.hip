@@ -120,10 +120,10 @@ template <int NB, int MR, int BLOCK>
 struct EnvScratch {
   static constexpr int N = NB + 2;
   static constexpr int OFF_M = 0;               // N*N   (becomes the Cholesky factor L)
-  static constexpr int OFF_J = OFF_M + N * N;   // MR*N
-  static constexpr int OFF_Y = OFF_J + MR * N;  // N*MR  (M^-1 J^T, column per row)
-  static constexpr int OFF_A = OFF_Y + N * MR;  // MR*MR
-  static constexpr int TOTAL = OFF_A + MR * MR;
+  static constexpr int OFF_J = OFF_M + N * N;   // MR*N  (row r becomes z_r = L^-1 j_r in place)
+  static constexpr int OFF_A = OFF_J + MR * N;  // MR*(MR+1)/2: A = J M^-1 J^T = Z Z^T, lower triangle packed
+  static constexpr int TOTAL = OFF_A + MR * (MR + 1) / 2;
+  static constexpr int a_idx(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 };
 
 // Forward dynamics with soft constraints: qacc = f(q, v, ctrl).  See oracle/planar_env.py::dynamics.
@@ -293,7 +293,8 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
     for (int i = 0; i < N; ++i) qacc[i] = qacc0[i];
     return;
   }
-  // ---- Y = M^-1 J^T, A = J Y, PGS on (A + R) f = aref - J qacc0
+  // ---- z_r = L^-1 j_r (forward substitution only, in place), A = Z Z^T (symmetric, packed), PGS on (A + R) f = aref - J qacc0.
+  // M^-1 J^T itself is never formed: the constraint acceleration is L^-T (Z^T f), one back-substitution at the end.
   double rhs_c[MR], Rd[MR], f[MR];
 #pragma unroll
   for (int t = 0; t < MR; ++t) { rhs_c[t] = 0.0; Rd[t] = 0.0; f[t] = 0.0; }
@@ -304,32 +305,37 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
     double jv = 0.0, ja = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { jv += x[i] * v[i]; ja += x[i] * qacc0[i]; }
-    chol_solve(x);
 #pragma unroll
-    for (int i = 0; i < N; ++i) SL(S::OFF_Y, i * MR + r) = x[i];
+    for (int i = 0; i < N; ++i) {
+      double sum = x[i];
 #pragma unroll
-    for (int t = 0; t < MR; ++t)
-      if (t == r) { rhs_c[t] = (-rb_[t] * jv - rk[t] * rd[t] * rr[t]) - ja; f[t] = 0.0; }
-  }
-  for (int r = 0; r < nr; ++r)
-    for (int c2 = 0; c2 < nr; ++c2) {
-      double sum = 0.0;
-#pragma unroll
-      for (int i = 0; i < N; ++i) sum += SL(S::OFF_J, r * N + i) * SL(S::OFF_Y, i * MR + c2);
-      SL(S::OFF_A, r * MR + c2) = sum;
+      for (int t = 0; t < i; ++t) sum -= SL(S::OFF_M, i * N + t) * x[t];
+      x[i] = sum / SL(S::OFF_M, i * N + i);
     }
 #pragma unroll
+    for (int i = 0; i < N; ++i) SL(S::OFF_J, r * N + i) = x[i];
+#pragma unroll
+    for (int t = 0; t < MR; ++t)
+      if (t == r) rhs_c[t] = (-rb_[t] * jv - rk[t] * rd[t] * rr[t]) - ja;
+    for (int c2 = 0; c2 <= r; ++c2) {
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sum += x[i] * SL(S::OFF_J, c2 * N + i);
+      SL(S::OFF_A, r * (r + 1) / 2 + c2) = sum;
+    }
+  }
+#pragma unroll
   for (int t = 0; t < MR; ++t)
-    if (t < nr) Rd[t] = (1.0 - rd[t]) / rd[t] * SL(S::OFF_A, t * MR + t);
+    if (t < nr) Rd[t] = (1.0 - rd[t]) / rd[t] * SL(S::OFF_A, S::a_idx(t, t));
   for (int it = 0; it < m.pgs_iters; ++it) {
 #pragma unroll
     for (int t = 0; t < MR; ++t) {
       if (t >= nr) continue;
-      const double aii = SL(S::OFF_A, t * MR + t);
+      const double aii = SL(S::OFF_A, S::a_idx(t, t));
       double res = rhs_c[t] + aii * f[t];
 #pragma unroll
       for (int u = 0; u < MR; ++u)
-        if (u < nr) res -= SL(S::OFF_A, t * MR + u) * f[u];
+        if (u < nr) res -= SL(S::OFF_A, S::a_idx(t, u)) * f[u];
       double fi = res / (aii + Rd[t]);
       if (rkind[t] == 1) {
         const double lim = rmu[t] * f[t > 0 ? t - 1 : 0];
@@ -340,14 +346,26 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
       f[t] = fi;
     }
   }
+  double w[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    double sum = qacc0[i];
+  for (int i = 0; i < N; ++i) w[i] = 0.0;
+  for (int r = 0; r < nr; ++r) {
+    double fr = 0.0;
 #pragma unroll
     for (int t = 0; t < MR; ++t)
-      if (t < nr) sum += SL(S::OFF_Y, i * MR + t) * f[t];
-    qacc[i] = sum;
+      if (t == r) fr = f[t];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] += SL(S::OFF_J, r * N + i) * fr;
   }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double sum = w[i];
+#pragma unroll
+    for (int t = i + 1; t < N; ++t) sum -= SL(S::OFF_M, t * N + i) * w[t];
+    w[i] = sum / SL(S::OFF_M, i * N + i);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) qacc[i] = qacc0[i] + w[i];
 }
 
 template <int NB, int MR, int BLOCK>
@@ -559,7 +577,7 @@ static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
 static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
   if (A.n_ids <= 0) return ILSX_OK;
   if (e->hm.nb == 4) return launch_env_step_t<4, 8, 64>(e, A);
-  if (e->hm.nb == 7) return e->hm.max_rows > 12 ? launch_env_step_t<7, 16, 16>(e, A) : launch_env_step_t<7, 12, 32>(e, A);
+  if (e->hm.nb == 7) return e->hm.max_rows > 12 ? launch_env_step_t<7, 16, 32>(e, A) : launch_env_step_t<7, 12, 64>(e, A);
   ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "vec-env kernels are instantiated for 4 (Hopper) and 7 (Walker2d) bodies, got %d", e->hm.nb);
 }
 static int launch_env_reset(ilsx_vecenv* e, const int* ids_dev, int n_ids, float* obs) {
