@@ -36,7 +36,7 @@ __global__ void k_ac_tick(AcScalars* sc, DevScalars* dsc, int mask, int advance,
     sc->step[i] = (float)((double)lr[i] / (1.0 - pow((double)b1, t)));
     sc->bc2s[i] = (float)sqrt(1.0 - pow(0.999, t));
   }
-  if (advance) dsc->step += 1;
+  if (advance) { dsc->step += 1; dsc->gather_step += 1; }
 }
 
 // ptu.soft_update_from_to (pytorch_util.py:10-12) over a contiguous arena slice

@@ -360,7 +360,13 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
     A.xs = ctx->xcd_shift;
     if (A.rt <= 0) A.rt = (A.tasks && ctx->rt_grouped > 0) ? ctx->rt_grouped : ctx->rt_single;
     const int tiles = (A.rows + 15) / 16;
-    dim3 grid(((tiles + A.rt - 1) / A.rt) << A.xs, A.ntasks, cs), block(4 * H / cs);
+    // XCD-aware tile mapping: workgroups are dealt to the 8 XCDs round-robin in linear order (x fastest), so with grid.x a
+    // multiple of 8 row tile t runs on XCD t % 8 in EVERY column-split launch, whatever its task / slice count — the
+    // activations a forward launch leaves in an XCD's L2 are read back by the backward launch's workgroups of the same
+    // tile from that L2.  (Measured: one extra x column in the two forward launches costs the backward launches that
+    // consume their activations 2.9 us each.)  Padding workgroups exit at once.
+    dim3 grid(((((tiles + A.rt - 1) / A.rt) + 7) & ~7) << A.xs, A.ntasks, cs), block(4 * H / cs);
+    if (A.tail_mode) { if (A.tasks || !A.tail) ILSX_FAIL(ILSX_ERR_ARG, "deferred tail: single-agent launches only"); grid.z += 1; }
     if (H == 256 && cs == 4) {
       if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
       else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
@@ -392,7 +398,7 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
   if (cs > 1) {
     const size_t lds = bwd_split_lds_bytes(H, cs);
     A.xs = ctx->xcd_shift;
-    dim3 grid(((A.rows + 15) / 16) << A.xs, A.ntasks, cs), block(4 * H / cs);
+    dim3 grid(((((A.rows + 15) / 16) + 7) & ~7) << A.xs, A.ntasks, cs), block(4 * H / cs);   // same tile -> XCD mapping as launch_fwd
     if (H == 256 && cs == 4) {
       if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
       else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }

@@ -71,6 +71,11 @@ struct ilsx_sac {
   hipGraphExec_t graph = nullptr;
   ilsx_replay* graph_rb = nullptr;
   int graph_B = 0;
+  bool graph_defer = false;
+  // deferred tail (TailLite, kernels.h): active inside ilsx_sac_train_from_replay on the column-split path
+  bool defer_tail = false;
+  TailLite* tail_dev = nullptr;
+  int tail_B = 0;
   float* base(int which) const {
     switch (which) {
       case W_Q1: return P;
@@ -167,44 +172,22 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
   }
 }
 
-// alpha Adam in float64 (sac_alpha.py:51-53,160-166) + step counters
-__device__ __host__ inline void adam_scalars(double lr, double b1, double b2, int t, float* step, float* bc2s) {
-  *step = (float)(lr / (1.0 - pow(b1, (double)t)));
-  *bc2s = (float)sqrt(1.0 - pow(b2, (double)t));
-}
-
 __global__ __launch_bounds__(256) void k_sac_stats(const StatsArgs S) { sac_stats_dev(S); }
 
-__device__ __forceinline__ void sac_finish_dev(DevScalars* sc, const float* alpha_grad_slot, int train_alpha, float lr,
-                                               float b1, float b2, float eps, float qf_lr, float policy_lr) {
-  if (train_alpha) {
-    const double g = (double)alpha_grad_slot[0];
-    const int t = sc->t_alpha + 1;
-    sc->m_alpha = sc->m_alpha * (double)b1 + (1.0 - (double)b1) * g;
-    sc->v_alpha = sc->v_alpha * (double)b2 + (1.0 - (double)b2) * g * g;
-    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
-    const double denom = sqrt(sc->v_alpha) / sqrt(bc2) + (double)eps;
-    sc->log_alpha -= ((double)lr / bc1) * (sc->m_alpha / denom);
-    sc->alpha = (float)exp(sc->log_alpha);
-    sc->t_alpha = t;
-  }
-  sc->t_q += 1;
-  sc->t_pi += 1;
-  sc->step += 1;
-  adam_scalars(qf_lr, b1, b2, sc->t_q + 1, &sc->adam_q_step, &sc->adam_q_bc2s);
-  adam_scalars(policy_lr, b1, b2, sc->t_pi + 1, &sc->adam_pi_step, &sc->adam_pi_bc2s);
-}
 __global__ void k_sac_finish(DevScalars* sc, const float* alpha_grad_slot, int train_alpha, float lr, float b1,
                              float b2, float eps, float qf_lr, float policy_lr) {
-  sac_finish_dev(sc, alpha_grad_slot, train_alpha, lr, b1, b2, eps, qf_lr, policy_lr);
+  sac_finish_dev(sc, alpha_grad_slot, train_alpha, lr, b1, b2, eps, qf_lr, policy_lr, 0);
 }
 // stats + alpha Adam + counters in ONE launch (the un-split step: nothing has to be all-reduced in between)
+// deferred = 1: this launch flushes a deferred tail (TailLite, kernels.h) — gather_step was advanced by the step itself
 __global__ __launch_bounds__(256) void k_sac_tail(const StatsArgs S, int train_alpha, float lr, float b1, float b2,
-                                                  float eps, float qf_lr, float policy_lr) {
+                                                  float eps, float qf_lr, float policy_lr, int deferred) {
   if (S.scal->want_stats) sac_stats_dev(S);   // workgroup-uniform
   else sac_alpha_grad_dev(S);
   if (threadIdx.x == 0) S.scal->want_stats = 0;
-  if (threadIdx.x == 0) sac_finish_dev(S.scal, S.alpha_grad_slot, train_alpha, lr, b1, b2, eps, qf_lr, policy_lr);
+  if (threadIdx.x == 0) {
+    sac_finish_dev(S.scal, S.alpha_grad_slot, train_alpha, lr, b1, b2, eps, qf_lr, policy_lr, deferred);
+  }
 }
 
 // grouped step: one workgroup per agent
@@ -214,7 +197,7 @@ __global__ __launch_bounds__(256) void k_sac_tail_group(const SacTailItem* items
   else sac_alpha_grad_dev(T.S);
   if (threadIdx.x == 0) {
     T.S.scal->want_stats = 0;
-    sac_finish_dev(T.S.scal, T.S.alpha_grad_slot, T.train_alpha, T.lr, T.b1, T.b2, T.eps, T.qf_lr, T.policy_lr);
+    sac_finish_dev(T.S.scal, T.S.alpha_grad_slot, T.train_alpha, T.lr, T.b1, T.b2, T.eps, T.qf_lr, T.policy_lr, 0);
   }
 }
 
@@ -323,6 +306,7 @@ extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
   hipSetDevice(s->ctx->device);
   hipStreamSynchronize(s->ctx->stream);
   if (s->graph) hipGraphExecDestroy(s->graph);
+  if (s->tail_dev) ctx_free(s->ctx, s->tail_dev);
   // give the networks private storage back so their handles stay usable
   ilsx_net* nets[3] = {s->pi, s->q1, s->q2};
   const int wh[3] = {W_PI, W_Q1, W_Q2};
@@ -431,6 +415,7 @@ static int sac_critic_backward(ilsx_sac* s) {
       A.t[2].g0_off = 0; A.t[2].g1_off = s->o; A.t[2].publish = 0;
       A.t[3].g0_off = 0; A.t[3].publish = 0;                              // pi reads obs
     }
+    if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 1; }
     ILSX_TRY(sac_fwd(s, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
   }
   {  // fwd: TQ1(s',a'), TQ2(s',a')
@@ -440,6 +425,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     sac_q_task(s, A.t[0], W_TQ1, w.s2, w.a2, w.tq1, false, false, 0);
     sac_q_task(s, A.t[1], W_TQ2, w.s2, w.a2, w.tq2, false, false, 1);
     sac_policy_fin(s, A, eps1, s->rng_stream, false, w.a2, w.logp2, w.ppart);
+    if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 2; }
     ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx with the TD-target loss head
@@ -568,10 +554,11 @@ static int sac_actor_update(ilsx_sac* s) {
     s->col->L.push_back(l);
     return ILSX_OK;
   }
+  if (s->fuse_now && s->defer_tail) return ILSX_OK;   // the next step's first launch (or sac_flush_tail) runs it
   if (s->fuse_now) {
     ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
     ILSX_LAUNCH(ps, k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, sac_stats_args(s), s->cfg.train_alpha,
-                       s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr);
+                       s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr, /*deferred=*/0);
     HIPCHK(hipGetLastError());
     return ILSX_OK;
   }
@@ -586,6 +573,38 @@ static int sac_actor_update(ilsx_sac* s) {
 static int sac_refresh_adam(ilsx_sac* s) {
   hipLaunchKernelGGL(k_sac_refresh_adam, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, s->cfg.qf_lr, s->cfg.policy_lr,
                      s->cfg.beta_1, 0.999f);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+// Deferred tail: see TailLite in kernels.h.  Enabled for the duration of one train_from_replay call when the whole step runs on
+// the fused column-split path (no gradient all-reduce between the phases, no XCD confinement); the last step's tail is flushed
+// by the ordinary tail kernel, so no tail is ever pending when the call returns.
+static int sac_defer_begin(ilsx_sac* s, int B) {
+  static const bool off = getenv("ILSX_NO_DEFER_TAIL") != nullptr || getenv("ILSX_NO_FUSE") != nullptr;
+  s->defer_tail = false;
+  if (off || s->cs <= 1 || s->cfg.grad_world != 1 || s->col) return ILSX_OK;
+  if (!s->tail_dev) ILSX_TRY(ctx_alloc(s->ctx, sizeof(TailLite), (void**)&s->tail_dev));
+  if (s->tail_B != B) {
+    TailLite t;
+    memset(&t, 0, sizeof t);
+    t.logp = s->ws.logp; t.B = B; t.target_entropy = s->target_entropy; t.inv_B = sac_inv_B(s);
+    t.alpha_grad_slot = s->G + 2 * s->nq + s->np; t.scal = s->scal;
+    t.train_alpha = s->cfg.train_alpha; t.lr = s->cfg.alpha_lr; t.b1 = s->cfg.beta_1; t.b2 = 0.999f; t.eps = 1e-8f;
+    t.qf_lr = s->cfg.qf_lr; t.policy_lr = s->cfg.policy_lr;
+    HIPCHK(hipMemcpyAsync(s->tail_dev, &t, sizeof t, hipMemcpyHostToDevice, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));   // `t` lives on this stack frame
+    s->tail_B = B;
+  }
+  s->defer_tail = true;
+  return ILSX_OK;
+}
+static int sac_flush_tail(ilsx_sac* s) {   // the pending tail of the call's last step (+ its statistics if requested)
+  if (!s->defer_tail) return ILSX_OK;
+  s->defer_tail = false;
+  ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
+  ILSX_LAUNCH(ps, k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, sac_stats_args(s), s->cfg.train_alpha,
+              s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr, /*deferred=*/1);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
@@ -694,30 +713,34 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   s->B = B;
   s->eps_explicit = false;
   static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
+  if (n_steps == 0) return stats ? sac_read_stats(s, stats) : ILSX_OK;
+  ILSX_TRY(sac_defer_begin(s, B));
   if (no_graph || s->ctx->prof_on) {
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
-      ILSX_TRY(sac_sample_and_step(s, rb, B));
+      const int rc = sac_sample_and_step(s, rb, B);
+      if (rc != ILSX_OK) { s->defer_tail = false; return rc; }
     }
   } else {
-    if (!s->graph || s->graph_rb != rb || s->graph_B != B) {
+    if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail) {
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
       hipGraph_t g = nullptr;
       HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       int rc = sac_sample_and_step(s, rb, B);
       hipError_t e = hipStreamEndCapture(st, &g);
-      if (rc != ILSX_OK) { if (g) hipGraphDestroy(g); return rc; }
+      if (rc != ILSX_OK) { if (g) hipGraphDestroy(g); s->defer_tail = false; return rc; }
       if (e != hipSuccess) ILSX_FAIL(ILSX_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
       e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
       if (e != hipSuccess) { s->graph = nullptr; ILSX_FAIL(ILSX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
-      s->graph_rb = rb; s->graph_B = B;
+      s->graph_rb = rb; s->graph_B = B; s->graph_defer = s->defer_tail;
     }
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
       HIPCHK(hipGraphLaunch(s->graph, st));
     }
   }
+  ILSX_TRY(sac_flush_tail(s));
   if (stats) return sac_read_stats(s, stats);
   return ILSX_OK;
 }
@@ -813,7 +836,7 @@ extern "C" int ilsx_sac_set_alpha_opt(ilsx_sac* s, double m, double v, int64_t t
   DevScalars h;
   HIPCHK(hipMemcpyAsync(&h, s->scal, sizeof h, hipMemcpyDeviceToHost, s->ctx->stream));
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
-  h.m_alpha = m; h.v_alpha = v; h.t_alpha = (int)t; h.step = rng_step;
+  h.m_alpha = m; h.v_alpha = v; h.t_alpha = (int)t; h.step = rng_step; h.gather_step = rng_step;
   HIPCHK(hipMemcpyAsync(s->scal, &h, sizeof h, hipMemcpyHostToDevice, s->ctx->stream));
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
   return ILSX_OK;

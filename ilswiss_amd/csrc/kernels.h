@@ -66,6 +66,11 @@ struct DevScalars {
   // Std / Max / Min of the five batch quantities of create_stats_ordered_dict (sac_alpha.py:202-233): q1, q2, log pi, mu, log std
   float ext_std[5], ext_max[5], ext_min[5];
   int want_stats;   // host sets 1 before the step whose statistics it will read (sac_alpha.py:186: one batch per epoch)
+  int pad1;
+  // Philox counter of the in-kernel replay draw.  Equal to `step` except inside a deferred-tail window (TailLite), where the
+  // second forward launch of a step advances it and the tail (one step late) advances `step`: gather_step == step + 1 means
+  // "the step just taken has not had its alpha / counter update yet".
+  unsigned long long gather_step;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -91,6 +96,65 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t step, uin
   const float r0 = sqrtf(-2.0f * logf(u01_open(c[0]))), r1 = sqrtf(-2.0f * logf(u01_open(c[2])));
   const float t0 = 6.28318530717958647692f * u01_open(c[1]), t1 = 6.28318530717958647692f * u01_open(c[3]);
   z[0] = r0 * cosf(t0); z[1] = r0 * sinf(t0); z[2] = r1 * cosf(t1); z[3] = r1 * sinf(t1);
+}
+
+// block-wide sum of one float per thread (256 threads); result valid in every thread
+__device__ __forceinline__ float block256_sum(float v, float* sh) {
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- the scalar tail of a SAC step: alpha Adam in float64 (sac_alpha.py:51-53,160-166), step counters, and the Adam
+// bias-correction scalars of the NEXT step.
+__device__ __host__ inline void adam_scalars(double lr, double b1, double b2, int t, float* step, float* bc2s) {
+  *step = (float)(lr / (1.0 - pow(b1, (double)t)));
+  *bc2s = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+__device__ __forceinline__ void sac_finish_dev(DevScalars* sc, const float* alpha_grad_slot, int train_alpha, float lr,
+                                               float b1, float b2, float eps, float qf_lr, float policy_lr, int deferred) {
+  if (train_alpha) {
+    const double g = (double)alpha_grad_slot[0];
+    const int t = sc->t_alpha + 1;
+    sc->m_alpha = sc->m_alpha * (double)b1 + (1.0 - (double)b1) * g;
+    sc->v_alpha = sc->v_alpha * (double)b2 + (1.0 - (double)b2) * g * g;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const double denom = sqrt(sc->v_alpha) / sqrt(bc2) + (double)eps;
+    sc->log_alpha -= ((double)lr / bc1) * (sc->m_alpha / denom);
+    sc->alpha = (float)exp(sc->log_alpha);
+    sc->t_alpha = t;
+  }
+  sc->t_q += 1;
+  sc->t_pi += 1;
+  sc->step += 1;
+  if (!deferred) sc->gather_step += 1;   // deferred: already advanced by the step's second forward launch
+  adam_scalars(qf_lr, b1, b2, sc->t_q + 1, &sc->adam_q_step, &sc->adam_q_bc2s);
+  adam_scalars(policy_lr, b1, b2, sc->t_pi + 1, &sc->adam_pi_step, &sc->adam_pi_bc2s);
+}
+// Deferred tail: inside ilsx_sac_train_from_replay the tail of step k is not a launch of its own.  ONE extra workgroup of the
+// first forward launch of step k+1 (FwdArgs::tail, tail_mode 1) does the alpha update while the other workgroups run pi(s'),
+// Q(s,a), pi(s) — none of which reads alpha, `step`, the Adam scalars or the t counters (first consumers: the second / third
+// launch); the replay draw of that launch is keyed by `gather_step`, which the extra workgroup of the step's SECOND forward
+// launch advances (tail_mode 2) — no reader of it is in flight there.  The last step of a call is flushed by the ordinary
+// k_sac_tail.  The record lives in device memory, so the kernel arguments grow by one pointer and one int.
+struct TailLite {
+  const float* logp; int B; float target_entropy, inv_B; float* alpha_grad_slot; DevScalars* scal;
+  int train_alpha; float lr, b1, b2, eps, qf_lr, policy_lr;
+};
+__device__ __forceinline__ void tail_lite_run(const TailLite& T, float* sh4) {   // one 256-thread workgroup
+  if (T.scal->gather_step != T.scal->step + 1) return;   // nothing pending (first step of a call); workgroup-uniform
+  float lpe = 0.f;
+  for (int r = threadIdx.x; r < T.B; r += 256) lpe += T.logp[r] + T.target_entropy;
+  lpe = block256_sum(lpe, sh4);
+  if (threadIdx.x == 0) {
+    T.scal->alpha_used = T.scal->alpha;
+    T.scal->log_alpha_used = T.scal->log_alpha;
+    T.alpha_grad_slot[0] = -lpe * T.inv_B;
+    T.alpha_grad_slot[1] = 0.f; T.alpha_grad_slot[2] = 0.f; T.alpha_grad_slot[3] = 0.f;
+    sac_finish_dev(T.scal, T.alpha_grad_slot, T.train_alpha, T.lr, T.b1, T.b2, T.eps, T.qf_lr, T.policy_lr, 1);
+  }
 }
 
 template <int ACT> __device__ __forceinline__ float act_fn(float z) {
@@ -213,6 +277,8 @@ struct FwdArgs {
   // tables in device memory, built once per group; blockIdx.y indexes `tasks`
   const struct FwdTaskG* tasks;
   int rt;                  // column-split kernels: consecutive 16-row tiles per workgroup (0 = 1); grid.x = ceil(tiles / rt)
+  const struct TailLite* tail;   // column-split kernels, tail_mode != 0: the launch carries one extra z layer whose (x=0,y=0)
+  int tail_mode;                 //   workgroup runs the deferred tail (1) or advances gather_step (2)
 };
 struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
 // one self-contained record per grid row: the task and its agent's per-launch state side by side, so a workgroup reaches
@@ -696,6 +762,13 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
   static_assert(NCS == NWV, "one k16 chunk of the slice per wave in the head phase");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (!GRP && A.tail_mode && blockIdx.z == CS) {   // the extra z layer of a deferred-tail launch (an extra x column would shift
+    if (blockIdx.x == 0 && blockIdx.y == 0) {      // the tile -> XCD mapping of every other workgroup, see launch_fwd)
+      if (A.tail_mode == 1) tail_lite_run(*A.tail, smem);
+      else if (threadIdx.x == 0) A.tail->scal->gather_step += 1;
+    }
+    return;
+  }
   // GRP: descriptor records in device memory, copied by value at entry (before any store) so that their fields are
   // loaded once with scalar loads; a reference would be re-read with vector loads after every store
   FwdTaskG Rg;
@@ -711,6 +784,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   float* hs = h0 + 16 * LDH;        // [16][LDSL]  this slice of the layer-1 activations
   float* red = hs + 16 * LDSL;      // [4 tiles][NWV][4][64] head partial tiles
   if (blockIdx.x & ((1u << A.xs) - 1u)) return;   // XCD confinement: the dispatcher deals workgroups round-robin to the 8 XCDs
+  if ((int)(blockIdx.x >> A.xs) * (A.rt > 0 ? A.rt : 1) * 16 >= A.rows) return;   // grid.x is padded to a multiple of 8
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int rows = A.rows, cs = blockIdx.z;
   const int RT = A.rt > 0 ? A.rt : 1;   // row tiles this workgroup walks with its weights held in registers
@@ -759,7 +833,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     float v = 0.0f;
     if (gr < rows) {
       if (G.on) {   // fused sample+index (simple_replay_buffer.py:239-293): row gr of the batch is record idx
-        const long long idx = replay_draw(G.seed, scal->step, G.stream, (uint32_t)gr, G.st->size);
+        const long long idx = replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)gr, G.st->size);
         const float* rec = G.records + (size_t)idx * G.rec;
         if (k < T.d0) v = rec[T.g0_off + k];
         else if (act_col) v = rec[T.g1_off + (k - T.d0)];
@@ -989,6 +1063,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
   float* d0s = d1 + 16 * LDH;            // [16][LDSL] this slice of delta_0
   float* dout = d0s + 16 * LDSL;         // [16][ILSX_MAX_NO]
   if (blockIdx.x & ((1u << A.xs) - 1u)) return;
+  if ((int)(blockIdx.x >> A.xs) * 16 >= A.rows) return;   // grid.x is padded to a multiple of 8 (launch_bwd)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int r0 = (blockIdx.x >> A.xs) * 16, rows = A.rows, cs = blockIdx.z;
   const bool lead = cs == 0;
@@ -1373,11 +1448,3 @@ __global__ __launch_bounds__(256) void k_adam_polyak(const AdamArgs A) {
 }
 #endif  // ILSX_KERNEL_IMPL
 
-// block-wide sum of one float per thread (256 threads); result valid in every thread
-__device__ __forceinline__ float block256_sum(float v, float* sh) {
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
-}
