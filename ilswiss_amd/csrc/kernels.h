@@ -1084,6 +1084,19 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
     const int gr = r0 + 4 * g + v;
     h0v[v] = gr < rows ? T.hsave[0][(size_t)gr * H + col0] : 0.0f;
   }
+  // first-layer weights of the dL/dx partial (last phase): they depend on (lane, column) only, so they are requested here with
+  // the other operands instead of as dx_cols dependent loads per row at the end of the kernel
+  constexpr int DXP = 8;
+  float w0dx[DXP][KPL];
+  if (T.dx) {
+    const float* W0 = N.base + N.off_W[0];
+    const int ld0 = N.ld[0];
+#pragma unroll
+    for (int c = 0; c < DXP; ++c)
+#pragma unroll
+      for (int i = 0; i < KPL; ++i)
+        w0dx[c][i] = c < T.dx_cols ? W0[pack_f(cs * SLW + lane + 64 * i, T.dx_col0 + c, ld0)] : 0.0f;
+  }
   // ---- head gradient (every slice recomputes it; the lead slice publishes it for the dW kernel)
   for (int e = tid; e < 16 * NO; e += NTH) {  // only the NO live outputs per row: one pass, loads batched
     const int row = e / NO, j = e - row * NO, gr = r0 + row;
@@ -1163,7 +1176,16 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
       float dv[KPL];
 #pragma unroll
       for (int i = 0; i < KPL; ++i) dv[i] = d0s[row * LDSL + lane + 64 * i];
-      for (int c = 0; c < T.dx_cols; ++c) {
+#pragma unroll
+      for (int c = 0; c < DXP; ++c) {
+        if (c >= T.dx_cols) break;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) s = fmaf(dv[i], w0dx[c][i], s);
+        s = wave_sum(s);
+        if (lane == 0 && gr < rows) T.dx[((size_t)cs * A.part_stride + gr) * T.dx_cols + c] = s;
+      }
+      for (int c = DXP; c < T.dx_cols; ++c) {
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < KPL; ++i) s = fmaf(dv[i], W0[pack_f(cs * SLW + lane + 64 * i, T.dx_col0 + c, ld0)], s);
