@@ -1337,24 +1337,30 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   bool k_ok[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) k_ok[t] = k0 + 16 * t + li < J.NB;
-  for (int rc = r_begin + 16 * wr; rc < rows; rc += 128) {
-    float a[4], b[4][4];
+  // two 128-row steps per trip: both steps' operands are requested before the first MFMA (a 256-row batch is one round of
+  // loads per wave instead of two dependent ones); accumulation order is unchanged
+  for (int rc = r_begin + 16 * wr; rc < rows; rc += 256) {
+    float a[2][4], b[2][4][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int r = rc + 4 * g + s;
-      const bool r_ok = r < rows;
-      a[s] = (r_ok && n_ok) ? J.A[(size_t)r * J.lda + nsub + li] : 0.0f;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        b[t][s] = (r_ok && k_ok[t]) ? J.Bm[(size_t)r * J.ldb + k0 + 16 * t + li] : 0.0f;
-    }
+      for (int s = 0; s < 4; ++s) {
+        const int r = rc + 128 * u + 4 * g + s;
+        const bool r_ok = r < rows;
+        a[u][s] = (r_ok && n_ok) ? J.A[(size_t)r * J.lda + nsub + li] : 0.0f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+        for (int t = 0; t < 4; ++t)
+          b[u][t][s] = (r_ok && k_ok[t]) ? J.Bm[(size_t)r * J.ldb + k0 + 16 * t + li] : 0.0f;
+      }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t < ntk) acc[t] = MFMA16(a[s], b[t][s], acc[t]);
-      bsum += (rc + 4 * g + s < brows) ? a[s] : 0.0f;
-    }
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (t < ntk) acc[t] = MFMA16(a[u][s], b[u][t][s], acc[t]);
+        bsum += (rc + 128 * u + 4 * g + s < brows) ? a[u][s] : 0.0f;
+      }
   }
   if (D.dbg && bx == 5 && tid == 0) D.dbg[1] = __builtin_amdgcn_s_memtime();
   // partial tiles -> LDS
