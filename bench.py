@@ -173,7 +173,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST"):   # the override exercises the RCCL path with one rank (single-GPU box)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
