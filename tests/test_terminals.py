@@ -32,6 +32,13 @@ def test_name_rule():
         T.TerminalFunc.is_terminal(None, None, None)
 
 
+def test_envpool_task_names():
+    from ilswiss_amd.envs.envpool import _model_name
+    assert _model_name("Hopper-v3") == "hopper" and _model_name("Walker2d-v4") == "walker2d" and _model_name("HalfCheetah-v2") == "halfcheetah"
+    with pytest.raises(KeyError):
+        _model_name("Ant-v3")
+
+
 @pytest.mark.gpu
 def test_hip_matches_reference_vectors(ctx):
     from ilswiss_amd.envs.terminals import get_terminal_func
