@@ -366,7 +366,7 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
     // tile from that L2.  (Measured: one extra x column in the two forward launches costs the backward launches that
     // consume their activations 2.9 us each.)  Padding workgroups exit at once.
     dim3 grid(((((tiles + A.rt - 1) / A.rt) + 7) & ~7) << A.xs, A.ntasks, cs), block(4 * H / cs);
-    if (A.tail_mode) { if (A.tasks || !A.tail) ILSX_FAIL(ILSX_ERR_ARG, "deferred tail: single-agent launches only"); grid.z += 1; }
+    if (A.tail_mode) { if (!A.tail || A.tail_n < 1 || A.tail_n > (int)(grid.x * grid.z)) ILSX_FAIL(ILSX_ERR_ARG, "deferred tail: bad record table"); grid.y += 1; }
     if (H == 256 && cs == 4) {
       if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
       else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }

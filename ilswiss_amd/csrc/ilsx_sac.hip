@@ -191,13 +191,13 @@ __global__ __launch_bounds__(256) void k_sac_tail(const StatsArgs S, int train_a
 }
 
 // grouped step: one workgroup per agent
-__global__ __launch_bounds__(256) void k_sac_tail_group(const SacTailItem* items) {
+__global__ __launch_bounds__(256) void k_sac_tail_group(const SacTailItem* items, int deferred) {
   const SacTailItem& T = items[blockIdx.x];
   if (T.S.scal->want_stats) sac_stats_dev(T.S);   // workgroup-uniform
   else sac_alpha_grad_dev(T.S);
   if (threadIdx.x == 0) {
     T.S.scal->want_stats = 0;
-    sac_finish_dev(T.S.scal, T.S.alpha_grad_slot, T.train_alpha, T.lr, T.b1, T.b2, T.eps, T.qf_lr, T.policy_lr, 0);
+    sac_finish_dev(T.S.scal, T.S.alpha_grad_slot, T.train_alpha, T.lr, T.b1, T.b2, T.eps, T.qf_lr, T.policy_lr, deferred);
   }
 }
 
@@ -415,7 +415,7 @@ static int sac_critic_backward(ilsx_sac* s) {
       A.t[2].g0_off = 0; A.t[2].g1_off = s->o; A.t[2].publish = 0;
       A.t[3].g0_off = 0; A.t[3].publish = 0;                              // pi reads obs
     }
-    if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 1; }
+    if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 1; A.tail_n = 1; }
     ILSX_TRY(sac_fwd(s, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
   }
   {  // fwd: TQ1(s',a'), TQ2(s',a')
@@ -425,7 +425,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     sac_q_task(s, A.t[0], W_TQ1, w.s2, w.a2, w.tq1, false, false, 0);
     sac_q_task(s, A.t[1], W_TQ2, w.s2, w.a2, w.tq2, false, false, 1);
     sac_policy_fin(s, A, eps1, s->rng_stream, false, w.a2, w.logp2, w.ppart);
-    if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 2; }
+    if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 2; A.tail_n = 1; }
     ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx with the TD-target loss head
@@ -580,18 +580,25 @@ static int sac_refresh_adam(ilsx_sac* s) {
 // Deferred tail: see TailLite in kernels.h.  Enabled for the duration of one train_from_replay call when the whole step runs on
 // the fused column-split path (no gradient all-reduce between the phases, no XCD confinement); the last step's tail is flushed
 // by the ordinary tail kernel, so no tail is ever pending when the call returns.
+static TailLite sac_tail_lite(ilsx_sac* s, int B) {
+  TailLite t;
+  memset(&t, 0, sizeof t);
+  const int keep = s->B;
+  s->B = B;
+  t.logp = s->ws.logp; t.B = B; t.target_entropy = s->target_entropy; t.inv_B = sac_inv_B(s);
+  s->B = keep;
+  t.alpha_grad_slot = s->G + 2 * s->nq + s->np; t.scal = s->scal;
+  t.train_alpha = s->cfg.train_alpha; t.lr = s->cfg.alpha_lr; t.b1 = s->cfg.beta_1; t.b2 = 0.999f; t.eps = 1e-8f;
+  t.qf_lr = s->cfg.qf_lr; t.policy_lr = s->cfg.policy_lr;
+  return t;
+}
 static int sac_defer_begin(ilsx_sac* s, int B) {
   static const bool off = getenv("ILSX_NO_DEFER_TAIL") != nullptr || getenv("ILSX_NO_FUSE") != nullptr;
   s->defer_tail = false;
   if (off || s->cs <= 1 || s->cfg.grad_world != 1 || s->col) return ILSX_OK;
   if (!s->tail_dev) ILSX_TRY(ctx_alloc(s->ctx, sizeof(TailLite), (void**)&s->tail_dev));
   if (s->tail_B != B) {
-    TailLite t;
-    memset(&t, 0, sizeof t);
-    t.logp = s->ws.logp; t.B = B; t.target_entropy = s->target_entropy; t.inv_B = sac_inv_B(s);
-    t.alpha_grad_slot = s->G + 2 * s->nq + s->np; t.scal = s->scal;
-    t.train_alpha = s->cfg.train_alpha; t.lr = s->cfg.alpha_lr; t.b1 = s->cfg.beta_1; t.b2 = 0.999f; t.eps = 1e-8f;
-    t.qf_lr = s->cfg.qf_lr; t.policy_lr = s->cfg.policy_lr;
+    const TailLite t = sac_tail_lite(s, B);
     HIPCHK(hipMemcpyAsync(s->tail_dev, &t, sizeof t, hipMemcpyHostToDevice, s->ctx->stream));
     HIPCHK(hipStreamSynchronize(s->ctx->stream));   // `t` lives on this stack frame
     s->tail_B = B;
@@ -859,6 +866,8 @@ struct ilsx_sac_group {
     void *tasks = nullptr, *gtiles = nullptr, *tails = nullptr;
   };
   std::vector<Stage> stages;
+  TailLite* tails_lite = nullptr;   // deferred tail: one record per agent (see TailLite, kernels.h)
+  bool defer = false;
 };
 
 template <class T>
@@ -950,24 +959,40 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
       ILSX_TRY(upload_table(g->ctx, items, &st.tails));
     }
   }
+  {
+    std::vector<TailLite> lite;
+    for (int k = 0; k < K; ++k) lite.push_back(sac_tail_lite(g->agents[k], B));
+    if (g->tails_lite) ctx_free(g->ctx, g->tails_lite);
+    g->tails_lite = nullptr;
+    ILSX_TRY(upload_table(g->ctx, lite, (void**)&g->tails_lite));
+  }
   HIPCHK(hipStreamSynchronize(g->ctx->stream));
   g->rbs.assign(rbs, rbs + K);
   g->B = B;
   return ILSX_OK;
 }
 
+static int group_launch_tail(ilsx_sac_group* g, const void* tails, int deferred) {
+  ProfScope ps(g->ctx, ILSX_K_SAC_FINISH);
+  ILSX_LAUNCH(ps, k_sac_tail_group, dim3((unsigned)g->agents.size()), dim3(256), 0, g->ctx->stream, (const SacTailItem*)tails, deferred);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
 static int group_launch_step(ilsx_sac_group* g) {
   ilsx_sac* s0 = g->agents[0];
   const int H = s0->Lq.cfg.hidden, act = s0->Lq.cfg.act, cs = s0->cs;
+  int nfwd = 0;
+  const int K = (int)g->agents.size();
   for (auto& st : g->stages) {
-    if (st.kind == 0) ILSX_TRY(launch_fwd(g->ctx, st.f, H, act, st.KP, cs));
+    if (st.kind == 0) {
+      FwdArgs A = st.f;
+      if (g->defer && nfwd < 2) { A.tail = g->tails_lite; A.tail_mode = nfwd + 1; A.tail_n = K; }   // tail of the previous step / gather_step
+      ++nfwd;
+      ILSX_TRY(launch_fwd(g->ctx, A, H, act, st.KP, cs));
+    }
     else if (st.kind == 1) ILSX_TRY(launch_bwd_dx(g->ctx, st.b, H, act, cs));
     else if (st.kind == 2) { AdamFuse on; memset(&on, 0, sizeof on); on.on = 1; ILSX_TRY(launch_bwd_dw(g->ctx, st.d, g->B, &on)); }
-    else {
-      ProfScope ps(g->ctx, ILSX_K_SAC_FINISH);
-      ILSX_LAUNCH(ps, k_sac_tail_group, dim3((unsigned)g->agents.size()), dim3(256), 0, g->ctx->stream, (const SacTailItem*)st.tails);
-      HIPCHK(hipGetLastError());
-    }
+    else if (!g->defer) ILSX_TRY(group_launch_tail(g, st.tails, 0));
   }
   return ILSX_OK;
 }
@@ -995,6 +1020,7 @@ extern "C" int ilsx_sac_group_destroy(ilsx_sac_group* g) {
   hipSetDevice(g->ctx->device);
   hipStreamSynchronize(g->ctx->stream);
   group_release_tables(g);
+  if (g->tails_lite) ctx_free(g->ctx, g->tails_lite);
   delete g;
   return ILSX_OK;
 }
@@ -1016,7 +1042,11 @@ extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* 
   if (rebuild) ILSX_TRY(group_build(g, rbs, B));
   hipStream_t st = g->ctx->stream;
   static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
+  static const bool no_defer = getenv("ILSX_NO_DEFER_TAIL") != nullptr;
   const bool use_graph = !(no_graph || g->ctx->prof_on);
+  if (n_steps == 0) return ILSX_OK;
+  if (g->defer != !no_defer && g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  g->defer = !no_defer;   // the last step's tail is flushed below: nothing is pending when the call returns
   if (use_graph && !g->graph) {
     hipGraph_t gr = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1034,5 +1064,8 @@ extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* 
     if (use_graph) HIPCHK(hipGraphLaunch(g->graph, st));
     else ILSX_TRY(group_launch_step(g));
   }
+  if (g->defer)
+    for (auto& stg : g->stages)
+      if (stg.kind == 3) ILSX_TRY(group_launch_tail(g, stg.tails, 1));
   return ILSX_OK;
 }

@@ -277,8 +277,8 @@ struct FwdArgs {
   // tables in device memory, built once per group; blockIdx.y indexes `tasks`
   const struct FwdTaskG* tasks;
   int rt;                  // column-split kernels: consecutive 16-row tiles per workgroup (0 = 1); grid.x = ceil(tiles / rt)
-  const struct TailLite* tail;   // column-split kernels, tail_mode != 0: the launch carries one extra z layer whose (x=0,y=0)
-  int tail_mode;                 //   workgroup runs the deferred tail (1) or advances gather_step (2)
+  const struct TailLite* tail;   // column-split kernels, tail_mode != 0: the launch carries one extra y row whose first
+  int tail_mode, tail_n;         //   workgroups (one per agent, tail_n of them) run the deferred tail (1) or advance gather_step (2)
 };
 struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
 // one self-contained record per grid row: the task and its agent's per-launch state side by side, so a workgroup reaches
@@ -762,10 +762,12 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
   static_assert(NCS == NWV, "one k16 chunk of the slice per wave in the head phase");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (!GRP && A.tail_mode && blockIdx.z == CS) {   // the extra z layer of a deferred-tail launch (an extra x column would shift
-    if (blockIdx.x == 0 && blockIdx.y == 0) {      // the tile -> XCD mapping of every other workgroup, see launch_fwd)
-      if (A.tail_mode == 1) tail_lite_run(*A.tail, smem);
-      else if (threadIdx.x == 0) A.tail->scal->gather_step += 1;
+  if (A.tail_mode && (int)blockIdx.y == A.ntasks) {   // the extra y row of a deferred-tail launch (an extra x column would shift
+    const int ag = blockIdx.x + gridDim.x * blockIdx.z;  // the tile -> XCD mapping of every other workgroup, see launch_fwd)
+    if (ag < A.tail_n) {
+      const TailLite& TL = A.tail[ag];             // one record per agent of a grouped launch (tail_n = 1 otherwise)
+      if (A.tail_mode == 1) tail_lite_run(TL, smem);
+      else if (threadIdx.x == 0) TL.scal->gather_step += 1;
     }
     return;
   }
