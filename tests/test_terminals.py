@@ -52,6 +52,14 @@ def test_hip_matches_reference_vectors(ctx):
         # device arrays stay on the device
         dx = ctx.from_numpy(x)
         np.testing.assert_array_equal(f(dx, None, dx, ctx=ctx).numpy().astype(bool)[:, None], done)
+    # argument errors are reported, not executed
+    import ctypes as C
+    from ilswiss_amd import _lib
+    dx = ctx.from_numpy(np.zeros((4, 3), np.float32)); dd = ctx.empty((4,), np.uint8)
+    with pytest.raises(RuntimeError, match="unknown kind"):
+        _lib.check(ctx.lib.ilsx_is_terminal(ctx.h, 9, dx.ptr, 4, 3, dd.ptr))
+    with pytest.raises(RuntimeError, match="observation columns"):
+        _lib.check(ctx.lib.ilsx_is_terminal(ctx.h, 1, dx.ptr, 4, 3, dd.ptr))   # the double pendulum reads 5 columns
     # ragged / degenerate sizes
     assert get_terminal_func("hopper")(np.zeros((0, 11), np.float32), None, np.zeros((0, 11), np.float32), ctx=ctx).shape == (0, 1)
     big = np.random.default_rng(0).normal(1.2, 0.4, (4099, 376)).astype(np.float32)
