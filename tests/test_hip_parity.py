@@ -516,3 +516,51 @@ def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx):
         assert np.isfinite(t2.eval_statistics["QF1 Loss"]) and t2.eval_statistics["QF1 Loss"] > 0
     assert np.abs(solo[0][1].get_params("policy") - solo[1][1].get_params("policy")).max() > 1e-4   # the seeds differ
     grp.close(); c1.close(); c2.close()
+
+
+_DEFER_SCRIPT = r'''
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, ".")
+import ilswiss_amd as ia
+from ilswiss_amd.replay import SimpleReplayBuffer
+o, a, hid, B, N = 11, 3, [256, 256], 256, 5000
+rng = np.random.default_rng(5)
+ctx = ia.Context(0, seed=77)
+rb = SimpleReplayBuffer(8192, o, a, random_seed=3, ctx=ctx)
+rb.add_rows(rng.normal(0, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),
+            rng.normal(0, 1, N).astype(np.float32), rng.random(N) < 0.01, rng.normal(0, 1, (N, o)).astype(np.float32))
+pol = ia.ReparamTanhMultivariateGaussianPolicy(hid, o, a, ctx=ctx, seed=10)
+q1, q2 = ia.FlattenMlp(hid, 1, o + a, ctx=ctx, seed=20), ia.FlattenMlp(hid, 1, o + a, ctx=ctx, seed=30)
+tr = ia.SoftActorCritic(pol, q1, q2, policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+tr.eval_statistics = {}
+tr.train_from_replay(rb, 3, B)            # a call boundary in the middle: the pending tail is flushed and picked up again
+tr.train_from_replay(rb, 1, B)
+tr.eval_statistics = None                  # statistics of the last step
+tr.train_from_replay(rb, 4, B)
+h = hashlib.sha256()
+for name in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+    h.update(np.ascontiguousarray(tr.get_params(name)).tobytes())
+st = tr.eval_statistics
+print(json.dumps(dict(params=h.hexdigest(), log_alpha=repr(tr.log_alpha), qf1=repr(float(st["QF1 Loss"])),
+                      pl=repr(float(st["Policy Loss"])), lp=repr(float(st["Log Pis Mean"])))))
+'''
+
+
+def test_deferred_tail_is_bitwise_the_tail_launch():
+    """Inside train_from_replay the step's tail (alpha Adam, counters, Adam scalars) runs one step late in an extra workgroup of
+    the next step's first launch (TailLite); ILSX_NO_DEFER_TAIL=1 restores the tail launch.  Parameters, log-alpha and the
+    statistics of the last step must agree bit for bit, with and without the hipGraph."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, extra in (("defer", {}), ("plain", {"ILSX_NO_DEFER_TAIL": "1"}), ("defer_nograph", {"ILSX_NO_GRAPH": "1"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _DEFER_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs["defer"] == outs["plain"], outs
+    assert outs["defer"] == outs["defer_nograph"], outs
