@@ -39,6 +39,29 @@ def test_envpool_task_names():
         _model_name("Ant-v3")
 
 
+def test_envpool_adapter_info_conversion_without_a_device():
+    """EnvpoolEnv.step (rlkit/envs/envpool.py:17-27): dict of arrays -> list of dicts, the nested "players" entry dropped;
+    attribute access and len() forward to the pool."""
+    from ilswiss_amd.envs.envpool import EnvpoolEnv
+
+    class FakePool:
+        marker = "pool"
+
+        def __len__(self):
+            return 3
+
+        def step(self, actions, env_id=None):
+            n = len(actions)
+            return (np.zeros((n, 2)), np.ones(n), np.zeros(n, bool),
+                    dict(env_id=np.arange(n) + 5, elapsed_step=np.full(n, 7), players=dict(env_id=np.arange(n))))
+
+    env = object.__new__(EnvpoolEnv)
+    env._envs = FakePool()
+    obs, rew, done, info = env.step(np.zeros((3, 1)))
+    assert isinstance(info, list) and len(info) == 3 and info[2] == dict(env_id=7, elapsed_step=7)
+    assert len(env) == 3 and env.marker == "pool" and env.envs is env._envs
+
+
 @pytest.mark.gpu
 def test_hip_matches_reference_vectors(ctx):
     from ilswiss_amd.envs.terminals import get_terminal_func
