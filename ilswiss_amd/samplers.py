@@ -64,33 +64,63 @@ class VecPathSampler:
         return paths
 
 
-def create_stats_ordered_dict(name, data, stat_prefix=None, always_show_all_stats=False):
-    """rlkit/core/eval_util.py create_stats_ordered_dict: `<prefix> <name> Mean/Std/Max/Min`."""
+def create_stats_ordered_dict(name, data, stat_prefix=None, always_show_all_stats=False, exclude_max_min=False):
+    """rlkit/core/eval_util.py:92-142: `<prefix> <name> Mean/Std/Max/Min`; a Number passes through, a tuple fans out into
+    `<name>_<i>` entries (computed without the prefix-less flags, as there), a list of arrays is concatenated, a size-1 array
+    collapses to its value unless `always_show_all_stats`."""
+    from numbers import Number
     if stat_prefix is not None:
         name = "{} {}".format(stat_prefix, name)
-    if isinstance(data, (list, tuple)) and len(data) and isinstance(data[0], (list, np.ndarray)):
-        data = np.concatenate([np.asarray(d).ravel() for d in data])
-    data = np.asarray(data, dtype=np.float64)
+    if isinstance(data, Number):
+        return OrderedDict({name: data})
+    if len(data) == 0:
+        return OrderedDict()
+    if isinstance(data, tuple):
+        out = OrderedDict()
+        for number, d in enumerate(data):
+            out.update(create_stats_ordered_dict("{0}_{1}".format(name, number), d))
+        return out
+    if isinstance(data, list):
+        try:
+            iter(data[0])
+        except TypeError:
+            pass
+        else:
+            data = np.concatenate([np.asarray(d) for d in data])
+    data = np.asarray(data)
     if data.size == 1 and not always_show_all_stats:
-        return OrderedDict({name: float(data.ravel()[0])})
-    return OrderedDict([(name + " Mean", np.mean(data)), (name + " Std", np.std(data)),
-                        (name + " Max", np.max(data)), (name + " Min", np.min(data))])
+        return OrderedDict({name: float(data.reshape(-1)[0])})
+    stats = OrderedDict([(name + " Mean", np.mean(data)), (name + " Std", np.std(data))])
+    if not exclude_max_min:
+        stats[name + " Max"] = np.max(data)
+        stats[name + " Min"] = np.min(data)
+    return stats
 
 
 def get_generic_path_information(paths, stat_prefix=""):
+    """rlkit/core/eval_util.py:15-81, incl. the `is_success` branch (Success Num / Traj Num / Success Rate)."""
     st = OrderedDict()
-    returns = [float(np.sum(p["rewards"])) for p in paths]
-    rewards = np.concatenate([np.asarray(p["rewards"]).ravel() for p in paths])
+    returns = [np.sum(p["rewards"], axis=0).reshape(-1) for p in paths]     # `sum(path["rewards"])`: one (1,) array per path
+    rewards = np.concatenate([np.asarray(p["rewards"]).reshape(-1) for p in paths])
     st.update(create_stats_ordered_dict("Rewards", rewards, stat_prefix, True))
     st.update(create_stats_ordered_dict("Returns", returns, stat_prefix, True))
+    infos0 = paths[0].get("env_infos")
+    if infos0 is not None and len(infos0) and "is_success" in infos0[0]:
+        acc_sum = [float(np.sum([x["is_success"] for x in p["env_infos"]]) > 0) for p in paths]
+        st.update(create_stats_ordered_dict("Success Num", float(np.sum(acc_sum)), stat_prefix, True))
+        st.update(create_stats_ordered_dict("Traj Num", len(paths), stat_prefix, True))
+        st.update(create_stats_ordered_dict("Success Rate", float(np.sum(acc_sum)) / len(paths), stat_prefix, True))
     st.update(create_stats_ordered_dict("Actions", [np.asarray(p["actions"]) for p in paths], stat_prefix, True))
     st.update(create_stats_ordered_dict("Ep. Len.", np.array([len(p["terminals"]) for p in paths]), stat_prefix, True))
     st["Num Paths"] = len(paths)
     return st
 
 
-def get_average_returns(paths):
-    return float(np.mean([np.sum(p["rewards"]) for p in paths]))
+def get_average_returns(paths, std=False):   # eval_util.py:84-89
+    returns = [float(np.sum(p["rewards"])) for p in paths]
+    if std:
+        return float(np.mean(returns)), float(np.std(returns))
+    return float(np.mean(returns))
 
 
 class DeviceEvalSampler:

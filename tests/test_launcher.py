@@ -30,3 +30,32 @@ def test_shipped_specs_name_existing_scripts_and_expand():
         assert os.path.exists(os.path.join(ROOT, spec["meta_data"]["script_path"])), path
         v = next(variants(spec))
         assert "env_specs" in v and "seed" in v, path
+
+
+def test_path_statistics_match_reference_vectors():
+    """get_generic_path_information / get_average_returns / create_stats_ordered_dict against the reference's own outputs
+    (tests/golden/g15_eval_stats.npz, core/eval_util.py:15-142): same keys in the same order, same values."""
+    import os
+
+    import numpy as np
+    from ilswiss_amd.samplers import create_stats_ordered_dict, get_average_returns, get_generic_path_information
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g15_eval_stats.npz"))
+    for tag, with_success in (("plain", False), ("success", True)):
+        paths = []
+        for i, T in enumerate(g[tag + "_lens"]):
+            infos = [dict(env_id=i, **({"is_success": float((i % 2 == 0) and t == T - 1)} if with_success else {})) for t in range(T)]
+            paths.append(dict(rewards=g[f"{tag}_rew{i}"], actions=g[f"{tag}_act{i}"], terminals=np.zeros((T, 1)), env_infos=infos))
+        st = get_generic_path_information(paths, stat_prefix="Test")
+        assert list(st.keys()) == [str(k) for k in g[tag + "_keys"]]
+        np.testing.assert_allclose([float(np.asarray(v).reshape(-1)[0]) for v in st.values()], g[tag + "_vals"], rtol=1e-12, atol=1e-12)
+        assert abs(get_average_returns(paths) - float(g[tag + "_avg_return"])) < 1e-12
+        np.testing.assert_allclose(get_average_returns(paths, std=True), g[tag + "_avg_return_std"], rtol=1e-12)
+    keys, vals = [], []
+    for d in (create_stats_ordered_dict("A", 3.5), create_stats_ordered_dict("B", np.array([2.0])),
+              create_stats_ordered_dict("C", (np.array([1.0, 2.0, 4.0]), np.array([5.0]))),
+              create_stats_ordered_dict("D", np.array([1.0, 3.0]), stat_prefix="P", exclude_max_min=True),
+              create_stats_ordered_dict("E", [])):
+        for k, v in d.items():
+            keys.append(k); vals.append(float(np.asarray(v).reshape(-1)[0]))
+    assert keys == [str(k) for k in g["corner_keys"]]
+    np.testing.assert_allclose(vals, g["corner_vals"], rtol=1e-12)

@@ -660,8 +660,51 @@ def gen_terminals():
     save("g14_terminals", **out)
 
 
+def gen_eval_stats():
+    """G15: get_generic_path_information / get_average_returns / create_stats_ordered_dict (core/eval_util.py:15-142) on scripted
+    paths of unequal length, with and without the `is_success` env-info branch."""
+    from rlkit.core.eval_util import create_stats_ordered_dict, get_average_returns, get_generic_path_information
+    rng = np.random.default_rng(1515)
+    out = {}
+    for tag, with_success in (("plain", False), ("success", True)):
+        paths, lens = [], (7, 1, 12, 4)
+        for pi_, T in enumerate(lens):
+            infos = [dict(env_id=pi_, **({"is_success": float((pi_ % 2 == 0) and t == T - 1)} if with_success else {})) for t in range(T)]
+            paths.append(dict(observations=rng.normal(0, 1, (T, 5)), actions=rng.uniform(-1, 1, (T, 3)),
+                              rewards=rng.normal(0.5, 1.0, (T, 1)), next_observations=rng.normal(0, 1, (T, 5)),
+                              terminals=np.zeros((T, 1)), env_infos=infos))
+        st = get_generic_path_information(paths, stat_prefix="Test")
+        keys = list(st.keys())
+        out[tag + "_keys"] = np.array(keys)
+        out[tag + "_vals"] = np.array([float(np.asarray(st[k]).reshape(-1)[0]) for k in keys])
+        out[tag + "_avg_return"] = float(get_average_returns(paths))
+        mean_std = get_average_returns(paths, std=True)
+        out[tag + "_avg_return_std"] = np.array([float(mean_std[0]), float(mean_std[1])])
+        out[tag + "_lens"] = np.array(lens)
+        for i, p_ in enumerate(paths):
+            out[f"{tag}_rew{i}"], out[f"{tag}_act{i}"] = p_["rewards"], p_["actions"]
+    # create_stats_ordered_dict corner cases: Number, size-1 array, tuple, exclude_max_min
+    c = OrderedDictFlat()
+    c.add(create_stats_ordered_dict("A", 3.5))
+    c.add(create_stats_ordered_dict("B", np.array([2.0])))
+    c.add(create_stats_ordered_dict("C", (np.array([1.0, 2.0, 4.0]), np.array([5.0]))))
+    c.add(create_stats_ordered_dict("D", np.array([1.0, 3.0]), stat_prefix="P", exclude_max_min=True))
+    c.add(create_stats_ordered_dict("E", []))
+    out["corner_keys"], out["corner_vals"] = np.array(c.keys), np.array(c.vals)
+    save("g15_eval_stats", **out)
+
+
+class OrderedDictFlat:
+    def __init__(self):
+        self.keys, self.vals = [], []
+
+    def add(self, d):
+        for k, v in d.items():
+            self.keys.append(k); self.vals.append(float(np.asarray(v).reshape(-1)[0]))
+
+
 GROUPS = dict(bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
-              rms=gen_rms_actionmap, terminals=gen_terminals)
+              rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)
