@@ -59,3 +59,18 @@ def test_path_statistics_match_reference_vectors():
             keys.append(k); vals.append(float(np.asarray(v).reshape(-1)[0]))
     assert keys == [str(k) for k in g["corner_keys"]]
     np.testing.assert_allclose(vals, g["corner_vals"], rtol=1e-12)
+
+
+def test_variant_grid_matches_reference_vectors():
+    """The variant list (content AND order: exp_id is the position) against launcher_util.build_nested_variant_generator run on
+    the same specs (tests/golden/g16_variants.npz): nested variables, a single-experiment spec, non-alphabetical key order."""
+    import copy
+    import json
+
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g16_variants.npz"))
+    for i in range(4):
+        spec, ref = json.loads(str(g[f"spec{i}"])), json.loads(str(g[f"variants{i}"]))
+        mine = list(variants(copy.deepcopy(spec)))
+        assert [v.pop("exp_id") for v in mine] == list(range(len(ref)))
+        assert mine == ref, i

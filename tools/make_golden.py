@@ -703,8 +703,36 @@ class OrderedDictFlat:
             self.keys.append(k); self.vals.append(float(np.asarray(v).reshape(-1)[0]))
 
 
+def gen_variants():
+    """G16: exp_spec -> variant list (launcher_util.build_nested_variant_generator, the grid run_experiment.py:25-45 walks):
+    order and content of the yielded dicts, as JSON."""
+    import copy
+    import json
+    from rlkit.launchers.launcher_util import build_nested_variant_generator
+    specs = [
+        dict(meta_data=dict(script_path="run_scripts/x.py", exp_name="x", num_workers=2),
+             variables=dict(seed=[0, 1, 2], sac_params=dict(reward_scale=[2.0, 4.0]), adv_irl_params=dict(grad_pen_weight=[8.0])),
+             constants=dict(net_size=256, sac_params=dict(discount=0.99), adv_irl_params=dict(mode="gail2"))),
+        dict(meta_data=dict(script_path="s.py", exp_name="nested", num_workers=1),     # shape of the reference's own self-test (:467-500)
+             variables=dict(hi=dict(one=[1, 2, 3, 4], two=[5678], three=dict(apple=["yummy", "sour", "sweet"])), bye=["omg", "lmfao", "waddup"]),
+             constants=dict(hi=dict(three=dict(constant_banana="potassium"), other_constant_stuff=dict(idk="something funny and cool")),
+                            yoyoyo="I like candy", wow=1e-4)),
+        dict(meta_data=dict(script_path="s.py", exp_name="single", num_workers=1), variables=None,
+             constants=dict(a=1, b=dict(c=2))),
+        dict(meta_data=dict(script_path="s.py", exp_name="zeta_first", num_workers=1),   # key order vs alphabetical order
+             variables=dict(zeta=[1, 2], alpha=dict(mid=[10, 20], aaa=[0.1, 0.2])), constants=dict(alpha=dict(k=0))),
+    ]
+    out = {}
+    for i, spec in enumerate(specs):
+        vs = [copy.deepcopy(v) for v in build_nested_variant_generator(copy.deepcopy(spec))()]
+        out[f"spec{i}"] = json.dumps(spec)
+        out[f"variants{i}"] = json.dumps(vs)
+        print(i, len(vs))
+    save("g16_variants", **out)
+
+
 GROUPS = dict(bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
-              rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats)
+              rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)
