@@ -74,3 +74,29 @@ def test_variant_grid_matches_reference_vectors():
         mine = list(variants(copy.deepcopy(spec)))
         assert [v.pop("exp_id") for v in mine] == list(range(len(ref)))
         assert mine == ref, i
+
+
+def test_progress_csv_matches_the_reference_logger(tmp_path, capsys):
+    """TabularLogger writes the progress.csv rlkit/core/logger.py writes (golden G17): header from the first dump in insertion
+    order, str() of every value, CSV quoting of string cells; a column that first appears later extends the header (our
+    extension, documented in DESIGN.md §6) without disturbing the earlier cells."""
+    import numpy as np
+    from ilswiss_amd.algorithm import TabularLogger
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g17_logger_csv.npz"))
+    rows = [[("Epoch", 0), ("AverageReturn", np.float64(12.5)), ("QF1 Loss", np.float32(0.25)), ("Alpha", 0.2),
+             ("Number of env steps total", 4096), ("Note", "a,b")],
+            [("Epoch", 1), ("AverageReturn", np.float64(1234.56789012345)), ("QF1 Loss", np.float32(1e-7)), ("Alpha", 0.19999),
+             ("Number of env steps total", 8192), ("Note", "x")]]
+    lg = TabularLogger(str(tmp_path))
+    for r in rows:
+        for k, v in r:
+            lg.record_tabular(k, v)
+        lg.dump_tabular()
+    capsys.readouterr()
+    assert open(tmp_path / "progress.csv", newline="").read() == str(g["csv_text"])
+    lg.record_tabular("Epoch", 2); lg.record_tabular("Late Column", 7)
+    lg.dump_tabular()
+    capsys.readouterr()
+    lines = open(tmp_path / "progress.csv", newline="").read().split("\r\n")
+    assert lines[0] == "Epoch,AverageReturn,QF1 Loss,Alpha,Number of env steps total,Note,Late Column"
+    assert lines[1] == '0,12.5,0.25,0.2,4096,"a,b",' and lines[3] == "2,,,,,,7"

@@ -731,8 +731,34 @@ def gen_variants():
     save("g16_variants", **out)
 
 
+def gen_logger_csv():
+    """G17: progress.csv as rlkit/core/logger.py writes it (record_tabular stringifies, header = keys of the first dump in
+    insertion order, :226-227,300-318) for a scripted two-epoch sequence with python / numpy scalars and a string cell."""
+    import contextlib
+    import io
+    import tempfile
+    from rlkit.core import logger
+    logger.set_log_tboard(False)
+    logger._log_wandb = False
+    rows = [[("Epoch", 0), ("AverageReturn", np.float64(12.5)), ("QF1 Loss", np.float32(0.25)), ("Alpha", 0.2),
+             ("Number of env steps total", 4096), ("Note", "a,b")],
+            [("Epoch", 1), ("AverageReturn", np.float64(1234.56789012345)), ("QF1 Loss", np.float32(1e-7)), ("Alpha", 0.19999),
+             ("Number of env steps total", 8192), ("Note", "x")]]
+    path = os.path.join(tempfile.mkdtemp(), "progress.csv")
+    logger.add_tabular_output(path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for r in rows:
+            for k, v in r:
+                logger.record_tabular(k, v)
+            logger.dump_tabular(with_prefix=False, with_timestamp=False)
+    logger.remove_tabular_output(path)
+    text = open(path, newline="").read()
+    print(repr(text))
+    save("g17_logger_csv", csv_text=np.array(text))
+
+
 GROUPS = dict(bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
-              rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants)
+              rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)
