@@ -100,3 +100,20 @@ def test_progress_csv_matches_the_reference_logger(tmp_path, capsys):
     lines = open(tmp_path / "progress.csv", newline="").read().split("\r\n")
     assert lines[0] == "Epoch,AverageReturn,QF1 Loss,Alpha,Number of env steps total,Note,Late Column"
     assert lines[1] == '0,12.5,0.25,0.2,4096,"a,b",' and lines[3] == "2,,,,,,7"
+
+
+def test_log_dir_layout_matches_the_reference(tmp_path, monkeypatch):
+    """logs/<exp-name>/<exp_name>_<Y_m_d_H_M_S>_<id:04d>--s-<seed>/variant.json: directory name at a frozen clock and the
+    variant.json text against launcher_util.create_log_dir + logger.log_variant (golden G18)."""
+    import time
+
+    import numpy as np
+    from ilswiss_amd import algorithm
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g18_logdir.npz"))
+    real_strftime = time.strftime
+    monkeypatch.setattr(algorithm.time, "strftime", lambda fmt, *a: real_strftime(fmt, (2024, 3, 9, 7, 5, 1, 5, 69, 0)))
+    variant = dict(seed=17, exp_id=3, exp_name="sac_hopper_hip", net_size=256, sac_params=dict(reward_scale=1.0, alpha=0.2, policy_lr=3e-4),
+                   env_specs=dict(env_name="hopper", env_kwargs={}, env_num=4096), flags=[True, None, 1e-7], script_path="run_scripts/x.py")
+    d = algorithm.setup_log_dir("sac_hopper_hip", 3, 17, variant, base_dir=str(tmp_path))
+    assert os.path.relpath(d, str(tmp_path)) == str(g["rel_dir"])
+    assert open(os.path.join(d, "variant.json")).read() == str(g["variant_json"])

@@ -757,8 +757,38 @@ def gen_logger_csv():
     save("g17_logger_csv", csv_text=np.array(text))
 
 
+def gen_logdir():
+    """G18: log-directory naming (launcher_util.create_exp_name / create_log_dir :176-206) at a frozen clock and the
+    variant.json text logger.log_variant writes (:379-382) for a nested variant."""
+    import datetime
+    import tempfile
+    from rlkit.core import logger
+    from rlkit.launchers import launcher_util as LU
+
+    class Frozen(datetime.datetime):
+        @classmethod
+        def now(cls, tz=None):
+            return cls(2024, 3, 9, 7, 5, 1, tzinfo=tz)
+
+    real = LU.datetime.datetime
+    LU.datetime.datetime = Frozen
+    try:
+        base = tempfile.mkdtemp()
+        d = LU.create_log_dir("sac_hopper_hip", exp_id=3, seed=17, base_log_dir=base)
+    finally:
+        LU.datetime.datetime = real
+    rel = os.path.relpath(d, base)
+    variant = dict(seed=17, exp_id=3, exp_name="sac_hopper_hip", net_size=256, sac_params=dict(reward_scale=1.0, alpha=0.2, policy_lr=3e-4),
+                   env_specs=dict(env_name="hopper", env_kwargs={}, env_num=4096), flags=[True, None, 1e-7], script_path="run_scripts/x.py")
+    path = os.path.join(d, "variant.json")
+    logger.log_variant(path, variant)
+    text = open(path).read()
+    print(rel); print(text[:200])
+    save("g18_logdir", rel_dir=np.array(rel), variant_json=np.array(text))
+
+
 GROUPS = dict(bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
-              rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv)
+              rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)
