@@ -606,9 +606,8 @@ static int sac_defer_begin(ilsx_sac* s, int B) {
   s->defer_tail = true;
   return ILSX_OK;
 }
-static int sac_flush_tail(ilsx_sac* s) {   // the pending tail of the call's last step (+ its statistics if requested)
-  if (!s->defer_tail) return ILSX_OK;
-  s->defer_tail = false;
+static int sac_flush_tail(ilsx_sac* s, bool deferred) {   // the pending tail of the call's last step (+ its statistics if requested)
+  if (!deferred) return ILSX_OK;
   ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
   ILSX_LAUNCH(ps, k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, sac_stats_args(s), s->cfg.train_alpha,
               s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr, /*deferred=*/1);
@@ -722,11 +721,13 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
   if (n_steps == 0) return stats ? sac_read_stats(s, stats) : ILSX_OK;
   ILSX_TRY(sac_defer_begin(s, B));
+  struct DeferGuard { ilsx_sac* s; ~DeferGuard() { s->defer_tail = false; } } guard{s};   // never left on, whatever path returns
+  const bool deferred = s->defer_tail;
   if (no_graph || s->ctx->prof_on) {
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
       const int rc = sac_sample_and_step(s, rb, B);
-      if (rc != ILSX_OK) { s->defer_tail = false; return rc; }
+      if (rc != ILSX_OK) return rc;
     }
   } else {
     if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail) {
@@ -735,7 +736,7 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
       HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       int rc = sac_sample_and_step(s, rb, B);
       hipError_t e = hipStreamEndCapture(st, &g);
-      if (rc != ILSX_OK) { if (g) hipGraphDestroy(g); s->defer_tail = false; return rc; }
+      if (rc != ILSX_OK) { if (g) hipGraphDestroy(g); return rc; }
       if (e != hipSuccess) ILSX_FAIL(ILSX_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
       e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
@@ -747,7 +748,8 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
       HIPCHK(hipGraphLaunch(s->graph, st));
     }
   }
-  ILSX_TRY(sac_flush_tail(s));
+  s->defer_tail = false;
+  ILSX_TRY(sac_flush_tail(s, deferred));
   if (stats) return sac_read_stats(s, stats);
   return ILSX_OK;
 }
