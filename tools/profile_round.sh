@@ -1,3 +1,5 @@
+# End-of-round evidence on the GPU box (from the repo root): bench line, the other configs, rocprofv3 kernel statistics of the
+# same bench command (ILSX_NO_GRAPH=1: rocprofv3 does not see graph launches here) -> gpurun_out/prof_e/; copy into profiles/.
 set -u
 ROOT=$(pwd)
 mkdir -p gpurun_out/prof_e

@@ -1,3 +1,8 @@
+"""Per-launch durations of the SAC step from a rocprofv3 kernel trace of tools/tail_trace.py (median over the steady-state steps).
+
+    cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/tt_<tag> -- python $REPO/tools/tail_trace.py
+    python tools/trace_per_launch.py <tag>        # F = forward, B = backward, D = weight gradients (+Adam), T = tail
+"""
 import csv, glob, sys, statistics
 mode = sys.argv[1]
 f = glob.glob(f"/root/repo/gpurun_out/tt_{mode}/runc/*_kernel_trace.csv")[0]
