@@ -219,6 +219,8 @@ PROTOTYPES = {
     "ilsx_sac_get_adam": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, c_i64p]),
     "ilsx_sac_set_adam": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, C.c_int64]),
     "ilsx_sac_get_alpha_opt": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64p, C.POINTER(C.c_uint64)]),
+    "ilsx_sac_debug_batch": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ilsx_sac_debug_last_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "ilsx_sac_set_alpha_opt": (C.c_int, [vp, C.c_double, C.c_double, C.c_int64, C.c_uint64]),
 }
 

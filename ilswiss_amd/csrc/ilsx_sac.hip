@@ -851,6 +851,61 @@ extern "C" int ilsx_sac_set_alpha_opt(ilsx_sac* s, double m, double v, int64_t t
   return ILSX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ parity aids
+// The fused path draws its rows inside k_mlp2_fwd_split (GatherSpec) and its noise inside the policy-finish prologue.  These two
+// entry points let a test rebuild exactly those inputs with INDEPENDENT kernels (k_replay_sample, k_debug_eps) and feed them to
+// the oracle (tests/test_fused_parity.py).
+__global__ __launch_bounds__(256) void k_debug_eps(uint64_t seed, uint64_t step, uint32_t stream, int B, int a, float* out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * a) return;
+  const int r = e / a, j = e - r * a;
+  float z4[4];
+  philox_normal4(seed, step, stream, (uint32_t)r, (uint32_t)(j >> 2), z4);
+  const int q = j & 3;
+  out[e] = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
+}
+
+extern "C" int ilsx_sac_debug_batch(ilsx_sac* s, ilsx_replay* rb, uint64_t step, int B, float* obs, float* act, float* rew,
+                                    float* done, float* nobs, float* eps_next, float* eps_cur, int64_t* idx) {
+  if (!s || !rb || B < 1 || B > s->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_debug_batch: bad argument");
+  if (rb->o != s->o || rb->a != s->a) ILSX_FAIL(ILSX_ERR_ARG, "replay dims do not match the agent");
+  if (rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "replay buffer is empty");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  hipStream_t st = s->ctx->stream;
+  const size_t o = s->o, a = s->a, b = B;
+  // scratch for the outputs the caller did not ask for (the sample kernel writes all five keys)
+  float* tmp = nullptr;
+  ILSX_TRY(ctx_alloc(s->ctx, (b * (2 * o + a + 2)) * sizeof(float), (void**)&tmp, false));
+  float* t_obs = tmp; float* t_act = t_obs + b * o; float* t_rew = t_act + b * a; float* t_done = t_rew + b; float* t_nobs = t_done + b;
+  int rc = replay_launch_sample(rb, B, nullptr, nullptr, step, obs ? obs : t_obs, act ? act : t_act, rew ? rew : t_rew,
+                                done ? done : t_done, nobs ? nobs : t_nobs, idx);
+  if (rc == ILSX_OK) {
+    const unsigned blocks = (unsigned)((b * a + 255) / 256);
+    if (eps_next) hipLaunchKernelGGL(k_debug_eps, dim3(blocks), dim3(256), 0, st, s->ctx->seed, step, s->rng_stream, B, (int)a, eps_next);
+    if (eps_cur) hipLaunchKernelGGL(k_debug_eps, dim3(blocks), dim3(256), 0, st, s->ctx->seed, step, s->rng_stream + 1, B, (int)a, eps_cur);
+    if (hipGetLastError() != hipSuccess) rc = ILSX_ERR_HIP;
+  }
+  const int rf = ctx_free(s->ctx, tmp);   // synchronises the stream
+  return rc != ILSX_OK ? rc : rf;
+}
+
+extern "C" int ilsx_sac_debug_last_batch(ilsx_sac* s, int B, float* obs, float* act, float* rew, float* done, float* nobs,
+                                         float* eps_cur) {
+  if (!s || B < 1 || B > s->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_debug_last_batch: bad argument");
+  HIPCHK(hipSetDevice(s->ctx->device));
+  hipStream_t st = s->ctx->stream;
+  const SacWs& w = s->ws;
+  const size_t o = s->o, a = s->a, b = B;
+  if (obs) HIPCHK(hipMemcpyAsync(obs, w.s, b * o * 4, hipMemcpyDeviceToDevice, st));
+  if (act) HIPCHK(hipMemcpyAsync(act, w.a, b * a * 4, hipMemcpyDeviceToDevice, st));
+  if (rew) HIPCHK(hipMemcpyAsync(rew, w.r, b * 4, hipMemcpyDeviceToDevice, st));
+  if (done) HIPCHK(hipMemcpyAsync(done, w.d, b * 4, hipMemcpyDeviceToDevice, st));
+  if (nobs) HIPCHK(hipMemcpyAsync(nobs, w.s2, b * o * 4, hipMemcpyDeviceToDevice, st));
+  if (eps_cur) HIPCHK(hipMemcpyAsync(eps_cur, w.epss, b * a * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return ILSX_OK;
+}
+
 // ================================================================================================ grouped agents
 // "within a GPU, the co-resident seeds are batched as grouped GEMMs (weights differ per seed)".  K independent
 // agents of identical shape step in lock-step: every stage of the fused step is ONE launch whose grid carries all agents'

@@ -198,6 +198,34 @@ class SoftActorCritic(Trainer):
         _lib.check(self.ctx.lib.ilsx_sac_set_alpha_opt(self.h, o["exp_avg"], o["exp_avg_sq"], int(o["step"]),
                                                        int(o["rng_step"])))
 
+    # ---- parity aids (tests): the inputs of a fused step, rebuilt by independent kernels
+    @property
+    def rng_step(self):
+        """Philox counter of the NEXT gradient step (== gradient steps taken so far for a fresh agent)."""
+        r = C.c_uint64()
+        _lib.check(self.ctx.lib.ilsx_sac_get_alpha_opt(self.h, None, None, None, C.byref(r)))
+        return r.value
+
+    def debug_batch(self, replay_buffer, step, batch_size):
+        """Batch dict + (eps_next, eps_cur, idx) that gradient step number `step` of train_from_replay(replay_buffer, ...) uses."""
+        ctx, B, o, a = self.ctx, int(batch_size), self.policy.obs_dim, self.policy.action_dim
+        bufs = [ctx.empty((B, o)), ctx.empty((B, a)), ctx.empty((B,)), ctx.empty((B,)), ctx.empty((B, o)),
+                ctx.empty((B, a)), ctx.empty((B, a)), ctx.empty((B,), np.int64)]
+        _lib.check(ctx.lib.ilsx_sac_debug_batch(self.h, replay_buffer.h, C.c_uint64(int(step)), B, *[b.ptr for b in bufs]))
+        obs, act, rew, done, nobs, e1, e2, idx = [b.numpy() for b in bufs]
+        batch = dict(observations=obs, actions=act, rewards=rew.reshape(B, 1), terminals=done.reshape(B, 1),
+                     next_observations=nobs)
+        return batch, e1, e2, idx
+
+    def debug_last_batch(self, batch_size):
+        """Rows the last fused step gathered (as published by its first launch) and the eps_cur its policy head consumed."""
+        ctx, B, o, a = self.ctx, int(batch_size), self.policy.obs_dim, self.policy.action_dim
+        bufs = [ctx.empty((B, o)), ctx.empty((B, a)), ctx.empty((B,)), ctx.empty((B,)), ctx.empty((B, o)), ctx.empty((B, a))]
+        _lib.check(ctx.lib.ilsx_sac_debug_last_batch(self.h, B, *[b.ptr for b in bufs]))
+        obs, act, rew, done, nobs, e2 = [b.numpy() for b in bufs]
+        return dict(observations=obs, actions=act, rewards=rew.reshape(B, 1), terminals=done.reshape(B, 1),
+                    next_observations=nobs), e2
+
     # ---- split-run phases (multi-GPU, SURVEY §8e)
     def set_batch(self, batch, eps_next=None, eps_cur=None):
         ctx, keep = self.ctx, []

@@ -209,6 +209,20 @@ int ilsx_sac_set_adam(ilsx_sac* sac, int which, const float* m_host, const float
 int ilsx_sac_get_alpha_opt(ilsx_sac* sac, double* m, double* v, int64_t* t, uint64_t* rng_step);
 int ilsx_sac_set_alpha_opt(ilsx_sac* sac, double m, double v, int64_t t, uint64_t rng_step);
 
+/* Parity aids for the fused path (tests only; nothing in the training path calls them).
+ * ilsx_sac_debug_batch re-derives, with the STANDALONE sample kernel (the one behind ilsx_replay_sample) and a
+ * standalone Philox kernel, the batch rows and the two N(0,1) draws that gradient step number `step` of this agent
+ * takes when it samples from `rb` inside ilsx_sac_train_from_replay / ilsx_sac_group_train_from_replay (`step` = the
+ * agent's Philox step counter when that step runs: 0 for a fresh agent's first step; ilsx_sac_get_alpha_opt's
+ * rng_step is the counter of the NEXT step).  All outputs are device pointers: obs[B,o] act[B,a] rew[B] done[B]
+ * nobs[B,o] eps_next[B,a] eps_cur[B,a] idx int64[B]; every one nullable.
+ * ilsx_sac_debug_last_batch copies what the LAST step actually used out of the agent's workspace: the rows its first
+ * forward launch gathered and published (obs/act/rew/done/nobs) and the eps_cur its policy head consumed. */
+int ilsx_sac_debug_batch(ilsx_sac* sac, ilsx_replay* rb, uint64_t step, int B, float* obs, float* act, float* rew,
+                         float* done, float* nobs, float* eps_next, float* eps_cur, int64_t* idx);
+int ilsx_sac_debug_last_batch(ilsx_sac* sac, int B, float* obs, float* act, float* rew, float* done, float* nobs,
+                              float* eps_cur);
+
 /* ---------------------------------------------------------------- adversarial-IRL discriminator
  * Replaces rlkit/torch/algorithms/adv_irl/disc_models/simple_disc_models.py:8-48 (MLPDisc, use_bn=False),
  * AdvIRL._do_reward_training (adv_irl.py:133-216: BCE-with-logits on [expert; policy] + WGAN-GP gradient
