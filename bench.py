@@ -11,7 +11,12 @@ num_train_steps_per_train_call = 1000 SAC gradient steps (on-device replay sampl
 (Sample Time / Train Time, base_algorithm.py:284-290,329-343).
 
 N > 1: one process per GPU, independent replicas (seeds shard with no data-path collective,
-run_experiment.py:57-78) -> weak scaling; torch.distributed (RCCL) only for the barrier + max-time.
+run_experiment.py:57-78) -> weak scaling; torch.distributed (RCCL) only for the barrier + max-time.  The ranks come
+either from the launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the env) or, when `--gpus N` is given WITHOUT a RANK in the env, from bench.py itself: it
+spawns N copies of itself, one per GPU, on 127.0.0.1 and relays rank 0's JSON line.  With N > 1 the line also carries
+`split_run`: ONE run split over the N GPUs (B/N rows per rank, RCCL all-reduce of the gradient arena on the library's
+stream between backward and update) — the only leg with a data-path collective, never `value`.
 """
 import argparse
 import json
@@ -28,13 +33,21 @@ O, A, H, B = 11, 3, 256, 256          # Hopper-v2 obs/act, hidden width, batch (
 N_ENV = 4096
 GRAD_PER_CALL = 1000                  # sac_hopper.yaml:20
 REPLAY_CAP = 1_000_000                # sac_hopper.yaml:28
-SAC_KW = dict(reward_scale=5.0, discount=0.99, soft_target_tau=0.005, policy_lr=3e-4, qf_lr=3e-4, alpha=0.2,
+SAC_KW = dict(reward_scale=1.0, discount=0.99, soft_target_tau=0.005, policy_lr=3e-4, qf_lr=3e-4, alpha=0.2,
               policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3)  # sac_hopper.yaml:36-47
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
 
 
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_pmc_summary.json")
+def _latest_pmc_summary():
+    """Newest committed counter summary (profiles/rNN_*_pmc_summary.json, written by tools/profile_round.sh); the bench line
+    names the file it read so that a stale one is visible."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_summary.json")))
+    return files[-1] if files else None
+
+
+PMC_SUMMARY = _latest_pmc_summary()
 PMC_NAMES = {0: ("k_mlp2_fwd_split", "k_mlp_fwd"), 1: ("k_mlp2_bwd_split", "k_mlp_bwd_dx"), 2: ("k_mlp_bwd_dw",),
              6: ("k_replay_sample_many",)}
 
@@ -46,7 +59,7 @@ def pmc_traffic(kid):
     try:
         with open(PMC_SUMMARY) as f:
             d = json.load(f)
-    except OSError:
+    except (OSError, TypeError):
         return None
     for name in PMC_NAMES.get(kid, ()):
         k = d.get(name)
@@ -161,6 +174,116 @@ def cpu_baseline(budget_s=12.0):
                        "oracle/sac_alpha.py numpy fp32")
 
 
+def spawn_ranks(n, argv):
+    """`--gpus N` without a launcher: N copies of this script, one per GPU (RANK = LOCAL_RANK = i), rendezvous on 127.0.0.1.
+    Rank 0's stdout is relayed; a failing rank fails the run."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=r == 0 or None))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out or "")
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench.py: ranks exited with {rcs}")
+    return out
+
+
+class Ranks:
+    """Process-group plumbing shared by the real run and the CPU dry run (tests/test_bench_spawn.py): backend "nccl" (= RCCL)
+    on GPUs, "gloo" for --dry-run."""
+
+    def __init__(self, dry_run):
+        self.rank = int(os.environ.get("RANK", 0))
+        self.local = int(os.environ.get("LOCAL_RANK", 0))
+        self.world = int(os.environ.get("WORLD_SIZE", 1))
+        self.dist, self.dry = None, dry_run
+        if self.world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST"):   # the override exercises the path with one rank
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
+            import torch
+            import torch.distributed as dist
+            if dry_run:
+                dist.init_process_group("gloo")
+            else:
+                torch.cuda.set_device(self.local)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+            self.dist = dist
+
+    def barrier(self, ctx=None):
+        if ctx is not None:
+            ctx.sync()
+        if self.dist is not None:
+            if not self.dry:
+                import torch
+                torch.cuda.synchronize()
+            self.dist.barrier()
+
+    def max_over_ranks(self, values):
+        if self.dist is None:
+            return list(values)
+        import torch
+        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if self.dry else "cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def split_run_leg(R, n=400):
+    """ONE SAC run split over the world's GPUs: every rank a full replica, B/G rows per rank from its own replay
+    shard, gradient arena all-reduced by RCCL on the library's stream (critics, then actor | alpha).  G = 1 (single-GPU box with
+    ILSX_BENCH_FORCE_DIST): the same code path on a one-rank communicator (ILSX_SPLIT_FORCE)."""
+    import ilswiss_amd as ia
+    from ilswiss_amd.parallel import SplitRunStep
+    G = R.world
+    if G == 1:
+        os.environ["ILSX_SPLIT_FORCE"] = "1"
+    if B % G:
+        return None
+    ctx = ia.Context(R.local, seed=555)          # identical parameter init on every rank (seeded nets below)
+    hid = [H, H]
+    tr = ia.SoftActorCritic(ia.ReparamTanhMultivariateGaussianPolicy(hid, O, A, ctx=ctx, seed=1),
+                            ia.FlattenMlp(hid, 1, O + A, ctx=ctx, seed=2), ia.FlattenMlp(hid, 1, O + A, ctx=ctx, seed=3),
+                            max_batch=B // G, grad_world=G, **SAC_KW)
+    tr.eval_statistics = {}
+    shard = REPLAY_CAP // G
+    rb = ia.SimpleReplayBuffer(shard, O, A, random_seed=100 + R.rank, ctx=ctx)
+    rng = np.random.default_rng(100 + R.rank)
+    left = shard
+    while left > 0:
+        k = min(left, 250_000)
+        rb.add_rows(*synth_rows(rng, k))
+        left -= k
+    step = SplitRunStep(tr)
+    step.train_from_replay(rb, 50, B // G)
+    R.barrier(ctx)
+    t0 = time.perf_counter()
+    step.train_from_replay(rb, n, B // G)
+    R.barrier(ctx)
+    dt = R.max_over_ranks([time.perf_counter() - t0])[0]
+    # every replica must have taken identical optimiser steps
+    chk = float(np.abs(tr.get_params("qf1")).sum())
+    lo, hi = -R.max_over_ranks([-chk])[0], R.max_over_ranks([chk])[0]
+    ctx.close()
+    return dict(ranks=G, local_batch=B // G, grad_steps_per_s=n / dt, us_per_step=1e6 * dt / n, replicas_identical=bool(lo == hi),
+                allreduce_bytes_per_step=4 * (tr.qf1.num_params * 2 + tr.policy.num_params + 4),
+                collective="ncclAllReduce(float32, sum) x2 per step on the ctx stream (librccl via dlopen)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,16 +291,29 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seeds", action="store_true", help="skip the co-resident seeds leg")
+    ap.add_argument("--no-split-run", action="store_true", help="skip the split-run (RCCL all-reduce) leg at N > 1")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU plumbing check (tests): spawn / rendezvous (gloo) / barrier / max-over-ranks / one JSON line, no GPU work")
     args = ap.parse_args()
-    rank = int(os.environ.get("RANK", 0))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    dist = None
-    if world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST"):   # the override exercises the RCCL path with one rank (single-GPU box)
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])
+        return None
+    R = Ranks(args.dry_run)
+    rank, local, world = R.rank, R.local, R.world
+    if world != args.gpus and not os.environ.get("ILSX_BENCH_FORCE_DIST"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        R.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.001 * (1 + rank))     # rank r is slower: the max must pick the slowest
+        R.barrier()
+        dt = R.max_over_ranks([time.perf_counter() - t0])[0]
+        if rank == 0:
+            print(json.dumps(dict(metric="dry-run", dry_run=True, n_gpus=world, steps=args.steps, warmup=args.warmup,
+                                  ms_per_step=1e3 * dt / args.steps, value=world * args.steps / dt)))
+        R.close()
+        return None
 
     import ctypes as C
 
@@ -205,16 +341,9 @@ def main():
         ro.vec_step()                                    # 4096 env-steps
         tr.train_from_replay(rb, GRAD_PER_CALL, B)       # 1000 grad steps
 
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    R.barrier(ctx)
     t0 = time.perf_counter()
     t_sample = t_train = 0.0
     for _ in range(args.steps):
@@ -227,13 +356,12 @@ def main():
         a2 = time.perf_counter()
         t_sample += a1 - a0
         t_train += a2 - a1
-    barrier()
+    R.barrier(ctx)
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt, t_sample, t_train], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, t_sample, t_train = [float(x) for x in tt.tolist()]
+    dt, t_sample, t_train = R.max_over_ranks([dt, t_sample, t_train])
+    split = None
+    if (world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST")) and not args.no_split_run:
+        split = split_run_leg(R)
 
     result = None
     if rank == 0:
@@ -258,7 +386,8 @@ def main():
         avg_s = ms * 1e-3 / nl
         achieved = flops_per_launch / avg_s / 1e12
         roofline = dict(bound="mfma", kernel=name, achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=pmc_traffic(dom), avg_launch_us=avg_s * 1e6,
+                        frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=pmc_traffic(dom),
+                        traffic_source=os.path.relpath(PMC_SUMMARY, ROOT) if PMC_SUMMARY else None, avg_launch_us=avg_s * 1e6,
                         algorithmic_flop_per_launch=flops_per_launch,
                         kernel_ms_per_grad_step={prof[k][0]: prof[k][2] / 200.0 for k in prof})
         # ---- HBM-bound kernel: replay sample (4096 batches x 256 rows per launch)
@@ -289,14 +418,14 @@ def main():
                         parallelism=f"{world} independent replicas (seed sharding, no collective)"),
             env_steps_per_s=env_total / dt, env_steps_per_s_sample_phase=env_total / t_sample,
             grad_steps_per_s_train_phase=grad_total / t_train, roofline=roofline, roofline_replay=roofline_replay)
+        if split is not None:
+            result["split_run"] = split
         if world == 1 and not args.no_seeds:
             result["co_resident_seeds"] = co_resident_seeds()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.close()
     ctx.close()
     return result
 

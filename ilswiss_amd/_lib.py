@@ -101,6 +101,10 @@ class DiscCfg(C.Structure):  # ilsx_disc_cfg
                 ("disc_momentum", C.c_float), ("grad_pen_weight", C.c_float), ("max_batch", C.c_int32)]
 
 
+class OptMeta(C.Structure):  # ilsx_opt_meta
+    _fields_ = [("t", C.c_int64), ("rng_step", C.c_uint64), ("n_train_steps", C.c_int64)]
+
+
 class DiscStats(C.Structure):
     _fields_ = [("ce_loss", C.c_float), ("grad_pen", C.c_float), ("accuracy", C.c_float)]
 
@@ -175,6 +179,21 @@ PROTOTYPES = {
     "ilsx_ctx_free": (C.c_int, [vp, vp]),
     "ilsx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ilsx_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "ilsx_comm_unique_id": (C.c_int, [vp]),
+    "ilsx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "ilsx_comm_destroy": (C.c_int, [vp]),
+    "ilsx_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ilsx_comm_allreduce_sum": (C.c_int, [vp, vp, C.c_size_t]),
+    "ilsx_td3_get_opt": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_td3_set_opt": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_sacv_get_opt": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_sacv_set_opt": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_bc_get_opt": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_bc_set_opt": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_ppo_get_opt": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_ppo_set_opt": (C.c_int, [vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_disc_get_opt": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
+    "ilsx_disc_set_opt": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(OptMeta)]),
     "ilsx_prof_enable": (C.c_int, [vp, C.c_int]),
     "ilsx_prof_reset": (C.c_int, [vp]),
     "ilsx_prof_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),

@@ -186,10 +186,19 @@ class AdvIRLTrainer:
     def networks(self):
         return self.policy_trainer.networks + [self.disc]
 
-    def get_snapshot(self):  # adv_irl.py:316-326, as plain arrays
+    def get_snapshot(self):  # adv_irl.py:316-326, as plain arrays (+ disc_optimizer's Adam state)
+        from .snapshot import get_opt
         snap = dict(self.policy_trainer.get_snapshot())
         snap["disc"] = self.disc.get_flat_params()
+        snap["disc_optimizer"] = get_opt(self.disc.ctx.lib, "disc", self.disc.h, snap["disc"].size)
         return snap
+
+    def load_snapshot(self, snap):
+        from .snapshot import set_opt
+        self.policy_trainer.load_snapshot(snap)
+        self.disc.set_flat_params(snap["disc"])
+        if "disc_optimizer" in snap:
+            set_opt(self.disc.ctx.lib, "disc", self.disc.h, snap["disc_optimizer"])
 
     def get_eval_statistics(self):
         st = OrderedDict()

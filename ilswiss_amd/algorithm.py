@@ -29,6 +29,11 @@ class TabularLogger:
         self.log_dir, self.row, self._header = log_dir, OrderedDict(), None
         if log_dir:
             os.makedirs(log_dir, exist_ok=True)
+            path = os.path.join(log_dir, "progress.csv")
+            if os.path.exists(path):   # resumed run (load_params.load_path == log dir): keep the earlier epochs' rows
+                with open(path, newline="") as f:
+                    rd = csv.DictReader(f)
+                    self._header, self._rows = list(rd.fieldnames or []), [dict(r) for r in rd]
 
     def record_tabular(self, k, v):
         self.row[k] = v
@@ -82,6 +87,7 @@ class DeviceRLAlgorithm:
         self.num_steps_per_eval, self.max_path_length = num_steps_per_eval, max_path_length
         self.min_steps_before_training, self.batch_size = min_steps_before_training, batch_size
         self.freq_saving, self.save_best, self.best_key = freq_saving, save_best, best_key
+        self.save_replay_buffer = bool(save_replay_buffer)
         self.env_num = len(training_env)
         if replay_buffer is None and not self.on_policy:
             seed = int(np.random.randint(10000))  # base_algorithm.py:118-120
@@ -92,7 +98,7 @@ class DeviceRLAlgorithm:
         sampler_cls = DeviceEvalSampler if (eval_on_device and hasattr(eval_env, "h")) else VecPathSampler
         self.eval_sampler = sampler_cls(eval_env, eval_policy, num_steps_per_eval, max_path_length)
         self.logger = TabularLogger(log_dir)
-        self._n_env_steps_total = self._n_train_steps_total = self._n_prev_train_env_steps = 0
+        self._n_env_steps_total = self._n_train_steps_total = self._n_prev_train_env_steps = self._n_grad_steps_total = 0
         self._n_rollouts_total, self.best_statistic_so_far = 0, -np.inf
         self._t_sample = self._t_train = self._t_eval = 0.0
 
@@ -114,7 +120,8 @@ class DeviceRLAlgorithm:
             while steps < self.num_env_steps_per_epoch:
                 steps += self.trainer.train_from_rollout(self.training_env, horizon, self.max_path_length,
                                                          bootstrap=self.bootstrap_open_segments)
-                self._n_train_steps_total += self.num_train_steps_per_train_call
+                self._n_train_steps_total += 1
+                self._n_grad_steps_total += self.num_train_steps_per_train_call
             ctx.sync()
             self._n_env_steps_total += steps
             self._t_train = time.perf_counter() - t_epoch   # rollout + update are one device pipeline here
@@ -146,10 +153,11 @@ class DeviceRLAlgorithm:
                     ctx.sync()
                     t1 = time.perf_counter()
                     self._t_sample += t1 - t0
-                    self._n_prev_train_env_steps = self._n_env_steps_total
-                    if self._can_train():
+                    if self._can_train():   # _try_to_train (base_algorithm.py:293-299): the gate only advances when training ran
+                        self._n_prev_train_env_steps = self._n_env_steps_total
                         self.trainer.train_from_replay(self.replay_buffer, self.num_train_steps_per_train_call, self.batch_size)
-                        self._n_train_steps_total += self.num_train_steps_per_train_call
+                        self._n_train_steps_total += 1                                   # the reference counts CALLS here (:298)
+                        self._n_grad_steps_total += self.num_train_steps_per_train_call
                         ctx.sync()
                     self._t_train += time.perf_counter() - t1
                 else:
@@ -183,8 +191,8 @@ class DeviceRLAlgorithm:
         for k, v in st.items():
             lg.record_tabular(k, float(np.mean(v)))
         # base_algorithm.py:322-343
-        lg.record_tabular("Number of train calls total", self._n_train_steps_total // max(self.num_train_steps_per_train_call, 1))
-        lg.record_tabular("Number of train steps total", self._n_train_steps_total)
+        lg.record_tabular("Number of train calls total", self._n_train_steps_total)   # the reference's column and counter
+        lg.record_tabular("Number of gradient steps total", self._n_grad_steps_total)  # ours: calls x steps per call
         lg.record_tabular("Number of env steps total", self._n_env_steps_total)
         lg.record_tabular("Number of rollouts total", self._n_rollouts_total)
         lg.record_tabular("Train Time (s)", self._t_train)
@@ -196,14 +204,46 @@ class DeviceRLAlgorithm:
         lg.dump_tabular()
         snap = dict(epoch=epoch, statistics=dict(st))
         if self.freq_saving and epoch % self.freq_saving == 0:
-            lg.save("params.pkl", dict(snap, **self.trainer.get_snapshot()))
+            lg.save("params.pkl", dict(snap, **self.get_epoch_snapshot()))
         if st[self.best_key] > self.best_statistic_so_far:
             self.best_statistic_so_far = st[self.best_key]
             if self.save_best:
-                lg.save("best.pkl", dict(snap, **self.trainer.get_snapshot()))
-        lg.save("extra_data.pkl", dict(_n_env_steps_total=self._n_env_steps_total,
-                                       _n_train_steps_total=self._n_train_steps_total, epoch=epoch))
+                lg.save("best.pkl", dict(snap, **self.get_epoch_snapshot()))
+        lg.save("extra_data.pkl", self.get_extra_data_to_save(epoch))
         return st
+
+    # ---- snapshots / resume (base_algorithm.py:560-597; logger.load_from_file -> ilswiss_amd/snapshot.py)
+    def get_epoch_snapshot(self):
+        """trainer.get_snapshot() + the training env's running observation statistics when it normalises (a PPO policy only
+        makes sense on the observations it was trained on; the reference pickles the env's obs_rms with the algorithm)."""
+        snap = dict(self.trainer.get_snapshot())
+        rms = getattr(self.training_env, "obs_rms", None)
+        if rms is not None:
+            m, v, c = rms._get()
+            snap["obs_rms"] = dict(mean=m, var=v, count=c)
+        return snap
+
+    def load_snapshot(self, snap):
+        self.trainer.load_snapshot(snap)
+        if "obs_rms" in snap:
+            for env in (self.training_env, self.eval_env):
+                if getattr(env, "obs_rms", None) is not None:
+                    env.obs_rms.set(snap["obs_rms"]["mean"], snap["obs_rms"]["var"], snap["obs_rms"]["count"])
+
+    def get_extra_data_to_save(self, epoch):
+        d = dict(epoch=epoch, _n_env_steps_total=self._n_env_steps_total, _n_train_steps_total=self._n_train_steps_total,
+                 _n_grad_steps_total=self._n_grad_steps_total, _n_rollouts_total=self._n_rollouts_total,
+                 _n_prev_train_env_steps=self._n_prev_train_env_steps, best_statistic_so_far=self.best_statistic_so_far)
+        if self.save_replay_buffer and self.replay_buffer is not None:   # base_algorithm.py:574-576
+            from .snapshot import dump_replay
+            d["replay_buffer"] = dump_replay(self.replay_buffer)
+        return d
+
+    def set_steps(self, extra):   # base_algorithm.py:591-597
+        for k in ("_n_env_steps_total", "_n_train_steps_total", "_n_grad_steps_total", "_n_rollouts_total",
+                  "_n_prev_train_env_steps", "best_statistic_so_far"):
+            if k in extra:
+                setattr(self, k, extra[k])
 
 
 def setup_log_dir(exp_name, exp_id, seed, variant, base_dir="logs"):

@@ -61,8 +61,16 @@ class BC(Trainer):
     def networks(self):
         return [self.policy]
 
-    def get_snapshot(self):
-        return dict(policy=self.policy.get_flat_params())
+    def get_snapshot(self):   # bc.py:108-113 (+ the optimiser's Adam state)
+        from .snapshot import get_opt
+        flat = self.policy.get_flat_params()
+        return dict(policy=flat, optimizer=get_opt(self.ctx.lib, "bc", self.h, flat.size))
+
+    def load_snapshot(self, snap):
+        from .snapshot import set_opt
+        self.policy.set_flat_params(snap["policy"])
+        if "optimizer" in snap:
+            set_opt(self.ctx.lib, "bc", self.h, snap["optimizer"])
 
 
 class DAgger(BC):

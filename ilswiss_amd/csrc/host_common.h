@@ -53,6 +53,8 @@ struct ilsx_ctx {
   int rt_single = 1, rt_grouped = 1;   // 16-row tiles per workgroup in the column-split kernels (ILSX_RT / ILSX_RT_GROUPED)
   int xcd_shift = 0;  // ILSX_XCD_SHIFT: confine the split-MLP / dW kernels to every 2^k-th workgroup slot (3 = one XCD)
   unsigned long long* dbg_stamps = nullptr;  // device buffer for ILSX_STAMP (debug)
+  void* comm = nullptr;   // ncclComm_t of a split run (ilsx_comm.hip); collectives go on `stream`
+  int comm_n = 0, comm_rank = 0;
   bool prof_on = false;
   struct ProfRec { int kid; hipEvent_t a, b; };
   std::vector<ProfRec> prof_pending;
@@ -80,6 +82,7 @@ struct ProfScope {
     }                                                                                                     \
   } while (0)
 
+int comm_allreduce_sum(ilsx_ctx* c, float* buf, size_t n);   // in place, on c->stream
 int ctx_alloc(ilsx_ctx* c, size_t bytes, void** out, bool zero = true);
 int ctx_free(ilsx_ctx* c, void* p);
 int ctx_stage(ilsx_ctx* c, size_t bytes, void** out);

@@ -210,6 +210,34 @@ static int ac_params(AcAgent* g, int which, bool set, float* host, size_t n) {
   return set ? net_upload_flat(g->ctx, g->L[i], base, host, n, 0) : net_download_flat(g->ctx, g->L[i], base, host, n, 0);
 }
 
+// optimiser state of trainable block `which` (snapshots / resume): Adam moments in the block's flat ABI layout + the step count
+// of the optimiser that owns it + the agent's Philox counter
+static int ac_opt(AcAgent* g, int which, bool set, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta) {
+  if (!m_host || !v_host || which < 0 || which >= g->nnets) ILSX_FAIL(ILSX_ERR_ARG, "optimiser block %d out of range", which);
+  HIPCHK(hipSetDevice(g->ctx->device));
+  hipStream_t st = g->ctx->stream;
+  float *M = g->M + g->off[which], *V = g->V + g->off[which];
+  if (set) {
+    ILSX_TRY(net_upload_flat(g->ctx, g->L[which], M, m_host, n, 0));
+    ILSX_TRY(net_upload_flat(g->ctx, g->L[which], V, v_host, n, 0));
+  } else {
+    ILSX_TRY(net_download_flat(g->ctx, g->L[which], M, m_host, n, 0));
+    ILSX_TRY(net_download_flat(g->ctx, g->L[which], V, v_host, n, 0));
+  }
+  if (!meta) return ILSX_OK;
+  AcScalars hs; DevScalars hd;
+  HIPCHK(hipMemcpyAsync(&hs, g->sc, sizeof hs, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&hd, g->dsc, sizeof hd, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (!set) { meta->t = hs.t[g->opt_of[which]]; meta->rng_step = hd.step; return ILSX_OK; }
+  hs.t[g->opt_of[which]] = (int)meta->t;
+  hd.step = meta->rng_step; hd.gather_step = meta->rng_step;
+  HIPCHK(hipMemcpyAsync(g->sc, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(g->dsc, &hd, sizeof hd, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return ac_tick(g, 0, 0);   // bias-correction scalars of the next step from the restored counters
+}
+
 static int ac_fetch(AcAgent* g, const float* dev, size_t n, std::vector<float>& out) {
   out.resize(n);
   HIPCHK(hipMemcpyAsync(out.data(), dev, n * 4, hipMemcpyDeviceToHost, g->ctx->stream));
@@ -448,6 +476,20 @@ extern "C" int ilsx_td3_set_params(ilsx_td3* t, int which, const float* src_host
   return ac_params(&t->g, which, true, const_cast<float*>(src_host), n);
 }
 
+extern "C" int ilsx_td3_get_opt(ilsx_td3* t, int which, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta) {
+  if (!t) ILSX_FAIL(ILSX_ERR_ARG, "NULL handle");
+  ILSX_TRY(ac_opt(&t->g, which, false, m_host, v_host, n, meta));
+  if (meta) meta->n_train_steps = t->n_steps;
+  return ILSX_OK;
+}
+extern "C" int ilsx_td3_set_opt(ilsx_td3* t, int which, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta) {
+  if (!t) ILSX_FAIL(ILSX_ERR_ARG, "NULL handle");
+  ilsx_opt_meta m2; if (meta) m2 = *meta;
+  ILSX_TRY(ac_opt(&t->g, which, true, const_cast<float*>(m_host), const_cast<float*>(v_host), n, meta ? &m2 : nullptr));
+  if (meta) t->n_steps = meta->n_train_steps;
+  return ILSX_OK;
+}
+
 // ================================================================================================ SAC-V
 enum { SV_Q1 = 0, SV_Q2 = 1, SV_V = 2, SV_PI = 3 };
 struct ilsx_sacv {
@@ -637,6 +679,17 @@ extern "C" int ilsx_sacv_set_params(ilsx_sacv* s, int which, const float* src_ho
   return ac_params(&s->g, which, true, const_cast<float*>(src_host), n);
 }
 
+extern "C" int ilsx_sacv_get_opt(ilsx_sacv* s, int which, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta) {
+  if (!s) ILSX_FAIL(ILSX_ERR_ARG, "NULL handle");
+  if (meta) meta->n_train_steps = 0;
+  return ac_opt(&s->g, which, false, m_host, v_host, n, meta);
+}
+extern "C" int ilsx_sacv_set_opt(ilsx_sacv* s, int which, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta) {
+  if (!s) ILSX_FAIL(ILSX_ERR_ARG, "NULL handle");
+  ilsx_opt_meta m2; if (meta) m2 = *meta;
+  return ac_opt(&s->g, which, true, const_cast<float*>(m_host), const_cast<float*>(v_host), n, meta ? &m2 : nullptr);
+}
+
 // ================================================================================================ behaviour cloning
 // rlkit/torch/algorithms/bc/bc.py:14-41,81-106: one Adam(lr, betas=(momentum, 0.999)) over a tanh-Gaussian policy;
 // mode MLE = -mean(get_log_prob(obs, acts)), mode MSE = mean_rows(sum_j (sampled action - acts)^2).
@@ -740,4 +793,15 @@ extern "C" int ilsx_bc_train_from_replay(ilsx_bc* b, ilsx_replay* expert_rb, int
     ILSX_TRY(bc_step(b, i == 0 ? stat : nullptr));
   }
   return ILSX_OK;
+}
+
+extern "C" int ilsx_bc_get_opt(ilsx_bc* b, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta) {
+  if (!b) ILSX_FAIL(ILSX_ERR_ARG, "NULL handle");
+  if (meta) meta->n_train_steps = 0;
+  return ac_opt(&b->g, 0, false, m_host, v_host, n, meta);
+}
+extern "C" int ilsx_bc_set_opt(ilsx_bc* b, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta) {
+  if (!b) ILSX_FAIL(ILSX_ERR_ARG, "NULL handle");
+  ilsx_opt_meta m2; if (meta) m2 = *meta;
+  return ac_opt(&b->g, 0, true, const_cast<float*>(m_host), const_cast<float*>(v_host), n, meta ? &m2 : nullptr);
 }

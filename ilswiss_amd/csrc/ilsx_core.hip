@@ -94,6 +94,7 @@ extern "C" int ilsx_ctx_destroy(ilsx_ctx* c) {
   if (!c) return ILSX_OK;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  ilsx_comm_destroy(c);
   for (auto& r : c->prof_pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (hipEvent_t e : c->prof_free) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);

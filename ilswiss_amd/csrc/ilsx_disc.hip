@@ -401,6 +401,32 @@ extern "C" int ilsx_disc_get_grads(ilsx_disc* d, float* dst, size_t n) {
   return net_download_flat(d->ctx, d->L, d->G, dst, n, 0);
 }
 
+// disc_optimizer state (adv_irl.py:75-77) for snapshots / resume: Adam moments in the flat ABI layout, step count, Philox counter
+static int disc_opt(ilsx_disc* d, bool set, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta) {
+  if (!d || !m_host || !v_host) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_disc_*_opt: NULL argument");
+  HIPCHK(hipSetDevice(d->ctx->device));
+  hipStream_t st = d->ctx->stream;
+  if (set) { ILSX_TRY(net_upload_flat(d->ctx, d->L, d->M, m_host, n, 0)); ILSX_TRY(net_upload_flat(d->ctx, d->L, d->V, v_host, n, 0)); }
+  else { ILSX_TRY(net_download_flat(d->ctx, d->L, d->M, m_host, n, 0)); ILSX_TRY(net_download_flat(d->ctx, d->L, d->V, v_host, n, 0)); }
+  if (!meta) return ILSX_OK;
+  DiscScalars h;
+  HIPCHK(hipMemcpyAsync(&h, d->scal, sizeof h, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (!set) { meta->t = h.t; meta->rng_step = d->step_ctr; meta->n_train_steps = 0; return ILSX_OK; }
+  h.t = (int)meta->t;
+  d->step_ctr = meta->rng_step;
+  HIPCHK(hipMemcpyAsync(d->scal, &h, sizeof h, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return disc_refresh(d);
+}
+extern "C" int ilsx_disc_get_opt(ilsx_disc* d, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta) {
+  return disc_opt(d, false, m_host, v_host, n, meta);
+}
+extern "C" int ilsx_disc_set_opt(ilsx_disc* d, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta) {
+  ilsx_opt_meta m2; if (meta) m2 = *meta;
+  return disc_opt(d, true, const_cast<float*>(m_host), const_cast<float*>(v_host), n, meta ? &m2 : nullptr);
+}
+
 // shared forward over `rows` rows of X (row stride D): raw head partials -> d->raw, optional activation saves
 static int disc_forward(ilsx_disc* d, const float* x0, int d0, int s0, const float* x1, int d1, int s1, int rows, bool save) {
   FwdArgs A;
@@ -517,7 +543,10 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
   if (ws.B < B) {
     float** ps[] = {&ws.eo, &ws.ea, &ws.er, &ws.ed, &ws.en, &ws.po, &ws.pa, &ws.pr, &ws.pd, &ws.pn};
     const size_t w[] = {(size_t)o, (size_t)a, 1, 1, (size_t)o, (size_t)o, (size_t)a, 1, 1, (size_t)o};
-    for (int i = 0; i < 10; ++i) ILSX_TRY(ctx_alloc(d->ctx, (size_t)B * w[i] * 4, (void**)ps[i], true));
+    for (int i = 0; i < 10; ++i) {   // a larger batch than before: release the old staging rows first
+      if (*ps[i]) { ILSX_TRY(ctx_free(d->ctx, *ps[i])); *ps[i] = nullptr; }
+      ILSX_TRY(ctx_alloc(d->ctx, (size_t)B * w[i] * 4, (void**)ps[i], true));
+    }
     ws.B = B;
   }
   bool first_disc = true, first_pol = true;

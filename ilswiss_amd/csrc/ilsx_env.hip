@@ -880,6 +880,12 @@ static int rollout_step_impl(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* label_pi, i
   HIPCHK(hipSetDevice(ctx->device));
   if (rb && (rb->o != e->o || rb->a != e->a)) ILSX_FAIL(ILSX_ERR_ARG, "replay dims (%d,%d) != env dims (%d,%d)", rb->o, rb->a, e->o, e->a);
   if (rb && e->n_env > rb->cap) ILSX_FAIL(ILSX_ERR_ARG, "n_env exceeds the replay capacity");
+  // the fused record holds the env's RAW observations while the policy acts on the normalised ones (policy_obs()): an
+  // off-policy learner fed from this ring would train on a different observation scale than it acts on.  The reference
+  // stores what step() returned, i.e. normalised observations (vecenvs.py:251-257); no shipped spec combines the two.
+  if (rb && e->norm_obs)
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "ilsx_rollout_step: norm_obs=1 with a replay ring is not supported (the fused insert records raw "
+              "observations); use the on-policy rollout (ilsx_ppo_rollout) or turn norm_obs off");
   const unsigned long long step = ++e->step_ctr;
   if (random_actions) {
     const int tot = e->n_env * e->a;

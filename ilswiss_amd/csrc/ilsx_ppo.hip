@@ -221,6 +221,7 @@ struct ilsx_ppo {
   float* partial = nullptr;
   int *offs = nullptr, *perm = nullptr;
   DwArgs jobs_v, jobs_p;
+  unsigned long long shuffles = 0;   // library-drawn minibatch permutations so far (key of the next one)
   float* log_std() const { return Pp + Lp.n_int; }
   float* g_log_std() const { return Gp + Lp.n_int; }
 };
@@ -321,6 +322,44 @@ extern "C" int ilsx_ppo_get_params(ilsx_ppo* p, int which, float* dst, size_t n)
   HIPCHK(hipMemcpyAsync(dst + p->Lp.n_flat, p->log_std(), p->a * sizeof(float), hipMemcpyDeviceToHost, p->ctx->stream));
   HIPCHK(hipStreamSynchronize(p->ctx->stream));
   return ILSX_OK;
+}
+
+// Adam state of the policy (mean net | action_log_std) / value optimiser (ppo.py:47-55), flat ABI layout of the block
+static int ppo_opt(ilsx_ppo* p, int which, bool set, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta) {
+  if (!p || !m_host || !v_host || which < 0 || which > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_*_opt: bad argument");
+  HIPCHK(hipSetDevice(p->ctx->device));
+  hipStream_t st = p->ctx->stream;
+  const NetLayout& L = which == 0 ? p->Lp : p->Lv;
+  float* arenas[2] = {which == 0 ? p->Mp : p->Mv, which == 0 ? p->Vp : p->Vv};
+  float* hosts[2] = {m_host, v_host};
+  const size_t want = L.n_flat + (which == 0 ? (size_t)p->a : 0);
+  if (n != want) ILSX_FAIL(ILSX_ERR_ARG, "optimiser state count %zu != %zu", n, want);
+  for (int k = 0; k < 2; ++k) {
+    if (set) ILSX_TRY(net_upload_flat(p->ctx, L, arenas[k], hosts[k], L.n_flat, 0));
+    else ILSX_TRY(net_download_flat(p->ctx, L, arenas[k], hosts[k], L.n_flat, 0));
+    if (which == 0) {   // the state-independent log-std parameter sits behind the mean net in the policy arena
+      if (set) HIPCHK(hipMemcpyAsync(arenas[k] + L.n_int, hosts[k] + L.n_flat, p->a * sizeof(float), hipMemcpyHostToDevice, st));
+      else HIPCHK(hipMemcpyAsync(hosts[k] + L.n_flat, arenas[k] + L.n_int, p->a * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
+  if (!meta) return ILSX_OK;
+  PpoScalars h;
+  HIPCHK(hipMemcpyAsync(&h, p->sc, sizeof h, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (!set) { meta->t = which == 0 ? h.t_p : h.t_v; meta->rng_step = p->shuffles; meta->n_train_steps = 0; return ILSX_OK; }
+  if (which == 0) h.t_p = (int)meta->t; else h.t_v = (int)meta->t;
+  p->shuffles = meta->rng_step;
+  HIPCHK(hipMemcpyAsync(p->sc, &h, sizeof h, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return ppo_refresh(p, -1);
+}
+extern "C" int ilsx_ppo_get_opt(ilsx_ppo* p, int which, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta) {
+  return ppo_opt(p, which, false, m_host, v_host, n, meta);
+}
+extern "C" int ilsx_ppo_set_opt(ilsx_ppo* p, int which, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta) {
+  ilsx_opt_meta m2; if (meta) m2 = *meta;
+  return ppo_opt(p, which, true, const_cast<float*>(m_host), const_cast<float*>(v_host), n, meta ? &m2 : nullptr);
 }
 
 static void ppo_fwd_task(FwdTask& t, const NetLayout& L, float* base, const float* obs, int o) {
@@ -456,7 +495,6 @@ extern "C" int ilsx_ppo_train(ilsx_ppo* p, const float* obs, const float* act, c
                               const int32_t* perms_host) {
   ILSX_TRY(ilsx_ppo_gae(p, obs, act, rew, traj_offsets_host, n_traj, bootstrap_values, nullptr, nullptr, nullptr, nullptr));
   const int N = p->N, mb = p->cfg.mini_batch_size;
-  static unsigned long long shuffles = 0;
   int half_bits = 1;
   while ((1ll << (2 * half_bits)) < (long long)N) ++half_bits;
   for (int ep = 0; ep < p->cfg.update_epoch; ++ep) {
@@ -465,7 +503,7 @@ extern "C" int ilsx_ppo_train(ilsx_ppo* p, const float* obs, const float* act, c
       HIPCHK(hipMemcpyAsync(p->perm, perms_host + (size_t)ep * N, (size_t)N * sizeof(int), hipMemcpyHostToDevice, p->ctx->stream));
       HIPCHK(hipStreamSynchronize(p->ctx->stream));
     } else {
-      ++shuffles;
+      const unsigned long long shuffles = ++p->shuffles;   // per agent (was process-wide): resumable through ilsx_ppo_set_opt
       hipLaunchKernelGGL(k_ppo_perm, dim3((N + 255) / 256), dim3(256), 0, p->ctx->stream, p->perm, N, half_bits,
                          (uint32_t)(p->ctx->seed ^ 0x70657261u), (uint32_t)shuffles);
       HIPCHK(hipGetLastError());

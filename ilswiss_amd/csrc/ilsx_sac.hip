@@ -592,10 +592,11 @@ static TailLite sac_tail_lite(ilsx_sac* s, int B) {
   t.qf_lr = s->cfg.qf_lr; t.policy_lr = s->cfg.policy_lr;
   return t;
 }
+static bool sac_is_split(const ilsx_sac* s);
 static int sac_defer_begin(ilsx_sac* s, int B) {
   static const bool off = getenv("ILSX_NO_DEFER_TAIL") != nullptr || getenv("ILSX_NO_FUSE") != nullptr;
   s->defer_tail = false;
-  if (off || s->cs <= 1 || s->cfg.grad_world != 1 || s->col) return ILSX_OK;
+  if (off || s->cs <= 1 || sac_is_split(s) || s->col) return ILSX_OK;
   if (!s->tail_dev) ILSX_TRY(ctx_alloc(s->ctx, sizeof(TailLite), (void**)&s->tail_dev));
   if (s->tail_B != B) {
     const TailLite t = sac_tail_lite(s, B);
@@ -615,12 +616,35 @@ static int sac_flush_tail(ilsx_sac* s, bool deferred) {   // the pending tail of
   return ILSX_OK;
 }
 
+// Split run (cfg.grad_world = G > 1): this rank holds B/G rows; the gradient arena is summed over the ranks between
+// backward and the optimiser step with RCCL on the ctx stream (segment 0 = critics, 1 = actor | alpha slot: two messages
+// because the actor loss is evaluated with the post-update critics, sac_alpha.py:142-146).
+// ILSX_SPLIT_FORCE=1 (tests): a run with grad_world = 1 whose ctx carries a one-rank communicator takes the split-run code path
+// too — un-fused phases with ncclAllReduce between them — so the collective plumbing is exercised on a single-GPU box.
+static bool sac_is_split(const ilsx_sac* s) {
+  return s->cfg.grad_world > 1 || (s->ctx->comm != nullptr && getenv("ILSX_SPLIT_FORCE") != nullptr);
+}
+static int sac_allreduce(ilsx_sac* s, int segment) {
+  if (!sac_is_split(s)) return ILSX_OK;
+  if (segment == 0) return comm_allreduce_sum(s->ctx, s->G, 2 * s->nq);
+  return comm_allreduce_sum(s->ctx, s->G + 2 * s->nq, s->np + 4);
+}
+static int sac_check_world(const ilsx_sac* s, const char* who) {
+  if (s->cfg.grad_world == 1) return ILSX_OK;
+  if (!s->ctx->comm || s->ctx->comm_n != s->cfg.grad_world)
+    ILSX_FAIL(ILSX_ERR_STATE, "%s: grad_world=%d needs a communicator of that many ranks on the ctx (ilsx_comm_init; found %d) — "
+              "or drive the four phases and all-reduce ilsx_sac_grads_ptr yourself", who, s->cfg.grad_world, s->ctx->comm ? s->ctx->comm_n : 0);
+  return ILSX_OK;
+}
+
 static int sac_full_step(ilsx_sac* s) {
   static const bool no_fuse = getenv("ILSX_NO_FUSE") != nullptr;
-  s->fuse_now = !no_fuse && s->cfg.grad_world == 1;
+  s->fuse_now = !no_fuse && !sac_is_split(s);
   int rc = sac_critic_backward(s);
+  if (rc == ILSX_OK) rc = sac_allreduce(s, 0);
   if (rc == ILSX_OK) rc = sac_critic_update(s);
   if (rc == ILSX_OK) rc = sac_actor_backward(s);
+  if (rc == ILSX_OK) rc = sac_allreduce(s, 1);
   if (rc == ILSX_OK) rc = sac_actor_update(s);
   s->fuse_now = false;
   return rc;
@@ -690,6 +714,7 @@ extern "C" int ilsx_sac_last_stats(ilsx_sac* s, ilsx_sac_stats* stats) {
 extern "C" int ilsx_sac_train_step(ilsx_sac* s, const float* obs, const float* act, const float* rew,
                                    const float* done, const float* nobs, int B, const float* eps_next,
                                    const float* eps_cur, ilsx_sac_stats* stats) {
+  if (s) ILSX_TRY(sac_check_world(s, "ilsx_sac_train_step"));
   ILSX_TRY(ilsx_sac_set_batch(s, obs, act, rew, done, nobs, B, eps_next, eps_cur));
   if (stats) ILSX_TRY(sac_request_stats(s));
   ILSX_TRY(sac_full_step(s));
@@ -714,11 +739,16 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   if (B < 1 || B > s->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch=%d", B, s->cfg.max_batch);
   if (rb->o != s->o || rb->a != s->a) ILSX_FAIL(ILSX_ERR_ARG, "replay dims (%d,%d) != agent dims (%d,%d)", rb->o, rb->a, s->o, s->a);
   if (rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "replay buffer is empty");
+  ILSX_TRY(sac_check_world(s, "ilsx_sac_train_from_replay"));
   HIPCHK(hipSetDevice(s->ctx->device));
   hipStream_t st = s->ctx->stream;
   s->B = B;
   s->eps_explicit = false;
-  static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
+  // split runs replay the step from a hipGraph only on request: RCCL calls inside a capture are the one part of this path
+  // that could not be exercised with more than one rank on the development box
+  static const bool split_graph = getenv("ILSX_SPLIT_GRAPH") != nullptr;
+  static const bool no_graph_env = getenv("ILSX_NO_GRAPH") != nullptr;
+  const bool no_graph = no_graph_env || (sac_is_split(s) && !split_graph);
   if (n_steps == 0) return stats ? sac_read_stats(s, stats) : ILSX_OK;
   ILSX_TRY(sac_defer_begin(s, B));
   struct DeferGuard { ilsx_sac* s; ~DeferGuard() { s->defer_tail = false; } } guard{s};   // never left on, whatever path returns

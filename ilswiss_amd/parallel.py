@@ -31,29 +31,70 @@ def shard_batch(batch, world_size, rank):
     return out
 
 
+def comm_init(ctx, group=None):
+    """Give `ctx` (an ilswiss_amd Context) an RCCL communicator spanning the torch.distributed group: rank 0 draws the id
+    (ilsx_comm_unique_id), torch.distributed carries its 128 bytes (any backend — this is the only thing the process group
+    is used for), every rank calls ilsx_comm_init.  From then on the library's own all-reduces run on the ctx stream."""
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from . import _lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    buf = (C.c_uint8 * 128)()
+    if rank == 0:
+        _lib.check(ctx.lib.ilsx_comm_unique_id(buf))
+    box = [bytes(buf)]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
+    buf = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    _lib.check(ctx.lib.ilsx_comm_init(ctx.h, buf, world, rank))
+    return world, rank
+
+
 class SplitRunStep:
     """Drives one split-run SAC step on this rank.
 
-    `trainer` exposes the four phases (`set_batch`, `critic_backward`, `critic_update`, `actor_backward`,
-    `actor_update`) and `grad_tensor(segment)` -> a torch tensor ALIASING the gradient arena segment
-    (0 = critics, 1 = actor + alpha slot).  `sync()` (optional) drains the trainer's own stream before the
-    collective reads the arena and is called again after it."""
+    Two engines behind the same call:
+      * a libilsx trainer (`ilswiss_amd.SoftActorCritic(grad_world=G)`) whose ctx carries an RCCL communicator
+        (`comm_init`): `train_step` / `train_from_replay` are ONE library call — critic-backward -> ncclAllReduce -> critic
+        Adam -> actor-backward -> ncclAllReduce -> actor Adam, all enqueued on the ctx stream (no host synchronisation, no
+        second stream);
+      * any object with the four phases (`set_batch`, `critic_backward`, `critic_update`, `actor_backward`,
+        `actor_update`) and `grad_tensor(segment)` -> a torch tensor ALIASING the gradient arena segment (0 = critics,
+        1 = actor + alpha slot): the collective is torch.distributed's.  This is what the CPU tests drive (gloo + the numpy
+        oracle).  For a device trainer on this route the trainer's stream is drained before the collective reads the arena
+        and torch's stream is drained before the update phase is enqueued (`sync` defaults to the trainer's `ctx.sync`)."""
 
-    def __init__(self, trainer, group=None, sync=None):
+    def __init__(self, trainer, group=None, sync=None, use_library_comm=None):
         import torch.distributed as dist
         self.dist, self.trainer, self.group = dist, trainer, group
+        ctx = getattr(trainer, "ctx", None)
+        if use_library_comm is None:
+            use_library_comm = ctx is not None and hasattr(ctx, "lib") and hasattr(trainer, "train_from_replay")
+        self.library = bool(use_library_comm)
+        if self.library:
+            import ctypes as C
+            n = C.c_int()
+            ctx.lib.ilsx_comm_info(ctx.h, C.byref(n), None)
+            if n.value == 0:
+                comm_init(ctx, group)
+        if sync is None and ctx is not None and hasattr(ctx, "sync"):
+            sync = ctx.sync
         self.sync = sync or (lambda: None)
 
     def _allreduce(self, seg):
         t = self.trainer.grad_tensor(seg)
-        self.sync()
+        self.sync()                                   # the trainer's stream has produced the arena
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         if t.is_cuda:
             import torch
-            torch.cuda.current_stream(t.device).synchronize()
+            torch.cuda.current_stream(t.device).synchronize()   # ... and the collective is done before the update is enqueued
 
     def train_step(self, local_batch, eps_next=None, eps_cur=None):
         tr = self.trainer
+        if self.library:
+            return tr.train_step(local_batch, eps_next, eps_cur)
         tr.set_batch(local_batch, eps_next, eps_cur)
         tr.critic_backward()
         self._allreduce(0)
@@ -61,3 +102,9 @@ class SplitRunStep:
         tr.actor_backward()
         self._allreduce(1)
         tr.actor_update()
+
+    def train_from_replay(self, replay_shard, n_steps, local_batch_size):
+        """n fused steps, each rank drawing its B/G rows from ITS replay shard (stratified-uniform over the union, §8e)."""
+        if not self.library:
+            raise RuntimeError("train_from_replay needs the library communicator (a libilsx trainer)")
+        return self.trainer.train_from_replay(replay_shard, n_steps, local_batch_size)

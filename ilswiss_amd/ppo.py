@@ -51,7 +51,8 @@ class PPO(Trainer):
                  value_lr=3e-4, gae_tau=0.9, value_l2_reg=1e-3, use_value_clip=False, update_epoch=10,
                  lambda_entropy_policy=0.0, max_samples=16384, **kwargs):
         if use_value_clip:
-            raise NotImplementedError("use_value_clip is never read by the reference's train_step (ppo.py:136-153)")
+            raise NotImplementedError("use_value_clip=True (the clipped value loss of ppo.py:137-143) is not implemented: no spec of "
+                                      "the reference turns it on (default False, ppo.py:24)")
         self.on_policy = True  # ppo.py:30
         self.policy, self.vf, self.ctx = policy, vf, policy.ctx
         if vf.act != 1 or policy.act != 1:
@@ -167,8 +168,19 @@ class PPO(Trainer):
     def networks(self):
         return [self.policy, self.vf]
 
-    def get_snapshot(self):
-        return dict(policy=self.get_flat_params(0), vf=self.get_flat_params(1))
+    def get_snapshot(self):   # ppo.py:178-185 (+ both optimisers' Adam state; the env's obs_rms is added by the algorithm)
+        from .snapshot import get_opt
+        snap = dict(policy=self.get_flat_params(0), vf=self.get_flat_params(1))
+        snap["policy_optimizer"] = get_opt(self.ctx.lib, "ppo", self.h, snap["policy"].size, 0)
+        snap["vf_optimizer"] = get_opt(self.ctx.lib, "ppo", self.h, snap["vf"].size, 1)
+        return snap
+
+    def load_snapshot(self, snap):
+        from .snapshot import set_opt
+        self.set_flat_params(snap["policy"], snap["vf"])
+        if "policy_optimizer" in snap:
+            set_opt(self.ctx.lib, "ppo", self.h, snap["policy_optimizer"], 0)
+            set_opt(self.ctx.lib, "ppo", self.h, snap["vf_optimizer"], 1)
 
     def get_eval_statistics(self):
         return self.eval_statistics

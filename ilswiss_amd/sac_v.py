@@ -78,5 +78,19 @@ class SoftActorCriticV(Trainer):
         flat = np.ascontiguousarray(flat, np.float32)
         _lib.check(self.ctx.lib.ilsx_sacv_set_params(self.h, self.WHICH[name], flat.ctypes.data_as(C.c_void_p), flat.size))
 
-    def get_snapshot(self):  # sac.py:245-253, as plain arrays
-        return {k: self.get_flat_params(k) for k in ("qf1", "qf2", "policy", "vf", "target_vf")}
+    _OPT = (("qf1", 0), ("qf2", 1), ("vf", 2), ("policy", 3))
+
+    def get_snapshot(self):  # sac.py:245-257, as plain arrays (+ the four optimisers' Adam state)
+        from .snapshot import get_opt
+        snap = {k: self.get_flat_params(k) for k in ("qf1", "qf2", "policy", "vf", "target_vf")}
+        for k, w in self._OPT:
+            snap[k + "_optimizer"] = get_opt(self.ctx.lib, "sacv", self.h, snap[k].size, w)
+        return snap
+
+    def load_snapshot(self, snap):  # sac.py:259-270
+        from .snapshot import set_opt
+        for k in ("qf1", "qf2", "policy", "vf", "target_vf"):
+            self.set_flat_params(k, snap[k])
+        for k, w in self._OPT:
+            if k + "_optimizer" in snap:
+                set_opt(self.ctx.lib, "sacv", self.h, snap[k + "_optimizer"], w)

@@ -124,5 +124,17 @@ class TD3(Trainer):
         flat = np.ascontiguousarray(flat, np.float32)
         _lib.check(self.ctx.lib.ilsx_td3_set_params(self.h, self.WHICH[name], flat.ctypes.data_as(C.c_void_p), flat.size))
 
-    def get_snapshot(self):  # td3.py:185-193, as plain arrays
-        return {k: self.get_flat_params(k) for k in ("qf1", "qf2", "policy", "target_policy", "target_qf1", "target_qf2")}
+    def get_snapshot(self):  # td3.py:185-196, as plain arrays (+ the three optimisers' Adam state)
+        from .snapshot import get_opt
+        snap = {k: self.get_flat_params(k) for k in ("qf1", "qf2", "policy", "target_policy", "target_qf1", "target_qf2")}
+        for k, w in (("qf1", 0), ("qf2", 1), ("policy", 2)):
+            snap[k + "_optimizer"] = get_opt(self.ctx.lib, "td3", self.h, snap[k].size, w)
+        return snap
+
+    def load_snapshot(self, snap):  # td3.py:198-206
+        from .snapshot import set_opt
+        for k in ("qf1", "qf2", "policy", "target_policy", "target_qf1", "target_qf2"):
+            self.set_flat_params(k, snap[k])
+        for k, w in (("qf1", 0), ("qf2", 1), ("policy", 2)):
+            if k + "_optimizer" in snap:
+                set_opt(self.ctx.lib, "td3", self.h, snap[k + "_optimizer"], w)

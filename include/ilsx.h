@@ -67,6 +67,23 @@ int ilsx_ctx_free(ilsx_ctx* ctx, void* ptr);
 int ilsx_memcpy_h2d(ilsx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int ilsx_memcpy_d2h(ilsx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* syncs */
 
+/* ---------------------------------------------------------------- split-run communicator
+ * The path's ONE exchange step: when a single run is split over G GPUs (one process / ctx per GPU, every rank a full
+ * replica of the parameters, B/G rows of the batch each, mean-loss gradients pre-scaled by 1/(B*G) through
+ * ilsx_sac_cfg.grad_world), the flat gradient arena is all-reduced (sum) between backward and the optimiser step.  No
+ * reference counterpart (run_experiment.py:57-78 runs independent processes only).  The collective is RCCL's
+ * ncclAllReduce enqueued on the ctx stream; librccl.so.1 is dlopen'ed at the first call here.  Rank 0 draws the id, the
+ * host program carries its 128 bytes to the other ranks (file, socket, torch.distributed — ilswiss_amd/parallel.py), then
+ * every rank calls ilsx_comm_init.  With a communicator of grad_world ranks on the ctx, ilsx_sac_train_step and
+ * ilsx_sac_train_from_replay run critic-backward -> all-reduce -> critic Adam+Polyak -> actor-backward -> all-reduce
+ * (alpha gradient in the same message) -> actor Adam, all stream-ordered, no host synchronisation. */
+#define ILSX_COMM_ID_BYTES 128
+int ilsx_comm_unique_id(uint8_t* id_host /* [ILSX_COMM_ID_BYTES] */);
+int ilsx_comm_init(ilsx_ctx* ctx, const uint8_t* id_host, int n_ranks, int rank);
+int ilsx_comm_destroy(ilsx_ctx* ctx);
+int ilsx_comm_info(const ilsx_ctx* ctx, int* n_ranks, int* rank);   /* 0 ranks = no communicator */
+int ilsx_comm_allreduce_sum(ilsx_ctx* ctx, float* dev_buf, size_t n);   /* in place, on the ctx stream */
+
 /* ---------------------------------------------------------------- kernel timing (bench.py roofline leg)
  * When enabled, every launch of a library kernel carries a start / stop hipEvent stamped with the dispatch's own
  * begin / end time (hipExtLaunchKernelGGL — the interval rocprofv3's kernel trace reports; the graph path is
@@ -322,6 +339,26 @@ int ilsx_sacv_train_from_replay(ilsx_sacv* sac, ilsx_replay* rb, int n_steps, in
 /* which: 0 qf1, 1 qf2, 2 vf, 3 policy, 6 target_vf; HOST flat arrays */
 int ilsx_sacv_get_params(ilsx_sacv* sac, int which, float* dst_host, size_t n);
 int ilsx_sacv_set_params(ilsx_sacv* sac, int which, const float* src_host, size_t n);
+
+/* ---------------------------------------------------------------- optimiser state (snapshots / resume)
+ * The optimizer.state_dict() halves of the reference's get_snapshot / load_snapshot pairs (td3.py:185-210, sac.py:245-270,
+ * ppo.py:47-55 policy/value optimisers, adv_irl.py:75-77 disc_optimizer, bc.py:33-41) and what `load_params` resumes from
+ * (run_scripts/sac_alpha_exp_script.py:106-108,142-146; rlkit/core/logger.py:31-49).  Adam's exp_avg / exp_avg_sq travel in
+ * the flat ABI layout of the parameter block they belong to (HOST fp32 [n], n = that block's parameter count); meta.t is the
+ * owning optimiser's step count, meta.rng_step the agent's Philox step counter, meta.n_train_steps the trainer's own step
+ * counter where it has one (TD3's delayed-update parity, td3.py:101).  `which` numbers the TRAINABLE blocks exactly like the
+ * agent's *_get_params.  SAC-alpha has its own pair (ilsx_sac_get_adam / _set_adam / _alpha_opt above). */
+typedef struct { int64_t t; uint64_t rng_step; int64_t n_train_steps; } ilsx_opt_meta;
+int ilsx_td3_get_opt(ilsx_td3* td3, int which, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta);    /* 0 qf1, 1 qf2, 2 policy */
+int ilsx_td3_set_opt(ilsx_td3* td3, int which, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta);
+int ilsx_sacv_get_opt(ilsx_sacv* sac, int which, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta);  /* 0 qf1, 1 qf2, 2 vf, 3 policy */
+int ilsx_sacv_set_opt(ilsx_sacv* sac, int which, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta);
+int ilsx_bc_get_opt(ilsx_bc* bc, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta);
+int ilsx_bc_set_opt(ilsx_bc* bc, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta);
+int ilsx_ppo_get_opt(ilsx_ppo* ppo, int which, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta);    /* 0 policy (| action_log_std), 1 value net */
+int ilsx_ppo_set_opt(ilsx_ppo* ppo, int which, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta);
+int ilsx_disc_get_opt(ilsx_disc* disc, float* m_host, float* v_host, size_t n, ilsx_opt_meta* meta);
+int ilsx_disc_set_opt(ilsx_disc* disc, const float* m_host, const float* v_host, size_t n, const ilsx_opt_meta* meta);
 
 /* ---------------------------------------------------------------- behaviour cloning
  * Replaces rlkit/torch/algorithms/bc/bc.py:14-41 (ctor: Adam(lr, betas=(momentum, 0.999)) over the policy) and :77-106

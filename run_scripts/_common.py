@@ -44,6 +44,17 @@ def start(variant, gpu):
     return ia.set_gpu_mode(True, gpu, seed=seed)
 
 
+def train(algorithm, variant):
+    """`load_params` (sac_alpha_exp_script.py:106-113): resume from <load_path>/{params,extra_data}.pkl, then train."""
+    from ilswiss_amd.snapshot import load_from_file
+    epoch = 0
+    if variant.get("load_params"):
+        algorithm, epoch = load_from_file(algorithm, **variant["load_params"])
+    print("Start from epoch", epoch)
+    algorithm.train(start_epoch=epoch)
+    return algorithm
+
+
 def main(experiment, default_name):
     ap = argparse.ArgumentParser()
     ap.add_argument("-e", "--experiment", required=True, help="experiment specification file")
@@ -51,5 +62,9 @@ def main(experiment, default_name):
     args = ap.parse_args()
     with open(args.experiment) as f:
         variant = flatten_spec(yaml.safe_load(f))
-    log_dir = setup_log_dir(variant.get("exp_name", default_name), int(variant.get("exp_id", 0)), int(variant.get("seed", 0)), variant)
+    load_path = (variant.get("load_params") or {}).get("load_path")
+    if load_path:   # a resumed run keeps logging into the directory it resumes from (sac_alpha_exp_script.py:142-146)
+        log_dir = load_path
+    else:
+        log_dir = setup_log_dir(variant.get("exp_name", default_name), int(variant.get("exp_id", 0)), int(variant.get("seed", 0)), variant)
     return experiment(variant, args.gpu, log_dir)

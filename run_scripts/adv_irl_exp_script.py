@@ -11,7 +11,7 @@ import random
 
 import numpy as np
 import yaml
-from _common import ia, main, make_envs, start
+from _common import ia, main, make_envs, start, train  # noqa: F401
 
 from ilswiss_amd.adv_irl import AdvIRLTrainer, MLPDisc
 from ilswiss_amd.algorithm import DeviceRLAlgorithm
@@ -86,7 +86,7 @@ def experiment(variant, gpu=0, log_dir=None):
     algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env, exploration_policy=policy,
                                   log_dir=log_dir, num_train_steps_per_train_call=p.get("num_update_loops_per_train_call", 1),
                                   batch_size=Bp, **alg)
-    algorithm.train()
+    train(algorithm, variant)
     return algorithm
 
 

@@ -3,7 +3,7 @@
 variant keys env_specs / net_size / num_hidden_layers / ppo_params / rl_alg_params / seed.  Observations are
 normalised by the training env's running statistics, which the eval env shares (:60-75); policy = Gaussian with a
 state-independent log-std, value net and policy use tanh units (:82-96)."""
-from _common import ia, main, make_envs, start
+from _common import ia, main, make_envs, start, train  # noqa: F401
 
 from ilswiss_amd.algorithm import DeviceRLAlgorithm
 from ilswiss_amd.ppo import PPO, ReparamMultivariateGaussianPolicy
@@ -22,7 +22,7 @@ def experiment(variant, gpu=0, log_dir=None):
     trainer = PPO(policy=policy, vf=vf, max_samples=horizon * len(training_env), **variant["ppo_params"])
     algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env,
                                   exploration_policy=policy, log_dir=log_dir, **alg)
-    algorithm.train()
+    train(algorithm, variant)
     return algorithm
 
 

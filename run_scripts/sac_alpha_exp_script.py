@@ -4,7 +4,7 @@ run_scripts/sac_alpha_exp_script.py:25-156: `python run_scripts/sac_alpha_exp_sc
 variant keys env_specs / net_size / num_hidden_layers / sac_params / rl_alg_params / seed / exp_name / exp_id.
 Accepts either a flat variant (what run_experiment.py writes per grid point) or a full exp_spec with
 meta_data / variables / constants (the first grid point is taken)."""
-from _common import flatten_spec, ia, main, make_envs, start  # noqa: F401
+from _common import flatten_spec, ia, main, make_envs, start, train  # noqa: F401
 
 from ilswiss_amd.algorithm import DeviceRLAlgorithm
 
@@ -23,7 +23,7 @@ def experiment(variant, gpu=0, log_dir=None):
                                  **variant["sac_params"])
     algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env,
                                   exploration_policy=policy, log_dir=log_dir, **alg)
-    algorithm.train()
+    train(algorithm, variant)
     return algorithm
 
 

@@ -2,7 +2,7 @@
 """SAC (state-value variant, fixed temperature) experiment script on the MI355X engine — same contract as the
 reference's run_scripts/sac_exp_script.py: variant keys env_specs / net_size / num_hidden_layers / sac_params /
 rl_alg_params / seed."""
-from _common import ia, main, make_envs, start
+from _common import ia, main, make_envs, start, train  # noqa: F401
 
 from ilswiss_amd.algorithm import DeviceRLAlgorithm
 from ilswiss_amd.sac_v import SoftActorCriticV
@@ -21,7 +21,7 @@ def experiment(variant, gpu=0, log_dir=None):
     trainer = SoftActorCriticV(policy=policy, qf1=qf1, qf2=qf2, vf=vf, max_batch=alg.get("batch_size", 256), **variant["sac_params"])
     algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env,
                                   exploration_policy=policy, log_dir=log_dir, **alg)
-    algorithm.train()
+    train(algorithm, variant)
     return algorithm
 
 

@@ -2,7 +2,7 @@
 """TD3 experiment script on the MI355X engine — same contract as the reference's run_scripts/td3_exp_script.py:
 `python run_scripts/td3_exp_script.py -e <variant.yaml> -g <gpu>`, variant keys env_specs / net_size /
 num_hidden_layers / policy_noise / policy_noise_clip / td3_params / rl_alg_params / seed."""
-from _common import ia, main, make_envs, start
+from _common import ia, main, make_envs, start, train  # noqa: F401
 
 from ilswiss_amd.algorithm import DeviceRLAlgorithm
 from ilswiss_amd.td3 import TD3, MlpGaussianNoisePolicy
@@ -21,7 +21,7 @@ def experiment(variant, gpu=0, log_dir=None):
     trainer = TD3(policy=policy, qf1=qf1, qf2=qf2, max_batch=alg.get("batch_size", 256), **variant["td3_params"])
     algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env,
                                   exploration_policy=policy, log_dir=log_dir, **alg)
-    algorithm.train()
+    train(algorithm, variant)
     return algorithm
 
 

@@ -194,3 +194,59 @@ def test_grouped_lockstep_matches_oracle():
         _check_against_oracle(agents[k], orcs[k], f"agent {k}")
     grp.close()
     ctx.close()
+
+
+_SPLIT_SCRIPT = r'''
+import ctypes as C, hashlib, json, os, sys
+import numpy as np
+sys.path.insert(0, ".")
+import ilswiss_amd as ia
+from ilswiss_amd import _lib
+o, a, hid, B, N = 11, 3, [256, 256], 256, 5000
+rng = np.random.default_rng(5)
+ctx = ia.Context(0, seed=77)
+if os.environ.get("ILSX_SPLIT_FORCE"):
+    ident = (C.c_uint8 * 128)()
+    _lib.check(ctx.lib.ilsx_comm_unique_id(ident))
+    _lib.check(ctx.lib.ilsx_comm_init(ctx.h, ident, 1, 0))
+    n, r = C.c_int(), C.c_int()
+    _lib.check(ctx.lib.ilsx_comm_info(ctx.h, C.byref(n), C.byref(r)))
+    assert (n.value, r.value) == (1, 0)
+    buf = ctx.from_numpy(np.arange(1000, dtype=np.float32))
+    _lib.check(ctx.lib.ilsx_comm_allreduce_sum(ctx.h, buf.ptr, 1000))
+    assert np.array_equal(buf.numpy(), np.arange(1000, dtype=np.float32))
+rb = ia.SimpleReplayBuffer(8192, o, a, random_seed=3, ctx=ctx)
+rb.add_rows(rng.normal(0, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),
+            rng.normal(0, 1, N).astype(np.float32), rng.random(N) < 0.01, rng.normal(0, 1, (N, o)).astype(np.float32))
+pol = ia.ReparamTanhMultivariateGaussianPolicy(hid, o, a, ctx=ctx, seed=10)
+q1, q2 = ia.FlattenMlp(hid, 1, o + a, ctx=ctx, seed=20), ia.FlattenMlp(hid, 1, o + a, ctx=ctx, seed=30)
+tr = ia.SoftActorCritic(pol, q1, q2, policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+tr.eval_statistics = {}
+tr.train_from_replay(rb, 6, B)
+tr.eval_statistics = None
+tr.train_from_replay(rb, 1, B)
+h = hashlib.sha256()
+for name in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+    h.update(np.ascontiguousarray(tr.get_params(name)).tobytes())
+print(json.dumps(dict(params=h.hexdigest(), log_alpha=repr(tr.log_alpha), qf1=repr(float(tr.eval_statistics["QF1 Loss"])))))
+ctx.close()
+'''
+
+
+def test_split_run_phases_with_rccl_on_the_ctx_stream_equal_the_fused_step():
+    """The split-run code path — un-fused phases with ncclAllReduce (librccl dlopen'ed by libilsx, enqueued on the ctx's own
+    stream, no host sync) between backward and update — on a ONE-rank communicator (all a single-GPU box allows) gives bit for
+    bit the parameters of the fused single-run step, with and without replaying the step from a hipGraph."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, extra in (("fused", {}), ("split", {"ILSX_SPLIT_FORCE": "1"}), ("split_graph", {"ILSX_SPLIT_FORCE": "1", "ILSX_SPLIT_GRAPH": "1"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _SPLIT_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-3000:])
+        outs[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])   # RCCL prints its own banner lines
+    assert outs["split"] == outs["fused"], outs
+    assert outs["split_graph"] == outs["fused"], outs

@@ -48,8 +48,10 @@ def test_run_script_c1_plumbing(tmp_path, spec_name):
     assert len(rows) == 2 and rows[-1]["Epoch"] == "1"
     for k in ("Test Returns Mean", "AverageReturn", "QF1 Loss", "QF2 Loss", "Policy Loss", "Alpha Loss", "Alpha",
               "Q1 Predictions Mean", "Log Pis Mean", "Train Time (s)", "Sample Time (s)", "Epoch Time (s)",
-              "Total Train Time (s)", "Number of env steps total", "Number of train steps total"):
+              "Total Train Time (s)", "Number of env steps total", "Number of train calls total", "Number of gradient steps total"):
         assert k in rows[-1], k
+    # _try_to_train (base_algorithm.py:293-299): 8 x 100 env steps, gate 100, min_steps_before_training 100 -> 8 train calls, counted as calls
+    assert float(rows[-1]["Number of train calls total"]) == 8 and float(rows[-1]["Number of gradient steps total"]) == 80
     assert float(rows[-1]["Number of env steps total"]) == 800
     assert os.path.exists(tmp_path / "params.pkl") and os.path.exists(tmp_path / "best.pkl")
     assert alg.replay_buffer.num_steps_can_sample() == 800
