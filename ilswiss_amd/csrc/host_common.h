@@ -52,7 +52,12 @@ struct ilsx_ctx {
   size_t dw_scratch_bytes = 0;
   int rt_single = 1, rt_grouped = 1;   // 16-row tiles per workgroup in the column-split kernels (ILSX_RT / ILSX_RT_GROUPED)
   int xcd_shift = 0;  // ILSX_XCD_SHIFT: confine the split-MLP / dW kernels to every 2^k-th workgroup slot (3 = one XCD)
-  unsigned long long* dbg_stamps = nullptr;  // device buffer for ILSX_STAMP (debug)
+  unsigned long long* dbg_stamps = nullptr;  // device trace buffer for ILSX_STAMP (debug): [launch][ILSX_TRACE_MAXWG][ILSX_TRACE_SLOTS]
+  int dbg_launches = 0, dbg_max_launches = 0;
+  unsigned long long* dbg_next() {   // slab of the next instrumented launch, or nullptr when tracing is off / full
+    if (!dbg_stamps || dbg_launches >= dbg_max_launches) return nullptr;
+    return dbg_stamps + (size_t)(dbg_launches++) * ILSX_TRACE_MAXWG * ILSX_TRACE_SLOTS;
+  }
   void* comm = nullptr;   // ncclComm_t of a split run (ilsx_comm.hip); collectives go on `stream`
   int comm_n = 0, comm_rank = 0;
   bool prof_on = false;
@@ -84,6 +89,25 @@ struct ProfScope {
 
 int comm_allreduce_sum(ilsx_ctx* c, float* buf, size_t n);   // in place, on c->stream
 int ctx_alloc(ilsx_ctx* c, size_t bytes, void** out, bool zero = true);
+// One allocation carved into many buffers.  Every buffer an agent touches in a step then sits in ONE virtually contiguous
+// range (a handful of 2 MiB translation fragments) instead of ~60 separate hipMalloc's: a kernel that reads a dozen of them
+// as its first operands otherwise pays a dozen page-table walks before its first useful byte (measured: the first operands of
+// the backward launch landed 2.5 us after workgroup start, the weights — one allocation — after 0.55 us).
+struct Slab {
+  std::vector<std::pair<void**, size_t>> items;
+  size_t bytes = 0;
+  template <class T> void add(T** p, size_t count) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    items.push_back({(void**)p, bytes});
+    bytes += count * sizeof(T);
+  }
+  int commit(ilsx_ctx* c, void** base) {   // zero-filled
+    int rc = ctx_alloc(c, bytes ? bytes : 256, base, true);
+    if (rc != ILSX_OK) return rc;
+    for (auto& it : items) *it.first = (char*)*base + it.second;
+    return ILSX_OK;
+  }
+};
 int ctx_free(ilsx_ctx* c, void* p);
 int ctx_stage(ilsx_ctx* c, size_t bytes, void** out);
 

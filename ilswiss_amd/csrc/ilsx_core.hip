@@ -331,9 +331,12 @@ static int kernels_init_once() {
     }                                                                  \
   } while (0)
 
-extern "C" int ilsx_debug_set_stamp_buffer(ilsx_ctx* c, void* dev_u64x16) {
+extern "C" int ilsx_debug_set_stamp_buffer(ilsx_ctx* c, void* dev_trace, int max_launches, int* launches_so_far) {
   if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
-  c->dbg_stamps = (unsigned long long*)dev_u64x16;
+  if (launches_so_far) *launches_so_far = c->dbg_launches;
+  c->dbg_stamps = (unsigned long long*)dev_trace;
+  c->dbg_max_launches = dev_trace ? max_launches : 0;
+  c->dbg_launches = 0;
   return ILSX_OK;
 }
 
@@ -353,7 +356,7 @@ static size_t bwd_split_lds_bytes(int H, int cs) {
 int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int cs) {
   if (A0.rows <= 0) return ILSX_OK;
   FwdArgs A = A0;
-  A.dbg = ctx->dbg_stamps;
+  A.dbg = ctx->dbg_next();
   ProfScope ps(ctx, ILSX_K_MLP_FWD);
   if (cs > 1) {
     const size_t lds = fwd_split_lds_bytes(H, KPmax, cs);
@@ -393,7 +396,7 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
 int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
   if (A0.rows <= 0) return ILSX_OK;
   BwdArgs A = A0;
-  A.dbg = ctx->dbg_stamps;
+  A.dbg = ctx->dbg_next();
   if (A.ga_parts < 1) A.ga_parts = 1;
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
   if (cs > 1) {
@@ -435,7 +438,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
   D.rows_all = rows;
   memset(&D.F, 0, sizeof D.F);
   if (fuse) D.F = *fuse;
-  D.dbg = ctx->dbg_stamps ? ctx->dbg_stamps + 4 : nullptr;
+  D.dbg = ctx->dbg_next();
   D.xs = ctx->xcd_shift;
   D.splits = 1; D.rows_per_split = rows; D.scratch = nullptr; D.span = 0;
   bool stacked = false;

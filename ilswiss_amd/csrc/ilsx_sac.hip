@@ -56,6 +56,7 @@ struct ilsx_sac {
   NetLayout Lq, Lp;
   int o = 0, a = 0;
   size_t nq = 0, np = 0;     // internal floats per critic / policy
+  void* slab = nullptr;      // the agent's one device allocation: scal | P | G | M | V | workspace
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
   DevScalars* scal = nullptr;
   SacWs ws;
@@ -209,30 +210,28 @@ __global__ void k_sac_refresh_adam(DevScalars* sc, float qf_lr, float policy_lr,
 static int sac_refresh_adam(struct ilsx_sac* s);
 
 // ------------------------------------------------------------------------------------------------
-static int sac_alloc_ws(ilsx_sac* s) {
-  ilsx_ctx* c = s->ctx;
+static void sac_plan_ws(ilsx_sac* s, Slab& L) {
   const size_t B = (size_t)s->cfg.max_batch;
   const int o = s->o, a = s->a, H = s->Lq.cfg.hidden;
   SacWs& w = s->ws;
-  auto A = [&](float** p, size_t n) { return ctx_alloc(c, n * sizeof(float), (void**)p, true); };
-  ILSX_TRY(A(&w.s, B * o)); ILSX_TRY(A(&w.a, B * a)); ILSX_TRY(A(&w.r, B)); ILSX_TRY(A(&w.d, B));
-  ILSX_TRY(A(&w.s2, B * o)); ILSX_TRY(A(&w.eps1, B * a)); ILSX_TRY(A(&w.eps2, B * a));
+  auto A = [&](float** p, size_t n) { L.add(p, n); };
+  A(&w.s, B * o); A(&w.a, B * a); A(&w.r, B); A(&w.d, B);
+  A(&w.s2, B * o); A(&w.eps1, B * a); A(&w.eps2, B * a);
   const size_t CS = (size_t)s->cs;
-  ILSX_TRY(A(&w.a2, B * a)); ILSX_TRY(A(&w.logp2, B)); ILSX_TRY(A(&w.q1, CS * B)); ILSX_TRY(A(&w.q2, CS * B));
-  ILSX_TRY(A(&w.tq1, CS * B)); ILSX_TRY(A(&w.tq2, CS * B)); ILSX_TRY(A(&w.ppart, CS * B * 2 * a));
-  ILSX_TRY(A(&w.ppart2, CS * B * 2 * a));
+  A(&w.a2, B * a); A(&w.logp2, B); A(&w.q1, CS * B); A(&w.q2, CS * B);
+  A(&w.tq1, CS * B); A(&w.tq2, CS * B); A(&w.ppart, CS * B * 2 * a);
+  A(&w.ppart2, CS * B * 2 * a);
   for (int i = 0; i < 2; ++i) {
-    ILSX_TRY(A(&w.xq[i], B * s->Lq.KP));
-    for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) { ILSX_TRY(A(&w.hq[i][l], B * H)); ILSX_TRY(A(&w.dq[i][l], B * H)); }
-    ILSX_TRY(A(&w.dhq[i], B * 4));
-    ILSX_TRY(A(&w.ga[i], CS * B * a));
+    A(&w.xq[i], B * s->Lq.KP);
+    for (int l = 0; l < s->Lq.cfg.n_hidden; ++l) { A(&w.hq[i][l], B * H); A(&w.dq[i][l], B * H); }
+    A(&w.dhq[i], B * 4);
+    A(&w.ga[i], CS * B * a);
   }
-  ILSX_TRY(A(&w.raw, B * 2 * a)); ILSX_TRY(A(&w.an, B * a)); ILSX_TRY(A(&w.logp, B)); ILSX_TRY(A(&w.epss, B * a));
-  ILSX_TRY(A(&w.q1n, CS * B)); ILSX_TRY(A(&w.q2n, CS * B));
-  ILSX_TRY(A(&w.xp, B * s->Lp.KP));
-  for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) { ILSX_TRY(A(&w.hp[l], B * H)); ILSX_TRY(A(&w.dp[l], B * H)); }
-  ILSX_TRY(A(&w.dhp, B * 2 * a));
-  return ILSX_OK;
+  A(&w.raw, B * 2 * a); A(&w.an, B * a); A(&w.logp, B); A(&w.epss, B * a);
+  A(&w.q1n, CS * B); A(&w.q2n, CS * B);
+  A(&w.xp, B * s->Lp.KP);
+  for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) { A(&w.hp[l], B * H); A(&w.dp[l], B * H); }
+  A(&w.dhp, B * 2 * a);
 }
 
 extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net* pi, ilsx_net* q1, ilsx_net* q2,
@@ -260,12 +259,11 @@ extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net*
   s->rng_stream = ctx->next_rng_stream;
   ctx->next_rng_stream += 2;
   const size_t nP = 4 * s->nq + s->np, nT = 2 * s->nq + s->np;
-  int rc = ctx_alloc(ctx, nP * 4, (void**)&s->P);
-  if (rc == ILSX_OK) rc = ctx_alloc(ctx, (nT + 4) * 4, (void**)&s->G);
-  if (rc == ILSX_OK) rc = ctx_alloc(ctx, nT * 4, (void**)&s->M);
-  if (rc == ILSX_OK) rc = ctx_alloc(ctx, nT * 4, (void**)&s->V);
-  if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(DevScalars), (void**)&s->scal);
-  if (rc == ILSX_OK) rc = sac_alloc_ws(s);
+  Slab L;   // parameters, optimiser state, scalars and the whole step workspace: one allocation (see Slab)
+  L.add(&s->scal, 1);
+  L.add(&s->P, nP); L.add(&s->G, nT + 4); L.add(&s->M, nT); L.add(&s->V, nT);
+  sac_plan_ws(s, L);
+  int rc = L.commit(ctx, &s->slab);
   if (rc != ILSX_OK) { delete s; return rc; }
   // adopt the networks' storage: copy into the arena, targets = copies (sac_alpha.py:60-61)
   hipStream_t st = ctx->stream;
@@ -320,7 +318,7 @@ extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
     }
   }
   // workspace / arenas are released with the ctx (ctx owns every allocation); free the big ones now
-  ctx_free(s->ctx, s->P); ctx_free(s->ctx, s->G); ctx_free(s->ctx, s->M); ctx_free(s->ctx, s->V);
+  ctx_free(s->ctx, s->slab);
   delete s;
   return ILSX_OK;
 }

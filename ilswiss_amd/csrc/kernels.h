@@ -93,17 +93,32 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t step, uin
                                                uint32_t quad, float (&z)[4]) {
   uint32_t c[4] = {row, quad, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream * 0x9E3779B9u)};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
-  const float r0 = sqrtf(-2.0f * logf(u01_open(c[0]))), r1 = sqrtf(-2.0f * logf(u01_open(c[2])));
-  const float t0 = 6.28318530717958647692f * u01_open(c[1]), t1 = 6.28318530717958647692f * u01_open(c[3]);
-  z[0] = r0 * cosf(t0); z[1] = r0 * sinf(t0); z[2] = r1 * cosf(t1); z[3] = r1 * sinf(t1);
+  // Box-Muller on the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, and v_sin_f32 / v_cos_f32, which take their argument
+  // in REVOLUTIONS — sin(2*pi*u) is one instruction on u.  ~1e-6 absolute accuracy: a sample of N(0,1) needs no more, and the
+  // libm forms (range reduction for the 2*pi*u arguments) were ~200 of the ~1000 instructions of the policy epilogue, each of
+  // which costs 4 cycles on the one wave per SIMD these kernels run (tools/ubench/icache.hip).
+  const float u0 = u01_open(c[0]), u2 = u01_open(c[2]);
+  const float r0 = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u0));   // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+  const float r1 = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u2));
+  const float t0 = u01_open(c[1]), t1 = u01_open(c[3]);
+  z[0] = r0 * __builtin_amdgcn_cosf(t0); z[1] = r0 * __builtin_amdgcn_sinf(t0);
+  z[2] = r1 * __builtin_amdgcn_cosf(t1); z[3] = r1 * __builtin_amdgcn_sinf(t1);
+}
+
+// Workgroup barrier for LDS hand-offs: waits for the LDS / scalar queue only.  __syncthreads() also drains the vector-memory
+// counter (the acknowledgement of every global STORE the phase before it issued), an ordering nothing in these kernels needs
+// (no thread reads another thread's global store within a launch).  Loads whose results are still in flight stay tracked by
+// the compiler's own waitcnt insertion.  (Measured neutral on the SAC step; kept because it removes a false dependency.)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // block-wide sum of one float per thread (256 threads); result valid in every thread
 __device__ __forceinline__ float block256_sum(float v, float* sh) {
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();
+  lds_barrier();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
@@ -167,8 +182,14 @@ template <int ACT> __device__ __forceinline__ float act_grad_from_out(float h) {
 }
 
 
-// phase timestamps (shader clock) of workgroup (0,0), wave 0: debugging aid, off unless a buffer is set
-#define ILSX_STAMP(dbg, i) do { if ((dbg) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (dbg)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// Phase timestamps of EVERY workgroup of a launch (thread 0 of each): debugging aid, off unless a trace buffer is set
+// (ilsx_debug_set_stamp_buffer).  Record layout: dbg[wg_linear][ILSX_TRACE_SLOTS] of wall_clock64() ticks (the 100 MHz constant
+// clock every XCD shares, so start / end times of different workgroups are comparable); tools/step_gantt.py reads it.  A stamp is
+// only a reliable marker right after a barrier (the compiler may sink the store past independent code).
+#define ILSX_TRACE_SLOTS 8
+#define ILSX_TRACE_MAXWG 2048
+#define ILSX_WG_LINEAR (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
+#define ILSX_STAMP(dbg, i) do { if ((dbg) && threadIdx.x == 0 && ILSX_WG_LINEAR < ILSX_TRACE_MAXWG) (dbg)[(size_t)ILSX_WG_LINEAR * ILSX_TRACE_SLOTS + (i)] = wall_clock64(); } while (0)
 
 // element (n,k) of a forward-packed matrix with K columns / of a backward-packed matrix with N rows
 __host__ __device__ __forceinline__ int pack_f(int n, int k, int K) {
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
   }
-  __syncthreads();
+  lds_barrier();
   ILSX_STAMP(A.dbg, 1);
 
   // ---- layer 0: K = KP (16 for Hopper, 400 for Humanoid critics), weights streamed with a 1-deep prefetch
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
         if (hs && r0 + row < rows) hs[(size_t)(r0 + row) * H + n0 + li] = h;
       }
     }
-    __syncthreads();
+    lds_barrier();
     ILSX_STAMP(A.dbg, 2 + l);
     if (l + 1 >= N.nhid) break;
     // layer l+1 straight out of registers
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   ILSX_STAMP(A.dbg, 6);
 
   // ---- head epilogue: wave <-> row, lane <-> output / action dim
@@ -577,8 +598,12 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
   } else if (T.loss == LOSS_TD3_POLICY) {
     // action = max_act*tanh(pre): d pre = dL/da * max_act * (1 - tanh(pre)^2)
     const float th = tanhf(T.raw[(size_t)gr * NO + j]);
-    float ga = 0.0f;   // dQ1/da, possibly in column-slice partial slabs
-    for (int pc = 0; pc < A.ga_parts; ++pc) ga += T.ga1[((size_t)pc * A.ga_stride + gr) * NO + j];
+    float ga = 0.0f;   // dQ1/da, possibly in column-slice partial slabs (<= 4: all requested before any is summed; a loop with a
+    float gp[4];       //   run-time trip count waits for its load on every trip)
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) { const float v = T.ga1[((size_t)(pc < A.ga_parts ? pc : 0) * A.ga_stride + gr) * NO + j]; gp[pc] = pc < A.ga_parts ? v : 0.0f; }
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) ga += gp[pc];
     d = ga * T.coef * (1.0f - th * th);
   } else if (T.loss == LOSS_BC_MLE || T.loss == LOSS_BC_MSE) {
     // bc.py:88-101.  raw = mean | log_std_raw [rows][2a]; act_all = expert actions [rows][a]
@@ -623,8 +648,15 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
     const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
     const float sd = expf(ls), ep = T.eps[(size_t)gr * a + jj], act = T.action[(size_t)gr * a + jj];
     float ga = 0.0f;  // d(-min Q)/da~: both critics, each possibly in column-slice partial slabs
-    for (int pc = 0; pc < A.ga_parts; ++pc)
-      ga += T.ga1[((size_t)pc * A.ga_stride + gr) * a + jj] + T.ga2[((size_t)pc * A.ga_stride + gr) * a + jj];
+    float g1[4], g2[4];   // <= 4 slabs per critic: all requested before any is summed
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+      const size_t at = ((size_t)(pc < A.ga_parts ? pc : 0) * A.ga_stride + gr) * a + jj;
+      const float v1 = T.ga1[at], v2 = T.ga2[at];
+      g1[pc] = pc < A.ga_parts ? v1 : 0.0f; g2[pc] = pc < A.ga_parts ? v2 : 0.0f;
+    }
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) ga += g1[pc] + g2[pc];
     const float om = 1.0f - act * act;
     const float dz = ga * om + glp * (2.0f * act * om / (om + TANH_EPS));
     if (j < a) {
@@ -670,7 +702,7 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
     }
     dout[row * ILSX_MAX_NO + j] = d;
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- delta_{L-1} = (dout Wh) * act'(h_{L-1}): small contraction (NO <= 64) on the VALU
   {
@@ -689,7 +721,7 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
       bufA[row * LDH + k] = dv;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- delta_{l-1} = (delta_l W_l) * act'(h_{l-1})  for l = L-1 .. 1   (matrix pipe, W_l from registers)
   float* cur = bufA;
@@ -721,7 +753,7 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
       }
       nxt[row * LDH + col] = dv;
     }
-    __syncthreads();
+    lds_barrier();
     cur = nxt;
   }
 
@@ -854,6 +886,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     }
     xs[r * LDX + k] = v;
   }
+  bool fin_logp = false;
   if (fin) {
     // the action columns are pi's output: combine its CS head partials, squash (policies.py:262-283,
     // distributions.py:23-28,43-50,74-97); slice 0 of task 0 publishes action / logp / raw / eps for later kernels
@@ -862,22 +895,30 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     const int a = P.a, NOp = det ? a : 2 * a;
     const bool pub = lead && (GRP ? T.first != 0 : blockIdx.y == 0);
     float* lp3 = red;   // [16][32][3] log-prob contributions (quad, log_std, jacobian)
+    const unsigned long long fstep = P.scal ? P.scal->step : P.step_host;   // requested with the partials, not after them
     for (int e = tid; e < 16 * a; e += NTH) {
       const int row = e / a, j = e - row * a, gr = r0 + row;
       float act = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
       if (gr < rows) {
-        float mu = 0.f, lsr = 0.f;
-        for (int c = 0; c < P.cs; ++c) {
-          mu += P.part[((size_t)c * P.part_stride + gr) * NOp + j];
-          if (!det) lsr += P.part[((size_t)c * P.part_stride + gr) * NOp + a + j];
+        // the CS (<= 4) head partials: all requested before any is summed (a loop with a run-time trip count waits for its
+        // loads on every trip: four serial round trips at the head of the launch's longest dependent chain)
+        float pm[4], pl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const size_t at = ((size_t)(c < P.cs ? c : 0) * P.part_stride + gr) * NOp + j;
+          pm[c] = P.part[at];
+          pl[c] = det ? 0.0f : P.part[at + a];
         }
+        float mu = 0.f, lsr = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { mu += c < P.cs ? pm[c] : 0.0f; lsr += c < P.cs ? pl[c] : 0.0f; }   // slab order
         float ep = 0.0f;
         if (!det || P.noise != 0.0f) {
           if (P.eps) {
             ep = P.eps[(size_t)gr * a + j];
           } else {
             float z4[4];
-            philox_normal4(P.seed, P.scal ? P.scal->step : P.step_host, P.rng_stream, gr, j >> 2, z4);
+            philox_normal4(P.seed, fstep, P.rng_stream, gr, j >> 2, z4);
             const int q = j & 3;
             ep = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
           }
@@ -904,17 +945,16 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
       xs[row * LDX + T.d0 + j] = act;
       lp3[(row * 32 + j) * 3 + 0] = c0; lp3[(row * 32 + j) * 3 + 1] = c1; lp3[(row * 32 + j) * 3 + 2] = c2;
     }
-    if (pub && P.logp && !det) {
-      __syncthreads();
-      if (tid < 16 && r0 + tid < rows) {
-        float q = 0.f, l = 0.f, jc = 0.f;
-        for (int j = 0; j < a; ++j) { q += lp3[(tid * 32 + j) * 3]; l += lp3[(tid * 32 + j) * 3 + 1]; jc += lp3[(tid * 32 + j) * 3 + 2]; }
-        P.logp[r0 + tid] = -0.5f * q - (l + HALF_LOG_2PI) - jc;
-      }
-    }
+    fin_logp = pub && P.logp && !det;
   }
-  __syncthreads();
+  lds_barrier();
   ILSX_STAMP(A.dbg, 1);
+  if (fin_logp && tid < 16 && r0 + tid < rows) {   // log pi of the tile's rows from the staged contributions: after the tile's ONE
+    const PolicyFinishArgs& P = GRP ? GP->fin : A.fin;   // barrier instead of behind a barrier of its own (`red` is next written two
+    float q = 0.f, l = 0.f, jc = 0.f;                    // barriers from here)
+    for (int j = 0; j < P.a; ++j) { q += red[(tid * 32 + j) * 3]; l += red[(tid * 32 + j) * 3 + 1]; jc += red[(tid * 32 + j) * 3 + 2]; }
+    P.logp[r0 + tid] = -0.5f * q - (l + HALF_LOG_2PI) - jc;
+  }
   // ---- layer 0, full width: CS column tiles per wave
   {
     f32x4 acc[CS];
@@ -953,7 +993,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   ILSX_STAMP(A.dbg, 2);
   // ---- layer 1, this slice: straight out of registers
   {
@@ -974,7 +1014,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
       if (hsv && r0 + row < rows) hsv[(size_t)(r0 + row) * H + col1] = h;
     }
   }
-  __syncthreads();
+  lds_barrier();
   ILSX_STAMP(A.dbg, 3);
   // ---- head partial sums over this column slice on the matrix pipe: wave w contracts k16 chunk w of the
   //      slice for every 16-output tile, the NWV partial tiles are summed through LDS
@@ -991,7 +1031,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   const float* bh = N.base + N.off_bh;
   for (int e = tid; e < NOT * 256; e += NTH) {
     const int t = e >> 8, v = (e >> 6) & 3, ol = e & 63;
@@ -1001,7 +1041,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     const int row = 4 * (ol >> 4) + v, j = 16 * t + (ol & 15), gr = r0 + row;
     if (j < NO && gr < rows) T.part[((size_t)cs * A.part_stride + gr) * NO + j] = sum + (lead ? bh[j] : 0.0f);
   }
-  __syncthreads();   // the next row tile reuses xs / h0 / hs / red
+  lds_barrier();   // the next row tile reuses xs / h0 / hs / red
   }  // rt
   ILSX_STAMP(A.dbg, 7);
 }
@@ -1069,7 +1109,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int r0 = (blockIdx.x >> A.xs) * 16, rows = A.rows, cs = blockIdx.z;
   const bool lead = cs == 0;
-  ILSX_STAMP(A.dbg, 8);
+  ILSX_STAMP(A.dbg, 0);
 
   // ---- operands of the later phases, requested first (they land while the loss head is evaluated)
   const int k1 = tid % H, rb1 = tid / H;
@@ -1086,18 +1126,26 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
     const int gr = r0 + 4 * g + v;
     h0v[v] = gr < rows ? T.hsave[0][(size_t)gr * H + col0] : 0.0f;
   }
-  // first-layer weights of the dL/dx partial (last phase): they depend on (lane, column) only, so they are requested here with
-  // the other operands instead of as dx_cols dependent loads per row at the end of the kernel
-  constexpr int DXP = 8;
-  float w0dx[DXP][KPL];
+  // head weights of this thread's column for the delta_1 phase: requested now (inside that phase's loop they were dependent loads)
+  constexpr int WHP = 12;
+  float whp[WHP];
+#pragma unroll
+  for (int j = 0; j < WHP; ++j) whp[j] = (N.base + N.off_Wh)[(size_t)(j < NO ? j : 0) * H + k1];
+  // first-layer weights of the dL/dx partial (last phase) as MFMA B fragments, requested here with the other operands: wave w
+  // contracts k16 chunk w of this slice, lane (g, li) supplies W0[n = slice + 16w + 4g + s][column dx_col0 + 16t + li], s = 0..3
+  constexpr int DXT = 2;   // 16-column tiles of dL/dx (dx_cols <= 32: a = 17 for Humanoid)
+  static_assert(SLW / 16 == NWV, "one k16 chunk of the slice per wave in the dL/dx phase");
+  float w0b[DXT][4];
   if (T.dx) {
     const float* W0 = N.base + N.off_W[0];
     const int ld0 = N.ld[0];
 #pragma unroll
-    for (int c = 0; c < DXP; ++c)
+    for (int t = 0; t < DXT; ++t)
 #pragma unroll
-      for (int i = 0; i < KPL; ++i)
-        w0dx[c][i] = c < T.dx_cols ? W0[pack_f(cs * SLW + lane + 64 * i, T.dx_col0 + c, ld0)] : 0.0f;
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int c = 16 * t + li;
+        w0b[t][s4] = c < T.dx_cols ? W0[pack_f(cs * SLW + 16 * wave + 4 * g + s4, T.dx_col0 + c, ld0)] : 0.0f;
+      }
   }
   // ---- head gradient (every slice recomputes it; the lead slice publishes it for the dW kernel)
   for (int e = tid; e < 16 * NO; e += NTH) {  // only the NO live outputs per row: one pass, loads batched
@@ -1116,16 +1164,23 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
 #pragma unroll
     for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
   }
-  __syncthreads();
-  ILSX_STAMP(A.dbg, 9);
+  lds_barrier();
+  ILSX_STAMP(A.dbg, 1);
   // ---- delta_1 = (dout Wh) * act'(h_1), full width on the VALU: thread <-> column k1
   {
     const float* Wh = N.base + N.off_Wh;
     float accd[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) accd[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < WHP; ++j) {   // head rows requested at kernel entry (critics: 1, Hopper / Walker policies: 6 / 12)
+      if (j < NO) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) accd[i] = fmaf(dout[(rb1 + RSTEP * i) * ILSX_MAX_NO + j], whp[j], accd[i]);
+      }
+    }
 #pragma unroll 4
-    for (int j = 0; j < NO; ++j) {
+    for (int j = WHP; j < NO; ++j) {
       const float w = Wh[(size_t)j * H + k1];
 #pragma unroll
       for (int i = 0; i < RPT; ++i) accd[i] = fmaf(dout[(rb1 + RSTEP * i) * ILSX_MAX_NO + j], w, accd[i]);
@@ -1142,8 +1197,8 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
       d1[row * LDH + k1] = dv;
     }
   }
-  __syncthreads();
-  ILSX_STAMP(A.dbg, 10);
+  lds_barrier();
+  ILSX_STAMP(A.dbg, 2);
   // ---- delta_0 slice = (delta_1 W_1)[:, slice] * act'(h_0[:, slice])
   {
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -1166,37 +1221,36 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
       d0s[row * LDSL + lc] = dv;
     }
   }
-  ILSX_STAMP(A.dbg, 11);
-  // ---- partial dL/dx over this slice of the H contraction
+  ILSX_STAMP(A.dbg, 3);
+  // ---- partial dL/dx over this slice of the H contraction, on the matrix pipe: dx[16 rows][dx_cols] = d0s[16][SLW] . W0[slice][cols].
+  //      (The first version reduced every (row, column) with a 6-step wave shuffle: 12 dependent butterflies per wave were 3 us of the
+  //      actor's critic-backward launch.)  Wave w contracts k16 chunk w; the NWV partial tiles are summed through LDS in wave order.
   if (T.dx) {
-    __syncthreads();
-    const float* W0 = N.base + N.off_W[0];
-    const int ld0 = N.ld[0];
+    lds_barrier();
+    float* red = d1;   // delta_1 is dead (every wave passed the barrier above after its last read): [DXT][NWV][4][64] floats
+    const float4 a4 = *reinterpret_cast<const float4*>(d0s + li * LDSL + 16 * wave + 4 * g);
+    const int ntile = (T.dx_cols + 15) >> 4;
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int row = wave * RPW + rr, gr = r0 + row;
-      float dv[KPL];
+    for (int t = 0; t < DXT; ++t) {
+      if (t < ntile) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc = MFMA16(a4.x, w0b[t][0], acc); acc = MFMA16(a4.y, w0b[t][1], acc);
+        acc = MFMA16(a4.z, w0b[t][2], acc); acc = MFMA16(a4.w, w0b[t][3], acc);
 #pragma unroll
-      for (int i = 0; i < KPL; ++i) dv[i] = d0s[row * LDSL + lane + 64 * i];
-#pragma unroll
-      for (int c = 0; c < DXP; ++c) {
-        if (c >= T.dx_cols) break;
-        float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < KPL; ++i) s = fmaf(dv[i], w0dx[c][i], s);
-        s = wave_sum(s);
-        if (lane == 0 && gr < rows) T.dx[((size_t)cs * A.part_stride + gr) * T.dx_cols + c] = s;
-      }
-      for (int c = DXP; c < T.dx_cols; ++c) {
-        float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < KPL; ++i) s = fmaf(dv[i], W0[pack_f(cs * SLW + lane + 64 * i, T.dx_col0 + c, ld0)], s);
-        s = wave_sum(s);
-        if (lane == 0 && gr < rows) T.dx[((size_t)cs * A.part_stride + gr) * T.dx_cols + c] = s;
+        for (int v = 0; v < 4; ++v) red[((t * NWV + wave) * 4 + v) * 64 + lane] = acc[v];
       }
     }
+    lds_barrier();
+    for (int e = tid; e < ntile * 256; e += NTH) {
+      const int t = e >> 8, v = (e >> 6) & 3, ol = e & 63;
+      float sum = 0.0f;
+#pragma unroll
+      for (int w2 = 0; w2 < NWV; ++w2) sum += red[((t * NWV + w2) * 4 + v) * 64 + ol];
+      const int row = 4 * (ol >> 4) + v, c = 16 * t + (ol & 15), gr = r0 + row;
+      if (c < T.dx_cols && gr < rows) T.dx[((size_t)cs * A.part_stride + gr) * T.dx_cols + c] = sum;
+    }
   }
-  ILSX_STAMP(A.dbg, 12);
+  ILSX_STAMP(A.dbg, 7);
 }
 #endif  // ILSX_KERNEL_IMPL
 
@@ -1303,7 +1357,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   const bool n_ok = nsub + li < J.NA;
   int ntk = (J.NB - k0 + 15) / 16;
   if (ntk > 4) ntk = 4;
-  if (D.dbg && bx == 5 && tid == 0) D.dbg[0] = __builtin_amdgcn_s_memtime();
+  ILSX_STAMP(D.dbg, 0);
   // ---- the two output elements this thread will finish (and their optimiser operands, requested now)
   float* g0p[2]; float* g1p[2]; bool live[2];
   AdamOperands ao[2];
@@ -1364,7 +1418,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
         bsum += (rc + 128 * u + 4 * g + s < brows) ? a[u][s] : 0.0f;
       }
   }
-  if (D.dbg && bx == 5 && tid == 0) D.dbg[1] = __builtin_amdgcn_s_memtime();
+  ILSX_STAMP(D.dbg, 1);
   // partial tiles -> LDS
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -1373,8 +1427,8 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   bsum += __shfl_xor(bsum, 16, 64);
   bsum += __shfl_xor(bsum, 32, 64);
   if (g == 0) bpart[wave * 16 + li] = bsum;
-  __syncthreads();
-  if (D.dbg && bx == 5 && tid == 0) D.dbg[2] = __builtin_amdgcn_s_memtime();
+  lds_barrier();
+  ILSX_STAMP(D.dbg, 2);
   // sum the 8 row-partials; thread <-> (n-half, tile, reg, lane)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1398,7 +1452,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
     *gbp = s;
     if (F.on) adam_apply(F, ad_step, ad_bc2s, aob, (size_t)(gbp - F.Gbase), 0, false, s);
   }
-  if (D.dbg && bx == 5 && tid == 0) D.dbg[3] = __builtin_amdgcn_s_memtime();
+  ILSX_STAMP(D.dbg, 7);
 }
 
 // Sum the row-range slabs of a split weight-gradient launch in slab order, store the gradient, and apply the optimiser

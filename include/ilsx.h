@@ -99,9 +99,12 @@ int ilsx_prof_reset(ilsx_ctx* ctx);
 int ilsx_prof_read(ilsx_ctx* ctx, int kernel_id, uint64_t* launches, double* total_ms);
 const char* ilsx_prof_kernel(ilsx_ctx* ctx, int kernel_id);
 const char* ilsx_kernel_name(int kernel_id);
-/* debugging aid: workgroup (0,0) of the MLP forward kernel writes shader-clock phase stamps into a
- * device uint64[16] buffer (NULL = off). */
-int ilsx_debug_set_stamp_buffer(ilsx_ctx* ctx, void* dev_u64x16);
+/* debugging aid (tools/step_gantt.py): while a trace buffer is set, thread 0 of EVERY workgroup of every MLP forward /
+ * backward / weight-gradient launch writes its phase timestamps (100 MHz constant clock) into
+ * dev_trace[launch][2048 workgroups][8 slots] (uint64; launch = order of launch since the buffer was set, at most
+ * max_launches; slot 0 = workgroup start, 7 = end, 1..3 = phase boundaries).  NULL = off; launches_so_far (nullable)
+ * receives the number of launches recorded into the PREVIOUS buffer. */
+int ilsx_debug_set_stamp_buffer(ilsx_ctx* ctx, void* dev_trace, int max_launches, int* launches_so_far);
 
 /* ---------------------------------------------------------------- networks
  * Replaces rlkit/torch/common/networks.py:23-115 (Mlp / FlattenMlp) and the heads of
