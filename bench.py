@@ -137,11 +137,19 @@ def synth_rows(rng, n):
             rng.standard_normal((n, O), dtype=np.float32))
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle (numpy fp32 restatement of sac_alpha.py:78-181 + replay gather) timed on the host cores."""
+def cpu_baseline(budget_s=8.0):
+    """SURVEY §8d's CPU legs on the GPU box's host cores, same synthetic inputs as the GPU run (C2):
+      * `value`: the numpy oracle (oracle/sac_alpha.py, hand-written backward) — replay gather + train_step, all BLAS threads;
+      * `torch_cpu`: the PyTorch-CPU restatement (oracle/sac_alpha_torch.py: autograd + torch.optim.Adam, the reference's own
+        idiom, ~1.8k ATen calls per step) at 1 thread and at all cores, train_step alone and with random_batch + conversion;
+      * `get_actions_ms`: policy inference for 4096 observations (policies.py:245-246) on the same cores.
+    Bounded samples (a few seconds each) so the default run stays within minutes."""
+    import torch
+
     from oracle import mlp as omlp
     from oracle.replay import ReplayOracle
     from oracle.sac_alpha import SacAlphaOracle
+    from oracle.sac_alpha_torch import SacAlphaTorch, _mlp
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
@@ -149,29 +157,47 @@ def cpu_baseline(budget_s=12.0):
         cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
     hid = [H, H]
-    orc = SacAlphaOracle(O, A, hid, omlp.init_mlp(rng, O, hid, A, init_w=1e-3, n_heads=2),
-                         omlp.init_mlp(rng, O + A, hid, 1), omlp.init_mlp(rng, O + A, hid, 1),
-                         **{k: v for k, v in SAC_KW.items()})
+    init = (omlp.init_mlp(rng, O, hid, A, init_w=1e-3, n_heads=2), omlp.init_mlp(rng, O + A, hid, 1), omlp.init_mlp(rng, O + A, hid, 1))
+    orc = SacAlphaOracle(O, A, hid, *init, **SAC_KW)
     n = 100_000
     rb = ReplayOracle(n, O, A)
     ob, ac, rw, dn, nob = synth_rows(rng, n)
     rb.obs[:], rb.act[:], rb.rew[:, 0], rb.term[:, 0], rb.next_obs[:] = ob, ac, rw, dn, nob
     rb.size = n
 
-    def one():
+    def batch():
         bt = rb.gather(rb.draw_indices(B))
         bt["terminals"] = bt["terminals"].astype(np.float32)
-        orc.train_step(bt, rng.standard_normal((B, A), dtype=np.float32), rng.standard_normal((B, A), dtype=np.float32))
-    for _ in range(3):
-        one()
-    t0, k = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s:
-        one()
-        k += 1
-    dt = time.perf_counter() - t0
-    return dict(value=k / dt, unit="grad-steps/s", cores=int(cores), kind="port",
-                sample=f"{k} SAC-alpha grad steps (replay gather + train_step, B={B}, H={H}, Hopper dims) in {dt:.1f} s, "
-                       "oracle/sac_alpha.py numpy fp32")
+        return bt
+
+    def timed(fn, budget):
+        for _ in range(3):
+            fn()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget:
+            fn()
+            k += 1
+        return k, time.perf_counter() - t0
+    eps = lambda: rng.standard_normal((B, A), dtype=np.float32)   # noqa: E731
+    k, dt = timed(lambda: orc.train_step(batch(), eps(), eps()), budget_s)
+    out = dict(value=k / dt, unit="grad-steps/s", cores=int(cores), kind="port",
+               sample=f"{k} SAC-alpha grad steps (replay gather + train_step, B={B}, H={H}, Hopper dims) in {dt:.1f} s, "
+                      "oracle/sac_alpha.py numpy fp32")
+    tc = {}
+    ncpu = os.cpu_count() or 1
+    fixed = batch()
+    for threads in (1, ncpu):
+        torch.set_num_threads(threads)
+        ag = SacAlphaTorch(O, A, hid, *init, **SAC_KW)
+        k1, d1 = timed(lambda: ag.train_step(fixed, eps(), eps()), budget_s / 4)
+        k2, d2 = timed(lambda: ag.train_step(batch(), eps(), eps()), budget_s / 4)
+        obs4096 = torch.as_tensor(rng.standard_normal((N_ENV, O), dtype=np.float32))
+        with torch.no_grad():
+            k3, d3 = timed(lambda: torch.tanh(_mlp(ag.pi_p, obs4096, 2, 2)[0] + torch.randn(N_ENV, A)).numpy(), 0.5)
+        tc[f"threads_{threads}"] = dict(train_step_per_s=k1 / d1, sample_convert_train_step_per_s=k2 / d2, get_actions_ms_4096=1e3 * d3 / k3)
+    out["torch_cpu"] = dict(tc, note="oracle/sac_alpha_torch.py (autograd + torch.optim.Adam), fp32, same inputs; "
+                                     f"host has {ncpu} logical cores")
+    return out
 
 
 def spawn_ranks(n, argv):
@@ -408,6 +434,22 @@ def main():
         roofline_replay = dict(bound="hbm", kernel="k_replay_sample_many", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
                                frac=gbs / PEAK_HBM_GBS, traffic=pmc_traffic(6), avg_launch_us=ms.value * 1e3 / nl.value,
                                algorithmic_bytes_per_launch=alg_bytes)
+        # the same gather from a ring well past the 256 MB Infinity Cache (MI355X_MICROARCH.md): 4M records x 128 B = 512 MB, every
+        # sampled row a fresh HBM line — the 1e6-row ring of the headline config (128 MB) is cache-resident after the first pass
+        big = ia.SimpleReplayBuffer(4_000_000, O, A, random_seed=77, ctx=ctx)
+        chunk_rows = synth_rows(rng, 500_000)
+        for _ in range(8):
+            big.add_rows(*chunk_rows)
+        _lib.check(lib.ilsx_replay_sample_many(big.h, nb, B, out.ptr))
+        _lib.check(lib.ilsx_prof_reset(ctx.h))
+        _lib.check(lib.ilsx_prof_enable(ctx.h, 1))
+        for _ in range(10):
+            _lib.check(lib.ilsx_replay_sample_many(big.h, nb, B, out.ptr))
+        _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
+        _lib.check(lib.ilsx_prof_read(ctx.h, 6, C.byref(nl), C.byref(ms)))
+        gbs_big = alg_bytes / (ms.value * 1e-3 / nl.value) / 1e9
+        roofline_replay["beyond_infinity_cache"] = dict(ring_bytes=4_000_000 * rec.value * 4, achieved=gbs_big, frac=gbs_big / PEAK_HBM_GBS,
+                                                         avg_launch_us=ms.value * 1e3 / nl.value)
         result = dict(
             metric="env-steps/s + SAC grad-steps/s, Hopper-v2 4096 envs", value=grad_total / dt, unit="grad-steps/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,

@@ -213,6 +213,8 @@ PROTOTYPES = {
     "ilsx_replay_destroy": (C.c_int, [vp]),
     "ilsx_replay_add": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int]),
     "ilsx_replay_terminate_episode": (C.c_int, [vp]),
+    "ilsx_replay_set_absorbing": (C.c_int, [vp, C.c_int64, C.c_int, vp]),
+    "ilsx_replay_get_absorbing": (C.c_int, [vp, vp, C.c_int, vp]),
     "ilsx_replay_sample": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "ilsx_replay_sample_many": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "ilsx_replay_record_floats": (C.c_int, [vp, C.POINTER(C.c_int)]),

@@ -12,6 +12,7 @@ import csv
 import json
 import os
 import pickle
+import sys
 import time
 from collections import OrderedDict
 
@@ -38,12 +39,23 @@ class TabularLogger:
     def record_tabular(self, k, v):
         self.row[k] = v
 
+    def log(self, line, with_timestamp=True):
+        """logger.log (rlkit/core/logger.py:209-223): stdout + the text output `debug.log` (launcher_util.py:215,267-269)."""
+        if with_timestamp:
+            line = f"{time.strftime('%Y-%m-%d %H:%M:%S')} | {line}"
+        print(line)
+        if self.log_dir:
+            with open(os.path.join(self.log_dir, "debug.log"), "a") as f:
+                f.write(line + "\n")
+
     def dump_tabular(self):
         width = max(len(k) for k in self.row)
-        print("-" * (width + 18))
+        self.log("-" * (width + 18), with_timestamp=False)   # the reference prints the table through logger.log too (:306-307)
         for k, v in self.row.items():
-            print(f"{k:<{width}}  {v:>14.6g}" if isinstance(v, (int, float, np.floating, np.integer)) else f"{k:<{width}}  {v}")
-        print("-" * (width + 18), flush=True)
+            self.log(f"{k:<{width}}  {v:>14.6g}" if isinstance(v, (int, float, np.floating, np.integer)) else f"{k:<{width}}  {v}",
+                     with_timestamp=False)
+        self.log("-" * (width + 18), with_timestamp=False)
+        sys.stdout.flush()
         if self.log_dir:
             path = os.path.join(self.log_dir, "progress.csv")
             if self._header is None:

@@ -510,6 +510,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
     rec[o + na] = (float)reward;
     rec[o + na + 1] = (done && !A.no_terminal) ? 1.0f : 0.0f;   // base_algorithm.py:195-196,208-210
     for (int i = 0; i < o; ++i) rec[o + na + 2 + i] = ob[i];
+    rec[2 * o + na + 2] = 0.0f; rec[2 * o + na + 3] = 0.0f;   // absorbing = [0, 0] (base_algorithm.py:211-213)
   }
   if (A.auto_reset) {
     const int len = A.ep_len[env] + 1;

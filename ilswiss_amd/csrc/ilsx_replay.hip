@@ -1,8 +1,8 @@
 // ilsx_replay.hip — HBM-resident replay ring (rlkit/data_management/simple_replay_buffer.py:17-442,
 // env_replay_buffer.py:7-49).
 //
-// Layout: one transition = one record [obs(o) | act(a) | rew | done | next_obs(o) | pad] of
-// `rec` = round_up(2o+a+2, 32) floats, so a random-row gather touches whole 128-byte lines (Hopper:
+// Layout: one transition = one record [obs(o) | act(a) | rew | done | next_obs(o) | absorbing(2) | pad] of
+// `rec` = round_up(2o+a+4, 32) floats, so a random-row gather touches whole 128-byte lines (Hopper:
 // exactly one line per transition) instead of the 5-6 partial lines an SoA layout would cost.
 // HBM-bound: algorithmic bytes per sampled row = 2*(2o+a+2)*4 (read + write), SURVEY.md §8d.
 #include "host_common.h"
@@ -86,7 +86,7 @@ extern "C" int ilsx_replay_create(ilsx_ctx* ctx, int64_t capacity, int obs_dim, 
   rb->cap = capacity;
   rb->o = obs_dim;
   rb->a = act_dim;
-  rb->rec = (2 * obs_dim + act_dim + 2 + 31) / 32 * 32;
+  rb->rec = (2 * obs_dim + act_dim + 4 + 31) / 32 * 32;   // obs | act | rew | done | next_obs | absorbing[2] | pad (Hopper: 29 -> 32 floats)
   rb->seed = seed;
   rb->rng_stream = ctx->next_rng_stream++;
   rb->start_flag.assign((size_t)capacity, 0);
@@ -188,6 +188,42 @@ int replay_advance_device_rows(ilsx_replay* rb, int n) {
   for (int i = 0; i < n; ++i) host_advance(rb);
   rb->cur_start = rb->top;
   return replay_push_state(rb);
+}
+
+// _absorbing [cap, 2] (simple_replay_buffer.py:66-67,91-92) lives in the two floats behind next_obs of every record; add_sample
+// without the keyword leaves [0, 0] (k_replay_add zero-fills the pad).
+__global__ void k_replay_absorbing(float* data, int rec, long long cap, long long slot0, int n, int off, const float* absorbing, int set,
+                                   const long long* idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n) return;
+  const int r = i >> 1, c = i & 1;
+  long long slot = idx ? idx[r] : slot0 + r;
+  if (slot >= cap) slot -= cap;
+  float* p = data + (size_t)slot * rec + off + c;
+  if (set) *p = absorbing[i];
+  else const_cast<float*>(absorbing)[i] = *p;
+}
+extern "C" int ilsx_replay_set_absorbing(ilsx_replay* rb, int64_t slot0, int n, const float* absorbing_host) {
+  if (!rb || n < 0 || slot0 < 0 || slot0 >= rb->cap || n > rb->cap || (!absorbing_host && n)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_set_absorbing: bad argument");
+  if (n == 0) return ILSX_OK;
+  ilsx_ctx* ctx = rb->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  void* st = nullptr;
+  ILSX_TRY(ctx_stage(ctx, (size_t)n * 2 * sizeof(float), &st));
+  HIPCHK(hipMemcpyAsync(st, absorbing_host, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_replay_absorbing, dim3((2 * n + 255) / 256), dim3(256), 0, ctx->stream, rb->data, rb->rec, (long long)rb->cap,
+                     (long long)slot0, n, 2 * rb->o + rb->a + 2, (const float*)st, 1, (const long long*)nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused
+  return ILSX_OK;
+}
+extern "C" int ilsx_replay_get_absorbing(ilsx_replay* rb, const int64_t* idx, int n, float* absorbing) {
+  if (!rb || !idx || !absorbing || n < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_replay_get_absorbing: bad argument");
+  HIPCHK(hipSetDevice(rb->ctx->device));
+  hipLaunchKernelGGL(k_replay_absorbing, dim3((2 * n + 255) / 256), dim3(256), 0, rb->ctx->stream, rb->data, rb->rec, (long long)rb->cap,
+                     0ll, n, 2 * rb->o + rb->a + 2, (const float*)absorbing, 0, (const long long*)idx);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
 }
 
 extern "C" int ilsx_replay_terminate_episode(ilsx_replay* rb) {

@@ -1301,6 +1301,9 @@ struct DwTileG { DwMat J; AdamFuse F; };
 #define DW_LDS_BYTES ((16 * 16 * 64 + 16 * 16) * 4)
 
 #ifdef ILSX_KERNEL_IMPL
+// (Measured and rejected, round 2: nontemporal stores here — no change; system-scope write-through stores — the launch got
+//  1.8 us slower and the step lost 3 %.  The 4 us between this launch and the next one is not the L2 write-back of these lines.)
+#define ILSX_ST(ptr, val) (*(ptr) = (val))
 struct AdamOperands { float p, m, v, t; };
 __device__ __forceinline__ AdamOperands adam_prefetch(const AdamFuse& F, size_t i0) {
   AdamOperands o;
@@ -1313,12 +1316,12 @@ __device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float 
   const float m = o.m * F.b1 + (1.0f - F.b1) * g;
   const float v = o.v * F.b2 + (1.0f - F.b2) * g * g;
   const float p = o.p - step * (m / (sqrtf(v) / bc2s + F.eps));
-  F.M[i0] = m; F.V[i0] = v; F.P[i0] = p;
+  ILSX_ST(F.M + i0, m); ILSX_ST(F.V + i0, v); ILSX_ST(F.P + i0, p);
   float tg = 0.0f;
-  if (F.T) { tg = o.t * (1.0f - F.tau) + p * F.tau; F.T[i0] = tg; }
+  if (F.T) { tg = o.t * (1.0f - F.tau) + p * F.tau; ILSX_ST(F.T + i0, tg); }
   if (two) {  // second packing of the same matrix
-    F.M[i1] = m; F.V[i1] = v; F.P[i1] = p;
-    if (F.T) F.T[i1] = tg;
+    ILSX_ST(F.M + i1, m); ILSX_ST(F.V + i1, v); ILSX_ST(F.P + i1, p);
+    if (F.T) ILSX_ST(F.T + i1, tg);
   }
 }
 
@@ -1438,8 +1441,8 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * 2 + on) * 16 + t * 4 + v) * 64 + ol];
     if (live[h]) {
-      *g0p[h] = s;
-      if (g1p[h]) *g1p[h] = s;
+      ILSX_ST(g0p[h], s);
+      if (g1p[h]) ILSX_ST(g1p[h], s);
       if (F.on) adam_apply(F, ad_step, ad_bc2s, ao[h], (size_t)(g0p[h] - F.Gbase), g1p[h] ? (size_t)(g1p[h] - F.Gbase) : 0,
                            g1p[h] != nullptr, s);
     }

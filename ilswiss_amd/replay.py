@@ -75,14 +75,34 @@ class SimpleReplayBuffer:
     def terminate_episode(self):
         _lib.check(self.ctx.lib.ilsx_replay_terminate_episode(self.h))
 
-    def add_path(self, path, absorbing=False, env=None):  # simple_replay_buffer.py:134-216 (non-absorbing branch)
-        if absorbing:
-            raise NotImplementedError("absorbing-state wrapping is a 'next' row (SURVEY §8f rank 2)")
+    def add_path(self, path, absorbing=False, env=None):  # simple_replay_buffer.py:134-216
         n = len(path["rewards"])
-        ep_end = np.zeros(n, np.uint8)
+        if not absorbing:
+            ep_end = np.zeros(n, np.uint8)
+            ep_end[-1] = 1
+            self.add_rows(path["observations"], path["actions"], np.asarray(path["rewards"]).reshape(n),
+                          np.asarray(path["terminals"]).reshape(n), path["next_observations"], ep_end)
+            self._trajs += 1
+            return
+        # wrap_absorbing (:163-213): stored terminals are all False; a terminal transition is followed by
+        # (next_ob -> 0, absorbing [0,1]) and (0 -> 0, absorbing [1,1]) with freshly sampled actions and the same reward
+        obs, act, rew, nobs, ab = [], [], [], [], []
+        for ob, a_, r_, nob, term in zip(path["observations"], path["actions"], np.asarray(path["rewards"]).reshape(n),
+                                         path["next_observations"], np.asarray(path["terminals"]).reshape(n)):
+            obs.append(ob), act.append(a_), rew.append(r_), nobs.append(nob), ab.append((0.0, 0.0))
+            if term:
+                zero = np.zeros_like(nob)
+                obs.append(nob), act.append(env.action_space.sample()), rew.append(r_), nobs.append(zero), ab.append((0.0, 1.0))
+                obs.append(zero), act.append(env.action_space.sample()), rew.append(r_), nobs.append(zero), ab.append((1.0, 1.0))
+        m = len(rew)
+        if m > self._max_replay_buffer_size:
+            raise ValueError("path longer than the buffer")
+        ep_end = np.zeros(m, np.uint8)
         ep_end[-1] = 1
-        self.add_rows(path["observations"], path["actions"], np.asarray(path["rewards"]).reshape(n),
-                      np.asarray(path["terminals"]).reshape(n), path["next_observations"], ep_end)
+        top = self._top
+        self.add_rows(np.asarray(obs), np.asarray(act), np.asarray(rew), np.zeros(m, np.uint8), np.asarray(nobs), ep_end)
+        flags = np.ascontiguousarray(ab, np.float32)
+        _lib.check(self.ctx.lib.ilsx_replay_set_absorbing(self.h, top, m, flags.ctypes.data_as(C.c_void_p)))
         self._trajs += 1
 
     def get_traj_num(self):
@@ -100,9 +120,11 @@ class SimpleReplayBuffer:
         obs, act, rew, done, nobs = (ctx.empty((B, o)), ctx.empty((B, a)), ctx.empty((B,)), ctx.empty((B,)),
                                      ctx.empty((B, o)))
         _lib.check(ctx.lib.ilsx_replay_sample(self.h, B, p_idx, obs.ptr, act.ptr, rew.ptr, done.ptr, nobs.ptr, None))
+        absb = ctx.empty((B, 2))
+        _lib.check(ctx.lib.ilsx_replay_get_absorbing(self.h, p_idx, B, absb.ptr))
         ret = dict(observations=obs.numpy(), actions=act.numpy(), rewards=rew.numpy().reshape(B, 1),
                    terminals=done.numpy().reshape(B, 1).astype(np.uint8), next_observations=nobs.numpy(),
-                   absorbing=np.zeros((B, 2)))
+                   absorbing=absb.numpy().astype(np.float64))
         if keys is not None:
             ret = {k: v for k, v in ret.items() if k in keys}
         return ret

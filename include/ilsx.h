@@ -142,7 +142,7 @@ int ilsx_net_set_noise_policy(ilsx_net* pi, float policy_noise, float policy_noi
 
 /* ---------------------------------------------------------------- replay buffer
  * Replaces rlkit/data_management/simple_replay_buffer.py:17-442 + env_replay_buffer.py:7-49.
- * HBM-resident ring of transition records (obs|act|rew|done|next_obs, one 128-byte-aligned record per
+ * HBM-resident ring of transition records (obs|act|rew|done|next_obs|absorbing, one 128-byte-aligned record per
  * transition).  Cursor semantics (_top/_size/_traj_endpoints) follow the reference exactly. */
 int ilsx_replay_create(ilsx_ctx* ctx, int64_t capacity, int obs_dim, int act_dim, uint64_t seed,
                        ilsx_replay** out);
@@ -154,6 +154,11 @@ int ilsx_replay_add(ilsx_replay* rb, const float* obs, const float* act, const f
                     const uint8_t* done, const float* nobs, int n, const uint8_t* ep_end_host,
                     int data_is_device);
 int ilsx_replay_terminate_episode(ilsx_replay* rb);
+/* _absorbing[cap,2] (simple_replay_buffer.py:66-67,91-92; the wrap_absorbing branch of add_path, :163-213): the flags of the n
+ * slots from slot0 on (ring order) are set from HOST absorbing[n,2]; rows added without them hold [0,0].  get: device
+ * idx int64[n] -> device absorbing[n,2] (the `absorbing` key of random_batch, :266-268). */
+int ilsx_replay_set_absorbing(ilsx_replay* rb, int64_t slot0, int n, const float* absorbing_host);
+int ilsx_replay_get_absorbing(ilsx_replay* rb, const int64_t* idx, int n, float* absorbing);
 /* random_batch (simple_replay_buffer.py:239-293): idx (device int64[B]) or NULL = uniform with
  * replacement over [0,size) from Philox.  Outputs (device): obs[B,o] act[B,a] rew[B] done[B] (0/1 as
  * float, rlkit/torch/core.py:124-143) nobs[B,o]; idx_out (nullable device int64[B]) gets the rows used. */

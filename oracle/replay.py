@@ -21,16 +21,19 @@ class ReplayOracle:
         self.act = np.zeros((c, self.a), np.float32)
         self.rew = np.zeros((c, 1), np.float32)
         self.term = np.zeros((c, 1), np.uint8)
+        self.absorbing = np.zeros((c, 2), np.float32)   # :66-67
         self.top = 0
         self.size = 0
         self.cur_start = 0
         self.traj_endpoints = {}  # start -> end, [start, end), insertion-ordered
 
-    def add_sample(self, obs, act, rew, terminal, next_obs):  # :78-108
+    def add_sample(self, obs, act, rew, terminal, next_obs, absorbing=None):  # :78-108
         t = self.top
         self.act[t] = act
         self.rew[t] = rew
         self.term[t] = terminal
+        if absorbing is not None:   # :91-92
+            self.absorbing[t] = absorbing
         if terminal:
             nxt = (t + 1) % self.cap
             self.traj_endpoints[self.cur_start] = nxt
@@ -60,6 +63,21 @@ class ReplayOracle:
             if ep_end is not None and ep_end[i]:
                 self.terminate_episode()
 
+    def add_path(self, path, absorbing=False, sample_action=None):
+        """:134-216.  absorbing=True (the wrap_absorbing branch of adversarial IRL, adv_irl_exp_script.py:135-138): every stored
+        terminal flag is False; a terminal transition is followed by (next_ob -> 0-state, absorbing [0,1]) and
+        (0-state -> 0-state, absorbing [1,1]), both with a freshly sampled action and the terminal transition's reward."""
+        for ob, act, rew, nob, term in zip(path["observations"], path["actions"], path["rewards"], path["next_observations"],
+                                           path["terminals"]):
+            if not absorbing:
+                self.add_sample(ob, act, np.ravel(rew)[0], int(np.ravel(term)[0]), nob)
+                continue
+            self.add_sample(ob, act, np.ravel(rew)[0], 0, nob, absorbing=[0.0, 0.0])
+            if np.ravel(term)[0]:
+                self.add_sample(nob, sample_action(), np.ravel(rew)[0], 0, np.zeros_like(nob), absorbing=[0.0, 1.0])
+                self.add_sample(np.zeros_like(nob), sample_action(), np.ravel(rew)[0], 0, np.zeros_like(nob), absorbing=[1.0, 1.0])
+        self.terminate_episode()
+
     def num_steps_can_sample(self):  # :371-372
         return self.size
 
@@ -69,7 +87,7 @@ class ReplayOracle:
     def gather(self, idx):  # :255-293
         idx = np.asarray(idx)
         return dict(observations=self.obs[idx], actions=self.act[idx], rewards=self.rew[idx],
-                    terminals=self.term[idx], next_observations=self.next_obs[idx])
+                    terminals=self.term[idx], next_observations=self.next_obs[idx], absorbing=self.absorbing[idx])
 
     def segment_indices(self, start, end):  # :325-332
         if start < end or end == 0:

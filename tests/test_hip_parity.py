@@ -445,6 +445,31 @@ def test_replay_sample_many_records(ctx):
     assert len(np.unique(rows)) > 0.5 * len(rows) * (1 - np.exp(-1))
 
 
+def test_replay_absorbing_add_path_golden(ctx):
+    """G19 (reference-generated): add_path(path, absorbing=True, env) on the HBM ring — rows, the absorbing flags, cursors,
+    trajectory end points, wrap-around (simple_replay_buffer.py:163-213)."""
+    import ilswiss_amd as ia
+    g = load_golden("g19_absorbing")
+    cap, o, a = int(g["cap"]), int(g["o"]), int(g["a"])
+    rb = ia.SimpleReplayBuffer(cap, o, a, random_seed=7, ctx=ctx)
+    stream = iter(g["acts_stream"])
+    env = type("E", (), {})()
+    env.action_space = type("S", (), dict(sample=lambda self: next(stream)))()
+    for i in range(int(g["n_paths"])):
+        rb.add_path({k: g[f"p{i}_{k}"] for k in ("observations", "actions", "rewards", "next_observations", "terminals")},
+                    absorbing=True, env=env)
+    assert rb._top == int(g["top"]) and rb._size == int(g["size"]) and rb.get_traj_num() == int(g["n_paths"])
+    assert rb._traj_endpoints == dict(zip(g["traj_starts"].tolist(), g["traj_ends"].tolist()))
+    b = rb._get_batch_using_indices(np.arange(cap))
+    for k, gk in (("observations", "ring_obs"), ("actions", "ring_act"), ("rewards", "ring_rew"), ("terminals", "ring_term"),
+                  ("next_observations", "ring_next_obs"), ("absorbing", "ring_absorbing")):
+        np.testing.assert_allclose(np.asarray(b[k], np.float64), np.asarray(g[gk], np.float64), rtol=0, atol=1e-6, err_msg=k)
+    # rows added without the keyword (and rows the fused rollout writes) carry [0, 0], also over old flags
+    rb.add_rows(np.zeros((cap, o), np.float32), np.zeros((cap, a), np.float32), np.zeros(cap, np.float32), np.zeros(cap, np.uint8),
+                np.zeros((cap, o), np.float32))
+    assert not rb._get_batch_using_indices(np.arange(cap))["absorbing"].any()
+
+
 # ------------------------------------------------------------------------------------------- fused loop
 def test_train_from_replay_graph_equals_direct_and_learns(ctx, monkeypatch):
     """The captured-graph loop (on-device sampling) is deterministic given the seed, and fits a toy target."""

@@ -2,6 +2,7 @@
 import glob
 import os
 
+import numpy as np
 import yaml
 
 from ilswiss_amd.launcher import variants
@@ -117,3 +118,28 @@ def test_log_dir_layout_matches_the_reference(tmp_path, monkeypatch):
     d = algorithm.setup_log_dir("sac_hopper_hip", 3, 17, variant, base_dir=str(tmp_path))
     assert os.path.relpath(d, str(tmp_path)) == str(g["rel_dir"])
     assert open(os.path.join(d, "variant.json")).read() == str(g["variant_json"])
+
+
+def test_normalize_exp_demos_statistics():
+    """scripts/normalize_exp_demos.py: the reference's get_normalized rule (normalize_exp_demos.py:24-38) — train statistics applied
+    to every split, a constant observation axis keeps std 1, actions untouched."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("norm_demos", os.path.join(ROOT, "scripts", "normalize_exp_demos.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(0)
+
+    def path(L):
+        o = rng.normal(3.0, 2.0, (L, 4))
+        o[:, 2] = 7.0                       # constant axis
+        return dict(observations=o, next_observations=o + 0.1, actions=rng.uniform(-1, 1, (L, 2)), rewards=np.zeros((L, 1)))
+    train, test = [path(50), path(30)], [path(20)]
+    tr, te, mean, std = m.normalize_paths(train, test)
+    allo = np.vstack([p["observations"] for p in train])
+    np.testing.assert_allclose(mean[0], allo.mean(0))
+    assert std[0, 2] == 1.0 and np.allclose(std[0, [0, 1, 3]], allo.std(0)[[0, 1, 3]])
+    z = np.vstack([p["observations"] for p in tr])
+    assert np.allclose(z.mean(0), 0, atol=1e-12) and np.allclose(z.std(0)[[0, 1, 3]], 1)
+    np.testing.assert_allclose(te[0]["next_observations"], (test[0]["next_observations"] - mean) / std)
+    assert tr[0]["actions"] is train[0]["actions"]

@@ -54,6 +54,7 @@ def test_run_script_c1_plumbing(tmp_path, spec_name):
     assert float(rows[-1]["Number of train calls total"]) == 8 and float(rows[-1]["Number of gradient steps total"]) == 80
     assert float(rows[-1]["Number of env steps total"]) == 800
     assert os.path.exists(tmp_path / "params.pkl") and os.path.exists(tmp_path / "best.pkl")
+    assert "AverageReturn" in open(tmp_path / "debug.log").read()      # the text output of launcher_util.py:215,267-269
     assert alg.replay_buffer.num_steps_can_sample() == 800
 
 

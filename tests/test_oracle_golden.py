@@ -168,3 +168,41 @@ def test_running_mean_std_and_action_map():
         assert rms.count == g["counts"][k]
     np.testing.assert_allclose(normalize_obs(g["probe"], rms), g["normed"], rtol=1e-12)
     np.testing.assert_allclose(action_map(g["acts"], g["lb"], g["ub"]), g["scaled"], rtol=1e-12)
+
+
+def test_oracle_absorbing_add_path_golden():
+    """G19: the wrap_absorbing branch of SimpleReplayBuffer.add_path (simple_replay_buffer.py:163-213), ring + cursors."""
+    from oracle.replay import ReplayOracle
+    g = load_golden("g19_absorbing")
+    orc = ReplayOracle(int(g["cap"]), int(g["o"]), int(g["a"]))
+    it = iter(g["acts_stream"])
+    for i in range(int(g["n_paths"])):
+        orc.add_path({k: g[f"p{i}_{k}"] for k in ("observations", "actions", "rewards", "next_observations", "terminals")},
+                     absorbing=True, sample_action=lambda: next(it))
+    assert orc.top == int(g["top"]) and orc.size == int(g["size"])
+    assert list(orc.traj_endpoints.keys()) == list(g["traj_starts"]) and list(orc.traj_endpoints.values()) == list(g["traj_ends"])
+    b = orc.gather(np.arange(int(g["cap"])))
+    for k, gk in (("observations", "ring_obs"), ("actions", "ring_act"), ("rewards", "ring_rew"), ("terminals", "ring_term"),
+                  ("next_observations", "ring_next_obs"), ("absorbing", "ring_absorbing")):
+        np.testing.assert_allclose(np.asarray(b[k], np.float64), np.asarray(g[gk], np.float64), rtol=0, atol=1e-6, err_msg=k)
+    assert g["ring_absorbing"].sum() > 0 and not g["ring_term"].any()
+
+
+def test_torch_cpu_restatement_matches_the_reference_vectors():
+    """oracle/sac_alpha_torch.py (the PyTorch-CPU restatement bench.py times) on the reference's own g4 vectors."""
+    import torch
+    from oracle.sac_alpha_torch import SacAlphaTorch
+    torch.set_num_threads(1)
+    for name, kw in (("g4_sac_alpha_small", SAC_KW), ("g4_sac_alpha_walker", SAC_KW_WALKER)):
+        g = load_golden(name)
+        o, a, B, steps = [int(v) for v in g["dims"][:4]]
+        hidden = [int(v) for v in g["dims"][4:]]
+        ag = SacAlphaTorch(o, a, hidden, g["pi0"], g["q10"], g["q20"], **kw)
+        for s in range(steps):
+            batch = {k: g[f"s{s}_{k}"] for k in ("observations", "actions", "rewards", "terminals", "next_observations")}
+            res = ag.train_step(batch, g[f"s{s}_eps_next"], g[f"s{s}_eps_cur"])
+            for k in ("qf1_loss", "qf2_loss", "policy_loss", "alpha_loss"):
+                np.testing.assert_allclose(res[k], g[k][s], rtol=2e-4, atol=1e-6, err_msg=f"{name} {k} step {s}")
+            np.testing.assert_allclose(float(ag.log_alpha), g["log_alpha"][s], rtol=0, atol=1e-6)
+            for nm in ("pi", "q1", "q2", "tq1", "tq2"):
+                np.testing.assert_allclose(ag.flat(nm), g[f"s{s}_{nm}"], rtol=0, atol=5e-5, err_msg=f"{name} {nm} step {s}")

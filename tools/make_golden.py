@@ -787,7 +787,53 @@ def gen_logdir():
     save("g18_logdir", rel_dir=np.array(rel), variant_json=np.array(text))
 
 
-GROUPS = dict(bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+def gen_absorbing():
+    """G19: SimpleReplayBuffer.add_path(path, absorbing=True, env) (simple_replay_buffer.py:134-216) on two scripted paths (one ends
+    with a terminal transition, one does not) into a ring small enough to wrap; env.action_space.sample() is a scripted stream."""
+    from rlkit.data_management.simple_replay_buffer import SimpleReplayBuffer
+    from oracle.replay import ReplayOracle
+    rng = np.random.default_rng(1919)
+    cap, o, a = 16, 3, 2
+    acts_stream = rng.uniform(-1, 1, (8, a))
+
+    class Space:
+        def __init__(self):
+            self.i = 0
+
+        def sample(self):
+            self.i += 1
+            return acts_stream[self.i - 1]
+    env = type("E", (), {})()
+    env.action_space = Space()
+    paths = []
+    for L, terminal_last in ((5, True), (4, False), (6, True)):
+        term = np.zeros((L, 1), bool)
+        term[-1, 0] = terminal_last
+        paths.append(dict(observations=rng.normal(0, 1, (L, o)), actions=rng.uniform(-1, 1, (L, a)), rewards=rng.normal(0, 1, (L, 1)),
+                          next_observations=rng.normal(0, 1, (L, o)), terminals=term))
+    rb = SimpleReplayBuffer(cap, o, a, random_seed=7)
+    orc = ReplayOracle(cap, o, a, random_seed=7)
+    it = iter(acts_stream)
+    for pth in paths:
+        rb.add_path(pth, absorbing=True, env=env)
+        orc.add_path(pth, absorbing=True, sample_action=lambda: next(it))
+    idx = np.arange(cap)
+    gb = rb._get_batch_using_indices(idx)
+    ob = orc.gather(idx)
+    for k in ("observations", "actions", "rewards", "terminals", "next_observations", "absorbing"):
+        assert np.allclose(np.asarray(gb[k], np.float64), np.asarray(ob[k], np.float64), atol=1e-6), k
+    assert rb._top == orc.top and rb._size == orc.size and dict(rb._traj_endpoints) == orc.traj_endpoints
+    out = dict(cap=cap, o=o, a=a, acts_stream=acts_stream, n_paths=len(paths), top=rb._top, size=rb._size,
+               traj_starts=np.array(list(rb._traj_endpoints.keys())), traj_ends=np.array(list(rb._traj_endpoints.values())),
+               ring_obs=gb["observations"], ring_act=gb["actions"], ring_rew=gb["rewards"], ring_term=gb["terminals"],
+               ring_next_obs=gb["next_observations"], ring_absorbing=gb["absorbing"])
+    for i, pth in enumerate(paths):
+        for k, v in pth.items():
+            out[f"p{i}_{k}"] = v
+    save("g19_absorbing", **out)
+
+
+GROUPS = dict(absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
 
 if __name__ == "__main__":
