@@ -110,7 +110,7 @@ def test_random_policy_known_answers_of_this_engine():
     std is ~15 here and in MuJoCo), so those numbers are means over many episodes of some exploration policy, and which one is
     not recoverable from the tree (no script produces the table).  What CAN be stated and is pinned here is THIS engine under a
     stated protocol: i.i.d. uniform actions in [-1, 1], reset noise of the env, run until done (max 1000 steps), n = 120 episodes,
-    seed 0.  Measured at n = 500: Hopper 16.9 +- 0.65 (s.e.), 20.9 steps; Walker2d 2.3 +- 0.33, 21.8 steps.  MuJoCo's own
+    seed 0.  Measured at n = 500 (seed 1): Hopper 18.38 +- 0.81 (s.e.; per-episode std 18.1), 22.3 steps; Walker2d 1.83 +- 0.27 (5.9), 20.3 steps.  MuJoCo's own
     Hopper-v2 / Walker2d-v2 under the same protocol give ~18 / ~1-2 (public d4rl `random` reference scores: Walker2d 1.63): the
     planar engine sits where the real simulator does, and neither reproduces the README's 13.09 / 7.07 — its protocol is
     something else.  Windows are +-3 s.e. at n = 120 around the n = 500 values."""
