@@ -57,6 +57,28 @@ class PlanarModel(C.Structure):  # ilsx_planar_model
                 ("max_rows", C.c_int32), ("pad1", C.c_int32)]
 
 
+_ML3, _MC3, _MB3 = 20, 32, 16
+
+
+class SpatialModel(C.Structure):  # ilsx_spatial_model
+    _fields_ = [("task", C.c_int32), ("n_link", C.c_int32), ("n_act", C.c_int32), ("n_contact", C.c_int32),
+                ("n_body", C.c_int32), ("frame_skip", C.c_int32), ("pgs_iters", C.c_int32), ("max_rows", C.c_int32),
+                ("parent", C.c_int32 * _ML3), ("limited", C.c_int32 * _ML3), ("act_link", C.c_int32 * _ML3),
+                ("contact_link", C.c_int32 * _MC3), ("body_link", C.c_int32 * _MB3),
+                ("anchor", (C.c_double * 3) * _ML3), ("axis", (C.c_double * 3) * _ML3), ("quat0", (C.c_double * 4) * _ML3),
+                ("com", (C.c_double * 3) * _ML3), ("mass", C.c_double * _ML3), ("inertia", (C.c_double * 6) * _ML3),
+                ("armature", C.c_double * _ML3), ("damping", C.c_double * _ML3), ("stiffness", C.c_double * _ML3),
+                ("range", (C.c_double * 2) * _ML3), ("gear", C.c_double * _ML3),
+                ("contact_pos", (C.c_double * 3) * _MC3), ("contact_radius", C.c_double * _MC3),
+                ("contact_friction", C.c_double * _MC3),
+                ("timestep", C.c_double), ("gravity", C.c_double), ("reset_noise", C.c_double),
+                ("reset_noise_vel_std", C.c_double), ("contact_margin", C.c_double), ("ctrl_range", C.c_double),
+                ("contact_solref", C.c_double * 2), ("contact_solimp", C.c_double * 3),
+                ("limit_solref", C.c_double * 2), ("limit_solimp", C.c_double * 3),
+                ("ctrl_cost", C.c_double), ("alive_bonus", C.c_double), ("vel_weight", C.c_double), ("z_min", C.c_double),
+                ("z_max", C.c_double), ("init_qpos", C.c_double * (_ML3 + 6))]
+
+
 class Td3Cfg(C.Structure):  # ilsx_td3_cfg
     _fields_ = [("reward_scale", C.c_float), ("discount", C.c_float), ("policy_lr", C.c_float), ("qf_lr", C.c_float),
                 ("policy_and_target_update_period", C.c_int32), ("soft_target_tau", C.c_float),
@@ -160,6 +182,8 @@ PROTOTYPES = {
     "ilsx_disc_train_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(DiscStats)]),
     "ilsx_disc_reward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, vp, vp]),
     "ilsx_vecenv_create": (C.c_int, [vp, C.POINTER(PlanarModel), C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "ilsx_vecenv_create_spatial": (C.c_int, [vp, C.POINTER(SpatialModel), C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "ilsx_vecenv_state_dims": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ilsx_vecenv_destroy": (C.c_int, [vp]),
     "ilsx_vecenv_dims": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ilsx_vecenv_reset": (C.c_int, [vp, vp, C.c_int, vp]),

@@ -13,6 +13,7 @@
 #include <cmath>
 
 #include "host_common.h"
+#include "env3d.h"
 
 #define ENV_MAXB 8
 #define ENV_MAXG 8
@@ -53,12 +54,15 @@ struct ilsx_vecenv {
   float* act_label = nullptr;   // [n_env][a] expert labels (ilsx_rollout_step_relabel)
   unsigned char* ev_frozen = nullptr; double* ev_ret = nullptr; int* ev_len = nullptr; double* ev_stats = nullptr; int* ev_alive = nullptr;
   bool norm_obs = false, update_rms = false;
+  // 3-D engine (Ant / Humanoid, env3d.h): model, its device copy, and the per-env working set [E3Off::TOTAL][n_env]
+  int engine = 0, nq = 0, nv = 0;
+  Spatial3Dev* hm3 = nullptr; Spatial3Dev* dm3 = nullptr; double* scr3 = nullptr;
   const float* policy_obs() const { return norm_obs ? obs_n : obs_cur; }
 };
 
 // RunningMeanStd (normalizer.py:128-152): float64, one owner workgroup per observation dimension (count is kept per
 // dimension so that no workgroup depends on another's update).
-#define ENV_MAX_OBS 64
+#define ENV_MAX_OBS E3_MAXOBS
 struct ObsRms { double mean[ENV_MAX_OBS], var[ENV_MAX_OBS], count[ENV_MAX_OBS]; };
 
 // update(x) with x = the selected rows of src[n_rows][o]: batch mean / population variance in two passes (np.mean,
@@ -560,6 +564,108 @@ __global__ void k_random_actions(float* act, int n, uint64_t seed, uint32_t stre
   act[t] = (float)(2.0 * env_uniform(seed, stream, step, (uint32_t)env, (uint32_t)k) - 1.0);
 }
 
+// ================================================================================================ 3-D engine kernels
+__device__ void e3_reset_state(const E3Ctx& C, uint64_t seed, uint32_t stream, unsigned long long step, uint32_t envu) {
+  const Spatial3Dev& m = *C.m;
+  double* scr = C.scr; const int n_env = C.n_env, env = C.env;
+  // humanoid.py:62-73 / ant.py:36-43: init + U(+-c) on every qpos component (the quaternion is re-normalised, as MuJoCo does
+  // before it uses it); qvel = U(+-c) (Humanoid) or 0.1 * randn (Ant)
+  for (int i = 0; i < m.nq; ++i) E3S(E3St::Q0 + i) = m.init_qpos[i] + m.reset_noise * (2.0 * env_uniform(seed, stream, step, envu, i) - 1.0);
+  {
+    double qw = E3S(E3St::Q0 + 3), qx = E3S(E3St::Q0 + 4), qy = E3S(E3St::Q0 + 5), qz = E3S(E3St::Q0 + 6);
+    const double nrm = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    E3S(E3St::Q0 + 3) = qw * nrm; E3S(E3St::Q0 + 4) = qx * nrm; E3S(E3St::Q0 + 5) = qy * nrm; E3S(E3St::Q0 + 6) = qz * nrm;
+  }
+  for (int i = 0; i < m.nv; ++i) {
+    if (m.reset_noise_vel_std > 0.0) {
+      const double u1 = env_uniform(seed, stream, step, envu, m.nq + 2 * i), u2 = env_uniform(seed, stream, step, envu, m.nq + 2 * i + 1);
+      E3S(E3St::V0 + i) = m.reset_noise_vel_std * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    } else {
+      E3S(E3St::V0 + i) = m.reset_noise * (2.0 * env_uniform(seed, stream, step, envu, m.nq + i) - 1.0);
+    }
+  }
+  for (int k = 0; k < m.n_act; ++k) E3S(E3St::CTRL + k) = 0.0;   // qfrc_actuator of a freshly reset model is zero
+}
+
+__global__ __launch_bounds__(64) void k_env3d_step(const EnvStepArgs A, const Spatial3Dev* mp, double* scr) {
+  const Spatial3Dev& m = *mp;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= A.n_ids) return;
+  const int env = A.ids ? A.ids[t] : t, n_env = A.n_env;
+  if (A.frozen && A.frozen[env]) return;
+  const E3Ctx C{scr, n_env, env, mp};
+  const int o = m.obs_dim, na = m.n_act;
+  for (int i = 0; i < m.nq; ++i) E3S(E3St::Q0 + i) = A.qpos[(size_t)i * n_env + env];
+  for (int i = 0; i < m.nv; ++i) E3S(E3St::V0 + i) = A.qvel[(size_t)i * n_env + env];
+  float* rec = nullptr;
+  if (A.replay) {   // fused replay insert: the observation the policy acted on is the stored current observation
+    long long slot = A.top + env;
+    if (slot >= A.cap) slot -= A.cap;
+    rec = A.replay + (size_t)slot * A.rec;
+    for (int i = 0; i < o; ++i) rec[i] = A.obs_cur[(size_t)env * o + i];
+  }
+  double reward; bool done;
+  e3_task_step(C, A.act + (size_t)t * na, reward, done);
+  bool end = false; int len = 0; double ret = 0.0;
+  if (A.auto_reset) {
+    len = A.ep_len[env] + 1; ret = A.ep_ret[env] + reward;
+    end = done || len >= A.max_path_length;   // time-limit ends are NOT terminal (base_algorithm.py:264-277)
+  }
+  float* obs_out = A.obs ? A.obs + (size_t)t * o : nullptr;
+  float* cur = (A.obs_cur && !end) ? A.obs_cur + (size_t)env * o : nullptr;
+  float* rnext = rec ? rec + o + na + 2 : nullptr;
+  e3_observe(C, [&](int i, double val) {
+    const float f = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]);
+    if (obs_out) obs_out[i] = f;
+    if (cur) cur[i] = f;
+    if (rnext) rnext[i] = f;
+  });
+  if (A.rew) A.rew[t] = (float)reward;
+  if (A.done) A.done[t] = done ? 1 : 0;
+  if (rec) {
+    const float* ra = A.rec_act ? A.rec_act : A.act;
+    for (int k = 0; k < na; ++k) rec[o + k] = ra[(size_t)t * na + k];
+    rec[o + na] = (float)reward;
+    rec[o + na + 1] = (done && !A.no_terminal) ? 1.0f : 0.0f;
+    rec[2 * o + na + 2] = 0.0f; rec[2 * o + na + 3] = 0.0f;
+  }
+  if (A.auto_reset) {
+    if (end) {
+      atomicAdd(&A.stats[0], 1.0);
+      atomicAdd(&A.stats[1], ret);
+      e3_reset_state(C, A.seed, A.stream, A.step, (uint32_t)env);
+      e3_kinematics(C, E3St::Q0, E3St::V0);
+      float* c2 = A.obs_cur + (size_t)env * o;
+      e3_observe(C, [&](int i, double val) { c2[i] = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]); });
+    }
+    A.ep_len[env] = end ? 0 : len;
+    A.ep_ret[env] = end ? 0.0 : ret;
+  }
+  for (int i = 0; i < m.nq; ++i) A.qpos[(size_t)i * n_env + env] = E3S(E3St::Q0 + i);
+  for (int i = 0; i < m.nv; ++i) A.qvel[(size_t)i * n_env + env] = E3S(E3St::V0 + i);
+}
+
+__global__ __launch_bounds__(64) void k_env3d_reset(const Spatial3Dev* mp, double* scr, double* qpos, double* qvel, int n_env, const int* ids,
+                                                    int n_ids, float* obs, float* obs_cur, int* ep_len, double* ep_ret, uint64_t seed,
+                                                    uint32_t stream, unsigned long long step) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= n_ids) return;
+  const int env = ids ? ids[t] : t;
+  const Spatial3Dev& m = *mp;
+  const E3Ctx C{scr, n_env, env, mp};
+  e3_reset_state(C, seed, stream, step, (uint32_t)env);
+  e3_kinematics(C, E3St::Q0, E3St::V0);
+  const int o = m.obs_dim;
+  e3_observe(C, [&](int i, double val) {
+    const float f = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]);
+    if (obs) obs[(size_t)t * o + i] = f;
+    if (obs_cur) obs_cur[(size_t)env * o + i] = f;
+  });
+  ep_len[env] = 0; ep_ret[env] = 0.0;
+  for (int i = 0; i < m.nq; ++i) qpos[(size_t)i * n_env + env] = E3S(E3St::Q0 + i);
+  for (int i = 0; i < m.nv; ++i) qvel[(size_t)i * n_env + env] = E3S(E3St::V0 + i);
+}
+
 // ------------------------------------------------------------------------------------------------ host
 template <int NB, int MR, int BLOCK>
 static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
@@ -577,6 +683,12 @@ static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
 }
 static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
   if (A.n_ids <= 0) return ILSX_OK;
+  if (e->engine == 1) {
+    ProfScope ps(e->ctx, ILSX_K_ENV_STEP);
+    ILSX_LAUNCH(ps, k_env3d_step, dim3((A.n_ids + 63) / 64), dim3(64), 0, e->ctx->stream, A, (const Spatial3Dev*)e->dm3, e->scr3);
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   if (e->hm.nb == 4) return launch_env_step_t<4, 8, 64>(e, A);
   if (e->hm.nb == 7) return e->hm.max_rows > 12 ? launch_env_step_t<7, 16, 32>(e, A) : launch_env_step_t<7, 12, 64>(e, A);
   ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "vec-env kernels are instantiated for 4 (Hopper) and 7 (Walker2d) bodies, got %d", e->hm.nb);
@@ -584,6 +696,12 @@ static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
 static int launch_env_reset(ilsx_vecenv* e, const int* ids_dev, int n_ids, float* obs) {
   if (n_ids <= 0) return ILSX_OK;
   const unsigned long long step = ++e->step_ctr;
+  if (e->engine == 1) {
+    hipLaunchKernelGGL(k_env3d_reset, dim3((n_ids + 63) / 64), dim3(64), 0, e->ctx->stream, (const Spatial3Dev*)e->dm3, e->scr3, e->qpos, e->qvel,
+                       e->n_env, ids_dev, n_ids, obs, e->obs_cur, e->ep_len, e->ep_ret, e->seed, e->rng_stream, step);
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   const dim3 grid((n_ids + 255) / 256), block(256);
   if (e->hm.nb == 4)
     hipLaunchKernelGGL(k_env_reset<4>, grid, block, 0, e->ctx->stream, e->dm, e->qpos, e->qvel, e->n_env, ids_dev, n_ids, obs,
@@ -648,7 +766,7 @@ extern "C" int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* pm, in
   for (int i = 0; i < 3; ++i) { m.c_solimp[i] = pm->contact_solimp[i]; m.l_solimp[i] = pm->limit_solimp[i]; }
   m.ctrl_cost = pm->ctrl_cost; m.alive = pm->alive_bonus; m.z_min = pm->z_min; m.z_max = pm->z_max;
   m.ang_max = pm->ang_max; m.state_max = pm->state_max;
-  e->n = m.nb + 2; e->o = 2 * e->n - 1; e->a = na;
+  e->n = m.nb + 2; e->nq = e->nv = e->n; e->o = 2 * e->n - 1; e->a = na;
   m.obs_dim = e->o;
   for (int i = 0; i < e->n; ++i) m.init_qpos[i] = pm->init_qpos[i];
   for (int i = 0; i < 2 * (ENV_MAXB + 2); ++i) { m.obs_shift[i] = 0.0; m.obs_inv_scale[i] = 1.0; }
@@ -680,10 +798,56 @@ extern "C" int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* pm, in
   return ILSX_OK;
 }
 
+// 3-D models (Ant / Humanoid): same handle type, same protocol entry points; the engine behind step / reset is env3d.h
+extern "C" int ilsx_vecenv_create_spatial(ilsx_ctx* ctx, const ilsx_spatial_model* sm, int n_env, uint64_t seed, ilsx_vecenv** out) {
+  if (!ctx || !sm || !out || n_env < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_vecenv_create_spatial: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  ilsx_vecenv* e = new ilsx_vecenv();
+  e->ctx = ctx; e->n_env = n_env; e->seed = seed; e->rng_stream = ctx->next_rng_stream++; e->engine = 1;
+  e->hm3 = new Spatial3Dev();
+  Spatial3Dev& m = *e->hm3;
+  if (const char* why = e3_build_model(sm, m)) { delete e->hm3; delete e; ILSX_FAIL(ILSX_ERR_ARG, "ilsx_vecenv_create_spatial: %s", why); }
+  e->n = m.nq; e->nq = m.nq; e->nv = m.nv; e->o = m.obs_dim; e->a = m.n_act;
+  const size_t N = (size_t)n_env;
+  int rc = ctx_alloc(ctx, sizeof m, (void**)&e->dm3);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, (size_t)E3Off::TOTAL * N * 8, (void**)&e->scr3);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->nq * 8, (void**)&e->qpos);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->nv * 8, (void**)&e->qvel);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->o * 4, (void**)&e->obs_cur);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->a * 4, (void**)&e->act);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->o * 4, (void**)&e->nobs);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->rew);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N, (void**)&e->done);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->ep_len);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * e->o * 4, (void**)&e->obs_n);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(ObsRms), (void**)&e->rms);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 8, (void**)&e->ep_ret);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, 4 * 8, (void**)&e->stats);
+  if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * 4, (void**)&e->ids);
+  if (rc != ILSX_OK) { delete e->hm3; delete e; return rc; }
+  HIPCHK(hipMemcpyAsync(e->dm3, &m, sizeof m, hipMemcpyHostToDevice, ctx->stream));
+  {
+    std::vector<ObsRms> h(1);
+    for (int i = 0; i < ENV_MAX_OBS; ++i) { h[0].mean[i] = 0.0; h[0].var[i] = 1.0; h[0].count[i] = 0.0; }
+    HIPCHK(hipMemcpyAsync(e->rms, h.data(), sizeof(ObsRms), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  ILSX_TRY(launch_env_reset(e, nullptr, n_env, nullptr));
+  *out = e;
+  return ILSX_OK;
+}
+extern "C" int ilsx_vecenv_state_dims(const ilsx_vecenv* e, int* nq, int* nv) {
+  if (!e) ILSX_FAIL(ILSX_ERR_ARG, "env is NULL");
+  if (nq) *nq = e->nq;
+  if (nv) *nv = e->nv;
+  return ILSX_OK;
+}
+
 extern "C" int ilsx_vecenv_destroy(ilsx_vecenv* e) {
   if (!e) return ILSX_OK;
-  void* ps[] = {e->dm, e->qpos, e->qvel, e->obs_cur, e->act, e->nobs, e->rew, e->done, e->ep_len, e->ep_ret, e->stats, e->ids};
-  for (void* p : ps) ctx_free(e->ctx, p);
+  void* ps[] = {e->dm, e->qpos, e->qvel, e->obs_cur, e->act, e->nobs, e->rew, e->done, e->ep_len, e->ep_ret, e->stats, e->ids, e->dm3, e->scr3};
+  for (void* p : ps) if (p) ctx_free(e->ctx, p);
+  delete e->hm3;
   delete e;
   return ILSX_OK;
 }
@@ -746,25 +910,29 @@ extern "C" int ilsx_vecenv_step(ilsx_vecenv* e, const float* act, const int32_t*
 extern "C" int ilsx_vecenv_get_state(ilsx_vecenv* e, double* qpos_host, double* qvel_host) {
   if (!e || !qpos_host || !qvel_host) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
   HIPCHK(hipSetDevice(e->ctx->device));
-  const size_t N = e->n_env, n = e->n;
-  std::vector<double> tq(N * n), tv(N * n);
-  HIPCHK(hipMemcpyAsync(tq.data(), e->qpos, N * n * 8, hipMemcpyDeviceToHost, e->ctx->stream));
-  HIPCHK(hipMemcpyAsync(tv.data(), e->qvel, N * n * 8, hipMemcpyDeviceToHost, e->ctx->stream));
+  const size_t N = e->n_env, nq = e->nq, nv = e->nv;
+  std::vector<double> tq(N * nq), tv(N * nv);
+  HIPCHK(hipMemcpyAsync(tq.data(), e->qpos, N * nq * 8, hipMemcpyDeviceToHost, e->ctx->stream));
+  HIPCHK(hipMemcpyAsync(tv.data(), e->qvel, N * nv * 8, hipMemcpyDeviceToHost, e->ctx->stream));
   HIPCHK(hipStreamSynchronize(e->ctx->stream));
-  for (size_t i = 0; i < n; ++i)
-    for (size_t j = 0; j < N; ++j) { qpos_host[j * n + i] = tq[i * N + j]; qvel_host[j * n + i] = tv[i * N + j]; }
+  for (size_t j = 0; j < N; ++j) {
+    for (size_t i = 0; i < nq; ++i) qpos_host[j * nq + i] = tq[i * N + j];
+    for (size_t i = 0; i < nv; ++i) qvel_host[j * nv + i] = tv[i * N + j];
+  }
   return ILSX_OK;
 }
 
 extern "C" int ilsx_vecenv_set_state(ilsx_vecenv* e, const double* qpos_host, const double* qvel_host) {
   if (!e || !qpos_host || !qvel_host) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
   HIPCHK(hipSetDevice(e->ctx->device));
-  const size_t N = e->n_env, n = e->n;
-  std::vector<double> tq(N * n), tv(N * n);
-  for (size_t i = 0; i < n; ++i)
-    for (size_t j = 0; j < N; ++j) { tq[i * N + j] = qpos_host[j * n + i]; tv[i * N + j] = qvel_host[j * n + i]; }
-  HIPCHK(hipMemcpyAsync(e->qpos, tq.data(), N * n * 8, hipMemcpyHostToDevice, e->ctx->stream));
-  HIPCHK(hipMemcpyAsync(e->qvel, tv.data(), N * n * 8, hipMemcpyHostToDevice, e->ctx->stream));
+  const size_t N = e->n_env, nq = e->nq, nv = e->nv;
+  std::vector<double> tq(N * nq), tv(N * nv);
+  for (size_t j = 0; j < N; ++j) {
+    for (size_t i = 0; i < nq; ++i) tq[i * N + j] = qpos_host[j * nq + i];
+    for (size_t i = 0; i < nv; ++i) tv[i * N + j] = qvel_host[j * nv + i];
+  }
+  HIPCHK(hipMemcpyAsync(e->qpos, tq.data(), N * nq * 8, hipMemcpyHostToDevice, e->ctx->stream));
+  HIPCHK(hipMemcpyAsync(e->qvel, tv.data(), N * nv * 8, hipMemcpyHostToDevice, e->ctx->stream));
   HIPCHK(hipStreamSynchronize(e->ctx->stream));
   return ILSX_OK;
 }
@@ -827,9 +995,11 @@ extern "C" int ilsx_vecenv_set_obs_affine(ilsx_vecenv* e, const double* shift_ho
   HIPCHK(hipSetDevice(e->ctx->device));
   for (int i = 0; i < e->o; ++i) {
     if (!(scale_host[i] != 0.0)) ILSX_FAIL(ILSX_ERR_ARG, "observation scale %d is zero", i);
-    e->hm.obs_shift[i] = shift_host[i]; e->hm.obs_inv_scale[i] = 1.0 / scale_host[i];
+    if (e->engine == 1) { e->hm3->obs_shift[i] = shift_host[i]; e->hm3->obs_inv_scale[i] = 1.0 / scale_host[i]; }
+    else { e->hm.obs_shift[i] = shift_host[i]; e->hm.obs_inv_scale[i] = 1.0 / scale_host[i]; }
   }
-  HIPCHK(hipMemcpyAsync(e->dm, &e->hm, sizeof e->hm, hipMemcpyHostToDevice, e->ctx->stream));
+  if (e->engine == 1) HIPCHK(hipMemcpyAsync(e->dm3, e->hm3, sizeof(Spatial3Dev), hipMemcpyHostToDevice, e->ctx->stream));
+  else HIPCHK(hipMemcpyAsync(e->dm, &e->hm, sizeof e->hm, hipMemcpyHostToDevice, e->ctx->stream));
   HIPCHK(hipStreamSynchronize(e->ctx->stream));
   ILSX_TRY(launch_env_reset(e, nullptr, e->n_env, nullptr));
   return env_obs_norm(e, nullptr, 0, nullptr, e->obs_cur, e->obs_n, e->n_env);

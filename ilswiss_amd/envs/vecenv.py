@@ -12,6 +12,7 @@ import numpy as np
 from .. import _lib
 from ..device import as_dev, get_context
 from .models import MODELS
+from .models3d import MODELS3D
 
 
 class Box:  # minimal gym.spaces.Box stand-in (gym is not installed here)
@@ -49,6 +50,43 @@ def model_struct(m):
     for i, v in enumerate(m["init_qpos"]):
         s.init_qpos[i] = v
     s.reset_noise_vel_std, s.qvel_clip, s.max_rows = m.get("reset_noise_vel_std", 0.0), m.get("qvel_clip", 10.0), m.get("max_rows", 0)
+    return s
+
+
+def spatial_struct(m):
+    """models3d dict -> ilsx_spatial_model (include/ilsx.h)."""
+    s = _lib.SpatialModel()
+    s.task, s.n_link, s.n_act, s.n_contact, s.n_body = m["task"], m["n_link"], m["act_dim"], m["n_contact"], len(m["body_link"])
+    s.frame_skip, s.pgs_iters, s.max_rows = m["frame_skip"], m["pgs_iters"], m["max_rows"]
+    inertia = np.asarray(m["inertia"], np.float64)
+    for l in range(m["n_link"]):
+        s.parent[l], s.limited[l] = int(m["parent"][l]), int(m["limited"][l])
+        for k in range(3):
+            s.anchor[l][k], s.axis[l][k], s.com[l][k] = m["anchor"][l][k], m["axis"][l][k], m["com"][l][k]
+        for k in range(4):
+            s.quat0[l][k] = m["quat0"][l][k]
+        I = inertia[l]
+        for k, (i, j) in enumerate(((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))):
+            s.inertia[l][k] = I[i, j]
+        s.mass[l], s.armature[l], s.damping[l], s.stiffness[l] = m["mass"][l], m["armature"][l], m["damping"][l], m["stiffness"][l]
+        s.range[l][0], s.range[l][1], s.gear[l] = m["range"][l][0], m["range"][l][1], m["gear"][l]
+    for k, l in enumerate(m["act_links"]):
+        s.act_link[k] = int(l)
+    for c in range(m["n_contact"]):
+        s.contact_link[c], s.contact_radius[c], s.contact_friction[c] = int(m["contact_link"][c]), m["contact_radius"][c], m["contact_friction"][c]
+        for k in range(3):
+            s.contact_pos[c][k] = m["contact_pos"][c][k]
+    for b, l in enumerate(m["body_link"]):
+        s.body_link[b] = int(l)
+    s.timestep, s.gravity, s.reset_noise, s.reset_noise_vel_std = m["timestep"], m["gravity"], m["reset_noise"], m["reset_noise_vel_std"]
+    s.contact_margin, s.ctrl_range = m["contact_margin"], m["ctrl_range"]
+    for k in (0, 1):
+        s.contact_solref[k], s.limit_solref[k] = m["contact_solref"][k], m["limit_solref"][k]
+    for k in (0, 1, 2):
+        s.contact_solimp[k], s.limit_solimp[k] = m["contact_solimp"][k], m["limit_solimp"][k]
+    s.ctrl_cost, s.alive_bonus, s.vel_weight, s.z_min, s.z_max = m["ctrl_cost"], m["alive_bonus"], m["vel_weight"], m["z_min"], m["z_max"]
+    for i, v in enumerate(m["init_qpos"]):
+        s.init_qpos[i] = v
     return s
 
 
@@ -111,14 +149,20 @@ class HipVectorEnv:
     def __init__(self, env_name, env_num, seed=0, ctx=None, model=None, norm_obs=False, obs_rms=None, update_obs_rms=True,
                  obs_shift=None, obs_scale=None):
         self.ctx = ctx or get_context()
-        self.model = model or MODELS[env_name]()
+        self.model = model or (MODELS3D[env_name]() if env_name in MODELS3D else MODELS[env_name]())
         self.env_num = int(env_num)
         self.h = C.c_void_p()
-        ms = model_struct(self.model)
-        _lib.check(self.ctx.lib.ilsx_vecenv_create(self.ctx.h, C.byref(ms), self.env_num, C.c_uint64(seed), C.byref(self.h)))
+        if "n_link" in self.model:      # 3-D engine (Ant / Humanoid)
+            ms = spatial_struct(self.model)
+            _lib.check(self.ctx.lib.ilsx_vecenv_create_spatial(self.ctx.h, C.byref(ms), self.env_num, C.c_uint64(seed), C.byref(self.h)))
+        else:
+            ms = model_struct(self.model)
+            _lib.check(self.ctx.lib.ilsx_vecenv_create(self.ctx.h, C.byref(ms), self.env_num, C.c_uint64(seed), C.byref(self.h)))
         o, a, n, ne = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _lib.check(self.ctx.lib.ilsx_vecenv_dims(self.h, C.byref(o), C.byref(a), C.byref(n), C.byref(ne)))
         self.obs_dim, self.act_dim, self.n_dof = o.value, a.value, n.value
+        _lib.check(self.ctx.lib.ilsx_vecenv_state_dims(self.h, C.byref(o), C.byref(a)))
+        self.nq, self.nv = o.value, a.value
         ob = Box(-np.inf * np.ones(self.obs_dim), np.inf * np.ones(self.obs_dim))
         ac = Box(-np.ones(self.act_dim), np.ones(self.act_dim))
         self.observation_space, self.action_space = [ob] * self.env_num, [ac] * self.env_num  # vecenvs.py:118-140
@@ -196,13 +240,13 @@ class HipVectorEnv:
 
     # ---- simulator state (tests, snapshots)
     def get_state(self):
-        q = np.empty((self.env_num, self.n_dof)); v = np.empty((self.env_num, self.n_dof))
+        q = np.empty((self.env_num, self.nq)); v = np.empty((self.env_num, self.nv))
         _lib.check(self.ctx.lib.ilsx_vecenv_get_state(self.h, q.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
         return q, v
 
     def set_state(self, qpos, qvel):
         q, v = np.ascontiguousarray(qpos, np.float64), np.ascontiguousarray(qvel, np.float64)
-        assert q.shape == (self.env_num, self.n_dof) and v.shape == q.shape
+        assert q.shape == (self.env_num, self.nq) and v.shape == (self.env_num, self.nv)
         _lib.check(self.ctx.lib.ilsx_vecenv_set_state(self.h, q.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
 
     # ---- fused device loop (BaseAlgorithm's sampling iteration, base_algorithm.py:183-277)

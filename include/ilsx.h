@@ -451,6 +451,36 @@ typedef struct {
 } ilsx_planar_model;
 
 int ilsx_vecenv_create(ilsx_ctx* ctx, const ilsx_planar_model* model, int n_env, uint64_t seed, ilsx_vecenv** out);
+/* 3-D models — Ant-v2 and Humanoid-v2 (rlkit/envs/envs_dict.py:6,9; reward / termination / observation / reset rules of
+ * rlkit/envs/mujoco/ant.py:11-43 and humanoid.py:24-73, Humanoid with the full 376-dim observation of gym's -v2: qpos[2:] | qvel |
+ * cinert | cvel | qfrc_actuator | cfrc_ext).  Link 0 is the root body on a free joint (qpos = position + unit quaternion w x y z,
+ * qvel = world linear + BODY-frame angular velocity); every other link hangs off its parent by one hinge (a MuJoCo body with k
+ * hinges is a chain of k links, the first k-1 massless).  Constants come from the caller (ilswiss_amd/envs/models3d.py); the
+ * engine is stated in oracle/spatial_env.py; physics parity with MuJoCo is UNPINNED.  The handle is an ordinary
+ * ilsx_vecenv: reset / step / rollout / evaluation entry points are the ones below. */
+#define ILSX_ENV3_MAX_LINK 20
+#define ILSX_ENV3_MAX_CONTACT 32
+#define ILSX_ENV3_MAX_BODY 16
+enum { ILSX_TASK_ANT = 3, ILSX_TASK_HUMANOID = 4 };
+typedef struct {
+  int32_t task, n_link, n_act, n_contact, n_body, frame_skip, pgs_iters, max_rows;
+  int32_t parent[ILSX_ENV3_MAX_LINK], limited[ILSX_ENV3_MAX_LINK], act_link[ILSX_ENV3_MAX_LINK];   /* act_link[k]: link whose hinge actuator k drives */
+  int32_t contact_link[ILSX_ENV3_MAX_CONTACT], body_link[ILSX_ENV3_MAX_BODY];   /* body_link[b]: link carrying MuJoCo body b+1 (observation rows) */
+  double anchor[ILSX_ENV3_MAX_LINK][3];   /* hinge anchor in the parent link's frame */
+  double axis[ILSX_ENV3_MAX_LINK][3];     /* unit hinge axis, link frame */
+  double quat0[ILSX_ENV3_MAX_LINK][4];    /* fixed rotation parent -> link at q = 0 (w x y z) */
+  double com[ILSX_ENV3_MAX_LINK][3], mass[ILSX_ENV3_MAX_LINK], inertia[ILSX_ENV3_MAX_LINK][6];   /* about the COM, link frame: xx yy zz xy xz yz */
+  double armature[ILSX_ENV3_MAX_LINK], damping[ILSX_ENV3_MAX_LINK], stiffness[ILSX_ENV3_MAX_LINK], range[ILSX_ENV3_MAX_LINK][2],
+      gear[ILSX_ENV3_MAX_LINK];
+  double contact_pos[ILSX_ENV3_MAX_CONTACT][3], contact_radius[ILSX_ENV3_MAX_CONTACT], contact_friction[ILSX_ENV3_MAX_CONTACT];
+  double timestep, gravity, reset_noise, reset_noise_vel_std, contact_margin, ctrl_range;
+  double contact_solref[2], contact_solimp[3], limit_solref[2], limit_solimp[3];
+  double ctrl_cost, alive_bonus, vel_weight, z_min, z_max;
+  double init_qpos[ILSX_ENV3_MAX_LINK + 6];
+} ilsx_spatial_model;
+int ilsx_vecenv_create_spatial(ilsx_ctx* ctx, const ilsx_spatial_model* model, int n_env, uint64_t seed, ilsx_vecenv** out);
+/* sizes of the simulator state rows of ilsx_vecenv_get_state / _set_state (planar: nq == nv; 3-D: nq == nv + 1) */
+int ilsx_vecenv_state_dims(const ilsx_vecenv* env, int* nq, int* nv);
 int ilsx_vecenv_destroy(ilsx_vecenv* env);
 int ilsx_vecenv_dims(const ilsx_vecenv* env, int* obs_dim, int* act_dim, int* n_dof, int* n_env);
 /* BaseVectorEnv.reset(id) (vecenvs.py:158-181): ids_host = NULL resets all; obs (device, nullable) [n_ids,o]. */
@@ -459,7 +489,7 @@ int ilsx_vecenv_reset(ilsx_vecenv* env, const int32_t* ids_host, int n_ids, floa
  * done[n_ids] (all device; outputs nullable).  No auto-reset (the caller resets finished ids, like the reference). */
 int ilsx_vecenv_step(ilsx_vecenv* env, const float* act, const int32_t* ids_host, int n_ids, float* obs, float* rew,
                      uint8_t* done);
-/* simulator state, HOST float64 [n_env, n_dof] (tests / snapshots) */
+/* simulator state, HOST float64 qpos [n_env, nq], qvel [n_env, nv] (tests / snapshots) */
 int ilsx_vecenv_get_state(ilsx_vecenv* env, double* qpos_host, double* qvel_host);
 int ilsx_vecenv_set_state(ilsx_vecenv* env, const double* qpos_host, const double* qvel_host);
 int ilsx_vecenv_cur_obs(ilsx_vecenv* env, float** dev_ptr);  /* [n_env,o] current (normalised if norm_obs) observations (device) */

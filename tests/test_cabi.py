@@ -46,7 +46,8 @@ def test_struct_sizes_match_header(built, tmp_path):
     import subprocess
     pairs = dict(ilsx_mlp_cfg="MlpCfg", ilsx_sac_cfg="SacCfg", ilsx_sac_stats="SacStats", ilsx_disc_cfg="DiscCfg",
                  ilsx_disc_stats="DiscStats", ilsx_ppo_cfg="PpoCfg", ilsx_td3_cfg="Td3Cfg", ilsx_td3_stats="Td3Stats",
-                 ilsx_sacv_cfg="SacvCfg", ilsx_sacv_stats="SacvStats", ilsx_bc_cfg="BcCfg", ilsx_planar_model="PlanarModel")
+                 ilsx_sacv_cfg="SacvCfg", ilsx_sacv_stats="SacvStats", ilsx_bc_cfg="BcCfg", ilsx_planar_model="PlanarModel", ilsx_spatial_model="SpatialModel",
+                 ilsx_opt_meta="OptMeta")
     src = tmp_path / "sizes.c"
     body = "".join(f'  printf("{c} %zu\\n", sizeof({c}));\n' for c in pairs)
     src.write_text('#include <stdio.h>\n#include "ilsx.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
