@@ -5,6 +5,7 @@
     python bench_aux.py gail    # C3: GAIL Walker2d dims, 1 discriminator step + 1 SAC step per loop iteration
     python bench_aux.py td3     # TD3 / SAC-V grad-steps/s at the SAC config's sizes
     python bench_aux.py seeds   # K co-resident SAC seeds on one GPU (multi-stream), aggregate grad-steps/s
+    python bench_aux.py humanoid  # C5 per-GPU share: 4 co-resident SAC seeds x 1024 Humanoid envs (obs 376, act 17)
 
 Each prints one JSON line.  Synthetic inputs of the configs' shapes, random-init networks.
 """
@@ -233,8 +234,72 @@ def bench_seeds(_ctx):
                 detail=res)
 
 
+def bench_humanoid(ctx):
+    """BASELINE config 5's share of ONE GPU: 4 seeds x 1024 Humanoid-v2 envs (obs 376 / act 17 / 256-256 SAC, batch 256), the four
+    runs stepped in lockstep by ilsx_sac_group.  Reports the 3-D stepper alone, the grouped SAC step alone, and the loop
+    (1 vec-env step per seed : 250 grad steps per seed — the 4096 : 1000 ratio of the headline config at 1024 envs)."""
+    from ilswiss_amd.envs.vecenv import HipVectorEnv
+    from ilswiss_amd.networks import FlattenMlp, ReparamTanhMultivariateGaussianPolicy
+    from ilswiss_amd.replay import SimpleReplayBuffer
+    from ilswiss_amd.sac import SoftActorCritic, SoftActorCriticGroup
+    o, a, H, B, K, N, CAP = 376, 17, 256, 256, 4, 1024, 200_000
+    envs, rbs, trs, pols = [], [], [], []
+    for k in range(K):
+        env = HipVectorEnv("humanoid", N, seed=10 + k, ctx=ctx)
+        rb = SimpleReplayBuffer(CAP, o, a, random_seed=k, ctx=ctx)
+        pol = ReparamTanhMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=k)
+        tr = SoftActorCritic(pol, FlattenMlp([H, H], 1, o + a, ctx=ctx, seed=k + 1), FlattenMlp([H, H], 1, o + a, ctx=ctx, seed=k + 2),
+                             policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+        tr.eval_statistics = {}
+        envs.append(env), rbs.append(rb), trs.append(tr), pols.append(pol)
+    grp = SoftActorCriticGroup(trs)
+    for t in range(12):     # fill: 12 x 1024 transitions per seed, random actions (min_steps_before_training)
+        for env, rb in zip(envs, rbs):
+            env.rollout_step(policy=None, replay=rb, max_path_length=1000, random_actions=True)
+    ctx.sync()
+    res = {}
+    n_env_steps = 30
+    nl, ms = _kernel_time(ctx, 9, lambda: [env.rollout_step(policy=p, replay=rb, max_path_length=1000)
+                                                              for _ in range(n_env_steps) for env, rb, p in zip(envs, rbs, pols)] and ctx.sync())
+    res["env_step_kernel_ms_1024_envs"] = ms / max(nl, 1)
+    t0 = time.perf_counter()
+    for _ in range(n_env_steps):
+        for env, rb, p in zip(envs, rbs, pols):
+            env.rollout_step(policy=p, replay=rb, max_path_length=1000)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    res["rollout_env_steps_per_s"] = K * N * n_env_steps / dt
+    grp.train_from_replay(rbs, 100, B); ctx.sync()
+    n = 1000
+    t0 = time.perf_counter()
+    grp.train_from_replay(rbs, n, B)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    res["grouped_grad_steps_per_s"] = K * n / dt
+    res["us_per_lockstep"] = 1e6 * dt / n
+    iters, per = 6, 250
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        for env, rb, p in zip(envs, rbs, pols):
+            env.rollout_step(policy=p, replay=rb, max_path_length=1000)
+        grp.train_from_replay(rbs, per, B)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    res["loop_grad_steps_per_s"] = K * per * iters / dt
+    res["loop_env_steps_per_s"] = K * N * iters / dt
+    ep, ret = 0, 0.0
+    for env in envs:
+        e_, r_ = env.rollout_stats()
+        ep, ret = ep + e_, ret + r_
+    res["episodes"], res["mean_return"] = ep, (ret / ep if ep else None)
+    return dict(metric="SAC Humanoid-v2 share of one GPU: 4 seeds x 1024 envs, aggregate grad-steps/s in the loop", unit="grad-steps/s (aggregate)",
+                value=res["loop_grad_steps_per_s"], dtype="f32 (networks) / f64 (stepper)", data="synthetic",
+                config=dict(workload="4 co-resident SAC runs, Humanoid-v2 model (obs 376, act 17), 1024 envs each, 256-256 MLP, batch 256, "
+                                     "1 vec-env step : 250 grad steps per run"), detail=res)
+
+
 if __name__ == "__main__":
     ctx = ilswiss_amd.Context(0, seed=0)
-    which = sys.argv[1:] or ["ppo", "gail", "td3", "seeds"]
+    which = sys.argv[1:] or ["ppo", "gail", "td3", "seeds", "humanoid"]
     for w in which:
-        print(json.dumps(dict(ppo=bench_ppo, gail=bench_gail, td3=bench_td3, seeds=bench_seeds)[w](ctx)), flush=True)
+        print(json.dumps(dict(ppo=bench_ppo, gail=bench_gail, td3=bench_td3, seeds=bench_seeds, humanoid=bench_humanoid)[w](ctx)), flush=True)
