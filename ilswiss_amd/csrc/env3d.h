@@ -34,6 +34,10 @@ struct Spatial3Dev {
   double ctrl_cost, alive, vel_weight, z_min, z_max;
   double init_qpos[E3_MAXL + 6];
   double obs_shift[E3_MAXOBS], obs_inv_scale[E3_MAXOBS];
+  // derived tables of the wave-per-env kernels (env3d_wave.h): links ordered by depth in the tree, ancestor-or-self bit masks,
+  // and the actuator on each hinge (-1: none)
+  int n_level, lvl_off[E3_MAXL + 1], lvl_link[E3_MAXL], link_act[E3_MAXL];
+  unsigned anc_mask[E3_MAXL];
 };
 
 // ---- scratch map (doubles per env); S(i) = element i of this env
@@ -611,5 +615,26 @@ static inline const char* e3_build_model(const ilsx_spatial_model* sm, Spatial3D
   m.obs_dim = m.task == ILSX_TASK_HUMANOID ? base + nb1 * 10 + nb1 * 6 + m.nv + nb1 * 6 : base + nb1 * 6;
   if (m.obs_dim > E3_MAXOBS) return "observation wider than E3_MAXOBS";
   for (int i = 0; i < E3_MAXOBS; ++i) { m.obs_shift[i] = 0.0; m.obs_inv_scale[i] = 1.0; }
+  {
+    int depth[E3_MAXL], maxd = 0;
+    depth[0] = 0; m.anc_mask[0] = 1u;
+    for (int l = 1; l < m.nl; ++l) {
+      depth[l] = depth[m.parent[l]] + 1;
+      m.anc_mask[l] = m.anc_mask[m.parent[l]] | (1u << l);
+      if (depth[l] > maxd) maxd = depth[l];
+    }
+    m.n_level = maxd + 1;
+    int at = 0;
+    for (int d = 0; d <= maxd; ++d) {
+      m.lvl_off[d] = at;
+      for (int l = 0; l < m.nl; ++l) if (depth[l] == d) m.lvl_link[at++] = l;
+    }
+    m.lvl_off[maxd + 1] = at;
+    for (int l = 0; l < E3_MAXL; ++l) m.link_act[l] = -1;
+    for (int k = 0; k < m.n_act; ++k) {
+      if (m.link_act[m.act_link[k]] >= 0) return "two actuators on one hinge";
+      m.link_act[m.act_link[k]] = k;
+    }
+  }
   return nullptr;
 }

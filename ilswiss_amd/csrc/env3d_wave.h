@@ -1,0 +1,573 @@
+// env3d_wave.h — the 3-D articulated-body stepper (Ant-v2 / Humanoid-v2), ONE WAVEFRONT PER ENV, working set in LDS.
+//
+// Same model, same equations and the same oracle as env3d.h (oracle/spatial_env.py; reference rules rlkit/envs/mujoco/humanoid.py:24-73,
+// ant.py:11-43).  env3d.h runs one env per lane with its ~2.8k-double working set in global scratch: every access is a memory round
+// trip and a 1024-env launch is 16 waves on a 1024-SIMD chip (measured 36.7 ms per vec-env step, profiles/r02).  Here the 64 lanes of a
+// wave share one env: link frames, composite inertias, the mass matrix / Cholesky factor, the constraint rows and the constraint-space
+// matrix live in 23 KB of LDS owned by that wave (6 envs resident per CU), and every O(n^2) / O(n^3) stage is spread over the lanes:
+//   kinematics            parallel over the links of one tree level (levels in sequence), joint rotations of all links first
+//   inertias / wrenches   parallel over links; subtree sums parallel over the 16 components, serial up the tree
+//   mass matrix (CRBA)    parallel over rows
+//   Cholesky, solves      right-looking / column-oriented: one uniform step per pivot, the update spread over the lanes
+//   constraint rows       parallel over contacts, then over (row, dof) Jacobian entries, then one row per lane for z_r = L^-1 j_r
+//   A = Z Z^T             parallel over entries
+//   Gauss-Seidel          rows in sequence (inherent), residuals kept incrementally: one multiply-add per lane per row update
+// Control flow is wave-uniform (one env per wave): the number of active rows, early exits and resets cost what THIS env needs.
+// Cross-lane hand-offs go through LDS inside one wave, which executes its LDS operations in order, so a hand-off needs only a
+// compiler fence (E3W_SYNC), never a workgroup barrier.
+//
+// The file also compiles for the host (tests/harness/env3d_host.cpp, E3W_HOST_EMU): a parallel loop becomes a serial loop run
+// forwards or backwards; any dependence between iterations of one parallel loop shows up as a mismatch between the two orders.
+#pragma once
+#include "env3d.h"
+
+#ifdef E3W_HOST_EMU
+typedef double e3w_lds;
+extern int e3w_reverse;
+#define E3W_FOR(i, n) for (int i##_c = 0, i##_n = (n), i = e3w_reverse ? i##_n - 1 : 0; i##_c < i##_n; ++i##_c, i += e3w_reverse ? -1 : 1)
+#define E3W_SYNC() ((void)0)
+#define E3W_ONE if (true)
+#else
+typedef __attribute__((address_space(3))) double e3w_lds;
+#define E3W_FOR(i, n) for (int i = lane; i < (n); i += 64)
+#define E3W_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define E3W_ONE if (lane == 0)
+#endif
+
+struct E3WOff {   // doubles
+  static constexpr int NVM = E3_MAXL + 5, NQM = NVM + 1;
+  static constexpr int KIN = 0;                                  // per link 27: R[9] o[3] w[3] vo[3] aw[3] al[3] ao[3]
+  static constexpr int CRB = KIN + 27 * E3_MAXL;                 // per link 10: m, h[3], Io[6] about the world origin
+  static constexpr int WR = CRB + 10 * E3_MAXL;                  // per link 6: subtree force, moment about the world origin
+  static constexpr int M = WR + 6 * E3_MAXL;                     // lower triangle (becomes L)
+  static constexpr int Z = M + NVM * (NVM + 1) / 2;              // rows [r][NVM]: j_r, then z_r = L^-1 j_r
+  static constexpr int A = Z + E3_MAXR * NVM;                    // lower triangle of Z Z^T; before that: contact distances and points
+  static constexpr int RM = A + E3_MAXR * (E3_MAXR + 1) / 2;     // per row 8: res, Rg, f, kind, mu, 1/(A_rr+Rg), source, r
+  static constexpr int VEC = RM + 8 * E3_MAXR;                   // qacc0[NVM], 1/L_kk[NVM], tmp[NVM]
+  static constexpr int Q0 = VEC + 3 * NVM, V0 = Q0 + NQM, QS = V0 + NVM, VS = QS + NQM, VSUM = VS + NVM, ASUM = VSUM + NVM,
+                       ACC = ASUM + NVM, CTRL = ACC + NVM, TOTAL = CTRL + E3_MAXL;
+};
+static_assert(E3_MAXC * 4 <= E3_MAXR * (E3_MAXR + 1) / 2, "contact scratch is overlaid on A");
+
+__device__ __forceinline__ void e3w_ld3(const e3w_lds* S, int at, double* v) { v[0] = S[at]; v[1] = S[at + 1]; v[2] = S[at + 2]; }
+__device__ __forceinline__ void e3w_st3(e3w_lds* S, int at, const double* v) { S[at] = v[0]; S[at + 1] = v[1]; S[at + 2] = v[2]; }
+__device__ __forceinline__ int e3w_tri_row(int t) {   // row of lower-triangle index t
+  int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (r * (r + 1) / 2 > t) --r;
+  while ((r + 1) * (r + 2) / 2 <= t) ++r;
+  return r;
+}
+
+// Link frames and velocity-product accelerations of the state at (qoff, voff) (oracle kin())
+__device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m, int lane, int qoff, int voff) {
+  E3W_FOR(l, m.nl) {
+    const int k = E3WOff::KIN + 27 * l;
+    if (l == 0) {
+      double qw = S[qoff + 3], qx = S[qoff + 4], qy = S[qoff + 5], qz = S[qoff + 6];
+      const double nrm = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+      qw *= nrm; qx *= nrm; qy *= nrm; qz *= nrm;
+      double R[9], o[3] = {S[qoff], S[qoff + 1], S[qoff + 2]}, wb[3] = {S[voff + 3], S[voff + 4], S[voff + 5]}, w[3];
+      e3_quat_to_R(qw, qx, qy, qz, R);
+      e3_matvec(R, wb, w);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) S[k + i] = R[i];
+      e3w_st3(S, k + 9, o); e3w_st3(S, k + 12, w);
+      const double vo[3] = {S[voff], S[voff + 1], S[voff + 2]}, z3[3] = {0.0, 0.0, 0.0};
+      e3w_st3(S, k + 15, vo); e3w_st3(S, k + 18, z3); e3w_st3(S, k + 21, z3); e3w_st3(S, k + 24, z3);
+    } else {   // rotation relative to the parent: fixed quat0, then Rodrigues about the hinge axis (parked in the link's R slot)
+      const double ang = S[qoff + 7 + l - 1];
+      const double s = sin(ang), c1 = 1.0 - cos(ang);
+      const double ax = m.axis[l][0], ay = m.axis[l][1], az = m.axis[l][2];
+      const double Rh[9] = {1.0 - c1 * (ay * ay + az * az), -s * az + c1 * ax * ay, s * ay + c1 * ax * az,
+                            s * az + c1 * ax * ay, 1.0 - c1 * (ax * ax + az * az), -s * ax + c1 * ay * az,
+                            -s * ay + c1 * ax * az, s * ax + c1 * ay * az, 1.0 - c1 * (ax * ax + ay * ay)};
+      double Rrel[9];
+      e3_mat3mul(m.Rq0[l], Rh, Rrel);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) S[k + i] = Rrel[i];
+    }
+  }
+  E3W_SYNC();
+  for (int d = 1; d < m.n_level; ++d) {
+    const int first = m.lvl_off[d], cnt = m.lvl_off[d + 1] - first;
+    E3W_FOR(ix, cnt) {
+      const int l = m.lvl_link[first + ix], p = m.parent[l], kp = E3WOff::KIN + 27 * p, k = E3WOff::KIN + 27 * l;
+      double Rp[9], Rrel[9], R[9], op[3], wp[3], vop[3], alp[3], aop[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { Rp[i] = S[kp + i]; Rrel[i] = S[k + i]; }
+      e3w_ld3(S, kp + 9, op); e3w_ld3(S, kp + 12, wp); e3w_ld3(S, kp + 15, vop); e3w_ld3(S, kp + 21, alp); e3w_ld3(S, kp + 24, aop);
+      const double qd = S[voff + 6 + l - 1];
+      e3_mat3mul(Rp, Rrel, R);
+      double rp[3], aw[3], o[3], w[3], al[3], vo[3], ao[3], t1[3], t2[3];
+      e3_matvec(Rp, m.anchor[l], rp);
+      e3_matvec(Rp, m.axis_p[l], aw);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { o[i] = op[i] + rp[i]; w[i] = wp[i] + aw[i] * qd; t1[i] = aw[i] * qd; }
+      e3_cross(wp, t1, t2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) al[i] = alp[i] + t2[i];
+      e3_cross(wp, rp, t1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) vo[i] = vop[i] + t1[i];
+      e3_cross(wp, t1, t2);         // w x (w x rp)
+      e3_cross(alp, rp, t1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) ao[i] = aop[i] + t1[i] + t2[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) S[k + i] = R[i];
+      e3w_st3(S, k + 9, o); e3w_st3(S, k + 12, w); e3w_st3(S, k + 15, vo); e3w_st3(S, k + 18, aw); e3w_st3(S, k + 21, al); e3w_st3(S, k + 24, ao);
+    }
+    E3W_SYNC();
+  }
+}
+
+// x <- L^-1 x, column by column: one uniform step per pivot, the update of the remaining entries spread over the lanes
+__device__ __forceinline__ void e3w_fwd_sub(e3w_lds* S, int lane, int nv, int x) {
+  for (int k = 0; k < nv; ++k) {
+    const double xk = S[x + k] * S[E3WOff::VEC + E3WOff::NVM + k];
+    E3W_FOR(ii, nv - 1 - k) { const int i = k + 1 + ii; S[x + i] -= S[E3WOff::M + e3_tri(i, k)] * xk; }
+    E3W_ONE S[x + k] = xk;
+    E3W_SYNC();
+  }
+}
+// x <- L^-T x
+__device__ __forceinline__ void e3w_bwd_sub(e3w_lds* S, int lane, int nv, int x) {
+  for (int k = nv - 1; k >= 0; --k) {
+    const double xk = S[x + k] * S[E3WOff::VEC + E3WOff::NVM + k];
+    E3W_FOR(i, k) S[x + i] -= S[E3WOff::M + e3_tri(k, i)] * xk;
+    E3W_ONE S[x + k] = xk;
+    E3W_SYNC();
+  }
+}
+
+// qacc = f(q, v, ctrl) with soft constraints (oracle dynamics()) -> S[out_off .. out_off + nv)
+__device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, int lane, int qoff, int voff, int ctrl_off, int out_off) {
+  const int nl = m.nl, nv = m.nv;
+  constexpr int NVM = E3WOff::NVM;
+  e3w_kinematics(S, m, lane, qoff, voff);
+  // ---- per link: composite-inertia seed about the world origin, Newton-Euler wrench about the world origin
+  E3W_FOR(l, nl) {
+    const int k = E3WOff::KIN + 27 * l, cb = E3WOff::CRB + 10 * l, wr = E3WOff::WR + 6 * l;
+    const double ml = m.mass[l];
+    double R[9], o[3], w[3], al[3], ao[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = S[k + i];
+    e3w_ld3(S, k + 9, o); e3w_ld3(S, k + 12, w); e3w_ld3(S, k + 21, al); e3w_ld3(S, k + 24, ao);
+    double rc[3], cw[3];
+    e3_matvec(R, m.com[l], rc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cw[i] = o[i] + rc[i];
+    const double* I6 = m.inertia[l];
+    const double Im[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+    double T[9], Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]}, Iw[9];
+    e3_mat3mul(R, Im, T);
+    e3_mat3mul(T, Rt, Iw);
+    const double c2 = e3_dot(cw, cw);
+    S[cb] = ml;
+    S[cb + 1] = ml * cw[0]; S[cb + 2] = ml * cw[1]; S[cb + 3] = ml * cw[2];
+    S[cb + 4] = Iw[0] + ml * (c2 - cw[0] * cw[0]); S[cb + 5] = Iw[4] + ml * (c2 - cw[1] * cw[1]); S[cb + 6] = Iw[8] + ml * (c2 - cw[2] * cw[2]);
+    S[cb + 7] = Iw[1] - ml * cw[0] * cw[1]; S[cb + 8] = Iw[2] - ml * cw[0] * cw[2]; S[cb + 9] = Iw[5] - ml * cw[1] * cw[2];
+    double t1[3], t2[3], ac[3], F[3], N[3], Iwv[3], n0[3];
+    e3_cross(w, rc, t1); e3_cross(w, t1, t2); e3_cross(al, rc, t1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ac[i] = ao[i] + t1[i] + t2[i];
+    ac[2] += m.gravity;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) F[i] = ml * ac[i];
+    e3_matvec(Iw, w, Iwv); e3_cross(w, Iwv, t1); e3_matvec(Iw, al, t2); e3_cross(cw, F, n0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) N[i] = t2[i] + t1[i] + n0[i];
+    e3w_st3(S, wr, F); e3w_st3(S, wr + 3, N);
+  }
+  E3W_FOR(t, nv * (nv + 1) / 2) S[E3WOff::M + t] = 0.0;
+  E3W_SYNC();
+  // ---- subtree sums, one component per lane, children before parents (a link's index exceeds its parent's)
+  E3W_FOR(c, 16) {
+    const int base = c < 10 ? E3WOff::CRB + c : E3WOff::WR + (c - 10), stride = c < 10 ? 10 : 6;
+    for (int l = nl - 1; l >= 1; --l) S[base + stride * m.parent[l]] += S[base + stride * l];
+  }
+  E3W_SYNC();
+  // ---- right-hand side tau - c (c: the subtree wrench projected on each dof) ; mass-matrix rows (CRBA)
+  const int q0v = E3WOff::VEC;
+  E3W_FOR(ix, nl + 6) {
+    double R0[9], o0[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R0[i] = S[E3WOff::KIN + i];
+    e3w_ld3(S, E3WOff::KIN + 9, o0);
+    double a[3] = {0.0, 0.0, 0.0}, v0[3] = {0.0, 0.0, 0.0};
+    int row, cb, l = 0;
+    if (ix < 6) {          // root dof ix: translation along world x/y/z, rotation about the body axes
+      row = ix; cb = E3WOff::CRB;
+      if (ix < 3) v0[ix] = 1.0;
+      else { a[0] = R0[ix - 3]; a[1] = R0[3 + ix - 3]; a[2] = R0[6 + ix - 3]; e3_cross(o0, a, v0); }
+    } else {
+      l = ix - 6 + 1;
+      if (l >= nl) continue;
+      row = 6 + l - 1; cb = E3WOff::CRB + 10 * l;
+      double o[3];
+      e3w_ld3(S, E3WOff::KIN + 27 * l + 18, a); e3w_ld3(S, E3WOff::KIN + 27 * l + 9, o);
+      e3_cross(o, a, v0);
+    }
+    // bias: S_row . (subtree wrench about the world origin)
+    {
+      const int wr = E3WOff::WR + 6 * l;
+      double f[3], n[3];
+      e3w_ld3(S, wr, f); e3w_ld3(S, wr + 3, n);
+      const double cvv = e3_dot(a, n) + e3_dot(v0, f);
+      double tau = 0.0;
+      if (l >= 1) {
+        tau = -m.damping[l] * S[voff + 6 + l - 1] - m.stiffness[l] * S[qoff + 7 + l - 1];
+        const int ka = m.link_act[l];
+        if (ka >= 0) tau += m.gear[l] * S[ctrl_off + ka];
+      }
+      S[q0v + row] = tau - cvv;
+    }
+    // momentum of the composite below this dof moving with (omega = a, v0): L about the world origin, p
+    double L[3], p[3];
+    {
+      const double mc = S[cb], h[3] = {S[cb + 1], S[cb + 2], S[cb + 3]};
+      const double Ixx = S[cb + 4], Iyy = S[cb + 5], Izz = S[cb + 6], Ixy = S[cb + 7], Ixz = S[cb + 8], Iyz = S[cb + 9];
+      double t[3];
+      e3_cross(a, h, t);
+      p[0] = mc * v0[0] + t[0]; p[1] = mc * v0[1] + t[1]; p[2] = mc * v0[2] + t[2];
+      e3_cross(h, v0, t);
+      L[0] = Ixx * a[0] + Ixy * a[1] + Ixz * a[2] + t[0];
+      L[1] = Ixy * a[0] + Iyy * a[1] + Iyz * a[2] + t[1];
+      L[2] = Ixz * a[0] + Iyz * a[1] + Izz * a[2] + t[2];
+    }
+    if (l >= 1) {
+      S[E3WOff::M + e3_tri(row, row)] = e3_dot(a, L) + e3_dot(v0, p) + m.armature[l];
+      for (int j = m.parent[l]; j >= 1; j = m.parent[j]) {
+        const int kj = E3WOff::KIN + 27 * j;
+        double aj[3], oj[3], vj[3];
+        e3w_ld3(S, kj + 18, aj); e3w_ld3(S, kj + 9, oj);
+        e3_cross(oj, aj, vj);
+        S[E3WOff::M + e3_tri(row, 6 + j - 1)] = e3_dot(aj, L) + e3_dot(vj, p);
+      }
+    }
+    for (int kx = 0; kx < 3; ++kx) {   // the six root columns of this row
+      if (kx <= row) S[E3WOff::M + e3_tri(row, kx)] = p[kx];
+      const double ar[3] = {R0[kx], R0[3 + kx], R0[6 + kx]};
+      double vr[3];
+      e3_cross(o0, ar, vr);
+      if (3 + kx <= row) S[E3WOff::M + e3_tri(row, 3 + kx)] = e3_dot(ar, L) + e3_dot(vr, p);
+    }
+  }
+  E3W_SYNC();
+  // ---- Cholesky in place (right-looking); 1 / L_kk kept for the solves
+  for (int k = 0; k < nv; ++k) {
+    const double d = sqrt(S[E3WOff::M + e3_tri(k, k)]), inv = 1.0 / d;
+    E3W_FOR(ii, nv - 1 - k) { const int i = k + 1 + ii; S[E3WOff::M + e3_tri(i, k)] *= inv; }
+    E3W_ONE { S[E3WOff::M + e3_tri(k, k)] = d; S[E3WOff::VEC + NVM + k] = inv; }
+    E3W_SYNC();
+    const int t0 = e3_tri(k + 1, k + 1), t1 = nv * (nv + 1) / 2;
+    E3W_FOR(tt, t1 - t0) {
+      const int t = t0 + tt, i = e3w_tri_row(t), j = t - i * (i + 1) / 2;
+      if (j > k) S[E3WOff::M + t] -= S[E3WOff::M + e3_tri(i, k)] * S[E3WOff::M + e3_tri(j, k)];
+    }
+    E3W_SYNC();
+  }
+  e3w_fwd_sub(S, lane, nv, q0v);
+  e3w_bwd_sub(S, lane, nv, q0v);
+  // ---- contacts: distance and contact point of every sphere
+  E3W_FOR(ci, m.n_contact) {
+    const int l = m.contact_link[ci], k = E3WOff::KIN + 27 * l;
+    double R[9], o[3], rp[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = S[k + i];
+    e3w_ld3(S, k + 9, o);
+    e3_matvec(R, m.cpos[ci], rp);
+    const double rad = m.crad[ci], dist = o[2] + rp[2] - rad;
+    S[E3WOff::A + ci] = dist;
+    S[E3WOff::A + E3_MAXC + 3 * ci] = o[0] + rp[0]; S[E3WOff::A + E3_MAXC + 3 * ci + 1] = o[1] + rp[1];
+    S[E3WOff::A + E3_MAXC + 3 * ci + 2] = o[2] + rp[2] - (rad + 0.5 * dist);
+  }
+  E3W_SYNC();
+  // ---- row table, in model order (contacts: normal, tangent x, tangent y ; then joint limits) — every lane walks it, one writes
+  int nr = 0;
+  for (int ci = 0; ci < m.n_contact; ++ci) {
+    const double dist = S[E3WOff::A + ci];
+    if (dist < m.margin && nr + 3 <= m.max_rows) {
+      E3W_ONE {
+        for (int d3 = 0; d3 < 3; ++d3) {
+          const int rm = E3WOff::RM + 8 * (nr + d3);
+          S[rm + 2] = 0.0; S[rm + 3] = (double)d3; S[rm + 4] = m.cfric[ci]; S[rm + 6] = (double)ci; S[rm + 7] = d3 == 0 ? dist : 0.0;
+        }
+      }
+      nr += 3;
+    }
+  }
+  for (int l = 1; l < nl; ++l) {
+    if (!m.limited[l] || nr + 1 > m.max_rows) continue;
+    const double ql = S[qoff + 7 + l - 1], lo = m.range[l][0], hi = m.range[l][1];
+    double sgn = 0.0, rr = 0.0;
+    if (ql - lo < 0.0) { sgn = 1.0; rr = ql - lo; }
+    else if (hi - ql < 0.0) { sgn = -1.0; rr = hi - ql; }
+    if (sgn == 0.0) continue;
+    E3W_ONE {
+      const int rm = E3WOff::RM + 8 * nr;
+      S[rm + 2] = 0.0; S[rm + 3] = 3.0; S[rm + 4] = sgn; S[rm + 6] = (double)l; S[rm + 7] = rr;
+    }
+    nr += 1;
+  }
+  if (nr == 0) {
+    E3W_FOR(i, nv) S[out_off + i] = S[q0v + i];
+    E3W_SYNC();
+    return;
+  }
+  E3W_SYNC();
+  // ---- Jacobian rows j_r, one (row, dof) entry per lane-iteration
+  E3W_FOR(e, nr * nv) {
+    const int r = e / nv, i = e - r * nv, rm = E3WOff::RM + 8 * r;
+    const int kind = (int)S[rm + 3], src = (int)S[rm + 6];
+    double val = 0.0;
+    if (kind == 3) {
+      val = (i == 6 + src - 1) ? S[rm + 4] : 0.0;
+    } else {
+      const int dir = kind == 0 ? 2 : kind - 1, l = m.contact_link[src];
+      double pw[3];
+      e3w_ld3(S, E3WOff::A + E3_MAXC + 3 * src, pw);
+      if (i < 3) val = (i == dir) ? 1.0 : 0.0;
+      else {
+        double aj[3], oj[3], rel[3], t[3];
+        bool on = true;
+        if (i < 6) {
+          aj[0] = S[E3WOff::KIN + i - 3]; aj[1] = S[E3WOff::KIN + 3 + i - 3]; aj[2] = S[E3WOff::KIN + 6 + i - 3];
+          e3w_ld3(S, E3WOff::KIN + 9, oj);
+        } else {
+          const int j = i - 6 + 1;
+          on = (m.anc_mask[l] >> j) & 1u;
+          e3w_ld3(S, E3WOff::KIN + 27 * j + 18, aj); e3w_ld3(S, E3WOff::KIN + 27 * j + 9, oj);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rel[c] = pw[c] - oj[c];
+        e3_cross(aj, rel, t);
+        val = on ? t[dir] : 0.0;
+      }
+    }
+    S[E3WOff::Z + r * NVM + i] = val;
+  }
+  E3W_SYNC();
+  // ---- one row per lane: J.v, J.qacc0, z = L^-1 j (row-oriented, private to the lane), the row's regulariser and reference
+  E3W_FOR(r, nr) {
+    const int zr = E3WOff::Z + r * NVM, rm = E3WOff::RM + 8 * r;
+    double jv = 0.0, jq = 0.0;
+    for (int i = 0; i < nv; ++i) { const double j = S[zr + i]; jv += j * S[voff + i]; jq += j * S[q0v + i]; }
+    double aii = 0.0;
+    for (int i = 0; i < nv; ++i) {
+      double sum = S[zr + i];
+      for (int t = 0; t < i; ++t) sum -= S[E3WOff::M + e3_tri(i, t)] * S[zr + t];
+      sum *= S[E3WOff::VEC + NVM + i];
+      S[zr + i] = sum;
+      aii += sum * sum;
+    }
+    const int kind = (int)S[rm + 3];
+    const double rr = S[rm + 7];
+    const double rdist = kind == 3 ? rr : S[E3WOff::A + (int)S[rm + 6]];
+    const double* solref = kind == 3 ? m.l_solref : m.c_solref;
+    const double* solimp = kind == 3 ? m.l_solimp : m.c_solimp;
+    const double d = e3_impedance(fabs(rdist), solimp);
+    const double dmax = solimp[1], tc = solref[0], dr = solref[1];
+    const double b = 2.0 / (dmax * tc), ks = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+    const double aref = -b * jv - ks * d * rr;
+    const double Rg = (1.0 - d) / d * aii;
+    S[rm] = aref - jq;          // residual rhs - A f at f = 0
+    S[rm + 1] = Rg;
+    S[rm + 5] = 1.0 / (aii + Rg);
+    if (kind != 3) S[rm + 4] = m.cfric[(int)S[rm + 6]];
+  }
+  E3W_SYNC();
+  // ---- A = Z Z^T (overwrites the contact scratch: every reader of it is behind the fence above)
+  E3W_FOR(t, nr * (nr + 1) / 2) {
+    const int r = e3w_tri_row(t), c = t - r * (r + 1) / 2;
+    double s = 0.0;
+    for (int i = 0; i < nv; ++i) s += S[E3WOff::Z + r * NVM + i] * S[E3WOff::Z + c * NVM + i];
+    S[E3WOff::A + t] = s;
+  }
+  E3W_SYNC();
+  // ---- projected Gauss-Seidel: rows in sequence; each update changes one force, every lane folds it into its row's residual
+  for (int it = 0; it < m.pgs_iters; ++it)
+    for (int r = 0; r < nr; ++r) {
+      const int rm = E3WOff::RM + 8 * r;
+      const double arr = S[E3WOff::A + e3_tri(r, r)], fold = S[rm + 2];
+      double fi = (S[rm] + arr * fold) * S[rm + 5];
+      const int kind = (int)S[rm + 3];
+      if (kind == 1 || kind == 2) {
+        const double lim = S[rm + 4] * S[E3WOff::RM + 8 * (r - kind) + 2];
+        fi = fmin(fmax(fi, -lim), lim);
+      } else {
+        fi = fmax(fi, 0.0);
+      }
+      const double delta = fi - fold;
+      E3W_FOR(c, nr) S[E3WOff::RM + 8 * c] -= (r >= c ? S[E3WOff::A + e3_tri(r, c)] : S[E3WOff::A + e3_tri(c, r)]) * delta;
+      E3W_ONE S[rm + 2] = fi;
+      E3W_SYNC();
+    }
+  // ---- qacc = qacc0 + L^-T (sum_r z_r f_r)
+  const int tv = E3WOff::VEC + 2 * NVM;
+  E3W_FOR(i, nv) {
+    double s = 0.0;
+    for (int r = 0; r < nr; ++r) s += S[E3WOff::Z + r * NVM + i] * S[E3WOff::RM + 8 * r + 2];
+    S[tv + i] = s;
+  }
+  E3W_SYNC();
+  e3w_bwd_sub(S, lane, nv, tv);
+  E3W_FOR(i, nv) S[out_off + i] = S[q0v + i] + S[tv + i];
+  E3W_SYNC();
+}
+
+// mj_integratePos: dst_q = src_q (+) h * vel.  The quaternion update is computed by every lane (uniform) and written by one.
+__device__ __forceinline__ void e3w_integrate_pos(e3w_lds* S, const Spatial3Dev& m, int lane, int src_q, int voff, double h, int dst_q) {
+  const double wx = S[voff + 3], wy = S[voff + 4], wz = S[voff + 5];
+  double qw = S[src_q + 3], qx = S[src_q + 4], qy = S[src_q + 5], qz = S[src_q + 6];
+  const double wn = sqrt(wx * wx + wy * wy + wz * wz), ang = wn * h;
+  if (ang > 0.0) {
+    const double sh = sin(0.5 * ang) / wn, ch = cos(0.5 * ang);
+    const double bx = sh * wx, by = sh * wy, bz = sh * wz;
+    const double nw = qw * ch - qx * bx - qy * by - qz * bz, nx = qw * bx + qx * ch + qy * bz - qz * by;
+    const double ny = qw * by - qx * bz + qy * ch + qz * bx, nz = qw * bz + qx * by - qy * bx + qz * ch;
+    qw = nw; qx = nx; qy = ny; qz = nz;
+  }
+  const double nrm = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+  const double p0 = S[src_q] + h * S[voff], p1 = S[src_q + 1] + h * S[voff + 1], p2 = S[src_q + 2] + h * S[voff + 2];
+  E3W_SYNC();   // src_q may be dst_q's neighbour in a later phase; keep reads ahead of the writes below
+  E3W_ONE {
+    S[dst_q] = p0; S[dst_q + 1] = p1; S[dst_q + 2] = p2;
+    S[dst_q + 3] = qw * nrm; S[dst_q + 4] = qx * nrm; S[dst_q + 5] = qy * nrm; S[dst_q + 6] = qz * nrm;
+  }
+  E3W_FOR(j, m.nl - 1) S[dst_q + 7 + j] = S[src_q + 7 + j] + h * S[voff + 6 + j];
+  E3W_SYNC();
+}
+
+// one RK4 substep on the state at (Q0, V0), positions on the manifold (oracle substep()).  Four stages through ONE dynamics call
+// site so that the largest piece of code exists once.
+__device__ __forceinline__ void e3w_substep(e3w_lds* S, const Spatial3Dev& m, int lane) {
+  const int nv = m.nv;
+  const double h = m.timestep;
+#pragma unroll 1
+  for (int st = 0; st < 4; ++st) {
+    const double hs = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h), wt = (st == 1 || st == 2) ? 2.0 : 1.0;
+    if (st == 0) {
+      E3W_FOR(i, m.nq) S[E3WOff::QS + i] = S[E3WOff::Q0 + i];
+      E3W_FOR(i, nv) { S[E3WOff::VS + i] = S[E3WOff::V0 + i]; S[E3WOff::VSUM + i] = 0.0; S[E3WOff::ASUM + i] = 0.0; }
+      E3W_SYNC();
+    } else {   // stage state: q_s = q0 (+) hs * v_(previous stage), v_s = v0 + hs * a_(previous stage)
+      e3w_integrate_pos(S, m, lane, E3WOff::Q0, E3WOff::VS, hs, E3WOff::QS);
+      E3W_FOR(i, nv) S[E3WOff::VS + i] = S[E3WOff::V0 + i] + hs * S[E3WOff::ACC + i];
+      E3W_SYNC();
+    }
+    e3w_dynamics(S, m, lane, E3WOff::QS, E3WOff::VS, E3WOff::CTRL, E3WOff::ACC);
+    E3W_FOR(i, nv) { S[E3WOff::VSUM + i] += wt * S[E3WOff::VS + i]; S[E3WOff::ASUM + i] += wt * S[E3WOff::ACC + i]; }
+    E3W_SYNC();
+  }
+  E3W_FOR(i, nv) S[E3WOff::VSUM + i] *= (1.0 / 6.0);
+  E3W_SYNC();
+  e3w_integrate_pos(S, m, lane, E3WOff::Q0, E3WOff::VSUM, h, E3WOff::QS);
+  E3W_FOR(i, m.nq) S[E3WOff::Q0 + i] = S[E3WOff::QS + i];
+  E3W_FOR(i, nv) S[E3WOff::V0 + i] += h / 6.0 * S[E3WOff::ASUM + i];
+  E3W_SYNC();
+}
+
+// whole-model centre of mass from the link frames in KIN (every lane computes it: uniform reads, no hand-off)
+__device__ __forceinline__ void e3w_com(const e3w_lds* S, const Spatial3Dev& m, double* com3) {
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int l = 0; l < m.nl; ++l) {
+    if (m.mass[l] == 0.0) continue;
+    const int k = E3WOff::KIN + 27 * l;
+    double R[9], o[3], rc[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = S[k + i];
+    e3w_ld3(S, k + 9, o);
+    e3_matvec(R, m.com[l], rc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i] += m.mass[l] * (o[i] + rc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) com3[i] = s[i] / m.total_mass;
+}
+
+// env.step() on the state at (Q0, V0) (oracle step()); leaves KIN = kinematics of the new state.  reward / done are wave-uniform.
+__device__ __forceinline__ void e3w_task_step(e3w_lds* S, const Spatial3Dev& m, int lane, const float* act, double& reward, bool& done) {
+  double ctrl_sq = 0.0;
+  for (int k = 0; k < m.n_act; ++k) {   // NormalizedBoxEnv: [-1, 1] -> ctrlrange, clip (wrappers.py:343-346)
+    const double a = (double)act[k];
+    const double u = fmin(fmax(a * m.ctrl_range, -m.ctrl_range), m.ctrl_range);
+    const double ac = fmin(fmax(a, -1.0), 1.0);
+    ctrl_sq += m.task == 4 ? u * u : ac * ac;   // humanoid.py:45 squares data.ctrl, ant.py:16 the action it was given
+  }
+  E3W_FOR(k, m.n_act) S[E3WOff::CTRL + k] = fmin(fmax((double)act[k] * m.ctrl_range, -m.ctrl_range), m.ctrl_range);
+  E3W_SYNC();
+  double x0 = S[E3WOff::Q0], com[3];
+  if (m.task == 4) { e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0); e3w_com(S, m, com); x0 = com[0]; }
+#pragma unroll 1
+  for (int s = 0; s < m.frame_skip; ++s) e3w_substep(S, m, lane);
+  e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0);
+  const double z = S[E3WOff::Q0 + 2];
+  if (m.task == 4) {   // humanoid.py:37-49
+    e3w_com(S, m, com);
+    reward = m.vel_weight * (com[0] - x0) / m.timestep - m.ctrl_cost * ctrl_sq + m.alive;
+    done = z < m.z_min || z > m.z_max;
+  } else {             // ant.py:11-24
+    reward = (S[E3WOff::Q0] - x0) / (m.timestep * m.frame_skip) - m.ctrl_cost * ctrl_sq + m.alive;
+    bool fin = true;
+    for (int i = 0; i < m.nq; ++i) fin = fin && isfinite(S[E3WOff::Q0 + i]);
+    for (int i = 0; i < m.nv; ++i) fin = fin && isfinite(S[E3WOff::V0 + i]);
+    done = !(fin && z >= m.z_min && z <= m.z_max);
+  }
+}
+
+// observation of the state at (Q0, V0) (oracle obs()); KIN must hold its kinematics.  put(i, value) is called once per component,
+// components spread over the lanes.
+template <class Put>
+__device__ __forceinline__ void e3w_observe(const e3w_lds* S, const Spatial3Dev& m, int lane, Put put) {
+  const int nq2 = m.nq - 2, nv = m.nv, nb = m.n_body;
+  E3W_FOR(i, nq2) put(i, S[E3WOff::Q0 + 2 + i]);
+  E3W_FOR(i, nv) put(nq2 + i, S[E3WOff::V0 + i]);
+  int at = nq2 + nv;
+  if (m.task == 3) {   // Ant-v2: clip(cfrc_ext, -1, 1) of 14 bodies — zeros (oracle/spatial_env.py::obs_extras)
+    E3W_FOR(i, (nb + 1) * 6) put(at + i, 0.0);
+    return;
+  }
+  double com[3];
+  e3w_com(S, m, com);
+  E3W_FOR(b1, nb + 1) {            // cinert: row 0 is the world body
+    const int base = at + 10 * b1, b = b1 - 1;
+    if (b1 == 0 || !m.body_first[b]) { for (int i = 0; i < 10; ++i) put(base + i, 0.0); continue; }   // welded body: mass sits in the link above
+    const int l = m.body_link[b], k = E3WOff::KIN + 27 * l;
+    double R[9], o[3], rc[3], d[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = S[k + i];
+    e3w_ld3(S, k + 9, o);
+    e3_matvec(R, m.com[l], rc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = o[i] + rc[i] - com[i];
+    const double* I6 = m.inertia[l];
+    const double Im[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+    double T[9], Rt[9] = {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]}, Iw[9];
+    e3_mat3mul(R, Im, T); e3_mat3mul(T, Rt, Iw);
+    const double ml = m.mass[l], d2 = e3_dot(d, d);
+    put(base, Iw[0] + ml * (d2 - d[0] * d[0])); put(base + 1, Iw[4] + ml * (d2 - d[1] * d[1])); put(base + 2, Iw[8] + ml * (d2 - d[2] * d[2]));
+    put(base + 3, Iw[1] - ml * d[0] * d[1]); put(base + 4, Iw[2] - ml * d[0] * d[2]); put(base + 5, Iw[5] - ml * d[1] * d[2]);
+    put(base + 6, ml * d[0]); put(base + 7, ml * d[1]); put(base + 8, ml * d[2]); put(base + 9, ml);
+  }
+  at += 10 * (nb + 1);
+  E3W_FOR(b1, nb + 1) {            // cvel
+    const int base = at + 6 * b1;
+    if (b1 == 0) { for (int i = 0; i < 6; ++i) put(base + i, 0.0); continue; }
+    const int k = E3WOff::KIN + 27 * m.body_link[b1 - 1];
+    double o[3], w[3], vo[3], rel[3], t[3];
+    e3w_ld3(S, k + 9, o); e3w_ld3(S, k + 12, w); e3w_ld3(S, k + 15, vo);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rel[i] = com[i] - o[i];
+    e3_cross(w, rel, t);
+    put(base, w[0]); put(base + 1, w[1]); put(base + 2, w[2]);
+    put(base + 3, vo[0] + t[0]); put(base + 4, vo[1] + t[1]); put(base + 5, vo[2] + t[2]);
+  }
+  at += 6 * (nb + 1);
+  E3W_FOR(i, nv) {                 // qfrc_actuator
+    const int l = i - 6 + 1, ka = (i >= 6) ? m.link_act[l] : -1;
+    put(at + i, ka >= 0 ? m.gear[l] * S[E3WOff::CTRL + ka] : 0.0);
+  }
+  at += nv;
+  E3W_FOR(i, (nb + 1) * 6) put(at + i, 0.0);   // cfrc_ext
+}

@@ -14,6 +14,7 @@
 
 #include "host_common.h"
 #include "env3d.h"
+#include "env3d_wave.h"
 
 #define ENV_MAXB 8
 #define ENV_MAXG 8
@@ -56,6 +57,7 @@ struct ilsx_vecenv {
   bool norm_obs = false, update_rms = false;
   // 3-D engine (Ant / Humanoid, env3d.h): model, its device copy, and the per-env working set [E3Off::TOTAL][n_env]
   int engine = 0, nq = 0, nv = 0;
+  bool wave3 = true;   // wave-per-env kernels (env3d_wave.h); ILSX_ENV3D_LANE=1 selects the lane-per-env form (env3d.h) for A/B runs
   Spatial3Dev* hm3 = nullptr; Spatial3Dev* dm3 = nullptr; double* scr3 = nullptr;
   const float* policy_obs() const { return norm_obs ? obs_n : obs_cur; }
 };
@@ -666,6 +668,111 @@ __global__ __launch_bounds__(64) void k_env3d_reset(const Spatial3Dev* mp, doubl
   for (int i = 0; i < m.nv; ++i) qvel[(size_t)i * n_env + env] = E3S(E3St::V0 + i);
 }
 
+// ---- wave-per-env form (env3d_wave.h): one 64-lane workgroup per env, working set in that wave's LDS
+__device__ __forceinline__ void e3w_reset_state(e3w_lds* S, const Spatial3Dev& m, int lane, uint64_t seed, uint32_t stream, unsigned long long step,
+                                                uint32_t envu) {
+  // same draws as e3_reset_state: component i of qpos uses counter i, qvel nq + i (uniform) or nq + 2i, nq + 2i + 1 (Box-Muller)
+  E3W_FOR(i, m.nq) S[E3WOff::Q0 + i] = m.init_qpos[i] + m.reset_noise * (2.0 * env_uniform(seed, stream, step, envu, i) - 1.0);
+  E3W_FOR(i, m.nv) {
+    if (m.reset_noise_vel_std > 0.0) {
+      const double u1 = env_uniform(seed, stream, step, envu, m.nq + 2 * i), u2 = env_uniform(seed, stream, step, envu, m.nq + 2 * i + 1);
+      S[E3WOff::V0 + i] = m.reset_noise_vel_std * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    } else {
+      S[E3WOff::V0 + i] = m.reset_noise * (2.0 * env_uniform(seed, stream, step, envu, m.nq + i) - 1.0);
+    }
+  }
+  E3W_FOR(k, m.n_act) S[E3WOff::CTRL + k] = 0.0;   // qfrc_actuator of a freshly reset model is zero
+  E3W_SYNC();
+  const double qw = S[E3WOff::Q0 + 3], qx = S[E3WOff::Q0 + 4], qy = S[E3WOff::Q0 + 5], qz = S[E3WOff::Q0 + 6];
+  const double nrm = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+  E3W_SYNC();
+  E3W_ONE { S[E3WOff::Q0 + 3] = qw * nrm; S[E3WOff::Q0 + 4] = qx * nrm; S[E3WOff::Q0 + 5] = qy * nrm; S[E3WOff::Q0 + 6] = qz * nrm; }
+  E3W_SYNC();
+}
+
+__global__ __launch_bounds__(64) void k_env3dw_step(const EnvStepArgs A, const Spatial3Dev* mp) {
+  extern __shared__ __attribute__((aligned(16))) double e3w_smem[];
+  e3w_lds* S = (e3w_lds*)e3w_smem;
+  const Spatial3Dev& m = *mp;
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int env = A.ids ? A.ids[t] : t, n_env = A.n_env;
+  if (A.frozen && A.frozen[env]) return;
+  const int o = m.obs_dim, na = m.n_act;
+  E3W_FOR(i, m.nq) S[E3WOff::Q0 + i] = A.qpos[(size_t)i * n_env + env];
+  E3W_FOR(i, m.nv) S[E3WOff::V0 + i] = A.qvel[(size_t)i * n_env + env];
+  float* rec = nullptr;
+  if (A.replay) {   // fused replay insert: the observation the policy acted on is the stored current observation
+    long long slot = A.top + env;
+    if (slot >= A.cap) slot -= A.cap;
+    rec = A.replay + (size_t)slot * A.rec;
+    E3W_FOR(i, o) rec[i] = A.obs_cur[(size_t)env * o + i];
+  }
+  E3W_SYNC();
+  double reward; bool done;
+  e3w_task_step(S, m, lane, A.act + (size_t)t * na, reward, done);
+  bool end = false; int len = 0; double ret = 0.0;
+  if (A.auto_reset) {
+    len = A.ep_len[env] + 1; ret = A.ep_ret[env] + reward;
+    end = done || len >= A.max_path_length;   // time-limit ends are NOT terminal (base_algorithm.py:264-277)
+  }
+  float* obs_out = A.obs ? A.obs + (size_t)t * o : nullptr;
+  float* cur = (A.obs_cur && !end) ? A.obs_cur + (size_t)env * o : nullptr;
+  float* rnext = rec ? rec + o + na + 2 : nullptr;
+  e3w_observe(S, m, lane, [&](int i, double val) {
+    const float f = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]);
+    if (obs_out) obs_out[i] = f;
+    if (cur) cur[i] = f;
+    if (rnext) rnext[i] = f;
+  });
+  if (lane == 0) {
+    if (A.rew) A.rew[t] = (float)reward;
+    if (A.done) A.done[t] = done ? 1 : 0;
+  }
+  if (rec) {
+    const float* ra = A.rec_act ? A.rec_act : A.act;
+    E3W_FOR(k, na) rec[o + k] = ra[(size_t)t * na + k];
+    if (lane == 0) {
+      rec[o + na] = (float)reward;
+      rec[o + na + 1] = (done && !A.no_terminal) ? 1.0f : 0.0f;
+      rec[2 * o + na + 2] = 0.0f; rec[2 * o + na + 3] = 0.0f;
+    }
+  }
+  if (A.auto_reset) {
+    if (end) {
+      if (lane == 0) { atomicAdd(&A.stats[0], 1.0); atomicAdd(&A.stats[1], ret); }
+      E3W_SYNC();
+      e3w_reset_state(S, m, lane, A.seed, A.stream, A.step, (uint32_t)env);
+      e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0);
+      float* c2 = A.obs_cur + (size_t)env * o;
+      e3w_observe(S, m, lane, [&](int i, double val) { c2[i] = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]); });
+    }
+    if (lane == 0) { A.ep_len[env] = end ? 0 : len; A.ep_ret[env] = end ? 0.0 : ret; }
+  }
+  E3W_FOR(i, m.nq) A.qpos[(size_t)i * n_env + env] = S[E3WOff::Q0 + i];
+  E3W_FOR(i, m.nv) A.qvel[(size_t)i * n_env + env] = S[E3WOff::V0 + i];
+}
+
+__global__ __launch_bounds__(64) void k_env3dw_reset(const Spatial3Dev* mp, double* qpos, double* qvel, int n_env, const int* ids, float* obs,
+                                                     float* obs_cur, int* ep_len, double* ep_ret, uint64_t seed, uint32_t stream,
+                                                     unsigned long long step) {
+  extern __shared__ __attribute__((aligned(16))) double e3w_smem[];
+  e3w_lds* S = (e3w_lds*)e3w_smem;
+  const Spatial3Dev& m = *mp;
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int env = ids ? ids[t] : t;
+  e3w_reset_state(S, m, lane, seed, stream, step, (uint32_t)env);
+  e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0);
+  const int o = m.obs_dim;
+  e3w_observe(S, m, lane, [&](int i, double val) {
+    const float f = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]);
+    if (obs) obs[(size_t)t * o + i] = f;
+    if (obs_cur) obs_cur[(size_t)env * o + i] = f;
+  });
+  if (lane == 0) { ep_len[env] = 0; ep_ret[env] = 0.0; }
+  E3W_FOR(i, m.nq) qpos[(size_t)i * n_env + env] = S[E3WOff::Q0 + i];
+  E3W_FOR(i, m.nv) qvel[(size_t)i * n_env + env] = S[E3WOff::V0 + i];
+}
+
 // ------------------------------------------------------------------------------------------------ host
 template <int NB, int MR, int BLOCK>
 static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
@@ -685,7 +792,10 @@ static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
   if (A.n_ids <= 0) return ILSX_OK;
   if (e->engine == 1) {
     ProfScope ps(e->ctx, ILSX_K_ENV_STEP);
-    ILSX_LAUNCH(ps, k_env3d_step, dim3((A.n_ids + 63) / 64), dim3(64), 0, e->ctx->stream, A, (const Spatial3Dev*)e->dm3, e->scr3);
+    if (e->wave3)
+      ILSX_LAUNCH(ps, k_env3dw_step, dim3(A.n_ids), dim3(64), (size_t)E3WOff::TOTAL * 8, e->ctx->stream, A, (const Spatial3Dev*)e->dm3);
+    else
+      ILSX_LAUNCH(ps, k_env3d_step, dim3((A.n_ids + 63) / 64), dim3(64), 0, e->ctx->stream, A, (const Spatial3Dev*)e->dm3, e->scr3);
     HIPCHK(hipGetLastError());
     return ILSX_OK;
   }
@@ -696,6 +806,12 @@ static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
 static int launch_env_reset(ilsx_vecenv* e, const int* ids_dev, int n_ids, float* obs) {
   if (n_ids <= 0) return ILSX_OK;
   const unsigned long long step = ++e->step_ctr;
+  if (e->engine == 1 && e->wave3) {
+    hipLaunchKernelGGL(k_env3dw_reset, dim3(n_ids), dim3(64), (size_t)E3WOff::TOTAL * 8, e->ctx->stream, (const Spatial3Dev*)e->dm3, e->qpos, e->qvel,
+                       e->n_env, ids_dev, obs, e->obs_cur, e->ep_len, e->ep_ret, e->seed, e->rng_stream, step);
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   if (e->engine == 1) {
     hipLaunchKernelGGL(k_env3d_reset, dim3((n_ids + 63) / 64), dim3(64), 0, e->ctx->stream, (const Spatial3Dev*)e->dm3, e->scr3, e->qpos, e->qvel,
                        e->n_env, ids_dev, n_ids, obs, e->obs_cur, e->ep_len, e->ep_ret, e->seed, e->rng_stream, step);
@@ -804,6 +920,11 @@ extern "C" int ilsx_vecenv_create_spatial(ilsx_ctx* ctx, const ilsx_spatial_mode
   HIPCHK(hipSetDevice(ctx->device));
   ilsx_vecenv* e = new ilsx_vecenv();
   e->ctx = ctx; e->n_env = n_env; e->seed = seed; e->rng_stream = ctx->next_rng_stream++; e->engine = 1;
+  e->wave3 = !(getenv("ILSX_ENV3D_LANE") && atoi(getenv("ILSX_ENV3D_LANE")) != 0);
+  if (e->wave3) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_env3dw_step, hipFuncAttributeMaxDynamicSharedMemorySize, E3WOff::TOTAL * 8));
+    HIPCHK(hipFuncSetAttribute((const void*)k_env3dw_reset, hipFuncAttributeMaxDynamicSharedMemorySize, E3WOff::TOTAL * 8));
+  }
   e->hm3 = new Spatial3Dev();
   Spatial3Dev& m = *e->hm3;
   if (const char* why = e3_build_model(sm, m)) { delete e->hm3; delete e; ILSX_FAIL(ILSX_ERR_ARG, "ilsx_vecenv_create_spatial: %s", why); }

@@ -3,8 +3,12 @@
 // by tests/test_env3d_host.py into a temp dir; nothing in ilswiss_amd/ loads it.  One "lane" at a time: n_env = 1, env = 0.
 #define __device__
 #define __forceinline__ inline
+#define E3W_HOST_EMU 1
 #include <vector>
 #include "../../ilswiss_amd/csrc/env3d.h"
+#include "../../ilswiss_amd/csrc/env3d_wave.h"
+
+int e3w_reverse = 0;   // order in which the emulated "parallel" loops of env3d_wave.h run: 0 ascending, 1 descending
 
 extern "C" int e3h_scratch_doubles() { return E3Off::TOTAL; }
 extern "C" int e3h_obs_dim(const ilsx_spatial_model* sm) {
@@ -42,5 +46,38 @@ extern "C" int e3h_qacc(const ilsx_spatial_model* sm, const double* q, const dou
   for (int k = 0; k < m.n_act; ++k) E3S(E3St::CTRL + k) = ctrl[k];
   e3_dynamics(C, E3St::Q0, E3St::V0, E3St::CTRL, E3St::ACC);
   for (int i = 0; i < m.nv; ++i) qacc[i] = E3S(E3St::ACC + i);
+  return 0;
+}
+
+// ---- the wave-per-env form (env3d_wave.h) under host emulation: parallel loops run serially, ascending or descending
+extern "C" int e3hw_scratch_doubles() { return E3WOff::TOTAL; }
+extern "C" int e3hw_step(const ilsx_spatial_model* sm, int reverse, double* q, double* v, const float* act, double* obs, double* reward, int* done) {
+  static Spatial3Dev m;
+  if (e3_build_model(sm, m)) return -1;
+  e3w_reverse = reverse;
+  std::vector<double> S(E3WOff::TOTAL, 0.0);
+  const int lane = 0;
+  for (int i = 0; i < m.nq; ++i) S[E3WOff::Q0 + i] = q[i];
+  for (int i = 0; i < m.nv; ++i) S[E3WOff::V0 + i] = v[i];
+  bool d; double r;
+  e3w_task_step(S.data(), m, lane, act, r, d);
+  for (int i = 0; i < m.obs_dim; ++i) obs[i] = -12345.0;
+  e3w_observe(S.data(), m, lane, [&](int i, double val) { obs[i] = val; });
+  *reward = r; *done = d ? 1 : 0;
+  for (int i = 0; i < m.nq; ++i) q[i] = S[E3WOff::Q0 + i];
+  for (int i = 0; i < m.nv; ++i) v[i] = S[E3WOff::V0 + i];
+  return 0;
+}
+extern "C" int e3hw_qacc(const ilsx_spatial_model* sm, int reverse, const double* q, const double* v, const double* ctrl, double* qacc) {
+  static Spatial3Dev m;
+  if (e3_build_model(sm, m)) return -1;
+  e3w_reverse = reverse;
+  std::vector<double> S(E3WOff::TOTAL, 0.0);
+  const int lane = 0;
+  for (int i = 0; i < m.nq; ++i) S[E3WOff::Q0 + i] = q[i];
+  for (int i = 0; i < m.nv; ++i) S[E3WOff::V0 + i] = v[i];
+  for (int k = 0; k < m.n_act; ++k) S[E3WOff::CTRL + k] = ctrl[k];
+  e3w_dynamics(S.data(), m, lane, E3WOff::Q0, E3WOff::V0, E3WOff::CTRL, E3WOff::ACC);
+  for (int i = 0; i < m.nv; ++i) qacc[i] = S[E3WOff::ACC + i];
   return 0;
 }

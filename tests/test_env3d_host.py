@@ -1,5 +1,7 @@
-"""CPU suite: the DEVICE code of the 3-D stepper (ilswiss_amd/csrc/env3d.h), compiled for the host by tests/harness/env3d_host.cpp,
-against oracle/spatial_env.py — tree recursions vs dense Jacobians + numpy solves.  The GPU suite (tests/test_env3d_hip.py) repeats
+"""CPU suite: the DEVICE code of the 3-D stepper (ilswiss_amd/csrc/env3d.h lane-per-env, env3d_wave.h wave-per-env), compiled for the
+host by tests/harness/env3d_host.cpp, against oracle/spatial_env.py — tree recursions vs dense Jacobians + numpy solves.  The
+wave-per-env form is emulated with every parallel loop run serially, once ascending and once descending: a dependence between
+iterations of one parallel loop (a race on the GPU) makes the two orders disagree with the oracle.  The GPU suite (tests/test_env3d_hip.py) repeats
 this through the C ABI; this file lets the recursions be checked where there is no GPU."""
 import ctypes as C
 import os
@@ -27,6 +29,21 @@ def harness():
     return lib
 
 
+def _step(harness, form, sm, q, v, act, obs, r, d):
+    if form == "lane":
+        return harness.e3h_step(C.byref(sm), _p(q), _p(v), _p(act), _p(obs), C.byref(r), C.byref(d))
+    return harness.e3hw_step(C.byref(sm), int(form == "wave-descending"), _p(q), _p(v), _p(act), _p(obs), C.byref(r), C.byref(d))
+
+
+def _qacc(harness, form, sm, q, v, ctrl, out):
+    if form == "lane":
+        return harness.e3h_qacc(C.byref(sm), _p(q), _p(v), _p(ctrl), _p(out))
+    return harness.e3hw_qacc(C.byref(sm), int(form == "wave-descending"), _p(q), _p(v), _p(ctrl), _p(out))
+
+
+FORMS = ["lane", "wave-ascending", "wave-descending"]   # env3d.h ; env3d_wave.h with its parallel loops run in either order
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -40,8 +57,9 @@ def _spread(m, rng, low):
     return q, v
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("mf", [ant, humanoid])
-def test_device_dynamics_match_oracle(harness, mf):
+def test_device_dynamics_match_oracle(harness, mf, form):
     m = mf()
     P = SpatialOracle(m)
     sm = spatial_struct(m)
@@ -53,14 +71,15 @@ def test_device_dynamics_match_oracle(harness, mf):
         ctrl = rng.uniform(-1, 1, m["act_dim"]) * m["ctrl_range"]
         ref = P.dynamics(q, v, ctrl)
         got = np.empty(m["nv"])
-        assert harness.e3h_qacc(C.byref(sm), _p(q), _p(v), _p(ctrl), _p(got)) == 0
+        assert _qacc(harness, form, sm, q, v, ctrl, got) == 0
         np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-7 * max(1.0, np.abs(ref).max()), err_msg=f"{mf.__name__} it {it}")
         n_rows.append(not np.allclose(ref, P.dynamics(q + np.r_[0, 0, 10.0, np.zeros(m["nq"] - 3)], v, ctrl)))
     assert any(n_rows)    # some of the sampled states are in contact
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("mf", [ant, humanoid])
-def test_device_step_matches_oracle(harness, mf):
+def test_device_step_matches_oracle(harness, mf, form):
     m = mf()
     P = SpatialOracle(m)
     sm = spatial_struct(m)
@@ -72,7 +91,7 @@ def test_device_step_matches_oracle(harness, mf):
             act = rng.uniform(-1.3, 1.3, m["act_dim"]).astype(np.float32)
             qo, vo, oo, ro, do = P.step(q.copy(), v.copy(), act)
             obs, r, d = np.empty(m["obs_dim"]), C.c_double(), C.c_int()
-            assert harness.e3h_step(C.byref(sm), _p(q), _p(v), _p(act), _p(obs), C.byref(r), C.byref(d)) == 0
+            assert _step(harness, form, sm, q, v, act, obs, r, d) == 0
             np.testing.assert_allclose(q, qo, rtol=1e-8, atol=1e-8, err_msg=f"qpos {it}.{k}")
             np.testing.assert_allclose(v, vo, rtol=1e-7, atol=1e-6, err_msg=f"qvel {it}.{k}")
             np.testing.assert_allclose(obs, oo, rtol=1e-7, atol=1e-6, err_msg=f"obs {it}.{k}")
