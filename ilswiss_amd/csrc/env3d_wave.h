@@ -33,6 +33,42 @@ typedef __attribute__((address_space(3))) double e3w_lds;
 #define E3W_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define E3W_ONE if (lane == 0)
 #endif
+// keep a group of independent LDS loads ahead of the arithmetic that consumes them (the scheduler otherwise pairs each load with
+// its use and every pair pays the full LDS latency)
+#ifdef E3W_HOST_EMU
+#define E3W_LOADS_FIRST() ((void)0)
+#else
+#define E3W_LOADS_FIRST() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// phase timing for tools/ubench/env3d_phases.hip: cycles per stage of e3w_dynamics accumulated in LDS behind the working set
+#ifdef E3W_PROFILE
+#define E3W_T(k) do { const unsigned long long e3w_now = __builtin_amdgcn_s_memtime(); \
+    if (lane == 0) { S[E3WOff::TOTAL + (k)] += (double)(e3w_now - (unsigned long long)S[E3WOff::TOTAL + 15]); S[E3WOff::TOTAL + 15] = (double)__builtin_amdgcn_s_memtime(); } \
+    E3W_SYNC(); } while (0)
+#else
+#define E3W_T(k) ((void)0)
+#endif
+#if defined(E3W_ASM_MARKS) && !defined(E3W_HOST_EMU)
+#define E3W_MARK(name) asm volatile("; E3W_MARK " name)
+#else
+#define E3W_MARK(name) ((void)0)
+#endif
+
+// Per-lane values that live across phases (registers on the device: one instance per lane; an array of 64 under host emulation)
+struct E3WRegs {
+  int ri[6], tj[6];   // the lower-triangle entries t = lane + 64 s this lane owns in the factorisation: row base i (i + 1) / 2 and column j (-1: none)
+};
+#ifdef E3W_HOST_EMU
+#define E3W_REGS(ln) regs[ln]
+#else
+#define E3W_REGS(ln) regs[0]
+#endif
+#ifdef __HIP_DEVICE_COMPILE__
+#define E3W_FMA _Pragma("clang fp contract(fast)")
+#else
+#define E3W_FMA
+#endif
 
 struct E3WOff {   // doubles
   static constexpr int NVM = E3_MAXL + 5, NQM = NVM + 1;
@@ -40,10 +76,10 @@ struct E3WOff {   // doubles
   static constexpr int CRB = KIN + 27 * E3_MAXL;                 // per link 10: m, h[3], Io[6] about the world origin
   static constexpr int WR = CRB + 10 * E3_MAXL;                  // per link 6: subtree force, moment about the world origin
   static constexpr int M = WR + 6 * E3_MAXL;                     // lower triangle (becomes L)
-  static constexpr int Z = M + NVM * (NVM + 1) / 2;              // rows [r][NVM]: j_r, then z_r = L^-1 j_r
-  static constexpr int A = Z + E3_MAXR * NVM;                    // lower triangle of Z Z^T; before that: contact distances and points
+  static constexpr int Z = M + NVM * (NVM + 1) / 2;              // rows [r][NVM]: j_r, then z_r = L^-1 j_r ; row MAXR: tau - c, then y
+  static constexpr int A = Z + (E3_MAXR + 1) * NVM;                   // lower triangle of Z Z^T; before that: contact distances and points
   static constexpr int RM = A + E3_MAXR * (E3_MAXR + 1) / 2;     // per row 8: res, Rg, f, kind, mu, 1/(A_rr+Rg), source, r
-  static constexpr int VEC = RM + 8 * E3_MAXR;                   // qacc0[NVM], 1/L_kk[NVM], tmp[NVM]
+  static constexpr int VEC = RM + 8 * E3_MAXR;                   // (free)[NVM], 1/L_kk[NVM], (free)[NVM]
   static constexpr int Q0 = VEC + 3 * NVM, V0 = Q0 + NQM, QS = V0 + NVM, VS = QS + NQM, VSUM = VS + NVM, ASUM = VSUM + NVM,
                        ACC = ASUM + NVM, CTRL = ACC + NVM, TOTAL = CTRL + E3_MAXL;
 };
@@ -58,8 +94,50 @@ __device__ __forceinline__ int e3w_tri_row(int t) {   // row of lower-triangle i
   return r;
 }
 
+__device__ __forceinline__ void e3w_regs_init(E3WRegs& R, int ln, int nv) {
+  for (int s = 0; s < 6; ++s) {
+    const int t = ln + 64 * s;
+    R.ri[s] = 0; R.tj[s] = -1;
+    if (t < nv * (nv + 1) / 2) { const int i = e3w_tri_row(t); R.ri[s] = i * (i + 1) / 2; R.tj[s] = t - R.ri[s]; }
+  }
+}
+
+// sum_t S[a + sa t] S[b + sb t], t < n: eight products per trip so that the 16 loads of a trip are in flight together (a loop with a
+// run-time trip count otherwise waits for every load before issuing the next)
+__device__ __forceinline__ double e3w_dot(const e3w_lds* S, int a, int sa, int b, int sb, int n) {
+  double s = 0.0;
+  for (int t = 0; t < n; t += 8) {
+    double x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int tc = t + u < n ? t + u : 0;
+      x[u] = S[a + sa * tc]; y[u] = S[b + sb * tc];
+    }
+    E3W_LOADS_FIRST();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (t + u < n ? x[u] : 0.0) * y[u];
+  }
+  return s;
+}
+// 1 / a for a pivot: hardware estimate + two Newton steps on the device (a few ulp; the oracle tolerance is 1e-8)
+__device__ __forceinline__ double e3w_rcp(double a) {
+#ifdef E3W_HOST_EMU
+  return 1.0 / a;
+#else
+  double x = __builtin_amdgcn_rcp(a);
+  x = x * (2.0 - a * x);
+  return x * (2.0 - a * x);
+#endif
+}
+#ifndef E3W_HOST_EMU
+__device__ __forceinline__ double e3w_readlane(double v, int src) {   // src is wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+#endif
+
 // Link frames and velocity-product accelerations of the state at (qoff, voff) (oracle kin())
 __device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m, int lane, int qoff, int voff) {
+  E3W_FMA
   E3W_FOR(l, m.nl) {
     const int k = E3WOff::KIN + 27 * l;
     if (l == 0) {
@@ -121,16 +199,8 @@ __device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m,
   }
 }
 
-// x <- L^-1 x, column by column: one uniform step per pivot, the update of the remaining entries spread over the lanes
-__device__ __forceinline__ void e3w_fwd_sub(e3w_lds* S, int lane, int nv, int x) {
-  for (int k = 0; k < nv; ++k) {
-    const double xk = S[x + k] * S[E3WOff::VEC + E3WOff::NVM + k];
-    E3W_FOR(ii, nv - 1 - k) { const int i = k + 1 + ii; S[x + i] -= S[E3WOff::M + e3_tri(i, k)] * xk; }
-    E3W_ONE S[x + k] = xk;
-    E3W_SYNC();
-  }
-}
-// x <- L^-T x
+// x <- L^-T x, column by column: one uniform step per pivot, the update of the remaining entries spread over the lanes (host form;
+// the device keeps x in registers, see the end of e3w_dynamics)
 __device__ __forceinline__ void e3w_bwd_sub(e3w_lds* S, int lane, int nv, int x) {
   for (int k = nv - 1; k >= 0; --k) {
     const double xk = S[x + k] * S[E3WOff::VEC + E3WOff::NVM + k];
@@ -141,10 +211,14 @@ __device__ __forceinline__ void e3w_bwd_sub(e3w_lds* S, int lane, int nv, int x)
 }
 
 // qacc = f(q, v, ctrl) with soft constraints (oracle dynamics()) -> S[out_off .. out_off + nv)
-__device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, int lane, int qoff, int voff, int ctrl_off, int out_off) {
-  const int nl = m.nl, nv = m.nv;
+template <int NV>
+__device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, int lane, const E3WRegs* regs, int qoff, int voff, int ctrl_off, int out_off) {
+  E3W_FMA
+  const int nl = m.nl, nv = NV > 0 ? NV : m.nv;   // NV > 0: the model's dof count at compile time (row solves and solves fully unrolled)
   constexpr int NVM = E3WOff::NVM;
+  E3W_T(12);
   e3w_kinematics(S, m, lane, qoff, voff);
+  E3W_T(0);
   // ---- per link: composite-inertia seed about the world origin, Newton-Euler wrench about the world origin
   E3W_FOR(l, nl) {
     const int k = E3WOff::KIN + 27 * l, cb = E3WOff::CRB + 10 * l, wr = E3WOff::WR + 6 * l;
@@ -181,14 +255,16 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
   }
   E3W_FOR(t, nv * (nv + 1) / 2) S[E3WOff::M + t] = 0.0;
   E3W_SYNC();
+  E3W_T(1);
   // ---- subtree sums, one component per lane, children before parents (a link's index exceeds its parent's)
   E3W_FOR(c, 16) {
     const int base = c < 10 ? E3WOff::CRB + c : E3WOff::WR + (c - 10), stride = c < 10 ? 10 : 6;
     for (int l = nl - 1; l >= 1; --l) S[base + stride * m.parent[l]] += S[base + stride * l];
   }
   E3W_SYNC();
+  E3W_T(2);
   // ---- right-hand side tau - c (c: the subtree wrench projected on each dof) ; mass-matrix rows (CRBA)
-  const int q0v = E3WOff::VEC;
+  const int yrow = E3WOff::Z + E3_MAXR * NVM;   // the right-hand side rides through L^-1 as one more row
   E3W_FOR(ix, nl + 6) {
     double R0[9], o0[3];
 #pragma unroll
@@ -220,7 +296,7 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
         const int ka = m.link_act[l];
         if (ka >= 0) tau += m.gear[l] * S[ctrl_off + ka];
       }
-      S[q0v + row] = tau - cvv;
+      S[yrow + row] = tau - cvv;
     }
     // momentum of the composite below this dof moving with (omega = a, v0): L about the world origin, p
     double L[3], p[3];
@@ -254,23 +330,44 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
     }
   }
   E3W_SYNC();
-  // ---- Cholesky in place (right-looking); 1 / L_kk kept for the solves
+  E3W_T(3);
+  // ---- Cholesky in place.  Step k subtracts column k's outer product from the trailing block using the UNSCALED column
+  // (M_ik M_jk / M_kk), so a step is one fence-to-fence phase; the columns are scaled by 1 / sqrt(pivot) in one pass at the end.
+  E3W_MARK("chol begin");
+  constexpr int NSLOT = NV > 0 ? (NV * (NV + 1) / 2 + 63) / 64 : 6;
   for (int k = 0; k < nv; ++k) {
-    const double d = sqrt(S[E3WOff::M + e3_tri(k, k)]), inv = 1.0 / d;
-    E3W_FOR(ii, nv - 1 - k) { const int i = k + 1 + ii; S[E3WOff::M + e3_tri(i, k)] *= inv; }
-    E3W_ONE { S[E3WOff::M + e3_tri(k, k)] = d; S[E3WOff::VEC + NVM + k] = inv; }
-    E3W_SYNC();
-    const int t0 = e3_tri(k + 1, k + 1), t1 = nv * (nv + 1) / 2;
-    E3W_FOR(tt, t1 - t0) {
-      const int t = t0 + tt, i = e3w_tri_row(t), j = t - i * (i + 1) / 2;
-      if (j > k) S[E3WOff::M + t] -= S[E3WOff::M + e3_tri(i, k)] * S[E3WOff::M + e3_tri(j, k)];
+    const double pinv = e3w_rcp(S[E3WOff::M + e3_tri(k, k)]);
+    E3W_FOR(ln, 64) {
+      const E3WRegs& R = E3W_REGS(ln);
+      double ci[NSLOT], cj[NSLOT], mt[NSLOT];
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl) {   // loads are unconditional (every address is inside the triangle), the store is not
+        ci[sl] = S[E3WOff::M + R.ri[sl] + k];
+        cj[sl] = S[E3WOff::M + (R.tj[sl] > k ? R.tj[sl] * (R.tj[sl] + 1) / 2 + k : 0)];
+        mt[sl] = S[E3WOff::M + ln + 64 * sl];
+      }
+      E3W_LOADS_FIRST();
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl)
+        if (R.tj[sl] > k) S[E3WOff::M + ln + 64 * sl] = mt[sl] - ci[sl] * cj[sl] * pinv;
     }
     E3W_SYNC();
   }
-  e3w_fwd_sub(S, lane, nv, q0v);
-  e3w_bwd_sub(S, lane, nv, q0v);
-  // ---- contacts: distance and contact point of every sphere
-  E3W_FOR(ci, m.n_contact) {
+  E3W_MARK("chol end");
+  E3W_FOR(k, nv) S[E3WOff::VEC + NVM + k] = 1.0 / sqrt(S[E3WOff::M + e3_tri(k, k)]);
+  E3W_SYNC();
+  E3W_FOR(ln, 64) {
+    const E3WRegs& R = E3W_REGS(ln);
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl)
+      if (R.tj[sl] >= 0) S[E3WOff::M + ln + 64 * sl] *= S[E3WOff::VEC + NVM + R.tj[sl]];
+  }
+  E3W_T(4);
+  // ---- contacts (lanes 32 .. 32 + n_contact): distance and contact point of every sphere
+  const int nc = m.n_contact;
+  E3W_FOR(ln, 64) {
+    const int ci = ln - 32;
+    if (ci < 0 || ci >= nc) continue;
     const int l = m.contact_link[ci], k = E3WOff::KIN + 27 * l;
     double R[9], o[3], rp[3];
 #pragma unroll
@@ -283,16 +380,16 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
     S[E3WOff::A + E3_MAXC + 3 * ci + 2] = o[2] + rp[2] - (rad + 0.5 * dist);
   }
   E3W_SYNC();
-  // ---- row table, in model order (contacts: normal, tangent x, tangent y ; then joint limits) — every lane walks it, one writes
+  // ---- row table, in model order: contacts (normal, tangent x, tangent y) while three rows fit, then violated joint limits while
+  // one fits.  Row record: [2] f, [3] kind, [4] friction or limit sign, [6] contact / link index, [7] r.
   int nr = 0;
-  for (int ci = 0; ci < m.n_contact; ++ci) {
+#ifdef E3W_HOST_EMU
+  for (int ci = 0; ci < nc; ++ci) {
     const double dist = S[E3WOff::A + ci];
     if (dist < m.margin && nr + 3 <= m.max_rows) {
-      E3W_ONE {
-        for (int d3 = 0; d3 < 3; ++d3) {
-          const int rm = E3WOff::RM + 8 * (nr + d3);
-          S[rm + 2] = 0.0; S[rm + 3] = (double)d3; S[rm + 4] = m.cfric[ci]; S[rm + 6] = (double)ci; S[rm + 7] = d3 == 0 ? dist : 0.0;
-        }
+      for (int d3 = 0; d3 < 3; ++d3) {
+        const int rm = E3WOff::RM + 8 * (nr + d3);
+        S[rm + 2] = 0.0; S[rm + 3] = (double)d3; S[rm + 4] = m.cfric[ci]; S[rm + 6] = (double)ci; S[rm + 7] = d3 == 0 ? dist : 0.0;
       }
       nr += 3;
     }
@@ -304,18 +401,48 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
     if (ql - lo < 0.0) { sgn = 1.0; rr = ql - lo; }
     else if (hi - ql < 0.0) { sgn = -1.0; rr = hi - ql; }
     if (sgn == 0.0) continue;
-    E3W_ONE {
-      const int rm = E3WOff::RM + 8 * nr;
-      S[rm + 2] = 0.0; S[rm + 3] = 3.0; S[rm + 4] = sgn; S[rm + 6] = (double)l; S[rm + 7] = rr;
-    }
+    const int rm = E3WOff::RM + 8 * nr;
+    S[rm + 2] = 0.0; S[rm + 3] = 3.0; S[rm + 4] = sgn; S[rm + 6] = (double)l; S[rm + 7] = rr;
     nr += 1;
   }
-  if (nr == 0) {
-    E3W_FOR(i, nv) S[out_off + i] = S[q0v + i];
-    E3W_SYNC();
-    return;
+#else
+  {   // contact ci is lane 32 + ci, link l is lane l: a row's position is a population count over the lanes below it
+    const int ci = lane - 32;
+    const bool isc = ci >= 0 && ci < nc;
+    const double dist = S[E3WOff::A + (isc ? ci : 0)];
+    const bool cflag = isc && dist < m.margin;
+    double sgn = 0.0, rr = 0.0;
+    if (lane >= 1 && lane < nl && m.limited[lane]) {
+      const double ql = S[qoff + 7 + lane - 1], lo = m.range[lane][0], hi = m.range[lane][1];
+      if (ql - lo < 0.0) { sgn = 1.0; rr = ql - lo; }
+      else if (hi - ql < 0.0) { sgn = -1.0; rr = hi - ql; }
+    }
+    const bool lflag = sgn != 0.0;
+    const unsigned long long cmask = __ballot(cflag), lmask = __ballot(lflag), below = (1ull << lane) - 1ull;
+    const int tot_c = __popcll(cmask), acc_c = tot_c < m.max_rows / 3 ? tot_c : m.max_rows / 3, nr_c = 3 * acc_c;
+    const int tot_l = __popcll(lmask), room = m.max_rows - nr_c, acc_l = tot_l < room ? tot_l : room;
+    nr = nr_c + acc_l;
+    if (cflag) {
+      const int rank = __popcll(cmask & below);
+      if (rank < acc_c) {
+        const double mu = m.cfric[ci];
+        for (int d3 = 0; d3 < 3; ++d3) {
+          const int rm = E3WOff::RM + 8 * (3 * rank + d3);
+          S[rm + 2] = 0.0; S[rm + 3] = (double)d3; S[rm + 4] = mu; S[rm + 6] = (double)ci; S[rm + 7] = d3 == 0 ? dist : 0.0;
+        }
+      }
+    }
+    if (lflag) {
+      const int rank = __popcll(lmask & below);
+      if (rank < acc_l) {
+        const int rm = E3WOff::RM + 8 * (nr_c + rank);
+        S[rm + 2] = 0.0; S[rm + 3] = 3.0; S[rm + 4] = sgn; S[rm + 6] = (double)lane; S[rm + 7] = rr;
+      }
+    }
   }
+#endif
   E3W_SYNC();
+  E3W_T(6);
   // ---- Jacobian rows j_r, one (row, dof) entry per lane-iteration
   E3W_FOR(e, nr * nv) {
     const int r = e / nv, i = e - r * nv, rm = E3WOff::RM + 8 * r;
@@ -348,72 +475,152 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
     S[E3WOff::Z + r * NVM + i] = val;
   }
   E3W_SYNC();
-  // ---- one row per lane: J.v, J.qacc0, z = L^-1 j (row-oriented, private to the lane), the row's regulariser and reference
-  E3W_FOR(r, nr) {
-    const int zr = E3WOff::Z + r * NVM, rm = E3WOff::RM + 8 * r;
-    double jv = 0.0, jq = 0.0;
-    for (int i = 0; i < nv; ++i) { const double j = S[zr + i]; jv += j * S[voff + i]; jq += j * S[q0v + i]; }
-    double aii = 0.0;
-    for (int i = 0; i < nv; ++i) {
-      double sum = S[zr + i];
-      for (int t = 0; t < i; ++t) sum -= S[E3WOff::M + e3_tri(i, t)] * S[zr + t];
-      sum *= S[E3WOff::VEC + NVM + i];
-      S[zr + i] = sum;
-      aii += sum * sum;
-    }
-    const int kind = (int)S[rm + 3];
-    const double rr = S[rm + 7];
-    const double rdist = kind == 3 ? rr : S[E3WOff::A + (int)S[rm + 6]];
-    const double* solref = kind == 3 ? m.l_solref : m.c_solref;
-    const double* solimp = kind == 3 ? m.l_solimp : m.c_solimp;
-    const double d = e3_impedance(fabs(rdist), solimp);
-    const double dmax = solimp[1], tc = solref[0], dr = solref[1];
-    const double b = 2.0 / (dmax * tc), ks = 1.0 / (dmax * dmax * tc * tc * dr * dr);
-    const double aref = -b * jv - ks * d * rr;
-    const double Rg = (1.0 - d) / d * aii;
-    S[rm] = aref - jq;          // residual rhs - A f at f = 0
-    S[rm + 1] = Rg;
-    S[rm + 5] = 1.0 / (aii + Rg);
-    if (kind != 3) S[rm + 4] = m.cfric[(int)S[rm + 6]];
-  }
-  E3W_SYNC();
-  // ---- A = Z Z^T (overwrites the contact scratch: every reader of it is behind the fence above)
-  E3W_FOR(t, nr * (nr + 1) / 2) {
-    const int r = e3w_tri_row(t), c = t - r * (r + 1) / 2;
-    double s = 0.0;
-    for (int i = 0; i < nv; ++i) s += S[E3WOff::Z + r * NVM + i] * S[E3WOff::Z + c * NVM + i];
-    S[E3WOff::A + t] = s;
-  }
-  E3W_SYNC();
-  // ---- projected Gauss-Seidel: rows in sequence; each update changes one force, every lane folds it into its row's residual
-  for (int it = 0; it < m.pgs_iters; ++it)
-    for (int r = 0; r < nr; ++r) {
-      const int rm = E3WOff::RM + 8 * r;
-      const double arr = S[E3WOff::A + e3_tri(r, r)], fold = S[rm + 2];
-      double fi = (S[rm] + arr * fold) * S[rm + 5];
-      const int kind = (int)S[rm + 3];
-      if (kind == 1 || kind == 2) {
-        const double lim = S[rm + 4] * S[E3WOff::RM + 8 * (r - kind) + 2];
-        fi = fmin(fmax(fi, -lim), lim);
-      } else {
-        fi = fmax(fi, 0.0);
+  E3W_T(7);
+  // ---- one vector per lane through L^-1: the nr rows (z_r = L^-1 j_r) and, as lane nr, the right-hand side (y = L^-1 (tau - c)).
+  // Row-oriented and private to the lane; the loads of a row of L are broadcasts.
+  E3W_MARK("rowsolve begin");
+  E3W_FOR(r, nr + 1) {
+    const int zr = r == nr ? yrow : E3WOff::Z + r * NVM, rm = E3WOff::RM + 8 * r;
+    double jv = 0.0, aii = 0.0;
+    if constexpr (NV > 0) {   // the vector stays in registers; rows of L arrive as broadcast loads at compile-time offsets
+      double z[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) z[i] = S[zr + i];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) jv += z[i] * S[voff + i];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double sum = z[i];
+#pragma unroll
+        for (int t = 0; t < i; ++t) sum -= S[E3WOff::M + i * (i + 1) / 2 + t] * z[t];
+        z[i] = sum * S[E3WOff::VEC + NVM + i];
+        aii += z[i] * z[i];
       }
-      const double delta = fi - fold;
-      E3W_FOR(c, nr) S[E3WOff::RM + 8 * c] -= (r >= c ? S[E3WOff::A + e3_tri(r, c)] : S[E3WOff::A + e3_tri(c, r)]) * delta;
-      E3W_ONE S[rm + 2] = fi;
-      E3W_SYNC();
+#pragma unroll
+      for (int i = 0; i < NV; ++i) S[zr + i] = z[i];
+    } else {
+      jv = r == nr ? 0.0 : e3w_dot(S, zr, 1, voff, 1, nv);
+      for (int i = 0; i < nv; ++i) {
+        const double sum = (S[zr + i] - e3w_dot(S, E3WOff::M + i * (i + 1) / 2, 1, zr, 1, i)) * S[E3WOff::VEC + NVM + i];
+        S[zr + i] = sum;
+        aii += sum * sum;
+      }
     }
-  // ---- qacc = qacc0 + L^-T (sum_r z_r f_r)
-  const int tv = E3WOff::VEC + 2 * NVM;
-  E3W_FOR(i, nv) {
-    double s = 0.0;
-    for (int r = 0; r < nr; ++r) s += S[E3WOff::Z + r * NVM + i] * S[E3WOff::RM + 8 * r + 2];
-    S[tv + i] = s;
+    if (r < nr) { S[rm] = jv; S[rm + 1] = aii; }
   }
+  E3W_MARK("rowsolve end");
   E3W_SYNC();
-  e3w_bwd_sub(S, lane, nv, tv);
-  E3W_FOR(i, nv) S[out_off + i] = S[q0v + i] + S[tv + i];
+  if (nr > 0) {
+    // ---- per row: J.qacc0 = z_r . y, the regulariser and the reference acceleration
+    E3W_FOR(r, nr) {
+      const int zr = E3WOff::Z + r * NVM, rm = E3WOff::RM + 8 * r;
+      const double jv = S[rm], aii = S[rm + 1], jq = e3w_dot(S, zr, 1, yrow, 1, nv);
+      const int kind = (int)S[rm + 3];
+      const double rr = S[rm + 7];
+      const double rdist = kind == 3 ? rr : S[E3WOff::A + (int)S[rm + 6]];
+      const double* solref = kind == 3 ? m.l_solref : m.c_solref;
+      const double* solimp = kind == 3 ? m.l_solimp : m.c_solimp;
+      const double d = e3_impedance(fabs(rdist), solimp);
+      const double dmax = solimp[1], tc = solref[0], dr = solref[1];
+      const double b = 2.0 / (dmax * tc), ks = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+      const double aref = -b * jv - ks * d * rr;
+      const double Rg = (1.0 - d) / d * aii;
+      S[rm] = aref - jq;          // residual rhs - A f at f = 0
+      S[rm + 1] = Rg;
+      S[rm + 5] = 1.0 / (aii + Rg);
+    }
+    E3W_SYNC();
+    E3W_T(8);
+    // ---- A = Z Z^T (overwrites the contact scratch: every reader of it is behind the fence above)
+    E3W_FOR(ln, 64) {
+      const int li = ln >> 3, lj = ln & 7;
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+          const int r = li + 8 * a, c = lj + 8 * b;
+          if (r < nr && c <= r) S[E3WOff::A + e3_tri(r, c)] = e3w_dot(S, E3WOff::Z + r * NVM, 1, E3WOff::Z + c * NVM, 1, nv);
+        }
+    }
+    E3W_SYNC();
+    E3W_T(9);
+    // ---- projected Gauss-Seidel: rows in sequence (inherent); each update changes one force and every row's residual
+#ifdef E3W_HOST_EMU
+    for (int it = 0; it < m.pgs_iters; ++it)
+      for (int r = 0; r < nr; ++r) {
+        const int rm = E3WOff::RM + 8 * r;
+        const double arr = S[E3WOff::A + e3_tri(r, r)], fold = S[rm + 2];
+        double fi = (S[rm] + arr * fold) * S[rm + 5];
+        const int kind = (int)S[rm + 3];
+        if (kind == 1 || kind == 2) {
+          const double lim = S[rm + 4] * S[E3WOff::RM + 8 * (r - kind) + 2];
+          fi = fmin(fmax(fi, -lim), lim);
+        } else {
+          fi = fmax(fi, 0.0);
+        }
+        const double delta = fi - fold;
+        E3W_FOR(c, nr) S[E3WOff::RM + 8 * c] -= (r >= c ? S[E3WOff::A + e3_tri(r, c)] : S[E3WOff::A + e3_tri(c, r)]) * delta;
+        E3W_ONE S[rm + 2] = fi;
+        E3W_SYNC();
+      }
+#else
+    {   // lane c is row c: residual, force, 1 / (A_cc + R_c), friction bound and column c of A stay in registers.  Every lane works out
+        // its own row's candidate each step (same instruction count as one lane doing it); the row whose turn it is publishes its
+        // change through readlane and every lane folds it into its residual with one multiply-add.
+      const bool on = lane < nr;
+      const int rmc = E3WOff::RM + 8 * (on ? lane : 0);
+      const int kind = (int)S[rmc + 3];
+      const bool fric = kind == 1 || kind == 2;
+      double res = S[rmc], f = 0.0, fn = 0.0;
+      const double inv = S[rmc + 5], arr = S[E3WOff::A + (on ? e3_tri(lane, lane) : 0)];
+      const double mu_eff = fric ? S[rmc + 4] : 0.0, open_hi = fric ? 0.0 : __builtin_inf();   // bounds: [-mu fn, mu fn] or [0, inf)
+      const int nidx = lane - kind;          // the row holding this row's normal force (friction rows)
+      double Acol[E3_MAXR];
+#pragma unroll
+      for (int r = 0; r < E3_MAXR; ++r) {
+        const int hi = r > lane ? r : lane, lo = r > lane ? lane : r;
+        Acol[r] = S[E3WOff::A + ((on && r < nr) ? e3_tri(hi, lo) : 0)];
+      }
+      for (int it = 0; it < m.pgs_iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < E3_MAXR; ++r) {
+          if (r >= nr) break;
+          const double lim = mu_eff * fn;
+          const double nw = fmin(fmax((res + arr * f) * inv, -lim), lim + open_hi);
+          const double sd = e3w_readlane(nw - f, r), sn = e3w_readlane(nw, r);
+          res -= Acol[r] * sd;
+          f = lane == r ? sn : f;
+          fn = nidx == r ? sn : fn;
+        }
+      }
+      if (on) S[rmc + 2] = f;
+    }
+    E3W_SYNC();
+#endif
+    E3W_T(10);
+    // ---- y + sum_r z_r f_r
+    E3W_FOR(i, nv) S[yrow + i] += e3w_dot(S, E3WOff::Z + i, NVM, E3WOff::RM + 2, 8, nr);
+    E3W_SYNC();
+  }
+  // ---- qacc = L^-T (y + sum_r z_r f_r)
+#ifdef E3W_HOST_EMU
+  e3w_bwd_sub(S, lane, nv, yrow);
+  E3W_FOR(i, nv) S[out_off + i] = S[yrow + i];
+#else
+  {   // lane i keeps x_i; pivot k's value and 1 / L_kk reach every lane through readlane, row k of L is fetched one step ahead
+    double x = S[yrow + (lane < nv ? lane : 0)];
+    const double invd = S[E3WOff::VEC + NVM + (lane < nv ? lane : 0)];
+    double Lnext = S[E3WOff::M + e3_tri(nv - 1, lane < nv - 1 ? lane : 0)];
+#pragma unroll
+    for (int k = nv - 1; k >= 0; --k) {
+      const double Lk = lane < k ? Lnext : 0.0;
+      if (k > 0) Lnext = S[E3WOff::M + e3_tri(k - 1, lane < k - 1 ? lane : 0)];
+      const double xk = e3w_readlane(x, k) * e3w_readlane(invd, k);
+      x = lane == k ? xk : x - Lk * xk;
+    }
+    if (lane < nv) S[out_off + lane] = x;
+  }
+#endif
   E3W_SYNC();
+  E3W_T(11);
 }
 
 // mj_integratePos: dst_q = src_q (+) h * vel.  The quaternion update is computed by every lane (uniform) and written by one.
@@ -441,8 +648,10 @@ __device__ __forceinline__ void e3w_integrate_pos(e3w_lds* S, const Spatial3Dev&
 
 // one RK4 substep on the state at (Q0, V0), positions on the manifold (oracle substep()).  Four stages through ONE dynamics call
 // site so that the largest piece of code exists once.
-__device__ __forceinline__ void e3w_substep(e3w_lds* S, const Spatial3Dev& m, int lane) {
-  const int nv = m.nv;
+template <int NV>
+__device__ __forceinline__ void e3w_substep(e3w_lds* S, const Spatial3Dev& m, int lane, const E3WRegs* regs) {
+  E3W_FMA
+  const int nv = NV > 0 ? NV : m.nv;
   const double h = m.timestep;
 #pragma unroll 1
   for (int st = 0; st < 4; ++st) {
@@ -456,7 +665,7 @@ __device__ __forceinline__ void e3w_substep(e3w_lds* S, const Spatial3Dev& m, in
       E3W_FOR(i, nv) S[E3WOff::VS + i] = S[E3WOff::V0 + i] + hs * S[E3WOff::ACC + i];
       E3W_SYNC();
     }
-    e3w_dynamics(S, m, lane, E3WOff::QS, E3WOff::VS, E3WOff::CTRL, E3WOff::ACC);
+    e3w_dynamics<NV>(S, m, lane, regs, E3WOff::QS, E3WOff::VS, E3WOff::CTRL, E3WOff::ACC);
     E3W_FOR(i, nv) { S[E3WOff::VSUM + i] += wt * S[E3WOff::VS + i]; S[E3WOff::ASUM + i] += wt * S[E3WOff::ACC + i]; }
     E3W_SYNC();
   }
@@ -487,7 +696,9 @@ __device__ __forceinline__ void e3w_com(const e3w_lds* S, const Spatial3Dev& m, 
 }
 
 // env.step() on the state at (Q0, V0) (oracle step()); leaves KIN = kinematics of the new state.  reward / done are wave-uniform.
-__device__ __forceinline__ void e3w_task_step(e3w_lds* S, const Spatial3Dev& m, int lane, const float* act, double& reward, bool& done) {
+template <int NV>
+__device__ __forceinline__ void e3w_task_step(e3w_lds* S, const Spatial3Dev& m, int lane, const E3WRegs* regs, const float* act, double& reward, bool& done) {
+  E3W_FMA
   double ctrl_sq = 0.0;
   for (int k = 0; k < m.n_act; ++k) {   // NormalizedBoxEnv: [-1, 1] -> ctrlrange, clip (wrappers.py:343-346)
     const double a = (double)act[k];
@@ -500,7 +711,7 @@ __device__ __forceinline__ void e3w_task_step(e3w_lds* S, const Spatial3Dev& m, 
   double x0 = S[E3WOff::Q0], com[3];
   if (m.task == 4) { e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0); e3w_com(S, m, com); x0 = com[0]; }
 #pragma unroll 1
-  for (int s = 0; s < m.frame_skip; ++s) e3w_substep(S, m, lane);
+  for (int s = 0; s < m.frame_skip; ++s) e3w_substep<NV>(S, m, lane, regs);
   e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0);
   const double z = S[E3WOff::Q0 + 2];
   if (m.task == 4) {   // humanoid.py:37-49

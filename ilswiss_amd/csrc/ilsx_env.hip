@@ -690,6 +690,7 @@ __device__ __forceinline__ void e3w_reset_state(e3w_lds* S, const Spatial3Dev& m
   E3W_SYNC();
 }
 
+template <int NV>
 __global__ __launch_bounds__(64) void k_env3dw_step(const EnvStepArgs A, const Spatial3Dev* mp) {
   extern __shared__ __attribute__((aligned(16))) double e3w_smem[];
   e3w_lds* S = (e3w_lds*)e3w_smem;
@@ -708,8 +709,10 @@ __global__ __launch_bounds__(64) void k_env3dw_step(const EnvStepArgs A, const S
     E3W_FOR(i, o) rec[i] = A.obs_cur[(size_t)env * o + i];
   }
   E3W_SYNC();
+  E3WRegs regs[1];
+  e3w_regs_init(regs[0], lane, m.nv);
   double reward; bool done;
-  e3w_task_step(S, m, lane, A.act + (size_t)t * na, reward, done);
+  e3w_task_step<NV>(S, m, lane, regs, A.act + (size_t)t * na, reward, done);
   bool end = false; int len = 0; double ret = 0.0;
   if (A.auto_reset) {
     len = A.ep_len[env] + 1; ret = A.ep_ret[env] + reward;
@@ -792,8 +795,12 @@ static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
   if (A.n_ids <= 0) return ILSX_OK;
   if (e->engine == 1) {
     ProfScope ps(e->ctx, ILSX_K_ENV_STEP);
-    if (e->wave3)
-      ILSX_LAUNCH(ps, k_env3dw_step, dim3(A.n_ids), dim3(64), (size_t)E3WOff::TOTAL * 8, e->ctx->stream, A, (const Spatial3Dev*)e->dm3);
+    if (e->wave3 && e->nv == 23)        // Humanoid
+      ILSX_LAUNCH(ps, k_env3dw_step<23>, dim3(A.n_ids), dim3(64), (size_t)E3WOff::TOTAL * 8, e->ctx->stream, A, (const Spatial3Dev*)e->dm3);
+    else if (e->wave3 && e->nv == 14)   // Ant
+      ILSX_LAUNCH(ps, k_env3dw_step<14>, dim3(A.n_ids), dim3(64), (size_t)E3WOff::TOTAL * 8, e->ctx->stream, A, (const Spatial3Dev*)e->dm3);
+    else if (e->wave3)                  // any other tree: run-time dof count
+      ILSX_LAUNCH(ps, k_env3dw_step<0>, dim3(A.n_ids), dim3(64), (size_t)E3WOff::TOTAL * 8, e->ctx->stream, A, (const Spatial3Dev*)e->dm3);
     else
       ILSX_LAUNCH(ps, k_env3d_step, dim3((A.n_ids + 63) / 64), dim3(64), 0, e->ctx->stream, A, (const Spatial3Dev*)e->dm3, e->scr3);
     HIPCHK(hipGetLastError());
@@ -922,7 +929,9 @@ extern "C" int ilsx_vecenv_create_spatial(ilsx_ctx* ctx, const ilsx_spatial_mode
   e->ctx = ctx; e->n_env = n_env; e->seed = seed; e->rng_stream = ctx->next_rng_stream++; e->engine = 1;
   e->wave3 = !(getenv("ILSX_ENV3D_LANE") && atoi(getenv("ILSX_ENV3D_LANE")) != 0);
   if (e->wave3) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_env3dw_step, hipFuncAttributeMaxDynamicSharedMemorySize, E3WOff::TOTAL * 8));
+    HIPCHK(hipFuncSetAttribute((const void*)k_env3dw_step<23>, hipFuncAttributeMaxDynamicSharedMemorySize, E3WOff::TOTAL * 8));
+    HIPCHK(hipFuncSetAttribute((const void*)k_env3dw_step<14>, hipFuncAttributeMaxDynamicSharedMemorySize, E3WOff::TOTAL * 8));
+    HIPCHK(hipFuncSetAttribute((const void*)k_env3dw_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize, E3WOff::TOTAL * 8));
     HIPCHK(hipFuncSetAttribute((const void*)k_env3dw_reset, hipFuncAttributeMaxDynamicSharedMemorySize, E3WOff::TOTAL * 8));
   }
   e->hm3 = new Spatial3Dev();

@@ -60,7 +60,13 @@ extern "C" int e3hw_step(const ilsx_spatial_model* sm, int reverse, double* q, d
   for (int i = 0; i < m.nq; ++i) S[E3WOff::Q0 + i] = q[i];
   for (int i = 0; i < m.nv; ++i) S[E3WOff::V0 + i] = v[i];
   bool d; double r;
-  e3w_task_step(S.data(), m, lane, act, r, d);
+  E3WRegs regs[64];
+  for (int ln = 0; ln < 64; ++ln) e3w_regs_init(regs[ln], ln, m.nv);
+  const int snv = reverse >> 1;   // bit 1: take the dof count at compile time (the device's Humanoid / Ant instantiations)
+  e3w_reverse = reverse & 1;
+  if (snv && m.nv == 23) e3w_task_step<23>(S.data(), m, lane, regs, act, r, d);
+  else if (snv && m.nv == 14) e3w_task_step<14>(S.data(), m, lane, regs, act, r, d);
+  else e3w_task_step<0>(S.data(), m, lane, regs, act, r, d);
   for (int i = 0; i < m.obs_dim; ++i) obs[i] = -12345.0;
   e3w_observe(S.data(), m, lane, [&](int i, double val) { obs[i] = val; });
   *reward = r; *done = d ? 1 : 0;
@@ -77,7 +83,13 @@ extern "C" int e3hw_qacc(const ilsx_spatial_model* sm, int reverse, const double
   for (int i = 0; i < m.nq; ++i) S[E3WOff::Q0 + i] = q[i];
   for (int i = 0; i < m.nv; ++i) S[E3WOff::V0 + i] = v[i];
   for (int k = 0; k < m.n_act; ++k) S[E3WOff::CTRL + k] = ctrl[k];
-  e3w_dynamics(S.data(), m, lane, E3WOff::Q0, E3WOff::V0, E3WOff::CTRL, E3WOff::ACC);
+  E3WRegs regs[64];
+  for (int ln = 0; ln < 64; ++ln) e3w_regs_init(regs[ln], ln, m.nv);
+  const int snv = reverse >> 1;
+  e3w_reverse = reverse & 1;
+  if (snv && m.nv == 23) e3w_dynamics<23>(S.data(), m, lane, regs, E3WOff::Q0, E3WOff::V0, E3WOff::CTRL, E3WOff::ACC);
+  else if (snv && m.nv == 14) e3w_dynamics<14>(S.data(), m, lane, regs, E3WOff::Q0, E3WOff::V0, E3WOff::CTRL, E3WOff::ACC);
+  else e3w_dynamics<0>(S.data(), m, lane, regs, E3WOff::Q0, E3WOff::V0, E3WOff::CTRL, E3WOff::ACC);
   for (int i = 0; i < m.nv; ++i) qacc[i] = S[E3WOff::ACC + i];
   return 0;
 }

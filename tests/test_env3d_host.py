@@ -32,16 +32,18 @@ def harness():
 def _step(harness, form, sm, q, v, act, obs, r, d):
     if form == "lane":
         return harness.e3h_step(C.byref(sm), _p(q), _p(v), _p(act), _p(obs), C.byref(r), C.byref(d))
-    return harness.e3hw_step(C.byref(sm), int(form == "wave-descending"), _p(q), _p(v), _p(act), _p(obs), C.byref(r), C.byref(d))
+    return harness.e3hw_step(C.byref(sm), WAVE_FLAGS[form], _p(q), _p(v), _p(act), _p(obs), C.byref(r), C.byref(d))
 
 
 def _qacc(harness, form, sm, q, v, ctrl, out):
     if form == "lane":
         return harness.e3h_qacc(C.byref(sm), _p(q), _p(v), _p(ctrl), _p(out))
-    return harness.e3hw_qacc(C.byref(sm), int(form == "wave-descending"), _p(q), _p(v), _p(ctrl), _p(out))
+    return harness.e3hw_qacc(C.byref(sm), WAVE_FLAGS[form], _p(q), _p(v), _p(ctrl), _p(out))
 
 
-FORMS = ["lane", "wave-ascending", "wave-descending"]   # env3d.h ; env3d_wave.h with its parallel loops run in either order
+# env3d.h ; env3d_wave.h with its parallel loops run in either order, dof count at run time or (the device's instantiations) compile time
+WAVE_FLAGS = {"wave-ascending": 0, "wave-descending": 1, "wave-static-ascending": 2, "wave-static-descending": 3}
+FORMS = ["lane"] + list(WAVE_FLAGS)
 
 
 def _p(a):
