@@ -36,7 +36,7 @@ struct Spatial3Dev {
   double obs_shift[E3_MAXOBS], obs_inv_scale[E3_MAXOBS];
   // derived tables of the wave-per-env kernels (env3d_wave.h): links ordered by depth in the tree, ancestor-or-self bit masks,
   // and the actuator on each hinge (-1: none)
-  int n_level, lvl_off[E3_MAXL + 1], lvl_link[E3_MAXL], link_act[E3_MAXL];
+  int n_level, lvl_off[E3_MAXL + 1], lvl_link[E3_MAXL], link_act[E3_MAXL], depth[E3_MAXL];
   unsigned anc_mask[E3_MAXL];
 };
 
@@ -58,24 +58,36 @@ struct E3Off {
 
 struct E3Ctx { double* scr; int n_env, env; const Spatial3Dev* m; };
 
+// multiply-adds may fuse in the fp64 helpers on the device (results are compared with the oracle at 1e-8, not bit for bit)
+#ifdef __HIP_DEVICE_COMPILE__
+#define E3_FMA _Pragma("clang fp contract(fast)")
+#else
+#define E3_FMA
+#endif
 __device__ __forceinline__ void e3_quat_to_R(double w, double x, double y, double z, double* R) {
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
   R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
   R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
 }
 __device__ __forceinline__ void e3_mat3mul(const double* A, const double* B, double* C) {
+  E3_FMA
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 __device__ __forceinline__ void e3_matvec(const double* A, const double* x, double* y) {
+  E3_FMA
   y[0] = A[0] * x[0] + A[1] * x[1] + A[2] * x[2]; y[1] = A[3] * x[0] + A[4] * x[1] + A[5] * x[2]; y[2] = A[6] * x[0] + A[7] * x[1] + A[8] * x[2];
 }
 __device__ __forceinline__ void e3_cross(const double* a, const double* b, double* c) {
+  E3_FMA
   c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
 }
-__device__ __forceinline__ double e3_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ double e3_dot(const double* a, const double* b) {
+  E3_FMA
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
 __device__ __forceinline__ double e3_impedance(double r_abs, const double* solimp) {
   const double d0 = solimp[0], dmax = solimp[1], width = solimp[2];
   const double x = width > 0.0 ? fmin(r_abs / width, 1.0) : 1.0;
@@ -624,6 +636,7 @@ static inline const char* e3_build_model(const ilsx_spatial_model* sm, Spatial3D
       if (depth[l] > maxd) maxd = depth[l];
     }
     m.n_level = maxd + 1;
+    for (int l = 0; l < E3_MAXL; ++l) m.depth[l] = l < m.nl ? depth[l] : -1;
     int at = 0;
     for (int d = 0; d <= maxd; ++d) {
       m.lvl_off[d] = at;

@@ -58,6 +58,15 @@ typedef __attribute__((address_space(3))) double e3w_lds;
 // Per-lane values that live across phases (registers on the device: one instance per lane; an array of 64 under host emulation)
 struct E3WRegs {
   int ri[6], tj[6];   // the lower-triangle entries t = lane + 64 s this lane owns in the factorisation: row base i (i + 1) / 2 and column j (-1: none)
+  // constants of link l == lane (the tree recursions map link l to lane l), so that no phase waits on the model in global memory
+  int parent, depth, act, limited;
+  unsigned anc;
+  double anchor[3], axis_p[3], damping, stiffness, armature, gear, lo, hi;
+  unsigned long long par_lo, par_hi;   // every link's parent, 5 bits each (wave-uniform): links 0..11, 12..23
+  // model scalars (wave-uniform).  A wavefront fence makes the compiler re-read anything it loaded from memory, the model included;
+  // these copies are values, not loads
+  int nl, n_level, nc, max_rows, pgs_iters;
+  double margin, timestep;
 };
 #ifdef E3W_HOST_EMU
 #define E3W_REGS(ln) regs[ln]
@@ -94,12 +103,65 @@ __device__ __forceinline__ int e3w_tri_row(int t) {   // row of lower-triangle i
   return r;
 }
 
-__device__ __forceinline__ void e3w_regs_init(E3WRegs& R, int ln, int nv) {
+__device__ __forceinline__ void e3w_regs_init(E3WRegs& R, const Spatial3Dev& m, int ln) {
+  const int nv = m.nv;
   for (int s = 0; s < 6; ++s) {
     const int t = ln + 64 * s;
     R.ri[s] = 0; R.tj[s] = -1;
     if (t < nv * (nv + 1) / 2) { const int i = e3w_tri_row(t); R.ri[s] = i * (i + 1) / 2; R.tj[s] = t - R.ri[s]; }
   }
+  const int l = ln < m.nl ? ln : 0;
+  R.parent = m.parent[l]; R.depth = ln < m.nl ? m.depth[l] : -1; R.act = m.link_act[l]; R.limited = ln >= 1 && ln < m.nl && m.limited[l];
+  R.anc = m.anc_mask[l];
+  for (int i = 0; i < 3; ++i) { R.anchor[i] = m.anchor[l][i]; R.axis_p[i] = m.axis_p[l][i]; }
+  R.damping = m.damping[l]; R.stiffness = m.stiffness[l]; R.armature = m.armature[l]; R.gear = m.gear[l];
+  R.lo = m.range[l][0]; R.hi = m.range[l][1];
+  R.nl = m.nl; R.n_level = m.n_level; R.nc = m.n_contact; R.max_rows = m.max_rows; R.pgs_iters = m.pgs_iters;
+  R.margin = m.margin; R.timestep = m.timestep;
+  R.par_lo = 0; R.par_hi = 0;
+  for (int j = 1; j < m.nl; ++j) {
+    if (j < 12) R.par_lo |= (unsigned long long)m.parent[j] << (5 * j);
+    else R.par_hi |= (unsigned long long)m.parent[j] << (5 * (j - 12));
+  }
+}
+// The values above are loads from read-only memory, which the compiler is free to repeat instead of keeping (it did: three global
+// loads per tree level).  Passing them through an empty asm makes them computed values that must stay in registers.
+__device__ __forceinline__ void e3w_regs_pin(E3WRegs& R) {
+#ifndef E3W_HOST_EMU
+  asm volatile("" : "+v"(R.parent), "+v"(R.depth), "+v"(R.act), "+v"(R.anc));
+  for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(R.anchor[i]), "+v"(R.axis_p[i]));
+  asm volatile("" : "+v"(R.damping), "+v"(R.stiffness), "+v"(R.armature), "+v"(R.gear));
+  for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(R.ri[s]), "+v"(R.tj[s]));
+  // wave-uniform ones: through readfirstlane, so that they are scalar values
+  R.nl = __builtin_amdgcn_readfirstlane(R.nl); R.n_level = __builtin_amdgcn_readfirstlane(R.n_level);
+  R.nc = __builtin_amdgcn_readfirstlane(R.nc); R.max_rows = __builtin_amdgcn_readfirstlane(R.max_rows);
+  R.pgs_iters = __builtin_amdgcn_readfirstlane(R.pgs_iters);
+  R.margin = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(R.margin)), __builtin_amdgcn_readfirstlane(__double2loint(R.margin)));
+  R.timestep = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(R.timestep)), __builtin_amdgcn_readfirstlane(__double2loint(R.timestep)));
+  R.par_lo = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(R.par_lo >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)R.par_lo);
+  R.par_hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(R.par_hi >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)R.par_hi);
+#endif
+}
+__device__ __forceinline__ int e3w_parent(const E3WRegs& R, int l) {
+  return (int)((l < 12 ? R.par_lo >> (5 * l) : R.par_hi >> (5 * (l - 12))) & 31ull);
+}
+// sin and cos of a joint angle: Cody-Waite reduction by pi/2 (two constants: exact for the few quadrants a joint angle spans) and
+// the fdlibm kernel polynomials on [-pi/4, pi/4]; ~1e-16 absolute, a fifth of the instructions of the general-range library pair
+__device__ __forceinline__ void e3w_sincos(double x, double& sn, double& cs) {
+  E3W_FMA
+  const double kf = rint(x * 0.63661977236758134308);
+  double r = x - kf * 1.57079632673412561417e+00;
+  r = r - kf * 6.07710050650619224932e-11;
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double s0 = r + r * z * ps, c0 = 1.0 - 0.5 * z + z * z * pc;
+  const int q = (int)kf & 3;
+  sn = (q & 1) ? c0 : s0; cs = (q & 1) ? s0 : c0;
+  if (q == 1 || q == 2) cs = -cs;
+  if (q >= 2) sn = -sn;
 }
 
 // sum_t S[a + sa t] S[b + sb t], t < n: eight products per trip so that the 16 loads of a trip are in flight together (a loop with a
@@ -136,9 +198,11 @@ __device__ __forceinline__ double e3w_readlane(double v, int src) {   // src is 
 #endif
 
 // Link frames and velocity-product accelerations of the state at (qoff, voff) (oracle kin())
-__device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m, int lane, int qoff, int voff) {
+__device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m, int lane, const E3WRegs* regs, int qoff, int voff) {
   E3W_FMA
-  E3W_FOR(l, m.nl) {
+  const int nl = E3W_REGS(0).nl, n_level = E3W_REGS(0).n_level;
+  E3W_MARK("kin0 begin");
+  E3W_FOR(l, nl) {
     const int k = E3WOff::KIN + 27 * l;
     if (l == 0) {
       double qw = S[qoff + 3], qx = S[qoff + 4], qy = S[qoff + 5], qz = S[qoff + 6];
@@ -153,8 +217,9 @@ __device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m,
       const double vo[3] = {S[voff], S[voff + 1], S[voff + 2]}, z3[3] = {0.0, 0.0, 0.0};
       e3w_st3(S, k + 15, vo); e3w_st3(S, k + 18, z3); e3w_st3(S, k + 21, z3); e3w_st3(S, k + 24, z3);
     } else {   // rotation relative to the parent: fixed quat0, then Rodrigues about the hinge axis (parked in the link's R slot)
-      const double ang = S[qoff + 7 + l - 1];
-      const double s = sin(ang), c1 = 1.0 - cos(ang);
+      double s, cang;
+      e3w_sincos(S[qoff + 7 + l - 1], s, cang);
+      const double c1 = 1.0 - cang;
       const double ax = m.axis[l][0], ay = m.axis[l][1], az = m.axis[l][2];
       const double Rh[9] = {1.0 - c1 * (ay * ay + az * az), -s * az + c1 * ax * ay, s * ay + c1 * ax * az,
                             s * az + c1 * ax * ay, 1.0 - c1 * (ax * ax + az * az), -s * ax + c1 * ay * az,
@@ -166,10 +231,12 @@ __device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m,
     }
   }
   E3W_SYNC();
-  for (int d = 1; d < m.n_level; ++d) {
-    const int first = m.lvl_off[d], cnt = m.lvl_off[d + 1] - first;
-    E3W_FOR(ix, cnt) {
-      const int l = m.lvl_link[first + ix], p = m.parent[l], kp = E3WOff::KIN + 27 * p, k = E3WOff::KIN + 27 * l;
+  E3W_MARK("kin levels begin");
+  for (int d = 1; d < n_level; ++d) {
+    E3W_FOR(l, nl) {
+      const E3WRegs& R_ = E3W_REGS(l);
+      if (R_.depth != d) continue;
+      const int p = R_.parent, kp = E3WOff::KIN + 27 * p, k = E3WOff::KIN + 27 * l;
       double Rp[9], Rrel[9], R[9], op[3], wp[3], vop[3], alp[3], aop[3];
 #pragma unroll
       for (int i = 0; i < 9; ++i) { Rp[i] = S[kp + i]; Rrel[i] = S[k + i]; }
@@ -177,8 +244,8 @@ __device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m,
       const double qd = S[voff + 6 + l - 1];
       e3_mat3mul(Rp, Rrel, R);
       double rp[3], aw[3], o[3], w[3], al[3], vo[3], ao[3], t1[3], t2[3];
-      e3_matvec(Rp, m.anchor[l], rp);
-      e3_matvec(Rp, m.axis_p[l], aw);
+      e3_matvec(Rp, R_.anchor, rp);
+      e3_matvec(Rp, R_.axis_p, aw);
 #pragma unroll
       for (int i = 0; i < 3; ++i) { o[i] = op[i] + rp[i]; w[i] = wp[i] + aw[i] * qd; t1[i] = aw[i] * qd; }
       e3_cross(wp, t1, t2);
@@ -197,6 +264,7 @@ __device__ __forceinline__ void e3w_kinematics(e3w_lds* S, const Spatial3Dev& m,
     }
     E3W_SYNC();
   }
+  E3W_MARK("kin end");
 }
 
 // x <- L^-T x, column by column: one uniform step per pivot, the update of the remaining entries spread over the lanes (host form;
@@ -214,10 +282,10 @@ __device__ __forceinline__ void e3w_bwd_sub(e3w_lds* S, int lane, int nv, int x)
 template <int NV>
 __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, int lane, const E3WRegs* regs, int qoff, int voff, int ctrl_off, int out_off) {
   E3W_FMA
-  const int nl = m.nl, nv = NV > 0 ? NV : m.nv;   // NV > 0: the model's dof count at compile time (row solves and solves fully unrolled)
+  const int nl = E3W_REGS(0).nl, nv = NV > 0 ? NV : m.nv;   // NV > 0: the model's dof count at compile time (row solves and solves fully unrolled)
   constexpr int NVM = E3WOff::NVM;
   E3W_T(12);
-  e3w_kinematics(S, m, lane, qoff, voff);
+  e3w_kinematics(S, m, lane, regs, qoff, voff);
   E3W_T(0);
   // ---- per link: composite-inertia seed about the world origin, Newton-Euler wrench about the world origin
   E3W_FOR(l, nl) {
@@ -259,13 +327,16 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
   // ---- subtree sums, one component per lane, children before parents (a link's index exceeds its parent's)
   E3W_FOR(c, 16) {
     const int base = c < 10 ? E3WOff::CRB + c : E3WOff::WR + (c - 10), stride = c < 10 ? 10 : 6;
-    for (int l = nl - 1; l >= 1; --l) S[base + stride * m.parent[l]] += S[base + stride * l];
+    for (int l = nl - 1; l >= 1; --l) S[base + stride * e3w_parent(E3W_REGS(c), l)] += S[base + stride * l];
   }
   E3W_SYNC();
   E3W_T(2);
   // ---- right-hand side tau - c (c: the subtree wrench projected on each dof) ; mass-matrix rows (CRBA)
   const int yrow = E3WOff::Z + E3_MAXR * NVM;   // the right-hand side rides through L^-1 as one more row
-  E3W_FOR(ix, nl + 6) {
+  E3W_FOR(ln, 64) {
+    const E3WRegs& R_ = E3W_REGS(ln);
+    const int ix = ln >= 32 ? ln - 32 : (ln >= 1 && ln < nl ? ln + 5 : -1);   // 0..5: root dofs (lanes 32..37) ; 6 + l - 1: link l on lane l
+    if (ix < 0 || (ln >= 32 && ix >= 6)) continue;
     double R0[9], o0[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R0[i] = S[E3WOff::KIN + i];
@@ -278,7 +349,6 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
       else { a[0] = R0[ix - 3]; a[1] = R0[3 + ix - 3]; a[2] = R0[6 + ix - 3]; e3_cross(o0, a, v0); }
     } else {
       l = ix - 6 + 1;
-      if (l >= nl) continue;
       row = 6 + l - 1; cb = E3WOff::CRB + 10 * l;
       double o[3];
       e3w_ld3(S, E3WOff::KIN + 27 * l + 18, a); e3w_ld3(S, E3WOff::KIN + 27 * l + 9, o);
@@ -292,9 +362,8 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
       const double cvv = e3_dot(a, n) + e3_dot(v0, f);
       double tau = 0.0;
       if (l >= 1) {
-        tau = -m.damping[l] * S[voff + 6 + l - 1] - m.stiffness[l] * S[qoff + 7 + l - 1];
-        const int ka = m.link_act[l];
-        if (ka >= 0) tau += m.gear[l] * S[ctrl_off + ka];
+        tau = -R_.damping * S[voff + 6 + l - 1] - R_.stiffness * S[qoff + 7 + l - 1];
+        if (R_.act >= 0) tau += R_.gear * S[ctrl_off + R_.act];
       }
       S[yrow + row] = tau - cvv;
     }
@@ -312,8 +381,9 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
       L[2] = Ixz * a[0] + Iyz * a[1] + Izz * a[2] + t[2];
     }
     if (l >= 1) {
-      S[E3WOff::M + e3_tri(row, row)] = e3_dot(a, L) + e3_dot(v0, p) + m.armature[l];
-      for (int j = m.parent[l]; j >= 1; j = m.parent[j]) {
+      S[E3WOff::M + e3_tri(row, row)] = e3_dot(a, L) + e3_dot(v0, p) + R_.armature;
+      for (unsigned left = R_.anc & ~(1u << l) & ~1u; left; left &= left - 1) {   // the hinges above this one
+        const int j = __builtin_ctz(left);
         const int kj = E3WOff::KIN + 27 * j;
         double aj[3], oj[3], vj[3];
         e3w_ld3(S, kj + 18, aj); e3w_ld3(S, kj + 9, oj);
@@ -364,7 +434,8 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
   }
   E3W_T(4);
   // ---- contacts (lanes 32 .. 32 + n_contact): distance and contact point of every sphere
-  const int nc = m.n_contact;
+  const int nc = E3W_REGS(0).nc, max_rows = E3W_REGS(0).max_rows;
+  const double margin = E3W_REGS(0).margin;
   E3W_FOR(ln, 64) {
     const int ci = ln - 32;
     if (ci < 0 || ci >= nc) continue;
@@ -386,7 +457,7 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
 #ifdef E3W_HOST_EMU
   for (int ci = 0; ci < nc; ++ci) {
     const double dist = S[E3WOff::A + ci];
-    if (dist < m.margin && nr + 3 <= m.max_rows) {
+    if (dist < margin && nr + 3 <= max_rows) {
       for (int d3 = 0; d3 < 3; ++d3) {
         const int rm = E3WOff::RM + 8 * (nr + d3);
         S[rm + 2] = 0.0; S[rm + 3] = (double)d3; S[rm + 4] = m.cfric[ci]; S[rm + 6] = (double)ci; S[rm + 7] = d3 == 0 ? dist : 0.0;
@@ -395,7 +466,7 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
     }
   }
   for (int l = 1; l < nl; ++l) {
-    if (!m.limited[l] || nr + 1 > m.max_rows) continue;
+    if (!m.limited[l] || nr + 1 > max_rows) continue;
     const double ql = S[qoff + 7 + l - 1], lo = m.range[l][0], hi = m.range[l][1];
     double sgn = 0.0, rr = 0.0;
     if (ql - lo < 0.0) { sgn = 1.0; rr = ql - lo; }
@@ -410,17 +481,17 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
     const int ci = lane - 32;
     const bool isc = ci >= 0 && ci < nc;
     const double dist = S[E3WOff::A + (isc ? ci : 0)];
-    const bool cflag = isc && dist < m.margin;
+    const bool cflag = isc && dist < margin;
     double sgn = 0.0, rr = 0.0;
-    if (lane >= 1 && lane < nl && m.limited[lane]) {
-      const double ql = S[qoff + 7 + lane - 1], lo = m.range[lane][0], hi = m.range[lane][1];
+    if (regs[0].limited) {
+      const double ql = S[qoff + 7 + lane - 1], lo = regs[0].lo, hi = regs[0].hi;
       if (ql - lo < 0.0) { sgn = 1.0; rr = ql - lo; }
       else if (hi - ql < 0.0) { sgn = -1.0; rr = hi - ql; }
     }
     const bool lflag = sgn != 0.0;
     const unsigned long long cmask = __ballot(cflag), lmask = __ballot(lflag), below = (1ull << lane) - 1ull;
-    const int tot_c = __popcll(cmask), acc_c = tot_c < m.max_rows / 3 ? tot_c : m.max_rows / 3, nr_c = 3 * acc_c;
-    const int tot_l = __popcll(lmask), room = m.max_rows - nr_c, acc_l = tot_l < room ? tot_l : room;
+    const int tot_c = __popcll(cmask), acc_c = tot_c < max_rows / 3 ? tot_c : max_rows / 3, nr_c = 3 * acc_c;
+    const int tot_l = __popcll(lmask), room = max_rows - nr_c, acc_l = tot_l < room ? tot_l : room;
     nr = nr_c + acc_l;
     if (cflag) {
       const int rank = __popcll(cmask & below);
@@ -544,7 +615,7 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
     E3W_T(9);
     // ---- projected Gauss-Seidel: rows in sequence (inherent); each update changes one force and every row's residual
 #ifdef E3W_HOST_EMU
-    for (int it = 0; it < m.pgs_iters; ++it)
+    for (int it = 0, n_it = E3W_REGS(0).pgs_iters; it < n_it; ++it)
       for (int r = 0; r < nr; ++r) {
         const int rm = E3WOff::RM + 8 * r;
         const double arr = S[E3WOff::A + e3_tri(r, r)], fold = S[rm + 2];
@@ -579,7 +650,7 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
         const int hi = r > lane ? r : lane, lo = r > lane ? lane : r;
         Acol[r] = S[E3WOff::A + ((on && r < nr) ? e3_tri(hi, lo) : 0)];
       }
-      for (int it = 0; it < m.pgs_iters; ++it) {
+      for (int it = 0, n_it = E3W_REGS(0).pgs_iters; it < n_it; ++it) {
 #pragma unroll
         for (int r = 0; r < E3_MAXR; ++r) {
           if (r >= nr) break;
@@ -629,7 +700,9 @@ __device__ __forceinline__ void e3w_integrate_pos(e3w_lds* S, const Spatial3Dev&
   double qw = S[src_q + 3], qx = S[src_q + 4], qy = S[src_q + 5], qz = S[src_q + 6];
   const double wn = sqrt(wx * wx + wy * wy + wz * wz), ang = wn * h;
   if (ang > 0.0) {
-    const double sh = sin(0.5 * ang) / wn, ch = cos(0.5 * ang);
+    double sh, ch;
+    e3w_sincos(0.5 * ang, sh, ch);
+    sh /= wn;
     const double bx = sh * wx, by = sh * wy, bz = sh * wz;
     const double nw = qw * ch - qx * bx - qy * by - qz * bz, nx = qw * bx + qx * ch + qy * bz - qz * by;
     const double ny = qw * by - qx * bz + qy * ch + qz * bx, nz = qw * bz + qx * by - qy * bx + qz * ch;
@@ -652,7 +725,7 @@ template <int NV>
 __device__ __forceinline__ void e3w_substep(e3w_lds* S, const Spatial3Dev& m, int lane, const E3WRegs* regs) {
   E3W_FMA
   const int nv = NV > 0 ? NV : m.nv;
-  const double h = m.timestep;
+  const double h = E3W_REGS(0).timestep;
 #pragma unroll 1
   for (int st = 0; st < 4; ++st) {
     const double hs = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h), wt = (st == 1 || st == 2) ? 2.0 : 1.0;
@@ -709,10 +782,10 @@ __device__ __forceinline__ void e3w_task_step(e3w_lds* S, const Spatial3Dev& m, 
   E3W_FOR(k, m.n_act) S[E3WOff::CTRL + k] = fmin(fmax((double)act[k] * m.ctrl_range, -m.ctrl_range), m.ctrl_range);
   E3W_SYNC();
   double x0 = S[E3WOff::Q0], com[3];
-  if (m.task == 4) { e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0); e3w_com(S, m, com); x0 = com[0]; }
+  if (m.task == 4) { e3w_kinematics(S, m, lane, regs, E3WOff::Q0, E3WOff::V0); e3w_com(S, m, com); x0 = com[0]; }
 #pragma unroll 1
   for (int s = 0; s < m.frame_skip; ++s) e3w_substep<NV>(S, m, lane, regs);
-  e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0);
+  e3w_kinematics(S, m, lane, regs, E3WOff::Q0, E3WOff::V0);
   const double z = S[E3WOff::Q0 + 2];
   if (m.task == 4) {   // humanoid.py:37-49
     e3w_com(S, m, com);

@@ -710,7 +710,8 @@ __global__ __launch_bounds__(64) void k_env3dw_step(const EnvStepArgs A, const S
   }
   E3W_SYNC();
   E3WRegs regs[1];
-  e3w_regs_init(regs[0], lane, m.nv);
+  e3w_regs_init(regs[0], m, lane);
+  e3w_regs_pin(regs[0]);
   double reward; bool done;
   e3w_task_step<NV>(S, m, lane, regs, A.act + (size_t)t * na, reward, done);
   bool end = false; int len = 0; double ret = 0.0;
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(64) void k_env3dw_step(const EnvStepArgs A, const S
       if (lane == 0) { atomicAdd(&A.stats[0], 1.0); atomicAdd(&A.stats[1], ret); }
       E3W_SYNC();
       e3w_reset_state(S, m, lane, A.seed, A.stream, A.step, (uint32_t)env);
-      e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0);
+      e3w_kinematics(S, m, lane, regs, E3WOff::Q0, E3WOff::V0);
       float* c2 = A.obs_cur + (size_t)env * o;
       e3w_observe(S, m, lane, [&](int i, double val) { c2[i] = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]); });
     }
@@ -764,7 +765,10 @@ __global__ __launch_bounds__(64) void k_env3dw_reset(const Spatial3Dev* mp, doub
   const int t = blockIdx.x, lane = threadIdx.x;
   const int env = ids ? ids[t] : t;
   e3w_reset_state(S, m, lane, seed, stream, step, (uint32_t)env);
-  e3w_kinematics(S, m, lane, E3WOff::Q0, E3WOff::V0);
+  E3WRegs regs[1];
+  e3w_regs_init(regs[0], m, lane);
+  e3w_regs_pin(regs[0]);
+  e3w_kinematics(S, m, lane, regs, E3WOff::Q0, E3WOff::V0);
   const int o = m.obs_dim;
   e3w_observe(S, m, lane, [&](int i, double val) {
     const float f = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]);

@@ -61,7 +61,7 @@ extern "C" int e3hw_step(const ilsx_spatial_model* sm, int reverse, double* q, d
   for (int i = 0; i < m.nv; ++i) S[E3WOff::V0 + i] = v[i];
   bool d; double r;
   E3WRegs regs[64];
-  for (int ln = 0; ln < 64; ++ln) e3w_regs_init(regs[ln], ln, m.nv);
+  for (int ln = 0; ln < 64; ++ln) e3w_regs_init(regs[ln], m, ln);
   const int snv = reverse >> 1;   // bit 1: take the dof count at compile time (the device's Humanoid / Ant instantiations)
   e3w_reverse = reverse & 1;
   if (snv && m.nv == 23) e3w_task_step<23>(S.data(), m, lane, regs, act, r, d);
@@ -84,7 +84,7 @@ extern "C" int e3hw_qacc(const ilsx_spatial_model* sm, int reverse, const double
   for (int i = 0; i < m.nv; ++i) S[E3WOff::V0 + i] = v[i];
   for (int k = 0; k < m.n_act; ++k) S[E3WOff::CTRL + k] = ctrl[k];
   E3WRegs regs[64];
-  for (int ln = 0; ln < 64; ++ln) e3w_regs_init(regs[ln], ln, m.nv);
+  for (int ln = 0; ln < 64; ++ln) e3w_regs_init(regs[ln], m, ln);
   const int snv = reverse >> 1;
   e3w_reverse = reverse & 1;
   if (snv && m.nv == 23) e3w_dynamics<23>(S.data(), m, lane, regs, E3WOff::Q0, E3WOff::V0, E3WOff::CTRL, E3WOff::ACC);

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(64) void k_phases(const Spatial3Dev* mp, const doub
   E3W_SYNC();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   E3WRegs regs[1];
-  e3w_regs_init(regs[0], lane, m.nv);
+  e3w_regs_init(regs[0], m, lane);
+  e3w_regs_pin(regs[0]);
   for (int s = 0; s < n_steps; ++s) {
     double r; bool d;
     if (m.nv == 23) e3w_task_step<23>(S, m, lane, regs, act + (size_t)env * m.n_act, r, d);
