@@ -186,7 +186,9 @@ def cpu_baseline(budget_s=8.0):
     tc = {}
     ncpu = os.cpu_count() or 1
     fixed = batch()
-    for threads in (1, ncpu):
+    # all logical cores is a pathological setting for a 256-wide MLP (measured on the 256-thread GPU host: 0.05 steps/s against 139 at one
+    # thread): the multi-thread point is 16, where intra-op threading of these matrix sizes stops paying
+    for threads in (1, min(16, ncpu)):
         torch.set_num_threads(threads)
         ag = SacAlphaTorch(O, A, hid, *init, **SAC_KW)
         k1, d1 = timed(lambda: ag.train_step(fixed, eps(), eps()), budget_s / 4)
