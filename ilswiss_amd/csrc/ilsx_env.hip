@@ -521,7 +521,13 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
   if (A.auto_reset) {
     const int len = A.ep_len[env] + 1;
     const double ret = A.ep_ret[env] + reward;
-    const bool end = done || len >= A.max_path_length;  // time-limit ends are NOT terminal (base_algorithm.py:264-277)
+    // time-limit ends are NOT terminal (base_algorithm.py:264-277).  With no_terminal the reference overwrites `terminals` BEFORE it
+    // decides to reset (:195-196 ahead of :215), so an unhealthy env is stepped on until the time limit: the fallen states are visited
+    // and rewarded, which is what grounds their values in adversarial IRL.  A state that is no longer finite always resets.
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) finite = finite && isfinite(q[i]) && isfinite(v[i]);
+    const bool end = (done && !A.no_terminal) || len >= A.max_path_length || !finite;
     if (end) {
       atomicAdd(&A.stats[0], 1.0);
       atomicAdd(&A.stats[1], ret);
@@ -611,7 +617,8 @@ __global__ __launch_bounds__(64) void k_env3d_step(const EnvStepArgs A, const Sp
   bool end = false; int len = 0; double ret = 0.0;
   if (A.auto_reset) {
     len = A.ep_len[env] + 1; ret = A.ep_ret[env] + reward;
-    end = done || len >= A.max_path_length;   // time-limit ends are NOT terminal (base_algorithm.py:264-277)
+    bool finite = isfinite(reward);
+    end = (done && !A.no_terminal) || len >= A.max_path_length || !finite;   // see k_env_step: no_terminal keeps stepping an unhealthy env
   }
   float* obs_out = A.obs ? A.obs + (size_t)t * o : nullptr;
   float* cur = (A.obs_cur && !end) ? A.obs_cur + (size_t)env * o : nullptr;
@@ -717,7 +724,8 @@ __global__ __launch_bounds__(64) void k_env3dw_step(const EnvStepArgs A, const S
   bool end = false; int len = 0; double ret = 0.0;
   if (A.auto_reset) {
     len = A.ep_len[env] + 1; ret = A.ep_ret[env] + reward;
-    end = done || len >= A.max_path_length;   // time-limit ends are NOT terminal (base_algorithm.py:264-277)
+    bool finite = isfinite(reward);
+    end = (done && !A.no_terminal) || len >= A.max_path_length || !finite;   // see k_env_step: no_terminal keeps stepping an unhealthy env
   }
   float* obs_out = A.obs ? A.obs + (size_t)t * o : nullptr;
   float* cur = (A.obs_cur && !end) ? A.obs_cur + (size_t)env * o : nullptr;

@@ -186,3 +186,28 @@ def test_limit_activating_mid_step_matches_oracle(ctx):
     np.testing.assert_allclose(q1, np.tile(qo, (64, 1)), rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(v1, np.tile(vo, (64, 1)), rtol=1e-8, atol=1e-8)
     env.close()
+
+
+def test_no_terminal_keeps_stepping_an_unhealthy_env(ctx):
+    """base_algorithm.py:195-196 overwrites `terminals` before the reset decision at :215: with no_terminal an env that fell is stepped on
+    until max_path_length (the fallen states are visited), every stored terminal flag is 0, and episodes end only at the time limit."""
+    import ilswiss_amd as ia
+    n, T = 128, 40
+    env = _mk(ctx, "hopper", n, seed=9)
+    rb = ia.SimpleReplayBuffer(2 * T * n, 11, 3, ctx=ctx)
+    for t in range(T - 1):
+        env.rollout_step(policy=None, replay=rb, max_path_length=T, random_actions=True, no_terminal=True)
+    assert env.rollout_stats(reset=False)[0] == 0            # nobody was reset by falling
+    b = rb._get_batch_using_indices(np.arange((T - 1) * n))
+    assert not b["terminals"].any()
+    z, ang = b["next_observations"][:, 0], b["next_observations"][:, 1]
+    unhealthy = (z <= 0.7) | (np.abs(ang) >= 0.2)
+    assert unhealthy.mean() > 0.2                              # random Hopper falls within ~20 steps: those states ARE in the buffer
+    nxt = b["next_observations"].reshape(T - 1, n, 11); cur = b["observations"].reshape(T - 1, n, 11)
+    np.testing.assert_array_equal(nxt[:-1], cur[1:])           # one unbroken trajectory per env, through the fall
+    env.rollout_step(policy=None, replay=rb, max_path_length=T, random_actions=True, no_terminal=True)
+    episodes, _ = env.rollout_stats()
+    assert episodes == n                                       # all of them end at the time limit, together
+    q, v = env.get_state()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    env.close()

@@ -13,12 +13,12 @@ PY
 python run_scripts/gen_expert_demos.py --snapshot /tmp/walker_expert.pkl --env walker --num-trajs 16 --out demos/walker_sac.pkl
 python run_experiment.py -e exp_specs/gail/$SPEC.yaml -g 0 > gpurun_out/${SPEC}_run.log 2>&1
 f=$(ls -d logs/$LOGNAME/*/ | head -1)
-cp $f/progress.csv gpurun_out/r01_f_${SPEC}_progress.csv
+cp $f/progress.csv gpurun_out/r02_${SPEC}_progress.csv
 python - <<PY
 import csv
-rows = list(csv.DictReader(open("gpurun_out/r01_f_${SPEC}_progress.csv")))
+rows = list(csv.DictReader(open("gpurun_out/r02_${SPEC}_progress.csv")))
 print(len(rows), "epochs")
 for r in rows[::6] + rows[-3:]:
     print(r["Epoch"], r["Number of env steps total"], r["Number of train steps total"], round(float(r["AverageReturn"]), 1),
-          round(float(r["Test Ep. Len. Mean"]), 1), round(float(r["Disc Acc"]), 3), round(float(r["Disc Rew Mean"]), 3), round(float(r["Total Train Time (s)"]), 1))
+          round(float(r["Test Ep. Len. Mean"]), 1), round(float(r["Disc Acc"]), 3), round(float(r["Disc Rew Mean"]), 3), "alpha", round(float(r["Alpha"]), 3), round(float(r["Total Train Time (s)"]), 1))
 PY
