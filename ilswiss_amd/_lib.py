@@ -184,6 +184,7 @@ PROTOTYPES = {
     "ilsx_vecenv_create": (C.c_int, [vp, C.POINTER(PlanarModel), C.c_int, C.c_uint64, C.POINTER(vp)]),
     "ilsx_vecenv_create_spatial": (C.c_int, [vp, C.POINTER(SpatialModel), C.c_int, C.c_uint64, C.POINTER(vp)]),
     "ilsx_vecenv_state_dims": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ilsx_vecenv_set_path_mode": (C.c_int, [vp, C.c_int]),
     "ilsx_vecenv_destroy": (C.c_int, [vp]),
     "ilsx_vecenv_dims": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ilsx_vecenv_reset": (C.c_int, [vp, vp, C.c_int, vp]),

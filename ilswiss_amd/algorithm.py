@@ -87,7 +87,12 @@ class DeviceRLAlgorithm:
                  num_steps_per_eval=1000, max_path_length=1000, min_steps_before_training=0, batch_size=256,
                  replay_buffer_size=1000000, no_terminal=False, eval_deterministic=True, freq_saving=1, save_best=True,
                  save_replay_buffer=False, replay_buffer=None, log_dir=None, best_key="AverageReturn", bootstrap_open_segments=True,
-                 eval_on_device=True, **kwargs):
+                 eval_on_device=True, insert_at_episode_end=False, **kwargs):
+        # insert_at_episode_end (an ilswiss_amd key, default off): the fused rollout keeps the reference's replay order — samples enter
+        # the ring when their episode ends, contiguous and registered in _traj_endpoints (base_algorithm.py:509-519) — instead of
+        # inserting every transition as it happens
+        if insert_at_episode_end and hasattr(training_env, "set_path_mode"):
+            training_env.set_path_mode(True)
         self.no_terminal = bool(no_terminal)   # base_algorithm.py:195-196,208-210: stored terminal flags forced to False
         self.on_policy = bool(getattr(trainer, "on_policy", False))   # torch_rl_algorithm.py:30-32
         self.bootstrap_open_segments = bootstrap_open_segments

@@ -173,6 +173,9 @@ struct ilsx_replay {
 };
 // n rows were written into the ring at [top, top+n) by a device kernel: advance the cursors.
 int replay_advance_device_rows(ilsx_replay* rb, int n);
+// n_paths whole episodes staged at stage[env][t][rec] enter the ring contiguously, in the order given (path mode of the fused rollout)
+int replay_insert_paths(ilsx_replay* rb, const float* stage, int stage_len, const int* envs, const int* lens, const uint8_t* last_terminal,
+                        int n_paths);
 int replay_launch_sample(ilsx_replay* rb, int B, const int64_t* idx, const DevScalars* scal,
                          unsigned long long step_host, float* obs, float* act, float* rew, float* done,
                          float* nobs, int64_t* idx_out);

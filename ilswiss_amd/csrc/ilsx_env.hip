@@ -55,6 +55,8 @@ struct ilsx_vecenv {
   float* act_label = nullptr;   // [n_env][a] expert labels (ilsx_rollout_step_relabel)
   unsigned char* ev_frozen = nullptr; double* ev_ret = nullptr; int* ev_len = nullptr; double* ev_stats = nullptr; int* ev_alive = nullptr;
   bool norm_obs = false, update_rms = false;
+  // path mode (ilsx_vecenv_set_path_mode): whole episodes are staged and enter the ring when they end (base_algorithm.py:509-519)
+  bool path_mode = false; float* stage = nullptr; int stage_len = 0, stage_rec = 0; int* flush_len = nullptr; std::vector<int> flush_host;
   // 3-D engine (Ant / Humanoid, env3d.h): model, its device copy, and the per-env working set [E3Off::TOTAL][n_env]
   int engine = 0, nq = 0, nv = 0;
   bool wave3 = true;   // wave-per-env kernels (env3d_wave.h); ILSX_ENV3D_LANE=1 selects the lane-per-env form (env3d.h) for A/B runs
@@ -419,6 +421,7 @@ struct EnvStepArgs {
   // fused-rollout extras (all nullable / 0)
   float* obs_cur;         // [n_env][o]: the policy's next input (post auto-reset)
   int auto_reset, max_path_length, no_terminal;
+  float* stage; int stage_len; int* flush_len;   // path mode: records go to stage[env][step of the episode], flush_len[env] = length | terminal << 30 when the episode ends
   const float* rec_act;          // nullable: [n_ids][a] action written into the replay record instead of `act`
   const unsigned char* frozen;   // nullable: envs whose flag is set do not step (evaluation: one episode per env)
   int* ep_len; double* ep_ret; double* stats;
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
   if (A.replay) {  // fused replay insert: one 128-byte-aligned record per transition
     long long slot = A.top + env;
     if (slot >= A.cap) slot -= A.cap;
-    float* rec = A.replay + (size_t)slot * A.rec;
+    float* rec = A.stage ? A.stage + ((size_t)env * A.stage_len + A.ep_len[env]) * A.rec : A.replay + (size_t)slot * A.rec;
     for (int i = 0; i < o; ++i) rec[i] = obs_before[i];
     const float* ra = A.rec_act ? A.rec_act : A.act;   // DAgger stores the expert's label, not the executed action
     for (int k = 0; k < na; ++k) rec[o + k] = ra[(size_t)t * na + k];
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
     }
     A.ep_len[env] = end ? 0 : len;
     A.ep_ret[env] = end ? 0.0 : ret;
+    if (A.flush_len) A.flush_len[env] = end ? (len | ((done && !A.no_terminal) ? (1 << 30) : 0)) : 0;
   }
   if (A.obs_cur) for (int i = 0; i < o; ++i) A.obs_cur[(size_t)env * o + i] = ob[i];
 #pragma unroll
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(64) void k_env3d_step(const EnvStepArgs A, const Sp
   if (A.replay) {   // fused replay insert: the observation the policy acted on is the stored current observation
     long long slot = A.top + env;
     if (slot >= A.cap) slot -= A.cap;
-    rec = A.replay + (size_t)slot * A.rec;
+    rec = A.stage ? A.stage + ((size_t)env * A.stage_len + A.ep_len[env]) * A.rec : A.replay + (size_t)slot * A.rec;
     for (int i = 0; i < o; ++i) rec[i] = A.obs_cur[(size_t)env * o + i];
   }
   double reward; bool done;
@@ -649,6 +653,7 @@ __global__ __launch_bounds__(64) void k_env3d_step(const EnvStepArgs A, const Sp
     }
     A.ep_len[env] = end ? 0 : len;
     A.ep_ret[env] = end ? 0.0 : ret;
+    if (A.flush_len) A.flush_len[env] = end ? (len | ((done && !A.no_terminal) ? (1 << 30) : 0)) : 0;
   }
   for (int i = 0; i < m.nq; ++i) A.qpos[(size_t)i * n_env + env] = E3S(E3St::Q0 + i);
   for (int i = 0; i < m.nv; ++i) A.qvel[(size_t)i * n_env + env] = E3S(E3St::V0 + i);
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(64) void k_env3dw_step(const EnvStepArgs A, const S
   if (A.replay) {   // fused replay insert: the observation the policy acted on is the stored current observation
     long long slot = A.top + env;
     if (slot >= A.cap) slot -= A.cap;
-    rec = A.replay + (size_t)slot * A.rec;
+    rec = A.stage ? A.stage + ((size_t)env * A.stage_len + A.ep_len[env]) * A.rec : A.replay + (size_t)slot * A.rec;
     E3W_FOR(i, o) rec[i] = A.obs_cur[(size_t)env * o + i];
   }
   E3W_SYNC();
@@ -758,7 +763,10 @@ __global__ __launch_bounds__(64) void k_env3dw_step(const EnvStepArgs A, const S
       float* c2 = A.obs_cur + (size_t)env * o;
       e3w_observe(S, m, lane, [&](int i, double val) { c2[i] = (float)((val - m.obs_shift[i]) * m.obs_inv_scale[i]); });
     }
-    if (lane == 0) { A.ep_len[env] = end ? 0 : len; A.ep_ret[env] = end ? 0.0 : ret; }
+    if (lane == 0) {
+      A.ep_len[env] = end ? 0 : len; A.ep_ret[env] = end ? 0.0 : ret;
+      if (A.flush_len) A.flush_len[env] = end ? (len | ((done && !A.no_terminal) ? (1 << 30) : 0)) : 0;
+    }
   }
   E3W_FOR(i, m.nq) A.qpos[(size_t)i * n_env + env] = S[E3WOff::Q0 + i];
   E3W_FOR(i, m.nv) A.qvel[(size_t)i * n_env + env] = S[E3WOff::V0 + i];
@@ -978,6 +986,11 @@ extern "C" int ilsx_vecenv_create_spatial(ilsx_ctx* ctx, const ilsx_spatial_mode
   *out = e;
   return ILSX_OK;
 }
+extern "C" int ilsx_vecenv_set_path_mode(ilsx_vecenv* e, int on) {
+  if (!e) ILSX_FAIL(ILSX_ERR_ARG, "env is NULL");
+  e->path_mode = on != 0;
+  return ILSX_OK;
+}
 extern "C" int ilsx_vecenv_state_dims(const ilsx_vecenv* e, int* nq, int* nv) {
   if (!e) ILSX_FAIL(ILSX_ERR_ARG, "env is NULL");
   if (nq) *nq = e->nq;
@@ -987,7 +1000,7 @@ extern "C" int ilsx_vecenv_state_dims(const ilsx_vecenv* e, int* nq, int* nv) {
 
 extern "C" int ilsx_vecenv_destroy(ilsx_vecenv* e) {
   if (!e) return ILSX_OK;
-  void* ps[] = {e->dm, e->qpos, e->qvel, e->obs_cur, e->act, e->nobs, e->rew, e->done, e->ep_len, e->ep_ret, e->stats, e->ids, e->dm3, e->scr3};
+  void* ps[] = {e->dm, e->qpos, e->qvel, e->obs_cur, e->act, e->nobs, e->rew, e->done, e->ep_len, e->ep_ret, e->stats, e->ids, e->dm3, e->scr3, e->stage, e->flush_len};
   for (void* p : ps) if (p) ctx_free(e->ctx, p);
   delete e->hm3;
   delete e;
@@ -1222,8 +1235,30 @@ static int rollout_step_impl(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* label_pi, i
     ILSX_TRY(ilsx_policy_act(label_pi, e->policy_obs(), e->n_env, label_deterministic, nullptr, e->act_label, nullptr));
     A.rec_act = e->act_label;
   }
+  const bool paths = rb && e->path_mode;
+  if (paths) {
+    if (e->stage && (e->stage_rec != rb->rec || e->stage_len < max_path_length))
+      ILSX_FAIL(ILSX_ERR_ARG, "path mode: staging holds %d-step episodes of %d-float records, asked for %d / %d", e->stage_len, e->stage_rec,
+                max_path_length, rb->rec);
+    if (!e->stage) {
+      if (max_path_length < 1 || max_path_length >= rb->cap) ILSX_FAIL(ILSX_ERR_ARG, "path mode needs 1 <= max_path_length < replay capacity");
+      ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * max_path_length * rb->rec * 4, (void**)&e->stage));
+      ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * 4, (void**)&e->flush_len));
+      e->stage_len = max_path_length; e->stage_rec = rb->rec; e->flush_host.resize(e->n_env);
+    }
+    A.stage = e->stage; A.stage_len = e->stage_len; A.flush_len = e->flush_len;
+  }
   ILSX_TRY(launch_env_step(e, A));
-  if (rb) ILSX_TRY(replay_advance_device_rows(rb, e->n_env));
+  if (paths) {
+    HIPCHK(hipMemcpyAsync(e->flush_host.data(), e->flush_len, (size_t)e->n_env * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<int> envs, lens; std::vector<uint8_t> term;
+    for (int i = 0; i < e->n_env; ++i)
+      if (e->flush_host[i]) { envs.push_back(i); lens.push_back(e->flush_host[i] & ((1 << 30) - 1)); term.push_back((e->flush_host[i] >> 30) & 1); }
+    ILSX_TRY(replay_insert_paths(rb, e->stage, e->stage_len, envs.data(), lens.data(), term.data(), (int)envs.size()));
+  } else if (rb) {
+    ILSX_TRY(replay_advance_device_rows(rb, e->n_env));
+  }
   return env_after_step_norm(e);
 }
 

@@ -182,6 +182,58 @@ extern "C" int ilsx_replay_add(ilsx_replay* rb, const float* obs, const float* a
   return replay_push_state(rb);
 }
 
+// Whole episodes staged by the fused rollout (path mode) enter the ring the way BaseAlgorithm._handle_vec_rollout_ending
+// (base_algorithm.py:509-519) does it: ended envs in ascending order, each path's samples appended contiguously through add_sample's
+// cursor logic (simple_replay_buffer.py:78-108: a terminal row closes the trajectory at top + 1), then terminate_episode (:126-132).
+struct PathEntry { int env, len; long long start; };
+__global__ void k_paths_copy(const float* __restrict__ stage, int stage_len, int rec, float* __restrict__ ring, long long cap,
+                             const PathEntry* __restrict__ table) {
+  const PathEntry e = table[blockIdx.x];
+  const int r4 = rec >> 2;   // rec is a multiple of 32 floats
+  const float4* src = reinterpret_cast<const float4*>(stage + (size_t)e.env * stage_len * rec);
+  for (long long i = threadIdx.x; i < (long long)e.len * r4; i += blockDim.x) {
+    const long long t = i / r4, c = i - t * r4;
+    long long slot = e.start + t;
+    if (slot >= cap) slot -= cap;
+    reinterpret_cast<float4*>(ring + (size_t)slot * rec)[c] = src[i];
+  }
+}
+int replay_insert_paths(ilsx_replay* rb, const float* stage, int stage_len, const int* envs, const int* lens, const uint8_t* last_terminal,
+                        int n_paths) {
+  if (n_paths <= 0) return ILSX_OK;
+  ilsx_ctx* ctx = rb->ctx;
+  std::vector<PathEntry> table((size_t)n_paths);
+  for (int k = 0; k < n_paths; ++k) {
+    if (lens[k] < 1 || lens[k] > stage_len || lens[k] >= rb->cap) ILSX_FAIL(ILSX_ERR_ARG, "path of %d samples does not fit (stage %d, capacity %lld)", lens[k], stage_len, (long long)rb->cap);
+    table[k] = PathEntry{envs[k], lens[k], (long long)rb->top};
+    for (int t = 0; t < lens[k]; ++t) {
+      if (t == lens[k] - 1 && last_terminal[k]) {
+        const int64_t nxt = (rb->top + 1) % rb->cap;
+        host_set_endpoint(rb, rb->cur_start, nxt);
+        rb->cur_start = nxt;
+      }
+      host_advance(rb);
+    }
+    host_terminate(rb);
+  }
+  void* st = nullptr;
+  ILSX_TRY(ctx_stage(ctx, table.size() * sizeof(PathEntry), &st));
+  HIPCHK(hipMemcpyAsync(st, table.data(), table.size() * sizeof(PathEntry), hipMemcpyHostToDevice, ctx->stream));
+  long long total = 0;
+  for (int k = 0; k < n_paths; ++k) total += lens[k];
+  if (total <= rb->cap) {
+    hipLaunchKernelGGL(k_paths_copy, dim3(n_paths), dim3(256), 0, ctx->stream, stage, stage_len, rb->rec, rb->data, (long long)rb->cap,
+                       (const PathEntry*)st);
+  } else {   // one flush larger than the ring: later paths overwrite earlier ones of the same flush, so the copies must be ordered
+    for (int k = 0; k < n_paths; ++k)
+      hipLaunchKernelGGL(k_paths_copy, dim3(1), dim3(256), 0, ctx->stream, stage, stage_len, rb->rec, rb->data, (long long)rb->cap,
+                         (const PathEntry*)st + k);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // `table` and the staging buffer are reused by the next call
+  return replay_push_state(rb);
+}
+
 int replay_advance_device_rows(ilsx_replay* rb, int n) {
   // rows inserted by the fused rollout kernel carry no trajectory bookkeeping of their own (SAC samples
   // uniformly over rows, simple_replay_buffer.py:242); overwritten trajectory starts are still dropped.

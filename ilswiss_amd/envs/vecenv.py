@@ -262,6 +262,11 @@ class HipVectorEnv:
                                                   replay.h if replay is not None else None, int(max_path_length),
                                                   int(bool(random_actions)), int(bool(deterministic)), int(bool(no_terminal))))
 
+    def set_path_mode(self, on=True):
+        """Fused rollouts insert whole episodes when they end, contiguously and registered in `_traj_endpoints` (the reference's
+        order, base_algorithm.py:509-519) instead of every transition as it happens."""
+        _lib.check(self.ctx.lib.ilsx_vecenv_set_path_mode(self.h, int(bool(on))))
+
     def rollout_stats(self, reset=True):
         e, r = C.c_double(), C.c_double()
         _lib.check(self.ctx.lib.ilsx_rollout_stats(self.h, C.byref(e), C.byref(r), int(reset)))

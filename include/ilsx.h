@@ -479,6 +479,11 @@ typedef struct {
   double init_qpos[ILSX_ENV3_MAX_LINK + 6];
 } ilsx_spatial_model;
 int ilsx_vecenv_create_spatial(ilsx_ctx* ctx, const ilsx_spatial_model* model, int n_env, uint64_t seed, ilsx_vecenv** out);
+/* Path mode of the fused rollout (ilsx_rollout_step with a replay ring): 0 (default) = every transition enters the ring when it
+ * happens; 1 = the reference's order (rlkit/core/base_algorithm.py:509-519, simple_replay_buffer.py:78-132): an episode's samples are
+ * staged in HBM and enter the ring contiguously when the episode ends (ended envs in ascending order), the trajectory is registered in
+ * _traj_endpoints, unfinished episodes are not sampleable.  Costs one 4-byte-per-env read-back per rollout step. */
+int ilsx_vecenv_set_path_mode(ilsx_vecenv* env, int on);
 /* sizes of the simulator state rows of ilsx_vecenv_get_state / _set_state (planar: nq == nv; 3-D: nq == nv + 1) */
 int ilsx_vecenv_state_dims(const ilsx_vecenv* env, int* nq, int* nv);
 int ilsx_vecenv_destroy(ilsx_vecenv* env);

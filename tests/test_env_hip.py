@@ -211,3 +211,52 @@ def test_no_terminal_keeps_stepping_an_unhealthy_env(ctx):
     q, v = env.get_state()
     assert np.isfinite(q).all() and np.isfinite(v).all()
     env.close()
+
+
+@pytest.mark.parametrize("no_terminal", [False, True])
+def test_path_mode_inserts_whole_episodes_in_the_references_order(no_terminal):
+    """Path mode of the fused rollout == BaseAlgorithm's bookkeeping (base_algorithm.py:490-519 over simple_replay_buffer.py:78-132):
+    samples enter the ring when their episode ends, ended envs in ascending order, contiguous, registered in _traj_endpoints, through
+    ring wrap-around.  Expected ring: the reference's cursor logic (oracle.replay) replayed over the transitions an identical env run
+    in immediate mode recorded."""
+    import ilswiss_amd as ia
+    from oracle.replay import ReplayOracle
+    n, T, maxlen, cap = 48, 70, 25, 900
+    got = {}
+    for mode in ("step", "path"):
+        c = ia.Context(0, seed=123)
+        env = _mk(c, "hopper", n, seed=5)
+        rb = ia.SimpleReplayBuffer(T * n if mode == "step" else cap, 11, 3, ctx=c)
+        if mode == "path":
+            env.set_path_mode(True)
+        sizes = []
+        for t in range(T):
+            env.rollout_step(policy=None, replay=rb, max_path_length=maxlen, random_actions=True, no_terminal=no_terminal)
+            sizes.append(rb._size)
+        got[mode] = (rb._gather(np.arange(rb._size)), rb._top, rb._size, dict(rb._traj_endpoints), sizes, rb)
+    rows, _, _, _, _, _ = got["step"]
+    ora = ReplayOracle(cap, 11, 3)
+    paths, lens, exp_sizes = [[] for _ in range(n)], np.zeros(n, int), []
+    for t in range(T):
+        for e in range(n):           # the vec step's samples go to the path builders (base_algorithm.py:490-497)
+            i = t * n + e
+            paths[e].append(i)
+        ended = [e for e in range(n) if rows["terminals"][paths[e][-1], 0] > 0 or len(paths[e]) >= maxlen]
+        for e in ended:              # _handle_vec_rollout_ending: ascending env index
+            for i in paths[e]:
+                ora.add_sample(rows["observations"][i], rows["actions"][i], rows["rewards"][i, 0], rows["terminals"][i, 0] > 0,
+                               rows["next_observations"][i])
+            ora.terminate_episode()
+            paths[e] = []
+        exp_sizes.append(ora.size)
+    b, top, size, ends, sizes, rb = got["path"]
+    assert (top, size) == (ora.top, ora.size) and size == cap            # wrapped
+    assert sizes == exp_sizes and sizes[0] == 0                          # unfinished episodes are not sampleable
+    assert ends == dict(ora.traj_endpoints) and list(ends) == list(ora.traj_endpoints) and len(ends) > 10
+    exp = ora.gather(np.arange(size))
+    for k in ("observations", "actions", "rewards", "terminals", "next_observations"):
+        np.testing.assert_array_equal(b[k].reshape(exp[k].shape), exp[k], err_msg=k)
+    trajs = rb.sample_all_trajs()
+    assert len(trajs) == len(ends)
+    for tr in trajs[:5]:            # contiguous: next_obs(t) == obs(t+1) inside a trajectory
+        np.testing.assert_array_equal(tr["next_observations"][:-1], tr["observations"][1:])
