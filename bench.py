@@ -19,6 +19,7 @@ spawns N copies of itself, one per GPU, on 127.0.0.1 and relays rank 0's JSON li
 stream between backward and update) — the only leg with a data-path collective, never `value`.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -199,7 +200,27 @@ def cpu_baseline(budget_s=8.0):
         tc[f"threads_{threads}"] = dict(train_step_per_s=k1 / d1, sample_convert_train_step_per_s=k2 / d2, get_actions_ms_4096=1e3 * d3 / k3)
     out["torch_cpu"] = dict(tc, note="oracle/sac_alpha_torch.py (autograd + torch.optim.Adam), fp32, same inputs; "
                                      f"host has {ncpu} logical cores")
+    out["env_stepper"] = cpu_env_baseline(ncpu)
     return out
+
+
+def cpu_env_baseline(ncpu):
+    """env-steps/s of the scalar compiled restatement of the Hopper stepper (oracle/planar_env.c == oracle/planar_env.py to 1e-10,
+    tests/test_env_oracle.py) on the host: one core, and every core with OpenMP over envs.  Uniform actions, auto-reset."""
+    from ilswiss_amd.envs.models import MODELS
+    from ilswiss_amd.envs.vecenv import model_struct
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_build", "liborc_planar.so")
+    if not os.path.exists(so):
+        return dict(error="oracle/_build/liborc_planar.so not built (__graft_entry__.build() / make -C oracle)")
+    lib = C.CDLL(so)
+    lib.orc_planar_bench.restype = C.c_double
+    ms, cs, res = model_struct(MODELS["hopper"]()), C.c_double(), {}
+    for threads, n_env, n_steps in ((1, 64, 1500), (ncpu, 4096, 250)):
+        lib.orc_planar_bench(C.byref(ms), n_env, 20, 1000, threads, C.byref(cs))      # warm (thread pool)
+        dt = lib.orc_planar_bench(C.byref(ms), n_env, n_steps, 1000, threads, C.byref(cs))
+        res[f"threads_{threads}"] = dict(env_steps_per_s=n_env * n_steps / dt, sample=f"{n_env} envs x {n_steps} steps in {dt:.2f} s")
+    res["note"] = "oracle/planar_env.c (gcc -O2, dense formulation of oracle/planar_env.py), Hopper model, uniform actions, auto-reset"
+    return res
 
 
 def spawn_ranks(n, argv):

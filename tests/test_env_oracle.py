@@ -142,3 +142,41 @@ def test_halfcheetah_reward_never_done_and_reset_noise():
     for _ in range(60):
         q, v, ob, rew, done = P.step(q, v, np.zeros(6))
     assert 0.3 < q[1] < 0.8 and np.all(np.isfinite(q)) and np.abs(v).max() < 1.0
+
+
+def test_c_restatement_matches_the_numpy_oracle():
+    """oracle/planar_env.c (the compiled CPU baseline of bench.py's env-steps/s) == oracle/planar_env.py over chained steps with
+    contacts, joint limits and terminations, all three planar models."""
+    import ctypes as C
+    import os
+    import subprocess
+    from ilswiss_amd.envs.models import MODELS
+    from ilswiss_amd.envs.vecenv import model_struct
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle")], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(root, "oracle", "_build", "liborc_planar.so"))
+    lib.orc_planar_bench.restype = C.c_double
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    for name in ("hopper", "walker", "halfcheetah"):
+        m = MODELS[name]()
+        P, ms = PlanarOracle(m), model_struct(m)
+        rng = np.random.default_rng(3)
+        n, na = m["n_body"] + 2, len(m["act_bodies"])
+        dones = []
+        for trial in range(8):
+            q, v = P.reset(rng)
+            q[1] += rng.uniform(-0.05, 0.3); q[2] += rng.uniform(-0.3, 0.3); q[3:] += rng.uniform(-0.8, 0.3, n - 3); v += rng.normal(0, 1.5, n)
+            qc, vc = q.copy(), v.copy()
+            for s in range(5):
+                a = rng.uniform(-1.3, 1.3, na)
+                q, v, ob, r, d = P.step(q, v, a)
+                obc, rc, dc = np.empty(2 * n - 1), C.c_double(), C.c_int()
+                assert lib.orc_planar_step(C.byref(ms), p(qc), p(vc), p(a), p(obc), C.byref(rc), C.byref(dc)) == 0
+                np.testing.assert_allclose(qc, q, rtol=1e-10, atol=1e-11)
+                np.testing.assert_allclose(vc, v, rtol=1e-9, atol=1e-9)
+                np.testing.assert_allclose(obc, ob, rtol=1e-9, atol=1e-9)
+                assert abs(rc.value - r) < 1e-8 and bool(dc.value) == bool(d)
+                dones.append(bool(d))
+        assert name != "hopper" or any(dones)            # Walker2d's healthy band is wide, HalfCheetah never terminates
+        cs = C.c_double()
+        assert lib.orc_planar_bench(C.byref(ms), 8, 20, 1000, 1, C.byref(cs)) > 0 and np.isfinite(cs.value)
