@@ -83,7 +83,7 @@ class Td3Cfg(C.Structure):  # ilsx_td3_cfg
     _fields_ = [("reward_scale", C.c_float), ("discount", C.c_float), ("policy_lr", C.c_float), ("qf_lr", C.c_float),
                 ("policy_and_target_update_period", C.c_int32), ("soft_target_tau", C.c_float),
                 ("policy_noise", C.c_float), ("policy_noise_clip", C.c_float), ("max_act", C.c_float),
-                ("max_batch", C.c_int32)]
+                ("max_batch", C.c_int32), ("her", C.c_int32), ("clip_return_l", C.c_float), ("clip_return_r", C.c_float)]
 
 
 class Td3Stats(C.Structure):  # ilsx_td3_stats

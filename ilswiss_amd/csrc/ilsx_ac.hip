@@ -297,6 +297,7 @@ struct ilsx_td3 {
   float *a2 = nullptr, *q1 = nullptr, *q2 = nullptr, *tq1 = nullptr, *tq2 = nullptr;   // critic phase
   float *pa = nullptr, *pre = nullptr, *qn = nullptr, *ga = nullptr;                     // actor phase
   float *ppt = nullptr, *ppc = nullptr;   // head partials of pi_tgt(s') / pi(s) (column-split path)
+  float* tqc = nullptr;                   // HER: clip(min(TQ1, TQ2), l, r) per row
 };
 
 extern "C" int ilsx_td3_create(ilsx_ctx* ctx, const ilsx_td3_cfg* cfg, ilsx_net* pi, ilsx_net* q1, ilsx_net* q2, ilsx_td3** out) {
@@ -325,6 +326,7 @@ extern "C" int ilsx_td3_create(ilsx_ctx* ctx, const ilsx_td3_cfg* cfg, ilsx_net*
   if (rc == ILSX_OK) rc = ac_alloc(g, &t->ga, CS * B * a);
   if (rc == ILSX_OK) rc = ac_alloc(g, &t->ppt, CS * B * a);
   if (rc == ILSX_OK) rc = ac_alloc(g, &t->ppc, CS * B * a);
+  if (rc == ILSX_OK && cfg->her) rc = ac_alloc(g, &t->tqc, B);
   if (rc == ILSX_OK) rc = ac_tick(g, 0, 0);
   if (rc != ILSX_OK) { delete t; return rc; }
   pi->noise = cfg->policy_noise; pi->noise_clip = cfg->policy_noise_clip; pi->max_act = cfg->max_act; pi->noise_policy = true;
@@ -336,6 +338,38 @@ extern "C" int ilsx_td3_destroy(ilsx_td3* t) {
   ac_release(&t->g);
   delete t;
   return ILSX_OK;
+}
+
+// ---- HER-TD3 (rlkit/torch/algorithms/her/td3.py:100-170), the three places where it departs from td3.py, as side kernels so that
+// the fused MLP kernels stay as they are:
+//  * target action (:104-114): the reference adds sigma * N(0,1) to the target policy's output and then clamps THE NOISE, not the sum
+//    (`torch.clamp(noise, min_act, max_act)`), so the action the target critics see is clamp(sigma * eps) and the target policy's
+//    forward pass has no effect — followed as written;
+//  * target value (:116-122): clip(min(TQ1, TQ2), clip_return_l, clip_return_r);
+//  * policy loss (:148-152): -mean(Q1(s, pi(s))) + mean(pi(s)^2), i.e. dL/da += 2 a / (B * A).
+__global__ void k_her_target_action(float* __restrict__ a2, const float* __restrict__ eps, int B, int a, float sigma, float max_act,
+                                    uint64_t seed, const DevScalars* scal, uint32_t stream) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * a) return;
+  const int gr = i / a, j = i - gr * a;
+  float e;
+  if (eps) {
+    e = eps[i];
+  } else {
+    float z4[4];
+    philox_normal4(seed, scal->step, stream, gr, j >> 2, z4);
+    const int q = j & 3;
+    e = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
+  }
+  a2[i] = fminf(fmaxf(sigma * e, -max_act), max_act);
+}
+__global__ void k_her_clip_target(PartVal tq1, PartVal tq2, float* __restrict__ out, int B, float lo, float hi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = fminf(fmaxf(fminf(tq1.get(i), tq2.get(i)), lo), hi);
+}
+__global__ void k_her_l2_grad(float* __restrict__ ga, const float* __restrict__ pa, int n, float coef) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ga[i] += coef * pa[i];
 }
 
 // policy trunk as a forward task; generic kernels finish the head (tanh + clipped noise) in their epilogue, the column-split
@@ -372,7 +406,17 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
   const ilsx_td3_cfg& c = t->cfg;
   const bool update = t->n_steps % c.policy_and_target_update_period == 0;
   const bool actor = update || stats != nullptr;
-  {  // noisy target action (td3.py:84-85; the target is policy.copy() and keeps its noise) ; pi(s) rides along when needed
+  const int na = g->B * g->a;
+  if (c.her) {   // her/td3.py:104-114: the target action is the clamped noise alone ; pi(s) still runs when the actor needs it
+    hipLaunchKernelGGL(k_her_target_action, dim3((na + 255) / 256), dim3(256), 0, g->ctx->stream, t->a2, g->eps_explicit ? (const float*)g->eps : nullptr,
+                       g->B, g->a, c.policy_noise, c.max_act, g->ctx->seed, (const DevScalars*)g->dsc, g->rng_stream);
+    HIPCHK(hipGetLastError());
+    if (actor) {
+      FwdArgs A = ac_fwd_args(g, 1);
+      td3_policy_task(t, A.t[0], false, g->s, false, update, t->pa, t->pre, t->ppc);
+      ILSX_TRY(ac_launch_fwd(g, A, g->L[T3_PI].KP));
+    }
+  } else {  // noisy target action (td3.py:84-85; the target is policy.copy() and keeps its noise) ; pi(s) rides along when needed
     FwdArgs A = ac_fwd_args(g, actor ? 2 : 1);
     td3_policy_task(t, A.t[0], true, g->s2, true, false, t->a2, nullptr, t->ppt);
     if (actor) td3_policy_task(t, A.t[1], false, g->s, false, update, t->pa, t->pre, t->ppc);
@@ -384,8 +428,13 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
     ac_fwd(g, A.t[1], T3_Q2, true, g->s2, g->o, t->a2, g->a, false); ac_out(g, A.t[1], t->tq2);
     ac_fwd(g, A.t[2], T3_Q1, false, g->s, g->o, g->ac, g->a, true); ac_out(g, A.t[2], t->q1); A.t[2].no_fin = 1;
     ac_fwd(g, A.t[3], T3_Q2, false, g->s, g->o, g->ac, g->a, true); ac_out(g, A.t[3], t->q2); A.t[3].no_fin = 1;
-    td3_policy_fin(t, A, true, t->ppt, t->a2, nullptr);
+    if (!c.her) td3_policy_fin(t, A, true, t->ppt, t->a2, nullptr);
     ILSX_TRY(ac_launch_fwd(g, A, g->L[T3_Q1].KP));
+  }
+  if (c.her) {
+    hipLaunchKernelGGL(k_her_clip_target, dim3((g->B + 255) / 256), dim3(256), 0, g->ctx->stream, pv(g, t->tq1), pv(g, t->tq2), t->tqc, g->B,
+                       c.clip_return_l, c.clip_return_r);
+    HIPCHK(hipGetLastError());
   }
   {
     BwdArgs A = ac_bwd_args(g, 2, c.discount, c.reward_scale);
@@ -393,7 +442,9 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
       BwdTask& b = A.t[i];
       ac_bwd(g, b, i, true);
       b.loss = LOSS_TD_CRITIC; b.coef = 2.0f;   // nn.MSELoss: no 1/2 (td3.py:36-37,92-97)
-      b.q = pv(g, i == 0 ? t->q1 : t->q2); b.tq1 = pv(g, t->tq1); b.tq2 = pv(g, t->tq2);
+      b.q = pv(g, i == 0 ? t->q1 : t->q2);
+      if (c.her) b.tq1 = b.tq2 = PartVal{t->tqc, 1, g->max_batch};
+      else { b.tq1 = pv(g, t->tq1); b.tq2 = pv(g, t->tq2); }
       b.rew = g->r; b.done = g->d;
     }
     ILSX_TRY(ac_launch_bwd(g, A));
@@ -408,6 +459,10 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
       b.loss = LOSS_CONST; b.coef = -1.0f;
       b.dx = t->ga; b.dx_col0 = g->o; b.dx_cols = g->a;
       ILSX_TRY(ac_launch_bwd(g, A));
+    }
+    if (c.her) {   // + mean(a^2): 2 a / (B A) added to the first partial slab of dQ/da
+      hipLaunchKernelGGL(k_her_l2_grad, dim3((na + 255) / 256), dim3(256), 0, g->ctx->stream, t->ga, (const float*)t->pa, na, 2.0f / (float)na);
+      HIPCHK(hipGetLastError());
     }
     {
       BwdArgs A = ac_bwd_args(g, 1, 0.f, 0.f);
@@ -430,12 +485,21 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
     ILSX_TRY(ac_fetch_pv(g, t->qn, B, qn)); ILSX_TRY(ac_fetch(g, t->pa, B * g->a, pa));
     HIPCHK(hipStreamSynchronize(g->ctx->stream));
     std::vector<float> y(B), e1, e2;
-    for (size_t i = 0; i < B; ++i) y[i] = c.reward_scale * r[i] + (1.0f - d[i]) * c.discount * std::min(tq1[i], tq2[i]);
+    for (size_t i = 0; i < B; ++i) {
+      float tq = std::min(tq1[i], tq2[i]);
+      if (c.her) tq = std::min(std::max(tq, c.clip_return_l), c.clip_return_r);
+      y[i] = c.reward_scale * r[i] + (1.0f - d[i]) * c.discount * tq;
+    }
     stats->qf1_loss = mean_sq_diff(q1, y, &e1);
     stats->qf2_loss = mean_sq_diff(q2, y, &e2);
     double s = 0;
     for (float v : qn) s += v;
     stats->policy_loss = (float)(-s / (double)B);
+    if (c.her && update) {   // her/td3.py:150-152; a step without a policy update reports -mean(Q) alone (:165-170)
+      double l2 = 0;
+      for (float v : pa) l2 += (double)v * v;
+      stats->policy_loss += (float)(l2 / (double)pa.size());
+    }
     msmm(q1.data(), B, stats->q1_pred); msmm(q2.data(), B, stats->q2_pred); msmm(y.data(), B, stats->q_target);
     msmm(e1.data(), B, stats->bellman1); msmm(e2.data(), B, stats->bellman2); msmm(pa.data(), pa.size(), stats->policy_action);
   }

@@ -65,13 +65,14 @@ class TD3(Trainer):
 
     def __init__(self, policy, qf1, qf2, reward_scale=1.0, discount=0.99, target_policy_noise=0.2,
                  target_policy_noise_clip=0.5, policy_lr=1e-3, qf_lr=1e-3, policy_and_target_update_period=2,
-                 soft_target_tau=0.005, max_batch=1024, **kwargs):
+                 soft_target_tau=0.005, max_batch=1024, her=False, clip_return_l=0.0, clip_return_r=0.0, **kwargs):
         # target_policy_noise* are accepted and, like in the reference (td3.py:46-47 store them, nothing reads them),
         # unused: the target policy is policy.copy() and adds the policy module's own noise.
         self.policy, self.qf1, self.qf2, self.ctx = policy, qf1, qf2, policy.ctx
         self.reward_scale = reward_scale
         cfg = _lib.Td3Cfg(reward_scale, discount, policy_lr, qf_lr, int(policy_and_target_update_period), soft_target_tau,
-                          policy.noise, policy.noise_clip, policy.max_act, int(max_batch))
+                          policy.noise, policy.noise_clip, policy.max_act, int(max_batch), int(bool(her)), float(clip_return_l),
+                          float(clip_return_r))   # her: rlkit/torch/algorithms/her/td3.py (ilswiss_amd/her.py:TD3)
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_td3_create(self.ctx.h, C.byref(cfg), policy.h, qf1.h, qf2.h, C.byref(self.h)))
         self.eval_statistics = None

@@ -308,6 +308,11 @@ typedef struct {
   int32_t policy_and_target_update_period;
   float soft_target_tau, policy_noise, policy_noise_clip, max_act;
   int32_t max_batch;
+  /* her != 0: rlkit/torch/algorithms/her/td3.py (goal-conditioned TD3; the caller concatenates observation | desired_goal): target
+   * action = clamp(policy_noise * N(0,1), -max_act, max_act) as that file computes it (:104-114), target value clipped to
+   * [clip_return_l, clip_return_r] (:116-122; defaults -1/(1-discount), 0 are the caller's to fill), policy loss + mean(a^2) (:148-152) */
+  int32_t her;
+  float clip_return_l, clip_return_r;
 } ilsx_td3_cfg;
 typedef struct {
   float qf1_loss, qf2_loss, policy_loss;

@@ -14,7 +14,7 @@ F32 = np.float32
 class TD3Oracle:
     def __init__(self, obs_dim, act_dim, hidden, pi, q1, q2, reward_scale=1.0, discount=0.99, policy_lr=1e-3, qf_lr=1e-3,
                  policy_and_target_update_period=2, soft_target_tau=0.005, policy_noise=0.2, policy_noise_clip=0.5,
-                 max_act=1.0):
+                 max_act=1.0, her=False, clip_return_l=None, clip_return_r=None):
         self.o, self.a, self.hidden = obs_dim, act_dim, list(hidden)
         self.pi, self.q1, self.q2 = pi.copy(), q1.copy(), q2.copy()
         self.tpi, self.tq1, self.tq2 = pi.copy(), q1.copy(), q2.copy()   # td3.py:53-55
@@ -23,6 +23,10 @@ class TD3Oracle:
         self.noise, self.noise_clip, self.max_act = policy_noise, policy_noise_clip, max_act
         self.opt_pi, self.opt_q1, self.opt_q2 = (optim.AdamState(pi.size), optim.AdamState(q1.size), optim.AdamState(q2.size))
         self.n_steps = 0
+        # rlkit/torch/algorithms/her/td3.py:79-86 (goal-conditioned TD3; inputs arrive concatenated observation | desired_goal)
+        self.her = bool(her)
+        self.clip_l = -1.0 / (1.0 - discount) if clip_return_l is None else clip_return_l
+        self.clip_r = 0.0 if clip_return_r is None else clip_return_r
 
     def policy(self, flat, s, eps=None):
         """policies.py:166-188.  eps = N(0,1) draws [B,a] or None (deterministic).  Returns (action, head pre-activation, hs)."""
@@ -45,8 +49,13 @@ class TD3Oracle:
         d = batch["terminals"].astype(F32).reshape(B, 1)
         inv = F32(1.0) / F32(B)
         out = {}
-        a2, _, _ = self.policy(self.tpi, s2, eps_target)                       # NOT re-clipped to [-1,1]
+        if self.her:   # her/td3.py:104-114: `noisy_next_actions = torch.clamp(noise, min_act, max_act)` — the clamped NOISE, as written
+            a2 = np.clip(F32(self.noise) * eps_target.astype(F32), -F32(self.max_act), F32(self.max_act)).astype(F32)
+        else:
+            a2, _, _ = self.policy(self.tpi, s2, eps_target)                   # NOT re-clipped to [-1,1]
         tq = np.minimum(self._q(self.tq1, s2, a2)[0], self._q(self.tq2, s2, a2)[0])
+        if self.her:   # her/td3.py:116-122
+            tq = np.clip(tq, F32(self.clip_l), F32(self.clip_r)).astype(F32)
         y = (r + (F32(1) - d) * F32(self.discount) * tq).astype(F32)
         q1, h1 = self._q(self.q1, s, a)
         q2, h2 = self._q(self.q2, s, a)
@@ -60,9 +69,14 @@ class TD3Oracle:
         pa, pre, hp = self.policy(self.pi, s)                                   # deterministic=True, td3.py:111
         qn, hq = self._q(self.q1, s, pa)                                        # updated qf1
         out.update(policy_loss=-np.mean(qn, dtype=F32), policy_actions=pa)
+        if self.her and self.n_steps % self.period == 0:   # her/td3.py:150-152: + mean(a^2); the statistics of a step without a policy
+            out["policy_loss"] = F32(out["policy_loss"] + np.mean(pa * pa, dtype=F32))   # update report -mean(Q) alone (:165-170)
         if self.n_steps % self.period == 0:                                     # td3.py:109-122
             _, dx = mlp.backward(self.q1, hq, [np.full((B, 1), -inv, F32)], self.o + self.a, self.hidden, 1)
-            dpre = (dx[:, self.o:] * F32(self.max_act) * (F32(1) - np.tanh(pre) ** 2)).astype(F32)
+            ga = dx[:, self.o:]
+            if self.her:
+                ga = (ga + F32(2.0) * pa / F32(pa.size)).astype(F32)
+            dpre = (ga * F32(self.max_act) * (F32(1) - np.tanh(pre) ** 2)).astype(F32)
             gp, _ = mlp.backward(self.pi, hp, [dpre], self.o, self.hidden, self.a, need_dx=False)
             optim.adam_step(self.pi, gp, self.opt_pi, self.policy_lr)
             for t, src in ((self.tpi, self.pi), (self.tq1, self.q1), (self.tq2, self.q2)):

@@ -833,7 +833,161 @@ def gen_absorbing():
     save("g19_absorbing", **out)
 
 
-GROUPS = dict(absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+def gen_her():
+    """G20-G22: the goal-conditioned trainers and the relabelling buffer of Hindsight Experience Replay.
+    g20: her/td3.py TD3.train_step, 4 chained steps (target action = clamped noise as that file computes it, target clip active on
+         some rows and not on others, policy loss with the action L2 term, delayed update at steps 0 and 2);
+    g21: her/sac.py SAC.train_step, 3 chained steps (sac_alpha with concatenated inputs, target entropy -|A|);
+    g22: relabel_replay_buffer.py HindsightReplayBuffer.random_batch, `future` and `final`, her_ratio 0.8 and 0, on scripted paths."""
+    from rlkit.torch.algorithms.her.td3 import TD3
+    from rlkit.torch.algorithms.her.sac import SAC
+    from rlkit.torch.common.networks import FlattenMlp
+    from rlkit.torch.common.policies import MlpGaussianAndEpsilonPolicy, ReparamTanhMultivariateGaussianPolicy
+    from oracle.td3 import TD3Oracle
+    from oracle.sac_alpha import SacAlphaOracle
+    # ---------------------------------------------------------------- g20
+    rng = np.random.default_rng(2020)
+    o, gd, a, Hh, B, steps = 10, 3, 4, [64, 64], 32, 4
+    kw = dict(reward_scale=1.0, discount=0.9, policy_lr=3e-4, qf_lr=3e-4, policy_and_target_update_period=2, soft_target_tau=0.005)
+    pi0 = omlp.init_mlp(rng, o + gd, Hh, a, init_w=1e-3)
+    pi0[-(Hh[-1] * a + a):] *= 300.0
+    q10, q20 = omlp.init_mlp(rng, o + gd + a, Hh, 1), omlp.init_mlp(rng, o + gd + a, Hh, 1)
+    for q in (q10, q20):                   # shift the critics so that min(TQ) straddles the clip window [-10, 0]
+        q[-1] = -5.0
+        q[-(Hh[-1] + 1):-1] *= 3000.0
+    space = type("S", (), {"shape": (a,), "sample": lambda self: np.zeros(a)})()
+    pol = MlpGaussianAndEpsilonPolicy(hidden_sizes=Hh, obs_dim=o + gd, action_dim=a, action_space=space, output_activation=torch.tanh,
+                                      max_sigma=0.3, min_sigma=0.3)
+    qf1 = FlattenMlp(hidden_sizes=Hh, input_size=o + gd + a, output_size=1)
+    qf2 = FlattenMlp(hidden_sizes=Hh, input_size=o + gd + a, output_size=1)
+    set_flat(pol, pi0), set_flat(qf1, q10), set_flat(qf2, q20)
+    tr = TD3(policy=pol, qf1=qf1, qf2=qf2, **kw)
+    orc = TD3Oracle(o + gd, a, Hh, pi0, q10, q20, policy_noise=0.3, policy_noise_clip=0.0, her=True, **kw)
+    grads = {}
+    _hook_grads(grads, tr.qf1_optimizer, "q1", qf1), _hook_grads(grads, tr.qf2_optimizer, "q2", qf2)
+    _hook_grads(grads, tr.policy_optimizer, "pi", pol)
+    rec = dict(pi0=pi0, q10=q10, q20=q20, dims=np.array([o, gd, a, B, steps] + Hh), sigma=np.float32(0.3),
+               clip=np.array([tr.clip_return_l, tr.clip_return_r], np.float32))
+    n_clipped = 0
+    for s in range(steps):
+        b = _rand_batch(rng, B, o, a)
+        b["desired_goals"] = rng.normal(0, 1, (B, gd)).astype(np.float32)
+        b["next_desired_goals"] = b["desired_goals"].copy()
+        eps = rng.normal(0, 1, (B, a)).astype(np.float32)
+        eps[0] = [4.0, -4.0, 0.1, 3.9]                 # 0.3 * 4 = 1.2 > max_act: the clamp is active
+        tr.eval_statistics = None
+        grads.pop("pi", None)
+        with H.NoiseInjector() as inj:
+            inj.push(eps)
+            tr.train_step({k: t(v) for k, v in b.items()})
+        st = tr.eval_statistics
+        cat = dict(b, observations=np.concatenate([b["observations"], b["desired_goals"]], 1),
+                   next_observations=np.concatenate([b["next_observations"], b["next_desired_goals"]], 1))
+        res = orc.train_step(cat, eps)
+        raw_tq = (res["q_target"] - b["rewards"]) / np.maximum(0.9 * (1 - b["terminals"]), 1e-9)
+        n_clipped += int(((np.abs(raw_tq - tr.clip_return_l) < 1e-6) | (np.abs(raw_tq - tr.clip_return_r) < 1e-6)).sum())
+        for k_ref, k_or in (("QF1 Loss", "qf1_loss"), ("QF2 Loss", "qf2_loss"), ("Policy Loss", "policy_loss")):
+            assert np.allclose(st[k_ref], res[k_or], rtol=2e-4, atol=1e-5), (s, k_ref, st[k_ref], res[k_or])
+        assert ("pi" in grads) == (s % 2 == 0) == ("pi_grad" in res)
+        for nm in grads:
+            err = np.abs(grads[nm] - res[nm + "_grad"]).max() / (np.abs(grads[nm]).max() + 1e-12)
+            assert err < 2e-3, (s, nm, err)
+        rec.update({f"s{s}_{k}": v for k, v in b.items()})
+        rec.update({f"s{s}_eps": eps, f"s{s}_qf1_loss": st["QF1 Loss"], f"s{s}_qf2_loss": st["QF2 Loss"],
+                    f"s{s}_policy_loss": st["Policy Loss"], f"s{s}_grad_q1": grads["q1"], f"s{s}_grad_q2": grads["q2"],
+                    f"s{s}_pi": get_flat(pol), f"s{s}_q1": get_flat(qf1), f"s{s}_q2": get_flat(qf2),
+                    f"s{s}_tpi": get_flat(tr.target_policy), f"s{s}_tq1": get_flat(tr.target_qf1), f"s{s}_q_target_mean": st["Q Targets Mean"]})
+        if "pi" in grads:
+            rec[f"s{s}_grad_pi"] = grads["pi"]
+        for k, mod in (("pi", pol), ("q1", qf1), ("q2", qf2), ("tpi", tr.target_policy), ("tq1", tr.target_qf1)):
+            assert np.abs(getattr(orc, k) - get_flat(mod)).max() < 5e-5, (s, k)
+    assert 10 < n_clipped < steps * B - 10, n_clipped          # the clip bites on some rows, not on all
+    save("g20_her_td3", **rec)
+    # ---------------------------------------------------------------- g21
+    rng = np.random.default_rng(2121)
+    o, gd, a, Hh, B, steps = 10, 3, 4, [64, 64], 16, 3
+    kws = dict(reward_scale=1.0, discount=0.99, policy_lr=3e-4, qf_lr=3e-4, alpha_lr=3e-4, soft_target_tau=0.005, alpha=0.2,
+               train_alpha=True, policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3, beta_1=0.9)
+    pi0 = omlp.init_mlp(rng, o + gd, Hh, a, init_w=1e-3, n_heads=2)
+    q10, q20 = omlp.init_mlp(rng, o + gd + a, Hh, 1), omlp.init_mlp(rng, o + gd + a, Hh, 1)
+    pol = ReparamTanhMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o + gd, action_dim=a)
+    qf1 = FlattenMlp(hidden_sizes=Hh, input_size=o + gd + a, output_size=1)
+    qf2 = FlattenMlp(hidden_sizes=Hh, input_size=o + gd + a, output_size=1)
+    set_flat(pol, pi0), set_flat(qf1, q10), set_flat(qf2, q20)
+    tr = SAC(policy=pol, qf1=qf1, qf2=qf2, env=_Env(a), **kws)
+    assert tr.target_entropy == -a
+    orc = SacAlphaOracle(o + gd, a, Hh, pi0, q10, q20, target_entropy=-float(a), **kws)
+    rec = dict(pi0=pi0, q10=q10, q20=q20, dims=np.array([o, gd, a, B, steps] + Hh))
+    for s in range(steps):
+        b = _rand_batch(rng, B, o, a)
+        b["desired_goals"] = rng.normal(0, 1, (B, gd)).astype(np.float32)
+        b["next_desired_goals"] = b["desired_goals"].copy()
+        e1, e2 = rng.normal(0, 1, (B, a)).astype(np.float32), rng.normal(0, 1, (B, a)).astype(np.float32)
+        tr.eval_statistics = None
+        with H.NoiseInjector() as inj:
+            inj.push(e1), inj.push(e2)
+            tr.train_step({k: t(v) for k, v in b.items()})
+        st = tr.eval_statistics
+        cat = dict(b, observations=np.concatenate([b["observations"], b["desired_goals"]], 1),
+                   next_observations=np.concatenate([b["next_observations"], b["next_desired_goals"]], 1))
+        res = orc.train_step(cat, e1, e2)
+        for k_ref, k_or in (("QF1 Loss", "qf1_loss"), ("Policy Loss", "policy_loss"), ("Alpha Loss", "alpha_loss")):
+            assert np.allclose(st[k_ref], res[k_or], rtol=2e-4, atol=1e-6), (s, k_ref, st[k_ref], res[k_or])
+        rec.update({f"s{s}_{k}": v for k, v in b.items()})
+        rec.update({f"s{s}_eps_next": e1, f"s{s}_eps_cur": e2, f"s{s}_qf1_loss": st["QF1 Loss"], f"s{s}_policy_loss": st["Policy Loss"],
+                    f"s{s}_alpha_loss": st["Alpha Loss"], f"s{s}_log_alpha": float(tr.log_alpha.detach()),
+                    f"s{s}_pi": get_flat(pol), f"s{s}_q1": get_flat(qf1), f"s{s}_tq1": get_flat(tr.target_qf1)})
+        for k, mod in (("pi", pol), ("q1", qf1), ("q2", qf2), ("tq1", tr.target_qf1)):
+            assert np.abs(getattr(orc, k) - get_flat(mod)).max() < 5e-5, (s, k)
+    save("g21_her_sac", **rec)
+    # ---------------------------------------------------------------- g22
+    import types
+    if "rlkit.envs" not in sys.modules:        # rlkit/envs/__init__.py imports envpool / gym envs that are absent here; the buffer needs
+        pkg = types.ModuleType("rlkit.envs")   # only goal_env_utils' two default callables, which the env below overrides
+        pkg.__path__ = []
+        sys.modules["rlkit.envs"] = pkg
+        geu = types.ModuleType("rlkit.envs.goal_env_utils")
+        geu.compute_reward = geu.compute_distance = None
+        sys.modules["rlkit.envs.goal_env_utils"] = geu
+    from rlkit.data_management.relabel_replay_buffer import HindsightReplayBuffer
+    Box = sys.modules["gym.spaces"].Box
+    o, gd, a, cap = 5, 2, 3, 40
+
+    class DSpace(sys.modules["gym.spaces"].Dict):
+        def __init__(self):
+            self.spaces = dict(observation=Box(-np.ones(o), np.ones(o)), desired_goal=Box(-np.ones(gd), np.ones(gd)),
+                               achieved_goal=Box(-np.ones(gd), np.ones(gd)))
+
+    def compute_reward(ag, dg, info=None):
+        return -(np.linalg.norm(ag - dg, axis=-1) > 0.5).astype(np.float32)
+    env = type("E", (), dict(observation_space=DSpace(), action_space=Box(-np.ones(a), np.ones(a)), compute_reward=staticmethod(compute_reward)))()
+    rng = np.random.default_rng(2222)
+    rec = dict(dims=np.array([o, gd, a, cap]))
+    paths = []
+    for L in (7, 5, 9, 6, 8, 10):          # 45 samples into a 40-slot ring: the first trajectory is overwritten
+        obs = [dict(observation=rng.normal(0, 1, o), desired_goal=rng.normal(0, 1, gd), achieved_goal=rng.normal(0, 1, gd)) for _ in range(L + 1)]
+        for ob in obs[1:]:
+            ob["desired_goal"] = obs[0]["desired_goal"]
+        paths.append(dict(obs=obs, act=rng.uniform(-1, 1, (L, a)), rew=rng.normal(0, 1, L), term=[False] * (L - 1) + [L % 2 == 0]))
+    for ci, (rtype, ratio) in enumerate((("future", 0.8), ("final", 0.8), ("future", 0.0))):
+        ref = HindsightReplayBuffer(cap, env, random_seed=77, relabel_type=rtype, her_ratio=ratio)
+        for pth in paths:
+            for i in range(len(pth["act"])):
+                ref.add_sample(pth["obs"][i], pth["act"][i], pth["rew"][i], pth["term"][i], pth["obs"][i + 1])
+            ref.terminate_episode()
+        np.random.seed(500 + ci)           # `future` draws its index from the GLOBAL numpy stream (relabel_replay_buffer.py:88)
+        bt = ref.random_batch(12)
+        rec.update({f"c{ci}_{k}": np.asarray(v) for k, v in bt.items()})
+        rec[f"c{ci}_endpoints"] = np.array(sorted(ref._traj_endpoints.items()))
+    for pi_, pth in enumerate(paths):
+        rec[f"p{pi_}_obs"] = np.array([x["observation"] for x in pth["obs"]])
+        rec[f"p{pi_}_dg"] = np.array([x["desired_goal"] for x in pth["obs"]])
+        rec[f"p{pi_}_ag"] = np.array([x["achieved_goal"] for x in pth["obs"]])
+        rec[f"p{pi_}_act"], rec[f"p{pi_}_rew"], rec[f"p{pi_}_term"] = pth["act"], pth["rew"], np.array(pth["term"])
+    save("g22_her_buffer", **rec)
+
+
+GROUPS = dict(her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
 
 if __name__ == "__main__":
