@@ -805,10 +805,12 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   }
   // GRP: descriptor records in device memory, copied by value at entry (before any store) so that their fields are
   // loaded once with scalar loads; a reference would be re-read with vector loads after every store
+  // !GRP: the record stays where it is, in the kernel-argument segment (constant address space): a field is a scalar load at its
+  // use and, when registers run short, is loaded again instead of being parked in a VGPR lane.  Copying the record by value here
+  // made ~100 scalars live at once: 196 v_writelane + 369 v_readlane in this kernel (a quarter of a wave's issue slots in the prologue).
   FwdTaskG Rg;
   if (GRP) Rg = A.tasks[blockIdx.y];
-  else Rg.t = A.t[blockIdx.y];
-  const FwdTask& T = Rg.t;
+  const FwdTask& T = GRP ? Rg.t : A.t[blockIdx.y];
   const FwdGroup* GP = GRP ? &Rg.g : nullptr;
   const DevScalars* scal = GRP ? GP->scal : A.scal;
   const NetView& N = T.net;
@@ -1097,8 +1099,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BwdTask Tg;
   if (GRP) Tg = A.tasks[blockIdx.y];   // by value at entry (see k_mlp2_fwd_split)
-  else Tg = A.t[blockIdx.y];
-  const BwdTask& T = Tg;
+  const BwdTask& T = GRP ? Tg : A.t[blockIdx.y];   // !GRP: read in place from the kernel-argument segment
   const NetView& N = T.net;
   const int NO = N.NO;
   float* d1 = smem;                      // [16][LDH]  delta_1, all H columns
