@@ -310,6 +310,10 @@ static int kernels_init_once() {
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+#define SET_PH(AA, GG) HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, GG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, GG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
+  SET_PH(ACT_RELU, false); SET_PH(ACT_RELU, true); SET_PH(ACT_TANH, false); SET_PH(ACT_TANH, true);
+#undef SET_PH
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -371,7 +375,16 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
     // consume their activations 2.9 us each.)  Padding workgroups exit at once.
     dim3 grid(((((tiles + A.rt - 1) / A.rt) + 7) & ~7) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (A.tail_mode) { if (!A.tail || A.tail_n < 1 || A.tail_n > (int)(grid.x * grid.z)) ILSX_FAIL(ILSX_ERR_ARG, "deferred tail: bad record table"); grid.y += 1; }
-    if (H == 256 && cs == 4) {
+    if (H == 256 && cs == 4 && A.l0_split) {   // wide inputs: layer 0 (column-split) in its own launch, then layer 1 + heads from hsave[0]
+      FwdArgs A2 = A;
+      A2.tail_mode = 0; A2.tail = nullptr; A2.tail_n = 0; A2.dbg = ctx->dbg_next();
+      dim3 grid2(grid.x, A.ntasks, cs);
+#define L0_CALL(AA, GG) do { ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, AA, 4, GG, 1>), grid, block, lds, ctx->stream, A); \
+                             ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, AA, 4, GG, 2>), grid2, block, lds, ctx->stream, A2); } while (0)
+      if (act == ILSX_ACT_RELU) { if (A.tasks) L0_CALL(ACT_RELU, true); else L0_CALL(ACT_RELU, false); }
+      else { if (A.tasks) L0_CALL(ACT_TANH, true); else L0_CALL(ACT_TANH, false); }
+#undef L0_CALL
+    } else if (H == 256 && cs == 4) {
       if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
       else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
     } else if (H == 128 && cs == 2) {

@@ -64,6 +64,7 @@ struct ilsx_sac {
   ilsx_replay* gather_rb = nullptr;  // train_from_replay: the first forward launch draws its rows from this ring
   bool fuse_now = false;     // this step applies Adam(+Polyak) inside the dW epilogue (not in split-run phases)
   int cs = 1;                // column-split factor of the 2-hidden-layer fast path (1 = generic kernels)
+  float* h0scr = nullptr;    // non-null: two-phase forward for wide inputs (layer 0 in its own launch); [4 tasks][max_batch][H] scratch
   int B = 0;                 // rows of the batch currently staged
   bool eps_explicit = false;
   float target_entropy = 0.f;
@@ -232,6 +233,11 @@ static void sac_plan_ws(ilsx_sac* s, Slab& L) {
   A(&w.xp, B * s->Lp.KP);
   for (int l = 0; l < s->Lp.cfg.n_hidden; ++l) { A(&w.hp[l], B * H); A(&w.dp[l], B * H); }
   A(&w.dhp, B * 2 * a);
+  // wide inputs (Humanoid: KP = 396 against 16 for the planar tasks): every column slice recomputing layer 0 costs 6x its own layer-1
+  // work, so the forward becomes two launches (kernels.h, k_mlp2_fwd_split PH 1 / 2).  ILSX_L0_SPLIT_KP moves the threshold.
+  const char* e = getenv("ILSX_L0_SPLIT_KP");
+  const int thr = e ? atoi(e) : 65;   // KP is a multiple of 16: the planar tasks (KP 16 / 32) keep the one-launch form, Ant (128) and Humanoid (396) do not
+  if (s->cs == 4 && H == 256 && std::max(s->Lq.KP, s->Lp.KP) >= thr) A(&s->h0scr, 4 * B * H);
 }
 
 extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net* pi, ilsx_net* q1, ilsx_net* q2,
@@ -369,7 +375,13 @@ static void sac_q_task(ilsx_sac* s, FwdTask& q, int which, const float* obs, con
   if (s->cs > 1) q.part = out; else q.out = out;
 }
 
-static int sac_fwd(ilsx_sac* s, const FwdArgs& A, int H, int act, int KP, int cs) {
+static int sac_fwd(ilsx_sac* s, const FwdArgs& A0, int H, int act, int KP, int cs) {
+  FwdArgs A = A0;
+  if (s->h0scr) {   // wide inputs: two-phase forward (k_mlp2_fwd_split PH 1 / 2); tasks that do not save layer 0 get scratch for it
+    A.l0_split = 1;
+    for (int t = 0; t < A.ntasks; ++t)
+      if (!A.t[t].hsave[0]) A.t[t].hsave[0] = s->h0scr + (size_t)t * s->cfg.max_batch * H;
+  }
   if (!s->col) return launch_fwd(s->ctx, A, H, act, KP, cs);
   SacLaunch l; memset(&l, 0, sizeof l); l.kind = 0; l.f = A; l.KP = KP;
   s->col->L.push_back(l);

@@ -300,6 +300,7 @@ struct FwdArgs {
   int rt;                  // column-split kernels: consecutive 16-row tiles per workgroup (0 = 1); grid.x = ceil(tiles / rt)
   const struct TailLite* tail;   // column-split kernels, tail_mode != 0: the launch carries one extra y row whose first
   int tail_mode, tail_n;         //   workgroups (one per agent, tail_n of them) run the deferred tail (1) or advance gather_step (2)
+  int l0_split;                  // wide inputs: layer 0 in a launch of its own, column-split like layer 1 (every task then has hsave[0])
 };
 struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
 // one self-contained record per grid row: the task and its agent's per-launch state side by side, so a workgroup reaches
@@ -788,9 +789,14 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
 // prologue (PartVal) or by k_policy_finish; backward input-gradients leave as CS partial slabs likewise.
 // block = 4*H/CS threads; wave w owns column tile(s) [w*CS, (w+1)*CS) of layer 0 and tile cs*NWV+w of layer 1.
 #ifdef ILSX_KERNEL_IMPL
-template <int H, int ACT, int CS, bool GRP>
+// PH: 0 = the whole forward in one launch, every slice recomputing layer 0 (K = KP is tiny for the planar tasks); for wide inputs
+// (Humanoid: KP = 396) that recomputation is 6x the slice's own layer-1 work, so the forward runs as two launches of the same grid:
+// PH = 1 stages x (gather / policy epilogue as in PH 0) and computes THIS slice's 64 columns of layer 0 into hsave[0];
+// PH = 2 starts from hsave[0] (16 KB per tile, L2-resident) and does layer 1 + heads.
+template <int H, int ACT, int CS, bool GRP, int PH = 0>
 __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) {
   constexpr int NTH = 4 * H / CS, NWV = NTH / 64, NC = H / 16, SLW = H / CS, NCS = SLW / 16;
+  constexpr int NT0 = PH == 1 ? 1 : CS;   // layer-0 column tiles per wave
   constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
   static_assert(NCS == NWV, "one k16 chunk of the slice per wave in the head phase");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -828,29 +834,38 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   ILSX_STAMP(A.dbg, 0);
 
   // ---- every small global operand is requested up front, in the order it is needed
-  const float* w0p = N.base + N.off_W[0] + (size_t)(wave * CS) * NCH0 * 256 + 4 * lane;
-  float4 b0[CS];
+  const int ct0 = PH == 1 ? cs * NWV + wave : wave * CS;   // this wave's first layer-0 column tile
+  const float* w0p = N.base + N.off_W[0] + (size_t)ct0 * NCH0 * 256 + 4 * lane;
+  constexpr int L0D = 8;   // PH 1: k16 chunks of layer-0 weights requested ahead of the MFMAs that consume them
+  float4 b0[NT0], b0first[NT0];
+  float4 l0first[PH == 1 ? L0D : 1];
+  float bias0[NT0];
+  if constexpr (PH == 1) {
 #pragma unroll
-  for (int i = 0; i < CS; ++i) b0[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256);
-  float4 b0first[CS];
-#pragma unroll
-  for (int i = 0; i < CS; ++i) b0first[i] = b0[i];
-  float bias0[CS];
-#pragma unroll
-  for (int i = 0; i < CS; ++i) bias0[i] = (N.base + N.off_b[0])[(wave * CS + i) * 16 + li];
-  const int lc = wave * 16 + li, col1 = cs * SLW + lc;
-  const float bias1 = (N.base + N.off_b[1])[col1];
-  // head weights of this slice as MFMA B fragments: wave w owns k16 chunk w of the slice, rows j = 16t + li
-  float4 whf[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int j = 16 * t + li;
-    whf[t] = (t < NOT && j < NO) ? *reinterpret_cast<const float4*>(N.base + N.off_Wh + (size_t)j * H + cs * SLW + 16 * wave + 4 * g)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int d = 0; d < L0D; ++d) l0first[d] = *reinterpret_cast<const float4*>(w0p + (size_t)(d < NCH0 ? d : 0) * 256);
   }
-  // ---- this wave's slice of layer 1 (16 columns x H): one coalesced burst, held for every row tile
+  if constexpr (PH != 2) {
+#pragma unroll
+    for (int i = 0; i < NT0; ++i) b0[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256);
+#pragma unroll
+    for (int i = 0; i < NT0; ++i) b0first[i] = b0[i];
+#pragma unroll
+    for (int i = 0; i < NT0; ++i) bias0[i] = (N.base + N.off_b[0])[(ct0 + i) * 16 + li];
+  }
+  const int lc = wave * 16 + li, col1 = cs * SLW + lc;
+  float bias1 = 0.0f;
+  float4 whf[4];
   float4 wreg[NC];
-  {
+  if constexpr (PH != 1) {
+    bias1 = (N.base + N.off_b[1])[col1];
+    // head weights of this slice as MFMA B fragments: wave w owns k16 chunk w of the slice, rows j = 16t + li
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = 16 * t + li;
+      whf[t] = (t < NOT && j < NO) ? *reinterpret_cast<const float4*>(N.base + N.off_Wh + (size_t)j * H + cs * SLW + 16 * wave + 4 * g)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- this wave's slice of layer 1 (16 columns x H): one coalesced burst, held for every row tile
     const float* wp = N.base + N.off_W[1] + (size_t)(cs * NWV + wave) * NC * 256 + 4 * lane;
 #pragma unroll
     for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
@@ -860,17 +875,17 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   for (int rt = 0; rt < RT; ++rt) {
   const int r0 = ((blockIdx.x >> A.xs) * RT + rt) * 16;
   if (r0 >= rows) break;   // workgroup-uniform
+  bool fin_logp = false;
+  if constexpr (PH != 2) {
 #pragma unroll
-  for (int i = 0; i < CS; ++i) b0[i] = b0first[i];
-  for (int e = tid; e < 16 * KP; e += NTH) {
-    const int r = e / KP, k = e - r * KP, gr = r0 + r;
+  for (int i = 0; i < NT0; ++i) b0[i] = b0first[i];
+  // one element of the staged input tile; rec = the replay record of row gr (fused sample+index, simple_replay_buffer.py:239-293)
+  auto stage = [&](int r, int k, int gr, const float* rec) {
     const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
-    if (fin && act_col) continue;   // filled by the policy epilogue below
+    if (fin && act_col) return;   // filled by the policy epilogue below
     float v = 0.0f;
     if (gr < rows) {
-      if (G.on) {   // fused sample+index (simple_replay_buffer.py:239-293): row gr of the batch is record idx
-        const long long idx = replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)gr, G.st->size);
-        const float* rec = G.records + (size_t)idx * G.rec;
+      if (G.on) {
         if (k < T.d0) v = rec[T.g0_off + k];
         else if (act_col) v = rec[T.g1_off + (k - T.d0)];
         if (lead && T.publish == 1) {
@@ -887,8 +902,75 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
       if (T.xsave && lead) T.xsave[(size_t)gr * KP + k] = v;
     }
     xs[r * LDX + k] = v;
+  };
+  if constexpr (PH == 0) {   // narrow inputs (the one-launch form): one element per thread, the row's index drawn where it is used
+    for (int e = tid; e < 16 * KP; e += NTH) {
+      const int r = e / KP, k = e - r * KP, gr = r0 + r;
+      const float* rec = nullptr;
+      if (G.on && gr < rows) rec = G.records + (size_t)replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)gr, G.st->size) * G.rec;
+      stage(r, k, gr, rec);
+    }
+  } else {          // PH 1, wide inputs (Humanoid: 25 elements per thread): the index is drawn ONCE per row — the form above spent a Philox
+                    // block and a division per element, 21 us per launch — and a wave walks whole rows in coalesced 64-float runs
+    long long* ridx = reinterpret_cast<long long*>(hs);   // hs is not live before layer 1
+    if (G.on) {
+      if (tid < 16) ridx[tid] = r0 + tid < rows ? replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)(r0 + tid), G.st->size) : 0;
+      lds_barrier();
+    }
+    if (KP <= 512 && T.d1 <= 64) {
+      // a row is [obs segment | action segment | zero padding]: the segments are copied with clamped, unconditional loads — every load of
+      // the wave's four rows is in flight before the first store (a loop around load + store waits per trip: 28 serial HBM round trips
+      // per wave for a 396-wide row; per-element source selection compiled to ~90 branchy instructions per element)
+      constexpr int RW = 16 / NWV, U = 8;
+      float vo[RW][U], va[RW];
+      const bool acts = T.d1 > 0 && !fin;
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        const int r = wave + NWV * rr, grc = r0 + r < rows ? r0 + r : rows - 1;
+        const float* rec = G.on ? G.records + (size_t)ridx[r] * G.rec : nullptr;
+        const float* s0p = G.on ? rec + T.g0_off : T.x0 + (size_t)grc * T.s0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int k = lane + 64 * u; vo[rr][u] = s0p[k < T.d0 ? k : T.d0 - 1]; }
+        va[rr] = 0.0f;
+        if (acts) { const float* s1p = G.on ? rec + T.g1_off : T.x1 + (size_t)grc * T.s1; va[rr] = s1p[lane < T.d1 ? lane : T.d1 - 1]; }
+      }
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        const int r = wave + NWV * rr, gr = r0 + r;
+        const bool rowok = gr < rows;
+        const bool pub1 = G.on && lead && T.publish == 1 && rowok, pub2 = G.on && lead && T.publish == 2 && rowok, xsv = T.xsave && lead && rowok;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = lane + 64 * u;
+          if (k < T.d0) {
+            const float x = rowok ? vo[rr][u] : 0.0f;
+            if (pub1) G.s[(size_t)gr * G.o + k] = x;
+            if (pub2) G.s2[(size_t)gr * G.o + k] = x;
+            if (xsv) T.xsave[(size_t)gr * KP + k] = x;
+            xs[r * LDX + k] = x;
+          }
+        }
+        if (acts && lane < T.d1) {
+          const float x = rowok ? va[rr] : 0.0f;
+          if (pub1) G.a[(size_t)gr * G.adim + lane] = x;
+          if (xsv) T.xsave[(size_t)gr * KP + T.d0 + lane] = x;
+          xs[r * LDX + T.d0 + lane] = x;
+        }
+        if (pub1 && lane == 0) { const float* rec = G.records + (size_t)ridx[r] * G.rec; G.r[gr] = rec[G.o + G.adim]; G.d[gr] = rec[G.o + G.adim + 1]; }
+        for (int k = T.d0 + T.d1 + lane; k < KP; k += 64) {   // zero padding up to the k16 multiple
+          if (xsv) T.xsave[(size_t)gr * KP + k] = 0.0f;
+          xs[r * LDX + k] = 0.0f;
+        }
+        if (T.d1 > 0 && !acts) { /* action columns: the policy epilogue below fills them */ }
+      }
+    } else {
+      for (int r = wave; r < 16; r += NWV) {
+        const int gr = r0 + r;
+        const float* rec = G.on ? G.records + (size_t)ridx[r] * G.rec : nullptr;
+        for (int k = lane; k < KP; k += 64) stage(r, k, gr, rec);
+      }
+    }
   }
-  bool fin_logp = false;
   if (fin) {
     // the action columns are pi's output: combine its CS head partials, squash (policies.py:262-283,
     // distributions.py:23-28,43-50,74-97); slice 0 of task 0 publishes action / logp / raw / eps for later kernels
@@ -949,6 +1031,15 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     }
     fin_logp = pub && P.logp && !det;
   }
+  }  // PH != 2
+  else {   // PH == 2: layer-0 activations of the tile, as the layer-0 launch left them
+    const float* hsrc = T.hsave[0];
+    for (int e = tid; e < 16 * (H / 4); e += NTH) {
+      const int row = e / (H / 4), c4 = e - row * (H / 4), gr = r0 + row;
+      const float4 v = gr < rows ? *reinterpret_cast<const float4*>(hsrc + (size_t)gr * H + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(h0 + row * LDH + 4 * c4) = v;
+    }
+  }
   lds_barrier();
   ILSX_STAMP(A.dbg, 1);
   if (fin_logp && tid < 16 && r0 + tid < rows) {   // log pi of the tile's rows from the staged contributions: after the tile's ONE
@@ -957,45 +1048,81 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     for (int j = 0; j < P.a; ++j) { q += red[(tid * 32 + j) * 3]; l += red[(tid * 32 + j) * 3 + 1]; jc += red[(tid * 32 + j) * 3 + 2]; }
     P.logp[r0 + tid] = -0.5f * q - (l + HALF_LOG_2PI) - jc;
   }
-  // ---- layer 0, full width: CS column tiles per wave
-  {
-    f32x4 acc[CS];
+  // ---- layer 0: CS column tiles per wave, full width (PH 0) ; this slice's own tile (PH 1)
+  if constexpr (PH == 1) {
+    // a wide layer 0 is a long K loop (25 k16 chunks for Humanoid): with the next chunk requested one step ahead every trip waited
+    // for an L2 round trip (24 us per launch); here L0D chunks are in flight while the previous L0D are consumed
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* ap = xs + li * LDX + 4 * g;
+    float4 cur[L0D], nxt[L0D];
 #pragma unroll
-    for (int i = 0; i < CS; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < L0D; ++d) cur[d] = l0first[d];
+    for (int cb = 0; cb < NCH0; cb += L0D) {
+#pragma unroll
+      for (int d = 0; d < L0D; ++d) {
+        const int c = cb + L0D + d;
+        nxt[d] = *reinterpret_cast<const float4*>(w0p + (size_t)(c < NCH0 ? c : 0) * 256);
+      }
+#pragma unroll
+      for (int d = 0; d < L0D; ++d) {
+        if (cb + d < NCH0) {   // uniform
+          const float4 a = *reinterpret_cast<const float4*>(ap + 16 * (cb + d));
+          acc = MFMA16(a.x, cur[d].x, acc); acc = MFMA16(a.y, cur[d].y, acc);
+          acc = MFMA16(a.z, cur[d].z, acc); acc = MFMA16(a.w, cur[d].w, acc);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < L0D; ++d) cur[d] = nxt[d];
+    }
+    float* hsv = T.hsave[0];
+    const int col = ct0 * 16 + li;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int row = 4 * g + v;
+      if (r0 + row < rows) hsv[(size_t)(r0 + row) * H + col] = act_fn<ACT>(acc[v] + bias0[0]);
+    }
+  } else if constexpr (PH != 2) {
+    f32x4 acc[NT0];
+#pragma unroll
+    for (int i = 0; i < NT0; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* ap = xs + li * LDX + 4 * g;
     for (int kc = 0; kc < KP; kc += 16) {
-      float4 bn[CS];
+      float4 bn[NT0];
 #pragma unroll
-      for (int i = 0; i < CS; ++i) {
+      for (int i = 0; i < NT0; ++i) {
         bn[i] = b0[i];
         if (kc + 16 < KP) bn[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256 + (kc + 16) * 16);
       }
       const float4 a = *reinterpret_cast<const float4*>(ap + kc);
 #pragma unroll
-      for (int i = 0; i < CS; ++i) acc[i] = MFMA16(a.x, b0[i].x, acc[i]);
+      for (int i = 0; i < NT0; ++i) acc[i] = MFMA16(a.x, b0[i].x, acc[i]);
 #pragma unroll
-      for (int i = 0; i < CS; ++i) acc[i] = MFMA16(a.y, b0[i].y, acc[i]);
+      for (int i = 0; i < NT0; ++i) acc[i] = MFMA16(a.y, b0[i].y, acc[i]);
 #pragma unroll
-      for (int i = 0; i < CS; ++i) acc[i] = MFMA16(a.z, b0[i].z, acc[i]);
+      for (int i = 0; i < NT0; ++i) acc[i] = MFMA16(a.z, b0[i].z, acc[i]);
 #pragma unroll
-      for (int i = 0; i < CS; ++i) acc[i] = MFMA16(a.w, b0[i].w, acc[i]);
+      for (int i = 0; i < NT0; ++i) acc[i] = MFMA16(a.w, b0[i].w, acc[i]);
 #pragma unroll
-      for (int i = 0; i < CS; ++i) b0[i] = bn[i];
+      for (int i = 0; i < NT0; ++i) b0[i] = bn[i];
     }
-    float* hsv = lead ? T.hsave[0] : nullptr;
+    float* hsv = (PH == 1 || lead) ? T.hsave[0] : nullptr;
 #pragma unroll
-    for (int i = 0; i < CS; ++i) {
-      const int col = (wave * CS + i) * 16 + li;
+    for (int i = 0; i < NT0; ++i) {
+      const int col = (ct0 + i) * 16 + li;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = 4 * g + v;
         const float h = act_fn<ACT>(acc[i][v] + bias0[i]);
-        h0[row * LDH + col] = h;
+        if constexpr (PH == 0) h0[row * LDH + col] = h;
         if (hsv && r0 + row < rows) hsv[(size_t)(r0 + row) * H + col] = h;
       }
     }
   }
-  lds_barrier();
+  if constexpr (PH == 1) {
+    lds_barrier();   // the next row tile restages xs
+    continue;
+  }
+  if constexpr (PH == 0) lds_barrier();
   ILSX_STAMP(A.dbg, 2);
   // ---- layer 1, this slice: straight out of registers
   {
