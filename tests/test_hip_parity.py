@@ -502,12 +502,13 @@ def test_train_from_replay_graph_equals_direct_and_learns(ctx, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx):
+@pytest.mark.parametrize("o,a", [(11, 3), (111, 8)])   # narrow: one-launch forward ; Ant widths: the two-phase forward (kernels.h PH 1 / 2)
+def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx, o, a):
     """K=3 co-resident seeds stepped by ONE launch per stage (ilsx_sac_group) == each agent stepped alone with
     ilsx_sac_train_from_replay: same kernels, same per-agent Philox streams, so every parameter is bit-identical."""
     import ilswiss_amd as ia
     from ilswiss_amd.replay import SimpleReplayBuffer
-    o, a, hid, B, K, n = 11, 3, [256, 256], 256, 3, 7
+    hid, B, K, n = [256, 256], 256, 3, 7
     rng = np.random.default_rng(5)
     N = 5000
     data = [(rng.normal(0, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),
