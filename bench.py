@@ -408,9 +408,7 @@ def main():
     R.barrier(ctx)
     dt = time.perf_counter() - t0
     dt, t_sample, t_train = R.max_over_ranks([dt, t_sample, t_train])
-    split = None
-    if (world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST")) and not args.no_split_run:
-        split = split_run_leg(R)
+    want_split = (world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST")) and not args.no_split_run
 
     result = None
     if rank == 0:
@@ -483,13 +481,33 @@ def main():
                         parallelism=f"{world} independent replicas (seed sharding, no collective)"),
             env_steps_per_s=env_total / dt, env_steps_per_s_sample_phase=env_total / t_sample,
             grad_steps_per_s_train_phase=grad_total / t_train, roofline=roofline, roofline_replay=roofline_replay)
-        if split is not None:
-            result["split_run"] = split
         if world == 1 and not args.no_seeds:
             result["co_resident_seeds"] = co_resident_seeds()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(result))
+    if want_split:
+        # the split-run leg comes LAST and under a watchdog: it is the one part of this file that needs a working multi-rank RCCL
+        # communicator, and the headline line must come out whatever happens to it (error -> recorded; no progress in 180 s -> rank 0
+        # prints the line with the reason, every rank exits)
+        import threading
+        done = threading.Event()
+
+        def dog():
+            if not done.wait(180.0):
+                if rank == 0:
+                    result["split_run"] = dict(error="split-run leg made no progress in 180 s (RCCL communicator?)")
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+        threading.Thread(target=dog, daemon=True).start()
+        try:
+            split = split_run_leg(R)
+        except Exception as e:   # noqa: BLE001
+            split = dict(error=repr(e)[:300])
+        done.set()
+        if rank == 0 and split is not None:
+            result["split_run"] = split
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     R.close()
     ctx.close()
     return result
