@@ -879,39 +879,59 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   if constexpr (PH != 2) {
 #pragma unroll
   for (int i = 0; i < NT0; ++i) b0[i] = b0first[i];
-  // one element of the staged input tile; rec = the replay record of row gr (fused sample+index, simple_replay_buffer.py:239-293)
-  auto stage = [&](int r, int k, int gr, const float* rec) {
-    const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
-    if (fin && act_col) return;   // filled by the policy epilogue below
-    float v = 0.0f;
-    if (gr < rows) {
-      if (G.on) {
-        if (k < T.d0) v = rec[T.g0_off + k];
-        else if (act_col) v = rec[T.g1_off + (k - T.d0)];
-        if (lead && T.publish == 1) {
-          if (k < T.d0) G.s[(size_t)gr * G.o + k] = v;
-          else if (act_col) G.a[(size_t)gr * G.adim + (k - T.d0)] = v;
-          if (k == 0) { G.r[gr] = rec[G.o + G.adim]; G.d[gr] = rec[G.o + G.adim + 1]; }
-        } else if (lead && T.publish == 2 && k < T.d0) {
-          G.s2[(size_t)gr * G.o + k] = v;
-        }
-      } else {
-        if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
-        else if (act_col) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
-      }
-      if (T.xsave && lead) T.xsave[(size_t)gr * KP + k] = v;
-    }
-    xs[r * LDX + k] = v;
-  };
   if constexpr (PH == 0) {   // narrow inputs (the one-launch form): one element per thread, the row's index drawn where it is used
     for (int e = tid; e < 16 * KP; e += NTH) {
       const int r = e / KP, k = e - r * KP, gr = r0 + r;
-      const float* rec = nullptr;
-      if (G.on && gr < rows) rec = G.records + (size_t)replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)gr, G.st->size) * G.rec;
-      stage(r, k, gr, rec);
+      const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
+      if (fin && act_col) continue;   // filled by the policy epilogue below
+      float v = 0.0f;
+      if (gr < rows) {
+        if (G.on) {   // fused sample+index (simple_replay_buffer.py:239-293): row gr of the batch is record idx
+          const long long idx = replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)gr, G.st->size);
+          const float* rec = G.records + (size_t)idx * G.rec;
+          if (k < T.d0) v = rec[T.g0_off + k];
+          else if (act_col) v = rec[T.g1_off + (k - T.d0)];
+          if (lead && T.publish == 1) {
+            if (k < T.d0) G.s[(size_t)gr * G.o + k] = v;
+            else if (act_col) G.a[(size_t)gr * G.adim + (k - T.d0)] = v;
+            if (k == 0) { G.r[gr] = rec[G.o + G.adim]; G.d[gr] = rec[G.o + G.adim + 1]; }
+          } else if (lead && T.publish == 2 && k < T.d0) {
+            G.s2[(size_t)gr * G.o + k] = v;
+          }
+        } else {
+          if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
+          else if (act_col) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
+        }
+        if (T.xsave && lead) T.xsave[(size_t)gr * KP + k] = v;
+      }
+      xs[r * LDX + k] = v;
     }
   } else {          // PH 1, wide inputs (Humanoid: 25 elements per thread): the index is drawn ONCE per row — the form above spent a Philox
                     // block and a division per element, 21 us per launch — and a wave walks whole rows in coalesced 64-float runs
+    // one element of the staged input tile; rec = the replay record of row gr (fused sample+index, simple_replay_buffer.py:239-293)
+    auto stage = [&](int r, int k, int gr, const float* rec) {
+      const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
+      if (fin && act_col) return;   // filled by the policy epilogue below
+      float v = 0.0f;
+      if (gr < rows) {
+        if (G.on) {
+          if (k < T.d0) v = rec[T.g0_off + k];
+          else if (act_col) v = rec[T.g1_off + (k - T.d0)];
+          if (lead && T.publish == 1) {
+            if (k < T.d0) G.s[(size_t)gr * G.o + k] = v;
+            else if (act_col) G.a[(size_t)gr * G.adim + (k - T.d0)] = v;
+            if (k == 0) { G.r[gr] = rec[G.o + G.adim]; G.d[gr] = rec[G.o + G.adim + 1]; }
+          } else if (lead && T.publish == 2 && k < T.d0) {
+            G.s2[(size_t)gr * G.o + k] = v;
+          }
+        } else {
+          if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
+          else if (act_col) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
+        }
+        if (T.xsave && lead) T.xsave[(size_t)gr * KP + k] = v;
+      }
+      xs[r * LDX + k] = v;
+    };
     long long* ridx = reinterpret_cast<long long*>(hs);   // hs is not live before layer 1
     if (G.on) {
       if (tid < 16) ridx[tid] = r0 + tid < rows ? replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)(r0 + tid), G.st->size) : 0;
