@@ -113,10 +113,12 @@ def test_hip_her_sac_golden(ctx):
 
 
 @pytest.mark.gpu
-def test_her_loop_learns_to_reach_on_the_stand_in_env(ctx):
-    """her.HER end to end (exploration policy -> HindsightReplayBuffer -> her.TD3 on the device) on PointReachEnv (NOT a reference env)."""
+def test_her_loop_learns_to_reach_on_the_stand_in_env():
+    """her.HER end to end (exploration policy -> HindsightReplayBuffer -> her.TD3 on the device) on PointReachEnv (NOT a reference env).
+    Own context: the device's noise streams then do not depend on which tests ran before."""
     import ilswiss_amd as ia
     from ilswiss_amd import her
+    ctx = ia.Context(0, seed=11)
     np.random.seed(3)
     env = her.PointReachEnv(seed=1)
     pol = her.MlpGaussianAndEpsilonPolicy([64, 64], 4, 2, action_space=env.action_space, condition_dim=2, ctx=ctx, seed=5)
@@ -128,3 +130,4 @@ def test_her_loop_learns_to_reach_on_the_stand_in_env(ctx):
     first = alg.evaluate()
     hist = alg.train()
     assert alg._n_train_steps_total >= 3000 and max(hist) >= max(0.6, first + 0.3), (first, hist)
+    ctx.close()
