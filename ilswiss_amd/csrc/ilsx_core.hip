@@ -337,6 +337,9 @@ static int kernels_init_once() {
 
 extern "C" int ilsx_debug_set_stamp_buffer(ilsx_ctx* c, void* dev_trace, int max_launches, int* launches_so_far) {
   if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
+#ifndef ILSX_STAMPS
+  if (dev_trace) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "this libilsx was built without stamps: make -C ilswiss_amd/csrc STAMPS=1 and load libilsx_stamps.so (ILSX_LIB)");
+#endif
   if (launches_so_far) *launches_so_far = c->dbg_launches;
   c->dbg_stamps = (unsigned long long*)dev_trace;
   c->dbg_max_launches = dev_trace ? max_launches : 0;

@@ -189,7 +189,13 @@ template <int ACT> __device__ __forceinline__ float act_grad_from_out(float h) {
 #define ILSX_TRACE_SLOTS 8
 #define ILSX_TRACE_MAXWG 2048
 #define ILSX_WG_LINEAR (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
+// Compiled in only with -DILSX_STAMPS (make STAMPS=1 -> libilsx_stamps.so, what tools/step_gantt.py loads): each stamp is ~8 issue slots
+// per wave plus a parked pointer pair, ~2.5 % of a forward launch at one wave per SIMD — measurement code, kept out of the product build.
+#ifdef ILSX_STAMPS
 #define ILSX_STAMP(dbg, i) do { if ((dbg) && threadIdx.x == 0 && ILSX_WG_LINEAR < ILSX_TRACE_MAXWG) (dbg)[(size_t)ILSX_WG_LINEAR * ILSX_TRACE_SLOTS + (i)] = wall_clock64(); } while (0)
+#else
+#define ILSX_STAMP(dbg, i) ((void)0)
+#endif
 
 // element (n,k) of a forward-packed matrix with K columns / of a backward-packed matrix with N rows
 __host__ __device__ __forceinline__ int pack_f(int n, int k, int K) {

@@ -11,6 +11,11 @@ import sys
 import numpy as np
 
 os.environ["ILSX_NO_GRAPH"] = "1"
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the timestamps are compiled in only in the measurement build of the library
+import subprocess  # noqa: E402
+subprocess.check_call(["make", "-C", os.path.join(_ROOT, "ilswiss_amd", "csrc"), "-j8", "STAMPS=1"], stdout=subprocess.DEVNULL)
+os.environ["ILSX_LIB"] = os.path.join(_ROOT, "ilswiss_amd", "libilsx_stamps.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ilswiss_amd as ia  # noqa: E402
 from ilswiss_amd import _lib  # noqa: E402
