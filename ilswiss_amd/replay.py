@@ -144,10 +144,46 @@ class SimpleReplayBuffer:
             return self._gather(np.arange(start, end), keys)
         return self._gather(np.concatenate([np.arange(start, cap), np.arange(0, end)]), keys)
 
+    def _np_randint(self, *args, **kwargs):  # :70-72
+        return self._np_rand_state.randint(*args, **kwargs)
+
+    def _np_choice(self, *args, **kwargs):  # :74-76
+        return self._np_rand_state.choice(*args, **kwargs)
+
+    def _get_samples_from_traj(self, start, end, samples_per_traj, keys=None):  # :334-347: subsample a trajectory
+        cap = self._max_replay_buffer_size
+        if start < end or end == 0:
+            inds = range(start, cap if end == 0 else end)
+        else:
+            inds = list(range(start, cap)) + list(range(0, end))
+        inds = self._np_choice(inds, size=samples_per_traj, replace=len(inds) < samples_per_traj)
+        return self._gather(inds, keys)
+
+    def sample_trajs(self, num_trajs, keys=None, samples_per_traj=None):  # :349-369
+        keys_list = list(self._traj_endpoints.keys())
+        ends_of = self._traj_endpoints
+        starts = self._np_choice(keys_list, size=num_trajs, replace=len(keys_list) < num_trajs)
+        if samples_per_traj is None:
+            return [self._get_segment(int(s), ends_of[s], keys) for s in starts]
+        return [self._get_samples_from_traj(int(s), ends_of[s], samples_per_traj, keys) for s in starts]
+
     def sample_all_trajs(self, keys=None, samples_per_traj=None):  # :374-395
-        if samples_per_traj is not None:
-            raise NotImplementedError
-        return [self._get_segment(s, e, keys) for s, e in self._traj_endpoints.items()]
+        items = list(self._traj_endpoints.items())
+        if samples_per_traj is None:
+            return [self._get_segment(s, e, keys) for s, e in items]
+        return [self._get_samples_from_traj(s, e, samples_per_traj, keys) for s, e in items]
+
+    def get_all(self, keys=None, **kwargs):  # :219-226
+        return self._gather(np.arange(self._size), keys)
+
+    def save_data(self, save_name):  # :110-123: the rows [0, _top) as one pickled dict
+        import pickle
+        n = self._top
+        b = self._gather(np.arange(n)) if n else {k: np.zeros((0, 1)) for k in ("observations", "actions", "next_observations", "terminals", "rewards")}
+        d = dict(observations=b["observations"], actions=b["actions"], next_observations=b["next_observations"], terminals=b["terminals"],
+                 timeouts=np.zeros((n, 1), np.uint8), rewards=b["rewards"], agent_infos=[None] * n, env_infos=[None] * n)
+        with open(save_name, "wb") as f:
+            pickle.dump(d, f)
 
     def clear(self):
         _lib.check(self.ctx.lib.ilsx_replay_clear(self.h))

@@ -96,5 +96,22 @@ class ReplayOracle:
             return list(range(start, end))
         return list(range(start, self.cap)) + list(range(0, end))
 
-    def sample_all_trajs(self):  # :374-395
-        return [self.gather(self.segment_indices(s, e)) for s, e in self.traj_endpoints.items()]
+    def traj_sample_indices(self, start, end, samples_per_traj):  # _get_samples_from_traj, :334-347 (draws from the buffer's RandomState)
+        inds = self.segment_indices(start, end)
+        return list(self._rs.choice(inds, size=samples_per_traj, replace=len(inds) < samples_per_traj))
+
+    def sample_all_trajs(self, samples_per_traj=None):  # :374-395
+        if samples_per_traj is None:
+            return [self.gather(self.segment_indices(s, e)) for s, e in self.traj_endpoints.items()]
+        return [self.gather(self.traj_sample_indices(s, e, samples_per_traj)) for s, e in list(self.traj_endpoints.items())]
+
+    def sample_trajs(self, num_trajs, samples_per_traj=None):  # :349-369
+        keys = list(self.traj_endpoints.keys())
+        starts = self._rs.choice(keys, size=num_trajs, replace=len(keys) < num_trajs)
+        ends = [self.traj_endpoints[k] for k in starts]
+        if samples_per_traj is None:
+            return [self.gather(self.segment_indices(s, e)) for s, e in zip(starts, ends)]
+        return [self.gather(self.traj_sample_indices(s, e, samples_per_traj)) for s, e in zip(starts, ends)]
+
+    def get_all(self):  # :219-226
+        return self.gather(np.arange(self.size))

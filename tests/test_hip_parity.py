@@ -389,6 +389,29 @@ def test_replay_ring_semantics_golden(ctx):
     assert rb._size == 0 and rb._top == 0 and rb._traj_endpoints == {}
 
 
+def test_replay_trajectory_sampling_golden(ctx, tmp_path):
+    """g23 through the adapter: sample_trajs / samples_per_traj / get_all draw and gather what the reference does; save_data's layout."""
+    import pickle
+    import ilswiss_amd as ia
+    g, t = load_golden("g10_replay"), load_golden("g23_replay_trajs")
+    rb = ia.SimpleReplayBuffer(int(g["cap"]), int(g["o"]), int(g["a"]), random_seed=int(t["seed"]), ctx=ctx)
+    rb.add_rows(g["obs"][:17], g["act"][:17], g["rew"][:17], g["term"][:17], g["next_obs"][:17], g["ep_end"][:17])
+    for lo, hi in ((17, 37), (37, len(g["rew"]))):
+        rb.add_rows(g["obs"][lo:hi], g["act"][lo:hi], g["rew"][lo:hi], g["term"][lo:hi], g["next_obs"][lo:hi], g["ep_end"][lo:hi])
+    calls = [("sample_trajs", dict(num_trajs=3)), ("sample_trajs", dict(num_trajs=2, samples_per_traj=4)),
+             ("sample_trajs", dict(num_trajs=9, samples_per_traj=12)), ("sample_all_trajs", dict(samples_per_traj=3)), ("get_all", {})]
+    for ci, (fn, kw) in enumerate(calls):
+        res = getattr(rb, fn)(**kw)
+        res = res if isinstance(res, list) else [res]
+        np.testing.assert_array_equal([len(x["rewards"]) for x in res], t[f"c{ci}_lens"])
+        np.testing.assert_allclose(np.concatenate([x["observations"] for x in res]), t[f"c{ci}_obs"], atol=1e-6)
+        np.testing.assert_allclose(np.concatenate([x["rewards"].ravel() for x in res]), t[f"c{ci}_rew"], atol=1e-6)
+    rb.save_data(str(tmp_path / "buf.pkl"))
+    d = pickle.load(open(tmp_path / "buf.pkl", "rb"))
+    assert set(d) == {"observations", "actions", "next_observations", "terminals", "timeouts", "rewards", "agent_infos", "env_infos"}
+    assert len(d["rewards"]) == rb._top == len(d["agent_infos"])
+
+
 def test_replay_random_batch_index_stream_and_uniformity(ctx):
     import ilswiss_amd as ia
     from oracle.replay import ReplayOracle

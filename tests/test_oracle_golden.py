@@ -157,6 +157,23 @@ def test_replay_ring_semantics():
     assert orc2.traj_endpoints == orc.traj_endpoints and orc2.top == orc.top
 
 
+def test_replay_trajectory_sampling_golden():
+    """g23: sample_trajs / sample_all_trajs(samples_per_traj) / get_all — same draws from RandomState(seed) as the reference's."""
+    g, t = load_golden("g10_replay"), load_golden("g23_replay_trajs")
+    orc = ReplayOracle(int(g["cap"]), int(g["o"]), int(g["a"]), random_seed=int(t["seed"]))
+    for i in range(len(g["rew"])):
+        orc.add_sample(g["obs"][i], g["act"][i], g["rew"][i], int(g["term"][i]), g["next_obs"][i])
+        if g["ep_end"][i]:
+            orc.terminate_episode()
+    calls = [("sample_trajs", dict(num_trajs=3)), ("sample_trajs", dict(num_trajs=2, samples_per_traj=4)),
+             ("sample_trajs", dict(num_trajs=9, samples_per_traj=12)), ("sample_all_trajs", dict(samples_per_traj=3)), ("get_all", {})]
+    for ci, (fn, kw) in enumerate(calls):
+        res = getattr(orc, fn)(**kw)
+        res = res if isinstance(res, list) else [res]
+        np.testing.assert_array_equal([len(x["rewards"]) for x in res], t[f"c{ci}_lens"])
+        np.testing.assert_allclose(np.concatenate([x["observations"] for x in res]), t[f"c{ci}_obs"], atol=1e-6)
+
+
 def test_running_mean_std_and_action_map():
     from oracle.envnorm import RunningMeanStd, action_map, normalize_obs
     g = load_golden("g11_g12_rms_actionmap")

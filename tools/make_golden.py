@@ -294,6 +294,37 @@ def gen_replay():
     save("g10_replay", **out)
 
 
+def gen_replay_trajs():
+    """G23: the trajectory-sampling surface of SimpleReplayBuffer (simple_replay_buffer.py:219-226, 334-395): sample_trajs with and without
+    samples_per_traj (incl. more samples than a trajectory holds: choice with replacement), sample_all_trajs(samples_per_traj), get_all —
+    on the scripted ring of G10 (wrapped, trajectories of unequal length), draws from the buffer's own RandomState(seed)."""
+    from rlkit.data_management.simple_replay_buffer import SimpleReplayBuffer
+    from oracle.replay import ReplayOracle
+    g = np.load(os.path.join(GOLD, "g10_replay.npz"))
+    cap, o, a = int(g["cap"]), int(g["o"]), int(g["a"])
+    rb, orc = SimpleReplayBuffer(cap, o, a, random_seed=31), ReplayOracle(cap, o, a, random_seed=31)
+    for i in range(len(g["rew"])):
+        for b in (rb, orc):
+            b.add_sample(g["obs"][i], g["act"][i], g["rew"][i], int(g["term"][i]), g["next_obs"][i])
+            if g["ep_end"][i]:
+                b.terminate_episode()
+    calls = [("sample_trajs", dict(num_trajs=3)), ("sample_trajs", dict(num_trajs=2, samples_per_traj=4)),
+             ("sample_trajs", dict(num_trajs=9, samples_per_traj=12)), ("sample_all_trajs", dict(samples_per_traj=3)), ("get_all", {})]
+    out = dict(seed=np.array(31), n_calls=np.array(len(calls)))
+    for ci, (fn, kw) in enumerate(calls):
+        ref = getattr(rb, fn)(**kw)
+        mine = getattr(orc, fn)(**kw)
+        ref, mine = (ref if isinstance(ref, list) else [ref]), (mine if isinstance(mine, list) else [mine])
+        assert len(ref) == len(mine)
+        for x, y in zip(ref, mine):
+            for k in ("observations", "actions", "rewards", "terminals", "next_observations"):
+                assert np.allclose(np.asarray(x[k], np.float64), np.asarray(y[k], np.float64), atol=1e-6), (fn, kw, k)
+        out[f"c{ci}_lens"] = np.array([len(x["rewards"]) for x in ref])
+        out[f"c{ci}_obs"] = np.concatenate([np.asarray(x["observations"]) for x in ref])
+        out[f"c{ci}_rew"] = np.concatenate([np.asarray(x["rewards"]).ravel() for x in ref])
+    save("g23_replay_trajs", **out)
+
+
 def gen_rms_actionmap():
     """G11 RunningMeanStd + normalize_obs (normalizer.py:128-152, vecenvs.py:299-327);
     G12 NormalizedBoxEnv action map (wrappers.py:342-346)."""
@@ -987,7 +1018,7 @@ def gen_her():
     save("g22_her_buffer", **rec)
 
 
-GROUPS = dict(her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+GROUPS = dict(replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
 
 if __name__ == "__main__":
