@@ -187,3 +187,6 @@ class PPO(Trainer):
 
     def end_epoch(self):
         self.eval_statistics = None
+
+    def to(self, device=None):   # the networks already live on the library's device
+        return self
