@@ -110,7 +110,7 @@ def bench_gail(ctx):
     q1, q2 = FlattenMlp([H, H], 1, o + a, ctx=ctx, seed=2), FlattenMlp([H, H], 1, o + a, ctx=ctx, seed=3)
     sac = SoftActorCritic(pol, q1, q2, reward_scale=2.0, policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, beta_1=0.25,
                           max_batch=B)
-    disc = MLPDisc(o, a, hid_dim=128, hid_act="tanh", clamp_magnitude=10.0, grad_pen_weight=8.0, max_batch=B, ctx=ctx, seed=4)
+    disc = MLPDisc(o + a, hid_dim=128, hid_act="tanh", use_bn=False, clamp_magnitude=10.0, ctx=ctx, seed=4)
 
     def fill(rb, n):
         rb.add_rows(rng.normal(0, 1, (n, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (n, a))).astype(np.float32),
@@ -118,7 +118,9 @@ def bench_gail(ctx):
     exp_rb = SimpleReplayBuffer(4000, o, a, random_seed=1, ctx=ctx)   # 4 expert trajectories x 1000 rows
     rb = SimpleReplayBuffer(20000, o, a, random_seed=2, ctx=ctx)      # gail_walker.yaml:46
     fill(exp_rb, 4000), fill(rb, 20000)
-    alg = AdvIRLTrainer("gail2", disc, sac, exp_rb, rb, disc_optim_batch_size=B, policy_optim_batch_size=B)
+    alg = AdvIRLTrainer("gail2", disc, sac, exp_rb, replay_buffer=rb, disc_optim_batch_size=B, policy_optim_batch_size=B,
+                        num_disc_updates_per_loop_iter=1, num_policy_updates_per_loop_iter=1, disc_lr=3e-4, disc_momentum=0.9,
+                        grad_pen_weight=8.0)   # gail_walker.yaml:55-66
     sac.eval_statistics, alg.disc_eval_statistics = {}, {}   # steady state: no statistics read-back
     alg.train(200); ctx.sync()
     n = 2000

@@ -114,13 +114,14 @@ class PpoCfg(C.Structure):  # ilsx_ppo_cfg
                 ("reward_scale", C.c_float), ("discount", C.c_float), ("clip_eps", C.c_float),
                 ("policy_lr", C.c_float), ("value_lr", C.c_float), ("gae_tau", C.c_float),
                 ("value_l2_reg", C.c_float), ("mini_batch_size", C.c_int32), ("update_epoch", C.c_int32),
-                ("max_samples", C.c_int32)]
+                ("max_samples", C.c_int32), ("use_value_clip", C.c_int32)]
 
 
 class DiscCfg(C.Structure):  # ilsx_disc_cfg
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("hid_dim", C.c_int32), ("hid_act", C.c_int32),
                 ("use_grad_pen", C.c_int32), ("clamp_magnitude", C.c_float), ("disc_lr", C.c_float),
-                ("disc_momentum", C.c_float), ("grad_pen_weight", C.c_float), ("max_batch", C.c_int32)]
+                ("disc_momentum", C.c_float), ("grad_pen_weight", C.c_float), ("max_batch", C.c_int32),
+                ("state_only", C.c_int32)]
 
 
 class OptMeta(C.Structure):  # ilsx_opt_meta
@@ -174,6 +175,8 @@ PROTOTYPES = {
     "ilsx_ppo_debug_perm": (C.c_int, [vp, C.c_int, C.c_uint32, vp]),
     "ilsx_ppo_policy_act": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "ilsx_disc_create": (C.c_int, [vp, C.POINTER(DiscCfg), C.POINTER(vp)]),
+    "ilsx_advirl_set_policy_batch_from_expert": (C.c_int, [vp, C.c_int]),
+    "ilsx_debug_philox": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp, vp]),
     "ilsx_disc_destroy": (C.c_int, [vp]),
     "ilsx_disc_num_params": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "ilsx_disc_set_params": (C.c_int, [vp, vp, C.c_size_t]),

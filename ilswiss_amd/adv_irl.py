@@ -1,7 +1,12 @@
 """Adversarial IRL (GAIL / AIRL / FAIRL / "gail2") over libilsx: the reference's `MLPDisc`
 (rlkit/torch/algorithms/adv_irl/disc_models/simple_disc_models.py:8-48) and the two inner steps of `AdvIRL`
 (rlkit/torch/algorithms/adv_irl/adv_irl.py:126-131 loop, :133-216 discriminator step, :238-314 reward
-relabel + policy step).  Constructor kwargs are the YAML keys of exp_specs/gail/gail_walker.yaml.
+relabel + policy step).  Constructor signatures and DEFAULTS are the reference's (simple_disc_models.py:9-17,
+adv_irl.py:34-54): a caller that relies on defaults gets the reference's algorithm or a loud error, never a
+different network.  What libilsx does not implement raises at construction:
+  * `use_bn=True` (the reference default): BatchNorm1d couples the rows of a batch, and the gradient penalty needs the
+    double backward through the batch statistics — not built; every exp_spec of the reference sets `disc_use_bn: false`;
+  * `num_layer_blocks != 2` (every exp_spec sets 2).
 """
 import ctypes as C
 from collections import OrderedDict
@@ -13,53 +18,135 @@ from .device import as_dev, get_context
 
 _MODES = dict(airl=0, gail=1, gail2=2, fairl=3)
 _ACT = dict(relu=0, tanh=1)
+_WIDTHS = (64, 128, 256)   # hidden widths the MFMA kernels are instantiated for
 
 
 class MLPDisc:
-    """MLPDisc(input_dim, num_layer_blocks=2, hid_dim, hid_act, use_bn=False, clamp_magnitude) + its optimiser
-    (torch.optim.Adam(lr=disc_lr, betas=(disc_momentum, 0.999)), adv_irl.py:75-77)."""
+    """MLPDisc(input_dim, num_layer_blocks=2, hid_dim=100, hid_act='relu', use_bn=True, clamp_magnitude=10.0)
+    (simple_disc_models.py:9-17).  The optimiser (Adam(lr=disc_lr, betas=(disc_momentum, 0.999)), adv_irl.py:75-77) and the
+    gradient-penalty settings belong to AdvIRL in the reference; here they reach the library through `bind`, which AdvIRLTrainer
+    calls with its own kwargs (standalone use: call `bind` yourself).  Until then the parameters live on the host.
 
-    def __init__(self, obs_dim, act_dim, num_layer_blocks=2, hid_dim=128, hid_act="tanh", use_bn=False,
-                 clamp_magnitude=10.0, disc_lr=3e-4, disc_momentum=0.9, use_grad_pen=True, grad_pen_weight=10.0,
-                 max_batch=256, ctx=None, seed=None):
-        if use_bn or num_layer_blocks != 2:
-            raise NotImplementedError("hot-path configs use 2 blocks without batch norm (gail_walker.yaml:24-28)")
+    A `hid_dim` the kernels have no instantiation for (the reference default 100) is zero-padded to the next supported width:
+    padded units have pre-activation 0, output 0 (tanh / relu), receive gradient 0 and are never moved by Adam, so the padded
+    network IS the hid_dim-wide one; flat parameter vectors cross this class in the logical (unpadded) layout."""
+
+    def __init__(self, input_dim, num_layer_blocks=2, hid_dim=100, hid_act="relu", use_bn=True, clamp_magnitude=10.0, *,
+                 ctx=None, seed=None):
+        if use_bn:
+            raise NotImplementedError("MLPDisc(use_bn=True) — the reference's default — is not implemented by libilsx (no batch-norm "
+                                      "double backward); pass use_bn=False explicitly (every exp_spec does: gail_walker.yaml:27)")
+        if num_layer_blocks != 2:
+            raise NotImplementedError("libilsx implements num_layer_blocks=2 (gail_walker.yaml:24); got %r" % (num_layer_blocks,))
+        if hid_act not in _ACT:
+            raise NotImplementedError()   # simple_disc_models.py:24-25
+        if hid_dim > _WIDTHS[-1]:
+            raise NotImplementedError("hid_dim > 256")
         self.ctx = ctx or get_context()
-        self.obs_dim, self.act_dim, self.hid_dim = int(obs_dim), int(act_dim), int(hid_dim)
-        self.clamp_magnitude, self.grad_pen_weight, self.use_grad_pen = clamp_magnitude, grad_pen_weight, use_grad_pen
-        cfg = _lib.DiscCfg(self.obs_dim, self.act_dim, self.hid_dim, _ACT[hid_act], int(bool(use_grad_pen)),
-                           clamp_magnitude, disc_lr, disc_momentum, grad_pen_weight, int(max_batch))
-        self.h = C.c_void_p()
-        _lib.check(self.ctx.lib.ilsx_disc_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
-        n = C.c_size_t()
-        _lib.check(self.ctx.lib.ilsx_disc_num_params(self.h, C.byref(n)))
-        self.num_params = n.value
+        self.input_dim, self.hid_dim, self.hid_act = int(input_dim), int(hid_dim), hid_act
+        self._Hp = next(w for w in _WIDTHS if w >= self.hid_dim)
+        self.clamp_magnitude = clamp_magnitude
         # torch nn.Linear default init: W, b ~ U(+-1/sqrt(fan_in))
         rng = np.random.default_rng(np.random.randint(0, 2**31 - 1) if seed is None else seed)
-        D, H = self.obs_dim + self.act_dim, self.hid_dim
+        D, H = self.input_dim, self.hid_dim
         parts = []
         for fan_in, out in ((D, H), (H, H), (H, 1)):
             b = 1.0 / np.sqrt(fan_in)
             parts += [rng.uniform(-b, b, (out, fan_in)).ravel(), rng.uniform(-b, b, out)]
-        self.set_flat_params(np.concatenate(parts).astype(np.float32))
+        self._flat = np.concatenate(parts).astype(np.float32)
+        self.num_params = self._flat.size
+        self.h, self._bound = None, None
         self._stats = _lib.DiscStats()
+        self.obs_dim = self.act_dim = None
+        self.use_grad_pen, self.grad_pen_weight = True, 10.0
+
+    # ---- logical <-> padded flat layouts (fc0.W | fc0.b | fc1.W | fc1.b | out.W | out.b)
+    def _pad(self, flat):
+        D, H, Hp = self.input_dim, self.hid_dim, self._Hp
+        flat = np.ascontiguousarray(flat, np.float32)
+        assert flat.size == self.num_params, (flat.size, self.num_params)
+        if H == Hp:
+            return flat
+        o, out = 0, []
+        for rows, cols, prow, pcol in ((H, D, Hp, D), (H, 1, Hp, 1), (H, H, Hp, Hp), (H, 1, Hp, 1), (1, H, 1, Hp), (1, 1, 1, 1)):
+            m = np.zeros((prow, pcol), np.float32)
+            m[:rows, :cols] = flat[o:o + rows * cols].reshape(rows, cols)
+            out.append(m.ravel())
+            o += rows * cols
+        return np.concatenate(out)
+
+    def _unpad(self, phys):
+        D, H, Hp = self.input_dim, self.hid_dim, self._Hp
+        if H == Hp:
+            return phys
+        o, out = 0, []
+        for rows, cols, prow, pcol in ((H, D, Hp, D), (H, 1, Hp, 1), (H, H, Hp, Hp), (H, 1, Hp, 1), (1, H, 1, Hp), (1, 1, 1, 1)):
+            out.append(phys[o:o + prow * pcol].reshape(prow, pcol)[:rows, :cols].ravel())
+            o += prow * pcol
+        return np.concatenate(out)
+
+    @property
+    def _nphys(self):
+        D, Hp = self.input_dim, self._Hp
+        return Hp * D + Hp + Hp * Hp + Hp + Hp + 1
+
+    def bind(self, obs_dim, second_dim=None, state_only=False, disc_lr=1e-3, disc_momentum=0.0, use_grad_pen=True,
+             grad_pen_weight=10.0, max_batch=1024):
+        """Create (or re-create, keeping the parameters) the library object.  The discriminator input is cat(obs, act) —
+        or cat(obs, next_obs) when state_only (adv_irl.py:140-162) — so obs_dim + second_dim == input_dim."""
+        obs_dim = int(obs_dim)
+        second_dim = self.input_dim - obs_dim if second_dim is None else int(second_dim)
+        if obs_dim + second_dim != self.input_dim:
+            raise ValueError(f"input_dim {self.input_dim} != {obs_dim} + {second_dim}")
+        key = (obs_dim, second_dim, bool(state_only), float(disc_lr), float(disc_momentum), bool(use_grad_pen),
+               float(grad_pen_weight), int(max_batch))
+        if self._bound == key:
+            return self
+        if self.h is not None:
+            self._flat = self.get_flat_params()
+            _lib.check(self.ctx.lib.ilsx_disc_destroy(self.h))
+        cfg = _lib.DiscCfg(obs_dim, second_dim, self._Hp, _ACT[self.hid_act], int(bool(use_grad_pen)), self.clamp_magnitude,
+                           disc_lr, disc_momentum, grad_pen_weight, int(max_batch), int(bool(state_only)))
+        self.h = C.c_void_p()
+        _lib.check(self.ctx.lib.ilsx_disc_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
+        self._bound = key
+        self.obs_dim, self.act_dim = obs_dim, second_dim
+        self.use_grad_pen, self.grad_pen_weight, self.state_only = bool(use_grad_pen), grad_pen_weight, bool(state_only)
+        self.set_flat_params(self._flat)
+        return self
+
+    def _need(self):
+        if self.h is None:
+            raise RuntimeError("MLPDisc is not bound to the library yet: construct the AdvIRLTrainer around it or call "
+                               "disc.bind(obs_dim, ...) (the optimiser settings live on AdvIRL, adv_irl.py:75-77)")
 
     def set_flat_params(self, flat):
         flat = np.ascontiguousarray(flat, np.float32)
-        _lib.check(self.ctx.lib.ilsx_disc_set_params(self.h, flat.ctypes.data_as(C.c_void_p), flat.size))
+        if self.h is None:
+            assert flat.size == self.num_params
+            self._flat = flat.copy()
+            return
+        phys = self._pad(flat)
+        _lib.check(self.ctx.lib.ilsx_disc_set_params(self.h, phys.ctypes.data_as(C.c_void_p), phys.size))
+
+    def _get(self, fn):
+        out = np.empty(self._nphys, np.float32)
+        _lib.check(fn(self.h, out.ctypes.data_as(C.c_void_p), out.size))
+        return self._unpad(out)
 
     def get_flat_params(self):
-        out = np.empty(self.num_params, np.float32)
-        _lib.check(self.ctx.lib.ilsx_disc_get_params(self.h, out.ctypes.data_as(C.c_void_p), out.size))
-        return out
+        if self.h is None:
+            return self._flat.copy()
+        return self._get(self.ctx.lib.ilsx_disc_get_params)
 
     def get_flat_grads(self):
-        out = np.empty(self.num_params, np.float32)
-        _lib.check(self.ctx.lib.ilsx_disc_get_grads(self.h, out.ctypes.data_as(C.c_void_p), out.size))
-        return out
+        self._need()
+        return self._get(self.ctx.lib.ilsx_disc_get_grads)
 
     def train_step(self, expert_obs, expert_act, policy_obs, policy_act, eps=None):
-        """AdvIRL._do_reward_training on explicit batches; returns the reference's statistics dict."""
+        """AdvIRL._do_reward_training on explicit batches (the second array of each pair holds next_obs when state_only);
+        returns the reference's statistics dict."""
+        self._need()
         ctx, keep = self.ctx, []
 
         def dev(x):
@@ -77,6 +164,7 @@ class MLPDisc:
         return st
 
     def reward_dev(self, obs_ptr, act_ptr, n, mode, rew_clip_min=None, rew_clip_max=None, rew=None, logits=None):
+        self._need()
         _lib.check(self.ctx.lib.ilsx_disc_reward(
             self.h, obs_ptr, act_ptr, n, _MODES[mode], int(rew_clip_min is not None), float(rew_clip_min or 0.0),
             int(rew_clip_max is not None), float(rew_clip_max or 0.0), rew.ptr if rew is not None else None,
@@ -91,53 +179,80 @@ class MLPDisc:
         self.reward_dev(po, pa, n, mode, rew_clip_min, rew_clip_max, rew, lg)
         return rew.numpy().reshape(n, 1), lg.numpy().reshape(n, 1)
 
-    def __call__(self, x):  # clamped logits of cat(obs, act) rows
+    def __call__(self, x):  # MLPDisc.forward: clamped logits of disc-input rows (simple_disc_models.py:42-48)
+        if self.h is None:
+            self.bind(self.input_dim - 1, 1)   # any split of the input will do for a forward
         x = np.ascontiguousarray(x, np.float32)
         return self.rewards(x[:, : self.obs_dim], x[:, self.obs_dim:], "airl")[1]
 
+    forward = __call__
+
 
 class AdvIRLTrainer:
-    """`AdvIRL._do_training` (adv_irl.py:126-131): per update loop, k discriminator steps then m policy steps
-    whose rewards are relabelled by the discriminator (adv_irl.py:256-301).  Batches are drawn on the device
-    from the two HBM replay buffers; nothing crosses PCIe."""
+    """`AdvIRL` (adv_irl.py:34-54 signature and defaults; the base-algorithm kwargs of the reference go to DeviceRLAlgorithm
+    instead, `replay_buffer` is the one this class keeps): per update loop, num_disc_updates_per_loop_iter discriminator steps then
+    num_policy_updates_per_loop_iter policy steps whose rewards are relabelled by the discriminator (adv_irl.py:126-131,256-301).
+    Batches are drawn on the device from the two HBM replay buffers; nothing crosses PCIe."""
 
-    def __init__(self, mode, discriminator, policy_trainer, expert_replay_buffer, replay_buffer,
-                 disc_optim_batch_size=256, policy_optim_batch_size=256, num_update_loops_per_train_call=1,
-                 num_disc_updates_per_loop_iter=1, num_policy_updates_per_loop_iter=1, rew_clip_min=None,
-                 rew_clip_max=None, state_only=False, **kwargs):
+    def __init__(self, mode, discriminator, policy_trainer, expert_replay_buffer, state_only=False, disc_optim_batch_size=1024,
+                 policy_optim_batch_size=1024, policy_optim_batch_size_from_expert=0, num_update_loops_per_train_call=1,
+                 num_disc_updates_per_loop_iter=100, num_policy_updates_per_loop_iter=100, disc_lr=1e-3, disc_momentum=0.0,
+                 disc_optimizer_class=None, use_grad_pen=True, grad_pen_weight=10, rew_clip_min=None, rew_clip_max=None,
+                 replay_buffer=None, wrap_absorbing=False, **kwargs):
         assert mode in _MODES, "Invalid adversarial irl algorithm!"
-        if state_only:
-            raise NotImplementedError("state_only discriminators are not on the hot path (gail_walker.yaml)")
+        if disc_optimizer_class is not None and getattr(disc_optimizer_class, "__name__", disc_optimizer_class) != "Adam":
+            raise NotImplementedError("the discriminator optimiser is Adam (adv_irl.py:48)")
+        if wrap_absorbing:
+            raise NotImplementedError("wrap_absorbing discriminator inputs (adv_irl.py:152-170) are not implemented")
         self.mode, self.disc, self.policy_trainer = mode, discriminator, policy_trainer
+        self.state_only = bool(state_only)
         self.expert_rb, self.rb = expert_replay_buffer, replay_buffer
         self.Bd, self.Bp = int(disc_optim_batch_size), int(policy_optim_batch_size)
+        self.Bpe = int(policy_optim_batch_size_from_expert)
+        if not 0 <= self.Bpe <= self.Bp:
+            raise ValueError("policy_optim_batch_size_from_expert must be in 0..policy_optim_batch_size")
         self.loops, self.k, self.m = num_update_loops_per_train_call, num_disc_updates_per_loop_iter, num_policy_updates_per_loop_iter
         self.rew_clip_min, self.rew_clip_max = rew_clip_min, rew_clip_max
         ctx = self.ctx = discriminator.ctx
-        o, a, B = discriminator.obs_dim, discriminator.act_dim, max(self.Bd, self.Bp)
+        o = int(expert_replay_buffer._observation_dim)
+        a = int(expert_replay_buffer._action_dim)
+        self.o, self.a = o, a
+        discriminator.bind(o, o if self.state_only else a, state_only=self.state_only, disc_lr=disc_lr, disc_momentum=disc_momentum,
+                           use_grad_pen=use_grad_pen, grad_pen_weight=grad_pen_weight, max_batch=max(self.Bd, self.Bp))
+        _lib.check(ctx.lib.ilsx_advirl_set_policy_batch_from_expert(discriminator.h, self.Bpe))
+        B = max(self.Bd, self.Bp)
         mk = lambda: [ctx.empty((B, o)), ctx.empty((B, a)), ctx.empty((B,)), ctx.empty((B,)), ctx.empty((B, o))]  # noqa
         self._e, self._p = mk(), mk()
         self.disc_eval_statistics = None
 
-    def _sample(self, rb, bufs, B):
-        _lib.check(self.ctx.lib.ilsx_replay_sample(rb.h, B, None, *[b.ptr for b in bufs], None))
+    def _sample(self, rb, bufs, B, row0=0):
+        ptrs = [C.c_void_p(b.ptr.value + 4 * row0 * (b.shape[1] if len(b.shape) > 1 else 1)) for b in bufs]
+        _lib.check(self.ctx.lib.ilsx_replay_sample(rb.h, B, None, *ptrs, None))
+
+    def _second(self, bufs):   # the discriminator's second input segment: actions, or next observations when state_only
+        return bufs[4] if self.state_only else bufs[1]
 
     def _do_reward_training(self):
         self._sample(self.expert_rb, self._e, self.Bd)
         self._sample(self.rb, self._p, self.Bd)
         want = self.disc_eval_statistics is None
-        _lib.check(self.ctx.lib.ilsx_disc_train_step(self.disc.h, self._e[0].ptr, self._e[1].ptr, self._p[0].ptr,
-                                                     self._p[1].ptr, self.Bd, None,
+        _lib.check(self.ctx.lib.ilsx_disc_train_step(self.disc.h, self._e[0].ptr, self._second(self._e).ptr, self._p[0].ptr,
+                                                     self._second(self._p).ptr, self.Bd, None,
                                                      C.byref(self.disc._stats) if want else None))
         if want:
             s = self.disc._stats
-            self.disc_eval_statistics = OrderedDict([("Disc CE Loss", s.ce_loss), ("Disc Acc", s.accuracy),
-                                                     ("Grad Pen", s.grad_pen), ("Grad Pen W", self.disc.grad_pen_weight)])
+            self.disc_eval_statistics = OrderedDict([("Disc CE Loss", s.ce_loss), ("Disc Acc", s.accuracy)])
+            if self.disc.use_grad_pen:
+                self.disc_eval_statistics.update({"Grad Pen": s.grad_pen, "Grad Pen W": self.disc.grad_pen_weight})
 
     def _do_policy_training(self):
         obs, act, rew, done, nobs = self._p
-        self._sample(self.rb, self._p, self.Bp)
-        self.disc.reward_dev(obs.ptr, act.ptr, self.Bp, self.mode, self.rew_clip_min, self.rew_clip_max, rew=rew)
+        npol = self.Bp - self.Bpe                      # adv_irl.py:239-255: cat([policy-buffer rows, expert-buffer rows])
+        if npol > 0:
+            self._sample(self.rb, self._p, npol)
+        if self.Bpe > 0:
+            self._sample(self.expert_rb, self._p, self.Bpe, row0=npol)
+        self.disc.reward_dev(obs.ptr, self._second(self._p).ptr, self.Bp, self.mode, self.rew_clip_min, self.rew_clip_max, rew=rew)
         tr = self.policy_trainer
         want = tr.eval_statistics is None
         _lib.check(self.ctx.lib.ilsx_sac_train_step(tr.h, obs.ptr, act.ptr, rew.ptr, done.ptr, nobs.ptr, self.Bp, None, None,
@@ -145,6 +260,8 @@ class AdvIRLTrainer:
         if want:
             tr._fill_stats()
             r = rew.numpy()[: self.Bp]
+            if self.disc_eval_statistics is None:
+                self.disc_eval_statistics = OrderedDict()
             self.disc_eval_statistics.update({"Disc Rew Mean": float(r.mean()), "Disc Rew Std": float(r.std()),
                                               "Disc Rew Max": float(r.max()), "Disc Rew Min": float(r.min())})
 
@@ -183,14 +300,14 @@ class AdvIRLTrainer:
         return self.policy_trainer.policy
 
     @property
-    def networks(self):
-        return self.policy_trainer.networks + [self.disc]
+    def networks(self):   # adv_irl.py:316-318
+        return [self.disc] + self.policy_trainer.networks
 
-    def get_snapshot(self):  # adv_irl.py:316-326, as plain arrays (+ disc_optimizer's Adam state)
+    def get_snapshot(self):  # adv_irl.py:320-326, as plain arrays (+ disc_optimizer's Adam state, padded layout)
         from .snapshot import get_opt
         snap = dict(self.policy_trainer.get_snapshot())
         snap["disc"] = self.disc.get_flat_params()
-        snap["disc_optimizer"] = get_opt(self.disc.ctx.lib, "disc", self.disc.h, snap["disc"].size)
+        snap["disc_optimizer"] = get_opt(self.disc.ctx.lib, "disc", self.disc.h, self.disc._nphys)
         return snap
 
     def load_snapshot(self, snap):
@@ -209,3 +326,9 @@ class AdvIRLTrainer:
     def end_epoch(self):
         self.policy_trainer.end_epoch()
         self.disc_eval_statistics = None
+
+    def to(self, device=None):   # adv_irl.py:328-331: everything already lives on the library's device
+        return self
+
+
+AdvIRL = AdvIRLTrainer   # the reference's class name

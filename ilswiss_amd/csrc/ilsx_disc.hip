@@ -316,6 +316,7 @@ struct ilsx_disc {
   NetLayout L;
   AdvIrlWs airl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};  // ilsx_advirl_train batches
   int cs = 1, D = 0, o = 0, a = 0;
+  int from_expert = 0;   // policy_optim_batch_size_from_expert (adv_irl.py:239-255)
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
   DiscScalars* scal = nullptr;
   float *X = nullptr, *xs = nullptr, *hs0 = nullptr, *hs1 = nullptr, *A2 = nullptr, *A1 = nullptr, *dhead = nullptr;
@@ -338,6 +339,8 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
   if (cfg->obs_dim < 1 || cfg->act_dim < 1 || cfg->obs_dim + cfg->act_dim > 64)
     ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "discriminator input obs+act=%d: this kernel supports up to 64", cfg->obs_dim + cfg->act_dim);
   if (cfg->max_batch < 1) ILSX_FAIL(ILSX_ERR_ARG, "max_batch must be >= 1");
+  if (cfg->state_only && cfg->act_dim != cfg->obs_dim)
+    ILSX_FAIL(ILSX_ERR_ARG, "state_only: the second input segment is next_obs, act_dim (%d) must equal obs_dim (%d)", cfg->act_dim, cfg->obs_dim);
   HIPCHK(hipSetDevice(ctx->device));
   ilsx_disc* d = new ilsx_disc();
   d->ctx = ctx; d->cfg = *cfg; d->o = cfg->obs_dim; d->a = cfg->act_dim; d->D = d->o + d->a;
@@ -539,7 +542,12 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
   if (disc_batch < 1 || disc_batch > d->cfg.max_batch || policy_batch < 1) ILSX_FAIL(ILSX_ERR_ARG, "batch sizes out of range");
   HIPCHK(hipSetDevice(d->ctx->device));
   AdvIrlWs& ws = d->airl;
-  const int o = d->cfg.obs_dim, a = d->cfg.act_dim;
+  const int o = d->cfg.obs_dim, a = policy_rb->a;   // a: the env's action width (state_only discriminators have cfg.act_dim == obs_dim)
+  const bool so = d->cfg.state_only != 0;
+  const int nfe = d->from_expert;
+  if (nfe < 0 || nfe > policy_batch) ILSX_FAIL(ILSX_ERR_ARG, "policy_optim_batch_size_from_expert=%d not in 0..policy_batch=%d", nfe, policy_batch);
+  if (expert_rb->o != o || policy_rb->o != o || expert_rb->a != a || (!so && a != d->cfg.act_dim))
+    ILSX_FAIL(ILSX_ERR_ARG, "replay dims do not match the discriminator");
   if (ws.B < B) {
     float** ps[] = {&ws.eo, &ws.ea, &ws.er, &ws.ed, &ws.en, &ws.po, &ws.pa, &ws.pr, &ws.pd, &ws.pn};
     const size_t w[] = {(size_t)o, (size_t)a, 1, 1, (size_t)o, (size_t)o, (size_t)a, 1, 1, (size_t)o};
@@ -554,12 +562,17 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
     for (int k = 0; k < disc_updates; ++k) {   // adv_irl.py:133-216
       ILSX_TRY(ilsx_replay_sample(expert_rb, disc_batch, nullptr, ws.eo, ws.ea, ws.er, ws.ed, ws.en, nullptr));
       ILSX_TRY(ilsx_replay_sample(policy_rb, disc_batch, nullptr, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, nullptr));
-      ILSX_TRY(ilsx_disc_train_step(d, ws.eo, ws.ea, ws.po, ws.pa, disc_batch, nullptr, first_disc ? disc_stats : nullptr));
+      ILSX_TRY(ilsx_disc_train_step(d, ws.eo, so ? ws.en : ws.ea, ws.po, so ? ws.pn : ws.pa, disc_batch, nullptr,
+                                    first_disc ? disc_stats : nullptr));
       first_disc = false;
     }
     for (int m = 0; m < policy_updates; ++m) {   // adv_irl.py:238-314
-      ILSX_TRY(ilsx_replay_sample(policy_rb, policy_batch, nullptr, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, nullptr));
-      ILSX_TRY(ilsx_disc_reward(d, ws.po, ws.pa, policy_batch, mode, has_min, rew_clip_min, has_max, rew_clip_max, ws.pr, nullptr));
+      const int npol = policy_batch - nfe;   // adv_irl.py:239-255: torch.cat([rows from the policy buffer, rows from the expert buffer])
+      if (npol > 0) ILSX_TRY(ilsx_replay_sample(policy_rb, npol, nullptr, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, nullptr));
+      if (nfe > 0)
+        ILSX_TRY(ilsx_replay_sample(expert_rb, nfe, nullptr, ws.po + (size_t)npol * o, ws.pa + (size_t)npol * a, ws.pr + npol, ws.pd + npol,
+                                    ws.pn + (size_t)npol * o, nullptr));
+      ILSX_TRY(ilsx_disc_reward(d, ws.po, so ? ws.pn : ws.pa, policy_batch, mode, has_min, rew_clip_min, has_max, rew_clip_max, ws.pr, nullptr));
       const bool want = first_pol && sac_stats;
       ILSX_TRY(ilsx_sac_train_step(sac, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, policy_batch, nullptr, nullptr, want ? sac_stats : nullptr));
       if (first_pol && rew_stats4) {   // "Disc Rew Mean/Std/Max/Min" of the first relabelled batch (adv_irl.py:303-314)
@@ -576,5 +589,11 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
       first_pol = false;
     }
   }
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_advirl_set_policy_batch_from_expert(ilsx_disc* d, int n_from_expert) {
+  if (!d || n_from_expert < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_advirl_set_policy_batch_from_expert: bad argument");
+  d->from_expert = n_from_expert;
   return ILSX_OK;
 }

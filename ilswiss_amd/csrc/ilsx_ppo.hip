@@ -438,6 +438,7 @@ static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const 
     b.net = net_view(p->Lv, p->Pv);
     for (int l = 0; l < nh; ++l) { b.hsave[l] = p->hv[l]; b.dsave[l] = p->dv[l]; }
     b.dhead = p->dhv; b.loss = LOSS_MSE; b.rows_idx = idx; b.pred = p->vpred; b.target = p->returns;
+    if (p->cfg.use_value_clip) { b.lp_old = p->values; b.clip_eps = p->cfg.clip_eps; }   // ppo.py:137-143
     ILSX_TRY(launch_bwd_dx(ctx, Bw, H, ILSX_ACT_TANH));
     AdamFuse F;
     memset(&F, 0, sizeof F);

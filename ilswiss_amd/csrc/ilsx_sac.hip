@@ -113,7 +113,6 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
   __shared__ float sh[4];
   const float alpha = S.scal->alpha;
   float l1 = 0, l2 = 0, pl = 0, lp = 0, mu2 = 0, ls2 = 0, mus = 0, lss = 0, q1s = 0, q2s = 0, lpe = 0;
-  float sq[3] = {0.f, 0.f, 0.f};                                   // sums of squares of q1, q2, log pi (mu / log std: mu2, ls2)
   float mx[5] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn[5] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
   for (int r = threadIdx.x; r < S.B; r += 256) {
     const float y = S.reward_scale * S.r[r] +
@@ -121,7 +120,6 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
     const float q1v = S.q1.get(r), q2v = S.q2.get(r);
     const float e1 = q1v - y, e2 = q2v - y;
     l1 += e1 * e1; l2 += e2 * e2; q1s += q1v; q2s += q2v;
-    sq[0] += q1v * q1v; sq[1] += q2v * q2v; sq[2] += S.logp[r] * S.logp[r];
     mx[0] = fmaxf(mx[0], q1v); mn[0] = fminf(mn[0], q1v); mx[1] = fmaxf(mx[1], q2v); mn[1] = fminf(mn[1], q2v);
     mx[2] = fmaxf(mx[2], S.logp[r]); mn[2] = fminf(mn[2], S.logp[r]);
     pl += alpha * S.logp[r] - fminf(S.q1n.get(r), S.q2n.get(r));
@@ -138,8 +136,6 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
   mu2 = block256_sum(mu2, sh); ls2 = block256_sum(ls2, sh); mus = block256_sum(mus, sh); lss = block256_sum(lss, sh);
   q1s = block256_sum(q1s, sh); q2s = block256_sum(q2s, sh); lpe = block256_sum(lpe, sh);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) sq[i] = block256_sum(sq[i], sh);
-#pragma unroll
   for (int i = 0; i < 5; ++i) {   // block extrema: wave butterflies, then the 4 wave results through LDS
     float a = mx[i], b = mn[i];
     for (int o = 32; o >= 1; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); b = fminf(b, __shfl_xor(b, o, 64)); }
@@ -152,19 +148,33 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
     __syncthreads();
     mn[i] = fminf(fminf(sh[0], sh[1]), fminf(sh[2], sh[3]));
   }
+  // np.std (create_stats_ordered_dict, core/eval_util.py:91-142) is the two-pass population standard deviation: centre on the mean, then
+  // average the squares.  (The first form, sqrt(E[x^2] - mean^2) from one pass, loses the digits a tight distribution around a
+  // large mean needs; this kernel only runs on the one batch per epoch whose statistics the host reads.)
+  const float iB = 1.0f / (float)S.B, iBa = iB / (float)S.a;
+  const float means[5] = {q1s * iB, q2s * iB, lp * iB, mus * iBa, lss * iBa};
+  float cs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = threadIdx.x; r < S.B; r += 256) {
+    const float d0 = S.q1.get(r) - means[0], d1 = S.q2.get(r) - means[1], d2 = S.logp[r] - means[2];
+    cs[0] += d0 * d0; cs[1] += d1 * d1; cs[2] += d2 * d2;
+    for (int j = 0; j < S.a; ++j) {
+      const float dm = S.raw[(size_t)r * 2 * S.a + j] - means[3];
+      const float dl = fminf(fmaxf(S.raw[(size_t)r * 2 * S.a + S.a + j], LOG_SIG_MIN), LOG_SIG_MAX) - means[4];
+      cs[3] += dm * dm; cs[4] += dl * dl;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) cs[i] = block256_sum(cs[i], sh);
   if (threadIdx.x == 0) {
-    const float iB = 1.0f / (float)S.B, iBa = iB / (float)S.a;
     DevScalars* sc = S.scal;
     sc->qf1_loss = 0.5f * l1 * iB;
     sc->qf2_loss = 0.5f * l2 * iB;
     sc->policy_loss = pl * iB + S.w_mu * mu2 * iBa + S.w_std * ls2 * iBa;
     sc->alpha_loss = -(float)sc->log_alpha * (lpe * iB);
-    sc->q1_mean = q1s * iB; sc->q2_mean = q2s * iB; sc->log_pi_mean = lp * iB;
-    sc->mu_mean = mus * iBa; sc->log_std_mean = lss * iBa;
-    const float means[5] = {sc->q1_mean, sc->q2_mean, sc->log_pi_mean, sc->mu_mean, sc->log_std_mean};
-    const float msq[5] = {sq[0] * iB, sq[1] * iB, sq[2] * iB, mu2 * iBa, ls2 * iBa};
-    for (int i = 0; i < 5; ++i) {   // np.std: population standard deviation
-      sc->ext_std[i] = sqrtf(fmaxf(msq[i] - means[i] * means[i], 0.0f));
+    sc->q1_mean = means[0]; sc->q2_mean = means[1]; sc->log_pi_mean = means[2];
+    sc->mu_mean = means[3]; sc->log_std_mean = means[4];
+    for (int i = 0; i < 5; ++i) {
+      sc->ext_std[i] = sqrtf(cs[i] * (i < 3 ? iB : iBa));
       sc->ext_max[i] = mx[i]; sc->ext_min[i] = mn[i];
     }
     sc->alpha_used = alpha;
@@ -903,6 +913,25 @@ __global__ __launch_bounds__(256) void k_debug_eps(uint64_t seed, uint64_t step,
   philox_normal4(seed, step, stream, (uint32_t)r, (uint32_t)(j >> 2), z4);
   const int q = j & 3;
   out[e] = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
+}
+
+// Known-answer aid: the raw Philox4x32-10 words and the N(0,1) values philox_normal4 makes of them, for explicit (seed, step, stream):
+// raw[r*4 + i] = word i of the block with counter (r, quad 0); normals[r*a + j] = what every policy epilogue draws for (row r, dim j).
+__global__ __launch_bounds__(256) void k_debug_philox_raw(uint64_t seed, uint64_t step, uint32_t stream, int n, uint32_t* out) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  uint32_t c[4] = {(uint32_t)r, 0u, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream * 0x9E3779B9u)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
+  out[4 * r + 0] = c[0]; out[4 * r + 1] = c[1]; out[4 * r + 2] = c[2]; out[4 * r + 3] = c[3];
+}
+extern "C" int ilsx_debug_philox(ilsx_ctx* ctx, uint64_t seed, uint64_t step, uint32_t stream, int n_rows, int a, uint32_t* raw,
+                                 float* normals) {
+  if (!ctx || n_rows < 1 || a < 1 || (!raw && !normals)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_debug_philox: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (raw) hipLaunchKernelGGL(k_debug_philox_raw, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, seed, step, stream, n_rows, raw);
+  if (normals) hipLaunchKernelGGL(k_debug_eps, dim3((n_rows * a + 255) / 256), dim3(256), 0, ctx->stream, seed, step, stream, n_rows, a, normals);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
 }
 
 extern "C" int ilsx_sac_debug_batch(ilsx_sac* s, ilsx_replay* rb, uint64_t step, int B, float* obs, float* act, float* rew,

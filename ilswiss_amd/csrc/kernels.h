@@ -631,7 +631,18 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
   } else if (T.loss == LOSS_MSE) {
     // ppo.py:145: mean((v - R)^2) over the minibatch
     const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;
-    d = 2.0f * (T.pred[gr] - T.target[sr]) * A.inv_B;
+    const float v = T.pred[gr], R = T.target[sr];
+    d = 2.0f * (v - R) * A.inv_B;
+    if (T.lp_old) {
+      // use_value_clip (ppo.py:137-143): mean(max((v - R)^2, (v_clip - R)^2)), v_clip = v_old + clamp(v - v_old, +-clip_eps);
+      // lp_old carries the fixed values v_old [N].  torch.max splits ties evenly; clamp passes the gradient on [-eps, eps].
+      const float vo = T.lp_old[sr], dv = v - vo;
+      const float vc = vo + fminf(fmaxf(dv, -T.clip_eps), T.clip_eps);
+      const float inside = (dv >= -T.clip_eps && dv <= T.clip_eps) ? 1.0f : 0.0f;
+      const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+      const float w = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f);
+      d = 2.0f * (w * (v - R) + (1.0f - w) * (vc - R) * inside) * A.inv_B;
+    }
   } else if (T.loss == LOSS_PPO_POLICY) {
     // ppo.py:155-164: ratio = exp(logp - logp_old); -mean(min(ratio*A, clamp(ratio, 1+-eps)*A)); j indexes the mean
     const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;

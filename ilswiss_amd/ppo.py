@@ -50,9 +50,6 @@ class PPO(Trainer):
     def __init__(self, policy, vf, mini_batch_size=64, clip_eps=0.2, reward_scale=1.0, discount=0.99, policy_lr=3e-4,
                  value_lr=3e-4, gae_tau=0.9, value_l2_reg=1e-3, use_value_clip=False, update_epoch=10,
                  lambda_entropy_policy=0.0, max_samples=16384, **kwargs):
-        if use_value_clip:
-            raise NotImplementedError("use_value_clip=True (the clipped value loss of ppo.py:137-143) is not implemented: no spec of "
-                                      "the reference turns it on (default False, ppo.py:24)")
         self.on_policy = True  # ppo.py:30
         self.policy, self.vf, self.ctx = policy, vf, policy.ctx
         if vf.act != 1 or policy.act != 1:
@@ -63,7 +60,7 @@ class PPO(Trainer):
         self.o, self.a = policy.obs_dim, policy.action_dim
         cfg = _lib.PpoCfg(self.o, self.a, len(policy.hidden_sizes), policy.hidden_sizes[0], reward_scale, discount,
                           clip_eps, policy_lr, value_lr, gae_tau, value_l2_reg, self.mini_batch_size,
-                          self.update_epoch, self.max_samples)
+                          self.update_epoch, self.max_samples, int(bool(use_value_clip)))
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_ppo_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
         self.set_flat_params(policy.ppo_flat(), vf.get_flat_params())

@@ -247,6 +247,10 @@ int ilsx_sac_debug_batch(ilsx_sac* sac, ilsx_replay* rb, uint64_t step, int B, f
                          float* done, float* nobs, float* eps_next, float* eps_cur, int64_t* idx);
 int ilsx_sac_debug_last_batch(ilsx_sac* sac, int B, float* obs, float* act, float* rew, float* done, float* nobs,
                               float* eps_cur);
+/* Known-answer aid (tests only): device raw[n_rows*4] = the Philox4x32-10 block of counter (row, 0, step lo, step hi ^ stream*0x9E3779B9)
+ * under key (seed lo, seed hi ^ stream); device normals[n_rows*a] = the N(0,1) draws every stochastic policy epilogue of the library
+ * makes for (seed, step, stream, row, dim).  Either output nullable. */
+int ilsx_debug_philox(ilsx_ctx* ctx, uint64_t seed, uint64_t step, uint32_t stream, int n_rows, int a, uint32_t* raw, float* normals);
 
 /* ---------------------------------------------------------------- adversarial-IRL discriminator
  * Replaces rlkit/torch/algorithms/adv_irl/disc_models/simple_disc_models.py:8-48 (MLPDisc, use_bn=False),
@@ -255,11 +259,13 @@ int ilsx_sac_debug_last_batch(ilsx_sac* sac, int B, float* obs, float* act, floa
  * cfg fields == the YAML keys (exp_specs/gail/gail_walker.yaml:24-28,55-59). */
 enum { ILSX_DISC_AIRL = 0, ILSX_DISC_GAIL = 1, ILSX_DISC_GAIL2 = 2, ILSX_DISC_FAIRL = 3 };
 typedef struct {
-  int32_t obs_dim, act_dim;       /* discriminator input = cat(obs, act)  (state_only=False) */
+  int32_t obs_dim, act_dim;       /* discriminator input = cat(obs, act); state_only: cat(obs, next_obs), act_dim == obs_dim */
   int32_t hid_dim, hid_act;       /* 2 layer blocks of hid_dim (64/128/256), ILSX_ACT_* */
   int32_t use_grad_pen;
   float clamp_magnitude, disc_lr, disc_momentum, grad_pen_weight;
   int32_t max_batch;              /* disc_optim_batch_size upper bound (rows per class) */
+  int32_t state_only;             /* adv_irl.py:140-162,269: discriminator input = cat(obs, next_obs); act_dim must equal obs_dim and
+                                     every `act` row pointer of the entry points below carries next_obs rows */
 } ilsx_disc_cfg;
 typedef struct { float ce_loss, grad_pen, accuracy; } ilsx_disc_stats;   /* "Disc CE Loss", "Grad Pen", "Disc Acc" */
 int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_disc** out);
@@ -297,6 +303,9 @@ int ilsx_advirl_train(ilsx_disc* disc, ilsx_sac* policy_trainer, ilsx_replay* ex
                       int disc_updates, int policy_updates, int disc_batch, int policy_batch, int mode, int has_min,
                       float rew_clip_min, int has_max, float rew_clip_max, ilsx_disc_stats* disc_stats,
                       ilsx_sac_stats* sac_stats, float* rew_stats4);
+/* policy_optim_batch_size_from_expert (adv_irl.py:239-255): the last n_from_expert rows of every policy batch are drawn from the
+ * expert ring (torch.cat([policy rows, expert rows])), relabelled and trained on like the others.  0 (default) = off. */
+int ilsx_advirl_set_policy_batch_from_expert(ilsx_disc* disc, int n_from_expert);
 
 /* ---------------------------------------------------------------- TD3
  * Replaces rlkit/torch/algorithms/td3/td3.py:21-70 (ctor), :72-124 (train_step), :180-183 (soft updates).  cfg fields ==
@@ -397,6 +406,7 @@ typedef struct {
   float reward_scale, discount, clip_eps, policy_lr, value_lr, gae_tau, value_l2_reg;
   int32_t mini_batch_size, update_epoch;
   int32_t max_samples;            /* upper bound on the on-policy samples of one train call */
+  int32_t use_value_clip;         /* ppo.py:24,137-143: value loss = mean(max((v-R)^2, (v_old + clamp(v-v_old, +-clip_eps) - R)^2)) */
 } ilsx_ppo_cfg;
 int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo** out);
 int ilsx_ppo_destroy(ilsx_ppo* ppo);

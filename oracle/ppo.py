@@ -35,12 +35,14 @@ def gae_one_traj(values, rewards, discount, tau):
 
 class PPOOracle:
     def __init__(self, obs_dim, act_dim, hidden, pi_flat, vf_flat, reward_scale=1.0, discount=0.99, clip_eps=0.2,
-                 policy_lr=3e-4, value_lr=3e-4, gae_tau=0.9, value_l2_reg=1e-3, mini_batch_size=64, update_epoch=10):
+                 policy_lr=3e-4, value_lr=3e-4, gae_tau=0.9, value_l2_reg=1e-3, mini_batch_size=64, update_epoch=10,
+                 use_value_clip=False):
         self.o, self.a, self.hidden = obs_dim, act_dim, list(hidden)
         self.pi, self.vf = pi_flat.copy(), vf_flat.copy()
         self.reward_scale, self.discount, self.clip_eps = reward_scale, discount, clip_eps
         self.policy_lr, self.value_lr, self.tau, self.l2 = policy_lr, value_lr, gae_tau, value_l2_reg
         self.mb, self.epochs = mini_batch_size, update_epoch
+        self.use_value_clip = use_value_clip
         self.opt_pi, self.opt_vf = optim.AdamState(pi_flat.size), optim.AdamState(vf_flat.size)
 
     # ---- networks (tanh hidden)
@@ -69,11 +71,23 @@ class PPOOracle:
             obs.append(o); act.append(tr["actions"].astype(F32)); ret.append(R); adv.append(A); val.append(v)
         return (np.concatenate(obs), np.concatenate(act), np.concatenate(ret), np.concatenate(adv), np.concatenate(val))
 
-    def value_step(self, ob, R):
+    def value_step(self, ob, R, v_old=None):
         mbn = ob.shape[0]
         v, hs = self.v(ob)
-        loss = np.mean((v - R) ** 2, dtype=F32) + F32(self.l2) * np.sum(self.vf ** 2, dtype=F32)   # ppo.py:145-148
-        g, _ = mlp.backward(self.vf, hs, [F32(2) * (v - R) / F32(mbn)], self.o, self.hidden, 1, act=mlp.TANH, need_dx=False)
+        if self.use_value_clip:   # ppo.py:137-143
+            eps = F32(self.clip_eps)
+            dv = v - v_old
+            vc = v_old + np.clip(dv, -eps, eps)
+            l1, l2 = (v - R) ** 2, (vc - R) ** 2
+            mse = np.mean(np.maximum(l1, l2), dtype=F32)
+            w = np.where(l1 > l2, F32(1), np.where(l1 == l2, F32(0.5), F32(0)))            # torch.max tie rule
+            inside = ((dv >= -eps) & (dv <= eps)).astype(F32)                               # clamp passes grad on [-eps, eps]
+            dhead = F32(2) * (w * (v - R) + (F32(1) - w) * (vc - R) * inside) / F32(mbn)
+        else:
+            mse = np.mean((v - R) ** 2, dtype=F32)
+            dhead = F32(2) * (v - R) / F32(mbn)
+        loss = mse + F32(self.l2) * np.sum(self.vf ** 2, dtype=F32)   # ppo.py:145-148
+        g, _ = mlp.backward(self.vf, hs, [dhead.astype(F32)], self.o, self.hidden, 1, act=mlp.TANH, need_dx=False)
         g = (g + F32(2 * self.l2) * self.vf).astype(F32)
         optim.adam_step(self.vf, g, self.opt_vf, self.value_lr)
         return loss, g
@@ -103,12 +117,12 @@ class PPOOracle:
 
     def train_step(self, trajs, perms):
         """perms: list (one per epoch) of index permutations (torch.randperm in the reference, ppo.py:116)."""
-        obs, act, R, A, _ = self.calc_adv(trajs)
+        obs, act, R, A, V = self.calc_adv(trajs)
         lp_old = self.log_prob(obs, act)[0]
         out = dict(returns=R, advantages=A, fixed_log_probs=lp_old)
         for perm in perms:
             for s in range(0, len(perm), self.mb):
                 ind = perm[s:s + self.mb]
-                out["vf_loss"], out["vf_grad"] = self.value_step(obs[ind], R[ind])
+                out["vf_loss"], out["vf_grad"] = self.value_step(obs[ind], R[ind], V[ind])
                 out["pg_loss"], out["pi_grad"], out["pi_grad_norm"] = self.policy_step(obs[ind], act[ind], A[ind], lp_old[ind])
         return out

@@ -60,8 +60,8 @@ def experiment(variant, gpu=0, log_dir=None):
     training_env, eval_env, env = make_envs(variant, ctx, env_wrapper=wrapper, wrapper_kwargs=wrapper_kwargs)
     obs_dim, action_dim = training_env.obs_dim, training_env.act_dim
     p = dict(variant["adv_irl_params"])
-    if p.get("wrap_absorbing") or p.get("state_only"):
-        raise NotImplementedError("wrap_absorbing / state_only are off in the hot-path config (gail_walker.yaml:35,49)")
+    if p.get("wrap_absorbing"):
+        raise NotImplementedError("wrap_absorbing is off in the hot-path config (gail_walker.yaml:49)")
     expert_rb = EnvReplayBuffer(p["replay_buffer_size"], env, random_seed=int(np.random.randint(10000)), ctx=ctx)
     for tj in traj_list:                                           # adv_irl_exp_script.py:135-138
         expert_rb.add_path(tj, absorbing=False, env=env)
@@ -69,17 +69,15 @@ def experiment(variant, gpu=0, log_dir=None):
     qf1 = ia.FlattenMlp(hidden_sizes=hid, input_size=obs_dim + action_dim, output_size=1, ctx=ctx)
     qf2 = ia.FlattenMlp(hidden_sizes=hid, input_size=obs_dim + action_dim, output_size=1, ctx=ctx)
     policy = ia.ReparamTanhMultivariateGaussianPolicy(hidden_sizes=hid, obs_dim=obs_dim, action_dim=action_dim, ctx=ctx)
-    Bd, Bp = p.get("disc_optim_batch_size", 1024), p.get("policy_optim_batch_size", 1024)
-    disc = MLPDisc(obs_dim, action_dim, num_layer_blocks=variant["disc_num_blocks"], hid_dim=variant["disc_hid_dim"],
-                   hid_act=variant["disc_hid_act"], use_bn=variant["disc_use_bn"], clamp_magnitude=variant["disc_clamp_magnitude"],
-                   disc_lr=p.get("disc_lr", 1e-3), disc_momentum=p.get("disc_momentum", 0.0),
-                   use_grad_pen=p.get("use_grad_pen", True), grad_pen_weight=p.get("grad_pen_weight", 10.0), max_batch=Bd, ctx=ctx)
+    Bp = p.get("policy_optim_batch_size", 1024)
+    input_dim = obs_dim + (obs_dim if p.get("state_only") else action_dim)   # adv_irl_exp_script.py:164-166
+    disc = MLPDisc(input_dim, num_layer_blocks=variant["disc_num_blocks"], hid_dim=variant["disc_hid_dim"],
+                   hid_act=variant["disc_hid_act"], use_bn=variant["disc_use_bn"], clamp_magnitude=variant["disc_clamp_magnitude"], ctx=ctx)
     sac = ia.SoftActorCritic(policy=policy, qf1=qf1, qf2=qf2, env=env, max_batch=Bp, **variant["sac_params"])
-    trainer = AdvIRLTrainer(p["mode"], disc, sac, expert_rb, None, disc_optim_batch_size=Bd, policy_optim_batch_size=Bp,
-                            num_update_loops_per_train_call=p.get("num_update_loops_per_train_call", 1),
-                            num_disc_updates_per_loop_iter=p.get("num_disc_updates_per_loop_iter", 1),
-                            num_policy_updates_per_loop_iter=p.get("num_policy_updates_per_loop_iter", 1),
-                            rew_clip_min=p.get("rew_clip_min"), rew_clip_max=p.get("rew_clip_max"))
+    irl_keys = ("state_only", "disc_optim_batch_size", "policy_optim_batch_size", "policy_optim_batch_size_from_expert",
+                "num_update_loops_per_train_call", "num_disc_updates_per_loop_iter", "num_policy_updates_per_loop_iter", "disc_lr",
+                "disc_momentum", "use_grad_pen", "grad_pen_weight", "rew_clip_min", "rew_clip_max")
+    trainer = AdvIRLTrainer(p["mode"], disc, sac, expert_rb, **{k: p[k] for k in irl_keys if k in p})   # adv_irl.py:34-54 defaults otherwise
     loop_keys = ("num_epochs", "num_steps_per_epoch", "num_steps_between_train_calls", "max_path_length", "min_steps_before_training",
                  "eval_deterministic", "num_steps_per_eval", "replay_buffer_size", "no_terminal", "save_best", "freq_saving")
     alg = {k: p[k] for k in loop_keys if k in p}

@@ -170,12 +170,12 @@ def test_sac_steps_vs_oracle(ctx, o, a, H, nhid, B, kw):
         np.testing.assert_allclose(st["Log Pis Mean"], res["log_pi"].mean(), rtol=1e-4, atol=1e-5)
         for name, arr in (("Q1 Predictions", res["q1_pred"]), ("Q2 Predictions", res["q2_pred"]), ("Log Pis", res["log_pi"]),
                           ("Policy mu", res["policy_mean"]), ("Policy log std", res["policy_log_std"])):   # create_stats_ordered_dict
-            np.testing.assert_allclose(st[name + " Std"], arr.std(), rtol=2e-3, atol=2e-4, err_msg=name)
+            np.testing.assert_allclose(st[name + " Std"], arr.std(), rtol=1e-4, atol=1e-6, err_msg=name)
             np.testing.assert_allclose(st[name + " Max"], arr.max(), rtol=1e-4, atol=1e-5, err_msg=name)
             np.testing.assert_allclose(st[name + " Min"], arr.min(), rtol=1e-4, atol=1e-5, err_msg=name)
         for nm, key in (("qf1", "q1_grad"), ("qf2", "q2_grad"), ("policy", "pi_grad")):
             got, ref = tr.get_grads(nm), res[key]
-            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, (s, nm, np.abs(got - ref).max(), np.abs(ref).max())
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (s, nm, np.abs(got - ref).max(), np.abs(ref).max())
         np.testing.assert_allclose(tr.log_alpha, orc.log_alpha[0], rtol=0, atol=1e-6)
         for nm, ov in (("policy", orc.pi), ("qf1", orc.q1), ("qf2", orc.q2), ("target_qf1", orc.tq1), ("target_qf2", orc.tq2)):
             np.testing.assert_allclose(tr.get_params(nm), ov, rtol=0, atol=5e-5, err_msg=f"{nm} step {s}")
@@ -225,9 +225,14 @@ def test_sac_golden_small(ctx, name, kw):
             np.testing.assert_allclose(st[k_ref], g[k_g][s], rtol=2e-4, atol=2e-6, err_msg=f"{k_ref} step {s}")
         np.testing.assert_allclose(tr.log_alpha, g["log_alpha"][s], rtol=0, atol=1e-6)
         for nm, gk, ind, od, nh in (("qf1", "q1", o + a, 1, 1), ("qf2", "q2", o + a, 1, 1), ("policy", "pi", o, a, 2)):
+            # gradients against the FLOAT64 run of the reference (tools/make_golden.py `tr64`): its fp32 autograd carries
+            # cancellation noise on the log-prob path (Appendix A.1; up to 3e-5 of the largest entry in these fixtures), the float64
+            # run does not, so one bound serves all three networks: 1e-4 of the largest entry (§8c "1e-4 chained")
             got = _extract32(omlp, tr.get_grads(nm), ind, od, nh)
-            ref = g[f"s{s}_grad_{gk}"]
-            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, (s, nm)
+            ref = g[f"s{s}_grad_{gk}_f64"]
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (s, nm, np.abs(got - ref).max() / np.abs(ref).max())
+            ref32 = g[f"s{s}_grad_{gk}"]       # and the reference's own fp32 numbers at the same bound
+            assert np.abs(got - ref32).max() <= 1e-4 * np.abs(ref32).max(), (s, nm)
         for nm, gk, ind, od, nh in (("qf1", "q1", o + a, 1, 1), ("qf2", "q2", o + a, 1, 1), ("policy", "pi", o, a, 2),
                                     ("target_qf1", "tq1", o + a, 1, 1), ("target_qf2", "tq2", o + a, 1, 1)):
             got = _extract32(omlp, tr.get_params(nm), ind, od, nh)

@@ -91,7 +91,9 @@ def _run_sac_case(name, kw, full):
         if full:
             for nm, key in (("q1", "q1_grad"), ("q2", "q2_grad"), ("pi", "pi_grad")):
                 ref = g[f"s{s}_grad_{nm}"]
-                assert np.abs(res[key] - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, (s, nm)
+                assert np.abs(res[key] - ref).max() <= 1e-4 * np.abs(ref).max(), (s, nm)
+                ref64 = g[f"s{s}_grad_{nm}_f64"]    # the float64 run of the reference: the oracle sits at ~1e-7 of it
+                assert np.abs(res[key] - ref64).max() <= 2e-6 * np.abs(ref64).max(), (s, nm)
             for nm in ("pi", "q1", "q2", "tq1", "tq2"):
                 np.testing.assert_allclose(getattr(orc, nm), g[f"s{s}_{nm}"], rtol=0, atol=5e-5, err_msg=f"{nm} step {s}")
     for nm in ("pi", "q1", "q2", "tq1", "tq2"):

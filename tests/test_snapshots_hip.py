@@ -105,8 +105,8 @@ def test_disc_and_bc_snapshot_roundtrip(ctx):
     from ilswiss_amd.snapshot import get_opt, set_opt
     rng = np.random.default_rng(6)
     o, a, B = 17, 6, 64
-    d1 = MLPDisc(o, a, hid_dim=128, max_batch=B, ctx=ctx, seed=1)
-    d2 = MLPDisc(o, a, hid_dim=128, max_batch=B, ctx=ctx, seed=2)
+    d1 = MLPDisc(o + a, hid_dim=128, hid_act="tanh", use_bn=False, ctx=ctx, seed=1).bind(o, max_batch=B, disc_lr=3e-4, disc_momentum=0.9)
+    d2 = MLPDisc(o + a, hid_dim=128, hid_act="tanh", use_bn=False, ctx=ctx, seed=2).bind(o, max_batch=B, disc_lr=3e-4, disc_momentum=0.9)
 
     def rows():
         return (rng.normal(0, 1, (B, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32),

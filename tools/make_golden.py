@@ -9,6 +9,7 @@ inputs are drawn from seeded numpy generators, noise is injected (torch.randn wr
 plain arrays (inputs + the reference's outputs) are written.  While generating, every fixture is
 also cross-checked against our restatement in oracle/ so a broken oracle is caught here.
 """
+import copy
 import os
 import sys
 
@@ -179,6 +180,40 @@ def _sac_case(seed, o, a, Hh, B, steps, kwargs, full):
         opt.step = step
     hook(tr.qf1_optimizer, "q1", qf1), hook(tr.qf2_optimizer, "q2", qf2), hook(tr.policy_optimizer, "pi", pol)
 
+    # float64 shadow of the reference (the fp32 autograd of the log-prob path carries ~1e-4 of cancellation
+    # noise, so gradient fixtures are "compared against a float64 run of the reference"): the SAME reference classes with double
+    # modules; before every step its parameters, targets, log_alpha and optimiser states are loaded from the fp32 run, it takes the
+    # step on the same batch / noise, and only the gradients its optimisers see are kept.  Draws nothing from `rng`.
+    grads64 = {}
+    if full:
+        pol64 = ReparamTanhMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a).double()
+        qf164 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1).double()
+        qf264 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1).double()
+        tr64 = SoftActorCritic(policy=pol64, qf1=qf164, qf2=qf264, env=_Env(a), **kwargs)
+        tr64.target_qf1.double(), tr64.target_qf2.double()     # .copy() rebuilds the targets as float modules
+
+        def hook64(opt, name, mod):
+            orig = opt.step
+
+            def step(*aa, **kk):
+                grads64[name] = np.concatenate([p.grad.detach().numpy().ravel() for p in mod.parameters()]).astype(np.float64)
+                return orig(*aa, **kk)
+            opt.step = step
+        hook64(tr64.qf1_optimizer, "q1", qf164), hook64(tr64.qf2_optimizer, "q2", qf264), hook64(tr64.policy_optimizer, "pi", pol64)
+
+        def sync64():
+            with torch.no_grad():
+                for dst, src in ((pol64, pol), (qf164, qf1), (qf264, qf2), (tr64.target_qf1, tr.target_qf1), (tr64.target_qf2, tr.target_qf2)):
+                    for pd, ps in zip(dst.parameters(), src.parameters()):
+                        pd.copy_(ps.double())
+                tr64.log_alpha.copy_(tr.log_alpha)
+            tr64.alpha = tr.alpha.clone().double() if torch.is_tensor(tr.alpha) else tr.alpha
+            for od, os_ in ((tr64.qf1_optimizer, tr.qf1_optimizer), (tr64.qf2_optimizer, tr.qf2_optimizer),
+                            (tr64.policy_optimizer, tr.policy_optimizer), (tr64.alpha_optimizer, tr.alpha_optimizer)):
+                # deep copy first: load_state_dict keeps the `step` tensors by reference, and the shadow's step() would advance the
+                # fp32 run's counters in place; the load casts exp_avg / exp_avg_sq to the double parameters' dtype
+                od.load_state_dict(copy.deepcopy(os_.state_dict()))
+
     rec = dict(pi0=pi0, q10=q10, q20=q20, dims=np.array([o, a, B, steps] + list(Hh)))
     scal = {k: [] for k in ("qf1_loss", "qf2_loss", "policy_loss", "alpha_loss", "log_alpha",
                             "q1_mean", "q2_mean", "log_pi_mean", "mu_mean", "log_std_mean")}
@@ -191,6 +226,11 @@ def _sac_case(seed, o, a, Hh, B, steps, kwargs, full):
             next_observations=rng.normal(0, 1, (B, o)).astype(np.float32))
         e1 = rng.normal(0, 1, (B, a)).astype(np.float32)
         e2 = rng.normal(0, 1, (B, a)).astype(np.float32)
+        if full:
+            sync64()
+            with H.NoiseInjector() as inj:
+                inj.push(e1.astype(np.float64)), inj.push(e2.astype(np.float64))
+                tr64.train_step({k: t(v).double() for k, v in batch.items()})
         tr.eval_statistics = None
         with H.NoiseInjector() as inj:
             inj.push(e1), inj.push(e2)
@@ -214,6 +254,12 @@ def _sac_case(seed, o, a, Hh, B, steps, kwargs, full):
             rec.update({f"s{s}_{k}": v for k, v in batch.items()})
             rec.update({f"s{s}_eps_next": e1, f"s{s}_eps_cur": e2})
         if full:
+            for nm, g in (("q1", res["q1_grad"]), ("q2", res["q2_grad"]), ("pi", res["pi_grad"])):   # the oracle against the float64 reference
+                err = np.abs(grads64[nm] - g).max() / np.abs(grads64[nm]).max()
+                assert err < 1e-4, (s, nm, err)
+                print(f"   step {s} {nm}: oracle vs f64 reference {err:.2e} ; fp32 reference vs f64 reference "
+                      f"{np.abs(grads64[nm] - grads[nm]).max() / np.abs(grads64[nm]).max():.2e}")
+            rec.update({f"s{s}_grad_q1_f64": grads64["q1"], f"s{s}_grad_q2_f64": grads64["q2"], f"s{s}_grad_pi_f64": grads64["pi"]})
             rec.update({f"s{s}_grad_q1": grads["q1"], f"s{s}_grad_q2": grads["q2"], f"s{s}_grad_pi": grads["pi"],
                         f"s{s}_pi": get_flat(pol), f"s{s}_q1": get_flat(qf1), f"s{s}_q2": get_flat(qf2),
                         f"s{s}_tq1": get_flat(tr.target_qf1), f"s{s}_tq2": get_flat(tr.target_qf2)})
@@ -424,14 +470,104 @@ def gen_disc():
     save("g8_g9_disc", **out)
 
 
+def gen_disc_branches():
+    """G24: the AdvIRL branches the YAMLs leave off — state_only=True (adv_irl.py:140-162: discriminator input = cat(obs, next_obs);
+    :269 in the reward relabel) and policy_optim_batch_size_from_expert > 0 (:239-255: the policy batch = cat([rows from the policy
+    buffer, rows from the expert buffer]) along dim 0, relabelled as a whole) — by running AdvIRL._do_reward_training /
+    _do_policy_training as unbound functions on a namespace, as gen_disc does."""
+    import types
+    import torch.nn as nn
+    import torch.optim as optim
+    from rlkit.torch.algorithms.adv_irl.adv_irl import AdvIRL
+    from rlkit.torch.algorithms.adv_irl.disc_models.simple_disc_models import MLPDisc
+    from oracle.disc import DiscOracle, disc_reward, TANH
+    rng = np.random.default_rng(2424)
+    o, a, Hd, B, steps = 11, 3, 64, 16, 2
+    D = 2 * o
+    flat = omlp.init_mlp(rng, D, [Hd, Hd], 1, init_w=0.3, b_init=0.05)
+    disc = MLPDisc(D, num_layer_blocks=2, hid_dim=Hd, hid_act="tanh", use_bn=False, clamp_magnitude=10.0)
+    set_flat(disc, flat)
+    kw = dict(disc_lr=1e-3, disc_momentum=0.0, use_grad_pen=True, grad_pen_weight=10.0)   # the defaults of adv_irl.py:46-50
+    orc = DiscOracle(D, Hd, flat, act=TANH, **kw)
+    ns = types.SimpleNamespace(
+        discriminator=disc, disc_optimizer=optim.Adam(disc.parameters(), lr=kw["disc_lr"], betas=(kw["disc_momentum"], 0.999)),
+        state_only=True, wrap_absorbing=False, disc_optim_batch_size=B, bce=nn.BCEWithLogitsLoss(),
+        bce_targets=torch.cat([torch.ones(B, 1), torch.zeros(B, 1)], 0), use_grad_pen=True, grad_pen_weight=kw["grad_pen_weight"],
+        disc_eval_statistics=None)
+    out = dict(dims=np.array([o, a, Hd, B, steps]), params0=flat)
+
+    def rows(n, shift):
+        return dict(observations=rng.normal(shift, 1, (n, o)).astype(np.float32), actions=np.tanh(rng.normal(0, 1, (n, a))).astype(np.float32),
+                    rewards=rng.normal(0, 1, (n, 1)).astype(np.float32), terminals=(rng.random((n, 1)) < 0.2).astype(np.float32),
+                    next_observations=rng.normal(shift, 1, (n, o)).astype(np.float32))
+    for st in range(steps):
+        be, bp = rows(B, 0.4), rows(B, -0.3)
+        eps = rng.random((B, 1)).astype(np.float32)
+        seen = []
+        batches = {True: {k: t(v) for k, v in be.items()}, False: {k: t(v) for k, v in bp.items()}}
+
+        def get_batch(bs, from_expert, keys=None):
+            seen.append(tuple(keys))
+            return {k: batches[from_expert][k] for k in keys}
+        ns.get_batch = get_batch
+        ns.disc_eval_statistics = None
+        with H.NoiseInjector() as inj:
+            inj.push(eps)
+            AdvIRL._do_reward_training(ns, 0)
+        assert seen == [("observations", "next_observations")] * 2, seen     # actions are never asked for
+        stt = ns.disc_eval_statistics
+        xe, xp = np.concatenate([be["observations"], be["next_observations"]], 1), np.concatenate([bp["observations"], bp["next_observations"]], 1)
+        res = orc.train_step(xe, xp, eps)
+        assert np.allclose(stt["Disc CE Loss"], res["ce_loss"], rtol=1e-4, atol=1e-6)
+        assert np.allclose(stt["Grad Pen"] * 10.0, res["grad_pen_loss"], rtol=2e-3, atol=1e-5)
+        gref = get_flat_grad(disc)
+        assert np.abs(gref - res["grad"]).max() < 5e-3 * np.abs(gref).max()
+        assert np.abs(get_flat(disc) - orc.p).max() < 5e-5
+        for tag, b in (("exp", be), ("pol", bp)):
+            out.update({f"s{st}_{tag}_{k}": v for k, v in b.items()})
+        out.update({f"s{st}_eps": eps, f"s{st}_ce": stt["Disc CE Loss"], f"s{st}_gp": stt["Grad Pen"], f"s{st}_acc": stt["Disc Acc"],
+                    f"s{st}_grad": gref, f"s{st}_params": get_flat(disc)})
+    # ---- _do_policy_training with 5 of 16 rows from the expert buffer, state_only relabel, gail2 + clips
+    Bp_, nfe = 16, 5
+    bpol, bexp = rows(Bp_ - nfe, -0.3), rows(nfe, 0.4)
+    asked, got = [], {}
+
+    def get_batch2(bs, from_expert, keys=None):
+        asked.append((bs, from_expert))
+        src = bexp if from_expert else bpol
+        assert src["observations"].shape[0] == bs
+        return {k: t(v) for k, v in src.items()}
+
+    class Trainer:
+        def train_step(self, batch):
+            got.update({k: n(v) for k, v in batch.items()})
+    ns2 = types.SimpleNamespace(discriminator=disc, state_only=True, wrap_absorbing=False, policy_optim_batch_size=Bp_,
+                                policy_optim_batch_size_from_expert=nfe, get_batch=get_batch2, mode="gail2", clip_max_rews=True,
+                                clip_min_rews=True, rew_clip_max=-0.05, rew_clip_min=-3.0, policy_trainer=Trainer(), disc_eval_statistics={})
+    AdvIRL._do_policy_training(ns2, 0)
+    assert asked == [(Bp_ - nfe, False), (nfe, True)], asked
+    for k in ("observations", "actions", "terminals", "next_observations"):
+        assert np.array_equal(got[k], np.concatenate([bpol[k], bexp[k]])), k      # policy rows first, expert rows last
+    lg = orc.logits(np.concatenate([got["observations"], got["next_observations"]], 1))
+    assert np.allclose(disc_reward(lg, "gail2", rew_clip_min=-3.0, rew_clip_max=-0.05), got["rewards"], rtol=1e-4, atol=1e-5)
+    out.update({f"pt_pol_{k}": v for k, v in bpol.items()})
+    out.update({f"pt_exp_{k}": v for k, v in bexp.items()})
+    out.update(pt_rewards=got["rewards"], pt_dims=np.array([Bp_, nfe]), pt_clip=np.array([-3.0, -0.05], np.float32),
+               pt_rew_stats=np.array([ns2.disc_eval_statistics[k] for k in ("Disc Rew Mean", "Disc Rew Std", "Disc Rew Max", "Disc Rew Min")]))
+    save("g24_disc_branches", **out)
+
+
 def gen_ppo():
     """G7: PPO.calc_adv + train_step (ppo.py:57-170) on scripted trajectories with injected permutations.
     g7_ppo: ordinary regime; g7b_ppo_clip: narrow policy (log_std ~ -3) so that clip_grad_norm_(20) bites."""
     _gen_ppo_case("g7_ppo", 707, -0.3, 2)
     _gen_ppo_case("g7b_ppo_clip", 708, -3.0, 1)
+    # g7c: use_value_clip=True (ppo.py:137-143) with a small clip_eps and a larger value lr so that, over three epochs, v moves past
+    # v_old +- clip_eps on part of the rows: both branches of the max and both sides of the clamp carry gradient
+    _gen_ppo_case("g7c_ppo_vclip", 709, -0.3, 3, use_value_clip=True, clip_eps=0.1, value_lr=3e-3)
 
 
-def _gen_ppo_case(name, seed, ls_mean, epochs):
+def _gen_ppo_case(name, seed, ls_mean, epochs, **extra):
     from rlkit.torch.algorithms.ppo.ppo import PPO
     from rlkit.torch.common.networks import FlattenMlp
     from rlkit.torch.common.policies import ReparamMultivariateGaussianPolicy
@@ -440,6 +576,7 @@ def _gen_ppo_case(name, seed, ls_mean, epochs):
     o, a, Hh = 11, 3, [64, 64]
     kw = dict(reward_scale=1.0, discount=0.99, clip_eps=0.2, policy_lr=3e-4, value_lr=3e-4, gae_tau=0.95,
               value_l2_reg=1e-3, mini_batch_size=16, update_epoch=epochs)
+    kw.update(extra)
     vf = FlattenMlp(hidden_sizes=Hh, input_size=o, output_size=1, hidden_activation=torch.tanh)
     pol = ReparamMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a, conditioned_std=False,
                                             hidden_activation=torch.tanh)
@@ -485,6 +622,15 @@ def _gen_ppo_case(name, seed, ls_mean, epochs):
     for i, tj in enumerate(trajs):
         out.update({f"t{i}_{k}": v for k, v in tj.items()})
     out.update(epochs=np.array(epochs), pi_grad_norm_last=np.array(res["pi_grad_norm"]))
+    if extra:
+        out.update({"kw_" + k: np.array(v) for k, v in extra.items()})
+        if extra.get("use_value_clip"):   # how many rows ended outside the clip window (the fixture must exercise both branches)
+            v_end = orc.v(obs_)[0]
+            outside = np.abs(v_end - V_) > np.float32(kw["clip_eps"])
+            print(name, "rows with |v - v_old| > clip_eps after training:", int(outside.sum()), "of", outside.size)
+            print("   max |v-v_old|", float(np.abs(v_end - V_).max()), "count", int(outside.sum()), outside.size)
+            assert 0 < outside.sum()
+            out["n_outside_clip"] = np.array(int(outside.sum()))
     print(name, "last policy grad norm", res["pi_grad_norm"])
     save(name, **out)
 
@@ -1018,7 +1164,7 @@ def gen_her():
     save("g22_her_buffer", **rec)
 
 
-GROUPS = dict(replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+GROUPS = dict(disc_branches=gen_disc_branches, replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
 
 if __name__ == "__main__":
