@@ -22,6 +22,53 @@ from ilswiss_amd import _lib
 PEAK_HBM_GBS = 8000.0
 
 
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def sac_flops(o, a, H, B):
+    """ALGORITHMIC FLOPs of one SAC-alpha gradient step by profiling slot: 0 forward, 1 backward-to-activations,
+    2 weight gradients."""
+    Wq, Wp = (o + a) * H + H * H + H, o * H + H * H + 2 * H * a
+    fwd = 6 * Wq + 2 * Wp
+    bwd_dx = 2 * (H * H + H) + 2 * (H + H * H + H * a) + (H * H + 2 * H * a)
+    bwd_dw = 2 * Wq + Wp
+    return {0: 2 * B * fwd, 1: 2 * B * bwd_dx, 2: 2 * B * bwd_dw, "total": 2 * B * (fwd + bwd_dx + bwd_dw)}
+
+
+def prof_slots(ctx, fn):
+    """Run fn() with the library's per-launch HIP-event timing on; {slot: (kernel spelling as launched, launches, total ms)}."""
+    lib = ctx.lib
+    _lib.check(lib.ilsx_prof_reset(ctx.h))
+    _lib.check(lib.ilsx_prof_enable(ctx.h, 1))
+    fn()
+    _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
+    out = {}
+    for kid in range(16):
+        nl, ms = C.c_uint64(), C.c_double()
+        _lib.check(lib.ilsx_prof_read(ctx.h, kid, C.byref(nl), C.byref(ms)))
+        if nl.value:
+            name = lib.ilsx_prof_kernel(ctx.h, kid).decode().strip("()") or lib.ilsx_kernel_name(kid).decode()
+            out[kid] = (name, nl.value, ms.value)
+    return out
+
+
+def mfma_roofline(prof, flops_by_slot, note=None):
+    """`roofline` block of the dominant MFMA kernel of a leg: achieved = the slot's algorithmic FLOPs / its summed launch time (= average
+    FLOPs per launch / average launch duration)."""
+    cand = [k for k in prof if k in flops_by_slot and flops_by_slot[k] > 0]
+    if not cand:
+        return None
+    dom = max(cand, key=lambda k: prof[k][2])
+    name, nl, ms = prof[dom]
+    ach = flops_by_slot[dom] / (ms * 1e-3) / 1e12
+    r = dict(bound="mfma", kernel=name, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None,
+             avg_launch_us=1e3 * ms / nl, launches=nl, algorithmic_flop_per_launch=flops_by_slot[dom] / nl,
+             kernel_ms={prof[k][0]: prof[k][2] for k in prof})
+    if note:
+        r["note"] = note
+    return r
+
+
 def _kernel_time(ctx, kid, fn):
     lib = ctx.lib
     _lib.check(lib.ilsx_prof_reset(ctx.h))
@@ -92,6 +139,26 @@ def bench_ppo(ctx):
     ctx.sync()
     roll = time.perf_counter() - t0
     out["end_to_end"] = dict(iteration_s=it, rollout_s=roll, env_steps_per_s_rollout=N / roll, samples_per_s_whole_iteration=N / it)
+    # roofline of the update's dominant MFMA kernel: one ilsx_ppo_train call on the rollout just collected (calc_adv + 10 x 32 minibatches)
+    offs = (np.arange(n_env + 1) * T).astype(np.int32)
+    prof = prof_slots(ctx, lambda: (_lib.check(ctx.lib.ilsx_ppo_train(tr.h, obs_b.ptr, act_b.ptr, rew_b.ptr, offs.ctypes.data_as(C.c_void_p),
+                                                                       n_env, None, None)), ctx.sync()))
+    Wv, Wp = o * H + H * H + H, o * H + H * H + H * a
+    steps = 10 * (N // 32768)
+    fl = {0: 2.0 * N * (Wv + Wp) + steps * 2.0 * 32768 * (Wv + Wp),                  # calc_adv's two full forwards + every minibatch forward
+          1: steps * 2.0 * 32768 * ((H + H * H) + (H * a + H * H)),
+          2: steps * 2.0 * 32768 * (Wv + Wp)}
+    roof = mfma_roofline(prof, fl, "slot FLOPs: forward = 2N(Wv+Wp) [calc_adv] + 320 minibatches x 2*32768*(Wv+Wp); backward-to-activations and "
+                                   "weight gradients per minibatch likewise (Wv = oH+HH+H, Wp = oH+HH+Ha)")
+    g = out["gae"]
+    return dict(roofline=roof,
+                roofline_gae=dict(bound="hbm", kernel="k_ppo_gae", achieved=g["achieved_GBps"], peak=PEAK_HBM_GBS, unit="GB/s",
+                                  frac=g["frac_of_hbm_peak"], traffic=None, avg_launch_us=g["avg_launch_us"],
+                                  algorithmic_bytes_per_launch=g["algorithmic_bytes_per_launch"]),
+                **_ppo_line(out))
+
+
+def _ppo_line(out):
     return dict(metric="PPO Hopper-v2 dims, 8192 envs x 128-step rollout, GAE + minibatch update", unit="sample-updates/s",
                 value=out["mb32768"]["sample_updates_per_s"], dtype="f32", data="synthetic",
                 config=dict(workload="o=11,a=3, tanh 256-256 policy + value net, gamma .99, lambda .95, clip .2, 10 epochs; "
@@ -133,7 +200,18 @@ def bench_gail(ctx):
         alg._do_reward_training()
     ctx.sync()
     dtd = time.perf_counter() - t0
-    return dict(metric="GAIL Walker2d-v2 dims: discriminator step + SAC step", unit="loop-iterations/s", value=n / dt,
+    npf = 200
+    prof = prof_slots(ctx, lambda: (alg.train(npf), ctx.sync()))
+    D, Hd = o + a, 128
+    Wd = D * Hd + Hd * Hd + Hd
+    sf = sac_flops(o, a, H, B)
+    fl = {0: npf * (sf[0] + 2.0 * (3 * B + B) * Wd),                                  # SAC forwards + discriminator forward (3B rows) + relabel forward (B rows)
+          1: npf * sf[1],
+          2: npf * (sf[2] + 2.0 * (4 * B * (D * Hd + Hd * Hd) + 3 * B * Hd)),           # + the discriminator's row-stacked weight-gradient jobs
+          11: npf * 2.0 * (2 * B * Hd * Hd + B * (3 * Hd * Hd + 2 * D * Hd))}         # k_disc_bwd: GEMM 1 on all rows, GEMM 2/3 + the two W1 contractions on GP rows
+    roof = mfma_roofline(prof, fl, "per loop iteration: 1 discriminator step (k_disc_prep, forward over 3B rows, k_disc_bwd, stacked dW, Adam, tail) + "
+                                   "relabel forward + 1 SAC step (8 launches)")
+    return dict(roofline=roof, metric="GAIL Walker2d-v2 dims: discriminator step + SAC step", unit="loop-iterations/s", value=n / dt,
                 dtype="f32", data="synthetic",
                 config=dict(workload="o=17,a=6; disc 23-128-128-1 tanh, B=256+256, WGAN-GP weight 8; SAC 256-256, B=256, "
                                      "reward_scale 2, beta_1 0.25; expert buffer 4x1000 rows (gail_walker.yaml)"),
@@ -294,7 +372,14 @@ def bench_humanoid(ctx):
         e_, r_ = env.rollout_stats()
         ep, ret = ep + e_, ret + r_
     res["episodes"], res["mean_return"] = ep, (ret / ep if ep else None)
-    return dict(metric="SAC Humanoid-v2 share of one GPU: 4 seeds x 1024 envs, aggregate grad-steps/s in the loop", unit="grad-steps/s (aggregate)",
+    npf = 50
+    prof = prof_slots(ctx, lambda: (grp.train_from_replay(rbs, npf, B), ctx.sync()))
+    sf = sac_flops(o, a, H, B)
+    roof = mfma_roofline(prof, {k: K * npf * sf[k] for k in (0, 1, 2)},
+                         "grouped launches carry all 4 seeds; wide inputs run the forward as two launches (layer 0, then layer 1 + heads)")
+    res["stepper_kernel"] = dict(kernel="k_env3dw_step<23>", avg_launch_ms_1024_envs=res["env_step_kernel_ms_1024_envs"],
+                                 bound="neither (fp64 issue-bound, one wavefront per env; DESIGN 3b)")
+    return dict(roofline=roof, metric="SAC Humanoid-v2 share of one GPU: 4 seeds x 1024 envs, aggregate grad-steps/s in the loop", unit="grad-steps/s (aggregate)",
                 value=res["loop_grad_steps_per_s"], dtype="f32 (networks) / f64 (stepper)", data="synthetic",
                 config=dict(workload="4 co-resident SAC runs, Humanoid-v2 model (obs 376, act 17), 1024 envs each, 256-256 MLP, batch 256, "
                                      "1 vec-env step : 250 grad steps per run"), detail=res)

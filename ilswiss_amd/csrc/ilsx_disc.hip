@@ -597,3 +597,10 @@ extern "C" int ilsx_advirl_set_policy_batch_from_expert(ilsx_disc* d, int n_from
   d->from_expert = n_from_expert;
   return ILSX_OK;
 }
+
+int disc_debug_stream(const void* obj, uint32_t* stream, uint64_t* seed) {   // ilsx_debug_rng_stream (ilsx_sac.hip)
+  const ilsx_disc* d = (const ilsx_disc*)obj;
+  *stream = d->rng_stream;
+  if (seed) *seed = d->ctx->seed;
+  return ILSX_OK;
+}

@@ -934,6 +934,14 @@ extern "C" int ilsx_debug_philox(ilsx_ctx* ctx, uint64_t seed, uint64_t step, ui
   return ILSX_OK;
 }
 
+int disc_debug_stream(const void* d, uint32_t* stream, uint64_t* seed);   // ilsx_disc.hip
+extern "C" int ilsx_debug_rng_stream(const void* object, int kind, uint32_t* stream, uint64_t* seed) {
+  if (!object || !stream || kind < 0 || kind > 2) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_debug_rng_stream: bad argument");
+  if (kind == 0) { const ilsx_replay* rb = (const ilsx_replay*)object; *stream = rb->rng_stream; if (seed) *seed = rb->seed; return ILSX_OK; }
+  if (kind == 1) { const ilsx_sac* s = (const ilsx_sac*)object; *stream = s->rng_stream; if (seed) *seed = s->ctx->seed; return ILSX_OK; }
+  return disc_debug_stream(object, stream, seed);
+}
+
 extern "C" int ilsx_sac_debug_batch(ilsx_sac* s, ilsx_replay* rb, uint64_t step, int B, float* obs, float* act, float* rew,
                                     float* done, float* nobs, float* eps_next, float* eps_cur, int64_t* idx) {
   if (!s || !rb || B < 1 || B > s->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_debug_batch: bad argument");

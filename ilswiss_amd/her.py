@@ -8,6 +8,8 @@ are a few floats per sample and the reference's specs train one small batch per 
 relabelled batch is uploaded by `train_step` like any explicit batch.  The reference's goal envs are gym's Fetch robots (MuJoCo),
 which do not exist here: `PointReachEnv` below is a stand-in with the same dictionary interface, used by the smoke test only.
 """
+import random
+
 import numpy as np
 
 from .sac import SoftActorCritic
@@ -64,7 +66,8 @@ class MlpGaussianAndEpsilonPolicy(MlpGaussianNoisePolicy):
         self._epsilon, self._decay_period, self._action_space = epsilon, decay_period, action_space
         self.min_act, self.t = min_act, 0
         self.observation_key, self.desired_goal_key = observation_key, desired_goal_key
-        self._rs = np.random.RandomState(kwargs.get("seed", 0))
+        # exploration randomness comes from the GLOBAL `random` / `np.random` streams, which set_seed(variant seed) seeds — as in the
+        # reference (policies.py:537-552); a private RandomState here gave every variant seed the same exploration noise
 
     def set_num_steps_total(self, t):
         self.t = t
@@ -81,10 +84,10 @@ class MlpGaussianAndEpsilonPolicy(MlpGaussianNoisePolicy):
         action = super().get_actions(obs, deterministic=True)
         if deterministic:
             return action
-        if self._rs.random_sample() < self._epsilon:
+        if random.random() < self._epsilon:
             return np.array([self._action_space.sample() for _ in range(obs.shape[0])], np.float32)
         self.sigma = self._max_sigma - (self._max_sigma - self._min_sigma) * min(1.0, self.t * 1.0 / self._decay_period)
-        return np.clip(action + self._rs.normal(size=action.shape) * self.sigma, self.min_act, self.max_act).astype(np.float32)
+        return np.clip(action + np.random.normal(size=action.shape) * self.sigma, self.min_act, self.max_act).astype(np.float32)
 
     def get_action(self, obs_np, deterministic=False):
         return self.get_actions(self._flat(obs_np)[None], deterministic)[0], {}
@@ -178,8 +181,15 @@ class HindsightReplayBuffer:
             step = (self._np_rand_state.randint(0, traj_len, 1)[0] + starts[i]) % self._size
             indices.append(step)
             if relabel:
-                indices_relabel.append({"final": lambda: ends[i] - 1,
-                                        "future": lambda: np.random.randint(step, traj_len + starts[i]) % self._size}[self.relabel_type]())
+                # the reference builds an eager dict literal (relabel_replay_buffer.py:85-88): the `future` draw from the GLOBAL numpy
+                # stream happens for every relabelled sample whatever the relabel_type — drawn here too so later global draws agree
+                try:
+                    fut = np.random.randint(step, traj_len + starts[i])
+                except ValueError:      # empty range after ring wrap-around (the reference prints and exits, :89-91); harmless for `final`
+                    if self.relabel_type != "final":
+                        raise
+                    fut = 0
+                indices_relabel.append(ends[i] - 1 if self.relabel_type == "final" else fut % self._size)
         b = self._gather(indices)
         if relabel:
             n = int(self.her_ratio * batch_size)

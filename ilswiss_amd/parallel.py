@@ -104,7 +104,10 @@ class SplitRunStep:
         tr.actor_update()
 
     def train_from_replay(self, replay_shard, n_steps, local_batch_size):
-        """n fused steps, each rank drawing its B/G rows from ITS replay shard (stratified-uniform over the union, §8e)."""
+        """n fused steps, each rank drawing its B/G rows from ITS replay shard (stratified-uniform over the union, §8e).
+        The policy noise (eps_next / eps_cur) of a rank's rows is keyed by its ctx seed: give every rank its OWN ctx seed (the networks'
+        init seeds stay identical) — with one ctx seed for all ranks the shards draw identical eps rows and the B-row batch carries
+        G-fold correlated noise (bench.py:split_run_leg mixes the rank into the ctx seed)."""
         if not self.library:
             raise RuntimeError("train_from_replay needs the library communicator (a libilsx trainer)")
         return self.trainer.train_from_replay(replay_shard, n_steps, local_batch_size)

@@ -116,15 +116,21 @@ class SimpleReplayBuffer:
         idx = np.ascontiguousarray(indices, np.int64)
         B = idx.size
         o, a, ctx = self._observation_dim, self._action_dim, self.ctx
-        k_idx, p_idx = as_dev(ctx, idx, np.int64)
-        obs, act, rew, done, nobs = (ctx.empty((B, o)), ctx.empty((B, a)), ctx.empty((B,)), ctx.empty((B,)),
-                                     ctx.empty((B, o)))
-        _lib.check(ctx.lib.ilsx_replay_sample(self.h, B, p_idx, obs.ptr, act.ptr, rew.ptr, done.ptr, nobs.ptr, None))
-        absb = ctx.empty((B, 2))
-        _lib.check(ctx.lib.ilsx_replay_get_absorbing(self.h, p_idx, B, absb.ptr))
-        ret = dict(observations=obs.numpy(), actions=act.numpy(), rewards=rew.numpy().reshape(B, 1),
-                   terminals=done.numpy().reshape(B, 1).astype(np.uint8), next_observations=nobs.numpy(),
-                   absorbing=absb.numpy().astype(np.float64))
+        want_abs = keys is None or "absorbing" in keys
+        if B == 0:   # get_all() / a gather on an empty buffer returns empty arrays in the reference
+            ret = dict(observations=np.empty((0, o), np.float32), actions=np.empty((0, a), np.float32), rewards=np.empty((0, 1), np.float32),
+                       terminals=np.empty((0, 1), np.uint8), next_observations=np.empty((0, o), np.float32), absorbing=np.empty((0, 2)))
+        else:
+            k_idx, p_idx = as_dev(ctx, idx, np.int64)
+            obs, act, rew, done, nobs = (ctx.empty((B, o)), ctx.empty((B, a)), ctx.empty((B,)), ctx.empty((B,)),
+                                         ctx.empty((B, o)))
+            _lib.check(ctx.lib.ilsx_replay_sample(self.h, B, p_idx, obs.ptr, act.ptr, rew.ptr, done.ptr, nobs.ptr, None))
+            ret = dict(observations=obs.numpy(), actions=act.numpy(), rewards=rew.numpy().reshape(B, 1),
+                       terminals=done.numpy().reshape(B, 1).astype(np.uint8), next_observations=nobs.numpy())
+            if want_abs:   # one more launch + copy: only when the caller asks for the key
+                absb = ctx.empty((B, 2))
+                _lib.check(ctx.lib.ilsx_replay_get_absorbing(self.h, p_idx, B, absb.ptr))
+                ret["absorbing"] = absb.numpy().astype(np.float64)
         if keys is not None:
             ret = {k: v for k, v in ret.items() if k in keys}
         return ret

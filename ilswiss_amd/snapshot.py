@@ -38,16 +38,29 @@ def dump_replay(rb):
     trajectory end points of device-inserted rows are rebuilt from the `ep_end` flags."""
     size, top = rb._cursors()
     cap = rb._max_replay_buffer_size
+    if size == 0:
+        o, a = rb._observation_dim, rb._action_dim
+        return dict(observations=np.empty((0, o), np.float32), actions=np.empty((0, a), np.float32), rewards=np.empty(0, np.float32),
+                    terminals=np.empty(0, np.uint8), next_observations=np.empty((0, o), np.float32), ep_end=np.empty(0, np.uint8),
+                    absorbing=np.empty((0, 2), np.float32), capacity=cap)
     order = np.arange(size) if size < cap else (np.arange(cap) + top) % cap
     b = rb._gather(order)
     ends = np.zeros(size, np.uint8)
     pos = {int(s): i for i, s in enumerate(order)}
+    starts = set()
     for s, e in rb._traj_endpoints.items():
         last = (e - 1) % cap
         if last in pos:
             ends[pos[last]] = 1
+        starts.add(int(s))
+    # a trajectory whose start was overwritten in the ring leaves tail rows that belong to no registered trajectory: close that tail
+    # at the row before the oldest surviving trajectory start, so that restore does not merge it into the next trajectory
+    if starts:
+        first = min(pos[s] for s in starts if s in pos) if any(s in pos for s in starts) else None
+        if first is not None and first > 0:
+            ends[first - 1] = 1
     return dict(observations=b["observations"], actions=b["actions"], rewards=b["rewards"][:, 0], terminals=b["terminals"][:, 0],
-                next_observations=b["next_observations"], ep_end=ends, capacity=cap)
+                next_observations=b["next_observations"], ep_end=ends, absorbing=b["absorbing"].astype(np.float32), capacity=cap)
 
 
 def restore_replay(rb, dump):
@@ -55,8 +68,13 @@ def restore_replay(rb, dump):
     n = len(dump["rewards"])
     for i in range(0, n, 262144):
         sl = slice(i, min(n, i + 262144))
+        slot0 = rb._top
         rb.add_rows(dump["observations"][sl], dump["actions"][sl], dump["rewards"][sl], dump["terminals"][sl],
                     dump["next_observations"][sl], dump["ep_end"][sl])
+        ab = dump.get("absorbing")
+        if ab is not None and len(ab) and np.any(ab[sl]):     # the wrap_absorbing flags travel with the rows (simple_replay_buffer.py:66-67)
+            flags = np.ascontiguousarray(ab[sl], np.float32)
+            _lib.check(rb.ctx.lib.ilsx_replay_set_absorbing(rb.h, int(slot0), int(flags.shape[0]), flags.ctypes.data_as(C.c_void_p)))
 
 
 def load_from_file(algorithm, load_replay_buffer=False, load_model=True, load_path=None):

@@ -250,6 +250,9 @@ int ilsx_sac_debug_last_batch(ilsx_sac* sac, int B, float* obs, float* act, floa
 /* Known-answer aid (tests only): device raw[n_rows*4] = the Philox4x32-10 block of counter (row, 0, step lo, step hi ^ stream*0x9E3779B9)
  * under key (seed lo, seed hi ^ stream); device normals[n_rows*a] = the N(0,1) draws every stochastic policy epilogue of the library
  * makes for (seed, step, stream, row, dim).  Either output nullable. */
+/* kind: 0 = ilsx_replay, 1 = ilsx_sac (its two streams are id, id + 1: eps_next, eps_cur), 2 = ilsx_disc.  The Philox stream id the
+ * object was given at creation (ids are handed out per ctx in creation order) and the seed its draws are keyed by. */
+int ilsx_debug_rng_stream(const void* object, int kind, uint32_t* stream, uint64_t* seed);
 int ilsx_debug_philox(ilsx_ctx* ctx, uint64_t seed, uint64_t step, uint32_t stream, int n_rows, int a, uint32_t* raw, float* normals);
 
 /* ---------------------------------------------------------------- adversarial-IRL discriminator

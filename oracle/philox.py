@@ -58,3 +58,12 @@ def replay_draw(seed, step, stream, n, size):
     c = philox4x32_10(*_ctr_key(seed, step, stream, r >> np.uint32(2), 0x52425546))
     u = c[np.arange(n), r & np.uint32(3)].astype(np.uint64)
     return ((u * np.uint64(size)) >> np.uint64(32)).astype(np.int64)
+
+
+def disc_eps(seed, step, stream, B):
+    """The U[0,1) interpolation weights of the discriminator's gradient penalty (ptu.rand(B, 1), adv_irl.py:184) as k_disc_prep draws
+    them: row r takes word r & 3 of the block with counter (r >> 2, 'DISC'); w = (word >> 8) * 2^-24 (exact in fp32)."""
+    r = np.arange(B, dtype=np.uint32)
+    c = philox4x32_10(*_ctr_key(seed, step, stream, r >> np.uint32(2), 0x44495343))
+    u = c[np.arange(B), r & np.uint32(3)]
+    return ((u >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(B, 1)

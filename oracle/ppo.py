@@ -17,12 +17,13 @@ from .tanh_gaussian import gaussian_log_prob
 F32 = np.float32
 
 
-def gae_one_traj(values, rewards, discount, tau):
-    """ppo.py:73-86.  values, rewards: [T,1].  Returns (returns, normalised advantages, raw advantages)."""
+def gae_one_traj(values, rewards, discount, tau, bootstrap=0.0):
+    """ppo.py:73-86.  values, rewards: [T,1].  Returns (returns, normalised advantages, raw advantages).  bootstrap: V of the
+    observation after the last sample — 0 in the reference (ppo.py:74), V(s_T) for a segment cut by the end of a fixed rollout."""
     T = rewards.shape[0]
     deltas = np.zeros_like(values)
     adv = np.zeros_like(values)
-    prev_v, prev_a = F32(0), F32(0)
+    prev_v, prev_a = F32(bootstrap), F32(0)
     for i in reversed(range(T)):
         deltas[i] = rewards[i] + F32(discount) * prev_v - values[i]
         adv[i] = deltas[i] + F32(discount) * F32(tau) * prev_a

@@ -41,7 +41,11 @@ def _init(rng, o, a, hidden):
             omlp.init_mlp(rng, o + a, hidden, 1))
 
 
-def _check_against_oracle(tr, orc, tag):
+def _check_against_oracle(tr, orc, tag, res=None):
+    if res is not None:   # gradients of the LAST step taken (the arena keeps them): SURVEY §8c's chained-step bound, all three networks
+        for nm, key in (("qf1", "q1_grad"), ("qf2", "q2_grad"), ("policy", "pi_grad")):
+            got, ref = tr.get_grads(nm), res[key]
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (tag, nm, np.abs(got - ref).max() / np.abs(ref).max())
     np.testing.assert_allclose(tr.log_alpha, orc.log_alpha[0], rtol=0, atol=1e-6, err_msg=tag)
     for nm, ov in (("policy", orc.pi), ("qf1", orc.q1), ("qf2", orc.q2), ("target_qf1", orc.tq1), ("target_qf2", orc.tq2)):
         np.testing.assert_allclose(tr.get_params(nm), ov, rtol=0, atol=5e-5, err_msg=f"{nm} {tag}")
@@ -122,7 +126,7 @@ def test_fused_train_from_replay_matches_oracle(o, a, H, B, n_steps):
         np.testing.assert_array_equal(last[key], inputs[-1][0][key], err_msg=key)
     np.testing.assert_array_equal(eps_cur_used, inputs[-1][2])
     _check_stats(tr.get_eval_statistics(), res, "last step")
-    _check_against_oracle(tr, orc, f"after {n_steps} fused steps")
+    _check_against_oracle(tr, orc, f"after {n_steps} fused steps", res)
     ctx.close()
 
 
