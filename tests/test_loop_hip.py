@@ -58,6 +58,44 @@ def test_run_script_c1_plumbing(tmp_path, spec_name):
     assert alg.replay_buffer.num_steps_can_sample() == 800
 
 
+def test_reference_sac_hopper_yaml_key_set_runs_unchanged(tmp_path):
+    """Config 1: exp_specs/sac/sac_hopper.yaml:1-54 of the reference, typed in as the config schema it is — every key and value as the
+    reference ships it (meta_data.num_workers / using_gpus, wrap_absorbing, save_replay_buffer, vf_lr, env_num 4, batch 512, the two
+    unused seeds) — through the launcher's grid expansion and sac_alpha_exp_script.experiment.  Only the run LENGTH is cut for the test
+    (six numbers, no key added or removed): 102 epochs x 10000 steps would be 1M env steps."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "run_scripts"))
+    import sac_alpha_exp_script as script
+    spec = dict(
+        meta_data=dict(script_path="run_scripts/sac_alpha_exp_script.py", exp_name="test_sac_hopper",
+                       description="Train an agent using Soft-Actor-Critic", num_workers=2, using_gpus=True),
+        variables=dict(seed=[0]),
+        constants=dict(
+            net_size=256, num_hidden_layers=2,
+            rl_alg_params=dict(num_epochs=102, num_steps_per_epoch=10000, num_steps_between_train_calls=1000, num_train_steps_per_train_call=1000,
+                               num_steps_per_eval=10000, max_path_length=1000, min_steps_before_training=0, eval_deterministic=True,
+                               batch_size=512, replay_buffer_size=1000000, no_terminal=False, wrap_absorbing=False, save_best=True,
+                               freq_saving=1, save_replay_buffer=False),
+            sac_params=dict(alpha=0.2, reward_scale=1.0, discount=0.99, soft_target_tau=0.005, policy_lr=0.0003, qf_lr=0.0003, vf_lr=0.0003,
+                            policy_mean_reg_weight=0.001, policy_std_reg_weight=0.001),
+            env_specs=dict(env_name="hopper", env_kwargs={}, env_num=4, eval_env_seed=0, training_env_seed=0)))
+    keys_before = {k: sorted(v) for k, v in spec["constants"].items() if isinstance(v, dict)}
+    v = script.flatten_spec(spec)
+    assert v["seed"] == 0 and v["env_specs"]["env_num"] == 4 and v["rl_alg_params"]["batch_size"] == 512
+    v["rl_alg_params"].update(num_epochs=1, num_steps_per_epoch=400, num_steps_between_train_calls=100, num_train_steps_per_train_call=10,
+                              num_steps_per_eval=100, max_path_length=100)
+    assert {k: sorted(x) for k, x in v.items() if isinstance(x, dict) and k in keys_before} == keys_before      # same key set
+    alg = script.experiment(v, 0, str(tmp_path))
+    rows = list(csv.DictReader(open(tmp_path / "progress.csv")))
+    assert len(rows) == 2 and rows[-1]["Epoch"] == "1"
+    # min_steps_before_training 0 (the reference's value): training starts with the first 100-step gate -> 8 calls of 10 steps
+    assert float(rows[-1]["Number of train calls total"]) == 8 and float(rows[-1]["Number of env steps total"]) == 800
+    for k in ("Test Returns Mean", "QF1 Loss", "Policy Loss", "Alpha", "Train Time (s)", "Sample Time (s)"):
+        assert k in rows[-1] and np.isfinite(float(rows[-1][k])), k
+    assert os.path.exists(tmp_path / "params.pkl") and os.path.exists(tmp_path / "best.pkl")
+    assert alg.replay_buffer.num_steps_can_sample() == 800
+
+
 def test_sac_learns_on_hip_hopper():
     """A few thousand gradient steps must lift the deterministic policy well above the random policy."""
     import ilswiss_amd as ia
