@@ -270,6 +270,34 @@ def spawn_ranks(n, argv):
     return out
 
 
+def pin_to_gpu_numa(local):
+    """Best-effort NUMA pinning of this rank's host threads to the node its GPU hangs off (an 8-GPU MI355X box has 2 sockets; a rank
+    whose launch thread sits on the far socket pays a cross-socket hop on every doorbell write).  rocm-smi reports the node; anything
+    missing -> no pinning.  Returns what was done, for the `scaling` block."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showtoponuma", "--json"], capture_output=True, text=True, timeout=20).stdout
+        info = json.loads(out)
+        card = info.get(f"card{local}") or {}
+        node = next((int(v) for k, v in card.items() if "numa node" in k.lower() and str(v).lstrip("-").isdigit()), None)
+        if node is None or node < 0:
+            return dict(pinned=False, reason="rocm-smi reported no NUMA node")
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus)
+        return dict(pinned=True, numa_node=node, cpus=len(cpus))
+    except Exception as e:   # noqa: BLE001
+        return dict(pinned=False, reason=repr(e)[:120])
+
+
+RCCL_ENV_KEYS = ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_P2P_LEVEL", "NCCL_DEBUG", "RCCL_MSCCL_ENABLE",
+                 "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")
+
+
 class Ranks:
     """Process-group plumbing shared by the real run and the CPU dry run (tests/test_bench_spawn.py): backend "nccl" (= RCCL)
     on GPUs, "gloo" for --dry-run."""
@@ -306,6 +334,16 @@ class Ranks:
         import torch
         t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if self.dry else "cuda")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    def gather(self, value):
+        """value of every rank, in rank order (one float per rank)"""
+        if self.dist is None:
+            return [float(value)]
+        import torch
+        t = torch.zeros(self.world, dtype=torch.float64, device="cpu" if self.dry else "cuda")
+        t[self.rank] = float(value)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [float(x) for x in t.tolist()]
 
     def close(self):
@@ -382,10 +420,13 @@ def main():
         for _ in range(args.steps):
             time.sleep(0.001 * (1 + rank))     # rank r is slower: the max must pick the slowest
         R.barrier()
-        dt = R.max_over_ranks([time.perf_counter() - t0])[0]
+        mine = time.perf_counter() - t0
+        dt = R.max_over_ranks([mine])[0]
+        per_rank = R.gather(1e3 * mine / args.steps)
         if rank == 0:
             print(json.dumps(dict(metric="dry-run", dry_run=True, n_gpus=world, steps=args.steps, warmup=args.warmup,
-                                  ms_per_step=1e3 * dt / args.steps, value=world * args.steps / dt)))
+                                  ms_per_step=1e3 * dt / args.steps, value=world * args.steps / dt,
+                                  scaling_detail=dict(per_rank_ms=per_rank, max_over_min=max(per_rank) / min(per_rank)))))
         R.close()
         return None
 
@@ -393,6 +434,7 @@ def main():
 
     import ilswiss_amd as ia
     from ilswiss_amd import _lib
+    numa = pin_to_gpu_numa(local) if world > 1 or os.environ.get("ILSX_BENCH_PIN") else dict(pinned=False, reason="single rank")
     ctx = ia.Context(local, seed=1000 + rank)   # independent seed per replica
     lib = ctx.lib
     hid = [H, H]
@@ -432,6 +474,7 @@ def main():
         t_train += a2 - a1
     R.barrier(ctx)
     dt = time.perf_counter() - t0
+    per_rank_ms = R.gather(1e3 * dt / args.steps)
     dt, t_sample, t_train = R.max_over_ranks([dt, t_sample, t_train])
     want_split = (world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST")) and not args.no_split_run
 
@@ -505,7 +548,14 @@ def main():
                                  "(sac_hopper.yaml:17-20)", env=ro.describe(), replicas=world,
                         parallelism=f"{world} independent replicas (seed sharding, no collective)"),
             env_steps_per_s=env_total / dt, env_steps_per_s_sample_phase=env_total / t_sample,
-            grad_steps_per_s_train_phase=grad_total / t_train, roofline=roofline, roofline_replay=roofline_replay)
+            grad_steps_per_s_train_phase=grad_total / t_train, roofline=roofline, roofline_replay=roofline_replay,
+            # per-rank step times behind the max-over-ranks `value` (the driver computes efficiency itself from its per-N runs); the
+            # replica leg has NO data-path collective, so a slow rank is a placement / clock matter, not a communication one
+            scaling_detail=dict(per_rank_ms=per_rank_ms, max_over_min=max(per_rank_ms) / min(per_rank_ms), numa_rank0=numa,
+                                rccl_env={k: os.environ[k] for k in RCCL_ENV_KEYS if k in os.environ},
+                                note="RCCL is used for the barrier + max-time of this leg and for the gradient all-reduce of `split_run` "
+                                     "only; message sizes there are 0.55 MB (critics) and 0.28 MB (actor | alpha): latency-bound on "
+                                     "xGMI, so NCCL_ALGO / NCCL_PROTO are left to RCCL's tuner unless set in the environment"))
         if world == 1 and not args.no_seeds:
             result["co_resident_seeds"] = co_resident_seeds()
         if world == 1 and not args.no_aux:

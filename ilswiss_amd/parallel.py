@@ -108,6 +108,11 @@ class SplitRunStep:
         The policy noise (eps_next / eps_cur) of a rank's rows is keyed by its ctx seed: give every rank its OWN ctx seed (the networks'
         init seeds stay identical) — with one ctx seed for all ranks the shards draw identical eps rows and the B-row batch carries
         G-fold correlated noise (bench.py:split_run_leg mixes the rank into the ctx seed)."""
-        if not self.library:
-            raise RuntimeError("train_from_replay needs the library communicator (a libilsx trainer)")
-        return self.trainer.train_from_replay(replay_shard, n_steps, local_batch_size)
+        if self.library:
+            return self.trainer.train_from_replay(replay_shard, n_steps, local_batch_size)
+        # host engines (the CPU tests: gloo + the numpy oracle): the same loop, one random_batch of the local shard per step
+        for _ in range(int(n_steps)):
+            b = replay_shard.random_batch(int(local_batch_size))
+            noise = getattr(self.trainer, "draw_noise", None)
+            e1, e2 = noise(int(local_batch_size)) if noise else (None, None)
+            self.train_step(b, e1, e2)

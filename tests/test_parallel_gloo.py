@@ -114,3 +114,72 @@ def test_two_rank_split_run_equals_single_process():
         np.testing.assert_allclose(r[2], single.o.q1, rtol=0, atol=2e-6)
         np.testing.assert_allclose(r[3], single.o.tq2, rtol=0, atol=2e-6)
         np.testing.assert_allclose(r[4], single.o.log_alpha[0], rtol=0, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------- split run FROM REPLAY SHARDS
+# SURVEY §8e / parallel.py: in a split run every rank draws its B/G rows from ITS OWN replay shard; the union of the ranks' draws is a
+# stratified-uniform B-row sample of the union of the shards, and the step on it is the single-process step on the concatenated batch.
+SHARD_ROWS = 500
+
+
+class ShardOracle:
+    """random_batch over oracle.replay.ReplayOracle (the reference's RandomState.randint draw, simple_replay_buffer.py:242)."""
+
+    def __init__(self, rank):
+        from oracle.replay import ReplayOracle
+        rng = np.random.default_rng(1000 + rank)
+        self.rb = ReplayOracle(SHARD_ROWS, O, A, random_seed=77 + rank)
+        n = SHARD_ROWS
+        self.rb.add_rows(rng.normal(rank, 1, (n, O)).astype(np.float32), np.tanh(rng.normal(0, 1, (n, A))).astype(np.float32),
+                         rng.normal(0, 1, n).astype(np.float32), (rng.random(n) < 0.1).astype(np.uint8), rng.normal(rank, 1, (n, O)).astype(np.float32))
+        self.noise = np.random.default_rng(2000 + rank)      # per-rank policy noise (a shared stream would correlate the shards' rows)
+
+    def random_batch(self, batch_size):
+        b = self.rb.gather(self.rb.draw_indices(batch_size))
+        b["terminals"] = b["terminals"].astype(np.float32)
+        return b
+
+    def draw_noise(self, n):
+        return self.noise.normal(0, 1, (n, A)).astype(np.float32), self.noise.normal(0, 1, (n, A)).astype(np.float32)
+
+
+def _replay_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = OracleTrainer(world)
+    shard = ShardOracle(rank)
+    tr.draw_noise = shard.draw_noise
+    SplitRunStep(tr).train_from_replay(shard, 4, B // world)
+    q.put((rank, tr.o.pi.copy(), tr.o.q1.copy(), tr.o.tq2.copy(), float(tr.o.log_alpha[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_from_replay_shards_is_the_stratified_batch_step():
+    world, port = 2, _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_replay_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # one process replays both shards' draws and steps on the concatenation: B/2 rows of shard 0, then B/2 rows of shard 1
+    shards = [ShardOracle(r) for r in range(world)]
+    single = OracleTrainer(1)
+    seen0, seen1 = [], []
+    for _ in range(4):
+        parts = [(s.random_batch(B // world), s.draw_noise(B // world)) for s in shards]
+        batch = {k: np.concatenate([p[0][k] for p in parts]) for k in parts[0][0]}
+        e1, e2 = np.concatenate([p[1][0] for p in parts]), np.concatenate([p[1][1] for p in parts])
+        seen0.append(parts[0][0]["observations"].mean()), seen1.append(parts[1][0]["observations"].mean())
+        single.o.train_step(batch, e1, e2)
+    assert abs(np.mean(seen0)) < 0.3 and abs(np.mean(seen1) - 1.0) < 0.3        # stratified: exactly half the rows from each shard's distribution
+    for r in res:
+        np.testing.assert_array_equal(r[1], res[0][1])                            # replicas took identical optimiser steps
+        np.testing.assert_allclose(r[1], single.o.pi, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r[2], single.o.q1, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r[3], single.o.tq2, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r[4], single.o.log_alpha[0], rtol=0, atol=1e-7)
