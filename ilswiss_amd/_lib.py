@@ -176,6 +176,7 @@ PROTOTYPES = {
     "ilsx_ppo_policy_act": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "ilsx_disc_create": (C.c_int, [vp, C.POINTER(DiscCfg), C.POINTER(vp)]),
     "ilsx_advirl_set_policy_batch_from_expert": (C.c_int, [vp, C.c_int]),
+    "ilsx_her_gather": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]),
     "ilsx_debug_rng_stream": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "ilsx_debug_philox": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp, vp]),
     "ilsx_disc_destroy": (C.c_int, [vp]),

@@ -54,6 +54,51 @@ __global__ __launch_bounds__(256) void k_replay_sample(const float* __restrict__
   if (idx_out && c == 0) idx_out[r] = row;
 }
 
+// Hindsight relabelling gather (rlkit/data_management/relabel_replay_buffer.py:66-163): the ring's observation segment is
+// [observation (d_obs) | desired_goal (dg) | achieved_goal (dg)].  Row r of the batch is record idx[r]; for the first n_relabel rows the
+// desired goal (of the observation AND of the next observation, :106-113) is replaced by the ACHIEVED goal of the NEXT observation of
+// record idx_rel[r] (the `future` / `final` index the host drew in the reference's RandomState order); when relabelling is on, EVERY
+// row's reward is recomputed from (next achieved goal, desired goal) (:139-147) with the goal env's sparse / dense rule.  Outputs are
+// what the goal-conditioned trainers consume (her/td3.py:95-99): obs_cat = observation | desired_goal, nobs_cat likewise.
+// One thread per (row, output column of obs_cat).
+__global__ __launch_bounds__(256) void k_her_gather(const float* __restrict__ data, int rec, const long long* __restrict__ idx,
+                                                    const long long* __restrict__ idx_rel, int B, int n_relabel, int relabel_on,
+                                                    int d_obs, int dg, int a, int reward_kind, float threshold,
+                                                    float* __restrict__ obs_cat, float* __restrict__ act, float* __restrict__ rew,
+                                                    float* __restrict__ done, float* __restrict__ nobs_cat) {
+  const int W = d_obs + dg, e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * W) return;
+  const int r = e / W, c = e - r * W, o = d_obs + 2 * dg;
+  const float* R = data + (size_t)idx[r] * rec;
+  const float* nob = R + o + a + 2;                    // next observation segment of this record
+  const bool rl = relabel_on && r < n_relabel;
+  const float* gsrc = rl ? data + (size_t)idx_rel[r] * rec + o + a + 2 + d_obs + dg : nullptr;   // next achieved goal of the relabel record
+  if (c < d_obs) {
+    obs_cat[(size_t)r * W + c] = R[c];
+    nobs_cat[(size_t)r * W + c] = nob[c];
+  } else {
+    const int j = c - d_obs;
+    obs_cat[(size_t)r * W + c] = rl ? gsrc[j] : R[d_obs + j];
+    nobs_cat[(size_t)r * W + c] = rl ? gsrc[j] : nob[d_obs + j];
+  }
+  if (c < a) act[(size_t)r * a + c] = R[o + c];
+  if (c == 0) {
+    done[r] = R[o + a + 1];
+    float rv = R[o + a];
+    if (relabel_on) {   // compute_reward(next_achieved_goals, desired_goals): gym's GoalEnv rule — sparse -(d > threshold), dense -d
+      float d2 = 0.0f;
+      for (int j = 0; j < dg; ++j) {
+        const float g = rl ? gsrc[j] : R[d_obs + j];
+        const float df = nob[d_obs + dg + j] - g;
+        d2 = fmaf(df, df, d2);
+      }
+      const float dist = sqrtf(d2);
+      rv = reward_kind == 0 ? (dist > threshold ? -1.0f : 0.0f) : -dist;
+    }
+    rew[r] = rv;
+  }
+}
+
 // Bandwidth form: n_batches*B whole records per launch, 16 bytes per lane.
 __global__ __launch_bounds__(256) void k_replay_sample_many(const float4* __restrict__ data, int rec4, const DevReplayState* st,
                                                             uint64_t seed, uint32_t stream, unsigned long long step0, int B,
@@ -349,5 +394,25 @@ extern "C" int ilsx_replay_traj_endpoints(ilsx_replay* rb, int64_t* starts, int6
     ++k;
   }
   *n = k;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_her_gather(ilsx_replay* rb, const int64_t* idx, const int64_t* idx_relabel, int B, int n_relabel, int relabel_on,
+                               int d_obs, int d_goal, int reward_kind, float threshold, float* obs_cat, float* act, float* rew,
+                               float* done, float* nobs_cat) {
+  if (!rb || !idx || B < 1 || !obs_cat || !act || !rew || !done || !nobs_cat) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_her_gather: bad argument");
+  if (d_obs < 1 || d_goal < 1 || d_obs + 2 * d_goal != rb->o)
+    ILSX_FAIL(ILSX_ERR_ARG, "ilsx_her_gather: ring observation width %d != d_obs %d + 2 * d_goal %d", rb->o, d_obs, d_goal);
+  if (rb->a > d_obs + d_goal) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "ilsx_her_gather: act_dim %d > d_obs + d_goal %d", rb->a, d_obs + d_goal);
+  if (relabel_on && (n_relabel < 0 || n_relabel > B || (n_relabel > 0 && !idx_relabel))) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_her_gather: n_relabel / idx_relabel");
+  if (reward_kind < 0 || reward_kind > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_her_gather: reward_kind must be 0 (sparse) or 1 (dense)");
+  if (rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_her_gather: buffer is empty");
+  HIPCHK(hipSetDevice(rb->ctx->device));
+  const int total = B * (d_obs + d_goal);
+  ProfScope ps(rb->ctx, ILSX_K_REPLAY_SAMPLE);
+  ILSX_LAUNCH(ps, k_her_gather, dim3((total + 255) / 256), dim3(256), 0, rb->ctx->stream, rb->data, rb->rec, (const long long*)idx,
+              (const long long*)idx_relabel, B, n_relabel, relabel_on, d_obs, d_goal, rb->a, reward_kind, threshold, obs_cat, act, rew,
+              done, nobs_cat);
+  HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

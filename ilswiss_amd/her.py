@@ -4,8 +4,9 @@ relabelling buffer (rlkit/data_management/relabel_replay_buffer.py), the explora
 
 The gradient steps run on the device (the TD3 / SAC-alpha kernels; `ilsx_td3_cfg.her` switches on the three places where
 her/td3.py departs from td3.py).  The buffer keeps the reference's dictionary observations in host memory and relabels there — goals
-are a few floats per sample and the reference's specs train one small batch per env step, so this is not a throughput path; the
-relabelled batch is uploaded by `train_step` like any explicit batch.  The reference's goal envs are gym's Fetch robots (MuJoCo),
+are a few floats per sample and the reference's specs train one small batch per env step.  `HindsightReplayBuffer` is the host form (any python
+`compute_reward`); `DeviceHindsightReplayBuffer` keeps the rows in an HBM ring and relabels in one gather kernel (ilsx_her_gather), so
+HER batches do not cross PCIe either — the HER loop uses it whenever the env exposes gym's sparse / dense goal reward rule.  The reference's goal envs are gym's Fetch robots (MuJoCo),
 which do not exist here: `PointReachEnv` below is a stand-in with the same dictionary interface, used by the smoke test only.
 """
 import random
@@ -18,6 +19,8 @@ from .td3 import TD3 as _TD3, MlpGaussianNoisePolicy
 
 def _cat(batch):
     """her/td3.py:95-99, her/sac.py:80-84: networks see observation | desired_goal."""
+    if batch.get("_her_cat"):      # DeviceHindsightReplayBuffer: already concatenated on the device by ilsx_her_gather
+        return {k: v for k, v in batch.items() if k != "_her_cat"}
     out = dict(batch)
     out["observations"] = np.concatenate([np.asarray(batch["observations"], np.float32), np.asarray(batch["desired_goals"], np.float32)], -1)
     out["next_observations"] = np.concatenate([np.asarray(batch["next_observations"], np.float32),
@@ -207,6 +210,108 @@ class HindsightReplayBuffer:
         return b
 
 
+class DeviceHindsightReplayBuffer(HindsightReplayBuffer):
+    """The same buffer with its rows in an HBM ring: cursors, `_traj_endpoints` and every random draw stay the
+    reference's (host integers, the reference's RandomState call order — g22 pins them), but the transitions live in an `ilsx_replay`
+    ring whose observation segment is observation | desired_goal | achieved_goal, and `random_batch` is ONE gather kernel
+    (ilsx_her_gather: goal overwrite for the first her_ratio * B rows, reward recompute for all rows, observation | goal concatenation)
+    whose outputs feed the trainer's device entry point directly: 2 x B int64 indices go up per batch, no batch comes down.
+
+    The reward rule is gym's GoalEnv one, evaluated on the device: sparse -(|achieved - goal| > distance_threshold) or dense -|.|, read
+    from the env (`reward_type`, `distance_threshold`, as gym's Fetch envs expose them)."""
+
+    def __init__(self, max_replay_buffer_size, env, random_seed=1995, relabel_type="future", her_ratio=0.8, observation_key="observation",
+                 desired_goal_key="desired_goal", achieved_goal_key="achieved_goal", ctx=None):
+        import ctypes as C
+        from . import _lib
+        from .device import get_context
+        self._np_rand_state = np.random.RandomState(random_seed)
+        self._max_replay_buffer_size = cap = int(max_replay_buffer_size)
+        spaces = env.observation_space.spaces
+        self._action_dim = int(np.prod(env.action_space.shape))
+        self.her_ratio, self.relabel_type = her_ratio, relabel_type
+        self.observation_key, self.desired_goal_key, self.achieved_goal_key = observation_key, desired_goal_key, achieved_goal_key
+        self.d_obs, self.d_goal = int(np.prod(spaces[observation_key].shape)), int(np.prod(spaces[desired_goal_key].shape))
+        assert int(np.prod(spaces[achieved_goal_key].shape)) == self.d_goal
+        self.reward_kind = 0 if getattr(env, "reward_type", "sparse") == "sparse" else 1
+        self.threshold = float(getattr(env, "distance_threshold", getattr(env, "tol", 0.05)))
+        self.ctx = ctx or get_context()
+        self._C, self._lib = C, _lib
+        self.h = C.c_void_p()
+        _lib.check(self.ctx.lib.ilsx_replay_create(self.ctx.h, cap, self.d_obs + 2 * self.d_goal, self._action_dim, C.c_uint64(random_seed),
+                                                   C.byref(self.h)))
+        self._top = self._size = self._cur_start = 0
+        self._traj_endpoints = {}
+        self._out = None
+
+    def _row(self, d):
+        return np.concatenate([np.asarray(d[self.observation_key], np.float32).ravel(), np.asarray(d[self.desired_goal_key], np.float32).ravel(),
+                               np.asarray(d[self.achieved_goal_key], np.float32).ravel()])[None]
+
+    def add_sample(self, observation, action, reward, terminal, next_observation, **kwargs):
+        assert isinstance(observation, dict), "Observation should be dict!"
+        C = self._C
+        obs, nobs = self._row(observation), self._row(next_observation)
+        act = np.asarray(action, np.float32).reshape(1, self._action_dim)
+        rew, done = np.asarray([reward], np.float32), np.asarray([1 if terminal else 0], np.uint8)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)   # noqa: E731
+        self._lib.check(self.ctx.lib.ilsx_replay_add(self.h, p(obs), p(act), p(rew), p(done), p(nobs), 1, None, 0))
+        t = self._top                               # host cursors exactly as the parent's (the ring's own cursor moves in step)
+        if terminal:
+            nxt = (t + 1) % self._max_replay_buffer_size
+            self._traj_endpoints[self._cur_start] = nxt
+            self._cur_start = nxt
+        if self._top in self._traj_endpoints:
+            del self._traj_endpoints[self._top]
+        self._top = (self._top + 1) % self._max_replay_buffer_size
+        if self._size < self._max_replay_buffer_size:
+            self._size += 1
+
+    def random_batch(self, batch_size, keys=None, **kwargs):
+        """Same draws as the parent (relabel_replay_buffer.py:66-100); the gather, relabel and reward run on the device.  Returns device
+        arrays: observations / next_observations are observation | desired_goal rows ready for the goal-conditioned trainers."""
+        C, B = self._C, int(batch_size)
+        relabel = (self.relabel_type is not None) and (self.her_ratio > 0)
+        keys_list = list(self._traj_endpoints.keys())
+        starts = self._np_rand_state.choice(keys_list, size=len(keys_list), replace=False)
+        ends = [self._traj_endpoints[k] for k in starts]
+        traj_indice = self._np_rand_state.randint(0, len(starts), B)
+        indices, indices_relabel = [], []
+        for i in traj_indice:
+            traj_len = (ends[i] - starts[i]) % self._size
+            step = (self._np_rand_state.randint(0, traj_len, 1)[0] + starts[i]) % self._size
+            indices.append(step)
+            if relabel:
+                try:
+                    fut = np.random.randint(step, traj_len + starts[i])
+                except ValueError:
+                    if self.relabel_type != "final":
+                        raise
+                    fut = 0
+                indices_relabel.append(ends[i] - 1 if self.relabel_type == "final" else fut % self._size)
+        ctx, W, a = self.ctx, self.d_obs + self.d_goal, self._action_dim
+        if self._out is None or self._out[0] != B:
+            self._out = (B, ctx.empty((B, W)), ctx.empty((B, a)), ctx.empty((B,)), ctx.empty((B,)), ctx.empty((B, W)),
+                         ctx.empty((B,), np.int64), ctx.empty((B,), np.int64))
+        _, obs, act, rew, done, nobs, di, dr = self._out
+        di.copy_from(np.asarray(indices, np.int64))
+        if relabel:
+            dr.copy_from(np.asarray(indices_relabel, np.int64))
+        n = int(self.her_ratio * B) if relabel else 0
+        self._lib.check(ctx.lib.ilsx_her_gather(self.h, di.ptr, dr.ptr if relabel else None, B, n, int(relabel), self.d_obs, self.d_goal,
+                                                self.reward_kind, self.threshold, obs.ptr, act.ptr, rew.ptr, done.ptr, nobs.ptr))
+        return dict(observations=obs, actions=act, rewards=rew, terminals=done, next_observations=nobs, _her_cat=True)
+
+    def numpy_batch(self, batch):
+        """A device batch split back into the reference's keys (tests)."""
+        o = self.d_obs
+        ob, nob = batch["observations"].numpy(), batch["next_observations"].numpy()
+        B = ob.shape[0]
+        return dict(observations=ob[:, :o], desired_goals=ob[:, o:], next_observations=nob[:, :o], next_desired_goals=nob[:, o:],
+                    actions=batch["actions"].numpy(), rewards=batch["rewards"].numpy().reshape(B, 1),
+                    terminals=batch["terminals"].numpy().reshape(B, 1).astype(np.uint8))
+
+
 class Box:
     def __init__(self, low, high):
         self.low, self.high = np.asarray(low, np.float32), np.asarray(high, np.float32)
@@ -260,8 +365,13 @@ class HER:
                  min_steps_before_training=1000, batch_size=128, replay_buffer_size=100000, num_steps_per_eval=500, **kwargs):
         assert max_path_length < replay_buffer_size
         self.trainer, self.env, self.policy = trainer, env, exploration_policy
-        self.replay_buffer = replay_buffer or HindsightReplayBuffer(replay_buffer_size, env, random_seed=np.random.randint(10000),
-                                                                    relabel_type=relabel_type, her_ratio=her_ratio)
+        # the device-resident buffer (batches never cross PCIe) when the env exposes gym's GoalEnv reward rule; the host buffer otherwise
+        # (an arbitrary python `compute_reward` can only run on the host)
+        cls = DeviceHindsightReplayBuffer if (hasattr(env, "distance_threshold") or hasattr(env, "tol")) and hasattr(trainer, "ctx") \
+            else HindsightReplayBuffer
+        kw = dict(ctx=trainer.ctx) if cls is DeviceHindsightReplayBuffer else {}
+        self.replay_buffer = replay_buffer or cls(replay_buffer_size, env, random_seed=np.random.randint(10000),
+                                                  relabel_type=relabel_type, her_ratio=her_ratio, **kw)
         self.num_epochs, self.num_steps_per_epoch = num_epochs, num_steps_per_epoch
         self.between, self.per_call, self.max_path_length = num_steps_between_train_calls, num_train_steps_per_train_call, max_path_length
         self.min_steps, self.batch_size, self.num_steps_per_eval = min_steps_before_training, batch_size, num_steps_per_eval

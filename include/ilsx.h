@@ -168,6 +168,15 @@ int ilsx_replay_sample(ilsx_replay* rb, int B, const int64_t* idx, float* obs, f
  * out[n_batches*B, record] (device, record = ilsx_replay_record_floats()). */
 int ilsx_replay_sample_many(ilsx_replay* rb, int n_batches, int B, float* out_records);
 int ilsx_replay_record_floats(const ilsx_replay* rb, int* out);
+/* Hindsight relabelling gather — HindsightReplayBuffer.random_batch (rlkit/data_management/relabel_replay_buffer.py:66-163) over a ring
+ * whose observation segment is [observation (d_obs) | desired_goal (d_goal) | achieved_goal (d_goal)].  idx / idx_relabel: DEVICE int64[B]
+ * (the sampled steps and their `future` / `final` relabel steps, drawn by the caller in the reference's RandomState order); the first
+ * n_relabel rows get the relabel step's next achieved goal as desired goal (:106-113); relabel_on: every reward is recomputed from
+ * (next achieved goal, desired goal) (:139-147) by gym's GoalEnv rule, reward_kind 0 = sparse -(dist > threshold), 1 = dense -dist.
+ * Device outputs: obs_cat[B, d_obs + d_goal] = observation | desired_goal and nobs_cat likewise (what her/td3.py:95-99 and
+ * her/sac.py:80-84 feed the networks), act[B, a], rew[B], done[B]. */
+int ilsx_her_gather(ilsx_replay* rb, const int64_t* idx, const int64_t* idx_relabel, int B, int n_relabel, int relabel_on, int d_obs,
+                    int d_goal, int reward_kind, float threshold, float* obs_cat, float* act, float* rew, float* done, float* nobs_cat);
 int ilsx_replay_size(ilsx_replay* rb, int64_t* size, int64_t* top);
 int ilsx_replay_clear(ilsx_replay* rb);
 /* _traj_endpoints in insertion order: writes up to max pairs (start,end) to HOST arrays; *n = count. */

@@ -131,3 +131,60 @@ def test_her_loop_learns_to_reach_on_the_stand_in_env():
     hist = alg.train()
     assert alg._n_train_steps_total >= 3000 and max(hist) >= max(0.6, first + 0.3), (first, hist)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_hindsight_buffer_golden(ctx):
+    """g22 on the device-resident buffer: the same scripted paths and seeds -> the reference's relabelled batches out of ONE gather kernel
+    (ilsx_her_gather) over the HBM ring; the ring stores fp32 (the reference's host arrays are float64: 1e-6 relative on the values,
+    rewards and terminals exact)."""
+    from ilswiss_amd.her import Box, DeviceHindsightReplayBuffer, DictSpace
+    g = np.load(os.path.join(G, "g22_her_buffer.npz"))
+    o, gd, a, cap = (int(v) for v in g["dims"])
+
+    class Env:
+        observation_space = DictSpace(observation=Box(-np.ones(o), np.ones(o)), desired_goal=Box(-np.ones(gd), np.ones(gd)),
+                                      achieved_goal=Box(-np.ones(gd), np.ones(gd)))
+        action_space = Box(-np.ones(a), np.ones(a))
+        reward_type, distance_threshold = "sparse", 0.5          # the rule tools/make_golden.py's compute_reward implements
+    for ci, (rtype, ratio) in enumerate((("future", 0.8), ("final", 0.8), ("future", 0.0))):
+        rb = DeviceHindsightReplayBuffer(cap, Env, random_seed=77, relabel_type=rtype, her_ratio=ratio, ctx=ctx)
+        for p in range(6):
+            obs, dg, ag = g[f"p{p}_obs"], g[f"p{p}_dg"], g[f"p{p}_ag"]
+            L = len(g[f"p{p}_act"])
+            d = lambda i: dict(observation=obs[i], desired_goal=dg[i], achieved_goal=ag[i])   # noqa: E731
+            for i in range(L):
+                rb.add_sample(d(i), g[f"p{p}_act"][i], g[f"p{p}_rew"][i], bool(g[f"p{p}_term"][i]), d(i + 1))
+            rb.terminate_episode()
+        np.testing.assert_array_equal(np.array(sorted(rb._traj_endpoints.items())), g[f"c{ci}_endpoints"])
+        np.random.seed(500 + ci)
+        dev = rb.random_batch(12)
+        assert dev["_her_cat"] and dev["observations"].shape == (12, o + gd)      # device arrays, already observation | goal
+        bt = rb.numpy_batch(dev)
+        for k in ("observations", "actions", "next_observations", "desired_goals", "next_desired_goals"):
+            np.testing.assert_allclose(bt[k], g[f"c{ci}_{k}"], rtol=1e-6, atol=1e-7, err_msg=f"{rtype} {ratio} {k}")
+        np.testing.assert_array_equal(bt["terminals"], g[f"c{ci}_terminals"], err_msg=f"{rtype} {ratio}")
+        np.testing.assert_allclose(bt["rewards"], g[f"c{ci}_rewards"], rtol=1e-6, atol=1e-7, err_msg=f"{rtype} {ratio} rewards")
+
+
+@pytest.mark.gpu
+def test_her_loop_uses_the_device_buffer_by_default():
+    import ilswiss_amd as ia
+    from ilswiss_amd import her
+    c = ia.Context(0, seed=12)
+    try:
+        env = her.PointReachEnv(seed=2)
+        pol = her.MlpGaussianAndEpsilonPolicy([64, 64], 4, 2, action_space=env.action_space, condition_dim=2, ctx=c, seed=5)
+        q1, q2 = ia.FlattenMlp([64, 64], 1, 8, ctx=c, seed=6), ia.FlattenMlp([64, 64], 1, 8, ctx=c, seed=7)
+        tr = her.TD3(pol, q1, q2, discount=0.95, policy_lr=1e-3, qf_lr=1e-3, max_batch=64)
+        alg = her.HER(tr, env, pol, num_epochs=1, num_steps_per_epoch=300, min_steps_before_training=100, max_path_length=25, batch_size=64,
+                      replay_buffer_size=5000, num_steps_per_eval=50)
+        assert isinstance(alg.replay_buffer, her.DeviceHindsightReplayBuffer)
+        alg.train()
+        assert alg._n_train_steps_total > 100 and np.isfinite(tr.get_flat_params("policy")).all()
+        b = alg.replay_buffer.numpy_batch(alg.replay_buffer.random_batch(64))
+        # relabelled rows (the first 80 %) mostly succeed by construction; every reward is the sparse rule of the env
+        d = np.linalg.norm(b["next_observations"][:, :2] - b["desired_goals"], axis=1)
+        np.testing.assert_array_equal(b["rewards"][:, 0], -(d > env.tol).astype(np.float32))
+    finally:
+        c.close()
