@@ -145,6 +145,10 @@ int net_download_flat(ilsx_ctx* ctx, const NetLayout& L, const float* dev_base, 
 int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A, int H, int act, int KP, int cs = 1);
 int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act, int cs = 1);
 int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P);
+// merged phase kernels of the single-run SAC step (kernels.h); phase_fits: every workgroup of such a launch is resident at once
+bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks);
+int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P, int H, int act, int KPmax, int cs);
+int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P, int H, int act, int KPmax, int cs);
 // column-split factor the 2-hidden-layer fast path uses for width H (1 = generic kernels)
 int mlp2_split_factor(int n_hidden, int H);
 int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* fuse = nullptr);

@@ -318,6 +318,10 @@ static int kernels_init_once() {
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+#define SET_PHASE(HH, AA, CC) HIPCHK(hipFuncSetAttribute((const void*)k_sac_phase_a<HH, AA, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+  HIPCHK(hipFuncSetAttribute((const void*)k_sac_phase_c<HH, AA, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
+  SET_PHASE(256, ACT_RELU, 4); SET_PHASE(256, ACT_TANH, 4); SET_PHASE(128, ACT_RELU, 2); SET_PHASE(128, ACT_TANH, 2);
+#undef SET_PHASE
   done = true;
   return ILSX_OK;
 }
@@ -405,6 +409,58 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
 #define CALL_FWD(HH, AA) ILSX_LAUNCH(ps, (k_mlp_fwd<HH, AA>), grid, block, lds, ctx->stream, A)
   DISPATCH_H_ACT(H, act, CALL_FWD);
 #undef CALL_FWD
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+// ---- merged phase kernels of the single-run SAC step (kernels.h: k_sac_phase_a / _c)
+// Every workgroup of a phase launch must be resident at once (they wait for each other): at most one workgroup per CU.
+bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t pr;
+    n_cu = hipGetDeviceProperties(&pr, ctx->device) == hipSuccess ? pr.multiProcessorCount : 1;
+  }
+  if (!((H == 256 && cs == 4) || (H == 128 && cs == 2))) return false;
+  const int tiles = (rows + 15) / 16, gx = (tiles + 7) & ~7;
+  (void)gx;   // padding tiles and the extra bookkeeping row exit at once: only the working workgroups have to be co-resident
+  return tiles <= PHASE_MAX_TILES && tiles * ntasks * cs <= n_cu;
+}
+static size_t phase_lds_bytes(int H, int KP, int cs) { return std::max(fwd_split_lds_bytes(H, KP, cs), bwd_split_lds_bytes(H, cs)); }
+
+int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P0, int H, int act, int KPmax, int cs) {
+  PhaseAArgs P = P0;
+  P.f1.xs = P.f2.xs = P.b1.xs = 0; P.f1.rt = P.f2.rt = 1;
+  P.f1.dbg = P.f2.dbg = nullptr; P.b1.dbg = nullptr;
+  P.dbg = ctx->dbg_next();
+  if (P.b1.ga_parts < 1) P.b1.ga_parts = 1;
+  const int tiles = (P.f1.rows + 15) / 16;
+  dim3 grid((tiles + 7) & ~7, 5, cs), block(4 * H / cs);
+  const size_t lds = phase_lds_bytes(H, KPmax, cs);
+  ProfScope ps(ctx, ILSX_K_MLP_FWD);
+  if (H == 256 && act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_a<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, P);
+  else if (H == 256) ILSX_LAUNCH(ps, (k_sac_phase_a<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, P);
+  else if (act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_a<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, P);
+  else ILSX_LAUNCH(ps, (k_sac_phase_a<128, ACT_TANH, 2>), grid, block, lds, ctx->stream, P);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P0, int H, int act, int KPmax, int cs) {
+  PhaseCArgs P = P0;
+  P.f3.xs = P.b2.xs = P.b3.xs = 0; P.f3.rt = 1;
+  P.f3.dbg = nullptr; P.b2.dbg = P.b3.dbg = nullptr;
+  P.dbg = ctx->dbg_next();
+  if (P.b2.ga_parts < 1) P.b2.ga_parts = 1;
+  if (P.b3.ga_parts < 1) P.b3.ga_parts = 1;
+  const int tiles = (P.f3.rows + 15) / 16;
+  dim3 grid((tiles + 7) & ~7, 3, cs), block(4 * H / cs);
+  const size_t lds = phase_lds_bytes(H, KPmax, cs);
+  ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
+  if (H == 256 && act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_c<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, P);
+  else if (H == 256) ILSX_LAUNCH(ps, (k_sac_phase_c<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, P);
+  else if (act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_c<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, P);
+  else ILSX_LAUNCH(ps, (k_sac_phase_c<128, ACT_TANH, 2>), grid, block, lds, ctx->stream, P);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

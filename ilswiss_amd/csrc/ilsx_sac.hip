@@ -78,6 +78,11 @@ struct ilsx_sac {
   bool defer_tail = false;
   TailLite* tail_dev = nullptr;
   int tail_B = 0;
+  // merged phase kernels (kernels.h k_sac_phase_a / _c): F1 F2 B1 and F3 B2 B3 as one launch each inside train_from_replay
+  unsigned* phase_flags = nullptr;   // PHASE_NFLAGS arrival counters, one 128-byte line each (zeroed by the dW launches)
+  int* phase_err = nullptr;          // set by a workgroup whose wait timed out
+  bool phase_now = false;            // this step runs on the phase kernels
+  bool phase_broken = false;         // a timeout was seen once: stay on the 8-launch path
   float* base(int which) const {
     switch (which) {
       case W_Q1: return P;
@@ -278,6 +283,7 @@ extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net*
   Slab L;   // parameters, optimiser state, scalars and the whole step workspace: one allocation (see Slab)
   L.add(&s->scal, 1);
   L.add(&s->P, nP); L.add(&s->G, nT + 4); L.add(&s->M, nT); L.add(&s->V, nT);
+  L.add(&s->phase_flags, (size_t)PHASE_FLAG_WORDS); L.add(&s->phase_err, 32);
   sac_plan_ws(s, L);
   int rc = L.commit(ctx, &s->slab);
   if (rc != ILSX_OK) { delete s; return rc; }
@@ -311,6 +317,8 @@ extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net*
   for (int i = 0; i < 2; ++i)
     ILSX_TRY(build_dw_jobs(s->Lq, s->gbase(i == 0 ? W_Q1 : W_Q2), s->ws.xq[i], s->ws.hq[i], s->ws.dq[i], s->ws.dhq[i], &s->jobs_q));
   ILSX_TRY(build_dw_jobs(s->Lp, s->gbase(W_PI), s->ws.xp, s->ws.hp, s->ws.dp, s->ws.dhp, &s->jobs_p));
+  s->jobs_q.zero_flags = s->phase_flags;   // each dW launch re-arms the arrival counters of the phase launch that follows it
+  s->jobs_p.zero_flags = s->phase_flags;
   *out = s;
   return ILSX_OK;
 }
@@ -415,6 +423,8 @@ static int sac_critic_backward(ilsx_sac* s) {
   const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
   const float* eps1 = s->eps_explicit ? w.eps1 : nullptr;
   const float* eps2 = s->eps_explicit ? w.eps2 : nullptr;
+  PhaseAArgs PA;
+  if (s->phase_now) memset(&PA, 0, sizeof PA);
   {  // fwd: pi(s') with eps_next ; Q1(s,a) ; Q2(s,a) ; pi(s) with eps_cur (its weights do not change before the actor
      // phase reads it, so its trunk rides along here and one dependent launch disappears from the step)
     FwdArgs A;
@@ -436,7 +446,8 @@ static int sac_critic_backward(ilsx_sac* s) {
       A.t[3].g0_off = 0; A.t[3].publish = 0;                              // pi reads obs
     }
     if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 1; A.tail_n = 1; }
-    ILSX_TRY(sac_fwd(s, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
+    if (s->phase_now) PA.f1 = A;
+    else ILSX_TRY(sac_fwd(s, A, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
   }
   {  // fwd: TQ1(s',a'), TQ2(s',a')
     FwdArgs A;
@@ -446,7 +457,18 @@ static int sac_critic_backward(ilsx_sac* s) {
     sac_q_task(s, A.t[1], W_TQ2, w.s2, w.a2, w.tq2, false, false, 1);
     sac_policy_fin(s, A, eps1, s->rng_stream, false, w.a2, w.logp2, w.ppart);
     if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 2; A.tail_n = 1; }
-    ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
+    if (s->phase_now) {
+      // stage 2 of the phase launch: the target critics' workgroups draw next_obs from the ring themselves (same Philox draw as the
+      // policy task of stage 1) instead of waiting for the published copy, and finish pi(s') under the replay-draw counter (== the
+      // step counter once the pending tail has run; the tail runs concurrently in this launch)
+      A.gather = PA.f1.gather;
+      for (int i = 0; i < 2; ++i) { A.t[i].g0_off = s->o + s->a + 2; A.t[i].g1_off = 0; A.t[i].publish = 0; }
+      A.fin.use_gather_step = 1;
+      A.tail_mode = 0;
+      PA.f2 = A;
+    } else {
+      ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
+    }
   }
   {  // bwd_dx with the TD-target loss head
     BwdArgs A;
@@ -463,7 +485,12 @@ static int sac_critic_backward(ilsx_sac* s) {
       t.q = s->pv(i == 0 ? w.q1 : w.q2); t.tq1 = s->pv(w.tq1); t.tq2 = s->pv(w.tq2);
       t.logp_next = w.logp2; t.rew = w.r; t.done = w.d;
     }
-    ILSX_TRY(sac_bwd(s, A, H, act, cs));
+    if (s->phase_now) {
+      PA.b1 = A; PA.flags = s->phase_flags; PA.err = s->phase_err;
+      ILSX_TRY(launch_phase_a(s->ctx, PA, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
+    } else {
+      ILSX_TRY(sac_bwd(s, A, H, act, cs));
+    }
   }
   AdamFuse F;
   memset(&F, 0, sizeof F);
@@ -490,6 +517,8 @@ static int sac_actor_backward(ilsx_sac* s) {
   const SacWs& w = s->ws;
   const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
   const float* eps2 = s->eps_explicit ? w.eps2 : nullptr;
+  PhaseCArgs PC;
+  if (s->phase_now) memset(&PC, 0, sizeof PC);
   // (pi(s) with eps_cur ran as the 4th task of the step's first forward launch, sac_critic_backward)
   {  // fwd Q1(s,a~), Q2(s,a~) with the just-updated critics (sac_alpha.py:144-146)
     FwdArgs A;
@@ -498,7 +527,8 @@ static int sac_actor_backward(ilsx_sac* s) {
     sac_q_task(s, A.t[0], W_Q1, w.s, w.an, w.q1n, false, true, 0);
     sac_q_task(s, A.t[1], W_Q2, w.s, w.an, w.q2n, false, true, 1);
     sac_policy_fin(s, A, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
-    ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
+    if (s->phase_now) { A.tail = s->tail_dev; PC.f3 = A; }   // the extra row of the phase launch advances the replay-draw counter
+    else ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
   }
   {  // bwd_dx through both critics to the action columns
     BwdArgs A;
@@ -511,7 +541,8 @@ static int sac_actor_backward(ilsx_sac* s) {
       t.loss = LOSS_SAC_ACTORQ; t.which = i; t.q1n = s->pv(w.q1n); t.q2n = s->pv(w.q2n);
       t.dx = w.ga[i]; t.dx_col0 = s->o; t.dx_cols = s->a;
     }
-    ILSX_TRY(sac_bwd(s, A, H, act, cs));
+    if (s->phase_now) PC.b2 = A;
+    else ILSX_TRY(sac_bwd(s, A, H, act, cs));
   }
   {  // bwd_dx of the policy with the tanh-Gaussian loss head
     BwdArgs A;
@@ -525,7 +556,12 @@ static int sac_actor_backward(ilsx_sac* s) {
     t.dhead = w.dhp;
     t.loss = LOSS_SAC_POLICY;
     t.raw = w.raw; t.eps = w.epss; t.action = w.an; t.ga1 = w.ga[0]; t.ga2 = w.ga[1];
-    ILSX_TRY(sac_bwd(s, A, H, act, cs));
+    if (s->phase_now) {
+      PC.b3 = A; PC.flags = s->phase_flags; PC.err = s->phase_err;
+      ILSX_TRY(launch_phase_c(s->ctx, PC, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
+    } else {
+      ILSX_TRY(sac_bwd(s, A, H, act, cs));
+    }
   }
   {
     AdamFuse F;
@@ -742,12 +778,25 @@ extern "C" int ilsx_sac_train_step(ilsx_sac* s, const float* obs, const float* a
   return ILSX_OK;
 }
 
+// The merged phase kernels need: the column-split path on narrow inputs, the fused in-kernel replay draw, the deferred tail, no
+// gradient all-reduce between the phases, no per-workgroup stamps, and every workgroup of a phase launch resident at once.
+static bool sac_phase_ok(ilsx_sac* s, int B) {
+  static const bool off = getenv("ILSX_NO_PHASE") != nullptr;
+  return !off && !s->phase_broken && s->cs > 1 && !s->h0scr && !s->col && s->defer_tail && !sac_is_split(s) &&
+         s->ctx->xcd_shift == 0 && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
+}
+static bool sac_phase_possible(ilsx_sac* s, int B) {   // as sac_phase_ok, for the state a train_from_replay call ran in (defer_tail already cleared)
+  static const bool off = getenv("ILSX_NO_PHASE") != nullptr;
+  return !off && s->cs > 1 && !s->h0scr && !sac_is_split(s) && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
+}
 static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
   const SacWs& w = s->ws;
   if (s->cs > 1) {
     s->gather_rb = rb;   // sampling is fused into the first forward launch
+    s->phase_now = sac_phase_ok(s, B);
     const int rc = sac_full_step(s);
     s->gather_rb = nullptr;
+    s->phase_now = false;
     return rc;
   }
   ILSX_TRY(replay_launch_sample(rb, B, nullptr, s->scal, 0, w.s, w.a, w.r, w.d, w.s2, nullptr));
@@ -800,6 +849,24 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   }
   s->defer_tail = false;
   ILSX_TRY(sac_flush_tail(s, deferred));
+  if (deferred && !s->phase_broken && sac_phase_possible(s, B)) {
+    // a phase-kernel workgroup that gave up waiting left a mark: the steps of this call are not to be trusted
+    int err = 0;
+    unsigned masks[PHASE_MAX_TILES * 32];
+    HIPCHK(hipMemcpyAsync(&err, s->phase_err, sizeof err, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(masks, s->phase_flags + PHASE_MASK_WORD(0), sizeof masks, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int t = 0; t < PHASE_MAX_TILES; ++t)
+      if (masks[t * 32] & (masks[t * 32] - 1)) err |= 2;   // a tile's workgroups ran on more than one XCD: its exchange went through two L2s
+    if (err) {
+      s->phase_broken = true;
+      if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
+      HIPCHK(hipMemsetAsync(s->phase_err, 0, sizeof(int), st));
+      ILSX_FAIL(ILSX_ERR_HIP, "ilsx_sac_train_from_replay: a merged phase kernel %s; this agent falls back to one launch per stage from now on — "
+                "the call's updates are invalid", (err & 1) ? "timed out waiting for the workgroups of its tile (are other kernels sharing this GPU?)"
+                                                            : "found the workgroups of one row tile on different XCDs");
+    }
+  }
   if (stats) return sac_read_stats(s, stats);
   return ILSX_OK;
 }

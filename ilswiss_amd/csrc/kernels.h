@@ -191,6 +191,13 @@ template <int ACT> __device__ __forceinline__ float act_grad_from_out(float h) {
 #define ILSX_WG_LINEAR (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))
 // Compiled in only with -DILSX_STAMPS (make STAMPS=1 -> libilsx_stamps.so, what tools/step_gantt.py loads): each stamp is ~8 issue slots
 // per wave plus a parked pointer pair, ~2.5 % of a forward launch at one wave per SIMD — measurement code, kept out of the product build.
+// ILSX_STAMPS_FINE (measurement only, changes the timing it measures): a stamp preceded by a full memory wait — "when had everything
+// requested so far arrived"
+#if defined(ILSX_STAMPS) && defined(ILSX_STAMPS_FINE)
+#define ILSX_STAMP_SYNC(dbg, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if ((dbg) && threadIdx.x == 0 && ILSX_WG_LINEAR < ILSX_TRACE_MAXWG) (dbg)[(size_t)ILSX_WG_LINEAR * ILSX_TRACE_SLOTS + (i)] = wall_clock64(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define ILSX_STAMP_SYNC(dbg, i) ((void)0)
+#endif
 #ifdef ILSX_STAMPS
 #define ILSX_STAMP(dbg, i) do { if ((dbg) && threadIdx.x == 0 && ILSX_WG_LINEAR < ILSX_TRACE_MAXWG) (dbg)[(size_t)ILSX_WG_LINEAR * ILSX_TRACE_SLOTS + (i)] = wall_clock64(); } while (0)
 #else
@@ -262,15 +269,32 @@ struct FwdTask {
   int no_fin;                        // this task's action segment is NOT the launch's finished policy (FwdArgs::fin)
   int agent, first;                  // grouped launches (FwdArgs::tasks): owning agent, 1 = the agent's publishing task
 };
+// In-kernel exchange (the merged phase kernels, k_sac_phase_a / _c below): data one workgroup of a launch writes and ANOTHER workgroup
+// of the SAME launch reads.  All workgroups that exchange sit on ONE XCD (same row tile), so the data travels through that XCD's L2:
+// the producer's ordinary stores are acknowledged by the L2 (the vector L1 is write-through) before it signals; the consumer drops its
+// CU's vector L1 once after the wait (buffer_inv sc0, xch_wait) and reads with ordinary loads.  No fence anywhere: a release / acquire
+// pair writes back and invalidates the whole L2.  Measured per hand-off (tools/ubench/tilesync.hip): release / acquire atomics 6.4 us,
+// __threadfence 9 us, every exchanged word as an agent-scope atomic (sc1: served past the L2) 1.3 us — but each such load is a trip to
+// the fabric and the stage bodies ran 3.5 us slower — this way 0.95 us; a kernel boundary is 2.7 us plus a cold prologue.
+// ldx / stx mark the exchanged accesses (X = the access happens inside a phase kernel); they compile to the ordinary access.
+template <bool X> __device__ __forceinline__ float ldx(const float* p) { return *p; }
+template <bool X> __device__ __forceinline__ void stx(float* p, float v) { *p = v; }
+// a value another workgroup of this launch wrote to a uniform address: a vector load past every cache (a plain load of a uniform
+// address becomes a scalar load, and the scalar cache is not dropped by buffer_inv sc0)
+template <bool X> __device__ __forceinline__ float ldx_uniform(const float* p) {
+  if constexpr (X) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
 // A per-row scalar (Q value) that may still be split into CS column-slice partial sums: summed in a fixed
 // order by whoever consumes it (the "combine in the next kernel's prologue" seam of a split-K reduction).
 struct PartVal {
   const float* p; int cs; int stride;
+  template <bool X = false>
   __device__ __forceinline__ float get(int r) const {  // cs <= 4; the loads are independent and issue together
-    const float v0 = p[r];
-    const float v1 = cs > 1 ? p[(size_t)stride + r] : 0.0f;
-    const float v2 = cs > 2 ? p[(size_t)2 * stride + r] : 0.0f;
-    const float v3 = cs > 3 ? p[(size_t)3 * stride + r] : 0.0f;
+    const float v0 = ldx<X>(p + r);
+    const float v1 = cs > 1 ? ldx<X>(p + (size_t)stride + r) : 0.0f;
+    const float v2 = cs > 2 ? ldx<X>(p + (size_t)2 * stride + r) : 0.0f;
+    const float v3 = cs > 3 ? ldx<X>(p + (size_t)3 * stride + r) : 0.0f;
     float s = v0;
     if (cs > 1) s += v1;
     if (cs > 2) s += v2;
@@ -286,6 +310,7 @@ struct PolicyFinishArgs {
   const float* eps; const float* act_in;
   float *raw, *eps_save, *action, *logp;
   float noise, noise_clip, max_act;   // head == HEAD_DET_TANH_NOISE (TD3): raw = pre-activation [rows][a]
+  int use_gather_step;                // phase kernels: the Philox step is scal->gather_step (== the step counter once the pending tail has run)
 };
 struct FwdGroup;
 struct FwdArgs {
@@ -576,6 +601,7 @@ struct BwdArgs {
 
 // dL/d(head output j) of row gr for the loss functor of task T (shared by the generic and the column-split
 // backward kernels).
+template <bool X = false>
 __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& A, int gr, int j, int NO) {
   float d = 0.0f;
   const DevScalars* scal = T.scal ? T.scal : A.scal;
@@ -583,13 +609,13 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
     d = T.given[(size_t)gr * NO + j];
   } else if (T.loss == LOSS_SAC_CRITIC) {
     // sac_alpha.py:110-123: y = r + (1-d)*gamma*(min(TQ1,TQ2) - alpha*logpi'); dL/dq = (q-y)/B
-    const float alpha = scal->alpha;
-    const float r = A.reward_scale * T.rew[gr];
-    const float y = r + (1.0f - T.done[gr]) * A.gamma * (fminf(T.tq1.get(gr), T.tq2.get(gr)) - alpha * T.logp_next[gr]);
-    d = (T.q.get(gr) - y) * A.inv_B;
+    const float alpha = ldx_uniform<X>(&scal->alpha);
+    const float r = A.reward_scale * ldx<X>(T.rew + gr);
+    const float y = r + (1.0f - ldx<X>(T.done + gr)) * A.gamma * (fminf(T.tq1.get<X>(gr), T.tq2.get<X>(gr)) - alpha * ldx<X>(T.logp_next + gr));
+    d = (T.q.get<X>(gr) - y) * A.inv_B;
   } else if (T.loss == LOSS_SAC_ACTORQ) {
     // sac_alpha.py:144-148: -mean(min(Q1,Q2)); torch.minimum splits ties evenly
-    const float a1 = T.q1n.get(gr), a2 = T.q2n.get(gr);
+    const float a1 = T.q1n.get<X>(gr), a2 = T.q2n.get<X>(gr);
     const float w1 = a1 < a2 ? 1.0f : (a1 == a2 ? 0.5f : 0.0f);
     d = -(T.which == 0 ? w1 : 1.0f - w1) * A.inv_B;
   } else if (T.loss == LOSS_TD_CRITIC) {
@@ -662,15 +688,15 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
     const float alpha = scal->alpha;
     const float glp = alpha * A.inv_B;
     const float inv_Ba = A.inv_B / (float)a;
-    const float mu = T.raw[(size_t)gr * NO + jj], lsr = T.raw[(size_t)gr * NO + a + jj];
+    const float mu = ldx<X>(T.raw + (size_t)gr * NO + jj), lsr = ldx<X>(T.raw + (size_t)gr * NO + a + jj);
     const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
-    const float sd = expf(ls), ep = T.eps[(size_t)gr * a + jj], act = T.action[(size_t)gr * a + jj];
+    const float sd = expf(ls), ep = ldx<X>(T.eps + (size_t)gr * a + jj), act = ldx<X>(T.action + (size_t)gr * a + jj);
     float ga = 0.0f;  // d(-min Q)/da~: both critics, each possibly in column-slice partial slabs
     float g1[4], g2[4];   // <= 4 slabs per critic: all requested before any is summed
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) {
       const size_t at = ((size_t)(pc < A.ga_parts ? pc : 0) * A.ga_stride + gr) * a + jj;
-      const float v1 = T.ga1[at], v2 = T.ga2[at];
+      const float v1 = ldx<X>(T.ga1 + at), v2 = ldx<X>(T.ga2 + at);
       g1[pc] = pc < A.ga_parts ? v1 : 0.0f; g2[pc] = pc < A.ga_parts ? v2 : 0.0f;
     }
 #pragma unroll
@@ -812,10 +838,6 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
 // PH = 2 starts from hsave[0] (16 KB per tile, L2-resident) and does layer 1 + heads.
 template <int H, int ACT, int CS, bool GRP, int PH = 0>
 __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) {
-  constexpr int NTH = 4 * H / CS, NWV = NTH / 64, NC = H / 16, SLW = H / CS, NCS = SLW / 16;
-  constexpr int NT0 = PH == 1 ? 1 : CS;   // layer-0 column tiles per wave
-  constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
-  static_assert(NCS == NWV, "one k16 chunk of the slice per wave in the head phase");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (A.tail_mode && (int)blockIdx.y == A.ntasks) {   // the extra y row of a deferred-tail launch (an extra x column would shift
     const int ag = blockIdx.x + gridDim.x * blockIdx.z;  // the tile -> XCD mapping of every other workgroup, see launch_fwd)
@@ -835,381 +857,13 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   if (GRP) Rg = A.tasks[blockIdx.y];
   const FwdTask& T = GRP ? Rg.t : A.t[blockIdx.y];
   const FwdGroup* GP = GRP ? &Rg.g : nullptr;
-  const DevScalars* scal = GRP ? GP->scal : A.scal;
-  const NetView& N = T.net;
-  const int KP = N.KP, LDX = KP + ILSX_LDS_PAD, NO = N.NO, NCH0 = KP >> 4, NOT = (NO + 15) >> 4;
-  float* xs = smem;                 // [16][LDX]
-  float* h0 = xs + 16 * LDX;        // [16][LDH]   layer-0 activations, all H columns
-  float* hs = h0 + 16 * LDH;        // [16][LDSL]  this slice of the layer-1 activations
-  float* red = hs + 16 * LDSL;      // [4 tiles][NWV][4][64] head partial tiles
-  if (blockIdx.x & ((1u << A.xs) - 1u)) return;   // XCD confinement: the dispatcher deals workgroups round-robin to the 8 XCDs
-  if ((int)(blockIdx.x >> A.xs) * (A.rt > 0 ? A.rt : 1) * 16 >= A.rows) return;   // grid.x is padded to a multiple of 8
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int rows = A.rows, cs = blockIdx.z;
-  const int RT = A.rt > 0 ? A.rt : 1;   // row tiles this workgroup walks with its weights held in registers
-  const bool lead = cs == 0;
-  ILSX_STAMP(A.dbg, 0);
-
-  // ---- every small global operand is requested up front, in the order it is needed
-  const int ct0 = PH == 1 ? cs * NWV + wave : wave * CS;   // this wave's first layer-0 column tile
-  const float* w0p = N.base + N.off_W[0] + (size_t)ct0 * NCH0 * 256 + 4 * lane;
-  constexpr int L0D = 8;   // PH 1: k16 chunks of layer-0 weights requested ahead of the MFMAs that consume them
-  float4 b0[NT0], b0first[NT0];
-  float4 l0first[PH == 1 ? L0D : 1];
-  float bias0[NT0];
-  if constexpr (PH == 1) {
-#pragma unroll
-    for (int d = 0; d < L0D; ++d) l0first[d] = *reinterpret_cast<const float4*>(w0p + (size_t)(d < NCH0 ? d : 0) * 256);
-  }
-  if constexpr (PH != 2) {
-#pragma unroll
-    for (int i = 0; i < NT0; ++i) b0[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256);
-#pragma unroll
-    for (int i = 0; i < NT0; ++i) b0first[i] = b0[i];
-#pragma unroll
-    for (int i = 0; i < NT0; ++i) bias0[i] = (N.base + N.off_b[0])[(ct0 + i) * 16 + li];
-  }
-  const int lc = wave * 16 + li, col1 = cs * SLW + lc;
-  float bias1 = 0.0f;
-  float4 whf[4];
-  float4 wreg[NC];
-  if constexpr (PH != 1) {
-    bias1 = (N.base + N.off_b[1])[col1];
-    // head weights of this slice as MFMA B fragments: wave w owns k16 chunk w of the slice, rows j = 16t + li
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int j = 16 * t + li;
-      whf[t] = (t < NOT && j < NO) ? *reinterpret_cast<const float4*>(N.base + N.off_Wh + (size_t)j * H + cs * SLW + 16 * wave + 4 * g)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // ---- this wave's slice of layer 1 (16 columns x H): one coalesced burst, held for every row tile
-    const float* wp = N.base + N.off_W[1] + (size_t)(cs * NWV + wave) * NC * 256 + 4 * lane;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
-  }
-  const bool fin = (GRP ? GP->fin_on : A.fin_on) != 0 && !T.no_fin && T.d1 > 0;
-  const GatherSpec& G = GRP ? GP->gather : A.gather;
-  for (int rt = 0; rt < RT; ++rt) {
-  const int r0 = ((blockIdx.x >> A.xs) * RT + rt) * 16;
-  if (r0 >= rows) break;   // workgroup-uniform
-  bool fin_logp = false;
-  if constexpr (PH != 2) {
-#pragma unroll
-  for (int i = 0; i < NT0; ++i) b0[i] = b0first[i];
-  if constexpr (PH == 0) {   // narrow inputs (the one-launch form): one element per thread, the row's index drawn where it is used
-    for (int e = tid; e < 16 * KP; e += NTH) {
-      const int r = e / KP, k = e - r * KP, gr = r0 + r;
-      const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
-      if (fin && act_col) continue;   // filled by the policy epilogue below
-      float v = 0.0f;
-      if (gr < rows) {
-        if (G.on) {   // fused sample+index (simple_replay_buffer.py:239-293): row gr of the batch is record idx
-          const long long idx = replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)gr, G.st->size);
-          const float* rec = G.records + (size_t)idx * G.rec;
-          if (k < T.d0) v = rec[T.g0_off + k];
-          else if (act_col) v = rec[T.g1_off + (k - T.d0)];
-          if (lead && T.publish == 1) {
-            if (k < T.d0) G.s[(size_t)gr * G.o + k] = v;
-            else if (act_col) G.a[(size_t)gr * G.adim + (k - T.d0)] = v;
-            if (k == 0) { G.r[gr] = rec[G.o + G.adim]; G.d[gr] = rec[G.o + G.adim + 1]; }
-          } else if (lead && T.publish == 2 && k < T.d0) {
-            G.s2[(size_t)gr * G.o + k] = v;
-          }
-        } else {
-          if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
-          else if (act_col) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
-        }
-        if (T.xsave && lead) T.xsave[(size_t)gr * KP + k] = v;
-      }
-      xs[r * LDX + k] = v;
-    }
-  } else {          // PH 1, wide inputs (Humanoid: 25 elements per thread): the index is drawn ONCE per row — the form above spent a Philox
-                    // block and a division per element, 21 us per launch — and a wave walks whole rows in coalesced 64-float runs
-    // one element of the staged input tile; rec = the replay record of row gr (fused sample+index, simple_replay_buffer.py:239-293)
-    auto stage = [&](int r, int k, int gr, const float* rec) {
-      const bool act_col = k >= T.d0 && k < T.d0 + T.d1;
-      if (fin && act_col) return;   // filled by the policy epilogue below
-      float v = 0.0f;
-      if (gr < rows) {
-        if (G.on) {
-          if (k < T.d0) v = rec[T.g0_off + k];
-          else if (act_col) v = rec[T.g1_off + (k - T.d0)];
-          if (lead && T.publish == 1) {
-            if (k < T.d0) G.s[(size_t)gr * G.o + k] = v;
-            else if (act_col) G.a[(size_t)gr * G.adim + (k - T.d0)] = v;
-            if (k == 0) { G.r[gr] = rec[G.o + G.adim]; G.d[gr] = rec[G.o + G.adim + 1]; }
-          } else if (lead && T.publish == 2 && k < T.d0) {
-            G.s2[(size_t)gr * G.o + k] = v;
-          }
-        } else {
-          if (k < T.d0) v = T.x0[(size_t)gr * T.s0 + k];
-          else if (act_col) v = T.x1[(size_t)gr * T.s1 + (k - T.d0)];
-        }
-        if (T.xsave && lead) T.xsave[(size_t)gr * KP + k] = v;
-      }
-      xs[r * LDX + k] = v;
-    };
-    long long* ridx = reinterpret_cast<long long*>(hs);   // hs is not live before layer 1
-    if (G.on) {
-      if (tid < 16) ridx[tid] = r0 + tid < rows ? replay_draw(G.seed, scal->gather_step, G.stream, (uint32_t)(r0 + tid), G.st->size) : 0;
-      lds_barrier();
-    }
-    if (KP <= 512 && T.d1 <= 64) {
-      // a row is [obs segment | action segment | zero padding]: the segments are copied with clamped, unconditional loads — every load of
-      // the wave's four rows is in flight before the first store (a loop around load + store waits per trip: 28 serial HBM round trips
-      // per wave for a 396-wide row; per-element source selection compiled to ~90 branchy instructions per element)
-      constexpr int RW = 16 / NWV, U = 8;
-      float vo[RW][U], va[RW];
-      const bool acts = T.d1 > 0 && !fin;
-#pragma unroll
-      for (int rr = 0; rr < RW; ++rr) {
-        const int r = wave + NWV * rr, grc = r0 + r < rows ? r0 + r : rows - 1;
-        const float* rec = G.on ? G.records + (size_t)ridx[r] * G.rec : nullptr;
-        const float* s0p = G.on ? rec + T.g0_off : T.x0 + (size_t)grc * T.s0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) { const int k = lane + 64 * u; vo[rr][u] = s0p[k < T.d0 ? k : T.d0 - 1]; }
-        va[rr] = 0.0f;
-        if (acts) { const float* s1p = G.on ? rec + T.g1_off : T.x1 + (size_t)grc * T.s1; va[rr] = s1p[lane < T.d1 ? lane : T.d1 - 1]; }
-      }
-#pragma unroll
-      for (int rr = 0; rr < RW; ++rr) {
-        const int r = wave + NWV * rr, gr = r0 + r;
-        const bool rowok = gr < rows;
-        const bool pub1 = G.on && lead && T.publish == 1 && rowok, pub2 = G.on && lead && T.publish == 2 && rowok, xsv = T.xsave && lead && rowok;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int k = lane + 64 * u;
-          if (k < T.d0) {
-            const float x = rowok ? vo[rr][u] : 0.0f;
-            if (pub1) G.s[(size_t)gr * G.o + k] = x;
-            if (pub2) G.s2[(size_t)gr * G.o + k] = x;
-            if (xsv) T.xsave[(size_t)gr * KP + k] = x;
-            xs[r * LDX + k] = x;
-          }
-        }
-        if (acts && lane < T.d1) {
-          const float x = rowok ? va[rr] : 0.0f;
-          if (pub1) G.a[(size_t)gr * G.adim + lane] = x;
-          if (xsv) T.xsave[(size_t)gr * KP + T.d0 + lane] = x;
-          xs[r * LDX + T.d0 + lane] = x;
-        }
-        if (pub1 && lane == 0) { const float* rec = G.records + (size_t)ridx[r] * G.rec; G.r[gr] = rec[G.o + G.adim]; G.d[gr] = rec[G.o + G.adim + 1]; }
-        for (int k = T.d0 + T.d1 + lane; k < KP; k += 64) {   // zero padding up to the k16 multiple
-          if (xsv) T.xsave[(size_t)gr * KP + k] = 0.0f;
-          xs[r * LDX + k] = 0.0f;
-        }
-        if (T.d1 > 0 && !acts) { /* action columns: the policy epilogue below fills them */ }
-      }
-    } else {
-      for (int r = wave; r < 16; r += NWV) {
-        const int gr = r0 + r;
-        const float* rec = G.on ? G.records + (size_t)ridx[r] * G.rec : nullptr;
-        for (int k = lane; k < KP; k += 64) stage(r, k, gr, rec);
-      }
-    }
-  }
-  if (fin) {
-    // the action columns are pi's output: combine its CS head partials, squash (policies.py:262-283,
-    // distributions.py:23-28,43-50,74-97); slice 0 of task 0 publishes action / logp / raw / eps for later kernels
-    const PolicyFinishArgs& P = GRP ? GP->fin : A.fin;
-    const bool det = P.head == HEAD_DET_TANH_NOISE;   // TD3: max_act*tanh(pre) + clipped noise, one head (policies.py:166-188)
-    const int a = P.a, NOp = det ? a : 2 * a;
-    const bool pub = lead && (GRP ? T.first != 0 : blockIdx.y == 0);
-    float* lp3 = red;   // [16][32][3] log-prob contributions (quad, log_std, jacobian)
-    const unsigned long long fstep = P.scal ? P.scal->step : P.step_host;   // requested with the partials, not after them
-    for (int e = tid; e < 16 * a; e += NTH) {
-      const int row = e / a, j = e - row * a, gr = r0 + row;
-      float act = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-      if (gr < rows) {
-        // the CS (<= 4) head partials: all requested before any is summed (a loop with a run-time trip count waits for its
-        // loads on every trip: four serial round trips at the head of the launch's longest dependent chain)
-        float pm[4], pl[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const size_t at = ((size_t)(c < P.cs ? c : 0) * P.part_stride + gr) * NOp + j;
-          pm[c] = P.part[at];
-          pl[c] = det ? 0.0f : P.part[at + a];
-        }
-        float mu = 0.f, lsr = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { mu += c < P.cs ? pm[c] : 0.0f; lsr += c < P.cs ? pl[c] : 0.0f; }   // slab order
-        float ep = 0.0f;
-        if (!det || P.noise != 0.0f) {
-          if (P.eps) {
-            ep = P.eps[(size_t)gr * a + j];
-          } else {
-            float z4[4];
-            philox_normal4(P.seed, fstep, P.rng_stream, gr, j >> 2, z4);
-            const int q = j & 3;
-            ep = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
-          }
-        }
-        if (det) {
-          act = P.max_act * tanhf(mu);
-          if (P.noise != 0.0f) act += fminf(fmaxf(P.noise * ep, -P.noise_clip), P.noise_clip);
-          if (pub && P.raw) P.raw[(size_t)gr * a + j] = mu;
-        } else {
-          const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
-          const float sd = expf(ls);
-          const float z = ep * sd + mu;
-          act = tanhf(z);
-          const float dm = mu - z;
-          c0 = dm * dm / expf(2.0f * ls); c1 = ls; c2 = logf(1.0f - act * act + TANH_EPS);
-          if (pub && P.raw) { P.raw[(size_t)gr * NOp + j] = mu; P.raw[(size_t)gr * NOp + a + j] = lsr; }
-        }
-        if (T.xsave && lead) T.xsave[(size_t)gr * KP + T.d0 + j] = act;
-        if (pub) {
-          if (P.action) P.action[(size_t)gr * a + j] = act;
-          if (P.eps_save) P.eps_save[(size_t)gr * a + j] = ep;
-        }
-      }
-      xs[row * LDX + T.d0 + j] = act;
-      lp3[(row * 32 + j) * 3 + 0] = c0; lp3[(row * 32 + j) * 3 + 1] = c1; lp3[(row * 32 + j) * 3 + 2] = c2;
-    }
-    fin_logp = pub && P.logp && !det;
-  }
-  }  // PH != 2
-  else {   // PH == 2: layer-0 activations of the tile, as the layer-0 launch left them
-    const float* hsrc = T.hsave[0];
-    for (int e = tid; e < 16 * (H / 4); e += NTH) {
-      const int row = e / (H / 4), c4 = e - row * (H / 4), gr = r0 + row;
-      const float4 v = gr < rows ? *reinterpret_cast<const float4*>(hsrc + (size_t)gr * H + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(h0 + row * LDH + 4 * c4) = v;
-    }
-  }
-  lds_barrier();
-  ILSX_STAMP(A.dbg, 1);
-  if (fin_logp && tid < 16 && r0 + tid < rows) {   // log pi of the tile's rows from the staged contributions: after the tile's ONE
-    const PolicyFinishArgs& P = GRP ? GP->fin : A.fin;   // barrier instead of behind a barrier of its own (`red` is next written two
-    float q = 0.f, l = 0.f, jc = 0.f;                    // barriers from here)
-    for (int j = 0; j < P.a; ++j) { q += red[(tid * 32 + j) * 3]; l += red[(tid * 32 + j) * 3 + 1]; jc += red[(tid * 32 + j) * 3 + 2]; }
-    P.logp[r0 + tid] = -0.5f * q - (l + HALF_LOG_2PI) - jc;
-  }
-  // ---- layer 0: CS column tiles per wave, full width (PH 0) ; this slice's own tile (PH 1)
-  if constexpr (PH == 1) {
-    // a wide layer 0 is a long K loop (25 k16 chunks for Humanoid): with the next chunk requested one step ahead every trip waited
-    // for an L2 round trip (24 us per launch); here L0D chunks are in flight while the previous L0D are consumed
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* ap = xs + li * LDX + 4 * g;
-    float4 cur[L0D], nxt[L0D];
-#pragma unroll
-    for (int d = 0; d < L0D; ++d) cur[d] = l0first[d];
-    for (int cb = 0; cb < NCH0; cb += L0D) {
-#pragma unroll
-      for (int d = 0; d < L0D; ++d) {
-        const int c = cb + L0D + d;
-        nxt[d] = *reinterpret_cast<const float4*>(w0p + (size_t)(c < NCH0 ? c : 0) * 256);
-      }
-#pragma unroll
-      for (int d = 0; d < L0D; ++d) {
-        if (cb + d < NCH0) {   // uniform
-          const float4 a = *reinterpret_cast<const float4*>(ap + 16 * (cb + d));
-          acc = MFMA16(a.x, cur[d].x, acc); acc = MFMA16(a.y, cur[d].y, acc);
-          acc = MFMA16(a.z, cur[d].z, acc); acc = MFMA16(a.w, cur[d].w, acc);
-        }
-      }
-#pragma unroll
-      for (int d = 0; d < L0D; ++d) cur[d] = nxt[d];
-    }
-    float* hsv = T.hsave[0];
-    const int col = ct0 * 16 + li;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int row = 4 * g + v;
-      if (r0 + row < rows) hsv[(size_t)(r0 + row) * H + col] = act_fn<ACT>(acc[v] + bias0[0]);
-    }
-  } else if constexpr (PH != 2) {
-    f32x4 acc[NT0];
-#pragma unroll
-    for (int i = 0; i < NT0; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* ap = xs + li * LDX + 4 * g;
-    for (int kc = 0; kc < KP; kc += 16) {
-      float4 bn[NT0];
-#pragma unroll
-      for (int i = 0; i < NT0; ++i) {
-        bn[i] = b0[i];
-        if (kc + 16 < KP) bn[i] = *reinterpret_cast<const float4*>(w0p + (size_t)i * NCH0 * 256 + (kc + 16) * 16);
-      }
-      const float4 a = *reinterpret_cast<const float4*>(ap + kc);
-#pragma unroll
-      for (int i = 0; i < NT0; ++i) acc[i] = MFMA16(a.x, b0[i].x, acc[i]);
-#pragma unroll
-      for (int i = 0; i < NT0; ++i) acc[i] = MFMA16(a.y, b0[i].y, acc[i]);
-#pragma unroll
-      for (int i = 0; i < NT0; ++i) acc[i] = MFMA16(a.z, b0[i].z, acc[i]);
-#pragma unroll
-      for (int i = 0; i < NT0; ++i) acc[i] = MFMA16(a.w, b0[i].w, acc[i]);
-#pragma unroll
-      for (int i = 0; i < NT0; ++i) b0[i] = bn[i];
-    }
-    float* hsv = (PH == 1 || lead) ? T.hsave[0] : nullptr;
-#pragma unroll
-    for (int i = 0; i < NT0; ++i) {
-      const int col = (ct0 + i) * 16 + li;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = 4 * g + v;
-        const float h = act_fn<ACT>(acc[i][v] + bias0[i]);
-        if constexpr (PH == 0) h0[row * LDH + col] = h;
-        if (hsv && r0 + row < rows) hsv[(size_t)(r0 + row) * H + col] = h;
-      }
-    }
-  }
-  if constexpr (PH == 1) {
-    lds_barrier();   // the next row tile restages xs
-    continue;
-  }
-  if constexpr (PH == 0) lds_barrier();
-  ILSX_STAMP(A.dbg, 2);
-  // ---- layer 1, this slice: straight out of registers
-  {
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    const float* ap = h0 + li * LDH + 4 * g;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
-      acc0 = MFMA16(a.x, wreg[c].x, acc0); acc1 = MFMA16(a.y, wreg[c].y, acc1);
-      acc0 = MFMA16(a.z, wreg[c].z, acc0); acc1 = MFMA16(a.w, wreg[c].w, acc1);
-    }
-    float* hsv = T.hsave[1];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int row = 4 * g + v;
-      const float h = act_fn<ACT>(acc0[v] + acc1[v] + bias1);
-      hs[row * LDSL + lc] = h;
-      if (hsv && r0 + row < rows) hsv[(size_t)(r0 + row) * H + col1] = h;
-    }
-  }
-  lds_barrier();
-  ILSX_STAMP(A.dbg, 3);
-  // ---- head partial sums over this column slice on the matrix pipe: wave w contracts k16 chunk w of the
-  //      slice for every 16-output tile, the NWV partial tiles are summed through LDS
-  {
-    const float4 a = *reinterpret_cast<const float4*>(hs + li * LDSL + 16 * wave + 4 * g);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t < NOT) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc = MFMA16(a.x, whf[t].x, acc); acc = MFMA16(a.y, whf[t].y, acc);
-        acc = MFMA16(a.z, whf[t].z, acc); acc = MFMA16(a.w, whf[t].w, acc);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) red[((t * NWV + wave) * 4 + v) * 64 + lane] = acc[v];
-      }
-    }
-  }
-  lds_barrier();
-  const float* bh = N.base + N.off_bh;
-  for (int e = tid; e < NOT * 256; e += NTH) {
-    const int t = e >> 8, v = (e >> 6) & 3, ol = e & 63;
-    float sum = 0.0f;
-#pragma unroll
-    for (int w2 = 0; w2 < NWV; ++w2) sum += red[((t * NWV + w2) * 4 + v) * 64 + ol];
-    const int row = 4 * (ol >> 4) + v, j = 16 * t + (ol & 15), gr = r0 + row;
-    if (j < NO && gr < rows) T.part[((size_t)cs * A.part_stride + gr) * NO + j] = sum + (lead ? bh[j] : 0.0f);
-  }
-  lds_barrier();   // the next row tile reuses xs / h0 / hs / red
-  }  // rt
-  ILSX_STAMP(A.dbg, 7);
+  // the body is shared as TEXT with the merged phase kernels (see fwd_split_tile.inc for why it is not a device function)
+  constexpr bool XCH = false;
+  const int bx = blockIdx.x, cs = blockIdx.z;
+  const bool first_task = blockIdx.y == 0;
+#define XCH_HOOK_FIN
+#include "fwd_split_tile.inc"
+#undef XCH_HOOK_FIN
 }
 #endif  // ILSX_KERNEL_IMPL
 #ifdef ILSX_KERNEL_IMPL
@@ -1256,166 +910,192 @@ __global__ __launch_bounds__(64) void k_policy_finish(const PolicyFinishArgs P) 
 
 template <int H, int ACT, int CS, bool GRP>
 __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) {
-  constexpr int NTH = 4 * H / CS, NWV = NTH / 64, NC = H / 16, SLW = H / CS, RPW = 16 / NWV, KPL = SLW / 64;
-  constexpr int RPT = 16 * H / NTH, RSTEP = NTH / H;   // delta_1: thread <-> one column, RPT rows RSTEP apart
-  constexpr int LDH = H + ILSX_LDS_PAD, LDSL = SLW + ILSX_LDS_PAD;
-  static_assert(NTH % H == 0 && RPW >= 1 && KPL >= 1, "unsupported split geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BwdTask Tg;
   if (GRP) Tg = A.tasks[blockIdx.y];   // by value at entry (see k_mlp2_fwd_split)
   const BwdTask& T = GRP ? Tg : A.t[blockIdx.y];   // !GRP: read in place from the kernel-argument segment
-  const NetView& N = T.net;
-  const int NO = N.NO;
-  float* d1 = smem;                      // [16][LDH]  delta_1, all H columns
-  float* d0s = d1 + 16 * LDH;            // [16][LDSL] this slice of delta_0
-  float* dout = d0s + 16 * LDSL;         // [16][ILSX_MAX_NO]
-  if (blockIdx.x & ((1u << A.xs) - 1u)) return;
-  if ((int)(blockIdx.x >> A.xs) * 16 >= A.rows) return;   // grid.x is padded to a multiple of 8 (launch_bwd)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int r0 = (blockIdx.x >> A.xs) * 16, rows = A.rows, cs = blockIdx.z;
-  const bool lead = cs == 0;
-  ILSX_STAMP(A.dbg, 0);
+  constexpr bool XCH = false;
+  const int bx = blockIdx.x, cs = blockIdx.z;
+#define XCH_HOOK_ACT
+#define XCH_HOOK_HEAD
+#include "bwd_split_tile.inc"
+#undef XCH_HOOK_ACT
+#undef XCH_HOOK_HEAD
+}
+#endif  // ILSX_KERNEL_IMPL
 
-  // ---- operands of the later phases, requested first (they land while the loss head is evaluated)
-  const int k1 = tid % H, rb1 = tid / H;
-  float h1v[RPT];
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int gr = r0 + rb1 + RSTEP * i;
-    h1v[i] = gr < rows ? T.hsave[1][(size_t)gr * H + k1] : 0.0f;
-  }
-  const int lc = wave * 16 + li, col0 = cs * SLW + lc;
-  float h0v[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int gr = r0 + 4 * g + v;
-    h0v[v] = gr < rows ? T.hsave[0][(size_t)gr * H + col0] : 0.0f;
-  }
-  // head weights of this thread's column for the delta_1 phase: requested now (inside that phase's loop they were dependent loads)
-  constexpr int WHP = 12;
-  float whp[WHP];
-#pragma unroll
-  for (int j = 0; j < WHP; ++j) whp[j] = (N.base + N.off_Wh)[(size_t)(j < NO ? j : 0) * H + k1];
-  // first-layer weights of the dL/dx partial (last phase) as MFMA B fragments, requested here with the other operands: wave w
-  // contracts k16 chunk w of this slice, lane (g, li) supplies W0[n = slice + 16w + 4g + s][column dx_col0 + 16t + li], s = 0..3
-  constexpr int DXT = 2;   // 16-column tiles of dL/dx (dx_cols <= 32: a = 17 for Humanoid)
-  static_assert(SLW / 16 == NWV, "one k16 chunk of the slice per wave in the dL/dx phase");
-  float w0b[DXT][4];
-  if (T.dx) {
-    const float* W0 = N.base + N.off_W[0];
-    const int ld0 = N.ld[0];
-#pragma unroll
-    for (int t = 0; t < DXT; ++t)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int c = 16 * t + li;
-        w0b[t][s4] = c < T.dx_cols ? W0[pack_f(cs * SLW + 16 * wave + 4 * g + s4, T.dx_col0 + c, ld0)] : 0.0f;
-      }
-  }
-  // ---- head gradient (every slice recomputes it; the lead slice publishes it for the dW kernel)
-  for (int e = tid; e < 16 * NO; e += NTH) {  // only the NO live outputs per row: one pass, loads batched
-    const int row = e / NO, j = e - row * NO, gr = r0 + row;
-    float d = 0.0f;
-    if (gr < rows) {
-      d = bwd_head_grad(T, A, gr, j, NO);
-      if (T.dhead && lead) T.dhead[(size_t)gr * NO + j] = d;
+// ================================================================================================
+// Merged phase kernels of the SAC step (single run, narrow inputs, every working workgroup co-resident: <= 1 per CU).
+// The step's forward / backward-to-activations launches are ROW-LOCAL: the workgroups that serve one 16-row tile (4 tasks x CS column
+// slices) only exchange data with each other, and they sit on one XCD (tile = blockIdx.x, x fastest in the linear workgroup order the
+// dispatcher deals round-robin to the 8 XCDs).  So F1 -> F2 -> B1 (phase A) and F3 -> B2 -> B3 (phase C) each run as ONE launch whose
+// workgroups walk the stages and hand data over through per-tile arrival counters instead of kernel boundaries (ldx / stx above).
+// The step becomes A, dW{Q}+Adam+Polyak, C, dW{pi}+Adam: 4 launches instead of 8 — the two dW launches stay, they contract over ALL
+// rows.  Arithmetic and summation order are those of the separate launches (the stage bodies are the same text: *_split_tile.inc),
+// so results are bit-identical to the 8-launch path.  A stage's batch-independent operands (its weights) are requested BEFORE the
+// wait for the previous stage (the XCH_HOOK_* points of the bodies), so their latency passes while waiting.
+//   flags: one 128-byte line per counter; counter 2t / 2t+1 = stage 1 / stage 2 arrivals of tile t, counter PHASE_TAIL_FLAG = "the
+//   deferred tail of the previous step has run" (alpha is valid).  The preceding dW launch zeroes them (DwArgs::zero_flags).  After the
+//   counters: one word per tile in which every workgroup ORs the XCD it runs on (checked by the host: one bit per tile or the call fails).
+//   A workgroup that waits longer than ~1 s sets *err and goes on (the host then fails the call and falls back to 8 launches): the
+//   co-residency the protocol needs holds by construction, the bound only keeps a broken assumption from hanging the GPU.
+#define PHASE_MAX_TILES 64
+#define PHASE_TAIL_FLAG (2 * PHASE_MAX_TILES)
+#define PHASE_NFLAGS (2 * PHASE_MAX_TILES + 1)
+#define PHASE_MASK_WORD(t) ((PHASE_NFLAGS + (t)) * 32)   // per-tile XCD masks live after the counters (never zeroed by the dW launches)
+#define PHASE_FLAG_WORDS ((PHASE_NFLAGS + PHASE_MAX_TILES) * 32)
+struct PhaseAArgs { FwdArgs f1, f2; BwdArgs b1; unsigned* flags; int* err; unsigned long long* dbg; };
+struct PhaseCArgs { FwdArgs f3; BwdArgs b2, b3; unsigned* flags; int* err; unsigned long long* dbg; };
+
+#ifdef ILSX_KERNEL_IMPL
+__device__ __forceinline__ void xch_arrive(unsigned* flag) {   // every thread of the workgroup calls it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's exchange stores are acknowledged by the L2
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xch_wait(const unsigned* flag, unsigned target, int* err) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 21)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
-    dout[row * ILSX_MAX_NO + j] = d;
   }
-  // ---- this wave's slice of W_1 (backward-packed: all H rows x its 16 columns), one coalesced burst
-  float4 wreg[NC];
+  __syncthreads();
+  asm volatile("buffer_inv sc0" ::: "memory");   // drop this CU's vector L1: the producers' lines are read from the XCD's L2
+}
+// which XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 15u;
+}
+// every working workgroup of a phase launch ORs its XCD into its tile's mask (fire and forget): more than one bit in a mask = the
+// placement the exchange relies on did not hold, the host fails the call (ilsx_sac_train_from_replay) and falls back
+__device__ __forceinline__ void xch_mark_xcd(unsigned* mask) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_or(mask, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Phase A: stage 1 = fwd{pi(s') | Q1(s,a) | Q2(s,a) | pi(s)} (tasks y = 0..3, rows drawn from the replay ring);
+//          stage 2 = fwd{TQ1, TQ2 (s', a')} on the workgroups of y = 0 / 3 (prologue: finish pi(s'), next_obs drawn from the ring again);
+//          stage 3 = bwd{Q1, Q2 <- TD target} on the workgroups of y = 1 / 2;  y = 4: the deferred tail of the previous step.
+template <int H, int ACT, int CS>
+__global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) {
+  constexpr bool GRP = false, XCH = true;
+  constexpr int PH = 0;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const FwdGroup* GP = nullptr;
+  const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;
+  unsigned* tflag = P.flags + PHASE_TAIL_FLAG * 32;
+  if (y == 4) {
+    if (bx == 0 && cs == 0) {
+      const TailLite& TL = P.f1.tail[0];
+      tail_lite_run(TL, smem);
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&TL.scal->alpha, TL.scal->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // what the critic target of THIS step reads (stage 3), past the caches
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(tflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  if (bx * 16 >= P.f1.rows) return;   // padding tiles (grid.x is a multiple of 8): no member of such a tile takes part
+  unsigned* f1 = P.flags + (2 * bx) * 32;
+  unsigned* f2 = P.flags + (2 * bx + 1) * 32;
+  ILSX_STAMP(P.dbg, 0);
+  xch_mark_xcd(P.flags + PHASE_MASK_WORD(bx));
   {
-    const float* wp = N.base + N.off_Wb[1] + (size_t)(cs * NWV + wave) * NC * 256 + 4 * lane;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
+    const FwdArgs& A = P.f1;
+    const FwdTask& T = A.t[y];
+    const bool first_task = y == 0;
+#define XCH_HOOK_FIN
+#include "fwd_split_tile.inc"
+#undef XCH_HOOK_FIN
   }
-  lds_barrier();
-  ILSX_STAMP(A.dbg, 1);
-  // ---- delta_1 = (dout Wh) * act'(h_1), full width on the VALU: thread <-> column k1
+  ILSX_STAMP(P.dbg, 1);
+  xch_arrive(f1);
+  ILSX_STAMP(P.dbg, 2);
+  if (y == 0 || y == 3) {
+    {   // the target critic's weights and its next_obs rows are on their way while the tile's policy slices finish
+      const FwdArgs& A = P.f2;
+      const FwdTask& T = A.t[y == 0 ? 0 : 1];
+      const bool first_task = y == 0;
+#define XCH_HOOK_FIN ILSX_STAMP_SYNC(P.dbg, 7); xch_wait(f1, 4 * CS, P.err); ILSX_STAMP(P.dbg, 3);
+#define XCH_FINE_DBG P.dbg
+#include "fwd_split_tile.inc"
+#undef XCH_FINE_DBG
+#undef XCH_HOOK_FIN
+    }
+    ILSX_STAMP(P.dbg, 4);
+    xch_arrive(f2);
+    ILSX_STAMP(P.dbg, 5);
+  } else {
+    xch_wait(f1, 4 * CS, P.err);   // the other slices' layer-1 activations, the lead slice's layer 0
+    {
+      const BwdArgs& A = P.b1;
+      const BwdTask& T = A.t[y - 1];
+#define XCH_HOOK_ACT
+#define XCH_HOOK_HEAD xch_wait(f2, 2 * CS, P.err); xch_wait(tflag, 1u, P.err); ILSX_STAMP(P.dbg, 3);
+#include "bwd_split_tile.inc"
+#undef XCH_HOOK_ACT
+#undef XCH_HOOK_HEAD
+    }
+    ILSX_STAMP(P.dbg, 4);
+  }
+}
+
+// Phase C: stage 1 = fwd{Q1, Q2 (s, a~)} with the updated critics (prologue: finish pi(s) with the second noise draw);
+//          stage 2 = bwd{Q1, Q2 -> d(-min Q)/da~} on the same workgroups;  stage 3 = bwd{pi} on the workgroups of y = 0;
+//          y = 2: advance the replay-draw counter (nothing in this launch reads it).
+template <int H, int ACT, int CS>
+__global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) {
+  constexpr bool GRP = false, XCH = true;
+  constexpr int PH = 0;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const FwdGroup* GP = nullptr;
+  const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;
+  if (y == 2) {
+    if (bx == 0 && cs == 0 && threadIdx.x == 0) P.f3.tail[0].scal->gather_step += 1;
+    return;
+  }
+  if (bx * 16 >= P.f3.rows) return;
+  unsigned* f1 = P.flags + (2 * bx) * 32;
+  unsigned* f2 = P.flags + (2 * bx + 1) * 32;
+  ILSX_STAMP(P.dbg, 0);
+  xch_mark_xcd(P.flags + PHASE_MASK_WORD(bx));
   {
-    const float* Wh = N.base + N.off_Wh;
-    float accd[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) accd[i] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < WHP; ++j) {   // head rows requested at kernel entry (critics: 1, Hopper / Walker policies: 6 / 12)
-      if (j < NO) {
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) accd[i] = fmaf(dout[(rb1 + RSTEP * i) * ILSX_MAX_NO + j], whp[j], accd[i]);
-      }
-    }
-#pragma unroll 4
-    for (int j = WHP; j < NO; ++j) {
-      const float w = Wh[(size_t)j * H + k1];
-#pragma unroll
-      for (int i = 0; i < RPT; ++i) accd[i] = fmaf(dout[(rb1 + RSTEP * i) * ILSX_MAX_NO + j], w, accd[i]);
-    }
-    float* ds = lead ? T.dsave[1] : nullptr;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int row = rb1 + RSTEP * i, gr = r0 + row;
-      float dv = 0.0f;
-      if (gr < rows) {
-        dv = accd[i] * act_grad_from_out<ACT>(h1v[i]);
-        if (ds) ds[(size_t)gr * H + k1] = dv;
-      }
-      d1[row * LDH + k1] = dv;
-    }
+    const FwdArgs& A = P.f3;
+    const FwdTask& T = A.t[y];
+    const bool first_task = y == 0;
+#define XCH_HOOK_FIN
+#include "fwd_split_tile.inc"
+#undef XCH_HOOK_FIN
   }
-  lds_barrier();
-  ILSX_STAMP(A.dbg, 2);
-  // ---- delta_0 slice = (delta_1 W_1)[:, slice] * act'(h_0[:, slice])
+  ILSX_STAMP(P.dbg, 1);
+  xch_arrive(f1);
   {
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    const float* ap = d1 + li * LDH + 4 * g;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(ap + 16 * c);
-      acc0 = MFMA16(a.x, wreg[c].x, acc0); acc1 = MFMA16(a.y, wreg[c].y, acc1);
-      acc0 = MFMA16(a.z, wreg[c].z, acc0); acc1 = MFMA16(a.w, wreg[c].w, acc1);
-    }
-    float* ds = T.dsave[0];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int row = 4 * g + v, gr = r0 + row;
-      float dv = 0.0f;
-      if (gr < rows) {
-        dv = (acc0[v] + acc1[v]) * act_grad_from_out<ACT>(h0v[v]);
-        if (ds) ds[(size_t)gr * H + col0] = dv;
-      }
-      d0s[row * LDSL + lc] = dv;
-    }
+    const BwdArgs& A = P.b2;
+    const BwdTask& T = A.t[y];
+#define XCH_HOOK_ACT xch_wait(f1, 2 * CS, P.err); ILSX_STAMP(P.dbg, 2);
+#define XCH_HOOK_HEAD
+#include "bwd_split_tile.inc"
+#undef XCH_HOOK_ACT
+#undef XCH_HOOK_HEAD
   }
-  ILSX_STAMP(A.dbg, 3);
-  // ---- partial dL/dx over this slice of the H contraction, on the matrix pipe: dx[16 rows][dx_cols] = d0s[16][SLW] . W0[slice][cols].
-  //      (The first version reduced every (row, column) with a 6-step wave shuffle: 12 dependent butterflies per wave were 3 us of the
-  //      actor's critic-backward launch.)  Wave w contracts k16 chunk w; the NWV partial tiles are summed through LDS in wave order.
-  if (T.dx) {
-    lds_barrier();
-    float* red = d1;   // delta_1 is dead (every wave passed the barrier above after its last read): [DXT][NWV][4][64] floats
-    const float4 a4 = *reinterpret_cast<const float4*>(d0s + li * LDSL + 16 * wave + 4 * g);
-    const int ntile = (T.dx_cols + 15) >> 4;
-#pragma unroll
-    for (int t = 0; t < DXT; ++t) {
-      if (t < ntile) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc = MFMA16(a4.x, w0b[t][0], acc); acc = MFMA16(a4.y, w0b[t][1], acc);
-        acc = MFMA16(a4.z, w0b[t][2], acc); acc = MFMA16(a4.w, w0b[t][3], acc);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) red[((t * NWV + wave) * 4 + v) * 64 + lane] = acc[v];
-      }
+  ILSX_STAMP(P.dbg, 3);
+  xch_arrive(f2);
+  if (y == 0) {
+    {
+      const BwdArgs& A = P.b3;
+      const BwdTask& T = A.t[0];
+#define XCH_HOOK_ACT
+#define XCH_HOOK_HEAD xch_wait(f2, 2 * CS, P.err); ILSX_STAMP(P.dbg, 4);
+#include "bwd_split_tile.inc"
+#undef XCH_HOOK_ACT
+#undef XCH_HOOK_HEAD
     }
-    lds_barrier();
-    for (int e = tid; e < ntile * 256; e += NTH) {
-      const int t = e >> 8, v = (e >> 6) & 3, ol = e & 63;
-      float sum = 0.0f;
-#pragma unroll
-      for (int w2 = 0; w2 < NWV; ++w2) sum += red[((t * NWV + w2) * 4 + v) * 64 + ol];
-      const int row = 4 * (ol >> 4) + v, c = 16 * t + (ol & 15), gr = r0 + row;
-      if (c < T.dx_cols && gr < rows) T.dx[((size_t)cs * A.part_stride + gr) * T.dx_cols + c] = sum;
-    }
+    ILSX_STAMP(P.dbg, 5);
   }
-  ILSX_STAMP(A.dbg, 7);
 }
 #endif  // ILSX_KERNEL_IMPL
 
@@ -1458,6 +1138,7 @@ struct DwArgs {
   float* scratch; size_t span;
   // grouped launch: one self-contained record per output tile (its matrix and its agent's optimiser) in device memory
   const struct DwTileG* gtiles;
+  unsigned* zero_flags;   // non-null: workgroup 0 zeroes the PHASE_NFLAGS arrival counters of the phase kernel that follows this launch
 };
 struct DwTileG { DwMat J; AdamFuse F; };
 #define DW_SPLIT_MIN_ROWS 1024
@@ -1497,6 +1178,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   float* bpart = smem + 16 * 16 * 64;    // [16 waves][16]
   if (blockIdx.x & ((1u << D.xs) - 1u)) return;
   const int bx = blockIdx.x >> D.xs;
+  if (D.zero_flags && bx == 0 && blockIdx.y == 0 && threadIdx.x < PHASE_NFLAGS) D.zero_flags[threadIdx.x * 32] = 0u;
   int mi = 0;
   if (!GRP) {
 #pragma unroll
