@@ -454,7 +454,7 @@ int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P0, int H, int act, int KPma
   if (P.b2.ga_parts < 1) P.b2.ga_parts = 1;
   if (P.b3.ga_parts < 1) P.b3.ga_parts = 1;
   const int tiles = (P.f3.rows + 15) / 16;
-  dim3 grid((tiles + 7) & ~7, 3, cs), block(4 * H / cs);
+  dim3 grid((tiles + 7) & ~7, 4, cs), block(4 * H / cs);   // y: Q1, Q2, the policy's backward, the bookkeeping row
   const size_t lds = phase_lds_bytes(H, KPmax, cs);
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
   if (H == 256 && act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_c<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, P);

@@ -458,11 +458,9 @@ static int sac_critic_backward(ilsx_sac* s) {
     sac_policy_fin(s, A, eps1, s->rng_stream, false, w.a2, w.logp2, w.ppart);
     if (s->defer_tail) { A.tail = s->tail_dev; A.tail_mode = 2; A.tail_n = 1; }
     if (s->phase_now) {
-      // stage 2 of the phase launch: the target critics' workgroups draw next_obs from the ring themselves (same Philox draw as the
-      // policy task of stage 1) instead of waiting for the published copy, and finish pi(s') under the replay-draw counter (== the
-      // step counter once the pending tail has run; the tail runs concurrently in this launch)
-      A.gather = PA.f1.gather;
-      for (int i = 0; i < 2; ++i) { A.t[i].g0_off = s->o + s->a + 2; A.t[i].g1_off = 0; A.t[i].publish = 0; }
+      // stage 2 of the phase launch: next_obs is the copy the policy task of stage 1 published (w.s2, read after the tile's hand-off);
+      // pi(s') is finished under the replay-draw counter (== the step counter once the pending tail has run; the tail runs
+      // concurrently in this launch)
       A.fin.use_gather_step = 1;
       A.tail_mode = 0;
       PA.f2 = A;

@@ -861,8 +861,10 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
   constexpr bool XCH = false;
   const int bx = blockIdx.x, cs = blockIdx.z;
   const bool first_task = blockIdx.y == 0;
+#define XCH_HOOK_STAGE
 #define XCH_HOOK_FIN
 #include "fwd_split_tile.inc"
+#undef XCH_HOOK_STAGE
 #undef XCH_HOOK_FIN
 }
 #endif  // ILSX_KERNEL_IMPL
@@ -934,14 +936,15 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
 // rows.  Arithmetic and summation order are those of the separate launches (the stage bodies are the same text: *_split_tile.inc),
 // so results are bit-identical to the 8-launch path.  A stage's batch-independent operands (its weights) are requested BEFORE the
 // wait for the previous stage (the XCH_HOOK_* points of the bodies), so their latency passes while waiting.
-//   flags: one 128-byte line per counter; counter 2t / 2t+1 = stage 1 / stage 2 arrivals of tile t, counter PHASE_TAIL_FLAG = "the
+//   flags: one 128-byte line per counter; counter 3t / 3t+1 = stage 1 / stage 2 arrivals of tile t, 3t+2 = stage 1 arrivals of the
+//   policy-on-next_obs slices alone (phase A: all the target critics wait for), counter PHASE_TAIL_FLAG = "the
 //   deferred tail of the previous step has run" (alpha is valid).  The preceding dW launch zeroes them (DwArgs::zero_flags).  After the
 //   counters: one word per tile in which every workgroup ORs the XCD it runs on (checked by the host: one bit per tile or the call fails).
 //   A workgroup that waits longer than ~1 s sets *err and goes on (the host then fails the call and falls back to 8 launches): the
 //   co-residency the protocol needs holds by construction, the bound only keeps a broken assumption from hanging the GPU.
 #define PHASE_MAX_TILES 64
-#define PHASE_TAIL_FLAG (2 * PHASE_MAX_TILES)
-#define PHASE_NFLAGS (2 * PHASE_MAX_TILES + 1)
+#define PHASE_TAIL_FLAG (3 * PHASE_MAX_TILES)
+#define PHASE_NFLAGS (3 * PHASE_MAX_TILES + 1)
 #define PHASE_MASK_WORD(t) ((PHASE_NFLAGS + (t)) * 32)   // per-tile XCD masks live after the counters (never zeroed by the dW launches)
 #define PHASE_FLAG_WORDS ((PHASE_NFLAGS + PHASE_MAX_TILES) * 32)
 struct PhaseAArgs { FwdArgs f1, f2; BwdArgs b1; unsigned* flags; int* err; unsigned long long* dbg; };
@@ -977,7 +980,7 @@ __device__ __forceinline__ void xch_mark_xcd(unsigned* mask) {
 }
 
 // Phase A: stage 1 = fwd{pi(s') | Q1(s,a) | Q2(s,a) | pi(s)} (tasks y = 0..3, rows drawn from the replay ring);
-//          stage 2 = fwd{TQ1, TQ2 (s', a')} on the workgroups of y = 0 / 3 (prologue: finish pi(s'), next_obs drawn from the ring again);
+//          stage 2 = fwd{TQ1, TQ2 (s', a')} on the workgroups of y = 0 / 3 (prologue: finish pi(s'); next_obs as the policy task published it);
 //          stage 3 = bwd{Q1, Q2 <- TD target} on the workgroups of y = 1 / 2;  y = 4: the deferred tail of the previous step.
 template <int H, int ACT, int CS>
 __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) {
@@ -1000,30 +1003,47 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
     return;
   }
   if (bx * 16 >= P.f1.rows) return;   // padding tiles (grid.x is a multiple of 8): no member of such a tile takes part
-  unsigned* f1 = P.flags + (2 * bx) * 32;
-  unsigned* f2 = P.flags + (2 * bx + 1) * 32;
+  unsigned* f1 = P.flags + (3 * bx) * 32;
+  unsigned* f2 = P.flags + (3 * bx + 1) * 32;
   ILSX_STAMP(P.dbg, 0);
+#if defined(ILSX_STAMPS) && defined(ILSX_STAMPS_FINE)
+  if (P.dbg && threadIdx.x == 0 && (y == 1 || y == 2)) P.dbg[(size_t)ILSX_WG_LINEAR * ILSX_TRACE_SLOTS + 5] = clock64();   // shader clock (s_memtime) beside the 100 MHz stamps
+#endif
   xch_mark_xcd(P.flags + PHASE_MASK_WORD(bx));
   {
     const FwdArgs& A = P.f1;
     const FwdTask& T = A.t[y];
     const bool first_task = y == 0;
+#define XCH_HOOK_STAGE
 #define XCH_HOOK_FIN
 #include "fwd_split_tile.inc"
+#undef XCH_HOOK_STAGE
 #undef XCH_HOOK_FIN
   }
   ILSX_STAMP(P.dbg, 1);
-  xch_arrive(f1);
+  unsigned* f0 = P.flags + (3 * bx + 2) * 32;
+  if (y == 0) {   // the policy-on-next_obs slices: what the target critics wait for (they do not need the critics' own stage 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(f0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(f1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    xch_arrive(f1);
+  }
   ILSX_STAMP(P.dbg, 2);
   if (y == 0 || y == 3) {
-    {   // the target critic's weights and its next_obs rows are on their way while the tile's policy slices finish
+    {   // the target critic's weights are on their way while the tile's policy slices finish; next_obs = the rows stage 1 published
       const FwdArgs& A = P.f2;
       const FwdTask& T = A.t[y == 0 ? 0 : 1];
       const bool first_task = y == 0;
-#define XCH_HOOK_FIN ILSX_STAMP_SYNC(P.dbg, 7); xch_wait(f1, 4 * CS, P.err); ILSX_STAMP(P.dbg, 3);
+#define XCH_HOOK_STAGE ILSX_STAMP_SYNC(P.dbg, 7); xch_wait(f0, CS, P.err); ILSX_STAMP(P.dbg, 3);
+#define XCH_HOOK_FIN
 #define XCH_FINE_DBG P.dbg
 #include "fwd_split_tile.inc"
 #undef XCH_FINE_DBG
+#undef XCH_HOOK_STAGE
 #undef XCH_HOOK_FIN
     }
     ILSX_STAMP(P.dbg, 4);
@@ -1041,12 +1061,15 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
 #undef XCH_HOOK_HEAD
     }
     ILSX_STAMP(P.dbg, 4);
+#if defined(ILSX_STAMPS) && defined(ILSX_STAMPS_FINE)
+    if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)ILSX_WG_LINEAR * ILSX_TRACE_SLOTS + 6] = clock64();
+#endif
   }
 }
 
 // Phase C: stage 1 = fwd{Q1, Q2 (s, a~)} with the updated critics (prologue: finish pi(s) with the second noise draw);
-//          stage 2 = bwd{Q1, Q2 -> d(-min Q)/da~} on the same workgroups;  stage 3 = bwd{pi} on the workgroups of y = 0;
-//          y = 2: advance the replay-draw counter (nothing in this launch reads it).
+//          stage 2 = bwd{Q1, Q2 -> d(-min Q)/da~} on the same workgroups (y = 0 / 1);  stage 3 = bwd{pi} on workgroups of its own (y = 2);
+//          y = 3: advance the replay-draw counter (nothing in this launch reads it).
 template <int H, int ACT, int CS>
 __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) {
   constexpr bool GRP = false, XCH = true;
@@ -1054,21 +1077,38 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const FwdGroup* GP = nullptr;
   const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;
-  if (y == 2) {
+  if (y == 3) {
     if (bx == 0 && cs == 0 && threadIdx.x == 0) P.f3.tail[0].scal->gather_step += 1;
     return;
   }
   if (bx * 16 >= P.f3.rows) return;
-  unsigned* f1 = P.flags + (2 * bx) * 32;
-  unsigned* f2 = P.flags + (2 * bx + 1) * 32;
+  unsigned* f1 = P.flags + (3 * bx) * 32;
+  unsigned* f2 = P.flags + (3 * bx + 1) * 32;
   ILSX_STAMP(P.dbg, 0);
   xch_mark_xcd(P.flags + PHASE_MASK_WORD(bx));
+  if (y == 2) {
+    // the policy's backward has workgroups of its own: weights and saved activations (from phase A's launch) are requested at once,
+    // the head gradient waits for both critics' dQ/da partials (stage 2) — and with them for the action / noise / raw head stage 1 published
+    {
+      const BwdArgs& A = P.b3;
+      const BwdTask& T = A.t[0];
+#define XCH_HOOK_ACT
+#define XCH_HOOK_HEAD xch_wait(f2, 2 * CS, P.err); ILSX_STAMP(P.dbg, 4);
+#include "bwd_split_tile.inc"
+#undef XCH_HOOK_ACT
+#undef XCH_HOOK_HEAD
+    }
+    ILSX_STAMP(P.dbg, 5);
+    return;
+  }
   {
     const FwdArgs& A = P.f3;
     const FwdTask& T = A.t[y];
     const bool first_task = y == 0;
+#define XCH_HOOK_STAGE
 #define XCH_HOOK_FIN
 #include "fwd_split_tile.inc"
+#undef XCH_HOOK_STAGE
 #undef XCH_HOOK_FIN
   }
   ILSX_STAMP(P.dbg, 1);
@@ -1084,18 +1124,6 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) 
   }
   ILSX_STAMP(P.dbg, 3);
   xch_arrive(f2);
-  if (y == 0) {
-    {
-      const BwdArgs& A = P.b3;
-      const BwdTask& T = A.t[0];
-#define XCH_HOOK_ACT
-#define XCH_HOOK_HEAD xch_wait(f2, 2 * CS, P.err); ILSX_STAMP(P.dbg, 4);
-#include "bwd_split_tile.inc"
-#undef XCH_HOOK_ACT
-#undef XCH_HOOK_HEAD
-    }
-    ILSX_STAMP(P.dbg, 5);
-  }
 }
 #endif  // ILSX_KERNEL_IMPL
 

@@ -40,7 +40,8 @@ for rep in range(2):
     ctx.sync()
     n = C.c_int()
     _lib.check(ctx.lib.ilsx_debug_set_stamp_buffer(ctx.h, None, 0, C.byref(n)))
-    t = buf.numpy().astype(np.float64) * 0.01   # 100 MHz ticks -> us
+    buf_raw = buf.numpy()
+    t = buf_raw.astype(np.float64) * 0.01   # 100 MHz ticks -> us
     print(f"--- rep {rep}: {n.value} instrumented launches (3 steps of A D1 C D2)")
     base = None
     for L in range(4, min(n.value, 8)):
@@ -53,7 +54,7 @@ for rep in range(2):
         kind = "ACAC"[L % 4] if False else ("A", "D1", "C", "D2")[L % 4]
         print(f"launch {L} ({kind}): {live.size} workgroups, begins {s0 - base:7.2f} us after the step's first launch")
         if kind in ("A", "C"):
-            ny = 5 if kind == "A" else 3
+            ny = 5 if kind == "A" else 4
             y = (live // 16) % ny
             for yy in range(ny - 1):
                 m = live[y == yy]
@@ -64,6 +65,13 @@ for rep in range(2):
                     if ok.any():
                         row.append(f"s{sl}@{np.median(v[ok]) - s0:6.2f}(max {v[ok].max() - s0:6.2f})")
                 print(f"    task row {yy}: " + "  ".join(row))
+                if kind == "A" and yy in (1, 2):     # fine build: slots 5 / 6 hold the shader clock at the same two points as stamps 0 / 4
+                    raw = buf_raw[L][m]
+                    ok = (raw[:, 5] > 0) & (raw[:, 6] > 0) & (raw[:, 4] > 0)
+                    if ok.any():
+                        cyc = (raw[ok, 6] - raw[ok, 5]).astype(np.float64)
+                        us = (raw[ok, 4] - raw[ok, 0]).astype(np.float64) * 0.01
+                        print(f"        shader clock over the workgroup's life: {np.median(cyc / us):.0f} MHz (s_memtime cycles / 100 MHz stamps)")
         else:
             e = t[L][live, 7]
             print(f"    span {e.max() - s0:6.2f}")
