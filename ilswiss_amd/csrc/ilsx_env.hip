@@ -141,6 +141,10 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
   constexpr int N = NB + 2;
   using S = EnvScratch<NB, MR, BLOCK>;
   double phi[NB], phid[NB], ox[NB], oz[NB], aox[NB], aoz[NB];
+  // cos / sin of every body angle, ONCE per evaluation (one sincos each: a shared range reduction): the kinematics of a child, the
+  // mass-matrix loop and the contact geometry all use the same values (the first form called cos and sin separately at each of the
+  // three places: ~11 pairs per evaluation of the 4-body model, a sixth of its instructions)
+  double cb[NB], sb[NB];
   // ---- kinematics
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -150,16 +154,16 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
       ox[b] = q[0]; oz[b] = q[1]; aox[b] = 0.0; aoz[b] = 0.0;
     } else {
       // parent index is data: select with a small unrolled scan (keeps the arrays in registers)
-      double pphi = 0, pphid = 0, pox = 0, poz = 0, paox = 0, paoz = 0;
+      double pphi = 0, pphid = 0, pox = 0, poz = 0, paox = 0, paoz = 0, c = 1.0, s = 0.0;
 #pragma unroll
       for (int j = 0; j < NB; ++j)
-        if (j == p) { pphi = phi[j]; pphid = phid[j]; pox = ox[j]; poz = oz[j]; paox = aox[j]; paoz = aoz[j]; }
+        if (j == p) { pphi = phi[j]; pphid = phid[j]; pox = ox[j]; poz = oz[j]; paox = aox[j]; paoz = aoz[j]; c = cb[j]; s = sb[j]; }
       phi[b] = pphi + m.jsign[b] * q[2 + b]; phid[b] = pphid + m.jsign[b] * v[2 + b];
-      const double c = cos(pphi), s = sin(pphi);
       const double wx = c * m.anchor[b][0] - s * m.anchor[b][1], wz = s * m.anchor[b][0] + c * m.anchor[b][1];
       ox[b] = pox + wx; oz[b] = poz + wz;
       aox[b] = paox - pphid * pphid * wx; aoz[b] = paoz - pphid * pphid * wz;
     }
+    sincos(phi[b], &sb[b], &cb[b]);
   }
   // ---- mass matrix + right-hand side
 #pragma unroll
@@ -169,7 +173,7 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
   for (int i = 0; i < N; ++i) rhs[i] = 0.0;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const double c = cos(phi[b]), s = sin(phi[b]);
+    const double c = cb[b], s = sb[b];
     const double cwx = c * m.com[b][0] - s * m.com[b][1], cwz = s * m.com[b][0] + c * m.com[b][1];
     const double cx = ox[b] + cwx, cz = oz[b] + cwz;
     const double acx = aox[b] - phid[b] * phid[b] * cwx, acz = aoz[b] - phid[b] * phid[b] * cwz;
@@ -201,7 +205,10 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
     for (int j = 0; j < NB; ++j)
       if (j == b) rhs[2 + j] += m.gear[j] * ctrl[k];
   }
-  // ---- Cholesky M = L L^T (lower triangle in place)
+  // ---- Cholesky M = L L^T (lower triangle in place).  Every division by a pivot is a multiplication by its reciprocal, taken once
+  // (an fp64 division is ~40 instructions on this pipe; the factorisation, the two solves, one forward substitution per constraint
+  // row and the final back-substitution held 30 + 6 per row of them per evaluation).  1 ulp away from the oracle's quotients.
+  double invd[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
 #pragma unroll
@@ -209,7 +216,8 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
       double sum = SL(S::OFF_M, i * N + k);
 #pragma unroll
       for (int t = 0; t < k; ++t) sum -= SL(S::OFF_M, i * N + t) * SL(S::OFF_M, k * N + t);
-      SL(S::OFF_M, i * N + k) = (i == k) ? sqrt(sum) : sum / SL(S::OFF_M, k * N + k);
+      if (i == k) { const double d = sqrt(sum); SL(S::OFF_M, i * N + k) = d; invd[i] = 1.0 / d; }
+      else SL(S::OFF_M, i * N + k) = sum * invd[k];
     }
   }
   auto chol_solve = [&](double (&x)[N]) {
@@ -218,14 +226,14 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
       double sum = x[i];
 #pragma unroll
       for (int t = 0; t < i; ++t) sum -= SL(S::OFF_M, i * N + t) * x[t];
-      x[i] = sum / SL(S::OFF_M, i * N + i);
+      x[i] = sum * invd[i];
     }
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
       double sum = x[i];
 #pragma unroll
       for (int t = i + 1; t < N; ++t) sum -= SL(S::OFF_M, t * N + i) * x[t];
-      x[i] = sum / SL(S::OFF_M, i * N + i);
+      x[i] = sum * invd[i];
     }
   };
   double qacc0[N];
@@ -252,11 +260,11 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
     const double bdamp = 2.0 / (dmax * tc), kstiff = 1.0 / (dmax * dmax * tc * tc * dr * dr);
     for (int gi = m.ng - 1; gi >= 0; --gi) {
       const int b = m.geom_body[gi];
-      double bphi = 0, box = 0, boz = 0;
+      double box = 0, boz = 0, c = 1.0, s = 0.0;
 #pragma unroll
       for (int j = 0; j < NB; ++j)
-        if (j == b) { bphi = phi[j]; box = ox[j]; boz = oz[j]; }
-      const double c = cos(bphi), s = sin(bphi), rad = m.grad[gi];
+        if (j == b) { box = ox[j]; boz = oz[j]; c = cb[j]; s = sb[j]; }
+      const double rad = m.grad[gi];
       for (int e = 0; e < 2; ++e) {
         const double ex = e == 0 ? m.gp1[gi][0] : m.gp2[gi][0], ez = e == 0 ? m.gp1[gi][1] : m.gp2[gi][1];
         const double wx = c * ex - s * ez, wz = s * ex + c * ez;
@@ -318,7 +326,7 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
       double sum = x[i];
 #pragma unroll
       for (int t = 0; t < i; ++t) sum -= SL(S::OFF_M, i * N + t) * x[t];
-      x[i] = sum / SL(S::OFF_M, i * N + i);
+      x[i] = sum * invd[i];
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) SL(S::OFF_J, r * N + i) = x[i];
@@ -332,9 +340,10 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
       SL(S::OFF_A, r * (r + 1) / 2 + c2) = sum;
     }
   }
+  // Rd is reused for 1 / (a_tt + R_t): the 30 sweeps divide by it once per row instead of once per row per sweep
 #pragma unroll
   for (int t = 0; t < MR; ++t)
-    if (t < nr) Rd[t] = (1.0 - rd[t]) / rd[t] * SL(S::OFF_A, S::a_idx(t, t));
+    if (t < nr) { const double att = SL(S::OFF_A, S::a_idx(t, t)); Rd[t] = 1.0 / (att + (1.0 - rd[t]) / rd[t] * att); }
   for (int it = 0; it < m.pgs_iters; ++it) {
 #pragma unroll
     for (int t = 0; t < MR; ++t) {
@@ -344,7 +353,7 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
 #pragma unroll
       for (int u = 0; u < MR; ++u)
         if (u < nr) res -= SL(S::OFF_A, S::a_idx(t, u)) * f[u];
-      double fi = res / (aii + Rd[t]);
+      double fi = res * Rd[t];
       if (rkind[t] == 1) {
         const double lim = rmu[t] * f[t > 0 ? t - 1 : 0];
         fi = fmin(fmax(fi, -lim), lim);
@@ -370,7 +379,7 @@ __device__ void env_dynamics(const PlanarModelDev& m, const double (&q)[NB + 2],
     double sum = w[i];
 #pragma unroll
     for (int t = i + 1; t < N; ++t) sum -= SL(S::OFF_M, t * N + i) * w[t];
-    w[i] = sum / SL(S::OFF_M, i * N + i);
+    w[i] = sum * invd[i];
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) qacc[i] = qacc0[i] + w[i];
@@ -468,8 +477,19 @@ __device__ __forceinline__ void env_reset_state(const PlanarModelDev& m, uint64_
 template <int NB, int MR, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
   constexpr int N = NB + 2;
-  extern __shared__ __attribute__((aligned(16))) double smd[];
-  const PlanarModelDev& m = *A.m;
+  extern __shared__ __attribute__((aligned(16))) double smd_all[];
+  // The model record (2 KB of constants every phase of the dynamics reads, many of them under run-time indices: geom -> body, actuator
+  // -> body) is copied into LDS once per workgroup.  Read in place from global memory it cost ~100 vector loads per dynamics evaluation,
+  // each waited for on the spot by the one wave of its SIMD (rocprofv3: 1546 VMEM reads per wave per env step, SQ_WAIT_ANY 54 % of
+  // the wave's cycles): a broadcast LDS read is a tenth of that latency.
+  constexpr int MODEL_DOUBLES = (sizeof(PlanarModelDev) + 7) / 8;
+  {
+    const double* src = reinterpret_cast<const double*>(A.m);
+    for (int i = threadIdx.x; i < MODEL_DOUBLES; i += BLOCK) smd_all[i] = src[i];
+    __syncthreads();
+  }
+  const PlanarModelDev& m = *reinterpret_cast<const PlanarModelDev*>(smd_all);
+  double* smd = smd_all + MODEL_DOUBLES;
   const int lane_in_block = threadIdx.x;
   const int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t >= A.n_ids) return;
@@ -800,7 +820,7 @@ __global__ __launch_bounds__(64) void k_env3dw_reset(const Spatial3Dev* mp, doub
 template <int NB, int MR, int BLOCK>
 static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
   using S = EnvScratch<NB, MR, BLOCK>;
-  const size_t lds = (size_t)S::TOTAL * BLOCK * sizeof(double);
+  const size_t lds = (size_t)S::TOTAL * BLOCK * sizeof(double) + ((sizeof(PlanarModelDev) + 7) / 8) * sizeof(double);   // per-env scratch + the model record
   static bool attr_done = false;
   if (!attr_done) {
     HIPCHK(hipFuncSetAttribute((const void*)k_env_step<NB, MR, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -73,7 +73,7 @@ struct ilsx_sac {
   hipGraphExec_t graph = nullptr;
   ilsx_replay* graph_rb = nullptr;
   int graph_B = 0;
-  bool graph_defer = false;
+  bool graph_defer = false, graph_phase = false;
   // deferred tail (TailLite, kernels.h): active inside ilsx_sac_train_from_replay on the column-split path
   bool defer_tail = false;
   TailLite* tail_dev = nullptr;
@@ -779,12 +779,12 @@ extern "C" int ilsx_sac_train_step(ilsx_sac* s, const float* obs, const float* a
 // The merged phase kernels need: the column-split path on narrow inputs, the fused in-kernel replay draw, the deferred tail, no
 // gradient all-reduce between the phases, no per-workgroup stamps, and every workgroup of a phase launch resident at once.
 static bool sac_phase_ok(ilsx_sac* s, int B) {
-  static const bool off = getenv("ILSX_NO_PHASE") != nullptr;
+  const bool off = getenv("ILSX_NO_PHASE") != nullptr;
   return !off && !s->phase_broken && s->cs > 1 && !s->h0scr && !s->col && s->defer_tail && !sac_is_split(s) &&
          s->ctx->xcd_shift == 0 && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
 }
 static bool sac_phase_possible(ilsx_sac* s, int B) {   // as sac_phase_ok, for the state a train_from_replay call ran in (defer_tail already cleared)
-  static const bool off = getenv("ILSX_NO_PHASE") != nullptr;
+  const bool off = getenv("ILSX_NO_PHASE") != nullptr;   // read per call: tests switch between the two paths in one process
   return !off && s->cs > 1 && !s->h0scr && !sac_is_split(s) && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
 }
 static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
@@ -827,7 +827,8 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
       if (rc != ILSX_OK) return rc;
     }
   } else {
-    if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail) {
+    const bool phase = sac_phase_ok(s, B);
+    if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail || s->graph_phase != phase) {
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
       hipGraph_t g = nullptr;
       HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -838,7 +839,7 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
       e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
       if (e != hipSuccess) { s->graph = nullptr; ILSX_FAIL(ILSX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
-      s->graph_rb = rb; s->graph_B = B; s->graph_defer = s->defer_tail;
+      s->graph_rb = rb; s->graph_B = B; s->graph_defer = s->defer_tail; s->graph_phase = phase;
     }
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));

@@ -254,3 +254,49 @@ def test_split_run_phases_with_rccl_on_the_ctx_stream_equal_the_fused_step():
         outs[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])   # RCCL prints its own banner lines
     assert outs["split"] == outs["fused"], outs
     assert outs["split_graph"] == outs["fused"], outs
+
+
+@pytest.mark.parametrize("o,a,H,B,n_steps", [(11, 3, 256, 256, 7), (17, 6, 128, 37, 5), (11, 3, 256, 100, 4)])
+def test_phase_kernels_are_bitwise_the_eight_launch_path(o, a, H, B, n_steps):
+    """ilsx_sac_train_from_replay runs F1 F2 B1 and F3 B2 B3 as ONE launch each (k_sac_phase_a / _c: the stages hand over through
+    per-tile counters in the XCD's L2).  Same stage bodies, same summation order: every parameter, target, optimiser moment and log_alpha
+    must equal the one-launch-per-stage path (ILSX_NO_PHASE=1) bit for bit — through several calls, a ragged last tile (B = 37, 100)
+    and the 128-wide / 2-slice instantiation."""
+    import os
+    import ilswiss_amd as ia
+    hidden, N = [H, H], 6000
+    rng = np.random.default_rng(o + H + B)
+    params = _init(rng, o, a, hidden)
+    data = _ring_data(rng, N, o, a)
+    runs = []
+    for no_phase in (False, True):
+        if no_phase:
+            os.environ["ILSX_NO_PHASE"] = "1"
+        else:
+            os.environ.pop("ILSX_NO_PHASE", None)
+        try:
+            ctx = ia.Context(0, seed=2024)
+            rb = ia.SimpleReplayBuffer(8192, o, a, random_seed=5, ctx=ctx)
+            rb.add_rows(*data)
+            tr = _agent(ia, ctx, o, a, hidden, params, SAC_KW, B)
+            tr.eval_statistics = {}
+            tr.train_from_replay(rb, n_steps, B)
+            tr.train_from_replay(rb, 1, B)             # call boundary: pending tail flushed and re-armed
+            tr.eval_statistics = None
+            tr.train_from_replay(rb, 2, B)             # statistics of the last step
+            st = dict(tr.get_eval_statistics())
+            snap = tr.get_snapshot()
+            runs.append((snap, st, tr.rng_step))
+            ctx.close()
+        finally:
+            os.environ.pop("ILSX_NO_PHASE", None)
+    (s0, st0, r0), (s1, st1, r1) = runs
+    assert r0 == r1 == n_steps + 3
+    for k in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+        np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
+    assert s0["log_alpha"] == s1["log_alpha"]
+    for k in ("policy_optimizer", "qf1_optimizer", "qf2_optimizer"):
+        np.testing.assert_array_equal(s0[k]["exp_avg"], s1[k]["exp_avg"], err_msg=k)
+        np.testing.assert_array_equal(s0[k]["exp_avg_sq"], s1[k]["exp_avg_sq"], err_msg=k)
+    for k, v in st0.items():
+        assert v == st1[k] or (np.isnan(v) and np.isnan(st1[k])), (k, v, st1[k])
