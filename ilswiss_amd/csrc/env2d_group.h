@@ -1,0 +1,485 @@
+// env2d_group.h — the planar articulated-body stepper with SIXTEEN LANES PER ENV (Hopper, Walker2d, HalfCheetah).
+//
+// The first form (k_env_step in ilsx_env.hip, kept for A/B runs: ILSX_ENV2D_LANE=1) gives every env ONE lane: 4096 envs are 64
+// wavefronts on a chip with 1024 SIMDs, and a vec step lasts as long as one lane needs for 16 dynamics evaluations of dependent fp64
+// arithmetic (0.9 ms: rocprofv3 — 165k instructions per wave per env step, half of the wave's cycles spent waiting on the previous
+// instruction's result), whatever the number of envs.  Here a DPP row of 16 lanes shares one env (4 envs per wavefront, one wavefront
+// per workgroup): lane l is degree of freedom l (0 = x, 1 = z, 2 + b = the hinge of body b), body l - 2, constraint row l and
+// contact candidate l at once, so every phase of oracle/planar_env.py::dynamics runs over its natural index in parallel:
+//
+//   kinematics, COM, inertial forces        one body per lane; ancestors' terms summed root-to-leaf under the ancestor bit mask
+//   mass matrix + right-hand side           one ROW per lane (bodies in ascending order: the oracle's summation order)
+//   Cholesky M = L L^T                      lane i owns row i; column step k: pivot from lane k, rank-1 update of the trailing rows
+//   L y = rhs, L^T x = y                    lane i keeps x_i; the value finished at step k travels by ds_swizzle (a row broadcast)
+//   contact / limit rows                    one candidate per lane, row numbers by ballot + population count in the oracle's order
+//   z_r = L^-1 j_r, right-hand sides        one row per lane (L read back from the env's LDS blackboard)
+//   A = Z Z^T                               one row of A per lane
+//   projected Gauss-Seidel                  lane t = row t with its residual, bounds and row t of A in registers; the row whose turn it
+//                                           is publishes its new force with one row broadcast, every lane folds the change into its
+//                                           residual with one multiply-add (the oracle recomputes the residual from scratch: same
+//                                           fixed point, rounding-level differences, 1e-9 against the oracle over chained steps)
+//   q.. = qacc0 + L^-T (Z^T f)              one degree of freedom per lane
+//
+// Hand-offs between lanes go through the env's LDS blackboard (one wavefront: LDS operations execute in order, a hand-off is a
+// compiler fence) or, on the latency-critical chains (substitutions, Gauss-Seidel), through ds_swizzle row broadcasts.  Control flow
+// is wave-uniform; an env without active rows in a wavefront that has some computes zero forces.
+// Included by ilsx_env.hip after PlanarModelDev / EnvStepArgs / impedance_d / env_uniform.
+#pragma once
+
+#define EG_LANES 16
+#define EG_ENVS 4    // per wavefront == per workgroup
+#define EG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// value of lane K of this lane's 16-lane row (ds_swizzle bit mode: lane' = (lane & 0x10) | K inside each half-wave)
+template <int K> __device__ __forceinline__ double eg_bcast(double x) {
+  constexpr int pat = 0x10 | (K << 5);
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pat);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pat);
+  return __hiloint2double(hi, lo);
+}
+
+// the same with the source lane as a (compile-time after unrolling) value: the swizzle pattern is an instruction immediate
+__device__ __forceinline__ double eg_bcast_k(double x, int k) {
+  switch (k) {
+    case 0: return eg_bcast<0>(x);   case 1: return eg_bcast<1>(x);   case 2: return eg_bcast<2>(x);   case 3: return eg_bcast<3>(x);
+    case 4: return eg_bcast<4>(x);   case 5: return eg_bcast<5>(x);   case 6: return eg_bcast<6>(x);   case 7: return eg_bcast<7>(x);
+    case 8: return eg_bcast<8>(x);   case 9: return eg_bcast<9>(x);   case 10: return eg_bcast<10>(x); case 11: return eg_bcast<11>(x);
+    case 12: return eg_bcast<12>(x); case 13: return eg_bcast<13>(x); case 14: return eg_bcast<14>(x); default: return eg_bcast<15>(x);
+  }
+}
+
+template <int NB, int MR>
+struct EgOff {   // the env's LDS blackboard, in doubles
+  static constexpr int N = NB + 2;
+  static constexpr int BODY_F = 12;                       // c s phid wx wz tax taz ox oz cx cz (+ 1 spare) ; fx fz live in FRC
+  static constexpr int QV = 0;                            // q[N] v[N]
+  static constexpr int BODY = QV + 2 * N;                 // [NB][BODY_F]
+  static constexpr int FRC = BODY + NB * BODY_F;          // [NB][2]
+  static constexpr int LMAT = FRC + 2 * NB;               // [N][N] lower triangle of L, row-major
+  static constexpr int INVD = LMAT + N * N;               // [N]
+  static constexpr int QACC0 = INVD + N;                  // [N]
+  static constexpr int ROWJ = QACC0 + N;                  // [MR][N]   J rows, overwritten by z_r
+  static constexpr int ROWS = ROWJ + MR * N;              // [MR][4]   residual r, kind, friction, impedance d
+  static constexpr int TOTAL = ROWS + MR * 4;
+};
+
+// Forward dynamics for the env this 16-lane row serves.  In: this lane's q_l, v_l (0 beyond N), `torque` = gear * ctrl of the actuator
+// on this lane's hinge (0 if none).  Out: this lane's acceleration.  E = the env's blackboard.
+template <int NB, int MR>
+__device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q, double v, double torque, double* E, int l, int grp) {
+  constexpr int N = NB + 2;
+  using O = EgOff<NB, MR>;
+  const bool dof = l < N;
+  const int jb = l >= 2 && l < N ? l - 2 : 0;        // the body on this lane (lanes 0, 1 and >= N shadow body 0; they publish nothing)
+  const bool body = l >= 2 && l < N;
+  // ---- q, v on the blackboard
+  if (dof) { E[O::QV + l] = q; E[O::QV + N + l] = v; }
+  EG_SYNC();
+  // ---- kinematics of body jb: angle and rate = the ancestors' hinge terms, root to leaf
+  const unsigned am = (unsigned)m.ancmask[jb];
+  double phi = 0.0, phid = 0.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double sg = ((am >> j) & 1u) ? m.jsign[j] : 0.0;
+    phi += sg * E[O::QV + 2 + j];
+    phid += sg * E[O::QV + N + 2 + j];
+  }
+  double sn, cs;
+  sincos(phi, &sn, &cs);
+  double* Bm = E + O::BODY + jb * O::BODY_F;
+  if (body) { Bm[0] = cs; Bm[1] = sn; Bm[2] = phid; }
+  EG_SYNC();
+  {   // hinge offset from the parent's origin (world frame) and what the origin's acceleration loses there; zero for the root
+    const int p = m.parent[jb];
+    const double* Pm = E + O::BODY + (p < 0 ? 0 : p) * O::BODY_F;
+    const double pc = Pm[0], ps = Pm[1], pphid = Pm[2];
+    double wx = pc * m.anchor[jb][0] - ps * m.anchor[jb][1], wz = ps * m.anchor[jb][0] + pc * m.anchor[jb][1];
+    double tax = pphid * pphid * wx, taz = pphid * pphid * wz;
+    if (p < 0) { wx = 0.0; wz = 0.0; tax = 0.0; taz = 0.0; }
+    if (body) { Bm[3] = wx; Bm[4] = wz; Bm[5] = tax; Bm[6] = taz; }
+  }
+  EG_SYNC();
+  double ox = E[O::QV + 0], oz = E[O::QV + 1], aox = 0.0, aoz = 0.0;
+#pragma unroll
+  for (int j = 1; j < NB; ++j) {
+    if ((am >> j) & 1u) {
+      const double* Jm = E + O::BODY + j * O::BODY_F;
+      ox += Jm[3]; oz += Jm[4]; aox -= Jm[5]; aoz -= Jm[6];
+    }
+  }
+  {
+    const double cwx = cs * m.com[jb][0] - sn * m.com[jb][1], cwz = sn * m.com[jb][0] + cs * m.com[jb][1];
+    const double cx = ox + cwx, cz = oz + cwz;
+    const double acx = aox - phid * phid * cwx, acz = aoz - phid * phid * cwz;
+    const double mb = m.mass[jb];
+    if (body) {
+      Bm[7] = ox; Bm[8] = oz; Bm[9] = cx; Bm[10] = cz;
+      E[O::FRC + 2 * jb] = mb * (0.0 - acx); E[O::FRC + 2 * jb + 1] = mb * (-m.gravity - acz);
+    }
+  }
+  EG_SYNC();
+  // ---- mass matrix row l and right-hand side l: bodies in ascending order
+  double Mrow[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) Mrow[k] = 0.0;
+  double rhs = 0.0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const double* Cm = E + O::BODY + b * O::BODY_F;
+    const double cx = Cm[9], cz = Cm[10];
+    const unsigned amb = (unsigned)m.ancmask[b];
+    // this lane's Jacobian entries of body b
+    double jxi, jzi, jpi;
+    if (l == 0) { jxi = 1.0; jzi = 0.0; jpi = 0.0; }
+    else if (l == 1) { jxi = 0.0; jzi = 1.0; jpi = 0.0; }
+    else {
+      const double sg = ((amb >> jb) & 1u) ? m.jsign[jb] : 0.0;
+      jxi = -sg * (cz - oz); jzi = sg * (cx - ox); jpi = sg;
+    }
+    const double mb = m.mass[b], ib = m.inertia[b];
+    rhs += jxi * E[O::FRC + 2 * b] + jzi * E[O::FRC + 2 * b + 1];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      double jxk, jzk, jpk;
+      if (k == 0) { jxk = 1.0; jzk = 0.0; jpk = 0.0; }
+      else if (k == 1) { jxk = 0.0; jzk = 1.0; jpk = 0.0; }
+      else {
+        const double* Km = E + O::BODY + (k - 2) * O::BODY_F;
+        const double sg = ((amb >> (k - 2)) & 1u) ? m.jsign[k - 2] : 0.0;
+        jxk = -sg * (cz - Km[8]); jzk = sg * (cx - Km[7]); jpk = sg;
+      }
+      if (k <= l) Mrow[k] += mb * (jxi * jxk + jzi * jzk) + ib * jpi * jpk;
+    }
+  }
+  if (body) {
+#pragma unroll
+    for (int k = 2; k < N; ++k)
+      if (k == l) Mrow[k] += m.armature[jb];
+    rhs -= m.damping[jb] * v + m.stiffness[jb] * q;
+    rhs += torque;
+  }
+  // ---- Cholesky, column steps.  Every lane takes the reciprocal of the broadcast pivot itself (same bits everywhere).
+  double invd[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double dk = eg_bcast_k(sqrt(Mrow[k]), k);
+    const double ik = 1.0 / dk;
+    invd[k] = ik;
+    if (l == k) Mrow[k] = dk;
+    else if (l > k) Mrow[k] = Mrow[k] * ik;          // L[l][k]
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      const double ljk = eg_bcast_k(Mrow[k], j);        // L[j][k]
+      if (l >= j) Mrow[j] -= Mrow[k] * ljk;
+    }
+  }
+  // L and the reciprocal pivots on the blackboard (the constraint rows read them back); L^T entries this lane needs for the back-substitutions
+  if (dof) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (k <= l) E[O::LMAT + l * N + k] = Mrow[k];
+  }
+  EG_SYNC();
+  double LT[N];   // LT[k] = L[k][l] for k > l
+#pragma unroll
+  for (int k = 0; k < N; ++k) LT[k] = (k > l && dof) ? E[O::LMAT + k * N + l] : 0.0;
+  // ---- qacc0 = M^-1 rhs
+  double y = dof ? rhs : 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double t = y * invd[k];
+    const double yk = eg_bcast_k(t, k);
+    if (l == k) y = t;
+    else if (l > k) y -= Mrow[k] * yk;
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    const double t = y * invd[k];
+    const double xk = eg_bcast_k(t, k);
+    if (l == k) y = t;
+    else if (l < k) y -= LT[k] * xk;
+  }
+  const double qacc0 = dof ? y : 0.0;
+  if (dof) E[O::QACC0 + l] = qacc0;
+  // ---- constraint rows.  Contacts: candidate c = the capsule end points in the oracle's order (distal geoms first, p1 then p2).
+  int ncon = 0, nr = 0;
+  {
+    const int ng2 = 2 * m.ng;
+    const bool is_cand = l < ng2;
+    const int gi = is_cand ? m.ng - 1 - (l >> 1) : 0;
+    const int gb = m.geom_body[gi];
+    const double* Gm = E + O::BODY + gb * O::BODY_F;
+    const double bc = Gm[0], bs = Gm[1], box = Gm[7], boz = Gm[8], rad = m.grad[gi];
+    const double ex = (l & 1) == 0 ? m.gp1[gi][0] : m.gp2[gi][0], ez = (l & 1) == 0 ? m.gp1[gi][1] : m.gp2[gi][1];
+    const double wx = bc * ex - bs * ez, wz = bs * ex + bc * ez;
+    const double dist = boz + wz - rad;
+    const bool active = is_cand && dist < m.margin;
+    const unsigned bal = (unsigned)((__ballot(active) >> (16 * grp)) & 0xFFFFull);
+    const int rank = __popc(bal & ((1u << l) - 1u));
+    const bool accept = active && 2 * rank + 2 <= m.max_rows;
+    ncon = min(__popc(bal), m.max_rows / 2);
+    if (accept) {
+      const double px = box + wx, pz = boz + wz - (rad + 0.5 * dist);
+      double* Jn = E + O::ROWJ + (2 * rank) * N;
+      double* Jt = Jn + N;
+      Jn[0] = 0.0; Jn[1] = 1.0; Jt[0] = 1.0; Jt[1] = 0.0;
+      const unsigned amg = (unsigned)m.ancmask[gb];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const double* Jm = E + O::BODY + j * O::BODY_F;
+        const double sg = ((amg >> j) & 1u) ? m.jsign[j] : 0.0;
+        Jn[2 + j] = sg * (px - Jm[7]); Jt[2 + j] = -sg * (pz - Jm[8]);
+      }
+      const double d = impedance_d(fabs(dist), m.c_solimp);
+      double* Sn = E + O::ROWS + (2 * rank) * 4;
+      Sn[0] = dist; Sn[1] = 0.0; Sn[2] = m.gfric[gi]; Sn[3] = d;
+      Sn[4] = 0.0; Sn[5] = 1.0; Sn[6] = m.gfric[gi]; Sn[7] = d;
+    }
+    // joint limits, bodies in ascending order
+    double r = 0.0, sgn = 0.0;
+    if (body && m.limited[jb]) {
+      const double lo = m.range[jb][0], hi = m.range[jb][1];
+      if (q - lo < 0.0) { r = q - lo; sgn = 1.0; }
+      else if (hi - q < 0.0) { r = hi - q; sgn = -1.0; }
+    }
+    const bool lact = sgn != 0.0;
+    const unsigned lbal = (unsigned)((__ballot(lact) >> (16 * grp)) & 0xFFFFull);
+    const int lrank = __popc(lbal & ((1u << l) - 1u));
+    const int row = 2 * ncon + lrank;
+    if (lact && row + 1 <= m.max_rows) {
+      double* Jl = E + O::ROWJ + row * N;
+#pragma unroll
+      for (int i = 0; i < N; ++i) Jl[i] = (i == l) ? sgn : 0.0;
+      double* Sl = E + O::ROWS + row * 4;
+      Sl[0] = r; Sl[1] = 2.0; Sl[2] = 0.0; Sl[3] = impedance_d(fabs(r), m.l_solimp);
+    }
+    nr = 2 * ncon + min(__popc(lbal), m.max_rows - 2 * ncon);
+  }
+  // rows of the busiest env of this wavefront (wave-uniform trip counts below)
+  int nrmax = max(max(__builtin_amdgcn_readlane(nr, 0), __builtin_amdgcn_readlane(nr, 16)),
+                  max(__builtin_amdgcn_readlane(nr, 32), __builtin_amdgcn_readlane(nr, 48)));
+  if (nrmax == 0) return qacc0;
+  EG_SYNC();
+  const bool rowl = l < nr && l < MR;
+  double x[N], rres = 0.0, rmu = 0.0, rd = 1.0;
+  int rkind = 0;
+  {
+    const double* Jr = E + O::ROWJ + (l < MR ? l : 0) * N;
+    const double* Sr = E + O::ROWS + (l < MR ? l : 0) * 4;
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = rowl ? Jr[i] : 0.0;
+    if (rowl) { rres = Sr[0]; rkind = (int)Sr[1]; rmu = Sr[2]; rd = Sr[3]; }
+  }
+  double rhs_c = 0.0;
+  {
+    double jv = 0.0, ja = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { jv += x[i] * E[O::QV + N + i]; ja += x[i] * E[O::QACC0 + i]; }
+    // z_r = L^-1 j_r (forward substitution only)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double sum = x[i];
+#pragma unroll
+      for (int t = 0; t < i; ++t) sum -= E[O::LMAT + i * N + t] * x[t];
+      x[i] = sum * invd[i];
+    }
+    const double* sref = rkind == 2 ? m.l_solref : m.c_solref;
+    const double dmax = rkind == 2 ? m.l_solimp[1] : m.c_solimp[1];
+    const double tc = sref[0], dr = sref[1];
+    const double bdamp = 2.0 / (dmax * tc), kstiff = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+    if (rowl) rhs_c = (-bdamp * jv - kstiff * rd * rres) - ja;
+  }
+  EG_SYNC();   // every lane has read its J row and L: the rows may be overwritten
+  if (rowl) {
+    double* Zr = E + O::ROWJ + l * N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) Zr[i] = x[i];
+  }
+  EG_SYNC();
+  // ---- row l of A = Z Z^T
+  double Arow[MR];
+#pragma unroll
+  for (int c = 0; c < MR; ++c) {
+    double sum = 0.0;
+    if (c < nrmax) {   // wave-uniform
+      const double* Zc = E + O::ROWJ + c * N;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sum += x[i] * Zc[i];
+    }
+    Arow[c] = (rowl && c < nr) ? sum : 0.0;
+  }
+  double att = 0.0;
+#pragma unroll
+  for (int c = 0; c < MR; ++c)
+    if (c == l) att = Arow[c];
+  const double invden = rowl ? 1.0 / (att + (1.0 - rd) / rd * att) : 0.0;
+  // ---- projected Gauss-Seidel: lane t is row t
+  double fcopy[MR];
+#pragma unroll
+  for (int c = 0; c < MR; ++c) fcopy[c] = 0.0;
+  double res = rhs_c;
+  for (int it = 0; it < m.pgs_iters; ++it) {
+#pragma unroll
+    for (int t = 0; t < MR; ++t) {
+      if (t >= nrmax) break;   // wave-uniform
+      double fi = (res + att * fcopy[t]) * invden;
+      if (rkind == 1) {
+        const double lim = rmu * fcopy[t > 0 ? t - 1 : 0];
+        fi = fmin(fmax(fi, -lim), lim);
+      } else {
+        fi = fmax(fi, 0.0);
+      }
+      const double fb = eg_bcast_k(fi, t);
+      const double dl = fb - fcopy[t];
+      fcopy[t] = fb;
+      res -= Arow[t] * dl;
+    }
+  }
+  // ---- q.. = qacc0 + L^-T (Z^T f)
+  double w = 0.0;
+#pragma unroll
+  for (int r = 0; r < MR; ++r) {
+    if (r >= nrmax) break;
+    const double z = (dof && r < nr) ? E[O::ROWJ + r * N + l] : 0.0;
+    w += z * fcopy[r];
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    const double t = w * invd[k];
+    const double xk = eg_bcast_k(t, k);
+    if (l == k) w = t;
+    else if (l < k) w -= LT[k] * xk;
+  }
+  EG_SYNC();   // the rows are rewritten by the next evaluation
+  return dof ? qacc0 + w : 0.0;
+}
+
+// One vec-env step; the arguments, the reward / termination / record / auto-reset rules are those of k_env_step.
+template <int NB, int MR>
+__global__ __launch_bounds__(64) void k_envg_step(const EnvStepArgs A) {
+  constexpr int N = NB + 2;
+  using O = EgOff<NB, MR>;
+  extern __shared__ __attribute__((aligned(16))) double smd_all[];
+  constexpr int MODEL_DOUBLES = (sizeof(PlanarModelDev) + 7) / 8;
+  {
+    const double* src = reinterpret_cast<const double*>(A.m);
+    for (int i = threadIdx.x; i < MODEL_DOUBLES; i += 64) smd_all[i] = src[i];
+    EG_SYNC();
+  }
+  const PlanarModelDev& m = *reinterpret_cast<const PlanarModelDev*>(smd_all);
+  const int lane = threadIdx.x, l = lane & 15, grp = lane >> 4;
+  double* E = smd_all + MODEL_DOUBLES + grp * O::TOTAL;
+  const int t_raw = blockIdx.x * EG_ENVS + grp;
+  const int t = t_raw < A.n_ids ? t_raw : A.n_ids - 1;     // surplus rows of the last wavefront shadow the last env and store nothing
+  const int env = A.ids ? A.ids[t] : t;
+  const bool live = t_raw < A.n_ids && !(A.frozen && A.frozen[env]);
+  const bool dof = l < N;
+  const int o = m.obs_dim, na = m.n_act;
+  double q = dof ? A.qpos[(size_t)l * A.n_env + env] : 0.0, v = dof ? A.qvel[(size_t)l * A.n_env + env] : 0.0;
+  // this lane's actuator torque (gear * clipped action) and the env's control cost
+  double torque = 0.0, ctrl_sq = 0.0;
+  for (int k = 0; k < na; ++k) {   // NormalizedBoxEnv: ctrlrange [-1, 1], clip (wrappers.py:343-346)
+    const double a = fmin(fmax((double)A.act[(size_t)t * na + k], -1.0), 1.0);
+    ctrl_sq += a * a;
+    if (m.act_body[k] + 2 == l) torque += m.gear[l - 2] * a;
+  }
+  // observation pieces of this lane: element l - 1 (qpos[1:]) and N - 1 + l (qvel)
+  auto obs_q = [&](double qq) { return (float)((qq - m.obs_shift[l - 1]) * m.obs_inv_scale[l - 1]); };
+  auto obs_v = [&](double vv) {
+    return (float)(((m.qvel_clip > 0.0 ? fmin(fmax(vv, -m.qvel_clip), m.qvel_clip) : vv) - m.obs_shift[N - 1 + l]) * m.obs_inv_scale[N - 1 + l]);
+  };
+  const float obq0 = (l >= 1 && dof) ? obs_q(q) : 0.0f, obv0 = dof ? obs_v(v) : 0.0f;
+  const double x0 = eg_bcast<0>(q);
+  const double h = m.timestep;
+  for (int s = 0; s < m.frame_skip; ++s) {   // RK4, the oracle's accumulation order (env_substep)
+    double qs = q, vs = v, qsum = 0.0, vsum = 0.0;
+#pragma unroll 1
+    for (int stage = 0; stage < 4; ++stage) {
+      const double a = eg_dynamics<NB, MR>(m, qs, vs, torque, E, l, grp);
+      const double w = (stage == 1 || stage == 2) ? 2.0 : 1.0;
+      const double ch = (stage == 2) ? h : 0.5 * h;
+      qsum = stage == 0 ? vs : qsum + w * vs;
+      vsum = stage == 0 ? a : vsum + w * a;
+      const double vn = v + ch * a;
+      qs = q + ch * vs;
+      vs = vn;
+    }
+    q = q + h / 6.0 * qsum;
+    v = v + h / 6.0 * vsum;
+  }
+  const double dt = m.timestep * m.frame_skip;
+  const double xq = eg_bcast<0>(q), zq = eg_bcast<1>(q), aq = eg_bcast<2>(q);
+  const double reward = (xq - x0) / dt + m.alive - m.ctrl_cost * ctrl_sq;
+  // termination (hopper.py:19-25 / walker2d.py:17-20 / never)
+  bool okl = true;
+  if (m.task == 0) {
+    if (dof) {
+      okl = isfinite(q) && isfinite(v) && fabs(v) < m.state_max;
+      if (l >= 2) okl = okl && fabs(q) < m.state_max;
+    }
+  }
+  const unsigned okbal = (unsigned)((__ballot(okl) >> (16 * grp)) & 0xFFFFull);
+  bool ok;
+  if (m.task == 0) ok = okbal == 0xFFFFu && zq > m.z_min && fabs(aq) < m.ang_max;
+  else if (m.task == 1) ok = zq > m.z_min && zq < m.z_max && aq > -m.ang_max && aq < m.ang_max;
+  else ok = true;
+  const bool done = !ok;
+  const bool finl = !dof || (isfinite(q) && isfinite(v));
+  const bool finite = (unsigned)((__ballot(finl) >> (16 * grp)) & 0xFFFFull) == 0xFFFFu;
+  float obq1 = (l >= 1 && dof) ? obs_q(q) : 0.0f, obv1 = dof ? obs_v(v) : 0.0f;
+  if (live) {
+    if (A.obs) {
+      if (l >= 1 && dof) A.obs[(size_t)t * o + l - 1] = obq1;
+      if (dof) A.obs[(size_t)t * o + N - 1 + l] = obv1;
+    }
+    if (l == 0) {
+      if (A.rew) A.rew[t] = (float)reward;
+      if (A.done) A.done[t] = done ? 1 : 0;
+    }
+    if (A.replay) {   // fused replay insert: one 128-byte-aligned record per transition
+      long long slot = A.top + env;
+      if (slot >= A.cap) slot -= A.cap;
+      float* rec = A.stage ? A.stage + ((size_t)env * A.stage_len + A.ep_len[env]) * A.rec : A.replay + (size_t)slot * A.rec;
+      if (l >= 1 && dof) { rec[l - 1] = obq0; rec[o + na + 2 + l - 1] = obq1; }
+      if (dof) { rec[N - 1 + l] = obv0; rec[o + na + 2 + N - 1 + l] = obv1; }
+      const float* ra = A.rec_act ? A.rec_act : A.act;   // DAgger stores the expert's label, not the executed action
+      if (l < na) rec[o + l] = ra[(size_t)t * na + l];
+      if (l == 0) {
+        rec[o + na] = (float)reward;
+        rec[o + na + 1] = (done && !A.no_terminal) ? 1.0f : 0.0f;   // base_algorithm.py:195-196,208-210
+        rec[2 * o + na + 2] = 0.0f; rec[2 * o + na + 3] = 0.0f;      // absorbing = [0, 0] (base_algorithm.py:211-213)
+      }
+    }
+  }
+  if (A.auto_reset) {
+    const int len = A.ep_len[env] + 1;
+    const double ret = A.ep_ret[env] + reward;
+    const bool end = (done && !A.no_terminal) || len >= A.max_path_length || !finite;
+    EG_SYNC();   // every lane has read ep_len / ep_ret
+    if (end) {
+      if (dof) {   // env_reset_state, one degree of freedom per lane: the same Philox draws
+        q = m.init_qpos[l] + m.reset_noise * (2.0 * env_uniform(A.seed, A.stream, A.step, (uint32_t)env, l) - 1.0);
+        if (m.reset_noise_vel_std > 0.0) {
+          const double u1 = env_uniform(A.seed, A.stream, A.step, (uint32_t)env, N + 2 * l), u2 = env_uniform(A.seed, A.stream, A.step, (uint32_t)env, N + 2 * l + 1);
+          v = m.reset_noise_vel_std * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        } else {
+          v = m.reset_noise * (2.0 * env_uniform(A.seed, A.stream, A.step, (uint32_t)env, N + l) - 1.0);
+        }
+        obq1 = l >= 1 ? obs_q(q) : 0.0f; obv1 = obs_v(v);
+      }
+      if (live && l == 0) { atomicAdd(&A.stats[0], 1.0); atomicAdd(&A.stats[1], ret); }
+    }
+    if (live && l == 0) {
+      A.ep_len[env] = end ? 0 : len;
+      A.ep_ret[env] = end ? 0.0 : ret;
+      if (A.flush_len) A.flush_len[env] = end ? (len | ((done && !A.no_terminal) ? (1 << 30) : 0)) : 0;
+    }
+  }
+  if (live) {
+    if (A.obs_cur) {
+      if (l >= 1 && dof) A.obs_cur[(size_t)env * o + l - 1] = obq1;
+      if (dof) A.obs_cur[(size_t)env * o + N - 1 + l] = obv1;
+    }
+    if (dof) { A.qpos[(size_t)l * A.n_env + env] = q; A.qvel[(size_t)l * A.n_env + env] = v; }
+  }
+}

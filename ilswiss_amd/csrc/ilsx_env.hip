@@ -474,6 +474,8 @@ __device__ __forceinline__ void env_reset_state(const PlanarModelDev& m, uint64_
   }
 }
 
+#include "env2d_group.h"
+
 template <int NB, int MR, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
   constexpr int N = NB + 2;
@@ -831,6 +833,15 @@ static int launch_env_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
+// 16 lanes per env (env2d_group.h): one wavefront = one workgroup = 4 envs
+template <int NB, int MR>
+static int launch_envg_step_t(ilsx_vecenv* e, const EnvStepArgs& A) {
+  const size_t lds = (((sizeof(PlanarModelDev) + 7) / 8) + (size_t)EG_ENVS * EgOff<NB, MR>::TOTAL) * sizeof(double);
+  ProfScope ps(e->ctx, ILSX_K_ENV_STEP);
+  ILSX_LAUNCH(ps, (k_envg_step<NB, MR>), dim3((A.n_ids + EG_ENVS - 1) / EG_ENVS), dim3(64), lds, e->ctx->stream, A);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
 static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
   if (A.n_ids <= 0) return ILSX_OK;
   if (e->engine == 1) {
@@ -845,6 +856,11 @@ static int launch_env_step(ilsx_vecenv* e, const EnvStepArgs& A) {
       ILSX_LAUNCH(ps, k_env3d_step, dim3((A.n_ids + 63) / 64), dim3(64), 0, e->ctx->stream, A, (const Spatial3Dev*)e->dm3, e->scr3);
     HIPCHK(hipGetLastError());
     return ILSX_OK;
+  }
+  static const bool lane_form = getenv("ILSX_ENV2D_LANE") != nullptr;   // A/B: the first form, one lane per env
+  if (!lane_form) {
+    if (e->hm.nb == 4) return launch_envg_step_t<4, 8>(e, A);
+    if (e->hm.nb == 7) return e->hm.max_rows > 12 ? launch_envg_step_t<7, 16>(e, A) : launch_envg_step_t<7, 12>(e, A);
   }
   if (e->hm.nb == 4) return launch_env_step_t<4, 8, 64>(e, A);
   if (e->hm.nb == 7) return e->hm.max_rows > 12 ? launch_env_step_t<7, 16, 32>(e, A) : launch_env_step_t<7, 12, 64>(e, A);
