@@ -940,7 +940,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
 //   policy-on-next_obs slices alone (phase A: all the target critics wait for), counter PHASE_TAIL_FLAG = "the
 //   deferred tail of the previous step has run" (alpha is valid).  The preceding dW launch zeroes them (DwArgs::zero_flags).  After the
 //   counters: one word per tile in which every workgroup ORs the XCD it runs on (checked by the host: one bit per tile or the call fails).
-//   A workgroup that waits longer than ~1 s sets *err and goes on (the host then fails the call and falls back to 8 launches): the
+//   A workgroup that waits longer than ~50 ms sets *err and goes on (the host then fails the call and falls back to 8 launches): the
 //   co-residency the protocol needs holds by construction, the bound only keeps a broken assumption from hanging the GPU.
 #define PHASE_MAX_TILES 64
 #define PHASE_TAIL_FLAG (3 * PHASE_MAX_TILES)
@@ -961,7 +961,7 @@ __device__ __forceinline__ void xch_wait(const unsigned* flag, unsigned target, 
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 21)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > (1 << 16)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
   }
   __syncthreads();
