@@ -49,7 +49,7 @@ def _latest_pmc_summary():
 
 
 PMC_SUMMARY = _latest_pmc_summary()
-PMC_NAMES = {0: ("k_mlp2_fwd_split", "k_mlp_fwd"), 1: ("k_mlp2_bwd_split", "k_mlp_bwd_dx"), 2: ("k_mlp_bwd_dw",),
+PMC_NAMES = {0: ("k_sac_phase_a", "k_mlp2_fwd_split", "k_mlp_fwd"), 1: ("k_sac_phase_c", "k_mlp2_bwd_split", "k_mlp_bwd_dx"), 2: ("k_mlp_bwd_dw",),
              6: ("k_replay_sample_many",)}
 
 
@@ -497,7 +497,9 @@ def main():
         dom = max((k for k in prof if k in (0, 1, 2)), key=lambda k: prof[k][2])
         name, nl, ms = prof[dom]
         launches_per_step = nl / 200.0
-        flops_per_launch = fl[dom] / launches_per_step
+        # a slot's algorithmic FLOPs: the merged phase kernels (one launch = three stages) carry their own count
+        slot_flops = next((fl[k] for k in ("k_sac_phase_a", "k_sac_phase_c") if k in name), fl[dom])
+        flops_per_launch = slot_flops / launches_per_step
         avg_s = ms * 1e-3 / nl
         achieved = flops_per_launch / avg_s / 1e12
         roofline = dict(bound="mfma", kernel=name, achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",

@@ -32,7 +32,11 @@ def sac_flops(o, a, H, B):
     fwd = 6 * Wq + 2 * Wp
     bwd_dx = 2 * (H * H + H) + 2 * (H + H * H + H * a) + (H * H + 2 * H * a)
     bwd_dw = 2 * Wq + Wp
-    return {0: 2 * B * fwd, 1: 2 * B * bwd_dx, 2: 2 * B * bwd_dw, "total": 2 * B * (fwd + bwd_dx + bwd_dw)}
+    # the merged phase kernels (k_sac_phase_a = F1 F2 B1, k_sac_phase_c = F3 B2 B3) mix forward and backward work in one launch
+    phase_a = 4 * Wq + 2 * Wp + 2 * (H * H + H)                      # pi(s'), Q1, Q2, pi(s) ; TQ1, TQ2 ; bwd{Q1, Q2 <- TD}
+    phase_c = 2 * Wq + 2 * (H + H * H + H * a) + (H * H + 2 * H * a)  # Q1, Q2 (s, a~) ; bwd{Q1, Q2 -> da} ; bwd{pi}
+    return {0: 2 * B * fwd, 1: 2 * B * bwd_dx, 2: 2 * B * bwd_dw, "total": 2 * B * (fwd + bwd_dx + bwd_dw),
+            "k_sac_phase_a": 2 * B * phase_a, "k_sac_phase_c": 2 * B * phase_c}
 
 
 def prof_slots(ctx, fn):

@@ -11,7 +11,7 @@ class Rollout:
         self.pol, self.rb = policy, replay
 
     def describe(self):
-        return ("Hopper-v2 model on the HIP planar articulated-body stepper (k_env_step: fp64, RK4, frame_skip 4, "
+        return ("Hopper-v2 model on the HIP planar articulated-body stepper (k_envg_step: 16 lanes per env, fp64, RK4, frame_skip 4, "
                 "soft contacts + joint limits via PGS), fused replay insert, auto-reset, max_path_length 1000")
 
     def vec_step(self):

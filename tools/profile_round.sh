@@ -3,22 +3,29 @@
 # graph launches here), the PMC passes (regenerated every round: bench.py reads the newest summary for roofline.traffic), the
 # per-launch timeline of the SAC step and the stage timers of the 3-D stepper -> gpurun_out/prof_<tag>/; copy into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 900 python bench_aux.py ppo gail td3 seeds humanoid > $OUT/bench_aux.log 2>&1
-timeout 200 python tools/step_gantt.py > $OUT/step_gantt.txt 2>&1
+timeout 600 python bench_aux.py td3 seeds > $OUT/bench_aux.log 2>&1
+ILSX_NO_PHASE=1 timeout 200 python tools/step_gantt.py > $OUT/step_gantt_8launch.txt 2>&1
+timeout 200 python tools/phase_gantt.py > $OUT/phase_gantt.txt 2>&1
+timeout 200 python tools/rollout_overhead.py 4096 > $OUT/rollout_overhead.txt 2>&1
+timeout 100 python tools/rollout_overhead.py 8192 >> $OUT/rollout_overhead.txt 2>&1
+(cd tools/ubench && timeout 60 ./tilesync) > $OUT/tilesync.txt 2>&1
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC tools/ubench/env3d_phases.hip -o /tmp/libe3p.so 2> /dev/null
 (python tools/ubench/env3d_phases.py humanoid 1024 8; python tools/ubench/env3d_phases.py ant 1024 8) > $OUT/env3d_phases.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-ILSX_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/rocprof -o $TAG -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-run > $ROOT/$OUT/rocprof.log 2>&1
+ILSX_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/rocprof -o $TAG -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-run --no-aux > $ROOT/$OUT/rocprof.log 2>&1
 cd $ROOT
 f=$(find $OUT/rocprof -name "*.db" | head -1)
 python tools/rocpd_summary.py "$f" > $OUT/kernel_stats.csv 2> $OUT/summary.err
 rm -rf $OUT/rocprof
 bash tools/pmc_collect.sh $TAG > $OUT/pmc.log 2>&1
+bash tools/pmc_env.sh $TAG > $OUT/envpmc.log 2>&1
+cp gpurun_out/envpmc_$TAG/summary.json $OUT/envpmc_summary.json 2> /dev/null
+rm -rf gpurun_out/envpmc_$TAG/*/ 2> /dev/null
 cp gpurun_out/pmc_$TAG/summary.json $OUT/pmc_summary.json 2> /dev/null
 cp gpurun_out/pmc_$TAG/passes.txt $OUT/pmc_passes.txt 2> /dev/null
 rm -rf gpurun_out/pmc_$TAG/*/ 2> /dev/null
