@@ -304,8 +304,10 @@ static int kernels_init_once() {
   SET_FWD(64, ACT_RELU); SET_FWD(128, ACT_RELU); SET_FWD(256, ACT_RELU);
   SET_FWD(64, ACT_TANH); SET_FWD(128, ACT_TANH); SET_FWD(256, ACT_TANH);
 #undef SET_FWD
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -415,12 +417,16 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
 
 // ---- merged phase kernels of the single-run SAC step (kernels.h: k_sac_phase_a / _c)
 // Every workgroup of a phase launch must be resident at once (they wait for each other): at most one workgroup per CU.
-bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks) {
+static int device_cus(ilsx_ctx* ctx) {
   static int n_cu = 0;
   if (!n_cu) {
     hipDeviceProp_t pr;
     n_cu = hipGetDeviceProperties(&pr, ctx->device) == hipSuccess ? pr.multiProcessorCount : 1;
   }
+  return n_cu;
+}
+bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks) {
+  const int n_cu = device_cus(ctx);
   if (!((H == 256 && cs == 4) || (H == 128 && cs == 2))) return false;
   const int tiles = (rows + 15) / 16, gx = (tiles + 7) & ~7;
   (void)gx;   // padding tiles and the extra bookkeeping row exit at once: only the working workgroups have to be co-resident
@@ -515,7 +521,9 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
   D.splits = 1; D.rows_per_split = rows; D.scratch = nullptr; D.span = 0;
   bool stacked = false;
   for (int i = 0; i < D.nmat && !D.gtiles; ++i) stacked = stacked || D.m[i].rows > 0;
-  if (rows >= DW_SPLIT_MIN_ROWS && D.g_lo && !stacked) {   // large batch: split the contraction over row ranges
+  if (D.gtiles) D.pre = nullptr;
+  if (rows >= DW_SPLIT_MIN_ROWS && D.g_lo && !stacked) {
+    D.pre = nullptr;   // large batch: split the contraction over row ranges
     int splits = rows / 512;
     if (splits > 32) splits = 32;
     const size_t span = (size_t)(D.g_hi - D.g_lo);
@@ -532,7 +540,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     D.F.on = 0;
     {
       ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-      ILSX_LAUNCH(ps, k_mlp_bwd_dw<false>, dim3(D.ntiles, splits), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+      ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 2, 4>), dim3(D.ntiles, splits), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
     }
     DwReduceArgs R;
     R.scratch = D.scratch; R.splits = splits; R.span = span; R.g_lo = D.g_lo; R.F = keep;
@@ -545,8 +553,46 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     return ILSX_OK;
   }
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-  if (D.gtiles) ILSX_LAUNCH(ps, k_mlp_bwd_dw<true>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
-  else ILSX_LAUNCH(ps, k_mlp_bwd_dw<false>, dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES, ctx->stream, D);
+  if (D.gtiles) {
+    ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 2, 4>), dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
+  } else {
+    // small batches (one 256-row trip per wave): the table's 32 x 64 tiles are a few dozen 16-wave workgroups, each CU's 4 waves per
+    // SIMD then share one MFMA pipe and one issue port while most of the chip idles; smaller tiles give the same waves (same
+    // arithmetic, same order) to more CUs
+    static const int shape = []() { const char* e = getenv("ILSX_DW_TILE"); return e ? atoi(e) : 0; }();   // "NH KT" digits; 0 = by size
+    int nh = 2, kt = 4;
+    auto retile = [&](int nh_, int kt_) {
+      D.ntiles = 0;
+      for (int i = 0; i < D.nmat; ++i) {
+        D.m[i].ktiles = (D.m[i].NB + 16 * kt_ - 1) / (16 * kt_);
+        D.m[i].tile0 = D.ntiles;
+        D.ntiles += ((D.m[i].NA + 16 * nh_ - 1) / (16 * nh_)) * D.m[i].ktiles;
+      }
+      nh = nh_; kt = kt_;
+    };
+    if (rows <= 512) {
+      if (shape) {
+        retile(shape / 10, shape % 10);
+      } else {   // the smallest tiles while the launch stays within ~2-3 workgroups per CU (measured on the SAC step: 16 x 16 tiles at
+                 // 576 workgroups beat 16 x 32 at 304; both beat 32 x 64 at 88)
+        const int n_cu = device_cus(ctx);
+        retile(1, 1);
+        if (D.ntiles > 3 * n_cu) retile(1, 2);
+        if (D.ntiles > 3 * n_cu) retile(2, 4);
+      }
+    }
+    const int extra = D.pre ? D.pre_tiles : 0;
+    if (nh == 2 && kt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 2, 4>), dim3((D.ntiles + extra) << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
+    else if (nh == 1 && kt == 2) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 1, 2>), dim3((D.ntiles + extra) << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 2), ctx->stream, D);
+    else if (nh == 1 && kt == 1) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 1, 1>), dim3((D.ntiles + extra) << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 1), ctx->stream, D);
+    else ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "ILSX_DW_TILE=%d: use 24, 12 or 11", shape);
+  }
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+
+int launch_pregather(ilsx_ctx* ctx, const PreGather& P, unsigned long long n_steps) {
+  hipLaunchKernelGGL(k_sac_pregather, dim3(P.tiles), dim3(256), 0, ctx->stream, P, n_steps);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

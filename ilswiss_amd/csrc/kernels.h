@@ -71,6 +71,9 @@ struct DevScalars {
   // second forward launch of a step advances it and the tail (one step late) advances `step`: gather_step == step + 1 means
   // "the step just taken has not had its alpha / counter update yet".
   unsigned long long gather_step;
+  // merged-phase steps of ilsx_sac_train_from_replay: the batch of step g is staged by the PREVIOUS step's last launch (PreGather below)
+  // while g < pregather_end (= first step of the call + its step count: the last step of a call stages nothing, the arrays keep its batch)
+  unsigned long long pregather_end;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -242,6 +245,41 @@ struct GatherSpec {
   float *s, *a, *r, *d, *s2;   // staging batch written by the publishing slices
   uint64_t seed; uint32_t stream; int rec, o, adim, on;
 };
+// Staging the NEXT step's batch ahead of its first launch (merged-phase SAC steps): a few extra workgroups of the step's last launch
+// (the policy's dW launch; nothing in it touches the batch arrays) draw the rows of step scal->gather_step — already advanced by the
+// step — and copy their records into the compact batch arrays (G.s / a / r / d / s2), so that the first stage of the next phase-A
+// launch reads 16 contiguous rows instead of running Philox and a dependent random HBM read at the head of the step's longest chain.
+// Same draw (replay_draw), same records: the batch is the one the in-kernel gather of the 8-launch path reads.
+struct PreGather { GatherSpec G; const DevScalars* scal; int rows, tiles; };
+#ifdef ILSX_KERNEL_IMPL
+__device__ __forceinline__ void pregather_tile(const PreGather& P, int tile, bool first_of_call, unsigned long long n_steps, long long* ridx /* LDS, 16 */) {
+  const GatherSpec& G = P.G;
+  const unsigned long long step = P.scal->gather_step;
+  if (first_of_call) {   // the stand-alone launch ahead of a call's first step also arms the window
+    if (tile == 0 && threadIdx.x == 0) const_cast<DevScalars*>(P.scal)->pregather_end = step + n_steps;
+  } else if (step >= P.scal->pregather_end) {
+    return;   // workgroup-uniform
+  }
+  const int r0 = tile * 16;
+  if (threadIdx.x < 16) ridx[threadIdx.x] = r0 + (int)threadIdx.x < P.rows ? replay_draw(G.seed, step, G.stream, (uint32_t)(r0 + threadIdx.x), G.st->size) : 0;
+  lds_barrier();
+  const int used = 2 * G.o + G.adim + 2;
+  for (int e = threadIdx.x; e < 16 * used; e += blockDim.x) {
+    const int r = e / used, k = e - r * used, gr = r0 + r;
+    if (gr >= P.rows) continue;
+    const float v = G.records[(size_t)ridx[r] * G.rec + k];
+    if (k < G.o) G.s[(size_t)gr * G.o + k] = v;
+    else if (k < G.o + G.adim) G.a[(size_t)gr * G.adim + (k - G.o)] = v;
+    else if (k == G.o + G.adim) G.r[gr] = v;
+    else if (k == G.o + G.adim + 1) G.d[gr] = v;
+    else G.s2[(size_t)gr * G.o + (k - G.o - G.adim - 2)] = v;
+  }
+}
+__global__ __launch_bounds__(256) void k_sac_pregather(const PreGather P, unsigned long long n_steps) {
+  __shared__ long long ridx[16];
+  pregather_tile(P, blockIdx.x, true, n_steps, ridx);
+}
+#endif
 
 // ================================================================================================
 // Fused MLP forward over 16-row tiles (Mlp.forward, networks.py:85-101; FlattenMlp cat, :108-115;
@@ -1167,12 +1205,13 @@ struct DwArgs {
   // grouped launch: one self-contained record per output tile (its matrix and its agent's optimiser) in device memory
   const struct DwTileG* gtiles;
   unsigned* zero_flags;   // non-null: workgroup 0 zeroes the PHASE_NFLAGS arrival counters of the phase kernel that follows this launch
+  const PreGather* pre;   // non-null (device memory): pre_tiles workgroups past the last tile stage the next step's batch (PreGather above)
+  int pre_tiles, pad2;
 };
 struct DwTileG { DwMat J; AdamFuse F; };
 #define DW_SPLIT_MIN_ROWS 1024
 #define DW_TILE_N 32
 #define DW_TILE_K 64
-#define DW_LDS_BYTES ((16 * 16 * 64 + 16 * 16) * 4)
 
 #ifdef ILSX_KERNEL_IMPL
 // (Measured and rejected, round 2: nontemporal stores here — no change; system-scope write-through stores — the launch got
@@ -1199,13 +1238,22 @@ __device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float 
   }
 }
 
-template <bool GRP>
-__global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
+// NH = 16-wide n blocks per workgroup (1 | 2), KT = 16-wide k tiles per wave (2 | 4): output tile (16 NH) x (16 KT), 8 NH waves
+// (wave = row-eighth x n block).  Per-element arithmetic and summation order do not depend on NH / KT (bit-identical results); small
+// tiles spread a small-batch launch over more CUs at fewer waves per SIMD (launch_bwd_dw picks them for the single-run steps).
+#define DW_LDS_BYTES_OF(NH, KT) ((8 * (NH) * 4 * (KT) * 64 + 8 * (NH) * 16) * 4)
+template <bool GRP, int NH, int KT>
+__global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* part = smem;                    // [16 waves][16 acc regs][64 lanes]
-  float* bpart = smem + 16 * 16 * 64;    // [16 waves][16]
+  constexpr int NW = 8 * NH, NT = 512 * NH, TN = 16 * NH, TK = 16 * KT, EPT = (KT + 1) / 2;   // EPT: output elements per thread (KT = 1: half the threads finish one)
+  float* part = smem;                         // [NW waves][4 KT acc regs][64 lanes]
+  float* bpart = smem + NW * 4 * KT * 64;     // [NW waves][16]
   if (blockIdx.x & ((1u << D.xs) - 1u)) return;
   const int bx = blockIdx.x >> D.xs;
+  if (!GRP && bx >= D.ntiles) {   // only launched with D.pre set
+    pregather_tile(*D.pre, bx - D.ntiles, false, 0, reinterpret_cast<long long*>(smem));
+    return;
+  }
   if (D.zero_flags && bx == 0 && blockIdx.y == 0 && threadIdx.x < PHASE_NFLAGS) D.zero_flags[threadIdx.x * 32] = 0u;
   int mi = 0;
   if (!GRP) {
@@ -1219,7 +1267,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   const DwMat& J = Rg.J;
   const AdamFuse& F = Rg.F;
   const int local = bx - J.tile0;
-  const int n0 = (local / J.ktiles) * DW_TILE_N, k0 = (local % J.ktiles) * DW_TILE_K;
+  const int n0 = (local / J.ktiles) * TN, k0 = (local % J.ktiles) * TK;
   int rows = J.rows > 0 ? J.rows : D.rows_all, brows = J.rows > 0 ? J.bias_rows : D.rows_all;
   int r_begin = 0;
   float* out_shift = nullptr;   // split mode: outputs land in this row range's slab
@@ -1230,23 +1278,23 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
     out_shift = D.scratch + (size_t)blockIdx.y * D.span;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int wn = wave & 1, wr = wave >> 1;
+  const int wn = wave % NH, wr = wave / NH;
   const int nsub = n0 + 16 * wn;
   const bool n_ok = nsub + li < J.NA;
   int ntk = (J.NB - k0 + 15) / 16;
-  if (ntk > 4) ntk = 4;
+  if (ntk > KT) ntk = KT;
   ILSX_STAMP(D.dbg, 0);
   // ---- the two output elements this thread will finish (and their optimiser operands, requested now)
-  float* g0p[2]; float* g1p[2]; bool live[2];
-  AdamOperands ao[2];
+  float* g0p[EPT]; float* g1p[EPT]; bool live[EPT];
+  AdamOperands ao[EPT];
   float ad_step = 0.f, ad_bc2s = 1.f;
   if (F.on) { ad_step = *F.step_size; ad_bc2s = *F.bc2_sqrt; }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int e = tid + 1024 * h;
-    const int on = e >> 10, rest = e & 1023, t = rest >> 8, v = (rest >> 6) & 3, ol = rest & 63;
+  for (int h = 0; h < EPT; ++h) {
+    const int e = tid + NT * h, ee = e % (256 * NH * KT);
+    const int on = ee / (256 * KT), rest = ee % (256 * KT), t = rest >> 8, v = (rest >> 6) & 3, ol = rest & 63;
     const int n = n0 + 16 * on + 4 * (ol >> 4) + v, k = k0 + 16 * t + (ol & 15);
-    live[h] = t < ntk && n < J.NA && k < J.NB;
+    live[h] = e < 256 * NH * KT && t < ntk && n < J.NA && k < J.NB;
     g0p[h] = nullptr; g1p[h] = nullptr;
     if (live[h]) {
       g0p[h] = J.mode == DW_OUT_NATURAL ? J.dW + (size_t)n * J.ldw + k : J.dW + pack_f(n, k, J.ldw);
@@ -1258,23 +1306,23 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
       if (F.on) ao[h] = adam_prefetch(F, (size_t)(g0p[h] - F.Gbase));
     }
   }
-  const bool bias_thread = J.db && k0 == 0 && tid < 32 && n0 + 16 * (tid >> 4) + (tid & 15) < J.NA;
+  const bool bias_thread = J.db && k0 == 0 && tid < 16 * NH && n0 + 16 * (tid >> 4) + (tid & 15) < J.NA;
   float* gbp = bias_thread ? J.db + n0 + 16 * (tid >> 4) + (tid & 15) : nullptr;
   if (gbp && out_shift) gbp = out_shift + (gbp - D.g_lo);
   AdamOperands aob;
   if (bias_thread && F.on) aob = adam_prefetch(F, (size_t)(gbp - F.Gbase));
 
-  f32x4 acc[4];
+  f32x4 acc[KT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < KT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.0f;
-  bool k_ok[4];
+  bool k_ok[KT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) k_ok[t] = k0 + 16 * t + li < J.NB;
+  for (int t = 0; t < KT; ++t) k_ok[t] = k0 + 16 * t + li < J.NB;
   // two 128-row steps per trip: both steps' operands are requested before the first MFMA (a 256-row batch is one round of
   // loads per wave instead of two dependent ones); accumulation order is unchanged
   for (int rc = r_begin + 16 * wr; rc < rows; rc += 256) {
-    float a[2][4], b[2][4][4];
+    float a[2][4], b[2][KT][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -1283,7 +1331,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
         const bool r_ok = r < rows;
         a[u][s] = (r_ok && n_ok) ? J.A[(size_t)r * J.lda + nsub + li] : 0.0f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < KT; ++t)
           b[u][t][s] = (r_ok && k_ok[t]) ? J.Bm[(size_t)r * J.ldb + k0 + 16 * t + li] : 0.0f;
       }
 #pragma unroll
@@ -1291,7 +1339,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < KT; ++t)
           if (t < ntk) acc[t] = MFMA16(a[u][s], b[u][t][s], acc[t]);
         bsum += (rc + 128 * u + 4 * g + s < brows) ? a[u][s] : 0.0f;
       }
@@ -1299,9 +1347,9 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   ILSX_STAMP(D.dbg, 1);
   // partial tiles -> LDS
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < KT; ++t)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) part[(wave * 16 + t * 4 + v) * 64 + lane] = acc[t][v];
+    for (int v = 0; v < 4; ++v) part[(wave * 4 * KT + t * 4 + v) * 64 + lane] = acc[t][v];
   bsum += __shfl_xor(bsum, 16, 64);
   bsum += __shfl_xor(bsum, 32, 64);
   if (g == 0) bpart[wave * 16 + li] = bsum;
@@ -1309,12 +1357,12 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
   ILSX_STAMP(D.dbg, 2);
   // sum the 8 row-partials; thread <-> (n-half, tile, reg, lane)
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int e = tid + 1024 * h;
-    const int on = e >> 10, rest = e & 1023, t = rest >> 8, v = (rest >> 6) & 3, ol = rest & 63;
+  for (int h = 0; h < EPT; ++h) {
+    const int e = tid + NT * h, ee = e % (256 * NH * KT);
+    const int on = ee / (256 * KT), rest = ee % (256 * KT), t = rest >> 8, v = (rest >> 6) & 3, ol = rest & 63;
     float s = 0.0f;
 #pragma unroll
-    for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * 2 + on) * 16 + t * 4 + v) * 64 + ol];
+    for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * NH + on) * 4 * KT + t * 4 + v) * 64 + ol];
     if (live[h]) {
       ILSX_ST(g0p[h], s);
       if (g1p[h]) ILSX_ST(g1p[h], s);
@@ -1326,7 +1374,7 @@ __global__ __launch_bounds__(1024) void k_mlp_bwd_dw(const DwArgs D) {
     const int on = tid >> 4, ol = tid & 15;
     float s = 0.0f;
 #pragma unroll
-    for (int r8 = 0; r8 < 8; ++r8) s += bpart[(r8 * 2 + on) * 16 + ol];
+    for (int r8 = 0; r8 < 8; ++r8) s += bpart[(r8 * NH + on) * 16 + ol];
     *gbp = s;
     if (F.on) adam_apply(F, ad_step, ad_bc2s, aob, (size_t)(gbp - F.Gbase), 0, false, s);
   }

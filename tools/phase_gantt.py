@@ -74,7 +74,10 @@ for rep in range(2):
                         print(f"        shader clock over the workgroup's life: {np.median(cyc / us):.0f} MHz (s_memtime cycles / 100 MHz stamps)")
         else:
             e = t[L][live, 7]
-            print(f"    span {e.max() - s0:6.2f}")
+            p1, p2 = t[L][live, 1], t[L][live, 2]
+            print(f"    span {e.max() - s0:6.2f}   workgroup starts: median {np.median(t[L][live, 0]) - s0:5.2f} max {t[L][live, 0].max() - s0:5.2f};  "
+                  f"operands + MFMA done @ {np.median(p1) - s0:5.2f} (max {p1.max() - s0:5.2f});  partials in LDS @ {np.median(p2) - s0:5.2f} (max {p2.max() - s0:5.2f});  "
+                  f"end median {np.median(e) - s0:5.2f}")
     nxt = np.flatnonzero(t[8][:, 0] > 0)
     if nxt.size and base is not None:
         print(f"    step: {t[8][nxt, 0].min() - base:.2f} us from A to the next A")
