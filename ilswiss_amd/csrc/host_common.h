@@ -149,7 +149,6 @@ int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P);
 bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks);
 int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P, int H, int act, int KPmax, int cs);
 int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P, int H, int act, int KPmax, int cs);
-int launch_pregather(ilsx_ctx* ctx, const PreGather& P, unsigned long long n_steps);
 // column-split factor the 2-hidden-layer fast path uses for width H (1 = generic kernels)
 int mlp2_split_factor(int n_hidden, int H);
 int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* fuse = nullptr);

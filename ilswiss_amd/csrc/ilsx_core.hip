@@ -521,9 +521,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
   D.splits = 1; D.rows_per_split = rows; D.scratch = nullptr; D.span = 0;
   bool stacked = false;
   for (int i = 0; i < D.nmat && !D.gtiles; ++i) stacked = stacked || D.m[i].rows > 0;
-  if (D.gtiles) D.pre = nullptr;
-  if (rows >= DW_SPLIT_MIN_ROWS && D.g_lo && !stacked) {
-    D.pre = nullptr;   // large batch: split the contraction over row ranges
+  if (rows >= DW_SPLIT_MIN_ROWS && D.g_lo && !stacked) {   // large batch: split the contraction over row ranges
     int splits = rows / 512;
     if (splits > 32) splits = 32;
     const size_t span = (size_t)(D.g_hi - D.g_lo);
@@ -581,18 +579,11 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
         if (D.ntiles > 3 * n_cu) retile(2, 4);
       }
     }
-    const int extra = D.pre ? D.pre_tiles : 0;
-    if (nh == 2 && kt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 2, 4>), dim3((D.ntiles + extra) << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
-    else if (nh == 1 && kt == 2) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 1, 2>), dim3((D.ntiles + extra) << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 2), ctx->stream, D);
-    else if (nh == 1 && kt == 1) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 1, 1>), dim3((D.ntiles + extra) << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 1), ctx->stream, D);
+    if (nh == 2 && kt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 2, 4>), dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
+    else if (nh == 1 && kt == 2) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 1, 2>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 2), ctx->stream, D);
+    else if (nh == 1 && kt == 1) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 1, 1>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 1), ctx->stream, D);
     else ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "ILSX_DW_TILE=%d: use 24, 12 or 11", shape);
   }
-  HIPCHK(hipGetLastError());
-  return ILSX_OK;
-}
-
-int launch_pregather(ilsx_ctx* ctx, const PreGather& P, unsigned long long n_steps) {
-  hipLaunchKernelGGL(k_sac_pregather, dim3(P.tiles), dim3(256), 0, ctx->stream, P, n_steps);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

@@ -82,9 +82,6 @@ struct ilsx_sac {
   unsigned* phase_flags = nullptr;   // PHASE_NFLAGS arrival counters, one 128-byte line each (zeroed by the dW launches)
   int* phase_err = nullptr;          // set by a workgroup whose wait timed out
   bool phase_now = false;            // this step runs on the phase kernels
-  PreGather* pre_dev = nullptr;      // descriptor of the batch staging job the policy's dW launch carries (kernels.h PreGather)
-  bool graph_pre = false;
-  bool pregather_now = false;        // phase steps of this call read a batch staged ahead of them instead of drawing it in the first stage
   bool phase_broken = false;         // a timeout was seen once: stay on the 8-launch path
   float* base(int which) const {
     switch (which) {
@@ -287,7 +284,6 @@ extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net*
   L.add(&s->scal, 1);
   L.add(&s->P, nP); L.add(&s->G, nT + 4); L.add(&s->M, nT); L.add(&s->V, nT);
   L.add(&s->phase_flags, (size_t)PHASE_FLAG_WORDS); L.add(&s->phase_err, 32);
-  L.add((char**)&s->pre_dev, sizeof(PreGather) + 64);
   sac_plan_ws(s, L);
   int rc = L.commit(ctx, &s->slab);
   if (rc != ILSX_OK) { delete s; return rc; }
@@ -438,8 +434,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     sac_policy_task(s, A.t[3], w.s, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
     sac_q_task(s, A.t[1], W_Q1, w.s, w.a, w.q1, true, true, 0);
     sac_q_task(s, A.t[2], W_Q2, w.s, w.a, w.q2, true, true, 1);
-    if (s->gather_rb && cs > 1 && !(s->phase_now && s->pregather_now)) {  // fused sample+index: rows are drawn from the ring inside this launch
-      // (merged-phase steps of a train_from_replay call read w.s / a / r / d / s2 as the previous step's last launch staged them)
+    if (s->gather_rb && cs > 1) {  // fused sample+index: rows are drawn from the ring inside this launch
       ilsx_replay* rb = s->gather_rb;
       GatherSpec& G = A.gather;
       G.records = rb->data; G.st = rb->dstate; G.rec = rb->rec; G.seed = rb->seed; G.stream = rb->rng_stream;
@@ -501,6 +496,7 @@ static int sac_critic_backward(ilsx_sac* s) {
     F.on = 1; F.Gbase = s->G; F.P = s->P; F.M = s->M; F.V = s->V; F.T = s->base(W_TQ1);
     F.b1 = s->cfg.beta_1; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = s->cfg.soft_target_tau;
     F.step_size = &s->scal->adam_q_step; F.bc2_sqrt = &s->scal->adam_q_bc2s;
+    if (s->phase_now) F.T = nullptr;   // the target update rides in the policy phase launch (PhaseCArgs::polyak_*)
   }
   return sac_dw(s, s->jobs_q, B, &F);
 }
@@ -561,6 +557,7 @@ static int sac_actor_backward(ilsx_sac* s) {
     t.raw = w.raw; t.eps = w.epss; t.action = w.an; t.ga1 = w.ga[0]; t.ga2 = w.ga[1];
     if (s->phase_now) {
       PC.b3 = A; PC.flags = s->phase_flags; PC.err = s->phase_err;
+      if (s->fuse_now) { PC.polyak_T = s->base(W_TQ1); PC.polyak_P = s->base(W_Q1); PC.polyak_n = (int)(2 * s->nq); PC.polyak_tau = s->cfg.soft_target_tau; }
       ILSX_TRY(launch_phase_c(s->ctx, PC, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
     } else {
       ILSX_TRY(sac_bwd(s, A, H, act, cs));
@@ -574,13 +571,7 @@ static int sac_actor_backward(ilsx_sac* s) {
       F.b1 = s->cfg.beta_1; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
       F.step_size = &s->scal->adam_pi_step; F.bc2_sqrt = &s->scal->adam_pi_bc2s;
     }
-    if (s->phase_now && s->pregather_now) {
-      DwArgs J = s->jobs_p;
-      J.pre = s->pre_dev; J.pre_tiles = (B + 15) / 16;
-      ILSX_TRY(sac_dw(s, J, B, &F));
-    } else {
-      ILSX_TRY(sac_dw(s, s->jobs_p, B, &F));
-    }
+    ILSX_TRY(sac_dw(s, s->jobs_p, B, &F));
   }
   if (s->fuse_now) return ILSX_OK;  // stats run inside k_sac_tail (sac_actor_update)
   StatsArgs S = sac_stats_args(s);
@@ -831,21 +822,6 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   ILSX_TRY(sac_defer_begin(s, B));
   struct DeferGuard { ilsx_sac* s; ~DeferGuard() { s->defer_tail = false; } } guard{s};   // never left on, whatever path returns
   const bool deferred = s->defer_tail;
-  static const bool no_pregather = getenv("ILSX_NO_PREGATHER") != nullptr;
-  s->pregather_now = !no_pregather && sac_phase_ok(s, B);
-  struct PreGuard { ilsx_sac* s; ~PreGuard() { s->pregather_now = false; } } pre_guard{s};
-  if (s->pregather_now) {   // stage the first step's batch and arm the window (kernels.h PreGather); later batches ride in the policy's dW launch
-    PreGather P;
-    memset(&P, 0, sizeof P);
-    GatherSpec& G = P.G;
-    const SacWs& w = s->ws;
-    G.records = rb->data; G.st = rb->dstate; G.rec = rb->rec; G.seed = rb->seed; G.stream = rb->rng_stream;
-    G.o = s->o; G.adim = s->a; G.on = 1;
-    G.s = w.s; G.a = w.a; G.r = w.r; G.d = w.d; G.s2 = w.s2;
-    P.scal = s->scal; P.rows = B; P.tiles = (B + 15) / 16;
-    HIPCHK(hipMemcpyAsync(s->pre_dev, &P, sizeof P, hipMemcpyHostToDevice, st));
-    ILSX_TRY(launch_pregather(s->ctx, P, (unsigned long long)n_steps));
-  }
   if (no_graph || s->ctx->prof_on) {
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
@@ -854,8 +830,7 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
     }
   } else {
     const bool phase = sac_phase_ok(s, B);
-    if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail || s->graph_phase != phase ||
-        s->graph_pre != s->pregather_now) {
+    if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail || s->graph_phase != phase) {
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
       hipGraph_t g = nullptr;
       HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -866,7 +841,7 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
       e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
       if (e != hipSuccess) { s->graph = nullptr; ILSX_FAIL(ILSX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
-      s->graph_rb = rb; s->graph_B = B; s->graph_defer = s->defer_tail; s->graph_phase = phase; s->graph_pre = s->pregather_now;
+      s->graph_rb = rb; s->graph_B = B; s->graph_defer = s->defer_tail; s->graph_phase = phase;
     }
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));

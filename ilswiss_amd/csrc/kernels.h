@@ -71,9 +71,6 @@ struct DevScalars {
   // second forward launch of a step advances it and the tail (one step late) advances `step`: gather_step == step + 1 means
   // "the step just taken has not had its alpha / counter update yet".
   unsigned long long gather_step;
-  // merged-phase steps of ilsx_sac_train_from_replay: the batch of step g is staged by the PREVIOUS step's last launch (PreGather below)
-  // while g < pregather_end (= first step of the call + its step count: the last step of a call stages nothing, the arrays keep its batch)
-  unsigned long long pregather_end;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -245,41 +242,6 @@ struct GatherSpec {
   float *s, *a, *r, *d, *s2;   // staging batch written by the publishing slices
   uint64_t seed; uint32_t stream; int rec, o, adim, on;
 };
-// Staging the NEXT step's batch ahead of its first launch (merged-phase SAC steps): a few extra workgroups of the step's last launch
-// (the policy's dW launch; nothing in it touches the batch arrays) draw the rows of step scal->gather_step — already advanced by the
-// step — and copy their records into the compact batch arrays (G.s / a / r / d / s2), so that the first stage of the next phase-A
-// launch reads 16 contiguous rows instead of running Philox and a dependent random HBM read at the head of the step's longest chain.
-// Same draw (replay_draw), same records: the batch is the one the in-kernel gather of the 8-launch path reads.
-struct PreGather { GatherSpec G; const DevScalars* scal; int rows, tiles; };
-#ifdef ILSX_KERNEL_IMPL
-__device__ __forceinline__ void pregather_tile(const PreGather& P, int tile, bool first_of_call, unsigned long long n_steps, long long* ridx /* LDS, 16 */) {
-  const GatherSpec& G = P.G;
-  const unsigned long long step = P.scal->gather_step;
-  if (first_of_call) {   // the stand-alone launch ahead of a call's first step also arms the window
-    if (tile == 0 && threadIdx.x == 0) const_cast<DevScalars*>(P.scal)->pregather_end = step + n_steps;
-  } else if (step >= P.scal->pregather_end) {
-    return;   // workgroup-uniform
-  }
-  const int r0 = tile * 16;
-  if (threadIdx.x < 16) ridx[threadIdx.x] = r0 + (int)threadIdx.x < P.rows ? replay_draw(G.seed, step, G.stream, (uint32_t)(r0 + threadIdx.x), G.st->size) : 0;
-  lds_barrier();
-  const int used = 2 * G.o + G.adim + 2;
-  for (int e = threadIdx.x; e < 16 * used; e += blockDim.x) {
-    const int r = e / used, k = e - r * used, gr = r0 + r;
-    if (gr >= P.rows) continue;
-    const float v = G.records[(size_t)ridx[r] * G.rec + k];
-    if (k < G.o) G.s[(size_t)gr * G.o + k] = v;
-    else if (k < G.o + G.adim) G.a[(size_t)gr * G.adim + (k - G.o)] = v;
-    else if (k == G.o + G.adim) G.r[gr] = v;
-    else if (k == G.o + G.adim + 1) G.d[gr] = v;
-    else G.s2[(size_t)gr * G.o + (k - G.o - G.adim - 2)] = v;
-  }
-}
-__global__ __launch_bounds__(256) void k_sac_pregather(const PreGather P, unsigned long long n_steps) {
-  __shared__ long long ridx[16];
-  pregather_tile(P, blockIdx.x, true, n_steps, ridx);
-}
-#endif
 
 // ================================================================================================
 // Fused MLP forward over 16-row tiles (Mlp.forward, networks.py:85-101; FlattenMlp cat, :108-115;
@@ -986,7 +948,12 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
 #define PHASE_MASK_WORD(t) ((PHASE_NFLAGS + (t)) * 32)   // per-tile XCD masks live after the counters (never zeroed by the dW launches)
 #define PHASE_FLAG_WORDS ((PHASE_NFLAGS + PHASE_MAX_TILES) * 32)
 struct PhaseAArgs { FwdArgs f1, f2; BwdArgs b1; unsigned* flags; int* err; unsigned long long* dbg; };
-struct PhaseCArgs { FwdArgs f3; BwdArgs b2, b3; unsigned* flags; int* err; unsigned long long* dbg; };
+struct PhaseCArgs {
+  FwdArgs f3; BwdArgs b2, b3; unsigned* flags; int* err; unsigned long long* dbg;
+  // Polyak update of the target critics (pytorch_util.py:10-12), run by the otherwise idle bookkeeping row while the policy phase
+  // computes: polyak_n > 0 = the critics' dW launch of this step left it out (AdamFuse::T null); same expression, same operands
+  float* polyak_T; const float* polyak_P; int polyak_n; float polyak_tau;
+};
 
 #ifdef ILSX_KERNEL_IMPL
 __device__ __forceinline__ void xch_arrive(unsigned* flag) {   // every thread of the workgroup calls it
@@ -1117,6 +1084,14 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) 
   const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;
   if (y == 3) {
     if (bx == 0 && cs == 0 && threadIdx.x == 0) P.f3.tail[0].scal->gather_step += 1;
+    const float tau = P.polyak_tau;
+    for (int i = ((int)(cs * gridDim.x + bx) * (int)blockDim.x + (int)threadIdx.x) * 4; i < P.polyak_n; i += (int)(gridDim.x * gridDim.z * blockDim.x) * 4) {
+      const float4 p = *reinterpret_cast<const float4*>(P.polyak_P + i);
+      float4 t = *reinterpret_cast<const float4*>(P.polyak_T + i);
+      t.x = t.x * (1.0f - tau) + p.x * tau; t.y = t.y * (1.0f - tau) + p.y * tau;
+      t.z = t.z * (1.0f - tau) + p.z * tau; t.w = t.w * (1.0f - tau) + p.w * tau;
+      *reinterpret_cast<float4*>(P.polyak_T + i) = t;
+    }
     return;
   }
   if (bx * 16 >= P.f3.rows) return;
@@ -1205,8 +1180,6 @@ struct DwArgs {
   // grouped launch: one self-contained record per output tile (its matrix and its agent's optimiser) in device memory
   const struct DwTileG* gtiles;
   unsigned* zero_flags;   // non-null: workgroup 0 zeroes the PHASE_NFLAGS arrival counters of the phase kernel that follows this launch
-  const PreGather* pre;   // non-null (device memory): pre_tiles workgroups past the last tile stage the next step's batch (PreGather above)
-  int pre_tiles, pad2;
 };
 struct DwTileG { DwMat J; AdamFuse F; };
 #define DW_SPLIT_MIN_ROWS 1024
@@ -1250,10 +1223,6 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
   float* bpart = smem + NW * 4 * KT * 64;     // [NW waves][16]
   if (blockIdx.x & ((1u << D.xs) - 1u)) return;
   const int bx = blockIdx.x >> D.xs;
-  if (!GRP && bx >= D.ntiles) {   // only launched with D.pre set
-    pregather_tile(*D.pre, bx - D.ntiles, false, 0, reinterpret_cast<long long*>(smem));
-    return;
-  }
   if (D.zero_flags && bx == 0 && blockIdx.y == 0 && threadIdx.x < PHASE_NFLAGS) D.zero_flags[threadIdx.x * 32] = 0u;
   int mi = 0;
   if (!GRP) {
