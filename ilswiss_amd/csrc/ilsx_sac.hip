@@ -485,6 +485,12 @@ static int sac_critic_backward(ilsx_sac* s) {
     }
     if (s->phase_now) {
       PA.b1 = A; PA.flags = s->phase_flags; PA.err = s->phase_err;
+      {   // pi(s) is finished inside this launch (kernels.h policy_fin_tile): the policy phase starts from finished actions
+        FwdArgs Fz;
+        memset(&Fz, 0, sizeof Fz);
+        sac_policy_fin(s, Fz, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
+        PA.fin_pi = Fz.fin; PA.fin_pi.use_gather_step = 1; PA.fin_pi_on = 1;
+      }
       ILSX_TRY(launch_phase_a(s->ctx, PA, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
     } else {
       ILSX_TRY(sac_bwd(s, A, H, act, cs));
@@ -525,7 +531,7 @@ static int sac_actor_backward(ilsx_sac* s) {
     A.rows = B; A.ntasks = 2; A.seed = s->ctx->seed; A.scal = s->scal; A.part_stride = s->cfg.max_batch;
     sac_q_task(s, A.t[0], W_Q1, w.s, w.an, w.q1n, false, true, 0);
     sac_q_task(s, A.t[1], W_Q2, w.s, w.an, w.q2n, false, true, 1);
-    sac_policy_fin(s, A, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
+    if (!s->phase_now) sac_policy_fin(s, A, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);   // phase steps: finished in phase A already
     if (s->phase_now) { A.tail = s->tail_dev; PC.f3 = A; }   // the extra row of the phase launch advances the replay-draw counter
     else ILSX_TRY(sac_fwd(s, A, H, act, s->Lq.KP, cs));
   }

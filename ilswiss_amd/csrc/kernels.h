@@ -947,7 +947,10 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
 #define PHASE_NFLAGS (3 * PHASE_MAX_TILES + 1)
 #define PHASE_MASK_WORD(t) ((PHASE_NFLAGS + (t)) * 32)   // per-tile XCD masks live after the counters (never zeroed by the dW launches)
 #define PHASE_FLAG_WORDS ((PHASE_NFLAGS + PHASE_MAX_TILES) * 32)
-struct PhaseAArgs { FwdArgs f1, f2; BwdArgs b1; unsigned* flags; int* err; unsigned long long* dbg; };
+struct PhaseAArgs {
+  FwdArgs f1, f2; BwdArgs b1; unsigned* flags; int* err; unsigned long long* dbg;
+  PolicyFinishArgs fin_pi; int fin_pi_on, pad;   // finish pi(s) (task 3 of stage 1) here, on the lead slice of the first critic's backward row (policy_fin_tile)
+};
 struct PhaseCArgs {
   FwdArgs f3; BwdArgs b2, b3; unsigned* flags; int* err; unsigned long long* dbg;
   // Polyak update of the target critics (pytorch_util.py:10-12), run by the otherwise idle bookkeeping row while the policy phase
@@ -982,6 +985,58 @@ __device__ __forceinline__ unsigned xcc_id() {
 // placement the exchange relies on did not hold, the host fails the call (ilsx_sac_train_from_replay) and falls back
 __device__ __forceinline__ void xch_mark_xcd(unsigned* mask) {
   if (threadIdx.x == 0) __hip_atomic_fetch_or(mask, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The tanh-Gaussian epilogue of a column-split policy forward for one 16-row tile (policies.py:262-283, distributions.py:23-28,43-50,
+// 74-97), as a job of its own: the CS head partials are combined, the action is sampled and everything later launches need (action,
+// noise, raw head, log pi) is published.  Same expressions, in the same order, as the epilogue a consuming forward runs in its prologue
+// (fwd_split_tile.inc, `fin`): phase A runs it for pi(s) on a workgroup that would otherwise idle until the TD target is ready, so the
+// policy phase launch starts from finished actions.  lp3 = [16][32][3] floats of LDS.
+__device__ __forceinline__ void policy_fin_tile(const PolicyFinishArgs& P, int r0, int rows, float* lp3, int nth) {
+  const int a = P.a, NOp = 2 * a, tid = threadIdx.x;
+  const unsigned long long fstep = P.scal ? (P.use_gather_step ? P.scal->gather_step : P.scal->step) : P.step_host;
+  for (int e = tid; e < 16 * a; e += nth) {
+    const int row = e / a, j = e - row * a, gr = r0 + row;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    if (gr < rows) {
+      float pm[4], pl[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t at = ((size_t)(c < P.cs ? c : 0) * P.part_stride + gr) * NOp + j;
+        pm[c] = P.part[at];
+        pl[c] = P.part[at + a];
+      }
+      float mu = 0.f, lsr = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { mu += c < P.cs ? pm[c] : 0.0f; lsr += c < P.cs ? pl[c] : 0.0f; }   // slab order
+      float ep;
+      if (P.eps) {
+        ep = P.eps[(size_t)gr * a + j];
+      } else {
+        float z4[4];
+        philox_normal4(P.seed, fstep, P.rng_stream, gr, j >> 2, z4);
+        const int q = j & 3;
+        ep = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
+      }
+      const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX);
+      const float sd = expf(ls);
+      const float z = ep * sd + mu;
+      const float act = tanhf(z);
+      const float dm = mu - z;
+      c0 = dm * dm / expf(2.0f * ls); c1 = ls; c2 = logf(1.0f - act * act + TANH_EPS);
+      if (P.raw) { P.raw[(size_t)gr * NOp + j] = mu; P.raw[(size_t)gr * NOp + a + j] = lsr; }
+      if (P.action) P.action[(size_t)gr * a + j] = act;
+      if (P.eps_save) P.eps_save[(size_t)gr * a + j] = ep;
+    }
+    lp3[(row * 32 + j) * 3 + 0] = c0; lp3[(row * 32 + j) * 3 + 1] = c1; lp3[(row * 32 + j) * 3 + 2] = c2;
+  }
+  lds_barrier();
+  if (P.logp && tid < 16 && r0 + tid < rows) {
+    float q = 0.f, l = 0.f, jc = 0.f;
+    for (int j = 0; j < a; ++j) { q += lp3[(tid * 32 + j) * 3]; l += lp3[(tid * 32 + j) * 3 + 1]; jc += lp3[(tid * 32 + j) * 3 + 2]; }
+    P.logp[r0 + tid] = -0.5f * q - (l + HALF_LOG_2PI) - jc;
+  }
+  lds_barrier();
 }
 
 // Phase A: stage 1 = fwd{pi(s') | Q1(s,a) | Q2(s,a) | pi(s)} (tasks y = 0..3, rows drawn from the replay ring);
@@ -1056,6 +1111,10 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
     ILSX_STAMP(P.dbg, 5);
   } else {
     xch_wait(f1, 4 * CS, P.err);   // the other slices' layer-1 activations, the lead slice's layer 0
+    if (P.fin_pi_on && y == 1 && cs == 0) {   // workgroup-uniform
+      xch_wait(tflag, 1u, P.err);   // the pending tail of the previous step reads that step's log pi: it has to be through before this one's lands
+      policy_fin_tile(P.fin_pi, bx * 16, P.f1.rows, smem, 4 * H / CS);
+    }
     {
       const BwdArgs& A = P.b1;
       const BwdTask& T = A.t[y - 1];
