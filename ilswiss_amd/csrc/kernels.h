@@ -1313,6 +1313,7 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
   if (ntk > KT) ntk = KT;
   ILSX_STAMP(D.dbg, 0);
   // ---- the two output elements this thread will finish (and their optimiser operands, requested now)
+  const bool packed = J.mode != DW_OUT_NATURAL;
   float* g0p[EPT]; float* g1p[EPT]; bool live[EPT];
   AdamOperands ao[EPT];
   float ad_step = 0.f, ad_bc2s = 1.f;
@@ -1320,7 +1321,12 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
 #pragma unroll
   for (int h = 0; h < EPT; ++h) {
     const int e = tid + NT * h, ee = e % (256 * NH * KT);
-    const int on = ee / (256 * KT), rest = ee % (256 * KT), t = rest >> 8, v = (rest >> 6) & 3, ol = rest & 63;
+    const int on = ee / (256 * KT), rest = ee % (256 * KT), t = rest >> 8, q = rest & 255;
+    // thread <-> element of the 16 x 16 block: packed outputs in ADDRESS order (consecutive lanes = consecutive floats of the forward
+    // packing and whole 64-byte runs of the backward packing: every optimiser stream of the epilogue moves full lines; the accumulator
+    // order — lane = column, register = row — touched 16 of every 64 bytes per instruction); natural outputs keep the accumulator order
+    const int v = packed ? (q >> 2) & 3 : (q >> 6) & 3;
+    const int ol = packed ? ((q >> 4) & 3) * 16 + 4 * (q >> 6) + (q & 3) : q & 63;
     const int n = n0 + 16 * on + 4 * (ol >> 4) + v, k = k0 + 16 * t + (ol & 15);
     live[h] = e < 256 * NH * KT && t < ntk && n < J.NA && k < J.NB;
     g0p[h] = nullptr; g1p[h] = nullptr;
@@ -1387,7 +1393,12 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
 #pragma unroll
   for (int h = 0; h < EPT; ++h) {
     const int e = tid + NT * h, ee = e % (256 * NH * KT);
-    const int on = ee / (256 * KT), rest = ee % (256 * KT), t = rest >> 8, v = (rest >> 6) & 3, ol = rest & 63;
+    const int on = ee / (256 * KT), rest = ee % (256 * KT), t = rest >> 8, q = rest & 255;
+    // thread <-> element of the 16 x 16 block: packed outputs in ADDRESS order (consecutive lanes = consecutive floats of the forward
+    // packing and whole 64-byte runs of the backward packing: every optimiser stream of the epilogue moves full lines; the accumulator
+    // order — lane = column, register = row — touched 16 of every 64 bytes per instruction); natural outputs keep the accumulator order
+    const int v = packed ? (q >> 2) & 3 : (q >> 6) & 3;
+    const int ol = packed ? ((q >> 4) & 3) * 16 + 4 * (q >> 6) + (q & 3) : q & 63;
     float s = 0.0f;
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * NH + on) * 4 * KT + t * 4 + v) * 64 + ol];

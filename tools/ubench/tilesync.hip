@@ -40,6 +40,13 @@ __global__ __launch_bounds__(256) void k_tilesync(float* slab, unsigned* flags, 
         if (MODE == 6) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
+        if (MODE == 7) {   // the poll on the SCALAR memory path (glc: past the scalar cache, from the L2): no vector-memory counter involved
+          unsigned v;
+          do {
+            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(flag) : "memory");
+            if (++spins > (1 << 22)) { *err = 1; break; }
+          } while (v < target);
+        } else
         while ((MODE == 6 ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
                           : __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
           __builtin_amdgcn_s_sleep(1);
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void k_tilesync(float* slab, unsigned* flags, 
     // the neighbour's line was written by another CU: read it past this CU's vector L1 (agent-scope load)
     const float* theirs = slab + ((size_t)(r & 1) * NWG + nb) * 256 + t;
     if (MODE == 4) asm volatile("buffer_inv sc1" ::: "memory");
-    if (MODE == 5 || MODE == 6) asm volatile("buffer_inv sc0" ::: "memory");
+    if (MODE == 5 || MODE == 6 || MODE == 7) asm volatile("buffer_inv sc0" ::: "memory");
     if (MODE >= 4) acc = *(volatile const float*)theirs;
     else
     acc = MODE == 2 ? __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -105,7 +112,7 @@ int main() {
   unsigned base = 0;
   // mode 2 (workgroup-scope atomics on the DATA, no invalidate) is not run by default: its first launch can spin on a stale L1 line
   // until the bound trips (4 s)
-  for (int mode = 3; mode < 7; ++mode) {
+  for (int mode = 3; mode < 8; ++mode) {
     CHK(hipMemset(err, 0, 4));
     for (int rep = 0; rep < 3; ++rep) {
       CHK(hipEventRecord(e0, st));
@@ -115,7 +122,8 @@ int main() {
       else if (mode == 3) hipLaunchKernelGGL(k_tilesync<3>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
       else if (mode == 4) hipLaunchKernelGGL(k_tilesync<4>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
       else if (mode == 5) hipLaunchKernelGGL(k_tilesync<5>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
-      else hipLaunchKernelGGL(k_tilesync<6>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
+      else if (mode == 6) hipLaunchKernelGGL(k_tilesync<6>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
+      else hipLaunchKernelGGL(k_tilesync<7>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
       CHK(hipEventRecord(e1, st));
       CHK(hipStreamSynchronize(st));
       base += ROUNDS * MEMBERS;
@@ -124,7 +132,7 @@ int main() {
       CHK(hipMemcpy(h, clk, sizeof h, hipMemcpyDeviceToHost)); CHK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost)); CHK(hipMemcpy(ho, out, 16, hipMemcpyDeviceToHost));
       unsigned long long mx = 0; for (auto v : h) mx = v > mx ? v : mx;
       printf("tile-local hand-off, %s: %.2f us per round (kernel %.1f us / %d rounds; slowest workgroup %.2f us per round)  err=%d out=%g\n",
-             mode == 0 ? "release/acquire atomics" : mode == 1 ? "relaxed atomics + __threadfence" : mode == 2 ? "WORKGROUP-scope relaxed atomics, no fence (same-XCD L2)" : mode == 3 ? "AGENT-scope relaxed atomics, no fence" : mode == 4 ? "plain data + agent flag + buffer_inv sc1" : mode == 5 ? "plain data + agent flag + buffer_inv sc0" : "plain data + WORKGROUP flag + buffer_inv sc0", 1e3 * ms / ROUNDS, 1e3 * ms, ROUNDS, mx * 0.01 / ROUNDS, herr, ho[0]);
+             mode == 0 ? "release/acquire atomics" : mode == 1 ? "relaxed atomics + __threadfence" : mode == 2 ? "WORKGROUP-scope relaxed atomics, no fence (same-XCD L2)" : mode == 3 ? "AGENT-scope relaxed atomics, no fence" : mode == 4 ? "plain data + agent flag + buffer_inv sc1" : mode == 5 ? "plain data + agent flag + buffer_inv sc0" : mode == 6 ? "plain data + WORKGROUP flag + buffer_inv sc0" : "plain data + agent flag polled by s_load glc + buffer_inv sc0", 1e3 * ms / ROUNDS, 1e3 * ms, ROUNDS, mx * 0.01 / ROUNDS, herr, ho[0]);
     }
   }
   hipGraph_t g; hipGraphExec_t ge;
