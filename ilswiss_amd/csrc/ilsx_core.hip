@@ -568,7 +568,7 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
       }
       nh = nh_; kt = kt_;
     };
-    if (rows <= 512) {
+    {   // (unsplit launches only get here: one to a few 256-row trips per wave, or row-stacked jobs)
       if (shape) {
         retile(shape / 10, shape % 10);
       } else {   // the smallest tiles while the launch stays within ~2-3 workgroups per CU (measured on the SAC step: 16 x 16 tiles at

@@ -9,8 +9,8 @@
 //   k_disc_bwd    per 16-row tile: CE rows -> delta2, delta1 ; GP rows -> dD/dx, its norm, and the whole
 //                 second-order chain (3 MFMA GEMMs with W2 / W2^T), written as ROW-STACKED operand
 //                 matrices so that every weight gradient is a single A^T.B contraction
-//   k_mlp_bwd_dw  3 stacked jobs: dW1 over 4B rows, dW2 over 4B rows, dw3 over 3B rows (bias rows limited)
-//   k_adam_polyak Adam(lr, betas=(disc_momentum, 0.999))
+//   k_mlp_bwd_dw  3 stacked jobs: dW1 over 4B rows, dW2 over 4B rows, dw3 over 3B rows (bias rows limited);
+//                 epilogue: Adam(lr, betas=(disc_momentum, 0.999)) on the tile it owns
 //   k_disc_tail   losses / accuracy, step counter, Adam scalars of the next step
 #include <cmath>
 
@@ -498,12 +498,15 @@ extern "C" int ilsx_disc_train_step(ilsx_disc* d, const float* exp_obs, const fl
     }
     HIPCHK(hipGetLastError());
   }
-  ILSX_TRY(launch_bwd_dw(ctx, d->jobs, rows));
-  AdamArgs Ad;
-  Ad.p = d->P; Ad.g = d->G; Ad.m = d->M; Ad.v = d->V; Ad.tgt = nullptr; Ad.n = (int)d->L.n_int;
-  Ad.b1 = d->cfg.disc_momentum; Ad.b2 = 0.999f; Ad.eps = 1e-8f; Ad.tau = 0.f;
-  Ad.step_size = &d->scal->adam_step; Ad.bc2_sqrt = &d->scal->adam_bc2s;
-  ILSX_TRY(launch_adam(ctx, Ad));
+  {   // Adam(lr, betas = (disc_momentum, 0.999)) in the epilogue of the weight-gradient tiles (kernels.h AdamFuse): same expressions as
+      // k_adam_polyak, one launch and one pass over the arena less
+    AdamFuse F;
+    memset(&F, 0, sizeof F);
+    F.on = 1; F.Gbase = d->G; F.P = d->P; F.M = d->M; F.V = d->V; F.T = nullptr;
+    F.b1 = d->cfg.disc_momentum; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
+    F.step_size = &d->scal->adam_step; F.bc2_sqrt = &d->scal->adam_bc2s;
+    ILSX_TRY(launch_bwd_dw(ctx, d->jobs, rows, &F));
+  }
   hipLaunchKernelGGL(k_disc_tail, dim3(1), dim3(256), 0, ctx->stream, d->scal, d->ce_row, d->correct, d->gp_row, B, gp,
                      d->cfg.disc_lr, d->cfg.disc_momentum, 0.999f);
   HIPCHK(hipGetLastError());
