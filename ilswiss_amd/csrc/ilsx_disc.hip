@@ -571,16 +571,19 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
     }
     for (int m = 0; m < policy_updates; ++m) {   // adv_irl.py:238-314
       const int npol = policy_batch - nfe;   // adv_irl.py:239-255: torch.cat([rows from the policy buffer, rows from the expert buffer])
-      if (npol > 0) ILSX_TRY(ilsx_replay_sample(policy_rb, npol, nullptr, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, nullptr));
+      // the batch is drawn straight into the agent's own batch arrays and relabelled there (same stream): no staging copy
+      float *bo, *ba, *br, *bd, *bn;
+      ILSX_TRY(sac_staged_batch(sac, policy_batch, &bo, &ba, &br, &bd, &bn));
+      if (npol > 0) ILSX_TRY(ilsx_replay_sample(policy_rb, npol, nullptr, bo, ba, br, bd, bn, nullptr));
       if (nfe > 0)
-        ILSX_TRY(ilsx_replay_sample(expert_rb, nfe, nullptr, ws.po + (size_t)npol * o, ws.pa + (size_t)npol * a, ws.pr + npol, ws.pd + npol,
-                                    ws.pn + (size_t)npol * o, nullptr));
-      ILSX_TRY(ilsx_disc_reward(d, ws.po, so ? ws.pn : ws.pa, policy_batch, mode, has_min, rew_clip_min, has_max, rew_clip_max, ws.pr, nullptr));
+        ILSX_TRY(ilsx_replay_sample(expert_rb, nfe, nullptr, bo + (size_t)npol * o, ba + (size_t)npol * a, br + npol, bd + npol,
+                                    bn + (size_t)npol * o, nullptr));
+      ILSX_TRY(ilsx_disc_reward(d, bo, so ? bn : ba, policy_batch, mode, has_min, rew_clip_min, has_max, rew_clip_max, br, nullptr));
       const bool want = first_pol && sac_stats;
-      ILSX_TRY(ilsx_sac_train_step(sac, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, policy_batch, nullptr, nullptr, want ? sac_stats : nullptr));
+      ILSX_TRY(sac_step_staged(sac, want ? sac_stats : nullptr));
       if (first_pol && rew_stats4) {   // "Disc Rew Mean/Std/Max/Min" of the first relabelled batch (adv_irl.py:303-314)
         std::vector<float> r(policy_batch);
-        HIPCHK(hipMemcpyAsync(r.data(), ws.pr, (size_t)policy_batch * 4, hipMemcpyDeviceToHost, d->ctx->stream));
+        HIPCHK(hipMemcpyAsync(r.data(), br, (size_t)policy_batch * 4, hipMemcpyDeviceToHost, d->ctx->stream));
         HIPCHK(hipStreamSynchronize(d->ctx->stream));
         double s = 0, ss = 0;
         float mx = r[0], mn = r[0];

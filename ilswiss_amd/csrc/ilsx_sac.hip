@@ -755,6 +755,25 @@ extern "C" int ilsx_sac_set_batch(ilsx_sac* s, const float* obs, const float* ac
   return ILSX_OK;
 }
 
+// internal (the adversarial-IRL loop, ilsx_disc.hip): the agent's batch arrays, for a caller on the same stream that fills them in place
+// (replay sample -> reward relabel -> step, without the five device-to-device copies of ilsx_sac_set_batch), and the step on them
+int sac_staged_batch(ilsx_sac* s, int B, float** obs, float** act, float** rew, float** done, float** nobs) {
+  if (!s || B < 1 || B > s->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch=%d", B, s ? s->cfg.max_batch : 0);
+  const SacWs& w = s->ws;
+  *obs = w.s; *act = w.a; *rew = w.r; *done = w.d; *nobs = w.s2;
+  s->eps_explicit = false;
+  s->B = B;
+  return ILSX_OK;
+}
+int sac_step_staged(ilsx_sac* s, ilsx_sac_stats* stats) {
+  ILSX_TRY(sac_check_world(s, "ilsx_advirl_train"));
+  if (stats) ILSX_TRY(sac_request_stats(s));
+  ILSX_TRY(sac_full_step(s));
+  if (stats) return sac_read_stats(s, stats);
+  return ILSX_OK;
+}
+int sac_dims(const ilsx_sac* s, int* o, int* a) { *o = s->o; *a = s->a; return ILSX_OK; }
+
 #define SAC_PHASE(name, fn)                                                        \
   extern "C" int name(ilsx_sac* s) {                                               \
     if (!s) ILSX_FAIL(ILSX_ERR_ARG, #name ": NULL agent");                         \
