@@ -66,6 +66,29 @@ __global__ void k_disc_prep(const float* __restrict__ eo, const float* __restric
   }
 }
 
+// k_disc_prep with the two batches drawn from the replay rings in place (the adversarial-IRL loop): row r of the expert / policy block is
+// the record ilsx_replay_sample would have drawn under the same counters (replay_draw), so X is bit for bit what
+// sample(expert) ; sample(policy) ; k_disc_prep builds — two launches and two staging round trips less per discriminator step.
+struct DiscRing { const float* data; const DevReplayState* st; uint64_t seed; uint32_t stream; int rec; unsigned long long step; };
+__global__ void k_disc_prep_rings(const DiscRing E, const DiscRing P, int B, int o, int a, int state_only, int use_gp, uint64_t seed,
+                                  uint32_t stream, unsigned long long step, float* __restrict__ X, float* __restrict__ eps_used) {
+  const int D = o + (state_only ? o : a), e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * D) return;
+  const int r = e / D, c = e - r * D;
+  const int col = c < o ? c : (state_only ? o + a + 2 + (c - o) : o + (c - o));   // record = [obs | act | rew | done | next_obs]
+  const float xe = E.data[(size_t)replay_draw(E.seed, E.step, E.stream, (uint32_t)r, E.st->size) * E.rec + col];
+  const float xp = P.data[(size_t)replay_draw(P.seed, P.step, P.stream, (uint32_t)r, P.st->size) * P.rec + col];
+  X[(size_t)r * D + c] = xe;
+  X[(size_t)(B + r) * D + c] = xp;
+  if (use_gp) {
+    uint32_t ctr[4] = {(uint32_t)r >> 2, 0x44495343u, (uint32_t)step, (uint32_t)(step >> 32) ^ (stream * 0x9E3779B9u)};
+    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32) ^ stream);
+    const float w = (float)(ctr[r & 3] >> 8) * (1.0f / 16777216.0f);   // ptu.rand(B, 1): U[0,1) (adv_irl.py:184)
+    X[(size_t)(2 * B + r) * D + c] = w * xe + (1.0f - w) * xp;   // adv_irl.py:187
+    if (c == 0 && eps_used) eps_used[r] = w;
+  }
+}
+
 template <int H, int ACT>
 __global__ __launch_bounds__(4 * H) void k_disc_bwd(const DiscBwdArgs A) {
   constexpr int NW = H / 16, NTH = 4 * H, NC = H / 16, KPL = H / 64, RPW = 16 / NW;
@@ -309,12 +332,10 @@ __global__ void k_disc_reward(PartVal raw, int n, float clamp, int mode, int has
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct AdvIrlWs { float *eo, *ea, *er, *ed, *en, *po, *pa, *pr, *pd, *pn; int B; };
 struct ilsx_disc {
   ilsx_ctx* ctx = nullptr;
   ilsx_disc_cfg cfg;
   NetLayout L;
-  AdvIrlWs airl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};  // ilsx_advirl_train batches
   int cs = 1, D = 0, o = 0, a = 0;
   int from_expert = 0;   // policy_optim_batch_size_from_expert (adv_irl.py:239-255)
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
@@ -460,20 +481,43 @@ static int disc_build_jobs(ilsx_disc* d, int B) {
   return ILSX_OK;
 }
 
+static int disc_step_after_prep(ilsx_disc* d, int B, ilsx_disc_stats* stats);
+
 extern "C" int ilsx_disc_train_step(ilsx_disc* d, const float* exp_obs, const float* exp_act, const float* pol_obs,
                                     const float* pol_act, int B, const float* eps, ilsx_disc_stats* stats) {
   if (!d || !exp_obs || !exp_act || !pol_obs || !pol_act) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_disc_train_step: NULL argument");
   if (B < 1 || B > d->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch=%d", B, d->cfg.max_batch);
   ilsx_ctx* ctx = d->ctx;
   HIPCHK(hipSetDevice(ctx->device));
-  ILSX_TRY(disc_build_jobs(d, B));
-  const int gp = d->cfg.use_grad_pen ? 1 : 0, rows = gp ? 3 * B : 2 * B, H = d->cfg.hid_dim;
+  const int gp = d->cfg.use_grad_pen ? 1 : 0;
   {
     const int tot = B * d->D;
     hipLaunchKernelGGL(k_disc_prep, dim3((tot + 255) / 256), dim3(256), 0, ctx->stream, exp_obs, exp_act, pol_obs, pol_act, eps,
                        B, d->o, d->a, gp, ctx->seed, d->rng_stream, ++d->step_ctr, d->X, d->eps_used);
     HIPCHK(hipGetLastError());
   }
+  return disc_step_after_prep(d, B, stats);
+}
+
+// the discriminator step of the adversarial-IRL loop: both batches drawn from the rings inside the prep launch (k_disc_prep_rings)
+static int disc_train_step_from_rings(ilsx_disc* d, ilsx_replay* expert_rb, ilsx_replay* policy_rb, int B, ilsx_disc_stats* stats) {
+  if (B < 1 || B > d->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch=%d", B, d->cfg.max_batch);
+  if (expert_rb->size < 1 || policy_rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_advirl_train: a replay buffer is empty");
+  ilsx_ctx* ctx = d->ctx;
+  const int gp = d->cfg.use_grad_pen ? 1 : 0, tot = B * d->D;
+  // the counters advance exactly as ilsx_replay_sample(expert) ; ilsx_replay_sample(policy) would advance them
+  const DiscRing E = {expert_rb->data, expert_rb->dstate, expert_rb->seed, expert_rb->rng_stream, expert_rb->rec, ++expert_rb->sample_ctr};
+  const DiscRing P = {policy_rb->data, policy_rb->dstate, policy_rb->seed, policy_rb->rng_stream, policy_rb->rec, ++policy_rb->sample_ctr};
+  hipLaunchKernelGGL(k_disc_prep_rings, dim3((tot + 255) / 256), dim3(256), 0, ctx->stream, E, P, B, d->cfg.obs_dim, policy_rb->a,
+                     d->cfg.state_only ? 1 : 0, gp, ctx->seed, d->rng_stream, ++d->step_ctr, d->X, d->eps_used);
+  HIPCHK(hipGetLastError());
+  return disc_step_after_prep(d, B, stats);
+}
+
+static int disc_step_after_prep(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
+  ilsx_ctx* ctx = d->ctx;
+  ILSX_TRY(disc_build_jobs(d, B));
+  const int gp = d->cfg.use_grad_pen ? 1 : 0, rows = gp ? 3 * B : 2 * B, H = d->cfg.hid_dim;
   ILSX_TRY(disc_forward(d, d->X, d->D, d->D, nullptr, 0, 0, rows, true));
   {
     DiscBwdArgs A;
@@ -541,32 +585,18 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
                                  float rew_clip_min, int has_max, float rew_clip_max, ilsx_disc_stats* disc_stats,
                                  ilsx_sac_stats* sac_stats, float* rew_stats4) {
   if (!d || !sac || !expert_rb || !policy_rb || loops < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_advirl_train: bad argument");
-  const int B = std::max(disc_batch, policy_batch);
   if (disc_batch < 1 || disc_batch > d->cfg.max_batch || policy_batch < 1) ILSX_FAIL(ILSX_ERR_ARG, "batch sizes out of range");
   HIPCHK(hipSetDevice(d->ctx->device));
-  AdvIrlWs& ws = d->airl;
   const int o = d->cfg.obs_dim, a = policy_rb->a;   // a: the env's action width (state_only discriminators have cfg.act_dim == obs_dim)
   const bool so = d->cfg.state_only != 0;
   const int nfe = d->from_expert;
   if (nfe < 0 || nfe > policy_batch) ILSX_FAIL(ILSX_ERR_ARG, "policy_optim_batch_size_from_expert=%d not in 0..policy_batch=%d", nfe, policy_batch);
   if (expert_rb->o != o || policy_rb->o != o || expert_rb->a != a || (!so && a != d->cfg.act_dim))
     ILSX_FAIL(ILSX_ERR_ARG, "replay dims do not match the discriminator");
-  if (ws.B < B) {
-    float** ps[] = {&ws.eo, &ws.ea, &ws.er, &ws.ed, &ws.en, &ws.po, &ws.pa, &ws.pr, &ws.pd, &ws.pn};
-    const size_t w[] = {(size_t)o, (size_t)a, 1, 1, (size_t)o, (size_t)o, (size_t)a, 1, 1, (size_t)o};
-    for (int i = 0; i < 10; ++i) {   // a larger batch than before: release the old staging rows first
-      if (*ps[i]) { ILSX_TRY(ctx_free(d->ctx, *ps[i])); *ps[i] = nullptr; }
-      ILSX_TRY(ctx_alloc(d->ctx, (size_t)B * w[i] * 4, (void**)ps[i], true));
-    }
-    ws.B = B;
-  }
   bool first_disc = true, first_pol = true;
   for (int it = 0; it < loops; ++it) {
     for (int k = 0; k < disc_updates; ++k) {   // adv_irl.py:133-216
-      ILSX_TRY(ilsx_replay_sample(expert_rb, disc_batch, nullptr, ws.eo, ws.ea, ws.er, ws.ed, ws.en, nullptr));
-      ILSX_TRY(ilsx_replay_sample(policy_rb, disc_batch, nullptr, ws.po, ws.pa, ws.pr, ws.pd, ws.pn, nullptr));
-      ILSX_TRY(ilsx_disc_train_step(d, ws.eo, so ? ws.en : ws.ea, ws.po, so ? ws.pn : ws.pa, disc_batch, nullptr,
-                                    first_disc ? disc_stats : nullptr));
+      ILSX_TRY(disc_train_step_from_rings(d, expert_rb, policy_rb, disc_batch, first_disc ? disc_stats : nullptr));
       first_disc = false;
     }
     for (int m = 0; m < policy_updates; ++m) {   // adv_irl.py:238-314
