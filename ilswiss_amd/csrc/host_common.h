@@ -149,6 +149,7 @@ int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P);
 bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks);
 int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P, int H, int act, int KPmax, int cs);
 int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P, int H, int act, int KPmax, int cs);
+int device_cus(ilsx_ctx* ctx);   // compute units of the context's device
 struct ilsx_sac;
 int sac_staged_batch(ilsx_sac* s, int B, float** obs, float** act, float** rew, float** done, float** nobs);   // ilsx_sac.hip
 int sac_step_staged(ilsx_sac* s, ilsx_sac_stats* stats);

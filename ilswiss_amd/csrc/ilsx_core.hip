@@ -306,6 +306,9 @@ static int kernels_init_once() {
 #undef SET_FWD
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -417,7 +420,7 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
 
 // ---- merged phase kernels of the single-run SAC step (kernels.h: k_sac_phase_a / _c)
 // Every workgroup of a phase launch must be resident at once (they wait for each other): at most one workgroup per CU.
-static int device_cus(ilsx_ctx* ctx) {
+int device_cus(ilsx_ctx* ctx) {
   static int n_cu = 0;
   if (!n_cu) {
     hipDeviceProp_t pr;
@@ -552,7 +555,12 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
   }
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
   if (D.gtiles) {
-    ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 2, 4>), dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
+    const int gnh = D.tile_nh ? D.tile_nh : 2, gkt = D.tile_kt ? D.tile_kt : 4;
+    if (gnh == 2 && gkt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 2, 4>), dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
+    else if (gnh == 1 && gkt == 2) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 1, 2>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 2), ctx->stream, D);
+    else if (gnh == 1 && gkt == 1) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 1, 1>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 1), ctx->stream, D);
+    else if (gnh == 1 && gkt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 1, 4>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 4), ctx->stream, D);
+    else ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "grouped dW tile %d x %d", gnh, gkt);
   } else {
     // small batches (one 256-row trip per wave): the table's 32 x 64 tiles are a few dozen 16-wave workgroups, each CU's 4 waves per
     // SIMD then share one MFMA pipe and one issue port while most of the chip idles; smaller tiles give the same waves (same

@@ -1165,12 +1165,32 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
       std::vector<DwTileG> gt;
       st.d = cols[0].L[i].d;
       int tiles = 0, nmat = 0;
+      // tile shape: as for single launches (launch_bwd_dw) the smallest that keeps the launch within ~3 workgroups per CU — it only
+      // matters for small groups (K = 1, 2: +4 %); at K >= 4 the launch is bound elsewhere and every shape measures the same
+      static const int gshape = []() { const char* e = getenv("ILSX_DW_TILE_GRP"); return e ? atoi(e) : 0; }();   // "NH KT" digits, 0 = by size
+      int gnh = 2, gkt = 4;
+      if (gshape) { gnh = gshape / 10; gkt = gshape % 10; }
+      else {
+        auto count = [&](int nh, int kt) {
+          long long n = 0;
+          for (int k = 0; k < K; ++k) {
+            const DwArgs& D = cols[k].L[i].d;
+            for (int m = 0; m < D.nmat; ++m) n += (long long)((D.m[m].NA + 16 * nh - 1) / (16 * nh)) * ((D.m[m].NB + 16 * kt - 1) / (16 * kt));
+          }
+          return n;
+        };
+        const long long cap = 3LL * device_cus(g->ctx);
+        if (count(1, 1) <= cap) { gnh = 1; gkt = 1; }
+        else if (count(1, 2) <= cap) { gnh = 1; gkt = 2; }
+      }
+      st.d.tile_nh = gnh; st.d.tile_kt = gkt;
       for (int k = 0; k < K; ++k) {
         const DwArgs& D = cols[k].L[i].d;
         for (int m = 0; m < D.nmat; ++m, ++nmat) {
           DwTileG R; memset(&R, 0, sizeof R);
           R.J = D.m[m]; R.F = cols[k].L[i].F;
-          const int n = (m + 1 < D.nmat ? D.m[m + 1].tile0 : D.ntiles) - R.J.tile0;
+          R.J.ktiles = (R.J.NB + 16 * gkt - 1) / (16 * gkt);
+          const int n = ((R.J.NA + 16 * gnh - 1) / (16 * gnh)) * R.J.ktiles;
           R.J.tile0 = tiles; R.J.agent = k;
           for (int t = 0; t < n; ++t) gt.push_back(R);
           tiles += n;

@@ -1239,6 +1239,7 @@ struct DwArgs {
   // grouped launch: one self-contained record per output tile (its matrix and its agent's optimiser) in device memory
   const struct DwTileG* gtiles;
   unsigned* zero_flags;   // non-null: workgroup 0 zeroes the PHASE_NFLAGS arrival counters of the phase kernel that follows this launch
+  int tile_nh, tile_kt;   // grouped launches: the tile shape the gtiles table was built for (0 = 2 x 4); host-side only
 };
 struct DwTileG { DwMat J; AdamFuse F; };
 #define DW_SPLIT_MIN_ROWS 1024
