@@ -565,7 +565,8 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     // small batches (one 256-row trip per wave): the table's 32 x 64 tiles are a few dozen 16-wave workgroups, each CU's 4 waves per
     // SIMD then share one MFMA pipe and one issue port while most of the chip idles; smaller tiles give the same waves (same
     // arithmetic, same order) to more CUs
-    static const int shape = []() { const char* e = getenv("ILSX_DW_TILE"); return e ? atoi(e) : 0; }();   // "NH KT" digits; 0 = by size
+    const char* shape_env = getenv("ILSX_DW_TILE");   // "NH KT" digits (24, 12, 11); unset / 0 = by size.  Read per launch: tests switch it
+    const int shape = shape_env ? atoi(shape_env) : 0;
     int nh = 2, kt = 4;
     auto retile = [&](int nh_, int kt_) {
       D.ntiles = 0;

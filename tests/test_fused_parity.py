@@ -300,3 +300,38 @@ def test_phase_kernels_are_bitwise_the_eight_launch_path(o, a, H, B, n_steps):
         np.testing.assert_array_equal(s0[k]["exp_avg_sq"], s1[k]["exp_avg_sq"], err_msg=k)
     for k, v in st0.items():
         assert v == st1[k] or (np.isnan(v) and np.isnan(st1[k])), (k, v, st1[k])
+
+
+def test_dw_tile_shapes_are_bitwise():
+    """k_mlp_bwd_dw<GRP, NH, KT>: the output tile of a workgroup (32 x 64, 16 x 32, 16 x 16) decides how many workgroups a launch has,
+    not what a wave computes or in which order an output element is summed — parameters, targets and Adam moments after several fused
+    steps must not depend on it (launch_bwd_dw picks 16 x 16 for the SAC step; ILSX_DW_TILE forces a shape)."""
+    import os
+    import ilswiss_amd as ia
+    o, a, H, B = 11, 3, 256, 100
+    hidden, N = [H, H], 6000
+    rng = np.random.default_rng(77)
+    params = _init(rng, o, a, hidden)
+    data = _ring_data(rng, N, o, a)
+    snaps = []
+    for shape in (None, "24", "12"):
+        if shape:
+            os.environ["ILSX_DW_TILE"] = shape
+        try:
+            ctx = ia.Context(0, seed=11)
+            rb = ia.SimpleReplayBuffer(8192, o, a, random_seed=5, ctx=ctx)
+            rb.add_rows(*data)
+            tr = _agent(ia, ctx, o, a, hidden, params, SAC_KW, B)
+            tr.eval_statistics = {}
+            tr.train_from_replay(rb, 6, B)
+            snaps.append(tr.get_snapshot())
+            ctx.close()
+        finally:
+            os.environ.pop("ILSX_DW_TILE", None)
+    for s in snaps[1:]:
+        for k in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+            np.testing.assert_array_equal(snaps[0][k], s[k], err_msg=k)
+        for k in ("policy_optimizer", "qf1_optimizer", "qf2_optimizer"):
+            np.testing.assert_array_equal(snaps[0][k]["exp_avg"], s[k]["exp_avg"], err_msg=k)
+            np.testing.assert_array_equal(snaps[0][k]["exp_avg_sq"], s[k]["exp_avg_sq"], err_msg=k)
+
