@@ -30,11 +30,19 @@
 #define EG_ENVS 4    // per wavefront == per workgroup
 #define EG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// value of lane K of this lane's 16-lane row (ds_swizzle bit mode: lane' = (lane & 0x10) | K inside each half-wave)
+// value of lane K of this lane's 16-lane row: DPP row_newbcast (gfx90a+: the one DPP control 64-bit operations accept) — a VALU move, or
+// folded into the consuming instruction; the first version went through the LDS crossbar (ds_swizzle bit mode, lane' = (lane & 0x10) | K:
+// an LDS round trip on every step of the substitution and Gauss-Seidel chains).  ILSX_EG_SWIZZLE selects that form (measurement).
 template <int K> __device__ __forceinline__ double eg_bcast(double x) {
+#ifdef ILSX_EG_SWIZZLE
   constexpr int pat = 0x10 | (K << 5);
   const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pat);
   const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pat);
+#else
+  constexpr int ctl = 0x150 + K;   // DPP_ROW_NEWBCAST_FIRST + K
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctl, 0xf, 0xf, false);
+#endif
   return __hiloint2double(hi, lo);
 }
 

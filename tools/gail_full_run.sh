@@ -21,7 +21,7 @@ import numpy as np
 rows = list(csv.DictReader(open("gpurun_out/r03_gail_full/gail_walker_progress.csv")))
 r = [float(x["Test Returns Mean"]) for x in rows]
 print("GAIL Walker:", len(rows), "epochs; best", round(max(r), 1), "at", int(np.argmax(r)), "; last-10 mean", round(float(np.mean(r[-10:])), 1),
-      "; last-50 mean", round(float(np.mean(r[-50:])), 1), "; train steps", rows[-1]["Number of train steps total"], "; wall", rows[-1].get("Total Train Time (s)"))
+      "; last-50 mean", round(float(np.mean(r[-50:])), 1), "; gradient steps", rows[-1]["Number of gradient steps total"], "; wall", rows[-1].get("Total Train Time (s)"))
 for i in range(0, len(r), 25):
     print(i, round(float(np.mean(r[i:i + 25])), 1))
 PY
