@@ -1101,9 +1101,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
 #define XCH_HOOK_STAGE ILSX_STAMP_SYNC(P.dbg, 7); xch_wait(f0, CS, P.err); ILSX_STAMP(P.dbg, 3);
 #define XCH_HOOK_FIN
 #define XCH_FINE_DBG P.dbg
-#define XCH_WREG_AFTER_FIN
 #include "fwd_split_tile.inc"
-#undef XCH_WREG_AFTER_FIN
 #undef XCH_FINE_DBG
 #undef XCH_HOOK_STAGE
 #undef XCH_HOOK_FIN
@@ -1192,9 +1190,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) 
     const BwdTask& T = A.t[y];
 #define XCH_HOOK_ACT xch_wait(f1, 2 * CS, P.err); ILSX_STAMP(P.dbg, 2);
 #define XCH_HOOK_HEAD
-#define XCH_WREG_AFTER_ACT
 #include "bwd_split_tile.inc"
-#undef XCH_WREG_AFTER_ACT
 #undef XCH_HOOK_ACT
 #undef XCH_HOOK_HEAD
   }
