@@ -214,10 +214,22 @@ __host__ __device__ __forceinline__ int pack_b(int n, int k, int N) {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Sum over the 64 lanes, the total in every lane.  Inside a 16-lane row the exchange is DPP (quad permutes, then the half-row and the
+// row mirrored onto themselves: VALU modifiers, no LDS round trip), the four row sums are combined through v_readlane.  The butterfly
+// of __shfl_xor this replaces is six ds_bpermute round trips per call (~60 cycles each on the one or two waves per SIMD these kernels
+// run): the discriminator's dD/dx loop calls it once per input column.  All lanes must be active (every call site is wave-uniform).
+template <int CTL> __device__ __forceinline__ float wave_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-  v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-  return v;
+  v += wave_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += wave_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += wave_dpp<0x141>(v);   // row_half_mirror
+  v += wave_dpp<0x140>(v);   // row_mirror: every lane of a row holds the row's sum
+  const int b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return ((r0 + r1) + r2) + r3;
 }
 template <int N> __device__ __forceinline__ void load_vec(const float* p, float (&v)[N]) {
   if constexpr (N == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
