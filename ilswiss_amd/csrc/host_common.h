@@ -154,6 +154,9 @@ struct ilsx_sac;
 int sac_staged_batch(ilsx_sac* s, int B, float** obs, float** act, float** rew, float** done, float** nobs);   // ilsx_sac.hip
 int sac_step_staged(ilsx_sac* s, ilsx_sac_stats* stats);
 int sac_dims(const ilsx_sac* s, int* o, int* a);
+int sac_window_begin(ilsx_sac* s, int B);   // steps on staged batches with the deferred tail + phase kernels (ilsx_sac.hip)
+int sac_window_step(ilsx_sac* s);
+int sac_window_end(ilsx_sac* s);
 // column-split factor the 2-hidden-layer fast path uses for width H (1 = generic kernels)
 int mlp2_split_factor(int n_hidden, int H);
 int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* fuse = nullptr);

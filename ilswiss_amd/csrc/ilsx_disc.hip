@@ -593,7 +593,9 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
   if (nfe < 0 || nfe > policy_batch) ILSX_FAIL(ILSX_ERR_ARG, "policy_optim_batch_size_from_expert=%d not in 0..policy_batch=%d", nfe, policy_batch);
   if (expert_rb->o != o || policy_rb->o != o || expert_rb->a != a || (!so && a != d->cfg.act_dim))
     ILSX_FAIL(ILSX_ERR_ARG, "replay dims do not match the discriminator");
-  bool first_disc = true, first_pol = true;
+  bool first_disc = true, first_pol = true, first_pol_plain = true, in_window = false;
+  static const bool no_window = getenv("ILSX_ADVIRL_NO_WINDOW") != nullptr;
+  struct WindowGuard { ilsx_sac* s; bool* on; ~WindowGuard() { if (*on) sac_window_end(s); } } window_guard{sac, &in_window};   // error paths
   for (int it = 0; it < loops; ++it) {
     for (int k = 0; k < disc_updates; ++k) {   // adv_irl.py:133-216
       ILSX_TRY(disc_train_step_from_rings(d, expert_rb, policy_rb, disc_batch, first_disc ? disc_stats : nullptr));
@@ -609,8 +611,16 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
         ILSX_TRY(ilsx_replay_sample(expert_rb, nfe, nullptr, bo + (size_t)npol * o, ba + (size_t)npol * a, br + npol, bd + npol,
                                     bn + (size_t)npol * o, nullptr));
       ILSX_TRY(ilsx_disc_reward(d, bo, so ? bn : ba, policy_batch, mode, has_min, rew_clip_min, has_max, rew_clip_max, br, nullptr));
+      // the step whose statistics the caller reads (the first one) runs with its own tail; every later step of the call sits in a window
+      // (ilsx_sac.hip sac_window_*): tail deferred into the next step's first launch, merged phase kernels where they fit
       const bool want = first_pol && sac_stats;
-      ILSX_TRY(sac_step_staged(sac, want ? sac_stats : nullptr));
+      if (want || first_pol_plain) {
+        ILSX_TRY(sac_step_staged(sac, want ? sac_stats : nullptr));
+        first_pol_plain = false;
+        if (!no_window) { ILSX_TRY(sac_window_begin(sac, policy_batch)); in_window = true; }
+      } else {
+        ILSX_TRY(sac_window_step(sac));
+      }
       if (first_pol && rew_stats4) {   // "Disc Rew Mean/Std/Max/Min" of the first relabelled batch (adv_irl.py:303-314)
         std::vector<float> r(policy_batch);
         HIPCHK(hipMemcpyAsync(r.data(), br, (size_t)policy_batch * 4, hipMemcpyDeviceToHost, d->ctx->stream));
@@ -625,6 +635,7 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
       first_pol = false;
     }
   }
+  if (in_window) { in_window = false; ILSX_TRY(sac_window_end(sac)); }
   return ILSX_OK;
 }
 

@@ -773,6 +773,28 @@ int sac_step_staged(ilsx_sac* s, ilsx_sac_stats* stats) {
   return ILSX_OK;
 }
 int sac_dims(const ilsx_sac* s, int* o, int* a) { *o = s->o; *a = s->a; return ILSX_OK; }
+// A window of steps on batches the caller stages in place (sac_staged_batch): the deferred tail and the merged phase kernels, as inside
+// one ilsx_sac_train_from_replay call — the rows just come from the batch arrays instead of the in-kernel replay draw.
+static bool sac_phase_ok(ilsx_sac* s, int B);
+static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who);
+int sac_window_begin(ilsx_sac* s, int B) {
+  ILSX_TRY(sac_check_world(s, "ilsx_advirl_train"));
+  s->B = B; s->eps_explicit = false;
+  return sac_defer_begin(s, B);
+}
+int sac_window_step(ilsx_sac* s) {
+  s->gather_rb = nullptr;
+  s->phase_now = sac_phase_ok(s, s->B);
+  const int rc = sac_full_step(s);
+  s->phase_now = false;
+  return rc;
+}
+int sac_window_end(ilsx_sac* s) {
+  const bool deferred = s->defer_tail;
+  s->defer_tail = false;
+  ILSX_TRY(sac_flush_tail(s, deferred));
+  return sac_phase_check(s, s->B, deferred, "ilsx_advirl_train");
+}
 
 #define SAC_PHASE(name, fn)                                                        \
   extern "C" int name(ilsx_sac* s) {                                               \
@@ -814,6 +836,31 @@ static bool sac_phase_possible(ilsx_sac* s, int B) {   // as sac_phase_ok, for t
   const bool off = getenv("ILSX_NO_PHASE") != nullptr;   // read per call: tests switch between the two paths in one process
   return !off && s->cs > 1 && !s->h0scr && !sac_is_split(s) && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
 }
+// After a window of steps that may have run on the merged phase kernels: a workgroup that gave up waiting, or a row tile whose workgroups
+// sat on two XCDs, left a mark — the window's updates are then not to be trusted and the agent stays on one launch per stage.
+static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who) {
+  hipStream_t st = s->ctx->stream;
+  if (deferred && !s->phase_broken && sac_phase_possible(s, B)) {
+    // a phase-kernel workgroup that gave up waiting left a mark: the steps of this call are not to be trusted
+    int err = 0;
+    unsigned masks[PHASE_MAX_TILES * 32];
+    HIPCHK(hipMemcpyAsync(&err, s->phase_err, sizeof err, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(masks, s->phase_flags + PHASE_MASK_WORD(0), sizeof masks, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int t = 0; t < PHASE_MAX_TILES; ++t)
+      if (masks[t * 32] & (masks[t * 32] - 1)) err |= 2;   // a tile's workgroups ran on more than one XCD: its exchange went through two L2s
+    if (err) {
+      s->phase_broken = true;
+      if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
+      HIPCHK(hipMemsetAsync(s->phase_err, 0, sizeof(int), st));
+      ILSX_FAIL(ILSX_ERR_HIP, "%s: a merged phase kernel %s; this agent falls back to one launch per stage from now on — "
+                "the call's updates are invalid", who, (err & 1) ? "timed out waiting for the workgroups of its tile (are other kernels sharing this GPU?)"
+                                                            : "found the workgroups of one row tile on different XCDs");
+    }
+  }
+  return ILSX_OK;
+}
+
 static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
   const SacWs& w = s->ws;
   if (s->cs > 1) {
@@ -875,24 +922,7 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   }
   s->defer_tail = false;
   ILSX_TRY(sac_flush_tail(s, deferred));
-  if (deferred && !s->phase_broken && sac_phase_possible(s, B)) {
-    // a phase-kernel workgroup that gave up waiting left a mark: the steps of this call are not to be trusted
-    int err = 0;
-    unsigned masks[PHASE_MAX_TILES * 32];
-    HIPCHK(hipMemcpyAsync(&err, s->phase_err, sizeof err, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(masks, s->phase_flags + PHASE_MASK_WORD(0), sizeof masks, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    for (int t = 0; t < PHASE_MAX_TILES; ++t)
-      if (masks[t * 32] & (masks[t * 32] - 1)) err |= 2;   // a tile's workgroups ran on more than one XCD: its exchange went through two L2s
-    if (err) {
-      s->phase_broken = true;
-      if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
-      HIPCHK(hipMemsetAsync(s->phase_err, 0, sizeof(int), st));
-      ILSX_FAIL(ILSX_ERR_HIP, "ilsx_sac_train_from_replay: a merged phase kernel %s; this agent falls back to one launch per stage from now on — "
-                "the call's updates are invalid", (err & 1) ? "timed out waiting for the workgroups of its tile (are other kernels sharing this GPU?)"
-                                                            : "found the workgroups of one row tile on different XCDs");
-    }
-  }
+  ILSX_TRY(sac_phase_check(s, B, deferred, "ilsx_sac_train_from_replay"));
   if (stats) return sac_read_stats(s, stats);
   return ILSX_OK;
 }
