@@ -49,8 +49,9 @@ def _latest_pmc_summary():
 
 
 PMC_SUMMARY = _latest_pmc_summary()
-PMC_NAMES = {0: ("k_sac_phase_a", "k_mlp2_fwd_split", "k_mlp_fwd"), 1: ("k_sac_phase_c", "k_mlp2_bwd_split", "k_mlp_bwd_dx"), 2: ("k_mlp_bwd_dw",),
-             6: ("k_replay_sample_many",)}
+PMC_NAMES = {0: ("k_mlp2_fwd_split", "k_mlp_fwd"), 1: ("k_mlp2_bwd_split", "k_mlp_bwd_dx"), 2: ("k_mlp_bwd_dw",),
+             6: ("k_replay_sample_many",), 13: ("k_sac_phase_a",), 14: ("k_sac_phase_c",)}
+MLP_SLOTS = (0, 1, 2, 13, 14)   # library profiling slots of the step's MFMA kernels (13 / 14: the merged phase kernels)
 
 
 def pmc_traffic(kid):
@@ -488,7 +489,7 @@ def main():
         tr.train_from_replay(rb, 200, B)
         _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
         prof = {}
-        for kid in range(10):
+        for kid in range(16):
             nl, ms = C.c_uint64(), C.c_double()
             _lib.check(lib.ilsx_prof_read(ctx.h, kid, C.byref(nl), C.byref(ms)))
             if nl.value:
@@ -496,8 +497,8 @@ def main():
         fl = flops_per_step()
         # a slot's algorithmic FLOPs per step: the merged phase kernels (one launch = three stages) carry their own count
         def slot_flops(k):
-            return next((fl[n] for n in ("k_sac_phase_a", "k_sac_phase_c") if n in prof[k][0]), fl[k])
-        mlp = [k for k in prof if k in (0, 1, 2)]
+            return fl[{13: "k_sac_phase_a", 14: "k_sac_phase_c"}.get(k, k)]
+        mlp = [k for k in prof if k in MLP_SLOTS]
         per_kernel = []
         for k in mlp:
             kname, knl, kms = prof[k]

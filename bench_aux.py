@@ -209,12 +209,14 @@ def bench_gail(ctx):
     D, Hd = o + a, 128
     Wd = D * Hd + Hd * Hd + Hd
     sf = sac_flops(o, a, H, B)
-    fl = {0: npf * (sf[0] + 2.0 * (3 * B + B) * Wd),                                  # SAC forwards + discriminator forward (3B rows) + relabel forward (B rows)
-          1: npf * sf[1],
+    phase = 13 in prof   # the SAC steps ran on the merged phase kernels (library slots 13 / 14): their forwards / backwards are not in slots 0 / 1
+    fl = {0: npf * ((0 if phase else sf[0]) + 2.0 * (3 * B + B) * Wd),                # SAC forwards + discriminator forward (3B rows) + relabel forward (B rows)
+          1: npf * (0 if phase else sf[1]),
+          13: npf * sf["k_sac_phase_a"] if phase else 0, 14: npf * sf["k_sac_phase_c"] if phase else 0,
           2: npf * (sf[2] + 2.0 * (4 * B * (D * Hd + Hd * Hd) + 3 * B * Hd)),           # + the discriminator's row-stacked weight-gradient jobs
           11: npf * 2.0 * (2 * B * Hd * Hd + B * (3 * Hd * Hd + 2 * D * Hd))}         # k_disc_bwd: GEMM 1 on all rows, GEMM 2/3 + the two W1 contractions on GP rows
     roof = mfma_roofline(prof, fl, "per loop iteration: 1 discriminator step (k_disc_prep, forward over 3B rows, k_disc_bwd, stacked dW, Adam, tail) + "
-                                   "relabel forward + 1 SAC step (8 launches)")
+                                   "relabel forward + 1 SAC step (4 launches: phase A, dW{Q}, phase C, dW{pi}; the first step of a train call: 8)")
     return dict(roofline=roof, metric="GAIL Walker2d-v2 dims: discriminator step + SAC step", unit="loop-iterations/s", value=n / dt,
                 dtype="f32", data="synthetic",
                 config=dict(workload="o=17,a=6; disc 23-128-128-1 tanh, B=256+256, WGAN-GP weight 8; SAC 256-256, B=256, "

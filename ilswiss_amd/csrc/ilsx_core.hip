@@ -178,7 +178,7 @@ extern "C" const char* ilsx_prof_kernel(ilsx_ctx* c, int kid) {
 extern "C" const char* ilsx_kernel_name(int kid) {
   static const char* names[ILSX_K_COUNT] = {"k_mlp_fwd", "k_mlp_bwd_dx", "k_mlp_bwd_dw", "k_adam_polyak",
       "k_replay_sample", "k_replay_add", "k_replay_sample_many", "k_sac_stats", "k_sac_finish", "k_env_step",
-      "k_policy_finish", "k_disc_bwd", "k_ppo_gae", "", "", ""};
+      "k_policy_finish", "k_disc_bwd", "k_ppo_gae", "k_sac_phase_a", "k_sac_phase_c", ""};
   return (kid >= 0 && kid < ILSX_K_COUNT) ? names[kid] : "";
 }
 
@@ -446,7 +446,7 @@ int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P0, int H, int act, int KPma
   const int tiles = (P.f1.rows + 15) / 16;
   dim3 grid((tiles + 7) & ~7, 5, cs), block(4 * H / cs);
   const size_t lds = phase_lds_bytes(H, KPmax, cs);
-  ProfScope ps(ctx, ILSX_K_MLP_FWD);
+  ProfScope ps(ctx, ILSX_K_SAC_PHASE_A);
   if (H == 256 && act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_a<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, P);
   else if (H == 256) ILSX_LAUNCH(ps, (k_sac_phase_a<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, P);
   else if (act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_a<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, P);
@@ -465,7 +465,7 @@ int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P0, int H, int act, int KPma
   const int tiles = (P.f3.rows + 15) / 16;
   dim3 grid((tiles + 7) & ~7, 4, cs), block(4 * H / cs);   // y: Q1, Q2, the policy's backward, the bookkeeping row
   const size_t lds = phase_lds_bytes(H, KPmax, cs);
-  ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
+  ProfScope ps(ctx, ILSX_K_SAC_PHASE_C);
   if (H == 256 && act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_c<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, P);
   else if (H == 256) ILSX_LAUNCH(ps, (k_sac_phase_c<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, P);
   else if (act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_c<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, P);

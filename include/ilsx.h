@@ -93,6 +93,7 @@ int ilsx_comm_allreduce_sum(ilsx_ctx* ctx, float* dev_buf, size_t n);   /* in pl
 enum { ILSX_K_MLP_FWD = 0, ILSX_K_MLP_BWD_DX = 1, ILSX_K_MLP_BWD_DW = 2, ILSX_K_ADAM = 3,
        ILSX_K_REPLAY_SAMPLE = 4, ILSX_K_REPLAY_ADD = 5, ILSX_K_REPLAY_SAMPLE_MANY = 6, ILSX_K_SAC_STATS = 7,
        ILSX_K_SAC_FINISH = 8, ILSX_K_ENV_STEP = 9, ILSX_K_POLICY_FINISH = 10, ILSX_K_DISC_BWD = 11, ILSX_K_PPO_GAE = 12,
+       ILSX_K_SAC_PHASE_A = 13, ILSX_K_SAC_PHASE_C = 14,   /* the merged phase launches of the single-run SAC step */
        ILSX_K_COUNT = 16 };
 int ilsx_prof_enable(ilsx_ctx* ctx, int on);
 int ilsx_prof_reset(ilsx_ctx* ctx);

@@ -20,7 +20,7 @@ if os.environ.get("ILSX_NO_GRAPH"):
     _lib.check(lib.ilsx_prof_reset(ctx.h)); _lib.check(lib.ilsx_prof_enable(ctx.h, 1))
     tr.train_from_replay(rb, 200, B); ctx.sync()
     _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
-    for kid, name in ((0, "mlp_fwd"), (1, "mlp_bwd_dx"), (2, "mlp_bwd_dw"), (8, "sac_finish")):
+    for kid, name in ((0, "mlp_fwd"), (1, "mlp_bwd_dx"), (13, "sac_phase_a"), (14, "sac_phase_c"), (2, "mlp_bwd_dw"), (8, "sac_finish")):
         nl, ms = C.c_uint64(), C.c_double()
         _lib.check(lib.ilsx_prof_read(ctx.h, kid, C.byref(nl), C.byref(ms)))
         if nl.value:
