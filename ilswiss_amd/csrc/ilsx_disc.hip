@@ -593,7 +593,7 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
   if (nfe < 0 || nfe > policy_batch) ILSX_FAIL(ILSX_ERR_ARG, "policy_optim_batch_size_from_expert=%d not in 0..policy_batch=%d", nfe, policy_batch);
   if (expert_rb->o != o || policy_rb->o != o || expert_rb->a != a || (!so && a != d->cfg.act_dim))
     ILSX_FAIL(ILSX_ERR_ARG, "replay dims do not match the discriminator");
-  bool first_disc = true, first_pol = true, first_pol_plain = true, in_window = false;
+  bool first_disc = true, first_pol = true, in_window = false;
   static const bool no_window = getenv("ILSX_ADVIRL_NO_WINDOW") != nullptr;
   struct WindowGuard { ilsx_sac* s; bool* on; ~WindowGuard() { if (*on) sac_window_end(s); } } window_guard{sac, &in_window};   // error paths
   for (int it = 0; it < loops; ++it) {
@@ -613,11 +613,9 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
       ILSX_TRY(ilsx_disc_reward(d, bo, so ? bn : ba, policy_batch, mode, has_min, rew_clip_min, has_max, rew_clip_max, br, nullptr));
       // the step whose statistics the caller reads (the first one) runs with its own tail; every later step of the call sits in a window
       // (ilsx_sac.hip sac_window_*): tail deferred into the next step's first launch, merged phase kernels where they fit
-      const bool want = first_pol && sac_stats;
-      if (want || first_pol_plain) {
-        ILSX_TRY(sac_step_staged(sac, want ? sac_stats : nullptr));
-        first_pol_plain = false;
-        if (!no_window) { ILSX_TRY(sac_window_begin(sac, policy_batch)); in_window = true; }
+      if (first_pol || no_window) {
+        ILSX_TRY(sac_step_staged(sac, first_pol ? sac_stats : nullptr));
+        if (first_pol && !no_window) { ILSX_TRY(sac_window_begin(sac, policy_batch)); in_window = true; }
       } else {
         ILSX_TRY(sac_window_step(sac));
       }
