@@ -40,8 +40,11 @@ template <int K> __device__ __forceinline__ double eg_bcast(double x) {
   const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pat);
 #else
   constexpr int ctl = 0x150 + K;   // DPP_ROW_NEWBCAST_FIRST + K
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctl, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctl, 0xf, 0xf, false);
+  // `old` (what a lane keeps when its source lane is disabled) is the value itself: every lane is active at every call site, and a
+  // constant there costs two moves per broadcast to materialise
+  const int xl = __double2loint(x), xh = __double2hiint(x);
+  const int lo = __builtin_amdgcn_update_dpp(xl, xl, ctl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(xh, xh, ctl, 0xf, 0xf, false);
 #endif
   return __hiloint2double(hi, lo);
 }
