@@ -76,7 +76,7 @@ def _relu_margin(orc, batch):
     return m
 
 
-@pytest.mark.parametrize("o,a,H,B,n_steps", [(11, 3, 256, 256, 6), (17, 6, 128, 37, 5), (376, 17, 256, 64, 5)])
+@pytest.mark.parametrize("o,a,H,B,n_steps", [(11, 3, 256, 256, 6), (17, 6, 128, 37, 5), (376, 17, 256, 64, 5), (11, 3, 256, 1, 4), (11, 3, 256, 16, 4)])
 def test_fused_train_from_replay_matches_oracle(o, a, H, B, n_steps):
     """ONE train_from_replay(rb, n, B) call (graph + deferred tail ON) == n oracle steps on the rebuilt inputs."""
     import ilswiss_amd as ia
@@ -114,7 +114,9 @@ def test_fused_train_from_replay_matches_oracle(o, a, H, B, n_steps):
         np.testing.assert_array_equal(batch["rewards"][:, 0], data[2][idx])
         np.testing.assert_array_equal(batch["terminals"][:, 0], data[3][idx].astype(np.float32))
         np.testing.assert_array_equal(batch["next_observations"], data[4][idx])
-        assert abs(e1.mean()) < 0.2 and abs(e1.std() - 1.0) < 0.2 and not np.array_equal(e1, e2)
+        assert not np.array_equal(e1, e2)
+        if e1.size >= 100:   # a sanity check of the noise, meaningless on the single-row edge case
+            assert abs(e1.mean()) < 0.2 and abs(e1.std() - 1.0) < 0.2
         if k:
             assert not np.array_equal(idx, inputs[k - 1][3])
     tr.eval_statistics = None   # statistics of the LAST step of the call
@@ -256,7 +258,7 @@ def test_split_run_phases_with_rccl_on_the_ctx_stream_equal_the_fused_step():
     assert outs["split_graph"] == outs["fused"], outs
 
 
-@pytest.mark.parametrize("o,a,H,B,n_steps", [(11, 3, 256, 256, 7), (17, 6, 128, 37, 5), (11, 3, 256, 100, 4)])
+@pytest.mark.parametrize("o,a,H,B,n_steps", [(11, 3, 256, 256, 7), (17, 6, 128, 37, 5), (11, 3, 256, 100, 4), (11, 3, 256, 1, 3)])
 def test_phase_kernels_are_bitwise_the_eight_launch_path(o, a, H, B, n_steps):
     """ilsx_sac_train_from_replay runs F1 F2 B1 and F3 B2 B3 as ONE launch each (k_sac_phase_a / _c: the stages hand over through
     per-tile counters in the XCD's L2).  Same stage bodies, same summation order: every parameter, target, optimiser moment and log_alpha
