@@ -573,7 +573,10 @@ def main():
                                      "only; message sizes there are 0.55 MB (critics) and 0.28 MB (actor | alpha): latency-bound on "
                                      "xGMI, so NCCL_ALGO / NCCL_PROTO are left to RCCL's tuner unless set in the environment"))
         if world == 1 and not args.no_seeds:
-            result["co_resident_seeds"] = co_resident_seeds()
+            try:
+                result["co_resident_seeds"] = co_resident_seeds()
+            except Exception as e:   # noqa: BLE001 — secondary leg
+                result["co_resident_seeds"] = dict(error=repr(e)[:300])
         if world == 1 and not args.no_aux:
             # BASELINE.json configs 3, 4, 5 (their single-GPU shapes) beside the headline, each with the roofline block of its dominant
             # kernel (live HIP-event timing, kernel named as rocprofv3 lists it); never `value`
@@ -588,7 +591,10 @@ def main():
             actx.close()
             result["extra_keys"] = ["co_resident_seeds", "ppo_8192x128", "gail_walker", "humanoid_4x1024", "roofline_replay", "cpu_baseline"]
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline()
+            try:
+                result["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # noqa: BLE001 — the line must come out; an absent baseline is visible as such
+                result["cpu_baseline"] = dict(error=repr(e)[:300])
     if want_split:
         # the split-run leg comes LAST and under a watchdog: it is the one part of this file that needs a working multi-rank RCCL
         # communicator, and the headline line must come out whatever happens to it (error -> recorded; no progress in 180 s -> rank 0
