@@ -236,7 +236,7 @@ def bench_td3(ctx):
     rb.add_rows(rng.normal(0, 1, (n, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (n, a))).astype(np.float32),
                  rng.normal(0, 1, n).astype(np.float32), (rng.random(n) < 1e-3), rng.normal(0, 1, (n, o)).astype(np.float32))
     mk = lambda i, s: FlattenMlp([H, H], 1, i, ctx=ctx, seed=s)  # noqa: E731
-    td3 = TD3(MlpGaussianNoisePolicy([H, H], o, a, policy_noise=0.2, ctx=ctx, seed=1), mk(o + a, 2), mk(o + a, 3),
+    td3 = TD3(MlpGaussianNoisePolicy([H, H], o, a, policy_noise=0.2, output_activation="tanh", ctx=ctx, seed=1), mk(o + a, 2), mk(o + a, 3),
               policy_lr=3e-4, qf_lr=3e-4, max_batch=B)
     sv = SoftActorCriticV(ReparamTanhMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=4), mk(o + a, 5), mk(o + a, 6), mk(o, 7),
                           alpha=0.2, policy_lr=3e-4, qf_lr=3e-4, vf_lr=3e-4, soft_target_tau=0.005, max_batch=B)

@@ -140,6 +140,7 @@ PROTOTYPES = {
     "ilsx_advirl_train": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_int, C.c_float, C.POINTER(DiscStats), C.POINTER(SacStats), vp]),
     "ilsx_net_set_noise_policy": (C.c_int, [vp, C.c_float, C.c_float, C.c_float]),
+    "ilsx_net_set_output_linear": (C.c_int, [vp, C.c_int]),
     "ilsx_td3_create": (C.c_int, [vp, C.POINTER(Td3Cfg), vp, vp, vp, C.POINTER(vp)]),
     "ilsx_td3_destroy": (C.c_int, [vp]),
     "ilsx_td3_train_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(Td3Stats)]),

@@ -137,6 +137,7 @@ struct ilsx_net {
   // MlpGaussianNoisePolicy (policies.py:130-188): single head, tanh output, clipped Gaussian exploration noise
   bool noise_policy = false;
   float noise = 0.f, noise_clip = 0.f, max_act = 1.f;
+  bool out_linear = false;   // output activation: identity (Mlp's default) instead of tanh (ilsx_net_set_output_linear)
 };
 
 int net_upload_flat(ilsx_ctx* ctx, const NetLayout& L, float* dev_base, const float* src, size_t n, int src_is_device);

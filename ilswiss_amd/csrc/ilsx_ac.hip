@@ -298,6 +298,8 @@ struct ilsx_td3 {
   float *pa = nullptr, *pre = nullptr, *qn = nullptr, *ga = nullptr;                     // actor phase
   float *ppt = nullptr, *ppc = nullptr;   // head partials of pi_tgt(s') / pi(s) (column-split path)
   float* tqc = nullptr;                   // HER: clip(min(TQ1, TQ2), l, r) per row
+  bool out_linear = false;                // the policy's output activation is the identity (ilsx_net_set_output_linear before create)
+  int det_head() const { return out_linear ? HEAD_DET_LIN_NOISE : HEAD_DET_TANH_NOISE; }
 };
 
 extern "C" int ilsx_td3_create(ilsx_ctx* ctx, const ilsx_td3_cfg* cfg, ilsx_net* pi, ilsx_net* q1, ilsx_net* q2, ilsx_td3** out) {
@@ -330,6 +332,7 @@ extern "C" int ilsx_td3_create(ilsx_ctx* ctx, const ilsx_td3_cfg* cfg, ilsx_net*
   if (rc == ILSX_OK) rc = ac_tick(g, 0, 0);
   if (rc != ILSX_OK) { delete t; return rc; }
   pi->noise = cfg->policy_noise; pi->noise_clip = cfg->policy_noise_clip; pi->max_act = cfg->max_act; pi->noise_policy = true;
+  t->out_linear = pi->out_linear;
   *out = t;
   return ILSX_OK;
 }
@@ -378,7 +381,7 @@ static void td3_policy_task(ilsx_td3* t, FwdTask& f, bool target, const float* o
                             float* part) {
   AcAgent* g = &t->g;
   ac_fwd(g, f, T3_PI, target, obs, g->o, nullptr, 0, save);
-  f.head = HEAD_DET_TANH_NOISE; f.rng_stream = g->rng_stream;
+  f.head = t->det_head(); f.rng_stream = g->rng_stream;
   if (g->cs > 1) { f.part = part; return; }
   f.action = action; f.out = pre;
   f.max_act = t->cfg.max_act; f.noise = noisy ? t->cfg.policy_noise : 0.0f; f.noise_clip = t->cfg.policy_noise_clip;
@@ -386,7 +389,7 @@ static void td3_policy_task(ilsx_td3* t, FwdTask& f, bool target, const float* o
 }
 static void td3_policy_fin(ilsx_td3* t, FwdArgs& A, bool noisy, const float* part, float* action, float* pre) {
   AcAgent* g = &t->g;
-  ac_policy_fin(g, A, HEAD_DET_TANH_NOISE, part, (noisy && g->eps_explicit) ? g->eps : nullptr, pre, action, nullptr, nullptr,
+  ac_policy_fin(g, A, t->det_head(), part, (noisy && g->eps_explicit) ? g->eps : nullptr, pre, action, nullptr, nullptr,
                 noisy ? t->cfg.policy_noise : 0.0f, t->cfg.policy_noise_clip, t->cfg.max_act);
 }
 
@@ -468,7 +471,7 @@ static int td3_step(ilsx_td3* t, ilsx_td3_stats* stats) {
       BwdArgs A = ac_bwd_args(g, 1, 0.f, 0.f);
       BwdTask& b = A.t[0];
       ac_bwd(g, b, T3_PI, true);
-      b.loss = LOSS_TD3_POLICY; b.coef = c.max_act; b.raw = t->pre; b.ga1 = t->ga;
+      b.loss = LOSS_TD3_POLICY; b.coef = c.max_act; b.which = t->out_linear ? 1 : 0; b.raw = t->pre; b.ga1 = t->ga;
       ILSX_TRY(ac_launch_bwd(g, A));
     }
     ILSX_TRY(ac_dw_adam(g, T3_PI, 1, false, 0.f));

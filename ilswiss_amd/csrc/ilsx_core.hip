@@ -752,7 +752,7 @@ extern "C" int ilsx_policy_act(ilsx_net* pi, const float* obs, int nrows, int de
   t.head = deterministic ? HEAD_TANH_DET : HEAD_TANH_SAMPLE;
   if (pi->noise_policy) {
     if (logp) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_act: a noise policy has no log-probability");
-    t.head = HEAD_DET_TANH_NOISE;
+    t.head = pi->out_linear ? HEAD_DET_LIN_NOISE : HEAD_DET_TANH_NOISE;
     t.noise = deterministic ? 0.0f : pi->noise; t.noise_clip = pi->noise_clip; t.max_act = pi->max_act;
   }
   t.eps = eps;
@@ -769,6 +769,13 @@ extern "C" int ilsx_net_set_noise_policy(ilsx_net* pi, float policy_noise, float
   if (!pi) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_net_set_noise_policy: NULL network");
   if (pi->lay.cfg.n_heads != 1) ILSX_FAIL(ILSX_ERR_ARG, "a noise policy is a single-head Mlp (policies.py:130-188)");
   pi->noise_policy = true; pi->noise = policy_noise; pi->noise_clip = policy_noise_clip; pi->max_act = max_act;
+  return ILSX_OK;
+}
+
+extern "C" int ilsx_net_set_output_linear(ilsx_net* pi, int linear) {
+  if (!pi) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_net_set_output_linear: NULL network");
+  if (!pi->noise_policy) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_net_set_output_linear: not a noise policy (ilsx_net_set_noise_policy first)");
+  pi->out_linear = linear != 0;
   return ILSX_OK;
 }
 

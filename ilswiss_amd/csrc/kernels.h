@@ -25,7 +25,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { HEAD_RAW = 0, HEAD_TANH_SAMPLE = 1, HEAD_TANH_DET = 2, HEAD_TANH_LOGP_OF_ACT = 3,
        HEAD_GAUSS_SAMPLE = 4, HEAD_GAUSS_LOGP_OF_ACT = 5,    // un-squashed Gaussian, state-independent log_std (PPO)
-       HEAD_DET_TANH_NOISE = 6 };                            // max_act*tanh(out) + clip(noise*eps) (TD3, policies.py:166-188)
+       HEAD_DET_TANH_NOISE = 6,                              // max_act*tanh(out) + clip(noise*eps) (TD3, policies.py:166-188)
+       HEAD_DET_LIN_NOISE = 7 };                             // the same with Mlp's default output activation (identity, networks.py:31)
 enum { LOSS_GIVEN = 0, LOSS_SAC_CRITIC = 1, LOSS_SAC_ACTORQ = 2, LOSS_SAC_POLICY = 3, LOSS_MSE = 4, LOSS_PPO_POLICY = 5,
        LOSS_TD_CRITIC = 6, LOSS_SACV_VALUE = 7, LOSS_CONST = 8, LOSS_TD3_POLICY = 9, LOSS_BC_MLE = 10, LOSS_BC_MSE = 11 };
 enum { ACT_RELU = 0, ACT_TANH = 1 };
@@ -478,11 +479,11 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
     const float* ho = hout + row * ILSX_MAX_NO;
     if (T.out && lane < NO) T.out[(size_t)gr * NO + lane] = ho[lane];
     if (T.head == HEAD_RAW) continue;
-    if (T.head == HEAD_DET_TANH_NOISE) {
+    if (T.head == HEAD_DET_TANH_NOISE || T.head == HEAD_DET_LIN_NOISE) {
       // MlpGaussianNoisePolicy.forward (policies.py:166-188): the result is NOT re-clipped to [-max_act, max_act]
       const int j = lane;
       if (j < NO && T.action) {
-        float act = T.max_act * tanhf(ho[j]);
+        float act = T.max_act * (T.head == HEAD_DET_LIN_NOISE ? ho[j] : tanhf(ho[j]));
         if (T.noise != 0.0f) {
           float e;
           if (T.eps) {
@@ -641,8 +642,8 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
   } else if (T.loss == LOSS_CONST) {
     d = T.coef * A.inv_B;   // td3.py:113-114: -mean(Q1(s, pi(s)))
   } else if (T.loss == LOSS_TD3_POLICY) {
-    // action = max_act*tanh(pre): d pre = dL/da * max_act * (1 - tanh(pre)^2)
-    const float th = tanhf(T.raw[(size_t)gr * NO + j]);
+    // action = max_act*tanh(pre): d pre = dL/da * max_act * (1 - tanh(pre)^2); identity output (T.which = 1): d pre = dL/da * max_act
+    const float th = T.which ? 0.0f : tanhf(T.raw[(size_t)gr * NO + j]);
     float ga = 0.0f;   // dQ1/da, possibly in column-slice partial slabs (<= 4: all requested before any is summed; a loop with a
     float gp[4];       //   run-time trip count waits for its load on every trip)
 #pragma unroll

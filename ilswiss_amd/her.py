@@ -60,9 +60,9 @@ class MlpGaussianAndEpsilonPolicy(MlpGaussianNoisePolicy):
 
     def __init__(self, hidden_sizes, obs_dim, action_dim, action_space=None, condition_dim=0, epsilon=0.3, max_sigma=0.2, min_sigma=0.2,
                  decay_period=1000000, max_act=1.0, min_act=-1.0, observation_key="observation", desired_goal_key="desired_goal", **kwargs):
+        # output_activation travels in kwargs to MlpGaussianNoisePolicy (identity unless given; her_td3_exp_script.py:85 passes tanh)
         if min_act != -max_act:
             raise NotImplementedError("the device target-action clamp is symmetric (her/td3.py:111-114 with the reference's defaults)")
-        kwargs.pop("output_activation", None)
         super().__init__(hidden_sizes, obs_dim + condition_dim, action_dim, policy_noise=max_sigma, policy_noise_clip=0.0, max_act=max_act,
                          **kwargs)
         self.sigma, self._max_sigma, self._min_sigma = max_sigma, max_sigma, (max_sigma if min_sigma is None else min_sigma)

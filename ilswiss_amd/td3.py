@@ -32,18 +32,21 @@ def _batch_ptrs(ctx, batch, keep):
 
 
 class MlpGaussianNoisePolicy(Mlp):
-    """policies.py:130-188: relu Mlp, `max_act * tanh(last_fc)`, plus clip(policy_noise * N(0,1), +-policy_noise_clip)
-    unless deterministic.  The reference passes output_activation=tanh from the run script (td3_exp_script.py:71-78);
-    libilsx implements exactly that output."""
+    """policies.py:130-188: relu Mlp, `max_act * output_activation(last_fc)`, plus clip(policy_noise * N(0,1), +-policy_noise_clip)
+    unless deterministic.  `output_activation` is Mlp's keyword (networks.py:31): identity by default, as in the reference; the run
+    script passes tanh (td3_exp_script.py:71-78).  Accepted: "tanh" / "identity" or a callable of that name (torch.tanh, ptu.identity)."""
 
     def __init__(self, hidden_sizes, obs_dim, action_dim, init_w=1e-3, policy_noise=0.1, policy_noise_clip=0.5, max_act=1.0,
-                 output_activation="tanh", **kwargs):
-        if getattr(output_activation, "__name__", output_activation) != "tanh":
-            raise NotImplementedError("libilsx implements the tanh output of td3_exp_script.py:75")
+                 output_activation="identity", **kwargs):
+        name = getattr(output_activation, "__name__", output_activation)
+        if name not in ("tanh", "identity"):
+            raise NotImplementedError(f"output_activation={name!r}: libilsx implements tanh and identity")
         super().__init__(hidden_sizes, input_size=obs_dim, output_size=action_dim, init_w=init_w, **kwargs)
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
         self.noise, self.noise_clip, self.max_act = float(policy_noise), float(policy_noise_clip), float(max_act)
         _lib.check(self.ctx.lib.ilsx_net_set_noise_policy(self.h, self.noise, self.noise_clip, self.max_act))
+        self.output_activation = name
+        _lib.check(self.ctx.lib.ilsx_net_set_output_linear(self.h, int(name == "identity")))
 
     def get_actions(self, obs_np, deterministic=False):  # policies.py:163-164
         obs = np.ascontiguousarray(obs_np, np.float32)

@@ -140,6 +140,9 @@ int ilsx_policy_log_prob(ilsx_net* pi, const float* obs, const float* act, int n
 /* Marks a single-head Mlp as MlpGaussianNoisePolicy (policies.py:130-188): ilsx_policy_act / ilsx_rollout_step then
  * return max_act*tanh(out) + clip(policy_noise*N(0,1), +-policy_noise_clip) (no noise when deterministic). */
 int ilsx_net_set_noise_policy(ilsx_net* pi, float policy_noise, float policy_noise_clip, float max_act);
+/* Output activation of a noise policy: 0 = tanh (what td3_exp_script.py:75 passes), 1 = identity (Mlp's default, networks.py:31:
+ * action = max_act * last_fc(h) + clipped noise).  Set it before ilsx_td3_create adopts the network. */
+int ilsx_net_set_output_linear(ilsx_net* pi, int linear);
 
 /* ---------------------------------------------------------------- replay buffer
  * Replaces rlkit/data_management/simple_replay_buffer.py:17-442 + env_replay_buffer.py:7-49.

@@ -1,5 +1,5 @@
 """TD3: restatement of rlkit/torch/algorithms/td3/td3.py:21-70 (ctor), :72-124 (train_step), :180-183 (targets)
-with the policy of rlkit/torch/common/policies.py:130-188 (MlpGaussianNoisePolicy: relu MLP, tanh output, clipped
+with the policy of rlkit/torch/common/policies.py:130-188 (MlpGaussianNoisePolicy: relu MLP, tanh or identity output, clipped
 Gaussian noise INSIDE the module; the target policy is `policy.copy()`, so it carries the policy's own
 policy_noise / policy_noise_clip and is called stochastically, td3.py:84-85 — TD3's `target_policy_noise*`
 kwargs are never read).  numpy fp32.  Test infrastructure.
@@ -14,7 +14,10 @@ F32 = np.float32
 class TD3Oracle:
     def __init__(self, obs_dim, act_dim, hidden, pi, q1, q2, reward_scale=1.0, discount=0.99, policy_lr=1e-3, qf_lr=1e-3,
                  policy_and_target_update_period=2, soft_target_tau=0.005, policy_noise=0.2, policy_noise_clip=0.5,
-                 max_act=1.0, her=False, clip_return_l=None, clip_return_r=None):
+                 max_act=1.0, her=False, clip_return_l=None, clip_return_r=None, output_activation="tanh"):
+        # output_activation: "tanh" (what td3_exp_script.py:75 passes) or "identity" (Mlp's default, networks.py:31)
+        assert output_activation in ("tanh", "identity")
+        self.linear_out = output_activation == "identity"
         self.o, self.a, self.hidden = obs_dim, act_dim, list(hidden)
         self.pi, self.q1, self.q2 = pi.copy(), q1.copy(), q2.copy()
         self.tpi, self.tq1, self.tq2 = pi.copy(), q1.copy(), q2.copy()   # td3.py:53-55
@@ -31,7 +34,7 @@ class TD3Oracle:
     def policy(self, flat, s, eps=None):
         """policies.py:166-188.  eps = N(0,1) draws [B,a] or None (deterministic).  Returns (action, head pre-activation, hs)."""
         outs, hs = mlp.forward(flat, s, self.o, self.hidden, self.a)
-        clean = (F32(self.max_act) * np.tanh(outs[0])).astype(F32)
+        clean = (F32(self.max_act) * (outs[0] if self.linear_out else np.tanh(outs[0]))).astype(F32)
         act = clean
         if eps is not None:
             act = (clean + np.clip(F32(self.noise) * eps.astype(F32), -F32(self.noise_clip), F32(self.noise_clip))).astype(F32)
@@ -76,7 +79,7 @@ class TD3Oracle:
             ga = dx[:, self.o:]
             if self.her:
                 ga = (ga + F32(2.0) * pa / F32(pa.size)).astype(F32)
-            dpre = (ga * F32(self.max_act) * (F32(1) - np.tanh(pre) ** 2)).astype(F32)
+            dpre = (ga * F32(self.max_act) * (F32(1) if self.linear_out else (F32(1) - np.tanh(pre) ** 2))).astype(F32)
             gp, _ = mlp.backward(self.pi, hp, [dpre], self.o, self.hidden, self.a, need_dx=False)
             optim.adam_step(self.pi, gp, self.opt_pi, self.policy_lr)
             for t, src in ((self.tpi, self.pi), (self.tq1, self.q1), (self.tq2, self.q2)):

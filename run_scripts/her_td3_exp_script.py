@@ -27,7 +27,7 @@ def experiment(variant, gpu=0, log_dir=None):
         trainer = her.SAC(policy, qf1, qf2, max_batch=alg.get("batch_size", 128), **variant["sac_params"])
     else:
         policy = explore = her.MlpGaussianAndEpsilonPolicy(hidden_sizes=hid, obs_dim=obs_dim, action_dim=action_dim, condition_dim=goal_dim,
-                                                           action_space=env.action_space, ctx=ctx)
+                                                           action_space=env.action_space, output_activation="tanh", ctx=ctx)
         trainer = her.TD3(policy, qf1, qf2, max_batch=alg.get("batch_size", 128), **variant["td3_params"])
     algorithm = her.HER(trainer, env, explore, **alg)
     logger = TabularLogger(log_dir)

@@ -42,7 +42,7 @@ def test_shape_and_state_errors_are_reported(ctx):
     two_head.noise, two_head.noise_clip, two_head.max_act = 0.2, 0.5, 1.0
     with pytest.raises(RuntimeError, match="single-head"):
         TD3(two_head, ia.FlattenMlp([64, 64], 1, 14, ctx=ctx), ia.FlattenMlp([64, 64], 1, 14, ctx=ctx), max_batch=64)
-    tpol = MlpGaussianNoisePolicy([64, 64], 11, 3, ctx=ctx)
+    tpol = MlpGaussianNoisePolicy([64, 64], 11, 3, output_activation="tanh", ctx=ctx)
     with pytest.raises(RuntimeError, match="no log-probability"):
         from ilswiss_amd import _lib
         from ilswiss_amd.device import as_dev

@@ -72,7 +72,7 @@ def test_hip_her_td3_golden(ctx):
     from ilswiss_amd import her
     g = np.load(os.path.join(G, "g20_her_td3.npz"))
     o, gd, a, B, steps, h1, h2 = (int(v) for v in g["dims"])
-    pol = her.MlpGaussianAndEpsilonPolicy([h1, h2], o, a, condition_dim=gd, max_sigma=float(g["sigma"]), min_sigma=float(g["sigma"]), ctx=ctx)
+    pol = her.MlpGaussianAndEpsilonPolicy([h1, h2], o, a, condition_dim=gd, max_sigma=float(g["sigma"]), min_sigma=float(g["sigma"]), output_activation="tanh", ctx=ctx)
     pol.set_flat_params(g["pi0"])
     q1, q2 = _nets(ia, ctx, g, o, gd, a, [h1, h2], False)
     tr = her.TD3(pol, q1, q2, reward_scale=1.0, discount=0.9, policy_lr=3e-4, qf_lr=3e-4, policy_and_target_update_period=2,
@@ -121,7 +121,7 @@ def test_her_loop_learns_to_reach_on_the_stand_in_env():
     ctx = ia.Context(0, seed=11)
     np.random.seed(3)
     env = her.PointReachEnv(seed=1)
-    pol = her.MlpGaussianAndEpsilonPolicy([64, 64], 4, 2, action_space=env.action_space, condition_dim=2, ctx=ctx, seed=5)
+    pol = her.MlpGaussianAndEpsilonPolicy([64, 64], 4, 2, action_space=env.action_space, condition_dim=2, output_activation="tanh", ctx=ctx, seed=5)
     q1, q2 = ia.FlattenMlp([64, 64], 1, 8, ctx=ctx, seed=6), ia.FlattenMlp([64, 64], 1, 8, ctx=ctx, seed=7)
     tr = her.TD3(pol, q1, q2, discount=0.95, policy_lr=1e-3, qf_lr=1e-3, max_batch=128)
     tr.eval_statistics = {}
@@ -174,7 +174,7 @@ def test_her_loop_uses_the_device_buffer_by_default():
     c = ia.Context(0, seed=12)
     try:
         env = her.PointReachEnv(seed=2)
-        pol = her.MlpGaussianAndEpsilonPolicy([64, 64], 4, 2, action_space=env.action_space, condition_dim=2, ctx=c, seed=5)
+        pol = her.MlpGaussianAndEpsilonPolicy([64, 64], 4, 2, action_space=env.action_space, condition_dim=2, output_activation="tanh", ctx=c, seed=5)
         q1, q2 = ia.FlattenMlp([64, 64], 1, 8, ctx=c, seed=6), ia.FlattenMlp([64, 64], 1, 8, ctx=c, seed=7)
         tr = her.TD3(pol, q1, q2, discount=0.95, policy_lr=1e-3, qf_lr=1e-3, max_batch=64)
         alg = her.HER(tr, env, pol, num_epochs=1, num_steps_per_epoch=300, min_steps_before_training=100, max_path_length=25, batch_size=64,

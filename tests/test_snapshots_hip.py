@@ -27,7 +27,7 @@ def test_td3_snapshot_roundtrip(ctx):
     o, a, hid, B = 11, 3, [64, 64], 32
 
     def make(seed):
-        pol = MlpGaussianNoisePolicy(hid, o, a, policy_noise=0.2, policy_noise_clip=0.5, ctx=ctx, seed=seed)
+        pol = MlpGaussianNoisePolicy(hid, o, a, policy_noise=0.2, policy_noise_clip=0.5, output_activation="tanh", ctx=ctx, seed=seed)
         return TD3(pol, FlattenMlp(hid, 1, o + a, ctx=ctx, seed=seed + 1), FlattenMlp(hid, 1, o + a, ctx=ctx, seed=seed + 2),
                    max_batch=B, policy_lr=3e-4, qf_lr=3e-4)
     t1, t2 = make(1), make(50)

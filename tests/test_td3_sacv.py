@@ -23,10 +23,11 @@ def _dims(g):
     return o, a, B, steps, [int(v) for v in g["dims"][4:]]
 
 
-def test_oracle_td3_golden():
-    g = load_golden("g6_td3")
+@pytest.mark.parametrize("tag,out_act", [("g6_td3", "tanh"), ("g6b_td3_identity", "identity")])
+def test_oracle_td3_golden(tag, out_act):
+    g = load_golden(tag)
     o, a, B, steps, hid = _dims(g)
-    orc = TD3Oracle(o, a, hid, g["pi0"], g["q10"], g["q20"], policy_noise=0.2, policy_noise_clip=0.5, **TD3_KW)
+    orc = TD3Oracle(o, a, hid, g["pi0"], g["q10"], g["q20"], policy_noise=0.2, policy_noise_clip=0.5, output_activation=out_act, **TD3_KW)
     for s in range(steps):
         res = orc.train_step(_batch(g, s), g[f"s{s}_eps"])
         for k in ("qf1_loss", "qf2_loss", "policy_loss"):
@@ -53,12 +54,14 @@ def test_oracle_sac_v_golden():
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-def test_hip_td3_golden(ctx):
+@pytest.mark.parametrize("tag,out_act", [("g6_td3", "tanh"), ("g6b_td3_identity", "identity")])
+def test_hip_td3_golden(ctx, tag, out_act):
+    """g6: the run script's tanh output; g6b: Mlp's default output activation (identity, networks.py:31) — both from the reference."""
     from ilswiss_amd.networks import FlattenMlp
     from ilswiss_amd.td3 import TD3, MlpGaussianNoisePolicy
-    g = load_golden("g6_td3")
+    g = load_golden(tag)
     o, a, B, steps, hid = _dims(g)
-    pol = MlpGaussianNoisePolicy(hid, o, a, policy_noise=0.2, policy_noise_clip=0.5, ctx=ctx, seed=1)
+    pol = MlpGaussianNoisePolicy(hid, o, a, policy_noise=0.2, policy_noise_clip=0.5, output_activation=out_act, ctx=ctx, seed=1)
     q1, q2 = FlattenMlp(hid, 1, o + a, ctx=ctx, seed=2), FlattenMlp(hid, 1, o + a, ctx=ctx, seed=3)
     pol.set_flat_params(g["pi0"]); q1.set_flat_params(g["q10"]); q2.set_flat_params(g["q20"])
     tr = TD3(pol, q1, q2, max_batch=B, **TD3_KW)
@@ -75,7 +78,8 @@ def test_hip_td3_golden(ctx):
 
 
 @pytest.mark.gpu
-def test_hip_td3_vs_oracle_h256(ctx):
+@pytest.mark.parametrize("out_act", ["tanh", "identity"])
+def test_hip_td3_vs_oracle_h256(ctx, out_act):
     """BASELINE dims (H=256, B=256), 6 steps with Philox-free explicit noise, no statistics requested in between."""
     from ilswiss_amd.networks import FlattenMlp
     from ilswiss_amd.td3 import TD3, MlpGaussianNoisePolicy
@@ -84,8 +88,8 @@ def test_hip_td3_vs_oracle_h256(ctx):
     o, a, hid, B = 17, 6, [256, 256], 256
     pi0, q10, q20 = omlp.init_mlp(rng, o, hid, a, init_w=1e-3), omlp.init_mlp(rng, o + a, hid, 1), omlp.init_mlp(rng, o + a, hid, 1)
     pi0[-(256 * a + a):] *= 100.0
-    orc = TD3Oracle(o, a, hid, pi0, q10, q20, policy_noise=0.2, policy_noise_clip=0.5, **TD3_KW)
-    pol = MlpGaussianNoisePolicy(hid, o, a, policy_noise=0.2, policy_noise_clip=0.5, ctx=ctx, seed=1)
+    orc = TD3Oracle(o, a, hid, pi0, q10, q20, policy_noise=0.2, policy_noise_clip=0.5, output_activation=out_act, **TD3_KW)
+    pol = MlpGaussianNoisePolicy(hid, o, a, policy_noise=0.2, policy_noise_clip=0.5, output_activation=out_act, ctx=ctx, seed=1)
     q1, q2 = FlattenMlp(hid, 1, o + a, ctx=ctx, seed=2), FlattenMlp(hid, 1, o + a, ctx=ctx, seed=3)
     pol.set_flat_params(pi0); q1.set_flat_params(q10); q2.set_flat_params(q20)
     tr = TD3(pol, q1, q2, max_batch=B, **TD3_KW)

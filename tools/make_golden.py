@@ -654,7 +654,13 @@ def _rand_batch(rng, B, o, a):
 
 def gen_td3():
     """G6: TD3.train_step (td3.py:72-124), 4 chained steps (delayed policy/target update at steps 0 and 2), the
-    target policy's clipped noise injected (policies.py:182-186)."""
+    target policy's clipped noise injected (policies.py:182-186).  G6b: the same with Mlp's default output activation
+    (identity, networks.py:31) instead of the tanh the run script passes."""
+    _td3_case("g6_td3", True)
+    _td3_case("g6b_td3_identity", False)
+
+
+def _td3_case(tag, tanh_out):
     from rlkit.torch.algorithms.td3.td3 import TD3
     from rlkit.torch.common.networks import FlattenMlp
     from rlkit.torch.common.policies import MlpGaussianNoisePolicy
@@ -666,13 +672,13 @@ def gen_td3():
     pi0 = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3)
     pi0[-(Hh[-1] * a + a):] *= 300.0      # head weights up so that tanh bends (init_w=1e-3 keeps it linear)
     q10, q20 = omlp.init_mlp(rng, o + a, Hh, 1), omlp.init_mlp(rng, o + a, Hh, 1)
-    pol = MlpGaussianNoisePolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a, output_activation=torch.tanh,
-                                 policy_noise=0.2, policy_noise_clip=0.5)
+    pol = MlpGaussianNoisePolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a, policy_noise=0.2, policy_noise_clip=0.5,
+                                 **(dict(output_activation=torch.tanh) if tanh_out else {}))
     qf1 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1)
     qf2 = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1)
     set_flat(pol, pi0), set_flat(qf1, q10), set_flat(qf2, q20)
     tr = TD3(policy=pol, qf1=qf1, qf2=qf2, **kw)
-    orc = TD3Oracle(o, a, Hh, pi0, q10, q20, policy_noise=0.2, policy_noise_clip=0.5, **kw)
+    orc = TD3Oracle(o, a, Hh, pi0, q10, q20, policy_noise=0.2, policy_noise_clip=0.5, output_activation="tanh" if tanh_out else "identity", **kw)
     grads = {}
     _hook_grads(grads, tr.qf1_optimizer, "q1", qf1), _hook_grads(grads, tr.qf2_optimizer, "q2", qf2)
     _hook_grads(grads, tr.policy_optimizer, "pi", pol)
@@ -705,7 +711,7 @@ def gen_td3():
         for k, mod in (("pi", pol), ("q1", qf1), ("q2", qf2), ("tpi", tr.target_policy), ("tq1", tr.target_qf1)):
             err = np.abs(getattr(orc, k) - get_flat(mod)).max()
             assert err < 5e-5, (s, k, err)
-    save("g6_td3", **rec)
+    save(tag, **rec)
 
 
 def gen_sac_v():
