@@ -90,7 +90,7 @@ def bench_ppo(ctx):
     o, a, H, n_env, T = 11, 3, 256, 8192, 128
     N = n_env * T
     rng = np.random.default_rng(0)
-    pol = ReparamMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=1)
+    pol = ReparamMultivariateGaussianPolicy([H, H], o, a, conditioned_std=False, hidden_activation="tanh", ctx=ctx, seed=1)
     vf = FlattenMlp([H, H], 1, o, hidden_activation="tanh", ctx=ctx, seed=2)
     out = {}
     obs = ctx.from_numpy(rng.normal(0, 1, (N, o)).astype(np.float32))

@@ -19,10 +19,13 @@ class ReparamMultivariateGaussianPolicy(Mlp):
     """policies.py:348-478 with conditioned_std=False: tanh-hidden mean network whose last layer is scaled by
     0.1 (bias 0) after the usual init (:378-379), and a state-independent `action_log_std` parameter (zeros)."""
 
-    def __init__(self, hidden_sizes, obs_dim, action_dim, conditioned_std=False, init_w=1e-3,
-                 hidden_activation="tanh", **kwargs):
+    def __init__(self, hidden_sizes, obs_dim, action_dim, conditioned_std=True, init_w=1e-3,
+                 hidden_activation="relu", **kwargs):
+        # the defaults are the reference's (policies.py:354, networks.py:30); its PPO scripts pass conditioned_std=False and
+        # hidden_activation=torch.tanh (ppo_exp_script.py:90-96), which is what libilsx implements
         if conditioned_std:
-            raise NotImplementedError("PPO configs use conditioned_std=False (ppo_exp_script.py:90-96)")
+            raise NotImplementedError("conditioned_std=True (the class default, policies.py:354,368-374) is not implemented: pass "
+                                      "conditioned_std=False as the reference's PPO scripts do (ppo_exp_script.py:94)")
         super().__init__(hidden_sizes, input_size=obs_dim, output_size=action_dim, init_w=init_w,
                          hidden_activation=hidden_activation, **kwargs)
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)

@@ -28,7 +28,7 @@ def test_c4_ppo_8192x128_iteration_properties():
     N = n_env * T
     ctx = ia.Context(0, seed=404)
     try:
-        pol = ReparamMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=1)
+        pol = ReparamMultivariateGaussianPolicy([H, H], o, a, conditioned_std=False, hidden_activation="tanh", ctx=ctx, seed=1)
         vf = FlattenMlp([H, H], 1, o, hidden_activation="tanh", ctx=ctx, seed=2)
         kw = dict(mini_batch_size=32768, update_epoch=10, gae_tau=0.95, discount=0.99, reward_scale=1.0)
         tr = PPO(pol, vf, max_samples=N, **kw)

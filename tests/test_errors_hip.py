@@ -49,7 +49,7 @@ def test_shape_and_state_errors_are_reported(ctx):
         k, p = as_dev(ctx, np.zeros((4, 11), np.float32))
         act, lp = ctx.empty((4, 3)), ctx.empty((4,))
         _lib.check(ctx.lib.ilsx_policy_act(tpol.h, p, 4, 0, None, act.ptr, lp.ptr))
-    ppol = ReparamMultivariateGaussianPolicy([64, 64], 11, 3, ctx=ctx)
+    ppol = ReparamMultivariateGaussianPolicy([64, 64], 11, 3, conditioned_std=False, hidden_activation="tanh", ctx=ctx)
     vf = ia.FlattenMlp([64, 64], 1, 11, hidden_activation="tanh", ctx=ctx)
     ppo = PPO(ppol, vf, mini_batch_size=16, update_epoch=1, max_samples=64)
     trajs = [dict(observations=np.zeros((100, 11), np.float32), actions=np.zeros((100, 3), np.float32), rewards=np.zeros((100, 1), np.float32))]

@@ -192,7 +192,7 @@ def test_ppo_learns_on_hip_hopper():
     np.random.seed(0)
     ctx = ia.Context(0, seed=0)
     env = HipVectorEnv("hopper", 512, seed=0, ctx=ctx, norm_obs=True)
-    pol = ReparamMultivariateGaussianPolicy([64, 64], 11, 3, ctx=ctx)
+    pol = ReparamMultivariateGaussianPolicy([64, 64], 11, 3, conditioned_std=False, hidden_activation="tanh", ctx=ctx)
     vf = ia.FlattenMlp([64, 64], 1, 11, hidden_activation="tanh", ctx=ctx)
     tr = PPO(pol, vf, mini_batch_size=2048, update_epoch=10, gae_tau=0.95, max_samples=512 * 128)
     env.rollout_stats(reset=True)

@@ -81,7 +81,7 @@ def _hip_ppo(ctx, g, **over):
     from ilswiss_amd.ppo import PPO, ReparamMultivariateGaussianPolicy
     o, a = int(g["dims"][0]), int(g["dims"][1])
     hid = [int(v) for v in g["dims"][2:]]
-    pol = ReparamMultivariateGaussianPolicy(hid, o, a, ctx=ctx, seed=3)
+    pol = ReparamMultivariateGaussianPolicy(hid, o, a, conditioned_std=False, hidden_activation="tanh", ctx=ctx, seed=3)
     vf = FlattenMlp(hid, 1, o, hidden_activation="tanh", ctx=ctx, seed=4)
     tr = PPO(pol, vf, max_samples=4096, **dict(_kw_of(g), **over))
     tr.set_flat_params(g["pi0"], g["vf0"])
@@ -217,3 +217,20 @@ def test_hip_train_step_large_minibatch_row_split_dw(ctx):
     tr.train_step(trajs, perms)
     np.testing.assert_allclose(tr.get_flat_params(1), orc.vf, rtol=0, atol=5e-5)
     np.testing.assert_allclose(tr.get_flat_params(0), orc.pi, rtol=0, atol=5e-5)
+
+
+def test_policy_ctor_defaults_are_the_references():
+    """policies.py:131-140 (MlpGaussianNoisePolicy), :349-356 (ReparamMultivariateGaussianPolicy) over networks.py:24-32 (Mlp), typed in:
+    a caller that relies on the class defaults gets the reference's network — or an explicit NotImplementedError, never another one."""
+    import inspect
+    from ilswiss_amd.ppo import ReparamMultivariateGaussianPolicy
+    from ilswiss_amd.td3 import MlpGaussianNoisePolicy
+    d = {n: p.default for n, p in inspect.signature(ReparamMultivariateGaussianPolicy.__init__).parameters.items()}
+    assert (d["conditioned_std"], d["init_w"], d["hidden_activation"]) == (True, 1e-3, "relu")
+    with pytest.raises(NotImplementedError, match="conditioned_std"):
+        ReparamMultivariateGaussianPolicy([64, 64], 11, 3, ctx=object())
+    d = {n: p.default for n, p in inspect.signature(MlpGaussianNoisePolicy.__init__).parameters.items()}
+    assert (d["init_w"], d["policy_noise"], d["policy_noise_clip"], d["max_act"], d["output_activation"]) == (1e-3, 0.1, 0.5, 1.0, "identity")
+    with pytest.raises(NotImplementedError, match="output_activation"):
+        MlpGaussianNoisePolicy([64, 64], 11, 3, output_activation="softmax", ctx=object())
+

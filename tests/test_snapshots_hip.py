@@ -77,7 +77,7 @@ def test_ppo_snapshot_roundtrip(ctx):
     o, a, hid = 11, 3, [64, 64]
 
     def make(seed):
-        pol = ReparamMultivariateGaussianPolicy(hid, o, a, ctx=ctx, seed=seed)
+        pol = ReparamMultivariateGaussianPolicy(hid, o, a, conditioned_std=False, hidden_activation="tanh", ctx=ctx, seed=seed)
         vf = FlattenMlp(hid, 1, o, hidden_activation="tanh", ctx=ctx, seed=seed + 1)
         return PPO(pol, vf, max_samples=2048, mini_batch_size=64, update_epoch=2, policy_lr=3e-4, value_lr=3e-4)
     t1, t2 = make(1), make(70)

@@ -38,7 +38,7 @@ tr.train_from_replay(rb, 50, B)
 ctx.sync()
 n_env, T = 8192, 128
 N = n_env * T
-ppol = ReparamMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=4)
+ppol = ReparamMultivariateGaussianPolicy([H, H], o, a, conditioned_std=False, hidden_activation="tanh", ctx=ctx, seed=4)
 vf = FlattenMlp([H, H], 1, o, hidden_activation="tanh", ctx=ctx, seed=5)
 ppo = PPO(ppol, vf, mini_batch_size=32768, update_epoch=1, gae_tau=0.95, max_samples=N)
 obs = ctx.from_numpy(rng.normal(0, 1, (N, o)).astype(np.float32))

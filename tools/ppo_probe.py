@@ -13,7 +13,7 @@ np.random.seed(0)
 ctx = ia.Context(0, seed=0)
 env = HipVectorEnv("hopper", n_env, seed=0, ctx=ctx, norm_obs=True)
 ev = HipVectorEnv("hopper", 16, seed=77, ctx=ctx, norm_obs=True, obs_rms=env.obs_rms, update_obs_rms=False)
-pol = ReparamMultivariateGaussianPolicy([64, 64], 11, 3, ctx=ctx)
+pol = ReparamMultivariateGaussianPolicy([64, 64], 11, 3, conditioned_std=False, hidden_activation="tanh", ctx=ctx)
 vf = ia.FlattenMlp([64, 64], 1, 11, hidden_activation="tanh", ctx=ctx)
 tr = PPO(pol, vf, mini_batch_size=mb, update_epoch=10, gae_tau=0.95, max_samples=n_env * T)
 sampler = VecPathSampler(ev, ia.MakeDeterministic(pol), num_steps=2000, max_path_length=1000)

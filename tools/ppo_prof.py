@@ -10,7 +10,7 @@ ctx = ia.Context(0, seed=0)
 o, a, H, n_env, T = 11, 3, 256, 8192, 128
 N = n_env * T
 rng = np.random.default_rng(0)
-pol = ReparamMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=1)
+pol = ReparamMultivariateGaussianPolicy([H, H], o, a, conditioned_std=False, hidden_activation="tanh", ctx=ctx, seed=1)
 vf = FlattenMlp([H, H], 1, o, hidden_activation="tanh", ctx=ctx, seed=2)
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 tr = PPO(pol, vf, mini_batch_size=mb, update_epoch=1, gae_tau=0.95, max_samples=N)
