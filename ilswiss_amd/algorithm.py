@@ -82,12 +82,14 @@ class TabularLogger:
 class DeviceRLAlgorithm:
     """TorchRLAlgorithm(trainer, env, training_env, eval_env, exploration_policy, **rl_alg_params)."""
 
-    def __init__(self, trainer, env, training_env, eval_env, exploration_policy, num_epochs=100,
-                 num_steps_per_epoch=10000, num_steps_between_train_calls=1000, num_train_steps_per_train_call=1000,
-                 num_steps_per_eval=1000, max_path_length=1000, min_steps_before_training=0, batch_size=256,
-                 replay_buffer_size=1000000, no_terminal=False, eval_deterministic=True, freq_saving=1, save_best=True,
-                 save_replay_buffer=False, replay_buffer=None, log_dir=None, best_key="AverageReturn", bootstrap_open_segments=True,
-                 eval_on_device=True, insert_at_episode_end=False, **kwargs):
+    def __init__(self, trainer, env, training_env, eval_env, exploration_policy, *, batch_size, num_train_steps_per_train_call,
+                 num_epochs=100, num_steps_per_epoch=10000, num_steps_between_train_calls=20, num_steps_per_eval=1000,
+                 max_path_length=1000, min_steps_before_training=5000, replay_buffer_size=10000, no_terminal=False,
+                 eval_deterministic=False, freq_saving=1, save_best=False, save_replay_buffer=False, replay_buffer=None, log_dir=None,
+                 best_key="AverageReturn", bootstrap_open_segments=True, eval_on_device=True, insert_at_episode_end=False, **kwargs):
+        # keyword names and DEFAULTS are BaseAlgorithm's (base_algorithm.py:21-54); batch_size and num_train_steps_per_train_call have
+        # none there either (torch_rl_algorithm.py:8-10).  Every shipped spec states all of them; log_dir / bootstrap_open_segments /
+        # eval_on_device / insert_at_episode_end are ilswiss_amd keys.
         # insert_at_episode_end (an ilswiss_amd key, default off): the fused rollout keeps the reference's replay order — samples enter
         # the ring when their episode ends, contiguous and registered in _traj_endpoints (base_algorithm.py:509-519) — instead of
         # inserting every transition as it happens (DESIGN.md section 6)
