@@ -143,3 +143,16 @@ def test_normalize_exp_demos_statistics():
     assert np.allclose(z.mean(0), 0, atol=1e-12) and np.allclose(z.std(0)[[0, 1, 3]], 1)
     np.testing.assert_allclose(te[0]["next_observations"], (test[0]["next_observations"] - mean) / std)
     assert tr[0]["actions"] is train[0]["actions"]
+
+
+def test_loop_driver_defaults_are_base_algorithms():
+    """base_algorithm.py:21-54 (+ torch_rl_algorithm.py:8-10: batch_size and num_train_steps_per_train_call have no default), typed in."""
+    import inspect
+    from ilswiss_amd.algorithm import DeviceRLAlgorithm
+    P = inspect.signature(DeviceRLAlgorithm.__init__).parameters
+    want = dict(num_epochs=100, num_steps_per_epoch=10000, num_steps_between_train_calls=20, num_steps_per_eval=1000, max_path_length=1000,
+                min_steps_before_training=5000, replay_buffer=None, replay_buffer_size=10000, freq_saving=1, save_replay_buffer=False,
+                save_best=False, best_key="AverageReturn", no_terminal=False, eval_deterministic=False)
+    assert {k: P[k].default for k in want} == want
+    assert P["batch_size"].default is inspect.Parameter.empty and P["num_train_steps_per_train_call"].default is inspect.Parameter.empty
+

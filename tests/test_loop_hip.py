@@ -316,16 +316,3 @@ def test_bc_run_script_with_generated_demos(tmp_path, ctx):
     assert len(rows) == 2 and float(rows[-1]["Number of train steps total"]) == 80
     assert float(rows[-1]["Log-Likelihood"]) > float(rows[0]["Log-Likelihood"])      # the clone's likelihood of the demos rises
     assert np.isfinite(float(rows[-1]["AverageReturn"])) and os.path.exists(tmp_path / "log" / "best.pkl")
-
-
-def test_loop_driver_defaults_are_base_algorithms():
-    """base_algorithm.py:21-54 (+ torch_rl_algorithm.py:8-10: batch_size and num_train_steps_per_train_call have no default), typed in."""
-    import inspect
-    from ilswiss_amd.algorithm import DeviceRLAlgorithm
-    P = inspect.signature(DeviceRLAlgorithm.__init__).parameters
-    want = dict(num_epochs=100, num_steps_per_epoch=10000, num_steps_between_train_calls=20, num_steps_per_eval=1000, max_path_length=1000,
-                min_steps_before_training=5000, replay_buffer=None, replay_buffer_size=10000, freq_saving=1, save_replay_buffer=False,
-                save_best=False, best_key="AverageReturn", no_terminal=False, eval_deterministic=False)
-    assert {k: P[k].default for k in want} == want
-    assert P["batch_size"].default is inspect.Parameter.empty and P["num_train_steps_per_train_call"].default is inspect.Parameter.empty
-
