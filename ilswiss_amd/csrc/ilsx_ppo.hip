@@ -222,7 +222,10 @@ struct ilsx_ppo {
   int *offs = nullptr, *perm = nullptr;
   DwArgs jobs_v, jobs_p;
   unsigned long long shuffles = 0;   // library-drawn minibatch permutations so far (key of the next one)
-  float* log_std() const { return Pp + Lp.n_int; }
+  bool cond() const { return cfg.conditioned_std != 0; }   // log-std from the policy net's second head (policies.py:368-374)
+  int n_ls() const { return cond() ? 0 : a; }             // trailing action_log_std parameters of the policy arena
+  int no() const { return cond() ? 2 * a : a; }           // head outputs of the policy net
+  float* log_std() const { return cond() ? nullptr : Pp + Lp.n_int; }   // null = "read it from the head" for the kernels
   float* g_log_std() const { return Gp + Lp.n_int; }
 };
 
@@ -239,12 +242,12 @@ extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo*
   HIPCHK(hipSetDevice(ctx->device));
   ilsx_ppo* p = new ilsx_ppo();
   p->ctx = ctx; p->cfg = *cfg; p->o = cfg->obs_dim; p->a = cfg->act_dim;
-  ilsx_mlp_cfg mp = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, cfg->act_dim, 1, ILSX_ACT_TANH};
+  ilsx_mlp_cfg mp = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, cfg->act_dim, cfg->conditioned_std ? 2 : 1, ILSX_ACT_TANH};
   ilsx_mlp_cfg mv = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, 1, 1, ILSX_ACT_TANH};
   int rc = net_layout_build(mp, &p->Lp);
   if (rc == ILSX_OK) rc = net_layout_build(mv, &p->Lv);
   if (rc != ILSX_OK) { delete p; return rc; }
-  p->np = p->Lp.n_int + ((cfg->act_dim + 3) / 4) * 4;
+  p->np = p->Lp.n_int + ((p->n_ls() + 3) / 4) * 4;
   p->nv = p->Lv.n_int;
   const size_t N = (size_t)cfg->max_samples, mb = (size_t)cfg->mini_batch_size, H = (size_t)cfg->hidden;
   auto A = [&](float** q, size_t cnt) { return ctx_alloc(ctx, cnt * sizeof(float), (void**)q, true); };
@@ -271,8 +274,8 @@ extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo*
   }
   if (rc == ILSX_OK) rc = A(&p->dhv, mb);
   if (rc == ILSX_OK) rc = A(&p->vpred, mb);
-  if (rc == ILSX_OK) rc = A(&p->dhp, mb * p->a);
-  if (rc == ILSX_OK) rc = A(&p->mu, mb * p->a);
+  if (rc == ILSX_OK) rc = A(&p->dhp, mb * p->no());
+  if (rc == ILSX_OK) rc = A(&p->mu, mb * p->no());
   if (rc == ILSX_OK) rc = A(&p->lp, mb);
   if (rc == ILSX_OK) rc = A(&p->aux, mb * p->a);
   if (rc == ILSX_OK) rc = A(&p->partial, 64 + 64 * PPO_MAX_A);
@@ -300,16 +303,16 @@ extern "C" int ilsx_ppo_destroy(ilsx_ppo* p) {
 // which: 0 = policy (flat: mean-net parameters | action_log_std[a]), 1 = value net
 extern "C" int ilsx_ppo_num_params(const ilsx_ppo* p, int which, size_t* out) {
   if (!p || !out || which < 0 || which > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_num_params: bad argument");
-  *out = which == 0 ? p->Lp.n_flat + p->a : p->Lv.n_flat;
+  *out = which == 0 ? p->Lp.n_flat + p->n_ls() : p->Lv.n_flat;
   return ILSX_OK;
 }
 extern "C" int ilsx_ppo_set_params(ilsx_ppo* p, int which, const float* src, size_t n) {
   if (!p || !src || which < 0 || which > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_set_params: bad argument");
   HIPCHK(hipSetDevice(p->ctx->device));
   if (which == 1) return net_upload_flat(p->ctx, p->Lv, p->Pv, src, n, 0);
-  if (n != p->Lp.n_flat + p->a) ILSX_FAIL(ILSX_ERR_ARG, "policy parameter count %zu != %zu", n, p->Lp.n_flat + p->a);
+  if (n != p->Lp.n_flat + p->n_ls()) ILSX_FAIL(ILSX_ERR_ARG, "policy parameter count %zu != %zu", n, p->Lp.n_flat + p->n_ls());
   ILSX_TRY(net_upload_flat(p->ctx, p->Lp, p->Pp, src, p->Lp.n_flat, 0));
-  HIPCHK(hipMemcpyAsync(p->log_std(), src + p->Lp.n_flat, p->a * sizeof(float), hipMemcpyHostToDevice, p->ctx->stream));
+  if (p->n_ls()) HIPCHK(hipMemcpyAsync(p->log_std(), src + p->Lp.n_flat, p->a * sizeof(float), hipMemcpyHostToDevice, p->ctx->stream));
   HIPCHK(hipStreamSynchronize(p->ctx->stream));
   return ILSX_OK;
 }
@@ -317,9 +320,9 @@ extern "C" int ilsx_ppo_get_params(ilsx_ppo* p, int which, float* dst, size_t n)
   if (!p || !dst || which < 0 || which > 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_get_params: bad argument");
   HIPCHK(hipSetDevice(p->ctx->device));
   if (which == 1) return net_download_flat(p->ctx, p->Lv, p->Pv, dst, n, 0);
-  if (n != p->Lp.n_flat + p->a) ILSX_FAIL(ILSX_ERR_ARG, "policy parameter count %zu != %zu", n, p->Lp.n_flat + p->a);
+  if (n != p->Lp.n_flat + p->n_ls()) ILSX_FAIL(ILSX_ERR_ARG, "policy parameter count %zu != %zu", n, p->Lp.n_flat + p->n_ls());
   ILSX_TRY(net_download_flat(p->ctx, p->Lp, p->Pp, dst, p->Lp.n_flat, 0));
-  HIPCHK(hipMemcpyAsync(dst + p->Lp.n_flat, p->log_std(), p->a * sizeof(float), hipMemcpyDeviceToHost, p->ctx->stream));
+  if (p->n_ls()) HIPCHK(hipMemcpyAsync(dst + p->Lp.n_flat, p->log_std(), p->a * sizeof(float), hipMemcpyDeviceToHost, p->ctx->stream));
   HIPCHK(hipStreamSynchronize(p->ctx->stream));
   return ILSX_OK;
 }
@@ -332,12 +335,12 @@ static int ppo_opt(ilsx_ppo* p, int which, bool set, float* m_host, float* v_hos
   const NetLayout& L = which == 0 ? p->Lp : p->Lv;
   float* arenas[2] = {which == 0 ? p->Mp : p->Mv, which == 0 ? p->Vp : p->Vv};
   float* hosts[2] = {m_host, v_host};
-  const size_t want = L.n_flat + (which == 0 ? (size_t)p->a : 0);
+  const size_t want = L.n_flat + (which == 0 ? (size_t)p->n_ls() : 0);
   if (n != want) ILSX_FAIL(ILSX_ERR_ARG, "optimiser state count %zu != %zu", n, want);
   for (int k = 0; k < 2; ++k) {
     if (set) ILSX_TRY(net_upload_flat(p->ctx, L, arenas[k], hosts[k], L.n_flat, 0));
     else ILSX_TRY(net_download_flat(p->ctx, L, arenas[k], hosts[k], L.n_flat, 0));
-    if (which == 0) {   // the state-independent log-std parameter sits behind the mean net in the policy arena
+    if (which == 0 && p->n_ls()) {   // the state-independent log-std parameter sits behind the mean net in the policy arena
       if (set) HIPCHK(hipMemcpyAsync(arenas[k] + L.n_int, hosts[k] + L.n_flat, p->a * sizeof(float), hipMemcpyHostToDevice, st));
       else HIPCHK(hipMemcpyAsync(hosts[k] + L.n_flat, arenas[k] + L.n_int, p->a * sizeof(float), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -467,7 +470,7 @@ static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const 
     for (int l = 0; l < nh; ++l) { b.hsave[l] = p->hp[l]; b.dsave[l] = p->dp[l]; }
     b.dhead = p->dhp; b.loss = LOSS_PPO_POLICY; b.rows_idx = idx;
     b.pred = p->lp; b.target = p->adv; b.lp_old = p->lp_old; b.act_all = act; b.log_std = p->log_std(); b.mu = p->mu;
-    b.aux = p->aux; b.clip_eps = p->cfg.clip_eps;
+    b.aux = p->cond() ? nullptr : p->aux; b.clip_eps = p->cfg.clip_eps;
     ILSX_TRY(launch_bwd_dx(ctx, Bw, H, ILSX_ACT_TANH));
     ILSX_TRY(launch_bwd_dw(ctx, p->jobs_p, rows, nullptr));
     PpoNormArgs Nn;
@@ -476,12 +479,12 @@ static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const 
       Nn.skip0[l - 1] = l < nh ? p->Lp.off_Wb[l] : 0;
       Nn.skip1[l - 1] = l < nh ? p->Lp.off_Wb[l] + H * H : 0;
     }
-    Nn.aux = p->aux; Nn.rows = rows; Nn.a = p->a; Nn.partial = p->partial; Nn.partial_ls = p->partial + 64;
+    Nn.aux = p->aux; Nn.rows = p->cond() ? 0 : rows; Nn.a = p->n_ls(); Nn.partial = p->partial; Nn.partial_ls = p->partial + 64;
     const int nblk = 32;
     hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
     PpoClipAdamArgs C;
     C.P = p->Pp; C.G = p->Gp; C.M = p->Mp; C.V = p->Vp; C.n = (int)p->np;
-    C.partial = p->partial; C.partial_ls = p->partial + 64; C.nparts = nblk; C.n_mean = (int)p->Lp.n_int; C.a = p->a; C.max_norm = 20.0f; C.b1 = 0.9f; C.b2 = 0.999f; C.eps = 1e-8f; C.sc = p->sc;
+    C.partial = p->partial; C.partial_ls = p->partial + 64; C.nparts = nblk; C.n_mean = (int)p->Lp.n_int; C.a = p->n_ls(); C.max_norm = 20.0f; C.b1 = 0.9f; C.b2 = 0.999f; C.eps = 1e-8f; C.sc = p->sc;
     hipLaunchKernelGGL(k_ppo_clip_adam, dim3(64), dim3(256), 0, ctx->stream, C);
     HIPCHK(hipGetLastError());
     ILSX_TRY(ppo_refresh(p, 1));
@@ -539,7 +542,7 @@ extern "C" int ilsx_ppo_policy_act(ilsx_ppo* p, const float* obs, int n, int det
   A.rows = n; A.ntasks = 1; A.seed = p->ctx->seed; A.step_host = ++calls;
   FwdTask& t = A.t[0];
   ppo_fwd_task(t, p->Lp, p->Pp, obs, p->o);
-  if (deterministic) { t.head = HEAD_RAW; t.out = act; }   // action = mean (policies.py:407-408)
+  if (deterministic) { t.head = HEAD_RAW; t.out = act; t.out_cols = p->a; }   // action = mean (policies.py:407-408): the first a head outputs
   else { t.head = HEAD_GAUSS_SAMPLE; t.eps = eps; t.action = act; t.logp = logp; t.log_std = p->log_std(); t.rng_stream = 0x50504f00u; }
   return launch_fwd(p->ctx, A, p->cfg.hidden, ILSX_ACT_TANH, p->Lp.KP);
 }

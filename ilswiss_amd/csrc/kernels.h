@@ -281,6 +281,7 @@ struct FwdTask {
   float noise, noise_clip, max_act;  // HEAD_DET_TANH_NOISE (noise == 0: deterministic)
   int no_fin;                        // this task's action segment is NOT the launch's finished policy (FwdArgs::fin)
   int agent, first;                  // grouped launches (FwdArgs::tasks): owning agent, 1 = the agent's publishing task
+  int out_cols;                      // generic kernel: `out` takes only the first out_cols head outputs, row stride out_cols (0 = all NO)
 };
 // In-kernel exchange (the merged phase kernels, k_sac_phase_a / _c below): data one workgroup of a launch writes and ANOTHER workgroup
 // of the SAME launch reads.  All workgroups that exchange sit on ONE XCD (same row tile), so the data travels through that XCD's L2:
@@ -477,7 +478,8 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
     const int row = wave * RPW + rr, gr = r0 + row;
     if (gr >= rows) continue;  // wave-uniform
     const float* ho = hout + row * ILSX_MAX_NO;
-    if (T.out && lane < NO) T.out[(size_t)gr * NO + lane] = ho[lane];
+    const int oc = T.out_cols > 0 ? T.out_cols : NO;
+    if (T.out && lane < oc) T.out[(size_t)gr * oc + lane] = ho[lane];
     if (T.head == HEAD_RAW) continue;
     if (T.head == HEAD_DET_TANH_NOISE || T.head == HEAD_DET_LIN_NOISE) {
       // MlpGaussianNoisePolicy.forward (policies.py:166-188): the result is NOT re-clipped to [-max_act, max_act]
@@ -501,11 +503,14 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
       continue;
     }
     if (T.head >= HEAD_GAUSS_SAMPLE) {
-      // ReparamMultivariateGaussianPolicy, conditioned_std=False (policies.py:398-417,462-478 + distributions.py:43-50)
-      const int a = NO, j = lane;
+      // ReparamMultivariateGaussianPolicy (policies.py:398-417,462-478 + distributions.py:43-50): log_std is the state-independent
+      // parameter (conditioned_std=False, T.log_std) or, with T.log_std null, the net's second head clamped to [LOG_SIG_MIN, LOG_SIG_MAX]
+      // (conditioned_std=True, :401-405: NO = 2a outputs, mean | log_std)
+      const bool cond = T.log_std == nullptr;
+      const int a = cond ? NO >> 1 : NO, j = lane;
       float q = 0.f, l = 0.f;
       if (j < a) {
-        const float mu = ho[j], ls = T.log_std[j];
+        const float mu = ho[j], ls = cond ? fminf(fmaxf(ho[a + j], LOG_SIG_MIN), LOG_SIG_MAX) : T.log_std[j];
         float act;
         if (T.head == HEAD_GAUSS_LOGP_OF_ACT) {
           const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;
@@ -692,10 +697,19 @@ __device__ __forceinline__ float bwd_head_grad(const BwdTask& T, const BwdArgs& 
     const float inside = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;          // clamp passes gradient on [lo,hi]
     const float w = s1 < s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f);                 // torch.min tie rule
     const float dlp = -(w * adv + (1.0f - w) * adv * inside) * A.inv_B * ratio;
-    const float ls = T.log_std[j], var = expf(2.0f * ls);
-    const float diff = T.act_all[sr * NO + j] - T.mu[(size_t)gr * NO + j];
-    d = dlp * diff / var;
-    if (T.aux) T.aux[(size_t)gr * NO + j] = dlp * (diff * diff / var - 1.0f);
+    if (T.log_std) {   // conditioned_std=False: j indexes the mean; the log-std parameter's gradient is the column sum of aux
+      const float ls = T.log_std[j], var = expf(2.0f * ls);
+      const float diff = T.act_all[sr * NO + j] - T.mu[(size_t)gr * NO + j];
+      d = dlp * diff / var;
+      if (T.aux) T.aux[(size_t)gr * NO + j] = dlp * (diff * diff / var - 1.0f);
+    } else {           // conditioned_std=True (policies.py:401-405): T.mu holds mean | raw log-std [rows][2a]; j < a -> d mean_j, else d raw log-std
+      const int a = NO >> 1, jj = j < a ? j : j - a;
+      const float lsr = T.mu[(size_t)gr * NO + a + jj];
+      const float ls = fminf(fmaxf(lsr, LOG_SIG_MIN), LOG_SIG_MAX), var = expf(2.0f * ls);
+      const float diff = T.act_all[sr * a + jj] - T.mu[(size_t)gr * NO + jj];
+      if (j < a) d = dlp * diff / var;
+      else d = (lsr >= LOG_SIG_MIN && lsr <= LOG_SIG_MAX) ? dlp * (diff * diff / var - 1.0f) : 0.0f;   // the clamp's gate
+    }
   } else {  // LOSS_SAC_POLICY: SURVEY Appendix A.1/A.2 ; j < a -> d mu_j, else d log_std_raw_{j-a}
     const int a = NO >> 1, jj = j < a ? j : j - a;
     const float alpha = scal->alpha;

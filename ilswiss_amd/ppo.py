@@ -1,5 +1,5 @@
 """PPO over libilsx: the reference's `PPO` trainer (rlkit/torch/algorithms/ppo/ppo.py:11-190) and its Gaussian
-policy `ReparamMultivariateGaussianPolicy(conditioned_std=False)` (rlkit/torch/common/policies.py:348-478).
+policy `ReparamMultivariateGaussianPolicy` (rlkit/torch/common/policies.py:348-478, both `conditioned_std` settings).
 Constructor kwargs are the YAML `ppo_params` keys (exp_specs/ppo/ppo_hopper.yaml:41-50); unknown keys are
 swallowed like the reference's **kwargs.  GAE, the fixed log-probs and every minibatch update run on the device
 (csrc/ilsx_ppo.hip); this module only moves trajectories to HBM and builds the trajectory offset table.
@@ -16,29 +16,32 @@ from .sac import Trainer
 
 
 class ReparamMultivariateGaussianPolicy(Mlp):
-    """policies.py:348-478 with conditioned_std=False: tanh-hidden mean network whose last layer is scaled by
-    0.1 (bias 0) after the usual init (:378-379), and a state-independent `action_log_std` parameter (zeros)."""
+    """policies.py:348-478: mean network whose last layer is scaled by 0.1 (bias 0) after the usual init (:378-379), and either a
+    state-independent `action_log_std` parameter (zeros; conditioned_std=False, what the reference's PPO scripts pass) or a second
+    head `last_fc_log_std` clamped to [LOG_SIG_MIN, LOG_SIG_MAX] (conditioned_std=True, the class default, :368-374,401-405)."""
 
     def __init__(self, hidden_sizes, obs_dim, action_dim, conditioned_std=True, init_w=1e-3,
                  hidden_activation="relu", **kwargs):
         # the defaults are the reference's (policies.py:354, networks.py:30); its PPO scripts pass conditioned_std=False and
-        # hidden_activation=torch.tanh (ppo_exp_script.py:90-96), which is what libilsx implements
-        if conditioned_std:
-            raise NotImplementedError("conditioned_std=True (the class default, policies.py:354,368-374) is not implemented: pass "
-                                      "conditioned_std=False as the reference's PPO scripts do (ppo_exp_script.py:94)")
+        # hidden_activation=torch.tanh (ppo_exp_script.py:90-96)
+        self.conditioned_std = bool(conditioned_std)
+        if self.conditioned_std:
+            self.n_heads = 2   # fc.. | last_fc | last_fc_log_std: torch's parameters() order of the reference module
         super().__init__(hidden_sizes, input_size=obs_dim, output_size=action_dim, init_w=init_w,
                          hidden_activation=hidden_activation, **kwargs)
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
         flat = self.get_flat_params()
-        nl = self.hidden_sizes[-1] * self.action_dim
-        flat[-(nl + self.action_dim):-self.action_dim] *= np.float32(0.1)
-        flat[-self.action_dim:] = 0.0
+        nl, a = self.hidden_sizes[-1] * self.action_dim, self.action_dim
+        tail = (nl + a) if self.conditioned_std else 0   # the log-std head sits behind last_fc and keeps its U(+-init_w) init
+        flat[flat.size - tail - (nl + a):flat.size - tail - a] *= np.float32(0.1)
+        flat[flat.size - tail - a:flat.size - tail] = 0.0
         self.set_flat_params(flat)
-        self.action_log_std = np.zeros(self.action_dim, np.float32)
+        self.action_log_std = None if self.conditioned_std else np.zeros(self.action_dim, np.float32)
         self._ppo = None   # set by PPO: from then on the trainer's device copy is the live one
 
-    def ppo_flat(self):  # mean net | action_log_std
-        return np.concatenate([self.get_flat_params(), self.action_log_std])
+    def ppo_flat(self):  # mean net | action_log_std   (conditioned_std: the two-head net alone)
+        flat = self.get_flat_params()
+        return flat if self.conditioned_std else np.concatenate([flat, self.action_log_std])
 
     def get_actions(self, obs_np, deterministic=False):  # policies.py:392-395
         if self._ppo is None:
@@ -63,7 +66,7 @@ class PPO(Trainer):
         self.o, self.a = policy.obs_dim, policy.action_dim
         cfg = _lib.PpoCfg(self.o, self.a, len(policy.hidden_sizes), policy.hidden_sizes[0], reward_scale, discount,
                           clip_eps, policy_lr, value_lr, gae_tau, value_l2_reg, self.mini_batch_size,
-                          self.update_epoch, self.max_samples, int(bool(use_value_clip)))
+                          self.update_epoch, self.max_samples, int(bool(use_value_clip)), int(bool(getattr(policy, "conditioned_std", False))))
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_ppo_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
         self.set_flat_params(policy.ppo_flat(), vf.get_flat_params())

@@ -414,7 +414,7 @@ int ilsx_bc_train_from_replay(ilsx_bc* bc, ilsx_replay* expert_rb, int n_updates
 /* ---------------------------------------------------------------- PPO
  * Replaces rlkit/torch/algorithms/ppo/ppo.py:57-100 (calc_adv: per-trajectory GAE, zero bootstrap, per-trajectory
  * advantage standardisation) and :102-170 (train_step: update_epoch x shuffled minibatches of value MSE + L2 and
- * the clipped surrogate, grad-norm clip 20), with ReparamMultivariateGaussianPolicy(conditioned_std=False)
+ * the clipped surrogate, grad-norm clip 20), with ReparamMultivariateGaussianPolicy (both conditioned_std settings)
  * (rlkit/torch/common/policies.py:348-478) and the tanh value net of run_scripts/ppo_exp_script.py:82-96.
  * cfg fields == the YAML keys of exp_specs/ppo/ppo_hopper.yaml:41-50 (+ net_size / num_hidden_layers :13-14). */
 typedef struct {
@@ -423,6 +423,8 @@ typedef struct {
   int32_t mini_batch_size, update_epoch;
   int32_t max_samples;            /* upper bound on the on-policy samples of one train call */
   int32_t use_value_clip;         /* ppo.py:24,137-143: value loss = mean(max((v-R)^2, (v_old + clamp(v-v_old, +-clip_eps) - R)^2)) */
+  int32_t conditioned_std;        /* policies.py:354,368-374,401-405: log_std = clamp(last_fc_log_std(h), -20, 2), a second head of the policy net
+                                   * (flat: fc.. | last_fc | last_fc_log_std) instead of the action_log_std parameter behind the mean net */
 } ilsx_ppo_cfg;
 int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo** out);
 int ilsx_ppo_destroy(ilsx_ppo* ppo);

@@ -12,7 +12,7 @@ Flat policy layout here (and in libilsx): fc0.W|fc0.b|fc1.W|fc1.b|last_fc.W|last
 import numpy as np
 
 from . import mlp, optim
-from .tanh_gaussian import gaussian_log_prob
+from .tanh_gaussian import LOG_SIG_MAX, LOG_SIG_MIN, gaussian_log_prob
 
 F32 = np.float32
 
@@ -37,7 +37,10 @@ def gae_one_traj(values, rewards, discount, tau, bootstrap=0.0):
 class PPOOracle:
     def __init__(self, obs_dim, act_dim, hidden, pi_flat, vf_flat, reward_scale=1.0, discount=0.99, clip_eps=0.2,
                  policy_lr=3e-4, value_lr=3e-4, gae_tau=0.9, value_l2_reg=1e-3, mini_batch_size=64, update_epoch=10,
-                 use_value_clip=False):
+                 use_value_clip=False, conditioned_std=False):
+        # conditioned_std (policies.py:368-374,401-405): log_std = clamp(last_fc_log_std(h), LOG_SIG_MIN, LOG_SIG_MAX), a second head of the
+        # policy net (flat layout fc.. | last_fc | last_fc_log_std: torch's parameters() order) instead of the action_log_std parameter
+        self.cond = bool(conditioned_std)
         self.o, self.a, self.hidden = obs_dim, act_dim, list(hidden)
         self.pi, self.vf = pi_flat.copy(), vf_flat.copy()
         self.reward_scale, self.discount, self.clip_eps = reward_scale, discount, clip_eps
@@ -52,13 +55,20 @@ class PPOOracle:
         return outs[0], hs
 
     def pi_mean(self, obs):
+        if self.cond:
+            outs, hs = mlp.forward(self.pi, obs, self.o, self.hidden, self.a, n_heads=2, act=mlp.TANH)
+            self._lsr = outs[1]
+            return outs[0], hs
         n = self.pi.size - self.a
         outs, hs = mlp.forward(self.pi[:n], obs, self.o, self.hidden, self.a, act=mlp.TANH)
         return outs[0], hs
 
     def log_prob(self, obs, act):
         mu, hs = self.pi_mean(obs)
-        ls = np.broadcast_to(self.pi[-self.a:], mu.shape).astype(F32)
+        if self.cond:
+            ls = np.clip(self._lsr, F32(LOG_SIG_MIN), F32(LOG_SIG_MAX)).astype(F32)
+        else:
+            ls = np.broadcast_to(self.pi[-self.a:], mu.shape).astype(F32)
         return gaussian_log_prob(mu, ls, act), mu, ls, hs
 
     # ---- ppo.py:57-100
@@ -106,10 +116,15 @@ class PPOOracle:
         dlp = dratio * ratio
         var = np.exp(F32(2) * ls)
         dmu = dlp * (ac - mu) / var
-        dls = np.sum(dlp * ((ac - mu) ** 2 / var - F32(1)), axis=0)
-        n = self.pi.size - self.a
-        gm, _ = mlp.backward(self.pi[:n], hs, [dmu.astype(F32)], self.o, self.hidden, self.a, act=mlp.TANH, need_dx=False)
-        g = np.concatenate([gm, dls.astype(F32)])
+        if self.cond:   # per-row gradient into the log-std head, through the clamp's gate
+            gate = ((self._lsr >= F32(LOG_SIG_MIN)) & (self._lsr <= F32(LOG_SIG_MAX))).astype(F32)
+            dlsr = (dlp * ((ac - mu) ** 2 / var - F32(1)) * gate).astype(F32)
+            g, _ = mlp.backward(self.pi, hs, [dmu.astype(F32), dlsr], self.o, self.hidden, self.a, n_heads=2, act=mlp.TANH, need_dx=False)
+        else:
+            dls = np.sum(dlp * ((ac - mu) ** 2 / var - F32(1)), axis=0)
+            n = self.pi.size - self.a
+            gm, _ = mlp.backward(self.pi[:n], hs, [dmu.astype(F32)], self.o, self.hidden, self.a, act=mlp.TANH, need_dx=False)
+            g = np.concatenate([gm, dls.astype(F32)])
         norm = np.sqrt(np.sum(g.astype(np.float64) ** 2))
         coef = 20.0 / (norm + 1e-6)                                                                 # clip_grad_norm_(…, 20)
         gc = (g * F32(coef)).astype(F32) if coef < 1.0 else g

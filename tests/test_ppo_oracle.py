@@ -57,7 +57,7 @@ def _kw_of(g):
 
 
 # g7b: clip_grad_norm_(20) active; g7c: use_value_clip=True (ppo.py:137-143), clip_eps 0.1, value_lr 3e-3 (rows cross the clip window)
-@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip", "g7c_ppo_vclip"])
+@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip", "g7c_ppo_vclip", "g7d_ppo_condstd"])
 def test_train_step(name):
     g = load_golden(name)
     o, a = int(g["dims"][0]), int(g["dims"][1])
@@ -81,9 +81,10 @@ def _hip_ppo(ctx, g, **over):
     from ilswiss_amd.ppo import PPO, ReparamMultivariateGaussianPolicy
     o, a = int(g["dims"][0]), int(g["dims"][1])
     hid = [int(v) for v in g["dims"][2:]]
-    pol = ReparamMultivariateGaussianPolicy(hid, o, a, conditioned_std=False, hidden_activation="tanh", ctx=ctx, seed=3)
+    kw = dict(_kw_of(g), **over)
+    pol = ReparamMultivariateGaussianPolicy(hid, o, a, conditioned_std=bool(kw.pop("conditioned_std", False)), hidden_activation="tanh", ctx=ctx, seed=3)
     vf = FlattenMlp(hid, 1, o, hidden_activation="tanh", ctx=ctx, seed=4)
-    tr = PPO(pol, vf, max_samples=4096, **dict(_kw_of(g), **over))
+    tr = PPO(pol, vf, max_samples=4096, **kw)
     tr.set_flat_params(g["pi0"], g["vf0"])
     return tr
 
@@ -102,7 +103,7 @@ def test_hip_gae_and_fixed_log_probs_golden(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip", "g7c_ppo_vclip"])
+@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip", "g7c_ppo_vclip", "g7d_ppo_condstd"])
 def test_hip_train_step_golden(ctx, name):
     g = load_golden(name)
     tr = _hip_ppo(ctx, g)
@@ -111,6 +112,15 @@ def test_hip_train_step_golden(ctx, name):
     np.testing.assert_allclose(tr.get_flat_params(1), g["vf_final"], rtol=0, atol=2e-4 if name == "g7c_ppo_vclip" else 5e-5)
     np.testing.assert_allclose(tr.get_flat_params(0), g["pi_final"], rtol=0, atol=5e-5)
     assert np.abs(tr.get_flat_params(0) - g["pi0"]).max() > 1e-4
+    if name == "g7d_ppo_condstd":   # conditioned_std=True: the fixed log-probs come from the clamped second head; deterministic action = the mean
+        tr2 = _hip_ppo(ctx, g)
+        _, _, _, lp = tr2.calc_adv(_trajs(g))
+        np.testing.assert_allclose(lp, g["fixed_log_probs"], rtol=1e-5, atol=1e-5)
+        obs = _trajs(g)[2]["observations"]
+        from oracle.ppo import PPOOracle
+        orc = PPOOracle(int(g["dims"][0]), int(g["dims"][1]), [int(v) for v in g["dims"][2:]], g["pi0"], g["vf0"], **_kw_of(g))
+        np.testing.assert_allclose(tr2.policy_act(obs, True)[0], orc.pi_mean(obs)[0], rtol=1e-5, atol=1e-6)
+        assert int(g["n_outside_clamp"]) > 0
 
 
 @pytest.mark.gpu
@@ -227,8 +237,6 @@ def test_policy_ctor_defaults_are_the_references():
     from ilswiss_amd.td3 import MlpGaussianNoisePolicy
     d = {n: p.default for n, p in inspect.signature(ReparamMultivariateGaussianPolicy.__init__).parameters.items()}
     assert (d["conditioned_std"], d["init_w"], d["hidden_activation"]) == (True, 1e-3, "relu")
-    with pytest.raises(NotImplementedError, match="conditioned_std"):
-        ReparamMultivariateGaussianPolicy([64, 64], 11, 3, ctx=object())
     d = {n: p.default for n, p in inspect.signature(MlpGaussianNoisePolicy.__init__).parameters.items()}
     assert (d["init_w"], d["policy_noise"], d["policy_noise_clip"], d["max_act"], d["output_activation"]) == (1e-3, 0.1, 0.5, 1.0, "identity")
     with pytest.raises(NotImplementedError, match="output_activation"):

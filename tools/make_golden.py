@@ -565,6 +565,9 @@ def gen_ppo():
     # g7c: use_value_clip=True (ppo.py:137-143) with a small clip_eps and a larger value lr so that, over three epochs, v moves past
     # v_old +- clip_eps on part of the rows: both branches of the max and both sides of the clamp carry gradient
     _gen_ppo_case("g7c_ppo_vclip", 709, -0.3, 3, use_value_clip=True, clip_eps=0.1, value_lr=3e-3)
+    # g7d: the policy class's DEFAULT head, conditioned_std=True (policies.py:368-374): log_std from a second head, clamped; the head's
+    # bias is set so that some rows sit outside [LOG_SIG_MIN, LOG_SIG_MAX] = [-20, 2] (the clamp's gate is exercised)
+    _gen_ppo_case("g7d_ppo_condstd", 710, -0.3, 2, conditioned_std=True)
 
 
 def _gen_ppo_case(name, seed, ls_mean, epochs, **extra):
@@ -577,18 +580,29 @@ def _gen_ppo_case(name, seed, ls_mean, epochs, **extra):
     kw = dict(reward_scale=1.0, discount=0.99, clip_eps=0.2, policy_lr=3e-4, value_lr=3e-4, gae_tau=0.95,
               value_l2_reg=1e-3, mini_batch_size=16, update_epoch=epochs)
     kw.update(extra)
+    cond = bool(extra.pop("conditioned_std", False))
+    kw.pop("conditioned_std", None)
     vf = FlattenMlp(hidden_sizes=Hh, input_size=o, output_size=1, hidden_activation=torch.tanh)
-    pol = ReparamMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a, conditioned_std=False,
+    pol = ReparamMultivariateGaussianPolicy(hidden_sizes=Hh, obs_dim=o, action_dim=a, conditioned_std=cond,
                                             hidden_activation=torch.tanh)
     vf0 = omlp.init_mlp(rng, o, Hh, 1)
-    pim = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, last_scale=(0.1, 0.0))   # policies.py:378-379
-    ls0 = rng.normal(ls_mean, 0.2, a).astype(np.float32)
-    pi0 = np.concatenate([pim, ls0])                      # our layout: mean net | action_log_std
+    if cond:
+        pi0 = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, n_heads=2, last_scale=(0.1, 0.0))   # fc.. | last_fc (x0.1, b 0) | last_fc_log_std
+        nls = Hh[-1] * a + a
+        pi0[-nls:-a] *= 1000.0                                                           # the log-std head varies over the rows ...
+        pi0[-a:] = np.array([-0.3, 2.0, -0.5], np.float32)                               # ... and one dimension straddles LOG_SIG_MAX = 2
+        names = [k for k, _ in pol.named_parameters()]
+        assert names[-4:] == ["last_fc.weight", "last_fc.bias", "last_fc_log_std.weight", "last_fc_log_std.bias"], names
+        set_flat(pol, pi0)
+    else:
+        pim = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, last_scale=(0.1, 0.0))   # policies.py:378-379
+        ls0 = rng.normal(ls_mean, 0.2, a).astype(np.float32)
+        pi0 = np.concatenate([pim, ls0])                      # our layout: mean net | action_log_std
+        set_flat(pol, np.concatenate([ls0, pim]))             # torch yields action_log_std first
+        assert [k for k, _ in pol.named_parameters()][0] == "action_log_std"
     set_flat(vf, vf0)
-    set_flat(pol, np.concatenate([ls0, pim]))             # torch yields action_log_std first
-    assert [k for k, _ in pol.named_parameters()][0] == "action_log_std"
     tr = PPO(policy=pol, vf=vf, **kw)
-    orc = PPOOracle(o, a, Hh, pi0, vf0, **kw)
+    orc = PPOOracle(o, a, Hh, pi0, vf0, conditioned_std=cond, **kw)
     lens = [2, 7, 50, 13]
     trajs = []
     for L in lens:
@@ -597,11 +611,24 @@ def _gen_ppo_case(name, seed, ls_mean, epochs, **extra):
                           rewards=rng.normal(1.0, 1.0, (L, 1)).astype(np.float32)))
     N = sum(lens)
     perms = [rng.permutation(N) for _ in range(kw["update_epoch"])]
+    if cond:   # centre dimension 1 of the log-std head on LOG_SIG_MAX over THESE observations, so that the clamp gates part of its rows
+        allobs = np.concatenate([tj["observations"] for tj in trajs])
+        lsr0 = omlp.forward(pi0, allobs, o, Hh, a, n_heads=2, act=omlp.TANH)[0][1]
+        pi0[-a + 1] += np.float32(2.0 - np.median(lsr0[:, 1]))
+        set_flat(pol, pi0)
+        orc = PPOOracle(o, a, Hh, pi0, vf0, conditioned_std=True, **kw)
     ttrajs = [{k: t(v) for k, v in tj.items()} for tj in trajs]
     with torch.no_grad():
         ref_obs, ref_act, ref_ret, ref_adv, ref_val = tr.calc_adv(ttrajs)
         ref_lp = pol.get_log_prob(ref_obs, ref_act)
     obs_, act_, R_, A_, V_ = orc.calc_adv(trajs)
+    n_out0 = 0
+    if cond:   # the clamp's gate must be exercised by the INITIAL policy: some, not all, entries of the log-std head outside [-20, 2]
+        orc.log_prob(obs_, act_)
+        outm = (orc._lsr < -20.0) | (orc._lsr > 2.0)
+        n_out0 = int(outm.sum())
+        print(name, "log-std head entries outside the clamp at the start:", n_out0, "of", outm.size, "per dim", outm.sum(0))
+        assert 0 < n_out0 < outm.size and 0 < outm.sum(0)[1] < outm.shape[0]
     assert np.allclose(R_, n(ref_ret), rtol=1e-5, atol=1e-5) and np.allclose(A_, n(ref_adv), rtol=2e-4, atol=2e-5)
     assert np.allclose(orc.log_prob(obs_, act_)[0], n(ref_lp), rtol=1e-5, atol=1e-5)
     q = list(perms)
@@ -613,7 +640,7 @@ def _gen_ppo_case(name, seed, ls_mean, epochs, **extra):
         torch.randperm = orig
     res = orc.train_step(trajs, perms)
     pi_ref_t = get_flat(pol)
-    pi_ref = np.concatenate([pi_ref_t[a:], pi_ref_t[:a]])
+    pi_ref = pi_ref_t if cond else np.concatenate([pi_ref_t[a:], pi_ref_t[:a]])
     assert np.abs(orc.vf - get_flat(vf)).max() < 5e-5, np.abs(orc.vf - get_flat(vf)).max()
     assert np.abs(orc.pi - pi_ref).max() < 5e-5, np.abs(orc.pi - pi_ref).max()
     out = dict(dims=np.array([o, a] + Hh), lens=np.array(lens), vf0=vf0, pi0=pi0, perms=np.array(perms),
@@ -622,6 +649,8 @@ def _gen_ppo_case(name, seed, ls_mean, epochs, **extra):
     for i, tj in enumerate(trajs):
         out.update({f"t{i}_{k}": v for k, v in tj.items()})
     out.update(epochs=np.array(epochs), pi_grad_norm_last=np.array(res["pi_grad_norm"]))
+    if cond:
+        out.update(kw_conditioned_std=np.array(True), n_outside_clamp=np.array(n_out0))
     if extra:
         out.update({"kw_" + k: np.array(v) for k, v in extra.items()})
         if extra.get("use_value_clip"):   # how many rows ended outside the clip window (the fixture must exercise both branches)
