@@ -121,7 +121,7 @@ class DiscCfg(C.Structure):  # ilsx_disc_cfg
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("hid_dim", C.c_int32), ("hid_act", C.c_int32),
                 ("use_grad_pen", C.c_int32), ("clamp_magnitude", C.c_float), ("disc_lr", C.c_float),
                 ("disc_momentum", C.c_float), ("grad_pen_weight", C.c_float), ("max_batch", C.c_int32),
-                ("state_only", C.c_int32)]
+                ("state_only", C.c_int32), ("num_layer_blocks", C.c_int32)]
 
 
 class OptMeta(C.Structure):  # ilsx_opt_meta

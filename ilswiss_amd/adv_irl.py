@@ -6,7 +6,8 @@ adv_irl.py:34-54): a caller that relies on defaults gets the reference's algorit
 different network.  What libilsx does not implement raises at construction:
   * `use_bn=True` (the reference default): BatchNorm1d couples the rows of a batch, and the gradient penalty needs the
     double backward through the batch statistics — not built; every exp_spec of the reference sets `disc_use_bn: false`;
-  * `num_layer_blocks != 2` (every exp_spec sets 2).
+  * `num_layer_blocks` outside 1..3 (every exp_spec sets 2, which runs the fused kernel; 1 and 3 run the same mathematics as a chain
+    of per-layer launches).
 """
 import ctypes as C
 from collections import OrderedDict
@@ -36,8 +37,9 @@ class MLPDisc:
         if use_bn:
             raise NotImplementedError("MLPDisc(use_bn=True) — the reference's default — is not implemented by libilsx (no batch-norm "
                                       "double backward); pass use_bn=False explicitly (every exp_spec does: gail_walker.yaml:27)")
-        if num_layer_blocks != 2:
-            raise NotImplementedError("libilsx implements num_layer_blocks=2 (gail_walker.yaml:24); got %r" % (num_layer_blocks,))
+        if num_layer_blocks not in (1, 2, 3):
+            raise NotImplementedError("libilsx implements num_layer_blocks 1..3 (gail_walker.yaml:24 uses 2); got %r" % (num_layer_blocks,))
+        self.num_layer_blocks = int(num_layer_blocks)
         if hid_act not in _ACT:
             raise NotImplementedError()   # simple_disc_models.py:24-25
         if hid_dim > _WIDTHS[-1]:
@@ -50,7 +52,7 @@ class MLPDisc:
         rng = np.random.default_rng(np.random.randint(0, 2**31 - 1) if seed is None else seed)
         D, H = self.input_dim, self.hid_dim
         parts = []
-        for fan_in, out in ((D, H), (H, H), (H, 1)):
+        for fan_in, out in [(D, H)] + [(H, H)] * (self.num_layer_blocks - 1) + [(H, 1)]:
             b = 1.0 / np.sqrt(fan_in)
             parts += [rng.uniform(-b, b, (out, fan_in)).ravel(), rng.uniform(-b, b, out)]
         self._flat = np.concatenate(parts).astype(np.float32)
@@ -68,27 +70,33 @@ class MLPDisc:
         if H == Hp:
             return flat
         o, out = 0, []
-        for rows, cols, prow, pcol in ((H, D, Hp, D), (H, 1, Hp, 1), (H, H, Hp, Hp), (H, 1, Hp, 1), (1, H, 1, Hp), (1, 1, 1, 1)):
+        for rows, cols, prow, pcol in self._shapes():
             m = np.zeros((prow, pcol), np.float32)
             m[:rows, :cols] = flat[o:o + rows * cols].reshape(rows, cols)
             out.append(m.ravel())
             o += rows * cols
         return np.concatenate(out)
 
+    def _shapes(self):   # (rows, cols, padded rows, padded cols) of every tensor in flat order: W_0, b_0, ..., w_head, b_head
+        D, H, Hp = self.input_dim, self.hid_dim, self._Hp
+        sh = [(H, D, Hp, D), (H, 1, Hp, 1)]
+        for _ in range(self.num_layer_blocks - 1):
+            sh += [(H, H, Hp, Hp), (H, 1, Hp, 1)]
+        return sh + [(1, H, 1, Hp), (1, 1, 1, 1)]
+
     def _unpad(self, phys):
         D, H, Hp = self.input_dim, self.hid_dim, self._Hp
         if H == Hp:
             return phys
         o, out = 0, []
-        for rows, cols, prow, pcol in ((H, D, Hp, D), (H, 1, Hp, 1), (H, H, Hp, Hp), (H, 1, Hp, 1), (1, H, 1, Hp), (1, 1, 1, 1)):
+        for rows, cols, prow, pcol in self._shapes():
             out.append(phys[o:o + prow * pcol].reshape(prow, pcol)[:rows, :cols].ravel())
             o += prow * pcol
         return np.concatenate(out)
 
     @property
     def _nphys(self):
-        D, Hp = self.input_dim, self._Hp
-        return Hp * D + Hp + Hp * Hp + Hp + Hp + 1
+        return sum(pr * pc for _, _, pr, pc in self._shapes())
 
     def bind(self, obs_dim, second_dim=None, state_only=False, disc_lr=1e-3, disc_momentum=0.0, use_grad_pen=True,
              grad_pen_weight=10.0, max_batch=1024):
@@ -106,7 +114,7 @@ class MLPDisc:
             self._flat = self.get_flat_params()
             _lib.check(self.ctx.lib.ilsx_disc_destroy(self.h))
         cfg = _lib.DiscCfg(obs_dim, second_dim, self._Hp, _ACT[self.hid_act], int(bool(use_grad_pen)), self.clamp_magnitude,
-                           disc_lr, disc_momentum, grad_pen_weight, int(max_batch), int(bool(state_only)))
+                           disc_lr, disc_momentum, grad_pen_weight, int(max_batch), int(bool(state_only)), self.num_layer_blocks)
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_disc_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
         self._bound = key

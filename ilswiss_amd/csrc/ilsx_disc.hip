@@ -1,6 +1,7 @@
 // ilsx_disc.hip — adversarial-IRL discriminator: rlkit/torch/algorithms/adv_irl/adv_irl.py:133-216
 // (_do_reward_training: BCE-with-logits + WGAN-GP gradient penalty), :277-298 (reward modes) and
-// disc_models/simple_disc_models.py:8-48 (MLPDisc: Linear-act-Linear-act-Linear, clamp +-10, no BN).
+// disc_models/simple_disc_models.py:8-48 (MLPDisc: 1-3 x (Linear, act) then Linear, clamp +-10, no BN; the fused kernel below is the
+// two-block network of every reference spec, disc_step_blocks the other depths).
 //
 // The reference gets the gradient-penalty gradient from autograd's double backward; here it is derived by
 // hand (oracle/disc.py) and fused into ONE row-tile kernel.  One step =
@@ -344,6 +345,11 @@ struct ilsx_disc {
   float *raw = nullptr, *ce_row = nullptr, *correct = nullptr, *gp_row = nullptr, *eps_used = nullptr;
   DwArgs jobs;
   int jobs_B = -1;
+  // num_layer_blocks != 2 (disc_step_blocks): per hidden layer l the activations hsb[l] [4B][H] (rows < 3B: forward; rows 3B..4B: v-bar_l),
+  // the row-stacked dW operand Ab[l] [4B][H] (delta_l of the CE rows | delta''_l of the GP rows | u_l) and z-bar_l [B][H]
+  int nblk = 2;
+  float *hsb[ILSX_MAX_HID] = {nullptr, nullptr, nullptr}, *Ab[ILSX_MAX_HID] = {nullptr, nullptr, nullptr}, *zb[ILSX_MAX_HID] = {nullptr, nullptr, nullptr};
+  float *given = nullptr, *gdx = nullptr, *dhead4 = nullptr;
   uint32_t rng_stream = 0;
   unsigned long long step_ctr = 0;
   PartVal pv() const { return PartVal{raw, cs, 3 * cfg.max_batch}; }
@@ -365,10 +371,12 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
   HIPCHK(hipSetDevice(ctx->device));
   ilsx_disc* d = new ilsx_disc();
   d->ctx = ctx; d->cfg = *cfg; d->o = cfg->obs_dim; d->a = cfg->act_dim; d->D = d->o + d->a;
-  ilsx_mlp_cfg mc = {d->D, 2, cfg->hid_dim, 1, 1, cfg->hid_act};
+  d->nblk = cfg->num_layer_blocks ? cfg->num_layer_blocks : 2;
+  if (d->nblk < 1 || d->nblk > ILSX_MAX_HID) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "num_layer_blocks=%d: 1..%d", d->nblk, ILSX_MAX_HID);
+  ilsx_mlp_cfg mc = {d->D, d->nblk, cfg->hid_dim, 1, 1, cfg->hid_act};
   int rc = net_layout_build(mc, &d->L);
   if (rc != ILSX_OK) { delete d; return rc; }
-  d->cs = getenv("ILSX_NO_SPLIT") ? 1 : mlp2_split_factor(2, cfg->hid_dim);
+  d->cs = (getenv("ILSX_NO_SPLIT") || d->nblk != 2) ? 1 : mlp2_split_factor(2, cfg->hid_dim);
   d->rng_stream = ctx->next_rng_stream++;
   const size_t n = d->L.n_int, B = (size_t)cfg->max_batch, H = (size_t)cfg->hid_dim, KP = (size_t)d->L.KP;
   auto A = [&](float** p, size_t cnt) { return ctx_alloc(ctx, cnt * sizeof(float), (void**)p, true); };
@@ -389,6 +397,16 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
   if (rc == ILSX_OK) rc = A(&d->correct, 2 * B);
   if (rc == ILSX_OK) rc = A(&d->gp_row, B);
   if (rc == ILSX_OK) rc = A(&d->eps_used, B);
+  if (d->nblk != 2) {
+    for (int l = 0; l < d->nblk && rc == ILSX_OK; ++l) {
+      rc = A(&d->hsb[l], 4 * B * H);
+      if (rc == ILSX_OK) rc = A(&d->Ab[l], 4 * B * H);
+      if (rc == ILSX_OK) rc = A(&d->zb[l], B * H);
+    }
+    if (rc == ILSX_OK) rc = A(&d->given, 3 * B);
+    if (rc == ILSX_OK) rc = A(&d->gdx, B * 64);
+    if (rc == ILSX_OK) rc = A(&d->dhead4, 4 * B);
+  }
   if (rc == ILSX_OK) rc = disc_refresh(d);
   if (rc != ILSX_OK) { delete d; return rc; }
   *out = d;
@@ -400,6 +418,10 @@ extern "C" int ilsx_disc_destroy(ilsx_disc* d) {
   void* ps[] = {d->P, d->G, d->M, d->V, d->scal, d->X, d->xs, d->hs0, d->hs1, d->A2, d->A1, d->dhead, d->raw, d->ce_row,
                 d->correct, d->gp_row, d->eps_used};
   for (void* p : ps) ctx_free(d->ctx, p);
+  for (int l = 0; l < ILSX_MAX_HID; ++l) { if (d->hsb[l]) ctx_free(d->ctx, d->hsb[l]); if (d->Ab[l]) ctx_free(d->ctx, d->Ab[l]); if (d->zb[l]) ctx_free(d->ctx, d->zb[l]); }
+  if (d->given) ctx_free(d->ctx, d->given);
+  if (d->gdx) ctx_free(d->ctx, d->gdx);
+  if (d->dhead4) ctx_free(d->ctx, d->dhead4);
   delete d;
   return ILSX_OK;
 }
@@ -459,7 +481,8 @@ static int disc_forward(ilsx_disc* d, const float* x0, int d0, int s0, const flo
   FwdTask& t = A.t[0];
   t.net = net_view(d->L, d->P);
   t.x0 = x0; t.d0 = d0; t.s0 = s0; t.x1 = x1; t.d1 = d1; t.s1 = s1;
-  if (save) { t.xsave = d->xs; t.hsave[0] = d->hs0; t.hsave[1] = d->hs1; }
+  if (save && d->nblk == 2) { t.xsave = d->xs; t.hsave[0] = d->hs0; t.hsave[1] = d->hs1; }
+  if (save && d->nblk != 2) { t.xsave = d->xs; for (int l = 0; l < d->nblk; ++l) t.hsave[l] = d->hsb[l]; }
   t.head = HEAD_RAW;
   if (d->cs > 1) t.part = d->raw; else t.out = d->raw;
   return launch_fwd(d->ctx, A, d->cfg.hid_dim, d->cfg.hid_act, d->L.KP, d->cs);
@@ -478,6 +501,148 @@ static int disc_build_jobs(ilsx_disc* d, int B) {
   ILSX_TRY(dw_table_add(&d->jobs, d->dhead, 1, 1, d->hs1, H, H, d->G + L.off_Wh, nullptr, H, d->G + L.off_bh,
                         DW_OUT_NATURAL, rows_o, 2 * B));
   d->jobs_B = B;
+  return ILSX_OK;
+}
+
+// ================================================================================================ num_layer_blocks = 1 or 3
+// The same loss and the same hand-derived double backward as k_disc_bwd (oracle/disc.py train_step_blocks) for any
+// depth, as a chain of small launches — a completeness path (the reference's specs all use 2 blocks), written for clarity, not speed:
+//   k_disc_head_rows   per row: CE terms, dlogit through the clamp gate ; the "given" head gradients of the two backward launches
+//   generic backward   CE rows: delta_l -> Ab[l] rows < 2B ;  GP rows (given = gate): u_l -> Ab[l] rows 3B..4B, dD/dx -> gdx
+//   k_disc_gp_rows     |dD/dx|, the penalty value, g-bar = dGP/dg -> xs rows 3B..4B
+//   k_disc_lin_layer   UP the net, l = 0..L-1: u-bar_l = W_l x_{l-1}; v-bar_l = phi'_l u-bar_l -> hsb[l] rows 3B..4B; z-bar_l = (phi''/phi')_l u_l u-bar_l
+//   k_disc_inj_layer   DOWN, l = L-2..0: delta''_l = z-bar_l + phi'_l (delta''_{l+1} W_{l+1}) -> Ab[l] rows 2B..3B
+//   k_mlp_bwd_dw       per layer ONE contraction over the 4B stacked rows (bias from the first 3B) + the head's, Adam in the epilogue
+__global__ void k_disc_head_rows(PartVal raw, int B, int use_gp, float clamp, float* __restrict__ ce_row, float* __restrict__ correct,
+                                 float* __restrict__ given, float* __restrict__ dhead4) {
+  const int gr = blockIdx.x * blockDim.x + threadIdx.x, rows = use_gp ? 3 * B : 2 * B;
+  if (gr >= 4 * B) return;
+  if (gr >= rows) { dhead4[gr] = (use_gp && gr >= 3 * B) ? 1.0f : 0.0f; return; }   // rows 3B..4B: the "ones" rows that carry v-bar_L into dw
+  const float r = raw.get(gr);
+  const float gate = (r >= -clamp && r <= clamp) ? 1.0f : 0.0f;
+  const float l = fminf(fmaxf(r, -clamp), clamp);
+  if (gr < 2 * B) {
+    const float t = gr < B ? 1.0f : 0.0f;
+    const float dl = gate * (1.0f / (1.0f + expf(-l)) - t) / (float)(2 * B);
+    ce_row[gr] = fmaxf(l, 0.0f) - l * t + log1pf(expf(-fabsf(l)));
+    correct[gr] = ((l > 0.0f) == (t > 0.5f)) ? 1.0f : 0.0f;
+    given[gr] = dl; dhead4[gr] = dl;
+  } else {
+    given[gr] = gate; dhead4[gr] = 0.0f;   // GP rows: the u chain starts from the gate; their forward activations feed no head gradient
+  }
+}
+__global__ void k_disc_gp_rows(const float* __restrict__ gdx, int B, int D, int KP, float gp_w, float* __restrict__ gbar /* xs rows 3B.. */,
+                               float* __restrict__ gp_row) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  float sq = 0.0f;
+  for (int c = 0; c < D; ++c) { const float g = gdx[(size_t)r * D + c]; sq += g * g; }
+  const float n = sqrtf(sq);
+  const float coef = n > 0.0f ? gp_w / (float)B * 2.0f * (n - 1.0f) / n : 0.0f;   // adv_irl.py:201-202; norm backward is 0 at 0
+  for (int c = 0; c < KP; ++c) gbar[(size_t)r * KP + c] = c < D ? coef * gdx[(size_t)r * D + c] : 0.0f;
+  gp_row[r] = (n - 1.0f) * (n - 1.0f);
+}
+// one thread per (row, output column n)
+template <int ACT>
+__global__ void k_disc_lin_layer(const float* __restrict__ W, int K, int ldw, const float* __restrict__ xin, int ldx, const float* __restrict__ hgp,
+                                 const float* __restrict__ u, int H, int B, float* __restrict__ vbar, float* __restrict__ zbar) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * H) return;
+  const int r = e / H, nn = e - r * H;
+  float ub = 0.0f;
+  for (int k = 0; k < K; ++k) ub = fmaf(W[pack_f(nn, k, ldw)], xin[(size_t)r * ldx + k], ub);
+  const float h = hgp[(size_t)r * H + nn];
+  vbar[(size_t)r * H + nn] = act_grad_from_out<ACT>(h) * ub;
+  zbar[(size_t)r * H + nn] = ACT == ACT_TANH ? -2.0f * h * u[(size_t)r * H + nn] * ub : 0.0f;
+}
+// one thread per (row, column k of layer l): delta''_l = z-bar_l + phi'_l * sum_n delta''_{l+1}[n] W_{l+1}[n][k]
+template <int ACT>
+__global__ void k_disc_inj_layer(const float* __restrict__ Wnext, int H, const float* __restrict__ dnext, const float* __restrict__ zbar,
+                                 const float* __restrict__ hgp, int B, float* __restrict__ dout) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * H) return;
+  const int r = e / H, k = e - r * H;
+  float s = 0.0f;
+  for (int nn = 0; nn < H; ++nn) s = fmaf(dnext[(size_t)r * H + nn], Wnext[pack_f(nn, k, H)], s);
+  dout[(size_t)r * H + k] = zbar[(size_t)r * H + k] + act_grad_from_out<ACT>(hgp[(size_t)r * H + k]) * s;
+}
+
+static int disc_step_blocks(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
+  ilsx_ctx* ctx = d->ctx;
+  hipStream_t st = ctx->stream;
+  const int gp = d->cfg.use_grad_pen ? 1 : 0, rows = gp ? 3 * B : 2 * B, H = d->cfg.hid_dim, L = d->nblk, KP = d->L.KP, act = d->cfg.hid_act;
+  const size_t sB = (size_t)B;
+  if (d->jobs_B != B) {   // row-stacked weight-gradient jobs (see the table above)
+    memset(&d->jobs, 0, sizeof d->jobs);
+    const int rows_h = gp ? 4 * B : 2 * B, bias_h = gp ? 3 * B : 2 * B;
+    for (int l = 0; l < L; ++l)
+      ILSX_TRY(dw_table_add(&d->jobs, d->Ab[l], H, H, l == 0 ? d->xs : d->hsb[l - 1], l == 0 ? KP : H, l == 0 ? KP : H, d->G + d->L.off_W[l],
+                            l > 0 ? d->G + d->L.off_Wb[l] : nullptr, l == 0 ? KP : H, d->G + d->L.off_b[l], l > 0 ? DW_OUT_PACK_FB : DW_OUT_PACK_F,
+                            rows_h, bias_h));
+    ILSX_TRY(dw_table_add(&d->jobs, d->dhead4, 1, 1, d->hsb[L - 1], H, H, d->G + d->L.off_Wh, nullptr, H, d->G + d->L.off_bh, DW_OUT_NATURAL,
+                          rows_h, 2 * B));
+    d->jobs_B = B;
+  }
+  ILSX_TRY(disc_forward(d, d->X, d->D, d->D, nullptr, 0, 0, rows, true));
+  hipLaunchKernelGGL(k_disc_head_rows, dim3((4 * B + 255) / 256), dim3(256), 0, st, d->pv(), B, gp, d->cfg.clamp_magnitude, d->ce_row, d->correct,
+                     d->given, d->dhead4);
+  HIPCHK(hipGetLastError());
+  for (int pass = 0; pass < (gp ? 2 : 1); ++pass) {   // 0: the CE rows ; 1: the interpolates (given = gate: the u chain + dD/dx)
+    BwdArgs A;
+    memset(&A, 0, sizeof A);
+    const size_t r0 = pass ? 2 * sB : 0;
+    A.rows = pass ? B : 2 * B; A.ntasks = 1; A.inv_B = 1.0f;
+    BwdTask& b = A.t[0];
+    b.net = net_view(d->L, d->P);
+    for (int l = 0; l < L; ++l) { b.hsave[l] = d->hsb[l] + r0 * H; b.dsave[l] = d->Ab[l] + (pass ? 3 * sB : 0) * H; }
+    b.loss = LOSS_GIVEN; b.given = d->given + r0;
+    if (pass) { b.dx = d->gdx; b.dx_col0 = 0; b.dx_cols = d->D; }
+    ILSX_TRY(launch_bwd_dx(ctx, A, H, act));
+  }
+  if (gp) {
+    hipLaunchKernelGGL(k_disc_gp_rows, dim3((B + 255) / 256), dim3(256), 0, st, (const float*)d->gdx, B, d->D, KP, d->cfg.grad_pen_weight,
+                       d->xs + 3 * sB * KP, d->gp_row);
+    const dim3 grid((unsigned)((sB * H + 255) / 256)), block(256);
+    for (int l = 0; l < L; ++l) {
+      const float* W = d->P + d->L.off_W[l];
+      const float* xin = l == 0 ? d->xs + 3 * sB * KP : d->hsb[l - 1] + 3 * sB * H;
+      float* zout = l == L - 1 ? d->Ab[l] + 2 * sB * H : d->zb[l];   // delta''_L = z-bar_L
+      const int K = l == 0 ? KP : H;
+      if (act == ILSX_ACT_TANH)
+        hipLaunchKernelGGL(k_disc_lin_layer<ACT_TANH>, grid, block, 0, st, W, K, K, xin, K, (const float*)(d->hsb[l] + 2 * sB * H),
+                           (const float*)(d->Ab[l] + 3 * sB * H), H, B, d->hsb[l] + 3 * sB * H, zout);
+      else
+        hipLaunchKernelGGL(k_disc_lin_layer<ACT_RELU>, grid, block, 0, st, W, K, K, xin, K, (const float*)(d->hsb[l] + 2 * sB * H),
+                           (const float*)(d->Ab[l] + 3 * sB * H), H, B, d->hsb[l] + 3 * sB * H, zout);
+    }
+    for (int l = L - 2; l >= 0; --l) {
+      const float* Wn = d->P + d->L.off_W[l + 1];
+      if (act == ILSX_ACT_TANH)
+        hipLaunchKernelGGL(k_disc_inj_layer<ACT_TANH>, grid, block, 0, st, Wn, H, (const float*)(d->Ab[l + 1] + 2 * sB * H), (const float*)d->zb[l],
+                           (const float*)(d->hsb[l] + 2 * sB * H), B, d->Ab[l] + 2 * sB * H);
+      else
+        hipLaunchKernelGGL(k_disc_inj_layer<ACT_RELU>, grid, block, 0, st, Wn, H, (const float*)(d->Ab[l + 1] + 2 * sB * H), (const float*)d->zb[l],
+                           (const float*)(d->hsb[l] + 2 * sB * H), B, d->Ab[l] + 2 * sB * H);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  {
+    AdamFuse F;
+    memset(&F, 0, sizeof F);
+    F.on = 1; F.Gbase = d->G; F.P = d->P; F.M = d->M; F.V = d->V; F.T = nullptr;
+    F.b1 = d->cfg.disc_momentum; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
+    F.step_size = &d->scal->adam_step; F.bc2_sqrt = &d->scal->adam_bc2s;
+    ILSX_TRY(launch_bwd_dw(ctx, d->jobs, gp ? 4 * B : 2 * B, &F));
+  }
+  hipLaunchKernelGGL(k_disc_tail, dim3(1), dim3(256), 0, st, d->scal, d->ce_row, d->correct, d->gp_row, B, gp, d->cfg.disc_lr, d->cfg.disc_momentum,
+                     0.999f);
+  HIPCHK(hipGetLastError());
+  if (stats) {
+    DiscScalars h;
+    HIPCHK(hipMemcpyAsync(&h, d->scal, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    stats->ce_loss = h.ce_loss; stats->grad_pen = h.grad_pen; stats->accuracy = h.accuracy;
+  }
   return ILSX_OK;
 }
 
@@ -515,6 +680,7 @@ static int disc_train_step_from_rings(ilsx_disc* d, ilsx_replay* expert_rb, ilsx
 }
 
 static int disc_step_after_prep(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
+  if (d->nblk != 2) return disc_step_blocks(d, B, stats);
   ilsx_ctx* ctx = d->ctx;
   ILSX_TRY(disc_build_jobs(d, B));
   const int gp = d->cfg.use_grad_pen ? 1 : 0, rows = gp ? 3 * B : 2 * B, H = d->cfg.hid_dim;

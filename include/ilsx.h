@@ -276,12 +276,14 @@ int ilsx_debug_philox(ilsx_ctx* ctx, uint64_t seed, uint64_t step, uint32_t stre
 enum { ILSX_DISC_AIRL = 0, ILSX_DISC_GAIL = 1, ILSX_DISC_GAIL2 = 2, ILSX_DISC_FAIRL = 3 };
 typedef struct {
   int32_t obs_dim, act_dim;       /* discriminator input = cat(obs, act); state_only: cat(obs, next_obs), act_dim == obs_dim */
-  int32_t hid_dim, hid_act;       /* 2 layer blocks of hid_dim (64/128/256), ILSX_ACT_* */
+  int32_t hid_dim, hid_act;       /* layer blocks of hid_dim (64/128/256), ILSX_ACT_* */
   int32_t use_grad_pen;
   float clamp_magnitude, disc_lr, disc_momentum, grad_pen_weight;
   int32_t max_batch;              /* disc_optim_batch_size upper bound (rows per class) */
   int32_t state_only;             /* adv_irl.py:140-162,269: discriminator input = cat(obs, next_obs); act_dim must equal obs_dim and
                                      every `act` row pointer of the entry points below carries next_obs rows */
+  int32_t num_layer_blocks;       /* simple_disc_models.py:11,29-39: hidden (Linear, act) blocks, 1..3; 0 = 2.  2 runs the fused
+                                     double-backward kernel, 1 and 3 the same mathematics as a chain of per-layer launches */
 } ilsx_disc_cfg;
 typedef struct { float ce_loss, grad_pen, accuracy; } ilsx_disc_stats;   /* "Disc CE Loss", "Grad Pen", "Disc Acc" */
 int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_disc** out);

@@ -36,7 +36,8 @@ def sigmoid(x):
 
 class DiscOracle:
     def __init__(self, in_dim, hid_dim, flat, act=TANH, clamp=10.0, disc_lr=3e-4, disc_momentum=0.9,
-                 use_grad_pen=True, grad_pen_weight=10.0):
+                 use_grad_pen=True, grad_pen_weight=10.0, num_layer_blocks=2):
+        self.L = int(num_layer_blocks)   # simple_disc_models.py:29-39: L x (Linear, act) then Linear(hid, 1); train_step_blocks for L != 2
         self.D, self.H, self.act, self.clamp = in_dim, hid_dim, act, F32(clamp)
         self.p = flat.copy()
         self.lr, self.b1 = disc_lr, disc_momentum
@@ -44,7 +45,80 @@ class DiscOracle:
         self.opt = optim.AdamState(flat.size)
 
     def _layers(self):
-        return mlp.unpack(self.p, self.D, [self.H, self.H], 1)
+        return mlp.unpack(self.p, self.D, [self.H] * self.L, 1)
+
+    def forward_blocks(self, x):
+        """any depth: (clamped logit, raw logit, [h_1 .. h_L])"""
+        lay, h, hs = self._layers(), x, []
+        for W, b in lay[:-1]:
+            h = _act(h @ W.T + b, self.act).astype(F32)
+            hs.append(h)
+        raw = (h @ lay[-1][0].T + lay[-1][1]).astype(F32)
+        return np.clip(raw, -self.clamp, self.clamp), raw, hs
+
+    def train_step_blocks(self, x_exp, x_pol, eps_gp):
+        """train_step for any number of layer blocks (same loss, adv_irl.py:133-216).  The gradient penalty's gradient, by reverse
+        over reverse: with u_L = phi'_L w gate, u_l = phi'_l (W_{l+1}^T u_{l+1}), g = W_1^T u_1 and g-bar = dGP/dg, the cotangents
+        run UP the net like a forward pass without biases — x_0 = g-bar, u-bar_l = W_l x_{l-1}, x_l = v-bar_l = phi'_l u-bar_l —
+        leaving dW_l += u_l x_{l-1}^T, dw += v-bar_L (gate inside u) and, where phi'' != 0, z-bar_l = (phi''_l / phi'_l) u_l u-bar_l
+        (tanh: -2 h_l u_l u-bar_l), which then goes DOWN the ordinary net: delta_L = z-bar_L, delta_l = z-bar_l + phi'_l (W_{l+1}^T
+        delta_{l+1}), dW_l += delta_l h_{l-1}^T, db_l += delta_l."""
+        lay = self._layers()
+        Ws, bs = [W for W, _ in lay], [b for _, b in lay]
+        L, act, B = self.L, self.act, x_exp.shape[0]
+        x = np.concatenate([x_exp, x_pol], 0).astype(F32)
+        t = np.concatenate([np.ones((B, 1), F32), np.zeros((B, 1), F32)], 0)
+        logit, raw, hs = self.forward_blocks(x)
+        ce = bce_with_logits(logit, t)
+        acc = np.mean(((logit > 0).astype(F32) == t).astype(F32))
+        gate = ((raw >= -self.clamp) & (raw <= self.clamp)).astype(F32)
+        dlogit = (sigmoid(logit) - t) / F32(2 * B) * gate
+        gW, gb = [None] * (L + 1), [None] * (L + 1)
+        gW[L], gb[L] = dlogit.T @ hs[-1], dlogit.sum(0)
+        d = (dlogit @ Ws[L]) * _dact(hs[L - 1], act)
+        for l in range(L - 1, -1, -1):   # layer index l: W_{l+1} in the docstring's numbering
+            inp = hs[l - 1] if l > 0 else x
+            gW[l], gb[l] = d.T @ inp, d.sum(0)
+            if l > 0:
+                d = (d @ Ws[l]) * _dact(hs[l - 1], act)
+        out = dict(logits=logit, ce_loss=ce, accuracy=acc)
+        gp_loss = F32(0)
+        if self.use_gp:
+            e = eps_gp.astype(F32).reshape(B, 1)
+            xh = (e * x_exp + (F32(1) - e) * x_pol).astype(F32)
+            _, rawh, gh = self.forward_blocks(xh)
+            gt = ((rawh >= -self.clamp) & (rawh <= self.clamp)).astype(F32)
+            ph = [_dact(h, act) for h in gh]
+            us = [None] * L
+            us[L - 1] = (ph[L - 1] * Ws[L]) * gt                     # gate folded into the top of the u chain
+            for l in range(L - 2, -1, -1):
+                us[l] = ph[l] * (us[l + 1] @ Ws[l + 1])
+            g = us[0] @ Ws[0]
+            n = np.sqrt(np.sum(g * g, 1, keepdims=True)).astype(F32)
+            gp = np.mean((n - F32(1)) ** 2, dtype=F32)
+            gp_loss = F32(gp * F32(self.gp_w))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                gbar = np.where(n > 0, F32(self.gp_w) / F32(B) * F32(2) * (n - F32(1)) / n * g, F32(0)).astype(F32)
+            xs, zb = gbar, [None] * L
+            for l in range(L):                                       # up: the linearised forward pass
+                gW[l] = gW[l] + us[l].T @ xs
+                ub = xs @ Ws[l].T
+                zb[l] = (F32(-2) * gh[l] * us[l] * ub).astype(F32) if act == TANH else np.zeros_like(ub)   # (phi''/phi') u u-bar; relu: 0
+                xs = (ub * ph[l]).astype(F32)
+            gW[L] = gW[L] + xs.sum(0, keepdims=True) * F32(1)       # dw += sum_r v-bar_L  (gate already in u, hence in g-bar's path)
+            d = zb[L - 1]                                           # down: the ordinary backward of the z-bar terms
+            for l in range(L - 1, -1, -1):
+                inp = gh[l - 1] if l > 0 else xh
+                gW[l] = gW[l] + d.T @ inp
+                gb[l] = gb[l] + d.sum(0)
+                if l > 0:
+                    d = (d @ Ws[l]) * ph[l - 1] + zb[l - 1]
+            out.update(interp=xh, dDdx=g, grad_norm=n)
+        out["grad_pen_loss"] = gp_loss
+        grad = mlp.pack([(gW[l].astype(F32), gb[l].astype(F32)) for l in range(L + 1)])
+        out["grad"] = grad
+        optim.adam_step(self.p, grad, self.opt, self.lr, self.b1)
+        return out
 
     def forward(self, x):
         (W1, b1), (W2, b2), (W3, b3) = self._layers()

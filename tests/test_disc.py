@@ -33,6 +33,40 @@ def test_oracle_disc_steps_golden():
     assert (res["grad_norm"] == 0).sum() >= 1 and np.isfinite(res["grad"]).all() and np.isfinite(g["tanh_sat_s0_grad"]).all()
 
 
+BLOCK_CASES = [("tanh1", TANH), ("tanh3", TANH), ("relu3", RELU), ("relu1", RELU)]
+
+
+@pytest.mark.parametrize("tag,act", BLOCK_CASES)
+def test_oracle_disc_blocks_golden(tag, act):
+    """g25: MLPDisc(num_layer_blocks = 1 / 3) through the reference's autograd double backward vs the general-depth restatement."""
+    g = load_golden("g25_disc_blocks")
+    D, Hd, B, steps, _, L = [int(v) for v in g[f"{tag}_dims"]]
+    orc = DiscOracle(D, Hd, g[f"{tag}_params0"], act=act, num_layer_blocks=L, **KW)
+    for s in range(steps):
+        res = orc.train_step_blocks(g[f"{tag}_s{s}_x_exp"], g[f"{tag}_s{s}_x_pol"], g[f"{tag}_s{s}_eps"])
+        np.testing.assert_allclose(res["ce_loss"], g[f"{tag}_s{s}_ce"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(res["grad_pen_loss"], 8.0 * g[f"{tag}_s{s}_gp"], rtol=1e-4, atol=1e-6)
+        if s == 0:
+            ref = g[f"{tag}_s0_grad"]
+            assert np.abs(res["grad"] - ref).max() <= 1e-4 * np.abs(ref).max()
+    np.testing.assert_allclose(orc.p, g[f"{tag}_params_final"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(orc.forward_blocks(g[f"{tag}_probe"])[0], g[f"{tag}_probe_logits"], rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_blocks_routine_is_the_two_block_routine():
+    """train_step_blocks at L = 2 == the hand-written two-block train_step (the one pinned by g8)."""
+    from oracle import mlp as omlp
+    rng = np.random.default_rng(0)
+    D, Hd, B = 9, 16, 12
+    for act in (TANH, RELU):
+        flat = omlp.init_mlp(rng, D, [Hd, Hd], 1, init_w=0.3)
+        a, b = DiscOracle(D, Hd, flat, act=act), DiscOracle(D, Hd, flat, act=act, num_layer_blocks=2)
+        xe, xp, e = (rng.normal(0, 1, (B, D)).astype(np.float32), rng.normal(0, 1, (B, D)).astype(np.float32), rng.random((B, 1)).astype(np.float32))
+        ra, rb = a.train_step(xe, xp, e), b.train_step_blocks(xe, xp, e)
+        assert np.abs(ra["grad"] - rb["grad"]).max() <= 1e-6 * np.abs(ra["grad"]).max()
+        assert ra["grad_pen_loss"] == rb["grad_pen_loss"]
+
+
 def test_oracle_reward_modes_golden():
     g = load_golden("g8_g9_disc")
     for mode in ("airl", "gail", "gail2", "fairl"):
@@ -60,6 +94,29 @@ def test_hip_disc_steps_golden(ctx, tag, act):
         got = disc.get_flat_grads()
         assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (s, np.abs(got - ref).max(), np.abs(ref).max())
         np.testing.assert_allclose(disc.get_flat_params(), g[f"{tag}_s{s}_params"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(disc(g[f"{tag}_probe"]), g[f"{tag}_probe_logits"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,act", BLOCK_CASES)
+def test_hip_disc_blocks_golden(ctx, tag, act):
+    """num_layer_blocks = 1 and 3 on the HIP path (the per-layer launch chain, ilsx_disc.hip disc_step_blocks) vs the reference's numbers."""
+    from ilswiss_amd.adv_irl import MLPDisc
+    g = load_golden("g25_disc_blocks")
+    D, Hd, B, steps, o, L = [int(v) for v in g[f"{tag}_dims"]]
+    disc = MLPDisc(D, num_layer_blocks=L, hid_dim=Hd, hid_act=tag[:4], use_bn=False, ctx=ctx).bind(o, max_batch=B, **KW)
+    disc.set_flat_params(g[f"{tag}_params0"])
+    np.testing.assert_array_equal(disc.get_flat_params(), g[f"{tag}_params0"])
+    for s in range(steps):
+        xe, xp = g[f"{tag}_s{s}_x_exp"], g[f"{tag}_s{s}_x_pol"]
+        st = disc.train_step(xe[:, :o], xe[:, o:], xp[:, :o], xp[:, o:], eps=g[f"{tag}_s{s}_eps"])
+        np.testing.assert_allclose(st["Disc CE Loss"], g[f"{tag}_s{s}_ce"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(st["Grad Pen"], g[f"{tag}_s{s}_gp"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(st["Disc Acc"], g[f"{tag}_s{s}_acc"])
+        if s == 0:
+            ref, got = g[f"{tag}_s0_grad"], disc.get_flat_grads()
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+    np.testing.assert_allclose(disc.get_flat_params(), g[f"{tag}_params_final"], rtol=0, atol=5e-5)
     np.testing.assert_allclose(disc(g[f"{tag}_probe"]), g[f"{tag}_probe_logits"], rtol=1e-4, atol=2e-5)
 
 
@@ -197,7 +254,7 @@ def test_unimplemented_disc_options_fail_loudly():
     with pytest.raises(NotImplementedError, match="use_bn"):
         MLPDisc(23, ctx=object())                      # the reference's default network has BatchNorm: never silently something else
     with pytest.raises(NotImplementedError, match="num_layer_blocks"):
-        MLPDisc(23, num_layer_blocks=3, use_bn=False, ctx=object())
+        MLPDisc(23, num_layer_blocks=4, use_bn=False, ctx=object())
 
 
 @pytest.mark.gpu
