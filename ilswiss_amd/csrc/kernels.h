@@ -985,6 +985,8 @@ struct PhaseCArgs {
   float* polyak_T; const float* polyak_P; int polyak_n; float polyak_tau;
 };
 
+static_assert(sizeof(PhaseAArgs) <= 4096 && sizeof(PhaseCArgs) <= 4096, "phase-kernel descriptors travel in the kernel-argument segment (4 KB)");
+
 #ifdef ILSX_KERNEL_IMPL
 __device__ __forceinline__ void xch_arrive(unsigned* flag) {   // every thread of the workgroup calls it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's exchange stores are acknowledged by the L2
