@@ -86,13 +86,22 @@ class DeviceRLAlgorithm:
                  num_epochs=100, num_steps_per_epoch=10000, num_steps_between_train_calls=20, num_steps_per_eval=1000,
                  max_path_length=1000, min_steps_before_training=5000, replay_buffer_size=10000, no_terminal=False,
                  eval_deterministic=False, freq_saving=1, save_best=False, save_replay_buffer=False, replay_buffer=None, log_dir=None,
-                 best_key="AverageReturn", bootstrap_open_segments=True, eval_on_device=True, insert_at_episode_end=False, **kwargs):
+                 best_key="AverageReturn", bootstrap_open_segments=True, eval_on_device=True, insert_at_episode_end=False,
+                 eval_policy=None, eval_sampler=None, save_epoch=False, save_best_starting_from_epoch=0, eval_no_terminal=False,
+                 wrap_absorbing=False, render=False, render_kwargs=None, freq_log_visuals=1, eval_preprocess_func=None):
         # keyword names and DEFAULTS are BaseAlgorithm's (base_algorithm.py:21-54); batch_size and num_train_steps_per_train_call have
         # none there either (torch_rl_algorithm.py:8-10).  Every shipped spec states all of them; log_dir / bootstrap_open_segments /
         # eval_on_device / insert_at_episode_end are ilswiss_amd keys.
         # insert_at_episode_end (an ilswiss_amd key, default off): the fused rollout keeps the reference's replay order — samples enter
         # the ring when their episode ends, contiguous and registered in _traj_endpoints (base_algorithm.py:509-519) — instead of
         # inserting every transition as it happens
+        # BaseAlgorithm takes no **kwargs (an unknown key is a TypeError there, and here); of its own keys the ones below select machinery
+        # this loop does not have: asking for them fails loudly instead of training something else
+        for name, val in (("eval_no_terminal", eval_no_terminal), ("wrap_absorbing", wrap_absorbing), ("render", render),
+                          ("eval_preprocess_func", eval_preprocess_func)):
+            if val:
+                raise NotImplementedError(f"DeviceRLAlgorithm({name}={val!r}) is not implemented (base_algorithm.py:46-53)")
+        self.save_epoch, self.save_best_starting_from_epoch = bool(save_epoch), int(save_best_starting_from_epoch)
         if insert_at_episode_end and hasattr(training_env, "set_path_mode"):
             training_env.set_path_mode(True)
         self.no_terminal = bool(no_terminal)   # base_algorithm.py:195-196,208-210: stored terminal flags forced to False
@@ -112,10 +121,11 @@ class DeviceRLAlgorithm:
             seed = int(np.random.randint(10000))  # base_algorithm.py:118-120
             replay_buffer = EnvReplayBuffer(replay_buffer_size, env, random_seed=seed, ctx=trainer.ctx)
         self.replay_buffer = replay_buffer
-        eval_policy = MakeDeterministic(exploration_policy) if eval_deterministic else exploration_policy
+        if eval_policy is None:   # base_algorithm.py:87-92
+            eval_policy = MakeDeterministic(exploration_policy) if eval_deterministic else exploration_policy
         # evaluation runs on the device unless asked otherwise (the host-walked VecPathSampler is the reference's own loop)
         sampler_cls = DeviceEvalSampler if (eval_on_device and hasattr(eval_env, "h")) else VecPathSampler
-        self.eval_sampler = sampler_cls(eval_env, eval_policy, num_steps_per_eval, max_path_length)
+        self.eval_sampler = eval_sampler if eval_sampler is not None else sampler_cls(eval_env, eval_policy, num_steps_per_eval, max_path_length)
         self.logger = TabularLogger(log_dir)
         self._n_env_steps_total = self._n_train_steps_total = self._n_prev_train_env_steps = self._n_grad_steps_total = 0
         self._n_rollouts_total, self.best_statistic_so_far = 0, -np.inf
@@ -224,9 +234,11 @@ class DeviceRLAlgorithm:
         snap = dict(epoch=epoch, statistics=dict(st))
         if self.freq_saving and epoch % self.freq_saving == 0:
             lg.save("params.pkl", dict(snap, **self.get_epoch_snapshot()))
+        if self.save_epoch:   # base_algorithm.py:647-649
+            lg.save(f"epoch{epoch}.pkl", dict(snap, **self.get_epoch_snapshot()))
         if st[self.best_key] > self.best_statistic_so_far:
             self.best_statistic_so_far = st[self.best_key]
-            if self.save_best:
+            if self.save_best and epoch >= self.save_best_starting_from_epoch:   # :650-656
                 lg.save("best.pkl", dict(snap, **self.get_epoch_snapshot()))
         lg.save("extra_data.pkl", self.get_extra_data_to_save(epoch))
         return st

@@ -79,7 +79,9 @@ def experiment(variant, gpu=0, log_dir=None):
                 "disc_momentum", "use_grad_pen", "grad_pen_weight", "rew_clip_min", "rew_clip_max")
     trainer = AdvIRLTrainer(p["mode"], disc, sac, expert_rb, **{k: p[k] for k in irl_keys if k in p})   # adv_irl.py:34-54 defaults otherwise
     loop_keys = ("num_epochs", "num_steps_per_epoch", "num_steps_between_train_calls", "max_path_length", "min_steps_before_training",
-                 "eval_deterministic", "num_steps_per_eval", "replay_buffer_size", "no_terminal", "save_best", "freq_saving")
+                 "eval_deterministic", "num_steps_per_eval", "replay_buffer_size", "no_terminal", "save_best", "freq_saving",
+                 "save_epoch", "save_best_starting_from_epoch", "save_replay_buffer", "best_key", "eval_no_terminal", "wrap_absorbing",
+                 "render", "freq_log_visuals")   # every BaseAlgorithm key of adv_irl_params (base_algorithm.py:21-54): honoured or refused, never dropped
     alg = {k: p[k] for k in loop_keys if k in p}
     algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env, exploration_policy=policy,
                                   log_dir=log_dir, num_train_steps_per_train_call=p.get("num_update_loops_per_train_call", 1),

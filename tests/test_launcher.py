@@ -155,4 +155,9 @@ def test_loop_driver_defaults_are_base_algorithms():
                 save_best=False, best_key="AverageReturn", no_terminal=False, eval_deterministic=False)
     assert {k: P[k].default for k in want} == want
     assert P["batch_size"].default is inspect.Parameter.empty and P["num_train_steps_per_train_call"].default is inspect.Parameter.empty
+    # no **kwargs, as in the reference: a misspelt or unsupported key is an error, not a silently different run
+    assert not any(p.kind == p.VAR_KEYWORD for p in P.values())
+    for k, dflt in (("eval_policy", None), ("eval_sampler", None), ("save_epoch", False), ("save_best_starting_from_epoch", 0),
+                    ("eval_no_terminal", False), ("wrap_absorbing", False), ("render", False), ("freq_log_visuals", 1), ("eval_preprocess_func", None)):
+        assert P[k].default == dflt, k
 
