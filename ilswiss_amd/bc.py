@@ -8,7 +8,7 @@ import numpy as np
 
 from . import _lib
 from .device import as_dev
-from .sac import Trainer
+from .sac import Trainer, check_swallowed_kwargs
 
 _MODES = dict(MLE=0, MSE=1)
 
@@ -19,6 +19,7 @@ class BC(Trainer):
         assert mode in _MODES, "Invalid mode!"           # bc.py:26
         if kwargs.get("wrap_absorbing"):
             raise NotImplementedError()                  # bc.py:27-28
+        check_swallowed_kwargs(kwargs, "BC")
         self.mode, self.policy, self.ctx = mode, policy, policy.ctx
         self.expert_replay_buffer, self.batch_size = expert_replay_buffer, int(batch_size)
         self.num_updates_per_train_call = int(num_updates_per_train_call)

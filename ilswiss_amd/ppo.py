@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from .device import as_dev
 from .networks import Mlp
-from .sac import Trainer
+from .sac import Trainer, check_swallowed_kwargs
 
 
 class ReparamMultivariateGaussianPolicy(Mlp):
@@ -56,6 +56,7 @@ class PPO(Trainer):
     def __init__(self, policy, vf, mini_batch_size=64, clip_eps=0.2, reward_scale=1.0, discount=0.99, policy_lr=3e-4,
                  value_lr=3e-4, gae_tau=0.9, value_l2_reg=1e-3, use_value_clip=False, update_epoch=10,
                  lambda_entropy_policy=0.0, max_samples=16384, **kwargs):
+        check_swallowed_kwargs(kwargs, "PPO")
         self.on_policy = True  # ppo.py:30
         self.policy, self.vf, self.ctx = policy, vf, policy.ctx
         if vf.act != 1 or policy.act != 1:

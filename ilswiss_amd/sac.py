@@ -13,6 +13,18 @@ from . import _lib
 from .device import RawView, as_dev, get_context
 
 
+def check_swallowed_kwargs(kwargs, who):
+    """The reference's trainers take **kwargs and ignore what they do not know; two of the keys they DO read select something libilsx
+    does not have — another optimiser than Adam (`optimizer_class`, e.g. sac_alpha.py:35) or another critic criterion than MSE
+    (`qf_criterion`, td3.py:36): those fail loudly, everything else is swallowed as in the reference."""
+    oc = kwargs.get("optimizer_class")
+    if oc is not None and getattr(oc, "__name__", oc) != "Adam":
+        raise NotImplementedError(f"{who}(optimizer_class={getattr(oc, '__name__', oc)}): libilsx implements torch.optim.Adam")
+    qc = kwargs.get("qf_criterion")
+    if qc is not None and type(qc).__name__ not in ("MSELoss", "str") and getattr(qc, "__name__", "") != "MSELoss":
+        raise NotImplementedError(f"{who}(qf_criterion={qc!r}): libilsx implements the MSE criterion")
+
+
 class Trainer(metaclass=abc.ABCMeta):  # rlkit/core/trainer.py:4-28
     @abc.abstractmethod
     def train_step(self, batch):
@@ -48,6 +60,7 @@ class SoftActorCritic(Trainer):
                  alpha_lr=3e-4, soft_target_tau=1e-2, alpha=0.2, train_alpha=True,
                  policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3, beta_1=0.9, target_entropy=None,
                  max_batch=1024, grad_world=1, **kwargs):
+        check_swallowed_kwargs(kwargs, "SoftActorCritic")
         self.policy, self.qf1, self.qf2 = policy, qf1, qf2
         self.ctx = policy.ctx
         self.reward_scale, self.discount, self.soft_target_tau = reward_scale, discount, soft_target_tau

@@ -9,7 +9,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
-from .sac import Trainer
+from .sac import Trainer, check_swallowed_kwargs
 from .td3 import _batch_ptrs, _stat_block
 
 
@@ -19,6 +19,7 @@ class SoftActorCriticV(Trainer):
     def __init__(self, policy, qf1, qf2, vf, reward_scale=1.0, discount=0.99, alpha=1.0, policy_lr=1e-3, qf_lr=1e-3,
                  vf_lr=1e-3, soft_target_tau=1e-2, policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3, beta_1=0.9,
                  max_batch=1024, **kwargs):
+        check_swallowed_kwargs(kwargs, "SoftActorCritic")
         self.policy, self.qf1, self.qf2, self.vf, self.ctx = policy, qf1, qf2, vf, policy.ctx
         self.reward_scale = reward_scale
         cfg = _lib.SacvCfg(reward_scale, discount, alpha, policy_lr, qf_lr, vf_lr, soft_target_tau, policy_mean_reg_weight,

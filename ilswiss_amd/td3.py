@@ -10,7 +10,7 @@ import numpy as np
 from . import _lib
 from .device import as_dev
 from .networks import Mlp
-from .sac import Trainer
+from .sac import Trainer, check_swallowed_kwargs
 
 _STAT4 = ("Mean", "Std", "Max", "Min")
 
@@ -71,6 +71,7 @@ class TD3(Trainer):
                  soft_target_tau=0.005, max_batch=1024, her=False, clip_return_l=0.0, clip_return_r=0.0, **kwargs):
         # target_policy_noise* are accepted and, like in the reference (td3.py:46-47 store them, nothing reads them),
         # unused: the target policy is policy.copy() and adds the policy module's own noise.
+        check_swallowed_kwargs(kwargs, "TD3")
         self.policy, self.qf1, self.qf2, self.ctx = policy, qf1, qf2, policy.ctx
         self.reward_scale = reward_scale
         cfg = _lib.Td3Cfg(reward_scale, discount, policy_lr, qf_lr, int(policy_and_target_update_period), soft_target_tau,

@@ -2,6 +2,8 @@
 import glob
 import os
 
+import pytest
+
 import numpy as np
 import yaml
 
@@ -160,4 +162,20 @@ def test_loop_driver_defaults_are_base_algorithms():
     for k, dflt in (("eval_policy", None), ("eval_sampler", None), ("save_epoch", False), ("save_best_starting_from_epoch", 0),
                     ("eval_no_terminal", False), ("wrap_absorbing", False), ("render", False), ("freq_log_visuals", 1), ("eval_preprocess_func", None)):
         assert P[k].default == dflt, k
+
+
+def test_trainers_refuse_another_optimiser_or_criterion():
+    """sac_alpha.py:35 / td3.py:36-37: `optimizer_class`, `qf_criterion` are read by the reference; values libilsx does not implement raise."""
+    from ilswiss_amd.sac import check_swallowed_kwargs
+
+    class SGD:   # stands for torch.optim.SGD
+        pass
+
+    class Adam:
+        pass
+    check_swallowed_kwargs(dict(optimizer_class=Adam, env=None, foo=1), "X")   # Adam and unknown keys: fine, as in the reference
+    with pytest.raises(NotImplementedError, match="optimizer_class"):
+        check_swallowed_kwargs(dict(optimizer_class=SGD), "X")
+    with pytest.raises(NotImplementedError, match="qf_criterion"):
+        check_swallowed_kwargs(dict(qf_criterion=SGD()), "X")
 
