@@ -31,6 +31,19 @@ class Mlp:
                  b_init_value=0.1, layer_norm=False, batch_norm=False, ctx=None, seed=None, **kwargs):
         if layer_norm or batch_norm:
             raise NotImplementedError("layer_norm / batch_norm are off in every hot-path config (SURVEY §2 #15)")
+        # the rest of Mlp's keywords (networks.py:31-38): their defaults are what libilsx computes; another value is refused, not ignored.
+        # (`output_activation` is consumed by MlpGaussianNoisePolicy before it gets here — the one class that applies it.)
+        oa = kwargs.pop("output_activation", None)
+        if oa is not None and getattr(oa, "__name__", oa) != "identity":
+            raise NotImplementedError(f"Mlp(output_activation={getattr(oa, '__name__', oa)}): the head is linear (identity) here")
+        hi = kwargs.pop("hidden_init", None)
+        if hi is not None and getattr(hi, "__name__", hi) != "fanin_init":
+            raise NotImplementedError("Mlp(hidden_init=...): libilsx initialises hidden layers with ptu.fanin_init (pytorch_util.py:20-29)")
+        if kwargs.pop("batch_norm_before_output_activation", False):
+            raise NotImplementedError("batch_norm_before_output_activation")
+        kwargs.pop("layer_norm_kwargs", None)   # only read when layer_norm is on
+        if kwargs:
+            raise TypeError(f"{type(self).__name__}: unexpected keyword arguments {sorted(kwargs)}")
         hidden_sizes = list(hidden_sizes)
         if len(set(hidden_sizes)) != 1:
             raise ValueError("libilsx needs equal hidden widths")
