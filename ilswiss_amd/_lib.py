@@ -273,6 +273,8 @@ PROTOTYPES = {
     "ilsx_sac_get_alpha_opt": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), c_i64p, C.POINTER(C.c_uint64)]),
     "ilsx_sac_debug_batch": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ilsx_sac_debug_last_batch": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "ilsx_sac_phase_state": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ilsx_sac_debug_break_phase": (C.c_int, [vp]),
     "ilsx_sac_set_alpha_opt": (C.c_int, [vp, C.c_double, C.c_double, C.c_int64, C.c_uint64]),
 }
 

@@ -110,8 +110,11 @@ class MLPDisc:
                float(grad_pen_weight), int(max_batch))
         if self._bound == key:
             return self
-        if self.h is not None:
+        opt = None
+        if self.h is not None:   # re-bind (e.g. a forward on an unbound discriminator bound it with default settings): parameters AND the
+            from .snapshot import get_opt   # optimiser's moments / step count move to the new library object
             self._flat = self.get_flat_params()
+            opt = get_opt(self.ctx.lib, "disc", self.h, self._nphys)
             _lib.check(self.ctx.lib.ilsx_disc_destroy(self.h))
         cfg = _lib.DiscCfg(obs_dim, second_dim, self._Hp, _ACT[self.hid_act], int(bool(use_grad_pen)), self.clamp_magnitude,
                            disc_lr, disc_momentum, grad_pen_weight, int(max_batch), int(bool(state_only)), self.num_layer_blocks)
@@ -121,6 +124,9 @@ class MLPDisc:
         self.obs_dim, self.act_dim = obs_dim, second_dim
         self.use_grad_pen, self.grad_pen_weight, self.state_only = bool(use_grad_pen), grad_pen_weight, bool(state_only)
         self.set_flat_params(self._flat)
+        if opt is not None:
+            from .snapshot import set_opt
+            set_opt(self.ctx.lib, "disc", self.h, opt)
         return self
 
     def _need(self):
@@ -265,6 +271,7 @@ class AdvIRLTrainer:
         want = tr.eval_statistics is None
         _lib.check(self.ctx.lib.ilsx_sac_train_step(tr.h, obs.ptr, act.ptr, rew.ptr, done.ptr, nobs.ptr, self.Bp, None, None,
                                                     C.byref(tr._stats) if want else None))
+        self._last_rew = "host"     # the relabelled rewards of this (the latest) policy batch stay in self._p: get_eval_statistics reads them
         if want:
             tr._fill_stats()
             r = rew.numpy()[: self.Bp]
@@ -292,6 +299,8 @@ class AdvIRLTrainer:
                                               "Disc Rew Min": rs[3]})
         if want_p:
             tr._fill_stats()
+        if n_calls * self.loops > 0 and self.m > 0:
+            self._last_rew = "staged"   # the last relabelled batch sits in the agent's batch arrays until the next call
 
     # ---- what DeviceRLAlgorithm asks of a trainer
     def train_from_replay(self, replay_buffer, n_loops, batch_size):
@@ -325,9 +334,25 @@ class AdvIRLTrainer:
         if "disc_optimizer" in snap:
             set_opt(self.disc.ctx.lib, "disc", self.disc.h, snap["disc_optimizer"])
 
+    def _last_disc_rewards(self):
+        """The relabelled rewards of the most recent policy batch (still on the device), or None before the first policy step."""
+        src = getattr(self, "_last_rew", None)
+        if src is None:
+            return None
+        if src == "host":
+            return self._p[2].numpy()[: self.Bp]
+        buf = self.ctx.empty((self.Bp,))
+        _lib.check(self.ctx.lib.ilsx_sac_debug_last_batch(self.policy_trainer.h, self.Bp, None, None, buf.ptr, None, None, None))
+        return buf.numpy()
+
     def get_eval_statistics(self):
         st = OrderedDict()
         st.update(self.disc_eval_statistics or {})
+        # "Disc Rew *": the reference overwrites the four entries after EVERY policy step (adv_irl.py:303-314), so what an epoch logs are
+        # the rewards of its LAST relabelled batch; the discriminator's own entries are those of the epoch's first batch (:205-216)
+        r = self._last_disc_rewards() if st else None
+        if r is not None and "Disc Rew Mean" in st:
+            st.update({"Disc Rew Mean": float(r.mean()), "Disc Rew Std": float(r.std()), "Disc Rew Max": float(r.max()), "Disc Rew Min": float(r.min())})
         st.update(self.policy_trainer.get_eval_statistics() or {})
         return st
 

@@ -157,7 +157,13 @@ int sac_step_staged(ilsx_sac* s, ilsx_sac_stats* stats);
 int sac_dims(const ilsx_sac* s, int* o, int* a);
 int sac_window_begin(ilsx_sac* s, int B);   // steps on staged batches with the deferred tail + phase kernels (ilsx_sac.hip)
 int sac_window_step(ilsx_sac* s);
-int sac_window_end(ilsx_sac* s);
+int sac_window_end(ilsx_sac* s);            // ILSX_RETRY_WINDOW: the window's phase kernels reported a broken hand-off — roll back and re-run
+// internal status (never crosses the C ABI): a window of steps that ran on the merged phase kernels has to be rolled back
+// (sac_snapshot_restore) and run again; the agent has switched itself to one launch per stage
+#define ILSX_RETRY_WINDOW (-1000)
+int sac_snapshot_take(ilsx_sac* s);         // checkpoint of scalars | parameters | gradients | Adam moments (one device-to-device copy)
+int sac_snapshot_restore(ilsx_sac* s);
+bool sac_window_may_use_phase(ilsx_sac* s, int B);
 // column-split factor the 2-hidden-layer fast path uses for width H (1 = generic kernels)
 int mlp2_split_factor(int n_hidden, int H);
 int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* fuse = nullptr);

@@ -323,6 +323,12 @@ static int kernels_init_once() {
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+#define SET_MT(AA, MM) HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, true, 0, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, true, 1, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, true, 2, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_bwd_split<256, AA, 4, true, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
+  SET_MT(ACT_RELU, 2); SET_MT(ACT_RELU, 4); SET_MT(ACT_TANH, 2); SET_MT(ACT_TANH, 4);
+#undef SET_MT
 #define SET_PHASE(HH, AA, CC) HIPCHK(hipFuncSetAttribute((const void*)k_sac_phase_a<HH, AA, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
   HIPCHK(hipFuncSetAttribute((const void*)k_sac_phase_c<HH, AA, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
   SET_PHASE(256, ACT_RELU, 4); SET_PHASE(256, ACT_TANH, 4); SET_PHASE(128, ACT_RELU, 2); SET_PHASE(128, ACT_TANH, 2);
@@ -365,8 +371,26 @@ static size_t fwd_split_lds_bytes(int H, int KP, int cs) {
   return sizeof(float) * (16 * (KP + ILSX_LDS_PAD) + 16 * (H + ILSX_LDS_PAD) + 16 * (H / cs + ILSX_LDS_PAD) +
                           4 * (4 * H / cs / 64) * 4 * 64);
 }
-static size_t bwd_split_lds_bytes(int H, int cs) {
-  return sizeof(float) * (16 * (H + ILSX_LDS_PAD) + 16 * (H / cs + ILSX_LDS_PAD) + 16 * ILSX_MAX_NO);
+static size_t bwd_split_lds_bytes(int H, int cs, int mt = 1) {
+  return sizeof(float) * mt * (16 * (H + ILSX_LDS_PAD) + 16 * (H / cs + ILSX_LDS_PAD) + 16 * ILSX_MAX_NO);
+}
+// macro tiles (fwd_split_tile.inc, MT > 1): mt row tiles per workgroup; ph = the forward's phase (0 whole, 1 layer 0 only, 2 layer 1 + heads);
+// not_max = the widest head of the launch in 16-output tiles, a_max = the widest finished policy (log-prob staging shares the partial-tile region)
+static size_t fwd_split_lds_bytes_mt(int H, int KP, int cs, int mt, int ph, int not_max, int a_max) {
+  const size_t mr = 16 * (size_t)mt, nwv = 4 * H / cs / 64;
+  size_t fl = mr * (H / cs + ILSX_LDS_PAD);                       // hs
+  if (ph != 2) fl += mr * (KP + ILSX_LDS_PAD);                    // xs
+  if (ph != 1) fl += mr * (H + ILSX_LDS_PAD);                     // h0
+  const size_t part = ph == 1 ? 0 : (size_t)mt * std::max(not_max, 1) * nwv * 256, lp3 = ph == 2 ? 0 : mr * std::max(a_max, 1) * 3;
+  fl += std::max(part, lp3);
+  return sizeof(float) * fl;
+}
+// the grouped macro-tile launches run on a 1-D grid (GrpSwizzle, kernels.h)
+static int grp_swizzle_fill(GrpSwizzle* S, int ntasks, int agents, int rows, int mt) {
+  if (agents < 1 || ntasks % agents) ILSX_FAIL(ILSX_ERR_ARG, "grouped launch: %d tasks do not divide over %d agents", ntasks, agents);
+  S->agents = agents; S->tpa = ntasks / agents; S->tiles = (rows + 16 * mt - 1) / (16 * mt);
+  S->np8 = (agents * S->tiles + 7) / 8;
+  return ILSX_OK;
 }
 
 int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int cs) {
@@ -374,6 +398,25 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
   FwdArgs A = A0;
   A.dbg = ctx->dbg_next();
   ProfScope ps(ctx, ILSX_K_MLP_FWD);
+  if (cs > 1 && A.tasks && A.mt > 1) {   // grouped launch on macro tiles: 1-D grid, (agent, tile) -> XCD fixed across the lock-step's launches
+    if (!(H == 256 && cs == 4) || (A.mt != 2 && A.mt != 4)) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "macro-tile forward: H=%d cs=%d mt=%d", H, cs, A.mt);
+    A.xs = 0; A.rt = 1;
+    ILSX_TRY(grp_swizzle_fill(&A.swz, A.ntasks, A.swz.agents, A.rows, A.mt));
+    const unsigned nwork = 8u * A.swz.np8 * A.swz.tpa * cs;
+    if (A.tail_mode && (!A.tail || A.tail_n < 1)) ILSX_FAIL(ILSX_ERR_ARG, "deferred tail: bad record table");
+    const dim3 grid(nwork + (A.tail_mode ? A.tail_n : 0)), gridw(nwork), block(4 * H / cs);
+#define MT_CALL(AA, PP, MM, GR, AR) do { const size_t lds = fwd_split_lds_bytes_mt(H, KPmax, cs, MM, PP, A.mt_not, A.mt_a); \
+      if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward macro tile needs %zu B of LDS (> 160 KiB)", lds); \
+      ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, AA, 4, true, PP, MM>), GR, block, lds, ctx->stream, AR); } while (0)
+#define MT_CALL_PH(AA, MM) do { if (A.l0_split) { FwdArgs A2 = A; A2.tail_mode = 0; A2.tail = nullptr; A2.tail_n = 0; A2.dbg = ctx->dbg_next(); \
+      MT_CALL(AA, 1, MM, grid, A); MT_CALL(AA, 2, MM, gridw, A2); } else { MT_CALL(AA, 0, MM, grid, A); } } while (0)
+    if (act == ILSX_ACT_RELU) { if (A.mt == 2) MT_CALL_PH(ACT_RELU, 2); else MT_CALL_PH(ACT_RELU, 4); }
+    else { if (A.mt == 2) MT_CALL_PH(ACT_TANH, 2); else MT_CALL_PH(ACT_TANH, 4); }
+#undef MT_CALL_PH
+#undef MT_CALL
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   if (cs > 1) {
     const size_t lds = fwd_split_lds_bytes(H, KPmax, cs);
     if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "forward tile needs %zu B of LDS (> 160 KiB)", lds);
@@ -428,14 +471,36 @@ int device_cus(ilsx_ctx* ctx) {
   }
   return n_cu;
 }
+static size_t phase_lds_bytes(int H, int KP, int cs) { return std::max(fwd_split_lds_bytes(H, KP, cs), bwd_split_lds_bytes(H, cs)); }
+// workgroups of a phase kernel one CU holds at once (registers, LDS): what the runtime's occupancy calculator says for the launch shape
+void phase_wgs_per_cu(int H, int cs, int* occ_a, int* occ_c) {
+  static int oa[2] = {-1, -1}, oc[2] = {-1, -1};
+  const int i = H == 256 ? 0 : 1;
+  if (oa[i] < 0) {
+    int a = 0, c = 0;
+    const size_t lds = phase_lds_bytes(H, 32, cs);
+    hipError_t e1, e2;
+    if (H == 256) { e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void*)k_sac_phase_a<256, ACT_RELU, 4>, 4 * H / cs, lds);
+                    e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, (const void*)k_sac_phase_c<256, ACT_RELU, 4>, 4 * H / cs, lds); }
+    else { e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void*)k_sac_phase_a<128, ACT_RELU, 2>, 4 * H / cs, lds);
+           e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, (const void*)k_sac_phase_c<128, ACT_RELU, 2>, 4 * H / cs, lds); }
+    oa[i] = e1 == hipSuccess ? std::max(a, 1) : 1;   // a launch that runs at all holds one workgroup per CU
+    oc[i] = e2 == hipSuccess ? std::max(c, 1) : 1;
+  }
+  *occ_a = oa[i]; *occ_c = oc[i];
+}
 bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks) {
   const int n_cu = device_cus(ctx);
   if (!((H == 256 && cs == 4) || (H == 128 && cs == 2))) return false;
-  const int tiles = (rows + 15) / 16, gx = (tiles + 7) & ~7;
-  (void)gx;   // padding tiles and the extra bookkeeping row exit at once: only the working workgroups have to be co-resident
-  return tiles <= PHASE_MAX_TILES && tiles * ntasks * cs <= n_cu;
+  const int tiles = (rows + 15) / 16, work = tiles * ntasks * cs;
+  // (padding tiles and the idle part of the bookkeeping rows exit at once.)  Two conditions: the launch is the latency shape the phase kernels
+  // are built for — at most one working workgroup per CU — and EVERY workgroup another one waits for is resident at once by the device's own
+  // occupancy figure, not by assumption: phase A = its four task rows plus the bookkeeping row's tail workgroup, whose flag the critics'
+  // backward waits for (+1); phase C = its three working rows (nobody waits for its bookkeeping row, which may run after them)
+  int occ_a = 1, occ_c = 1;
+  phase_wgs_per_cu(H, cs, &occ_a, &occ_c);
+  return tiles <= PHASE_MAX_TILES && work <= n_cu && work + 1 <= occ_a * n_cu && tiles * 3 * cs <= occ_c * n_cu;
 }
-static size_t phase_lds_bytes(int H, int KP, int cs) { return std::max(fwd_split_lds_bytes(H, KP, cs), bwd_split_lds_bytes(H, cs)); }
 
 int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P0, int H, int act, int KPmax, int cs) {
   PhaseAArgs P = P0;
@@ -480,6 +545,18 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
   A.dbg = ctx->dbg_next();
   if (A.ga_parts < 1) A.ga_parts = 1;
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
+  if (cs > 1 && A.tasks && A.mt > 1) {   // grouped launch on macro tiles (see launch_fwd)
+    if (!(H == 256 && cs == 4) || (A.mt != 2 && A.mt != 4)) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "macro-tile backward: H=%d cs=%d mt=%d", H, cs, A.mt);
+    A.xs = 0;
+    ILSX_TRY(grp_swizzle_fill(&A.swz, A.ntasks, A.swz.agents, A.rows, A.mt));
+    const dim3 grid(8u * A.swz.np8 * A.swz.tpa * cs), block(4 * H / cs);
+    const size_t lds = bwd_split_lds_bytes(H, cs, A.mt);
+    if (lds > 160 * 1024) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "backward macro tile needs %zu B of LDS (> 160 KiB)", lds);
+    if (act == ILSX_ACT_RELU) { if (A.mt == 2) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_RELU, 4, true, 2>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_RELU, 4, true, 4>), grid, block, lds, ctx->stream, A); }
+    else { if (A.mt == 2) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_TANH, 4, true, 2>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_TANH, 4, true, 4>), grid, block, lds, ctx->stream, A); }
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   if (cs > 1) {
     const size_t lds = bwd_split_lds_bytes(H, cs);
     A.xs = ctx->xcd_shift;

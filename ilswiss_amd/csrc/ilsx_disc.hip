@@ -352,6 +352,7 @@ struct ilsx_disc {
   float *given = nullptr, *gdx = nullptr, *dhead4 = nullptr;
   uint32_t rng_stream = 0;
   unsigned long long step_ctr = 0;
+  float* snap = nullptr;   // checkpoint of P | M | V | scalars for a window that is rolled back (ilsx_advirl_train)
   PartVal pv() const { return PartVal{raw, cs, 3 * cfg.max_batch}; }
 };
 
@@ -422,6 +423,7 @@ extern "C" int ilsx_disc_destroy(ilsx_disc* d) {
   if (d->given) ctx_free(d->ctx, d->given);
   if (d->gdx) ctx_free(d->ctx, d->gdx);
   if (d->dhead4) ctx_free(d->ctx, d->dhead4);
+  if (d->snap) ctx_free(d->ctx, d->snap);
   delete d;
   return ILSX_OK;
 }
@@ -746,13 +748,55 @@ extern "C" int ilsx_disc_reward(ilsx_disc* d, const float* obs, const float* act
 // AdvIRL._do_training (adv_irl.py:126-131): `loops` x { k discriminator steps ; m policy steps whose rewards are
 // relabelled by the discriminator (:256-301) }, with every batch drawn on the device from the two HBM replay rings
 // (get_batch, :106-113).  One C call per train call instead of ~6 per loop iteration from the host language.
+static int advirl_train_once(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* expert_rb, ilsx_replay* policy_rb, int loops,
+                             int disc_updates, int policy_updates, int disc_batch, int policy_batch, int mode, int has_min,
+                             float rew_clip_min, int has_max, float rew_clip_max, ilsx_disc_stats* disc_stats,
+                             ilsx_sac_stats* sac_stats, float* rew_stats4);
+// The policy steps of a call after the first run in a window on the agent's merged phase kernels where those fit (ilsx_sac.hip).  Their
+// tile-local hand-offs need the GPU to this process; when another process's kernels break them the window reports it at its end and
+// the WHOLE call is rolled back — agent and discriminator are checkpointed at entry (two device-to-device copies), the rings' and the
+// discriminator's draw counters with them — and run again on one launch per stage, which the agent then keeps.
 extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* expert_rb, ilsx_replay* policy_rb, int loops,
                                  int disc_updates, int policy_updates, int disc_batch, int policy_batch, int mode, int has_min,
                                  float rew_clip_min, int has_max, float rew_clip_max, ilsx_disc_stats* disc_stats,
                                  ilsx_sac_stats* sac_stats, float* rew_stats4) {
   if (!d || !sac || !expert_rb || !policy_rb || loops < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_advirl_train: bad argument");
-  if (disc_batch < 1 || disc_batch > d->cfg.max_batch || policy_batch < 1) ILSX_FAIL(ILSX_ERR_ARG, "batch sizes out of range");
   HIPCHK(hipSetDevice(d->ctx->device));
+  static const bool no_window = getenv("ILSX_ADVIRL_NO_WINDOW") != nullptr;
+  const bool checkpoint = !no_window && policy_batch >= 1 && sac_window_may_use_phase(sac, policy_batch);
+  const size_t n = d->L.n_int;
+  const unsigned long long c_e = expert_rb->sample_ctr, c_p = policy_rb->sample_ctr, c_d = d->step_ctr;
+  if (checkpoint) {
+    hipStream_t st = d->ctx->stream;
+    if (!d->snap) ILSX_TRY(ctx_alloc(d->ctx, (3 * n) * sizeof(float) + sizeof(DiscScalars), (void**)&d->snap, false));
+    HIPCHK(hipMemcpyAsync(d->snap, d->P, n * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->snap + n, d->M, n * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->snap + 2 * n, d->V, n * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->snap + 3 * n, d->scal, sizeof(DiscScalars), hipMemcpyDeviceToDevice, st));
+    ILSX_TRY(sac_snapshot_take(sac));
+  }
+  int rc = advirl_train_once(d, sac, expert_rb, policy_rb, loops, disc_updates, policy_updates, disc_batch, policy_batch, mode, has_min,
+                             rew_clip_min, has_max, rew_clip_max, disc_stats, sac_stats, rew_stats4);
+  if (rc == ILSX_RETRY_WINDOW) {
+    if (!checkpoint) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_advirl_train: a window asked for a roll-back without a checkpoint");
+    hipStream_t st = d->ctx->stream;
+    HIPCHK(hipMemcpyAsync(d->P, d->snap, n * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->M, d->snap + n, n * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->V, d->snap + 2 * n, n * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->scal, d->snap + 3 * n, sizeof(DiscScalars), hipMemcpyDeviceToDevice, st));
+    ILSX_TRY(sac_snapshot_restore(sac));
+    expert_rb->sample_ctr = c_e; policy_rb->sample_ctr = c_p; d->step_ctr = c_d;
+    rc = advirl_train_once(d, sac, expert_rb, policy_rb, loops, disc_updates, policy_updates, disc_batch, policy_batch, mode, has_min,
+                           rew_clip_min, has_max, rew_clip_max, disc_stats, sac_stats, rew_stats4);
+    if (rc == ILSX_RETRY_WINDOW) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_advirl_train: the fallback path asked for a retry");
+  }
+  return rc;
+}
+static int advirl_train_once(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* expert_rb, ilsx_replay* policy_rb, int loops,
+                             int disc_updates, int policy_updates, int disc_batch, int policy_batch, int mode, int has_min,
+                             float rew_clip_min, int has_max, float rew_clip_max, ilsx_disc_stats* disc_stats,
+                             ilsx_sac_stats* sac_stats, float* rew_stats4) {
+  if (disc_batch < 1 || disc_batch > d->cfg.max_batch || policy_batch < 1) ILSX_FAIL(ILSX_ERR_ARG, "batch sizes out of range");
   const int o = d->cfg.obs_dim, a = policy_rb->a;   // a: the env's action width (state_only discriminators have cfg.act_dim == obs_dim)
   const bool so = d->cfg.state_only != 0;
   const int nfe = d->from_expert;

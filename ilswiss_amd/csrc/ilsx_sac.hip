@@ -83,6 +83,11 @@ struct ilsx_sac {
   int* phase_err = nullptr;          // set by a workgroup whose wait timed out
   bool phase_now = false;            // this step runs on the phase kernels
   bool phase_broken = false;         // a timeout was seen once: stay on the 8-launch path
+  bool phase_last = false;           // the last window of steps ran on the phase kernels
+  bool debug_break = false;          // ilsx_sac_debug_break_phase
+  int phase_fallbacks = 0;           // windows rolled back and re-run (ilsx_sac_phase_state)
+  void* snap = nullptr;              // checkpoint of [scal | P | G | M | V] taken at the start of every window that may run on the phase kernels
+  size_t snap_bytes = 0;
   float* base(int which) const {
     switch (which) {
       case W_Q1: return P;
@@ -329,6 +334,7 @@ extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
   hipStreamSynchronize(s->ctx->stream);
   if (s->graph) hipGraphExecDestroy(s->graph);
   if (s->tail_dev) ctx_free(s->ctx, s->tail_dev);
+  if (s->snap) ctx_free(s->ctx, s->snap);
   // give the networks private storage back so their handles stay usable
   ilsx_net* nets[3] = {s->pi, s->q1, s->q2};
   const int wh[3] = {W_PI, W_Q1, W_Q2};
@@ -785,6 +791,7 @@ int sac_window_begin(ilsx_sac* s, int B) {
 int sac_window_step(ilsx_sac* s) {
   s->gather_rb = nullptr;
   s->phase_now = sac_phase_ok(s, s->B);
+  s->phase_last = s->phase_now;
   const int rc = sac_full_step(s);
   s->phase_now = false;
   return rc;
@@ -836,8 +843,27 @@ static bool sac_phase_possible(ilsx_sac* s, int B) {   // as sac_phase_ok, for t
   const bool off = getenv("ILSX_NO_PHASE") != nullptr;   // read per call: tests switch between the two paths in one process
   return !off && s->cs > 1 && !s->h0scr && !sac_is_split(s) && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
 }
+// Checkpoint / roll-back of everything a gradient step mutates — device scalars (log alpha and its moments, step / Philox counters,
+// Adam scalars), parameters + targets, gradients, Adam moments: one contiguous range of the agent's slab (ilsx_sac_create adds them
+// in this order).  Taken at the start of every window that may run on the merged phase kernels (~3 MB device-to-device, once per
+// train call); restored when the window's phase kernels reported a broken wait or placement, before the window is re-run.
+static size_t sac_snap_range(const ilsx_sac* s) { return (size_t)((const char*)(s->V + (2 * s->nq + s->np)) - (const char*)s->scal); }
+int sac_snapshot_take(ilsx_sac* s) {
+  const size_t n = sac_snap_range(s);
+  if (!s->snap) { ILSX_TRY(ctx_alloc(s->ctx, n, &s->snap, false)); s->snap_bytes = n; }
+  HIPCHK(hipMemcpyAsync(s->snap, s->scal, n, hipMemcpyDeviceToDevice, s->ctx->stream));
+  return ILSX_OK;
+}
+int sac_snapshot_restore(ilsx_sac* s) {
+  if (!s->snap) ILSX_FAIL(ILSX_ERR_STATE, "no checkpoint to roll back to");
+  HIPCHK(hipMemcpyAsync(s->scal, s->snap, s->snap_bytes, hipMemcpyDeviceToDevice, s->ctx->stream));
+  HIPCHK(hipMemsetAsync(s->phase_flags, 0, (size_t)PHASE_FLAG_WORDS * sizeof(unsigned), s->ctx->stream));
+  return ILSX_OK;
+}
+bool sac_window_may_use_phase(ilsx_sac* s, int B) { return !s->phase_broken && s->cs > 1 && !s->col && sac_phase_possible(s, B) && s->ctx->xcd_shift == 0; }
 // After a window of steps that may have run on the merged phase kernels: a workgroup that gave up waiting, or a row tile whose workgroups
-// sat on two XCDs, left a mark — the window's updates are then not to be trusted and the agent stays on one launch per stage.
+// sat on two XCDs, left a mark — the window's updates are then not to be trusted.  Returns ILSX_RETRY_WINDOW: the caller rolls the window
+// back (sac_snapshot_restore) and runs it again; the agent stays on one launch per stage from here on.
 static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who) {
   hipStream_t st = s->ctx->stream;
   if (deferred && !s->phase_broken && sac_phase_possible(s, B)) {
@@ -849,13 +875,16 @@ static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who) {
     HIPCHK(hipStreamSynchronize(st));
     for (int t = 0; t < PHASE_MAX_TILES; ++t)
       if (masks[t * 32] & (masks[t * 32] - 1)) err |= 2;   // a tile's workgroups ran on more than one XCD: its exchange went through two L2s
+    if (s->debug_break) { err |= 1; s->debug_break = false; }
     if (err) {
       s->phase_broken = true;
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
       HIPCHK(hipMemsetAsync(s->phase_err, 0, sizeof(int), st));
-      ILSX_FAIL(ILSX_ERR_HIP, "%s: a merged phase kernel %s; this agent falls back to one launch per stage from now on — "
-                "the call's updates are invalid", who, (err & 1) ? "timed out waiting for the workgroups of its tile (are other kernels sharing this GPU?)"
-                                                            : "found the workgroups of one row tile on different XCDs");
+      if (getenv("ILSX_PHASE_VERBOSE"))
+        fprintf(stderr, "[ilsx] %s: a merged phase kernel %s; the window is rolled back and re-run, this agent stays on one launch per stage\n", who,
+                (err & 1) ? "timed out waiting for the workgroups of its tile (other kernels sharing this GPU?)" : "found the workgroups of one row tile on different XCDs");
+      s->phase_fallbacks += 1;
+      return ILSX_RETRY_WINDOW;
     }
   }
   return ILSX_OK;
@@ -866,6 +895,7 @@ static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
   if (s->cs > 1) {
     s->gather_rb = rb;   // sampling is fused into the first forward launch
     s->phase_now = sac_phase_ok(s, B);
+    s->phase_last = s->phase_now;
     const int rc = sac_full_step(s);
     s->gather_rb = nullptr;
     s->phase_now = false;
@@ -875,7 +905,34 @@ static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
   return sac_full_step(s);
 }
 
+static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats);
 extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats) {
+  int rc = sac_train_from_replay_once(s, rb, n_steps, B, stats);
+  if (rc == ILSX_RETRY_WINDOW) {   // the phase kernels' hand-offs broke (shared GPU): back to the checkpoint, same steps on one launch per stage
+    ILSX_TRY(sac_snapshot_restore(s));
+    rc = sac_train_from_replay_once(s, rb, n_steps, B, stats);
+    if (rc == ILSX_RETRY_WINDOW) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_sac_train_from_replay: the fallback path asked for a retry");
+  }
+  return rc;
+}
+void phase_wgs_per_cu(int H, int cs, int* occ_a, int* occ_c);   // ilsx_core.hip
+extern "C" int ilsx_sac_phase_state(ilsx_sac* s, int* fallbacks, int* disabled, int* last_window_on_phase, int* wgs_per_cu_a, int* wgs_per_cu_c) {
+  if (!s) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_phase_state: NULL agent");
+  if (fallbacks) *fallbacks = s->phase_fallbacks;
+  if (disabled) *disabled = s->phase_broken ? 1 : 0;
+  if (last_window_on_phase) *last_window_on_phase = s->phase_last ? 1 : 0;
+  int oa = 0, oc = 0;
+  if (s->cs > 1 && (s->Lq.cfg.hidden == 256 || s->Lq.cfg.hidden == 128)) phase_wgs_per_cu(s->Lq.cfg.hidden, s->cs, &oa, &oc);
+  if (wgs_per_cu_a) *wgs_per_cu_a = oa;
+  if (wgs_per_cu_c) *wgs_per_cu_c = oc;
+  return ILSX_OK;
+}
+extern "C" int ilsx_sac_debug_break_phase(ilsx_sac* s) {   // test aid: the next window finds a "timed out" mark and takes the roll-back path
+  if (!s) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_debug_break_phase: NULL agent");
+  s->debug_break = true;
+  return ILSX_OK;
+}
+static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats) {
   if (!s || !rb || n_steps < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_train_from_replay: bad argument");
   if (B < 1 || B > s->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch=%d", B, s->cfg.max_batch);
   if (rb->o != s->o || rb->a != s->a) ILSX_FAIL(ILSX_ERR_ARG, "replay dims (%d,%d) != agent dims (%d,%d)", rb->o, rb->a, s->o, s->a);
@@ -894,6 +951,7 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
   ILSX_TRY(sac_defer_begin(s, B));
   struct DeferGuard { ilsx_sac* s; ~DeferGuard() { s->defer_tail = false; } } guard{s};   // never left on, whatever path returns
   const bool deferred = s->defer_tail;
+  if (deferred && sac_window_may_use_phase(s, B)) ILSX_TRY(sac_snapshot_take(s));   // the roll-back point of this window
   if (no_graph || s->ctx->prof_on) {
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
@@ -902,6 +960,7 @@ extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_st
     }
   } else {
     const bool phase = sac_phase_ok(s, B);
+    s->phase_last = phase;
     if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail || s->graph_phase != phase) {
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
       hipGraph_t g = nullptr;
@@ -1125,6 +1184,7 @@ struct ilsx_sac_group {
   std::vector<Stage> stages;
   TailLite* tails_lite = nullptr;   // deferred tail: one record per agent (see TailLite, kernels.h)
   bool defer = false;
+  int mt = 1;                       // 16-row tiles per workgroup of the forward / backward launches (macro tiles, fwd_split_tile.inc)
 };
 
 template <class T>
@@ -1142,6 +1202,7 @@ static void group_release_tables(ilsx_sac_group* g) {
   if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
 }
 
+static int group_pick_mt(const ilsx_sac_group* g, int B);
 // collect every agent's launch list for one fused step on (rbs, B) and merge stage by stage
 static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
   const int K = (int)g->agents.size();
@@ -1246,6 +1307,7 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
   HIPCHK(hipStreamSynchronize(g->ctx->stream));
   g->rbs.assign(rbs, rbs + K);
   g->B = B;
+  g->mt = group_pick_mt(g, B);
   return ILSX_OK;
 }
 
@@ -1254,6 +1316,16 @@ static int group_launch_tail(ilsx_sac_group* g, const void* tails, int deferred)
   ILSX_LAUNCH(ps, k_sac_tail_group, dim3((unsigned)g->agents.size()), dim3(256), 0, g->ctx->stream, (const SacTailItem*)tails, deferred);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
+}
+// Row tiles per workgroup of the grouped forward / backward launches.  ILSX_GRP_MT = 1 | 2 | 4 overrides; by default macro tiles are used
+// when the launches hold several workgroups per CU anyway (K >= 2 agents): the throughput shape — a wave's weight fragments, the
+// descriptor reads and the barriers are paid once per 16 MT rows; one agent alone keeps the latency shape (16 rows, most workgroups).
+static int group_pick_mt(const ilsx_sac_group* g, int B) {
+  const ilsx_sac* s0 = g->agents[0];
+  if (!(s0->Lq.cfg.hidden == 256 && s0->cs == 4)) return 1;
+  if (const char* e = getenv("ILSX_GRP_MT")) { const int v = atoi(e); return (v == 2 || v == 4) ? v : 1; }
+  if (g->agents.size() < 2 || B < 64) return 1;
+  return s0->h0scr ? 2 : 4;   // wide inputs stage 16 MT x KP floats of input per workgroup: two row tiles keep two workgroups per CU
 }
 static int group_launch_step(ilsx_sac_group* g) {
   ilsx_sac* s0 = g->agents[0];
@@ -1265,9 +1337,11 @@ static int group_launch_step(ilsx_sac_group* g) {
       FwdArgs A = st.f;
       if (g->defer && nfwd < 2) { A.tail = g->tails_lite; A.tail_mode = nfwd + 1; A.tail_n = K; }   // tail of the previous step / gather_step
       ++nfwd;
+      A.mt = g->mt; A.swz.agents = K; A.mt_a = s0->a;
+      A.mt_not = std::max((s0->Lp.NO + 15) / 16, (s0->Lq.NO + 15) / 16);
       ILSX_TRY(launch_fwd(g->ctx, A, H, act, st.KP, cs));
     }
-    else if (st.kind == 1) ILSX_TRY(launch_bwd_dx(g->ctx, st.b, H, act, cs));
+    else if (st.kind == 1) { BwdArgs A = st.b; A.mt = g->mt; A.swz.agents = K; ILSX_TRY(launch_bwd_dx(g->ctx, A, H, act, cs)); }
     else if (st.kind == 2) { AdamFuse on; memset(&on, 0, sizeof on); on.on = 1; ILSX_TRY(launch_bwd_dw(g->ctx, st.d, g->B, &on)); }
     else if (!g->defer) ILSX_TRY(group_launch_tail(g, st.tails, 0));
   }

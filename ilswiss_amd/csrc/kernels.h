@@ -20,6 +20,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define ILSX_LDS_PAD 4
+#ifndef ILSX_MT_WAVES
+#define ILSX_MT_WAVES 2   // waves per SIMD the macro-tile instantiations are compiled for (register budget 512 / this)
+#endif
 #define ILSX_MAX_HID 3
 #define ILSX_MAX_NO 64   // max total head outputs (n_heads*out_dim)
 
@@ -326,6 +329,25 @@ struct PolicyFinishArgs {
   float noise, noise_clip, max_act;   // head == HEAD_DET_TANH_NOISE (TD3): raw = pre-activation [rows][a]
   int use_gather_step;                // phase kernels: the Philox step is scal->gather_step (== the step counter once the pending tail has run)
 };
+// Grouped launches on a 1-D grid: workgroup -> (macro tile, task, column slice) such that the XCD a workgroup lands on (the dispatcher deals
+// workgroups to the 8 XCDs round-robin in linear order) depends on (agent, macro tile) ONLY — the same in every forward / backward launch
+// of the lock-step whatever its task count, so the activations of a row range stay in ONE XCD's L2 from the launch that writes them to the
+// launches that read them, and every XCD gets the same number of (agent, tile) pairs.  (With a (tiles, tasks, slices) grid padded to 8 in x,
+// four macro tiles per agent would put all work on XCDs 0-3.)   tpa = 0: off (3-D grid).
+struct GrpSwizzle { int tpa, tiles, agents, np8; };   // tasks per agent in this launch, macro tiles per agent, agents, ceil(agents*tiles/8)
+// decode: false = padding workgroup
+__device__ __forceinline__ bool grp_swizzle(const GrpSwizzle& S, int ncs, unsigned lin, int* bx, int* task, int* cs) {
+  const int xcd = lin & 7, q = lin >> 3;
+  const int pidx = q % S.np8, rest = q / S.np8;
+  const int p = pidx * 8 + xcd;
+  *cs = rest % ncs;
+  const int tk = rest / ncs;
+  if (p >= S.agents * S.tiles || tk >= S.tpa) return false;
+  const int ag = p / S.tiles;
+  *bx = p - ag * S.tiles;
+  *task = ag * S.tpa + tk;
+  return true;
+}
 struct FwdGroup;
 struct FwdArgs {
   FwdTask t[4];
@@ -346,6 +368,9 @@ struct FwdArgs {
   const struct TailLite* tail;   // column-split kernels, tail_mode != 0: the launch carries one extra y row whose first
   int tail_mode, tail_n;         //   workgroups (one per agent, tail_n of them) run the deferred tail (1) or advance gather_step (2)
   int l0_split;                  // wide inputs: layer 0 in a launch of its own, column-split like layer 1 (every task then has hsave[0])
+  int mt;                        // grouped launches: 16-row tiles per workgroup processed together (macro tile; 0 / 1 = one) — host side: picks the instantiation
+  int mt_not, mt_a;              //   host side (LDS sizing): the widest head of the launch's tasks in 16-output tiles, the widest finished policy
+  GrpSwizzle swz;                // grouped launches with a 1-D grid (see GrpSwizzle)
 };
 struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
 // one self-contained record per grid row: the task and its agent's per-launch state side by side, so a workgroup reaches
@@ -615,6 +640,8 @@ struct BwdArgs {
   int part_stride;          // column-split kernels: rows of one dx partial slab
   int xs;                   // XCD confinement (see FwdArgs)
   const BwdTask* tasks;     // grouped launch: descriptor table in device memory, indexed by blockIdx.y
+  int mt;                   // grouped launches: row tiles per workgroup (see FwdArgs::mt)
+  GrpSwizzle swz;
 };
 
 // dL/d(head output j) of row gr for the loss functor of task T (shared by the generic and the column-split
@@ -863,9 +890,24 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
 // (Humanoid: KP = 396) that recomputation is 6x the slice's own layer-1 work, so the forward runs as two launches of the same grid:
 // PH = 1 stages x (gather / policy epilogue as in PH 0) and computes THIS slice's 64 columns of layer 0 into hsave[0];
 // PH = 2 starts from hsave[0] (16 KB per tile, L2-resident) and does layer 1 + heads.
-template <int H, int ACT, int CS, bool GRP, int PH = 0>
-__global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) {
+template <int H, int ACT, int CS, bool GRP, int PH = 0, int MT = 1>
+__global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_mlp2_fwd_split(const FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(MT == 1 || GRP, "macro tiles are a grouped-launch shape");
+  int sw_bx = 0, sw_task = 0, sw_cs = 0;
+  if constexpr (GRP && MT > 1) {   // 1-D grid (GrpSwizzle); the deferred-tail workgroups follow the working ones
+    const unsigned nwork = 8u * A.swz.np8 * A.swz.tpa * CS;
+    if (blockIdx.x >= nwork) {
+      const int ag = blockIdx.x - nwork;
+      if (A.tail_mode && ag < A.tail_n) {
+        const TailLite& TL = A.tail[ag];
+        if (A.tail_mode == 1) tail_lite_run(TL, smem);
+        else if (threadIdx.x == 0) TL.scal->gather_step += 1;
+      }
+      return;
+    }
+    if (!grp_swizzle(A.swz, CS, blockIdx.x, &sw_bx, &sw_task, &sw_cs)) return;
+  } else {
   if (A.tail_mode && (int)blockIdx.y == A.ntasks) {   // the extra y row of a deferred-tail launch (an extra x column would shift
     const int ag = blockIdx.x + gridDim.x * blockIdx.z;  // the tile -> XCD mapping of every other workgroup, see launch_fwd)
     if (ag < A.tail_n) {
@@ -875,19 +917,21 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_fwd_split(const FwdArgs A) 
     }
     return;
   }
+  }
   // GRP: descriptor records in device memory, copied by value at entry (before any store) so that their fields are
   // loaded once with scalar loads; a reference would be re-read with vector loads after every store
   // !GRP: the record stays where it is, in the kernel-argument segment (constant address space): a field is a scalar load at its
   // use and, when registers run short, is loaded again instead of being parked in a VGPR lane.  Copying the record by value here
   // made ~100 scalars live at once: 196 v_writelane + 369 v_readlane in this kernel (a quarter of a wave's issue slots in the prologue).
   FwdTaskG Rg;
-  if (GRP) Rg = A.tasks[blockIdx.y];
-  const FwdTask& T = GRP ? Rg.t : A.t[blockIdx.y];
+  const int ty = (GRP && MT > 1) ? sw_task : (int)blockIdx.y;
+  if (GRP) Rg = A.tasks[ty];
+  const FwdTask& T = GRP ? Rg.t : A.t[ty];
   const FwdGroup* GP = GRP ? &Rg.g : nullptr;
   // the body is shared as TEXT with the merged phase kernels (see fwd_split_tile.inc for why it is not a device function)
   constexpr bool XCH = false;
-  const int bx = blockIdx.x, cs = blockIdx.z;
-  const bool first_task = blockIdx.y == 0;
+  const int bx = (GRP && MT > 1) ? sw_bx : (int)blockIdx.x, cs = (GRP && MT > 1) ? sw_cs : (int)blockIdx.z;
+  const bool first_task = ty == 0;
 #define XCH_HOOK_STAGE
 #define XCH_HOOK_FIN
 #include "fwd_split_tile.inc"
@@ -937,14 +981,20 @@ __global__ __launch_bounds__(64) void k_policy_finish(const PolicyFinishArgs P) 
   if (P.logp) P.logp[gr] = -0.5f * lp_quad - (lp_ls + HALF_LOG_2PI) - lp_jac;
 }
 
-template <int H, int ACT, int CS, bool GRP>
-__global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) {
+template <int H, int ACT, int CS, bool GRP, int MT = 1>
+__global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_mlp2_bwd_split(const BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(MT == 1 || GRP, "macro tiles are a grouped-launch shape");
+  int sw_bx = 0, sw_task = 0, sw_cs = 0;
+  if constexpr (GRP && MT > 1) {
+    if (!grp_swizzle(A.swz, CS, blockIdx.x, &sw_bx, &sw_task, &sw_cs)) return;
+  }
+  const int ty = (GRP && MT > 1) ? sw_task : (int)blockIdx.y;
   BwdTask Tg;
-  if (GRP) Tg = A.tasks[blockIdx.y];   // by value at entry (see k_mlp2_fwd_split)
-  const BwdTask& T = GRP ? Tg : A.t[blockIdx.y];   // !GRP: read in place from the kernel-argument segment
+  if (GRP) Tg = A.tasks[ty];   // by value at entry (see k_mlp2_fwd_split)
+  const BwdTask& T = GRP ? Tg : A.t[ty];   // !GRP: read in place from the kernel-argument segment
   constexpr bool XCH = false;
-  const int bx = blockIdx.x, cs = blockIdx.z;
+  const int bx = (GRP && MT > 1) ? sw_bx : (int)blockIdx.x, cs = (GRP && MT > 1) ? sw_cs : (int)blockIdx.z;
 #define XCH_HOOK_ACT
 #define XCH_HOOK_HEAD
 #include "bwd_split_tile.inc"
@@ -967,8 +1017,11 @@ __global__ __launch_bounds__(4 * H / CS) void k_mlp2_bwd_split(const BwdArgs A) 
 //   policy-on-next_obs slices alone (phase A: all the target critics wait for), counter PHASE_TAIL_FLAG = "the
 //   deferred tail of the previous step has run" (alpha is valid).  The preceding dW launch zeroes them (DwArgs::zero_flags).  After the
 //   counters: one word per tile in which every workgroup ORs the XCD it runs on (checked by the host: one bit per tile or the call fails).
-//   A workgroup that waits longer than ~50 ms sets *err and goes on (the host then fails the call and falls back to 8 launches): the
-//   co-residency the protocol needs holds by construction, the bound only keeps a broken assumption from hanging the GPU.
+//   A workgroup that waits longer than ~50 ms sets *err and goes on; the host then ROLLS THE WINDOW BACK (parameters, optimiser state and
+//   counters are checkpointed at the start of every window: one device-to-device copy) and re-runs it on one launch per stage, where it
+//   stays (ilsx_sac.hip sac_phase_check).  The co-residency the protocol needs holds on a GPU this process has to itself; another
+//   process's kernels on the same GPU (the reference's launcher runs all workers of a sweep on one GPU, run_experiment.py:57-78) can
+//   break it, and then costs one bounded wait, not the run.
 #define PHASE_MAX_TILES 64
 #define PHASE_TAIL_FLAG (3 * PHASE_MAX_TILES)
 #define PHASE_NFLAGS (3 * PHASE_MAX_TILES + 1)
@@ -998,7 +1051,11 @@ __device__ __forceinline__ void xch_wait(const unsigned* flag, unsigned target, 
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 16)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      ++spins;
+      if (spins > (1 << 16)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      // a wait of this window already gave up (the host will roll the window back and re-run it on one launch per stage, ilsx_sac.hip
+      // sac_phase_check): do not sit out the bound again in every later wait of the window
+      if ((spins & 255) == 255 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
   }
   __syncthreads();
@@ -1074,7 +1131,7 @@ __device__ __forceinline__ void policy_fin_tile(const PolicyFinishArgs& P, int r
 template <int H, int ACT, int CS>
 __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) {
   constexpr bool GRP = false, XCH = true;
-  constexpr int PH = 0;
+  constexpr int PH = 0, MT = 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const FwdGroup* GP = nullptr;
   const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;
@@ -1166,7 +1223,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
 template <int H, int ACT, int CS>
 __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) {
   constexpr bool GRP = false, XCH = true;
-  constexpr int PH = 0;
+  constexpr int PH = 0, MT = 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const FwdGroup* GP = nullptr;
   const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;

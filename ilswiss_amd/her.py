@@ -233,8 +233,7 @@ class DeviceHindsightReplayBuffer(HindsightReplayBuffer):
         self.observation_key, self.desired_goal_key, self.achieved_goal_key = observation_key, desired_goal_key, achieved_goal_key
         self.d_obs, self.d_goal = int(np.prod(spaces[observation_key].shape)), int(np.prod(spaces[desired_goal_key].shape))
         assert int(np.prod(spaces[achieved_goal_key].shape)) == self.d_goal
-        self.reward_kind = 0 if getattr(env, "reward_type", "sparse") == "sparse" else 1
-        self.threshold = float(getattr(env, "distance_threshold", getattr(env, "tol", 0.05)))
+        self.reward_kind, self.threshold = device_reward_rule(env)
         self.ctx = ctx or get_context()
         self._C, self._lib = C, _lib
         self.h = C.c_void_p()
@@ -312,6 +311,42 @@ class DeviceHindsightReplayBuffer(HindsightReplayBuffer):
                     terminals=batch["terminals"].numpy().reshape(B, 1).astype(np.uint8))
 
 
+def device_reward_rule(env):
+    """(kind, threshold) of the ONE reward rule the device-side relabel implements (k_her_gather): gym's robotics GoalEnv rule on the
+    Euclidean goal distance d — kind 0 'sparse': -(d > distance_threshold), kind 1 'dense': -d.  Raises for anything else: an env whose
+    reward_type is neither, or a sparse rule without a threshold attribute (`distance_threshold`, or `tol` of the stand-in env)."""
+    rt = getattr(env, "reward_type", "sparse")
+    if rt not in ("sparse", "dense"):
+        raise NotImplementedError(f"DeviceHindsightReplayBuffer: reward_type={rt!r}; the device rule knows 'sparse' and 'dense' (use HindsightReplayBuffer)")
+    thr = getattr(env, "distance_threshold", getattr(env, "tol", None))
+    if rt == "sparse" and thr is None:
+        raise NotImplementedError("DeviceHindsightReplayBuffer: a sparse goal reward needs env.distance_threshold")
+    return (0 if rt == "sparse" else 1), float(thr if thr is not None else 0.0)
+
+
+def device_reward_rule_matches(env, d_goal, n=512, seed=0):
+    """Does env.compute_reward (what the reference calls on every relabelled row, relabel_replay_buffer.py:37-40) equal the device rule?
+    Probed on n random goal pairs whose distances straddle the threshold (and some exact copies: d = 0).  False on any mismatch, shape
+    surprise or exception — e.g. gym's HandManipulate* tasks, which expose distance_threshold but also test a rotation_threshold."""
+    try:
+        kind, thr = device_reward_rule(env)
+        rs = np.random.RandomState(seed)
+        ag = rs.uniform(-1, 1, (n, d_goal)).astype(np.float32)
+        scale = (thr if kind == 0 and thr > 0 else 0.5) * rs.uniform(0, 3, (n, 1)) / np.sqrt(d_goal)
+        dg = (ag + scale * rs.uniform(-1, 1, (n, d_goal))).astype(np.float32)
+        dg[: n // 16] = ag[: n // 16]
+        d = np.linalg.norm(ag.astype(np.float64) - dg.astype(np.float64), axis=-1)
+        if kind == 0:
+            keep = np.abs(d - thr) > 1e-4 * max(thr, 1e-6)     # rows within fp32 rounding of the threshold decide nothing
+            want = -(d > thr).astype(np.float64)
+        else:
+            keep, want = np.ones(n, bool), -d
+        got = np.asarray(env.compute_reward(ag, dg, None), np.float64).reshape(-1)
+        return got.shape == want.shape and bool(np.allclose(got[keep], want[keep], rtol=1e-5, atol=1e-6))
+    except Exception:
+        return False
+
+
 class Box:
     def __init__(self, low, high):
         self.low, self.high = np.asarray(low, np.float32), np.asarray(high, np.float32)
@@ -365,10 +400,13 @@ class HER:
                  min_steps_before_training=1000, batch_size=128, replay_buffer_size=100000, num_steps_per_eval=500, **kwargs):
         assert max_path_length < replay_buffer_size
         self.trainer, self.env, self.policy = trainer, env, exploration_policy
-        # the device-resident buffer (batches never cross PCIe) when the env exposes gym's GoalEnv reward rule; the host buffer otherwise
-        # (an arbitrary python `compute_reward` can only run on the host)
-        cls = DeviceHindsightReplayBuffer if (hasattr(env, "distance_threshold") or hasattr(env, "tol")) and hasattr(trainer, "ctx") \
-            else HindsightReplayBuffer
+        # the device-resident buffer (batches never cross PCIe) only when the env's OWN compute_reward is the rule the device implements —
+        # checked by evaluating it on a probe batch, not inferred from attribute names; the host buffer (which calls compute_reward on
+        # every relabelled row like relabel_replay_buffer.py:37-40) otherwise
+        spaces = getattr(getattr(env, "observation_space", None), "spaces", None)
+        ok = hasattr(trainer, "ctx") and spaces is not None and "desired_goal" in spaces and \
+            device_reward_rule_matches(env, int(np.prod(spaces["desired_goal"].shape)))
+        cls = DeviceHindsightReplayBuffer if ok else HindsightReplayBuffer
         kw = dict(ctx=trainer.ctx) if cls is DeviceHindsightReplayBuffer else {}
         self.replay_buffer = replay_buffer or cls(replay_buffer_size, env, random_seed=np.random.randint(10000),
                                                   relabel_type=relabel_type, her_ratio=her_ratio, **kw)

@@ -21,8 +21,10 @@ def check_swallowed_kwargs(kwargs, who):
     if oc is not None and getattr(oc, "__name__", oc) != "Adam":
         raise NotImplementedError(f"{who}(optimizer_class={getattr(oc, '__name__', oc)}): libilsx implements torch.optim.Adam")
     qc = kwargs.get("qf_criterion")
-    if qc is not None and type(qc).__name__ not in ("MSELoss", "str") and getattr(qc, "__name__", "") != "MSELoss":
-        raise NotImplementedError(f"{who}(qf_criterion={qc!r}): libilsx implements the MSE criterion")
+    if qc is not None:   # an nn.MSELoss instance, the class itself, or its name; anything else (L1Loss, "huber", ...) is refused, not trained as MSE
+        name = qc if isinstance(qc, str) else (getattr(qc, "__name__", None) or type(qc).__name__)
+        if name.lower() not in ("mseloss", "mse"):
+            raise NotImplementedError(f"{who}(qf_criterion={qc!r}): libilsx implements the MSE criterion")
 
 
 class Trainer(metaclass=abc.ABCMeta):  # rlkit/core/trainer.py:4-28
@@ -60,7 +62,7 @@ class SoftActorCritic(Trainer):
                  alpha_lr=3e-4, soft_target_tau=1e-2, alpha=0.2, train_alpha=True,
                  policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3, beta_1=0.9, target_entropy=None,
                  max_batch=1024, grad_world=1, **kwargs):
-        check_swallowed_kwargs(kwargs, "SoftActorCritic")
+        check_swallowed_kwargs(kwargs, type(self).__name__)
         self.policy, self.qf1, self.qf2 = policy, qf1, qf2
         self.ctx = policy.ctx
         self.reward_scale, self.discount, self.soft_target_tau = reward_scale, discount, soft_target_tau
@@ -109,6 +111,14 @@ class SoftActorCritic(Trainer):
                                                            C.byref(self._stats) if want else None))
         if want:
             self._fill_stats()
+
+    def phase_state(self):
+        """How the merged phase kernels of this agent's train windows are doing (include/ilsx.h ilsx_sac_phase_state): a shared GPU can
+        break their in-launch hand-offs; the library then rolls the window back, re-runs it on one launch per stage and stays there."""
+        v = [C.c_int() for _ in range(5)]
+        _lib.check(self.ctx.lib.ilsx_sac_phase_state(self.h, *[C.byref(x) for x in v]))
+        return dict(fallbacks=v[0].value, disabled=bool(v[1].value), last_window_on_phase=bool(v[2].value),
+                    wgs_per_cu_a=v[3].value, wgs_per_cu_c=v[4].value)
 
     def _fill_stats(self):  # sac_alpha.py:186-233
         s, st = self._stats, OrderedDict()

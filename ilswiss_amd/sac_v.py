@@ -19,7 +19,7 @@ class SoftActorCriticV(Trainer):
     def __init__(self, policy, qf1, qf2, vf, reward_scale=1.0, discount=0.99, alpha=1.0, policy_lr=1e-3, qf_lr=1e-3,
                  vf_lr=1e-3, soft_target_tau=1e-2, policy_mean_reg_weight=1e-3, policy_std_reg_weight=1e-3, beta_1=0.9,
                  max_batch=1024, **kwargs):
-        check_swallowed_kwargs(kwargs, "SoftActorCritic")
+        check_swallowed_kwargs(kwargs, "SoftActorCriticV")
         self.policy, self.qf1, self.qf2, self.vf, self.ctx = policy, qf1, qf2, vf, policy.ctx
         self.reward_scale = reward_scale
         cfg = _lib.SacvCfg(reward_scale, discount, alpha, policy_lr, qf_lr, vf_lr, soft_target_tau, policy_mean_reg_weight,

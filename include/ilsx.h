@@ -221,6 +221,17 @@ int ilsx_sac_train_step(ilsx_sac* sac, const float* obs, const float* act, const
 /* TorchRLAlgorithm._do_training (torch_rl_algorithm.py:28-34): n_steps x (random_batch + train_step)
  * with on-device sampling; one hipGraph replay per step, no host round trip. */
 int ilsx_sac_train_from_replay(ilsx_sac* sac, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats);
+/* A single run's steps inside ilsx_sac_train_from_replay / ilsx_advirl_train run on merged "phase" kernels whose workgroups hand data to
+ * each other inside one launch; that needs the GPU to this process.  The reference's launcher starts every worker of a sweep on the SAME
+ * GPU (run_experiment.py:57-78), so the library checkpoints parameters / optimiser state / counters at the start of every such window
+ * and, if a hand-off timed out or a row tile's workgroups were placed on two XCDs, rolls the window back and re-runs it on one launch
+ * per stage (where the agent then stays): the caller sees the same updates either way.  This reports what happened:
+ * fallbacks = windows rolled back so far, disabled = 1 once the agent has left the phase kernels, last_window_on_phase = 1 if the most
+ * recent window used them, wgs_per_cu_a / _c = resident workgroups per CU the runtime's occupancy calculator gives the two kernels
+ * (what the "every waited-for workgroup is resident" check is made with).  Every output nullable. */
+int ilsx_sac_phase_state(ilsx_sac* sac, int* fallbacks, int* disabled, int* last_window_on_phase, int* wgs_per_cu_a, int* wgs_per_cu_c);
+/* test aid: the next window behaves as if one of its hand-offs had timed out (exercises the roll-back path on an exclusive GPU) */
+int ilsx_sac_debug_break_phase(ilsx_sac* sac);
 /* Split-run (multi-GPU) phases: train_step == critic_backward ; critic_update ; actor_backward ;
  * actor_update, with an all-reduce(sum) of the gradient arena between backward and update. */
 int ilsx_sac_set_batch(ilsx_sac* sac, const float* obs, const float* act, const float* rew,

@@ -40,12 +40,18 @@ if __name__ == "__main__":
         with open(paths[-1], "w") as f:
             yaml.dump(v, f, default_flow_style=False)
     workers = max(1, min(int(meta.get("num_workers", 1)) * args.gpus, len(paths)))
+    # Like the reference (run_experiment.py:57-78) all `num_workers` children of a GPU run on it at once.  A single run's train windows use
+    # merged "phase" kernels that want the GPU to themselves (include/ilsx.h ilsx_sac_phase_state); with company the library would notice,
+    # roll the first window back and leave them by itself — telling the children up front saves them that one bounded wait.
+    child_env = dict(os.environ)
+    if workers > args.gpus:
+        child_env.setdefault("ILSX_NO_PHASE", "1")
     running, nxt, failed = [], 0, 0
     while nxt < len(paths) or running:
         while nxt < len(paths) and len(running) < workers:
             cmd = [sys.executable, meta["script_path"], "-e", paths[nxt], "-g", str(args.gpu + nxt % args.gpus)]
             print(cmd, flush=True)
-            running.append(subprocess.Popen(cmd))
+            running.append(subprocess.Popen(cmd, env=child_env))
             nxt += 1
         time.sleep(0.5)
         still = []

