@@ -631,7 +631,11 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     return ILSX_OK;
   }
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
-  if (D.gtiles) {
+  if (D.gtiles && D.strip) {
+    bool whole = (rows & 255) == 0;   // whole 256-row trips, and every matrix contracts over the batch rows (grouped tables hold no row-stacked jobs: group_build)
+    if (whole) ILSX_LAUNCH(ps, (k_dw_strip<true, true>), dim3(D.ntiles), dim3(64), 0, ctx->stream, D);
+    else ILSX_LAUNCH(ps, (k_dw_strip<true, false>), dim3(D.ntiles), dim3(64), 0, ctx->stream, D);
+  } else if (D.gtiles) {
     const int gnh = D.tile_nh ? D.tile_nh : 2, gkt = D.tile_kt ? D.tile_kt : 4;
     if (gnh == 2 && gkt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 2, 4>), dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
     else if (gnh == 1 && gkt == 2) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 1, 2>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 2), ctx->stream, D);

@@ -1260,7 +1260,12 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
       // matters for small groups (K = 1, 2: +4 %); at K >= 4 the launch is bound elsewhere and every shape measures the same
       static const int gshape = []() { const char* e = getenv("ILSX_DW_TILE_GRP"); return e ? atoi(e) : 0; }();   // "NH KT" digits, 0 = by size
       int gnh = 2, gkt = 4;
-      if (gshape) { gnh = gshape / 10; gkt = gshape % 10; }
+      // the throughput shape (k_dw_strip: one wavefront per 16 x 64 output strip, no cross-wave reduction) once the launch holds several
+      // agents' matrices; one agent alone keeps the small tiles that spread its few outputs over the chip.  ILSX_DW_GRP_STRIP = 0 | 1 overrides
+      const char* se = getenv("ILSX_DW_GRP_STRIP");
+      const bool strip = se ? atoi(se) != 0 : (K >= 2 && !gshape);
+      if (strip) { gnh = 1; gkt = 4; }
+      else if (gshape) { gnh = gshape / 10; gkt = gshape % 10; }
       else {
         auto count = [&](int nh, int kt) {
           long long n = 0;
@@ -1274,7 +1279,7 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
         if (count(1, 1) <= cap) { gnh = 1; gkt = 1; }
         else if (count(1, 2) <= cap) { gnh = 1; gkt = 2; }
       }
-      st.d.tile_nh = gnh; st.d.tile_kt = gkt;
+      st.d.tile_nh = gnh; st.d.tile_kt = gkt; st.d.strip = strip ? 1 : 0;
       for (int k = 0; k < K; ++k) {
         const DwArgs& D = cols[k].L[i].d;
         for (int m = 0; m < D.nmat; ++m, ++nmat) {

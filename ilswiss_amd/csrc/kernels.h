@@ -1326,6 +1326,7 @@ struct DwArgs {
   const struct DwTileG* gtiles;
   unsigned* zero_flags;   // non-null: workgroup 0 zeroes the PHASE_NFLAGS arrival counters of the phase kernel that follows this launch
   int tile_nh, tile_kt;   // grouped launches: the tile shape the gtiles table was built for (0 = 2 x 4); host-side only
+  int strip;              // grouped launches: the table is one record per 16 x 64 output strip of k_dw_strip (one wavefront each); host-side only
 };
 struct DwTileG { DwMat J; AdamFuse F; };
 #define DW_SPLIT_MIN_ROWS 1024
@@ -1505,6 +1506,212 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
     if (F.on) adam_apply(F, ad_step, ad_bc2s, aob, (size_t)(gbp - F.Gbase), 0, false, s);
   }
   ILSX_STAMP(D.dbg, 7);
+}
+
+// ---- the weight gradients in throughput shape (grouped launches: K co-resident runs).  ONE wavefront (a 64-thread workgroup) owns a
+// 16 (n) x 64 (k) output strip completely: it runs all eight row-eighth contractions k_mlp_bwd_dw spreads over eight waves — eight
+// accumulator sets, the same MFMA chain per row-eighth (rows rc + 128 u + 4 g + s, u = 0..1, s = 0..3, per 256-row trip) — and adds
+// the eight partial tiles in the order that kernel's LDS reduction adds them (r8 = 0..7), so every gradient, moment and parameter
+// is bit-identical to the tiled kernel's.  What goes away: the 16-wave workgroup whose barrier waits for its slowest wave, the 8-way
+// reduction through LDS, and 15 of 16 descriptor reads; what stays in LDS is one wave-private 16 x 16 transpose per output block
+// (accumulator order -> address order of the packed layouts: every optimiser stream of the epilogue then moves whole 16-byte words
+// per lane, 1 KiB per instruction).  The second packing of a hidden -> hidden matrix is updated from ITS OWN copies of P / M / V / T
+// (identical to the first packing's by construction: both are written with the same values by every kernel) instead of from values
+// carried across lanes.  256 MFMAs per strip.
+#define DW_STRIP_LDS_FLOATS (4 * 16 * 20)
+template <bool GRP, bool WHOLE>   // WHOLE: the contraction is whole 256-row trips (host-checked), no row guards
+__global__ __launch_bounds__(64, 2) void k_dw_strip(const DwArgs D) {
+  __shared__ __attribute__((aligned(16))) float tile[DW_STRIP_LDS_FLOATS];   // [4 k tiles][16 n][20: 16 k + pad]
+  static_assert(GRP, "the strip shape is a grouped-launch shape");
+  const DwTileG Rg = D.gtiles[blockIdx.x];   // by value at entry: scalar loads (blockIdx is uniform)
+  const DwMat& J = Rg.J;
+  const AdamFuse& F = Rg.F;
+  const int local = blockIdx.x - J.tile0;
+  const int n0 = (local / J.ktiles) * 16, k0 = (local % J.ktiles) * 64;
+  const int rows = J.rows > 0 ? J.rows : D.rows_all, brows = J.rows > 0 ? J.bias_rows : D.rows_all;
+  const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+  const bool n_ok = n0 + li < J.NA;
+  int ntk = (J.NB - k0 + 15) / 16;
+  if (ntk > 4) ntk = 4;
+  bool k_ok[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) k_ok[t] = k0 + 16 * t + li < J.NB;
+  float ad_step = 0.f, ad_bc2s = 1.f;
+  if (F.on) { ad_step = *F.step_size; ad_bc2s = *F.bc2_sqrt; }
+  f32x4 acc[8][4];
+  float bs[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    bs[w] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[w][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_bias = J.db != nullptr && k0 == 0;
+  // operand addresses: one pointer per lane and operand column (columns past the matrix are clamped onto its last one and the value
+  // dropped by a select, so that no load sits under a branch: a predicated load costs ~8 instructions of mask handling, and this kernel
+  // lives on instruction issue); rows need no clamp when the batch is whole 256-row trips (the SAC batch), else the guarded form below
+  // (the table's pointers come out of memory, so the compiler knows no address space for them and would emit FLAT loads, which count on
+  //  both memory counters and force full waits between batches; they are global memory)
+  typedef const float __attribute__((address_space(1)))* gfptr;
+  const gfptr pa = (gfptr)(J.A + (size_t)(4 * g) * J.lda + (n_ok ? n0 + li : J.NA - 1));
+  gfptr pb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) pb[t] = (gfptr)(J.Bm + (size_t)(4 * g) * J.ldb + (k_ok[t] ? k0 + 16 * t + li : J.NB - 1));
+  for (int rc0 = 0; rc0 < rows; rc0 += 256) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {   // row-eighth w of this 256-row trip: rows rc0 + 16 w + {0..15} and + 128
+      const int rc = rc0 + 16 * w;
+      if (rc >= rows) continue;   // uniform (the tiled kernel's wave w does not take this trip either)
+      float a[2][4], b[2][4][4];
+      if constexpr (WHOLE) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const size_t ro = (size_t)(rc + 128 * u + s4);   // uniform part of the row index (the lane's 4 g is in the pointers)
+            const float av = pa[ro * J.lda];
+            a[u][s4] = n_ok ? av : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const float bv = pb[t][ro * J.ldb]; b[u][t][s4] = k_ok[t] ? bv : 0.0f; }
+          }
+      } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int r = rc + 128 * u + 4 * g + s4;
+          const bool r_ok = r < rows;
+          a[u][s4] = (r_ok && n_ok) ? J.A[(size_t)r * J.lda + n0 + li] : 0.0f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) b[u][t][s4] = (r_ok && k_ok[t]) ? J.Bm[(size_t)r * J.ldb + k0 + 16 * t + li] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[w][t] = MFMA16(a[u][s4], b[u][t][s4], acc[w][t]);   // k tiles past the matrix contract zeros and are not stored
+        }
+      if (want_bias) {   // uniform; same order of additions as the tiled kernel (u, then s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            if constexpr (WHOLE) bs[w] += a[u][s4];   // whole trips and no row-stacked jobs (host-checked): every row feeds the bias
+            else bs[w] += (rc + 128 * u + 4 * g + s4 < brows) ? a[u][s4] : 0.0f;
+          }
+      }
+    }
+  }
+  // ---- the eight partial tiles in r8 order (k_mlp_bwd_dw: s = 0; s += part[r8])
+  f32x4 out[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    out[t] = (f32x4){0.f, 0.f, 0.f, 0.f};   // (0 + part[0] like the tiled kernel: a -0 partial ends as +0 there too)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { out[t][0] += acc[w][t][0]; out[t][1] += acc[w][t][1]; out[t][2] += acc[w][t][2]; out[t][3] += acc[w][t][3]; }
+  }
+  // accumulator order (lane = column k, register = row n = 4 g + v) -> LDS [t][n][k]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) tile[(t * 16 + 4 * g + v) * 20 + li] = out[t][v];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wavefront: its LDS operations execute in order, this only keeps the compiler from moving the reads up
+  const int nl = lane & 15, q4 = lane >> 4;   // address order of a forward-packed / natural block: lane <-> (n = lane % 16, k = 4 (lane / 16) .. + 3)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t >= ntk) continue;   // uniform
+    const int n = n0 + nl, k = k0 + 16 * t + 4 * q4;
+    const float4 gv = *reinterpret_cast<const float4*>(tile + (t * 16 + nl) * 20 + 4 * q4);
+    const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    if (J.mode == DW_OUT_NATURAL) {   // row-major [NA][ldw]: heads (NB = H: k + 3 < NB whenever k < NB, H is a multiple of 16)
+      if (n < J.NA && k < J.NB) {
+        float* gp = J.dW + (size_t)n * J.ldw + k;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (k + c < J.NB) {
+            gp[c] = gs[c];
+            if (F.on) { const AdamOperands o = adam_prefetch(F, (size_t)(gp + c - F.Gbase)); adam_apply(F, ad_step, ad_bc2s, o, (size_t)(gp + c - F.Gbase), 0, false, gs[c]); }
+          }
+        }
+      }
+    } else if (n < J.NA && k < J.NB) {   // forward-packed block: 4 consecutive floats per lane (k % 4 = 0..3).  NA, NB are multiples of 16 for packed matrices
+      float* gp = J.dW + pack_f(n, k, J.ldw);
+      const size_t i0 = (size_t)(gp - F.Gbase);
+      float4 p4, m4, v4, t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (F.on) {
+        p4 = *reinterpret_cast<const float4*>(F.P + i0); m4 = *reinterpret_cast<const float4*>(F.M + i0); v4 = *reinterpret_cast<const float4*>(F.V + i0);
+        if (F.T) t4 = *reinterpret_cast<const float4*>(F.T + i0);
+      }
+      *reinterpret_cast<float4*>(gp) = gv;
+      if (F.on) {
+        float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {   // adam_apply's expressions, in its order
+          const float gg = gs[c] + F.l2x2 * pp[c];
+          const float m = mm[c] * F.b1 + (1.0f - F.b1) * gg;
+          const float v = vv[c] * F.b2 + (1.0f - F.b2) * gg * gg;
+          const float pn = pp[c] - ad_step * (m / (sqrtf(v) / ad_bc2s + F.eps));
+          mm[c] = m; vv[c] = v; pp[c] = pn;
+          if (F.T) tt[c] = tt[c] * (1.0f - F.tau) + pn * F.tau;
+        }
+        *reinterpret_cast<float4*>(F.M + i0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *reinterpret_cast<float4*>(F.V + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        *reinterpret_cast<float4*>(F.P + i0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        if (F.T) *reinterpret_cast<float4*>(F.T + i0) = make_float4(tt[0], tt[1], tt[2], tt[3]);
+      }
+    }
+    if (J.mode == DW_OUT_PACK_FB) {   // second packing: lane <-> (k = lane % 16, n = 4 (lane / 16) .. + 3); its own P / M / V / T copies
+      const int kb = k0 + 16 * t + nl, nb = n0 + 4 * q4;
+      if (nb < J.NA && kb < J.NB) {
+        float gb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gb[c] = tile[(t * 16 + 4 * q4 + c) * 20 + nl];
+        float* gp = J.dWb + pack_b(nb, kb, J.NA);
+        const size_t i1 = (size_t)(gp - F.Gbase);
+        float4 p4, m4, v4, t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (F.on) {
+          p4 = *reinterpret_cast<const float4*>(F.P + i1); m4 = *reinterpret_cast<const float4*>(F.M + i1); v4 = *reinterpret_cast<const float4*>(F.V + i1);
+          if (F.T) t4 = *reinterpret_cast<const float4*>(F.T + i1);
+        }
+        *reinterpret_cast<float4*>(gp) = make_float4(gb[0], gb[1], gb[2], gb[3]);
+        if (F.on) {
+          float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float gg = gb[c] + F.l2x2 * pp[c];
+            const float m = mm[c] * F.b1 + (1.0f - F.b1) * gg;
+            const float v = vv[c] * F.b2 + (1.0f - F.b2) * gg * gg;
+            const float pn = pp[c] - ad_step * (m / (sqrtf(v) / ad_bc2s + F.eps));
+            mm[c] = m; vv[c] = v; pp[c] = pn;
+            if (F.T) tt[c] = tt[c] * (1.0f - F.tau) + pn * F.tau;
+          }
+          *reinterpret_cast<float4*>(F.M + i1) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+          *reinterpret_cast<float4*>(F.V + i1) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+          *reinterpret_cast<float4*>(F.P + i1) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+          if (F.T) *reinterpret_cast<float4*>(F.T + i1) = make_float4(tt[0], tt[1], tt[2], tt[3]);
+        }
+      }
+    }
+  }
+  // ---- bias gradients (strips with k0 == 0): per row-eighth the sum over the four lane groups as the tiled kernel's two shuffles form it,
+  //      then the eighths in r8 order
+  if (want_bias) {   // uniform
+    float sb = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      float x = bs[w];
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      sb += x;
+    }
+    if (g == 0 && n_ok) {
+      float* gbp = J.db + n0 + li;
+      *gbp = sb;
+      if (F.on) { const AdamOperands o = adam_prefetch(F, (size_t)(gbp - F.Gbase)); adam_apply(F, ad_step, ad_bc2s, o, (size_t)(gbp - F.Gbase), 0, false, sb); }
+    }
+  }
 }
 
 // Sum the row-range slabs of a split weight-gradient launch in slab order, store the gradient, and apply the optimiser

@@ -530,13 +530,19 @@ def test_train_from_replay_graph_equals_direct_and_learns(ctx, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("o,a", [(11, 3), (111, 8)])   # narrow: one-launch forward ; Ant widths: the two-phase forward (kernels.h PH 1 / 2)
-def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx, o, a):
+@pytest.mark.parametrize("knobs", [{}, {"ILSX_GRP_MT": "2"}, {"ILSX_GRP_MT": "4"}, {"ILSX_GRP_MT": "1", "ILSX_DW_GRP_STRIP": "0"}],
+                         ids=["default", "mt2", "mt4", "tiles16"])
+@pytest.mark.parametrize("o,a,B", [(11, 3, 256), (111, 8, 256), (17, 6, 100)])   # narrow: one-launch forward ; Ant widths: the two-phase forward (kernels.h PH 1 / 2) ; a ragged batch
+def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx, o, a, B, knobs, monkeypatch):
     """K=3 co-resident seeds stepped by ONE launch per stage (ilsx_sac_group) == each agent stepped alone with
-    ilsx_sac_train_from_replay: same kernels, same per-agent Philox streams, so every parameter is bit-identical."""
+    ilsx_sac_train_from_replay: same per-agent Philox streams, and per 16-row tile / per output element the same chain of MFMAs
+    whatever the launch shape — macro tiles of 2 or 4 row tiles per workgroup on the XCD-stable 1-D grid (fwd_split_tile.inc MT,
+    GrpSwizzle), weight gradients as one-wavefront strips (k_dw_strip) or as 8-wave tiles — so every parameter is bit-identical."""
     import ilswiss_amd as ia
     from ilswiss_amd.replay import SimpleReplayBuffer
-    hid, B, K, n = [256, 256], 256, 3, 7
+    for k_, v_ in knobs.items():
+        monkeypatch.setenv(k_, v_)
+    hid, K, n = [256, 256], 3, 7
     rng = np.random.default_rng(5)
     N = 5000
     data = [(rng.normal(0, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),

@@ -9,10 +9,14 @@ for lib in ilswiss_amd/libilsx.so ilswiss_amd/libilsx_w1.so; do
   [ -f $lib ] || continue
   for mt in 1 2 4; do
     if [ $mt = 1 ] && [ $lib != ilswiss_amd/libilsx.so ]; then continue; fi
-    for cfg in "hopper 8" "hopper 4" "hopper 16" "humanoid 4" "walker 8"; do
+    for cfg in "hopper 8" "hopper 4" "humanoid 4" "walker 8"; do
       ILSX_LIB=$lib ILSX_GRP_MT=$mt timeout 120 python tools/grp_sweep.py $cfg 1500 >> $out 2>> gpurun_out/grp_sweep.err || echo "{\"failed\": \"$lib $mt $cfg\"}" >> $out
     done
   done
+done
+# the weight gradients as 8-wave tiles instead of one-wavefront strips (ILSX_DW_GRP_STRIP=0), at the default macro tile
+for cfg in "hopper 8" "humanoid 4"; do
+  ILSX_DW_GRP_STRIP=0 timeout 120 python tools/grp_sweep.py $cfg 1500 | sed 's/"mt": "default"/"mt": "default, dW tiles"/' >> $out 2>> gpurun_out/grp_sweep.err
 done
 python - <<'PY'
 import json
