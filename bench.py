@@ -226,6 +226,27 @@ def cpu_env_baseline(ncpu):
         dt = lib.orc_planar_bench(C.byref(ms), n_env, n_steps, 1000, threads, C.byref(cs))
         res[f"threads_{threads}"] = dict(env_steps_per_s=n_env * n_steps / dt, sample=f"{n_env} envs x {n_steps} steps in {dt:.2f} s")
     res["note"] = "oracle/planar_env.c (gcc -O2, dense formulation of oracle/planar_env.py), Hopper model, uniform actions, auto-reset"
+    res["humanoid"] = cpu_env3d_baseline(ncpu)
+    return res
+
+
+def cpu_env3d_baseline(ncpu):
+    """The same for BASELINE config 5's env: env-steps/s of oracle/spatial_env.c — the scalar compiled restatement of the
+    3-D stepper's oracle (== oracle/spatial_env.py to 1e-9, tests/test_env3d_oracle.py) — on the Humanoid-v2 model, one core and every core."""
+    from ilswiss_amd.envs.models3d import humanoid
+    from ilswiss_amd.envs.vecenv import spatial_struct
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_build", "liborc_spatial.so")
+    if not os.path.exists(so):
+        return dict(error="oracle/_build/liborc_spatial.so not built (__graft_entry__.build() / make -C oracle)")
+    lib = C.CDLL(so)
+    lib.orc_spatial_bench.restype = C.c_double
+    ms, cs, res = spatial_struct(humanoid()), C.c_double(), {}
+    for threads, n_env, n_steps in ((1, 16, 60), (ncpu, 1024, 200 if ncpu >= 32 else 40)):
+        lib.orc_spatial_bench(C.byref(ms), n_env, 2, 1000, threads, C.byref(cs))      # warm (thread pool)
+        dt = lib.orc_spatial_bench(C.byref(ms), n_env, n_steps, 1000, threads, C.byref(cs))
+        res[f"threads_{threads}"] = dict(env_steps_per_s=n_env * n_steps / dt, sample=f"{n_env} envs x {n_steps} steps in {dt:.2f} s")
+    res["note"] = ("oracle/spatial_env.c (gcc -O2, dense Jacobian formulation of oracle/spatial_env.py), Humanoid-v2 model (23 dof, 376-dim "
+                   "observation), uniform actions, auto-reset; beside k_env3dw_step<23> in `humanoid_4x1024`")
     return res
 
 

@@ -117,3 +117,46 @@ def test_ant_task_formulas_and_settling():
         q, v, ob, rew, done = P.step(q, v, np.zeros(8))
     assert not done and 0.25 < q[2] < 0.8 and np.abs(v).max() < 2.0      # dropped from 0.75 onto its legs, at rest above the floor
     assert np.all(q[7:][1::2] * np.array([1, -1, -1, 1]) > 0.3)          # the ankle limits (30..70 deg) have pushed the lower legs in range
+
+
+def test_c_restatement_matches_the_numpy_oracle():
+    """oracle/spatial_env.c (the compiled CPU baseline of bench.py's Humanoid env-steps/s) == oracle/spatial_env.py over
+    chained steps with ground contacts, violated joint limits and terminations, for both 3-D models: state, observation (all 376 / 111
+    entries, cinert / cvel / qfrc_actuator included), reward and done."""
+    import ctypes as C
+    import os
+    import subprocess
+    from ilswiss_amd.envs.vecenv import spatial_struct
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle")], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(root, "oracle", "_build", "liborc_spatial.so"))
+    lib.orc_spatial_bench.restype = C.c_double
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    for make in (humanoid, ant):
+        m = make()
+        S, ms = SpatialOracle(m), spatial_struct(m)
+        assert lib.orc_spatial_obs_dim(C.byref(ms)) == m["obs_dim"]
+        rng = np.random.default_rng(11)
+        nv, na = m["nv"], m["act_dim"]
+        dones = []
+        for trial in range(5):
+            q, v = S.reset(rng)
+            q[2] += rng.uniform(-0.25, 0.15)                       # some start in the ground (contacts)
+            if trial == 4:                                         # the last trial starts outside the healthy band (done): Humanoid z < 1, Ant z > 1
+                q[2] = 0.8 if make is humanoid else 1.3
+            q[7:] += rng.uniform(-1.2, 1.2, m["nq"] - 7)           # push hinges past their ranges (limit rows)
+            v += rng.normal(0, 1.0, nv)
+            qc, vc = q.copy(), v.copy()
+            for s in range(3):
+                a = rng.uniform(-1.3, 1.3, na)
+                q, v, ob, r, d = S.step(q, v, a)
+                obc, rc, dc = np.empty(m["obs_dim"]), C.c_double(), C.c_int()
+                assert lib.orc_spatial_step(C.byref(ms), p(qc), p(vc), p(a), p(obc), C.byref(rc), C.byref(dc)) == 0
+                np.testing.assert_allclose(qc, q, rtol=1e-9, atol=1e-10, err_msg=f"{m['task']} qpos trial {trial} step {s}")
+                np.testing.assert_allclose(vc, v, rtol=1e-8, atol=1e-8)
+                np.testing.assert_allclose(obc, ob, rtol=1e-8, atol=1e-8)
+                assert abs(rc.value - r) < 1e-6 * max(1.0, abs(r)) and bool(dc.value) == bool(d)
+                dones.append(bool(d))
+        assert any(dones) and not all(dones)
+        cs = C.c_double()
+        assert lib.orc_spatial_bench(C.byref(ms), 4, 5, 1000, 1, C.byref(cs)) > 0 and np.isfinite(cs.value)
