@@ -1,0 +1,254 @@
+// disc_bn.h — the discriminator step with BatchNorm1d blocks: MLPDisc(use_bn=True), the reference constructor's DEFAULT
+// (rlkit/torch/algorithms/adv_irl/disc_models/simple_disc_models.py:15,30-31,36-37), trained by AdvIRL._do_reward_training
+// (adv_irl.py:133-216) with the module in train mode and evaluated in eval mode by _do_policy_training (adv_irl.py:268-274).
+//
+// Every block is Linear -> BatchNorm1d -> act.  Batch statistics couple the rows of a batch, so the step is a sequence of PHASES that are
+// each embarrassingly parallel over rows x features, over features (one wavefront per feature COLUMN: lanes split the rows, the column's
+// means are wave reductions) or over a weight matrix; a phase is one launch.  The gradient penalty's gradient is a double backward
+// THROUGH the batch statistics, derived by hand (reverse over reverse; oracle/disc.py:DiscBNOracle states it in numpy and is pinned to
+// the reference's autograd by tests/golden/g26_disc_bn.npz):
+//
+//   forward (n rows)        a = x W^T + b ; mu, var = column mean / biased variance ; s = (var + eps)^-1/2 ; ch = a - mu ; ah = ch s ;
+//                           y = gamma ah + beta ; h = phi(y) ; p = phi'(y)
+//   backward (CE and the first backward of the penalty, cotangent uh of h)
+//                           uy = uh p ; uah = uy gamma ; m1 = mean(uah) ; m2 = mean(uah ah) ; tt = uah - m1 - ah m2 ; ua = s tt ; ux = ua W
+//   reverse of that (xbar = adjoint of ux, bottom block first)
+//                           W += ua^T xbar ; uabar = xbar W^T ; sbar = sum(uabar tt) ; ttbar = uabar s ; m1bar = -sum ttbar ;
+//                           m2bar = -sum(ttbar ah) ; uahbar = ttbar + m1bar / n + ah m2bar / n ; ahbar = -ttbar m2 + uah m2bar / n ;
+//                           gamma += sum(uahbar uy) ; uybar = uahbar gamma ; ybar = uybar uh phi''(y) ; xbar' = uybar p  (next block up)
+//   and down the forward graph (hbar = adjoint of h from the block above)
+//                           yb = ybar + hbar p ; gamma += sum(yb ah) ; beta += sum yb ; ahb = ahbar + yb gamma ; sb = sbar + sum(ahb ch) ;
+//                           chb = ahb s - sb s^3 ch / n ; ab = chb - mean(chb) ; W += ab^T x ; b += sum ab ; hbar' = ab W
+//
+// This path is simple fp32 FMA code, not MFMA tiles: it exists so that the constructor default WORKS (no exp_spec of the reference turns
+// batch norm on); the use_bn=False path keeps the fused kernels.  Natural (row-major) parameter layout, any hid_dim.
+// The same text compiles for the host (tests/harness/disc_bn_host.cpp, DBN_HOST_EMU: every phase as a serial loop) so that the CPU
+// suite checks the phases against the oracle and the reference's vectors without a GPU.
+#pragma once
+#include <math.h>
+
+#ifdef DBN_HOST_EMU
+#define DBN_HD inline
+#define DBN_LANES 1
+static inline float dbn_wsum(float v) { return v; }
+#else
+#define DBN_HD __device__ __forceinline__
+#define DBN_LANES 64
+__device__ __forceinline__ float dbn_wsum(float v) {   // all 64 lanes active
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#endif
+
+#define DBN_EPS 1e-5f
+#define DBN_MOM 0.1f
+enum { DBN_RELU = 0, DBN_TANH = 1 };
+
+DBN_HD float dbn_act(float z, int act) { return act == DBN_RELU ? fmaxf(z, 0.0f) : tanhf(z); }
+DBN_HD float dbn_dact(float h, int act) { return act == DBN_RELU ? (h > 0.0f ? 1.0f : 0.0f) : 1.0f - h * h; }
+DBN_HD float dbn_d2act(float h, int act) { return act == DBN_RELU ? 0.0f : -2.0f * h * (1.0f - h * h); }   // phi''(y) written with h
+
+// ---- dense phases (one output element per index)
+// out[r][j] = sum_k x[r][k] W[j][k] (+ b[j])                     idx in [0, n * H)
+DBN_HD void dbn_dense(int idx, const float* x, int ldx, const float* W, const float* b, float* out, int H, int K) {
+  const int r = idx / H, j = idx - r * H;
+  const float* xr = x + (size_t)r * ldx;
+  const float* wj = W + (size_t)j * K;
+  float s = 0.0f;
+  for (int k = 0; k < K; ++k) s = fmaf(xr[k], wj[k], s);
+  out[(size_t)r * H + j] = s + (b ? b[j] : 0.0f);
+}
+// out[r][k] = sum_j d[r][j] W[j][k]                               idx in [0, n * K)
+DBN_HD void dbn_dense_t(int idx, const float* d, const float* W, float* out, int H, int K) {
+  const int r = idx / K, k = idx - r * K;
+  const float* dr = d + (size_t)r * H;
+  float s = 0.0f;
+  for (int j = 0; j < H; ++j) s = fmaf(dr[j], W[(size_t)j * K + k], s);
+  out[(size_t)r * K + k] = s;
+}
+// G[j][k] (+)= sum_r a[r][j] x[r][k]                               idx in [0, H * K)
+DBN_HD void dbn_outer(int idx, const float* a, const float* x, int ldx, float* G, int n, int H, int K, int acc) {
+  const int j = idx / K, k = idx - j * K;
+  float s = 0.0f;
+  for (int r = 0; r < n; ++r) s = fmaf(a[(size_t)r * H + j], x[(size_t)r * ldx + k], s);
+  G[(size_t)j * K + k] = acc ? G[(size_t)j * K + k] + s : s;
+}
+
+// ---- column phases: one wavefront per feature column j; lanes split the rows (host emulation: one lane)
+// forward of a block after the dense phase: a (in buf `ch`, overwritten by a - mu) -> s[j], ah, h, p; train: batch statistics (+ running
+// update), eval: running statistics
+DBN_HD void dbn_col_fwd(int j, int lane, float* ch, float* ah, float* h, float* p, float* s_out, const float* gamma, const float* beta,
+                        float* rmean, float* rvar, int n, int H, int act, int train, int update_running) {
+  float mu, var;
+  if (train) {
+    float sm = 0.0f;
+    for (int r = lane; r < n; r += DBN_LANES) sm += ch[(size_t)r * H + j];
+    mu = dbn_wsum(sm) / (float)n;
+    float sv = 0.0f;
+    for (int r = lane; r < n; r += DBN_LANES) { const float c = ch[(size_t)r * H + j] - mu; sv += c * c; }
+    var = dbn_wsum(sv) / (float)n;
+    if (update_running && lane == 0) {   // torch: running = (1 - momentum) running + momentum batch, the variance UNBIASED
+      rmean[j] = (1.0f - DBN_MOM) * rmean[j] + DBN_MOM * mu;
+      rvar[j] = (1.0f - DBN_MOM) * rvar[j] + DBN_MOM * var * ((float)n / (float)(n - 1));
+    }
+  } else {
+    mu = rmean[j]; var = rvar[j];
+  }
+  const float s = 1.0f / sqrtf(var + DBN_EPS), g = gamma[j], be = beta[j];
+  if (lane == 0 && s_out) s_out[j] = s;
+  for (int r = lane; r < n; r += DBN_LANES) {
+    const size_t at = (size_t)r * H + j;
+    const float c = ch[at] - mu, a_ = c * s, hh = dbn_act(g * a_ + be, act);
+    ch[at] = c;
+    if (ah) ah[at] = a_;
+    h[at] = hh;
+    if (p) p[at] = dbn_dact(hh, act);
+  }
+}
+// backward through act -> BN (the CE backward, and the FIRST backward of the penalty): cotangent uh of h -> ua of the dense output.
+// uh == null: the top block, uh[r][j] = top[r] * w[j].  Optional outputs uy / uah / tt (the penalty's tape), m2 ; optional gradient
+// accumulations dgamma += sum(uy ah), dbeta += sum(uy), db += sum(ua)  (CE backward only).
+DBN_HD void dbn_col_bwd(int j, int lane, const float* uh, const float* top, const float* w, const float* p, const float* ah, const float* s,
+                        const float* gamma, float* ua, float* uh_out, float* uy, float* uah, float* tt, float* m2_out, float* dgamma, float* dbeta,
+                        float* db, int n, int H) {
+  const float g = gamma[j], sj = s[j], wj = w ? w[j] : 0.0f;
+  float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) {
+    const size_t at = (size_t)r * H + j;
+    const float u = uh ? uh[at] : top[r] * wj;
+    const float y_ = u * p[at], q = y_ * g;
+    a1 += q; a2 += q * ah[at]; a3 += y_ * ah[at]; a4 += y_;
+    if (uh_out) uh_out[at] = u;
+  }
+  const float m1 = dbn_wsum(a1) / (float)n, m2 = dbn_wsum(a2) / (float)n;
+  a3 = dbn_wsum(a3); a4 = dbn_wsum(a4);
+  float sa = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) {
+    const size_t at = (size_t)r * H + j;
+    const float u = uh ? uh[at] : top[r] * wj;
+    const float y_ = u * p[at], q = y_ * g, t = q - m1 - ah[at] * m2, a_ = sj * t;
+    ua[at] = a_;
+    sa += a_;
+    if (uy) { uy[at] = y_; uah[at] = q; tt[at] = t; }
+  }
+  sa = dbn_wsum(sa);
+  if (lane == 0) {
+    if (m2_out) m2_out[j] = m2;
+    if (dgamma) { dgamma[j] += a3; dbeta[j] += a4; db[j] += sa; }
+  }
+}
+// reverse of the first backward for one block: uabar (adjoint of ua) -> ybar, ahbar, sbar[j], xbar_up (adjoint of this block's uh) ; dgamma
+DBN_HD void dbn_col_rev(int j, int lane, const float* uabar, const float* tt, const float* s, const float* ah, const float* uah, const float* uy,
+                        const float* uh, const float* p, const float* h, const float* m2, const float* gamma, float* ybar, float* ahbar,
+                        float* sbar, float* xbar_up, float* dgamma, int n, int H, int act) {
+  const float sj = s[j], g = gamma[j], m2j = m2[j];
+  float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) {
+    const size_t at = (size_t)r * H + j;
+    const float ub = uabar[at], tb = ub * sj;
+    a1 += ub * tt[at]; a2 += tb; a3 += tb * ah[at];
+  }
+  const float sb = dbn_wsum(a1), m1bar = -dbn_wsum(a2), m2bar = -dbn_wsum(a3);
+  float dg = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) {
+    const size_t at = (size_t)r * H + j;
+    const float tb = uabar[at] * sj;
+    const float uahb = tb + m1bar / (float)n + (m2bar / (float)n) * ah[at];
+    ahbar[at] = -tb * m2j + (m2bar / (float)n) * uah[at];
+    dg += uahb * uy[at];
+    const float uyb = uahb * g;
+    ybar[at] = uyb * uh[at] * dbn_d2act(h[at], act);
+    xbar_up[at] = uyb * p[at];
+  }
+  dg = dbn_wsum(dg);
+  if (lane == 0) { sbar[j] = sb; dgamma[j] += dg; }
+}
+// the adjoints of the forward quantities go down the forward graph: (ybar, ahbar, sbar, hbar from above [null at the top]) -> ab ; dgamma, dbeta, db
+DBN_HD void dbn_col_down(int j, int lane, const float* ybar, const float* hbar, const float* p, const float* ah, const float* ahbar,
+                         const float* ch, const float* s, const float* sbar, const float* gamma, float* ab, float* dgamma, float* dbeta,
+                         float* db, int n, int H) {
+  const float sj = s[j], g = gamma[j];
+  float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) {
+    const size_t at = (size_t)r * H + j;
+    const float yb = ybar[at] + (hbar ? hbar[at] * p[at] : 0.0f);
+    const float ahb = ahbar[at] + yb * g;
+    a1 += yb * ah[at]; a2 += yb; a3 += ahb * ch[at];
+  }
+  a1 = dbn_wsum(a1); a2 = dbn_wsum(a2);
+  const float sb = sbar[j] + dbn_wsum(a3), vb = -0.5f * sb * sj * sj * sj;
+  float cm = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) {
+    const size_t at = (size_t)r * H + j;
+    const float yb = ybar[at] + (hbar ? hbar[at] * p[at] : 0.0f);
+    const float ahb = ahbar[at] + yb * g;
+    const float chb = ahb * sj + vb * 2.0f * ch[at] / (float)n;
+    ab[at] = chb;
+    cm += chb;
+  }
+  cm = dbn_wsum(cm) / (float)n;
+  float sa = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) {
+    const size_t at = (size_t)r * H + j;
+    const float v = ab[at] - cm;
+    ab[at] = v;
+    sa += v;
+  }
+  sa = dbn_wsum(sa);
+  if (lane == 0) { dgamma[j] += a1; dbeta[j] += a2; db[j] += sa; }
+}
+// column sums for the head: gw[j] (+)= sum_r v[r] * m[r][j]       (v = dlogit with m = h_L ; v = gate with m = xbar_up)
+DBN_HD void dbn_col_dot(int j, int lane, const float* v, const float* m, float* out, int n, int H, int acc) {
+  float a = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) a += v[r] * m[(size_t)r * H + j];
+  a = dbn_wsum(a);
+  if (lane == 0) out[j] = acc ? out[j] + a : a;
+}
+
+// ---- row phases
+// head of the cross-entropy pass (2B rows: the first B are expert rows, target 1): raw = h w + c ; clamp ; BCE-with-logits row term, accuracy,
+// dlogit = (sigmoid(logit) - t) / (2B) * gate          idx in [0, 2B)
+DBN_HD void dbn_head_ce(int r, const float* h, const float* w, float c, float clampv, int B, int H, float* logit_out, float* dlogit,
+                        float* ce_row, float* correct) {
+  float raw = c;
+  for (int j = 0; j < H; ++j) raw = fmaf(h[(size_t)r * H + j], w[j], raw);
+  const float x = fminf(fmaxf(raw, -clampv), clampv), t = r < B ? 1.0f : 0.0f;
+  const float gate = (raw >= -clampv && raw <= clampv) ? 1.0f : 0.0f;
+  ce_row[r] = fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x)));
+  correct[r] = ((x > 0.0f ? 1.0f : 0.0f) == t) ? 1.0f : 0.0f;
+  dlogit[r] = (1.0f / (1.0f + expf(-x)) - t) / (float)(2 * B) * gate;
+  if (logit_out) logit_out[r] = x;
+}
+// head of a plain forward: clamped logit (+ the clamp's gate)
+DBN_HD void dbn_head(int r, const float* h, const float* w, float c, float clampv, int H, float* logit, float* gate) {
+  float raw = c;
+  for (int j = 0; j < H; ++j) raw = fmaf(h[(size_t)r * H + j], w[j], raw);
+  if (logit) logit[r] = fminf(fmaxf(raw, -clampv), clampv);
+  if (gate) gate[r] = (raw >= -clampv && raw <= clampv) ? 1.0f : 0.0f;
+}
+// interpolates xh = eps x_exp + (1 - eps) x_pol (adv_irl.py:187-189) and the stacked CE input [x_exp ; x_pol]        idx in [0, B * D)
+DBN_HD void dbn_prep(int idx, const float* eo, const float* ea, const float* po, const float* pa, const float* eps, float* X, float* XH, int B, int o,
+                     int a) {
+  const int D = o + a, r = idx / D, k = idx - r * D;
+  const float xe = k < o ? eo[(size_t)r * o + k] : ea[(size_t)r * a + (k - o)], xp = k < o ? po[(size_t)r * o + k] : pa[(size_t)r * a + (k - o)];
+  X[(size_t)r * D + k] = xe;
+  X[(size_t)(B + r) * D + k] = xp;
+  if (XH) { const float e = eps[r]; XH[(size_t)r * D + k] = e * xe + (1.0f - e) * xp; }
+}
+// penalty rows: n = |g_r| ; row term (n - 1)^2 ; xbar = w_gp / B * 2 (n - 1) / n * g  (0 where n == 0)        idx in [0, B)
+DBN_HD void dbn_gp_row(int r, const float* g, float* xbar, float* gp_row, int B, int D, float gp_w) {
+  float ss = 0.0f;
+  for (int k = 0; k < D; ++k) ss = fmaf(g[(size_t)r * D + k], g[(size_t)r * D + k], ss);
+  const float nn = sqrtf(ss);
+  gp_row[r] = (nn - 1.0f) * (nn - 1.0f);
+  const float coef = nn > 0.0f ? gp_w / (float)B * 2.0f * (nn - 1.0f) / nn : 0.0f;
+  for (int k = 0; k < D; ++k) xbar[(size_t)r * D + k] = coef * g[(size_t)r * D + k];
+}
+// torch 1.9 Adam (no weight decay): elementwise                  idx in [0, n_params)
+DBN_HD void dbn_adam(int i, float* P, const float* G, float* M, float* V, float lr_over_bc1, float bc2_sqrt, float b1, float b2, float eps) {
+  const float g = G[i];
+  const float m = M[i] * b1 + (1.0f - b1) * g;
+  const float v = V[i] * b2 + (1.0f - b2) * g * g;
+  M[i] = m; V[i] = v;
+  P[i] = P[i] - lr_over_bc1 * (m / (sqrtf(v) / bc2_sqrt + eps));
+}

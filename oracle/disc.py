@@ -211,3 +211,191 @@ def disc_reward(logits, mode, rew_clip_min=None, rew_clip_max=None):
     if rew_clip_min is not None:
         r = np.maximum(r, F32(rew_clip_min))
     return r.astype(F32)
+
+
+class DiscBNOracle:
+    """MLPDisc(use_bn=True) — the reference constructor's DEFAULT (simple_disc_models.py:15,30-31,36-37): every block is
+    Linear -> BatchNorm1d -> act.  One discriminator step = AdvIRL._do_reward_training (adv_irl.py:133-216) with the module in train mode:
+    the cross-entropy forward normalises the 2B rows with THEIR batch statistics, the gradient-penalty forward the B interpolates with
+    theirs, both update the running statistics (momentum 0.1, unbiased variance), and the penalty's gradient is a double backward
+    THROUGH the batch statistics.  `logits(x)` is the eval-mode forward (running statistics) that _do_policy_training uses
+    (adv_irl.py:268-274).  numpy fp32; derivation in train_step's comments.  Test infrastructure.
+
+    Flat parameter order = torch's parameters(): per block W [H, in], b [H], gamma [H], beta [H]; then w [1, H], c [1].
+    Buffers (not parameters): running_mean / running_var per block."""
+
+    EPS, MOM = F32(1e-5), F32(0.1)   # torch.nn.BatchNorm1d defaults
+
+    def __init__(self, in_dim, hid_dim, flat, act=TANH, clamp=10.0, disc_lr=3e-4, disc_momentum=0.9, use_grad_pen=True,
+                 grad_pen_weight=10.0, num_layer_blocks=2):
+        self.L, self.D, self.H, self.act, self.clamp = int(num_layer_blocks), in_dim, hid_dim, act, F32(clamp)
+        self.p = np.asarray(flat, F32).copy()
+        assert self.p.size == self.n_params(in_dim, hid_dim, self.L)
+        self.lr, self.b1, self.use_gp, self.gp_w = disc_lr, disc_momentum, use_grad_pen, grad_pen_weight
+        self.opt = optim.AdamState(self.p.size)
+        self.rm = [np.zeros(hid_dim, F32) for _ in range(self.L)]
+        self.rv = [np.ones(hid_dim, F32) for _ in range(self.L)]
+
+    @staticmethod
+    def n_params(D, H, L):
+        return sum((D if l == 0 else H) * H + 3 * H for l in range(L)) + H + 1
+
+    @staticmethod
+    def init(rng, D, H, L, w_scale=0.3):
+        """a parameter vector in the flat order: weights U(+-w_scale / sqrt(in)), small biases, gamma near 1, beta near 0"""
+        parts = []
+        for l in range(L):
+            i = D if l == 0 else H
+            parts += [rng.uniform(-1, 1, (H, i)) * w_scale * 3 / np.sqrt(i), rng.normal(0, 0.05, H), 1.0 + rng.normal(0, 0.1, H), rng.normal(0, 0.1, H)]
+        parts += [rng.uniform(-1, 1, (1, H)) * w_scale, rng.normal(0, 0.05, 1)]
+        return np.concatenate([np.asarray(a, F32).ravel() for a in parts]).astype(F32)
+
+    def unpack(self, flat=None):
+        flat = self.p if flat is None else flat
+        o, blocks = 0, []
+        for l in range(self.L):
+            i = self.D if l == 0 else self.H
+            W = flat[o:o + self.H * i].reshape(self.H, i); o += self.H * i
+            b, g, be = flat[o:o + self.H], flat[o + self.H:o + 2 * self.H], flat[o + 2 * self.H:o + 3 * self.H]; o += 3 * self.H
+            blocks.append((W, b, g, be))
+        w = flat[o:o + self.H].reshape(1, self.H); c = flat[o + self.H:o + self.H + 1]
+        return blocks, w, c
+
+    def dead_bias_mask(self):
+        """flat-vector mask of the Linear biases that sit under a BatchNorm: their gradient is exactly 0 (the batch mean is subtracted), what any
+        implementation holds there is rounding noise that Adam turns into +-lr steps; they do not influence the function"""
+        m, o = np.zeros(self.p.size, bool), 0
+        for l in range(self.L):
+            o += self.H * (self.D if l == 0 else self.H)
+            m[o:o + self.H] = True
+            o += 3 * self.H
+        return m
+
+    def pack(self, gblocks, gw, gc):
+        return np.concatenate([np.asarray(a, F32).ravel() for blk in gblocks for a in blk] + [np.asarray(gw, F32).ravel(), np.asarray(gc, F32).ravel()])
+
+    # ---- forward passes
+    def forward_train(self, x, update_running=True):
+        """train-mode forward of n rows: (clamped logit, raw, per block dict(x_in, chat = a - mu, s = 1/sqrt(var + eps), ahat, y, h, p = phi'(y)))"""
+        blocks, w, c = self.unpack()
+        n_rows, h, tape = x.shape[0], x.astype(F32), []
+        for l, (W, b, g, be) in enumerate(blocks):
+            a = (h @ W.T + b).astype(F32)
+            mu = a.mean(0, dtype=F32)
+            ch = (a - mu).astype(F32)
+            var = np.mean(ch * ch, 0, dtype=F32)
+            s = (F32(1) / np.sqrt(var + self.EPS)).astype(F32)
+            ah = (ch * s).astype(F32)
+            y = (g * ah + be).astype(F32)
+            hh = _act(y, self.act).astype(F32)
+            tape.append(dict(x=h, ch=ch, s=s, ah=ah, y=y, h=hh, p=_dact(hh, self.act)))
+            if update_running:   # torch: running = (1 - momentum) running + momentum batch; the variance enters UNBIASED
+                self.rm[l] = ((F32(1) - self.MOM) * self.rm[l] + self.MOM * mu).astype(F32)
+                self.rv[l] = ((F32(1) - self.MOM) * self.rv[l] + self.MOM * var * F32(n_rows / (n_rows - 1))).astype(F32)
+            h = hh
+        raw = (h @ w.T + c).astype(F32)
+        return np.clip(raw, -self.clamp, self.clamp), raw, tape
+
+    def logits(self, x):
+        """eval-mode forward (module.eval(), adv_irl.py:268-274): running statistics"""
+        blocks, w, c = self.unpack()
+        h = np.ascontiguousarray(x, F32)
+        for l, (W, b, g, be) in enumerate(blocks):
+            a = (h @ W.T + b).astype(F32)
+            y = (g * ((a - self.rm[l]) / np.sqrt(self.rv[l] + self.EPS)) + be).astype(F32)
+            h = _act(y, self.act).astype(F32)
+        return np.clip((h @ w.T + c).astype(F32), -self.clamp, self.clamp)
+
+    def _bn_backward(self, t, dy, g):
+        """cotangent of the pre-normalisation activations a from the cotangent dy of y = gamma ahat + beta (batch statistics are functions
+        of a): da = s (dahat - mean(dahat) - ahat mean(dahat ahat)); also (dgamma, dbeta)"""
+        dah = (dy * g).astype(F32)
+        m1, m2 = dah.mean(0, dtype=F32), (dah * t["ah"]).mean(0, dtype=F32)
+        return (t["s"] * (dah - m1 - t["ah"] * m2)).astype(F32), (dy * t["ah"]).sum(0, dtype=F32), dy.sum(0, dtype=F32)
+
+    def train_step(self, x_exp, x_pol, eps_gp):
+        blocks, w, c = self.unpack()
+        L, act, B = self.L, self.act, x_exp.shape[0]
+        x = np.concatenate([x_exp, x_pol], 0).astype(F32)
+        tgt = np.concatenate([np.ones((B, 1), F32), np.zeros((B, 1), F32)], 0)
+        logit, raw, tape = self.forward_train(x)
+        ce = bce_with_logits(logit, tgt)
+        acc = np.mean(((logit > 0).astype(F32) == tgt).astype(F32))
+        gate = ((raw >= -self.clamp) & (raw <= self.clamp)).astype(F32)
+        dlogit = ((sigmoid(logit) - tgt) / F32(2 * B) * gate).astype(F32)
+        gB = [[np.zeros_like(W), np.zeros_like(b), np.zeros_like(g), np.zeros_like(be)] for (W, b, g, be) in blocks]
+        gw, gc = (dlogit.T @ tape[-1]["h"]).astype(F32), dlogit.sum(0, dtype=F32)
+        dh = (dlogit @ w).astype(F32)
+        for l in range(L - 1, -1, -1):   # ordinary backward through Linear -> BN -> act
+            W, b, g, be = blocks[l]
+            t = tape[l]
+            da, dg, dbe = self._bn_backward(t, (dh * t["p"]).astype(F32), g)
+            gB[l][0] += da.T @ t["x"]; gB[l][1] += da.sum(0, dtype=F32); gB[l][2] += dg; gB[l][3] += dbe
+            dh = (da @ W).astype(F32)
+        out = dict(logits=logit, ce_loss=ce, accuracy=acc)
+        gp_loss = F32(0)
+        if self.use_gp:
+            e = eps_gp.astype(F32).reshape(B, 1)
+            xh = (e * x_exp + (F32(1) - e) * x_pol).astype(F32)                          # adv_irl.py:187-189
+            _, rawh, tp = self.forward_train(xh)                                         # its own batch statistics (and a running-statistics update)
+            gt = ((rawh >= -self.clamp) & (rawh <= self.clamp)).astype(F32)
+            n_rows = F32(B)
+            # ---- first backward: g = d(sum_r D(xh_r)) / d xh, THROUGH the batch statistics.  Per block (top down), with uh the cotangent of h:
+            #      uy = uh p ; uah = uy gamma ; m1 = mean(uah) ; m2 = mean(uah ahat) ; tt = uah - m1 - ahat m2 ; ua = s tt ; ux = ua W
+            fb = [None] * L
+            uh = (gt * w).astype(F32)                                                    # [B, H]: the clamp's gate times the output weights
+            for l in range(L - 1, -1, -1):
+                W, b, g, be = blocks[l]
+                t = tp[l]
+                uy = (uh * t["p"]).astype(F32)
+                uah = (uy * g).astype(F32)
+                m1, m2 = uah.mean(0, dtype=F32), (uah * t["ah"]).mean(0, dtype=F32)
+                tt = (uah - m1 - t["ah"] * m2).astype(F32)
+                ua = (t["s"] * tt).astype(F32)
+                fb[l] = dict(uh=uh, uy=uy, uah=uah, m2=m2, tt=tt, ua=ua)
+                uh = (ua @ W).astype(F32)
+            gvec = uh                                                                    # dD/dx [B, D]
+            nrm = np.sqrt(np.sum(gvec * gvec, 1, keepdims=True)).astype(F32)
+            gp = np.mean((nrm - F32(1)) ** 2, dtype=F32)
+            gp_loss = F32(gp * F32(self.gp_w))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                xbar = np.where(nrm > 0, F32(self.gp_w) / F32(B) * F32(2) * (nrm - F32(1)) / nrm * gvec, F32(0)).astype(F32)
+            # ---- reverse of the first backward, bottom up (xbar = adjoint of ux of the block below).  Leaves: adjoints of the parameters the
+            #      first backward read (W, gamma, w) and of the FORWARD quantities it read: ybar (through p = phi'(y)), ahbar, sbar.
+            ybar, ahbar, sbar = [None] * L, [None] * L, [None] * L
+            for l in range(L):
+                W, b, g, be = blocks[l]
+                t, f = tp[l], fb[l]
+                gB[l][0] += f["ua"].T @ xbar                                             # ux = ua W
+                uabar = (xbar @ W.T).astype(F32)
+                sbar[l] = (uabar * f["tt"]).sum(0, dtype=F32)                            # ua = s tt
+                ttbar = (uabar * t["s"]).astype(F32)
+                m1bar, m2bar = -ttbar.sum(0, dtype=F32), -(ttbar * t["ah"]).sum(0, dtype=F32)
+                uahbar = (ttbar + m1bar / n_rows + (m2bar / n_rows) * t["ah"]).astype(F32)   # tt = uah - mean(uah) - ahat mean(uah ahat)
+                ahbar[l] = (-ttbar * f["m2"] + (m2bar / n_rows) * f["uah"]).astype(F32)
+                gB[l][2] += (uahbar * f["uy"]).sum(0, dtype=F32)                         # uah = uy gamma
+                uybar = (uahbar * g).astype(F32)
+                ybar[l] = (uybar * f["uh"] * _d2act_over(t["h"], act)).astype(F32)        # uy = uh phi'(y): d phi'/dy = phi''  (relu: 0)
+                xbar = (uybar * t["p"]).astype(F32)                                       # adjoint of uh = ux of the block above
+            gw = gw + (xbar * gt).sum(0, keepdims=True, dtype=F32)                       # uh_L = gate w
+            # ---- and those adjoints go DOWN the forward graph like an ordinary backward with extra sources
+            hbar = np.zeros((B, self.H), F32)
+            for l in range(L - 1, -1, -1):
+                W, b, g, be = blocks[l]
+                t = tp[l]
+                yb = (ybar[l] + hbar * t["p"]).astype(F32)
+                gB[l][2] += (yb * t["ah"]).sum(0, dtype=F32); gB[l][3] += yb.sum(0, dtype=F32)      # y = gamma ahat + beta
+                ahb = (ahbar[l] + yb * g).astype(F32)
+                chb = (ahb * t["s"]).astype(F32)                                          # ahat = chat s
+                sb = (sbar[l] + (ahb * t["ch"]).sum(0, dtype=F32)).astype(F32)
+                vb = (F32(-0.5) * sb * t["s"] ** 3).astype(F32)                           # s = (var + eps)^(-1/2)
+                chb = (chb + vb * F32(2) * t["ch"] / n_rows).astype(F32)                  # var = mean(chat^2)
+                ab = (chb - chb.mean(0, dtype=F32)).astype(F32)                           # chat = a - mean(a)
+                gB[l][0] += ab.T @ t["x"]; gB[l][1] += ab.sum(0, dtype=F32)
+                hbar = (ab @ W).astype(F32)
+            out.update(interp=xh, dDdx=gvec, grad_norm=nrm)
+        out["grad_pen_loss"] = gp_loss
+        grad = self.pack(gB, gw, gc)
+        out["grad"] = grad
+        optim.adam_step(self.p, grad, self.opt, self.lr, self.b1)
+        return out

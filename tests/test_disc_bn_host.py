@@ -1,0 +1,110 @@
+"""CPU suite: the BatchNorm discriminator (MLPDisc(use_bn=True), the reference constructor's default: simple_disc_models.py:15,30-37).
+(1) oracle/disc.py:DiscBNOracle against the reference's own vectors (tests/golden/g26_disc_bn.npz: AdvIRL._do_reward_training with the
+module in train mode — batch statistics in both forwards, the gradient penalty's double backward through them, running-statistics updates —
+and the eval-mode logits of _do_policy_training).  (2) The DEVICE code of the step (ilswiss_amd/csrc/disc_bn.h phases in the order of
+disc_bn_step.h) compiled for the host, every phase a serial loop (tests/harness/disc_bn_host.cpp), against the same vectors: the phases and
+their order are checked without a GPU; the GPU suite (tests/test_disc.py) then runs the same text as kernels."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle.disc import RELU, TANH, DiscBNOracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "g26_disc_bn.npz"))
+CASES = ["tanh2", "relu2", "tanh3", "relu1"]
+KW = dict(disc_lr=3e-4, disc_momentum=0.9, use_grad_pen=True, grad_pen_weight=8.0)
+
+
+def _dims(tag):
+    D, Hd, B, steps, o_dim, L = [int(v) for v in G[f"{tag}_dims"]]
+    return D, Hd, B, steps, o_dim, L, (TANH if tag.startswith("tanh") else RELU)
+
+
+def _check_final(tag, params, rmean, rvar, steps, logits_probe):
+    dead = G[f"{tag}_dead_bias_mask"].astype(bool)
+    d = np.abs(params - G[f"{tag}_params_final"])
+    # the Linear biases under a BatchNorm have gradient exactly 0: what any implementation holds there is rounding noise that Adam turns into
+    # +-lr steps; they do not influence the function.  Every other parameter: 5e-5 after the chained steps
+    assert d[~dead].max() < 5e-5, (tag, d[~dead].max())
+    assert d[dead].max() <= steps * 2.02 * KW["disc_lr"], (tag, d[dead].max())
+    np.testing.assert_allclose(rvar, G[f"{tag}_running_var"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rmean, G[f"{tag}_running_mean"], rtol=0, atol=steps * 2.02 * KW["disc_lr"] + 1e-5)   # the batch mean carries the dead bias
+    np.testing.assert_allclose(logits_probe, G[f"{tag}_probe_logits_eval"], rtol=1e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_bn_oracle_matches_the_reference(tag):
+    D, Hd, B, steps, o_dim, L, act = _dims(tag)
+    orc = DiscBNOracle(D, Hd, G[f"{tag}_params0"], act=act, num_layer_blocks=L, **KW)
+    for st in range(steps):
+        res = orc.train_step(G[f"{tag}_s{st}_x_exp"], G[f"{tag}_s{st}_x_pol"], G[f"{tag}_s{st}_eps"])
+        np.testing.assert_allclose(res["ce_loss"], G[f"{tag}_s{st}_ce"], rtol=1e-5)
+        np.testing.assert_allclose(res["grad_pen_loss"] / 8.0, G[f"{tag}_s{st}_gp"], rtol=1e-4)
+        np.testing.assert_allclose(res["accuracy"], G[f"{tag}_s{st}_acc"])
+        if st == 0:
+            ref = G[f"{tag}_s0_grad"]
+            assert np.abs(res["grad"] - ref).max() <= 1e-4 * np.abs(ref).max()
+    _check_final(tag, orc.p, np.stack(orc.rm), np.stack(orc.rv), steps, orc.logits(G[f"{tag}_probe"]))
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    d = tempfile.mkdtemp(prefix="dbnh_")
+    so = os.path.join(d, "libdbnh.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", os.path.join(ROOT, "tests", "harness", "disc_bn_host.cpp"), "-o", so])
+    lib = C.CDLL(so)
+    lib.dbnh_create.restype = C.c_void_p
+    lib.dbnh_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    for f in ("dbnh_destroy", "dbnh_set_params", "dbnh_get", "dbnh_train_step", "dbnh_logits_eval", "dbnh_num_params"):
+        getattr(lib, f).argtypes = None
+    lib.dbnh_train_step.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    lib.dbnh_set_params.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dbnh_get.argtypes = [C.c_void_p] * 5
+    lib.dbnh_logits_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.dbnh_destroy.argtypes = [C.c_void_p]
+    lib.dbnh_num_params.argtypes = [C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_device_phases_on_the_host_match_the_reference(hostlib, tag):
+    lib = hostlib
+    D, Hd, B, steps, o_dim, L, act = _dims(tag)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    h = lib.dbnh_create(D, Hd, L, act, 10.0, max(B, 32))   # workspace rows = 2 * max_batch: the 40-row probe needs 20
+    assert lib.dbnh_num_params(h) == G[f"{tag}_params0"].size
+    p0 = np.ascontiguousarray(G[f"{tag}_params0"], np.float32)
+    lib.dbnh_set_params(h, p(p0))
+    orc = DiscBNOracle(D, Hd, p0, act=act, num_layer_blocks=L, **KW)
+    np_ = p0.size
+    for st in range(steps):
+        xe, xp = np.ascontiguousarray(G[f"{tag}_s{st}_x_exp"]), np.ascontiguousarray(G[f"{tag}_s{st}_x_pol"])
+        eps = np.ascontiguousarray(G[f"{tag}_s{st}_eps"].reshape(B), np.float32)
+        eo, ea = np.ascontiguousarray(xe[:, :o_dim]), np.ascontiguousarray(xe[:, o_dim:])
+        po, pa = np.ascontiguousarray(xp[:, :o_dim]), np.ascontiguousarray(xp[:, o_dim:])
+        stats = np.zeros(3, np.float32)
+        assert lib.dbnh_train_step(h, p(eo), p(ea), p(po), p(pa), p(eps), B, o_dim, D - o_dim, 1, KW["grad_pen_weight"], KW["disc_lr"],
+                                   KW["disc_momentum"], p(stats)) == 0
+        np.testing.assert_allclose(stats[0], G[f"{tag}_s{st}_ce"], rtol=1e-5)
+        np.testing.assert_allclose(stats[1], G[f"{tag}_s{st}_acc"])
+        np.testing.assert_allclose(stats[2], G[f"{tag}_s{st}_gp"], rtol=1e-4)
+        grad = np.empty(np_, np.float32)
+        lib.dbnh_get(h, None, p(grad), None, None)
+        res = orc.train_step(xe, xp, eps.reshape(B, 1))
+        live = ~orc.dead_bias_mask()
+        assert np.abs(grad - res["grad"])[live].max() <= 1e-4 * np.abs(res["grad"]).max(), (tag, st)
+        if st == 0:
+            ref = G[f"{tag}_s0_grad"]
+            assert np.abs(grad - ref)[live].max() <= 1e-4 * np.abs(ref).max()
+    params, rm, rv = np.empty(np_, np.float32), np.empty((L, Hd), np.float32), np.empty((L, Hd), np.float32)
+    lib.dbnh_get(h, p(params), None, p(rm), p(rv))
+    probe = np.ascontiguousarray(G[f"{tag}_probe"], np.float32)
+    lg = np.empty(probe.shape[0], np.float32)
+    assert lib.dbnh_logits_eval(h, p(probe), probe.shape[0], p(lg)) == 0
+    _check_final(tag, params, rm, rv, steps, lg.reshape(-1, 1))
+    lib.dbnh_destroy(h)

@@ -527,6 +527,80 @@ def gen_disc_blocks():
     save("g25_disc_blocks", **out)
 
 
+def gen_disc_bn():
+    """G26: AdvIRL._do_reward_training with MLPDisc(use_bn=True) — the constructor's DEFAULT (simple_disc_models.py:15,30-31,36-37): BatchNorm1d
+    in train mode in both forwards of the step (cross-entropy over 2B rows, gradient penalty over the B interpolates, each with its own batch
+    statistics), the penalty's double backward through the batch statistics, running-statistics updates; then the eval-mode forward that
+    _do_policy_training relabels rewards with (adv_irl.py:268-274).  tanh / relu, 2 and 3 blocks, chained steps."""
+    import types
+    import torch.nn as nn
+    import torch.optim as optim
+    from rlkit.torch.algorithms.adv_irl.adv_irl import AdvIRL
+    from rlkit.torch.algorithms.adv_irl.disc_models.simple_disc_models import MLPDisc
+    from oracle.disc import DiscBNOracle, RELU, TANH
+    out = {}
+    for tag, act, L, D, Hd, B, steps in (("tanh2", TANH, 2, 23, 128, 32, 3), ("relu2", RELU, 2, 14, 64, 16, 3), ("tanh3", TANH, 3, 14, 64, 16, 2),
+                                          ("relu1", RELU, 1, 23, 100, 32, 2)):
+        rng = np.random.default_rng(2600 + L + 10 * act)
+        flat = DiscBNOracle.init(rng, D, Hd, L)
+        disc = MLPDisc(D, num_layer_blocks=L, hid_dim=Hd, hid_act="tanh" if act == TANH else "relu", use_bn=True, clamp_magnitude=10.0)
+        set_flat(disc, flat)
+        disc.train()
+        kw = dict(disc_lr=3e-4, disc_momentum=0.9, use_grad_pen=True, grad_pen_weight=8.0)
+        orc = DiscBNOracle(D, Hd, flat, act=act, num_layer_blocks=L, **kw)
+        ns = types.SimpleNamespace(
+            discriminator=disc, disc_optimizer=optim.Adam(disc.parameters(), lr=kw["disc_lr"], betas=(kw["disc_momentum"], 0.999)),
+            state_only=False, wrap_absorbing=False, disc_optim_batch_size=B, bce=nn.BCEWithLogitsLoss(),
+            bce_targets=torch.cat([torch.ones(B, 1), torch.zeros(B, 1)], 0), use_grad_pen=True,
+            grad_pen_weight=kw["grad_pen_weight"], disc_eval_statistics=None)
+        o_dim = D - 6 if D == 23 else D - 3
+        out[f"{tag}_params0"] = flat
+        out[f"{tag}_dims"] = np.array([D, Hd, B, steps, o_dim, L])
+        bns = [m for m in disc.modules() if isinstance(m, nn.BatchNorm1d)]
+        for st in range(steps):
+            xe = rng.normal(0, 1, (B, D)).astype(np.float32)
+            xp = (rng.normal(0, 1, (B, D)) * 1.5 + 0.3).astype(np.float32)
+            eps = rng.random((B, 1)).astype(np.float32)
+            batches = {True: dict(observations=t(xe[:, :o_dim]), actions=t(xe[:, o_dim:])),
+                       False: dict(observations=t(xp[:, :o_dim]), actions=t(xp[:, o_dim:]))}
+            ns.get_batch = lambda bs, from_expert, keys=None: batches[from_expert]
+            ns.disc_eval_statistics = None
+            with H.NoiseInjector() as inj:
+                inj.push(eps)
+                AdvIRL._do_reward_training(ns, 0)
+            stt = ns.disc_eval_statistics
+            res = orc.train_step(xe, xp, eps)
+            assert np.allclose(stt["Disc CE Loss"], res["ce_loss"], rtol=1e-4, atol=1e-6), (tag, st)
+            assert np.allclose(stt["Grad Pen"] * 8.0, res["grad_pen_loss"], rtol=2e-3, atol=1e-5), (tag, st, stt["Grad Pen"] * 8, res["grad_pen_loss"])
+            gref = get_flat_grad(disc)
+            err = np.abs(gref - res["grad"]).max() / np.abs(gref).max()
+            assert err < 1e-4, (tag, st, err)
+            # the Linear biases under a BatchNorm have gradient exactly 0 (the batch mean is subtracted): what autograd / the oracle hold there is
+            # rounding noise (~1e-9), which Adam normalises to a full +-lr step in a noise-determined direction.  They do not influence the
+            # function; every OTHER parameter must agree to 5e-5, the dead biases only stay within steps * lr
+            dead = orc.dead_bias_mask()
+            d = np.abs(get_flat(disc) - orc.p)
+            assert d[~dead].max() < 5e-5 and d[dead].max() <= (st + 1) * 2.02 * kw["disc_lr"], (tag, st, d[~dead].max(), d[dead].max())
+            for l, m in enumerate(bns):
+                assert np.abs(n(m.running_mean) - orc.rm[l]).max() < 1e-3 and np.abs(n(m.running_var) - orc.rv[l]).max() < 1e-5, (tag, st, l)
+            out.update({f"{tag}_s{st}_x_exp": xe, f"{tag}_s{st}_x_pol": xp, f"{tag}_s{st}_eps": eps,
+                        f"{tag}_s{st}_ce": stt["Disc CE Loss"], f"{tag}_s{st}_gp": stt["Grad Pen"], f"{tag}_s{st}_acc": stt["Disc Acc"]})
+            if st == 0:
+                out[f"{tag}_s0_grad"] = gref          # the gradient of the first step, the parameters after the last (file size)
+        out[f"{tag}_params_final"] = get_flat(disc)
+        out[f"{tag}_running_mean"] = np.stack([n(m.running_mean) for m in bns])
+        out[f"{tag}_running_var"] = np.stack([n(m.running_var) for m in bns])
+        probe = rng.normal(0, 2, (40, D)).astype(np.float32)
+        disc.eval()                                   # adv_irl.py:268: the policy's rewards come from the eval-mode discriminator
+        out[f"{tag}_probe"] = probe
+        out[f"{tag}_probe_logits_eval"] = n(disc(t(probe)))
+        disc.train()
+        assert np.allclose(orc.logits(probe), out[f"{tag}_probe_logits_eval"], rtol=1e-3, atol=2e-3), (tag, np.abs(orc.logits(probe) - out[f"{tag}_probe_logits_eval"]).max())
+        out[f"{tag}_dead_bias_mask"] = dead
+        print(tag, "gradient error vs autograd < 1e-4, parameters within 5e-5, running statistics within 1e-5 after", steps, "steps")
+    save("g26_disc_bn", **out)
+
+
 def gen_disc_branches():
     """G24: the AdvIRL branches the YAMLs leave off — state_only=True (adv_irl.py:140-162: discriminator input = cat(obs, next_obs);
     :269 in the reward relabel) and policy_optim_batch_size_from_expert > 0 (:239-255: the policy batch = cat([rows from the policy
@@ -1256,7 +1330,7 @@ def gen_her():
     save("g22_her_buffer", **rec)
 
 
-GROUPS = dict(disc_blocks=gen_disc_blocks, disc_branches=gen_disc_branches, replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+GROUPS = dict(disc_bn=gen_disc_bn, disc_blocks=gen_disc_blocks, disc_branches=gen_disc_branches, replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
 
 if __name__ == "__main__":
