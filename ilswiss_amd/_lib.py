@@ -121,7 +121,7 @@ class DiscCfg(C.Structure):  # ilsx_disc_cfg
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("hid_dim", C.c_int32), ("hid_act", C.c_int32),
                 ("use_grad_pen", C.c_int32), ("clamp_magnitude", C.c_float), ("disc_lr", C.c_float),
                 ("disc_momentum", C.c_float), ("grad_pen_weight", C.c_float), ("max_batch", C.c_int32),
-                ("state_only", C.c_int32), ("num_layer_blocks", C.c_int32)]
+                ("state_only", C.c_int32), ("num_layer_blocks", C.c_int32), ("use_bn", C.c_int32)]
 
 
 class OptMeta(C.Structure):  # ilsx_opt_meta
@@ -185,6 +185,8 @@ PROTOTYPES = {
     "ilsx_disc_set_params": (C.c_int, [vp, vp, C.c_size_t]),
     "ilsx_disc_get_params": (C.c_int, [vp, vp, C.c_size_t]),
     "ilsx_disc_get_grads": (C.c_int, [vp, vp, C.c_size_t]),
+    "ilsx_disc_get_bn_stats": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "ilsx_disc_set_bn_stats": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ilsx_disc_train_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(DiscStats)]),
     "ilsx_disc_reward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, vp, vp]),
     "ilsx_vecenv_create": (C.c_int, [vp, C.POINTER(PlanarModel), C.c_int, C.c_uint64, C.POINTER(vp)]),

@@ -3,11 +3,13 @@
 (rlkit/torch/algorithms/adv_irl/adv_irl.py:126-131 loop, :133-216 discriminator step, :238-314 reward
 relabel + policy step).  Constructor signatures and DEFAULTS are the reference's (simple_disc_models.py:9-17,
 adv_irl.py:34-54): a caller that relies on defaults gets the reference's algorithm or a loud error, never a
-different network.  What libilsx does not implement raises at construction:
-  * `use_bn=True` (the reference default): BatchNorm1d couples the rows of a batch, and the gradient penalty needs the
-    double backward through the batch statistics — not built; every exp_spec of the reference sets `disc_use_bn: false`;
-  * `num_layer_blocks` outside 1..3 (every exp_spec sets 2, which runs the fused kernel; 1 and 3 run the same mathematics as a chain
-    of per-layer launches).
+different network.
+  * `use_bn=True` (the reference default) runs: Linear -> BatchNorm1d -> act blocks in train mode inside the discriminator step (both
+    forwards on their own batch statistics, the gradient penalty's double backward THROUGH those statistics, running-statistics
+    updates) and in eval mode for the policy's rewards (adv_irl.py:268-274) — a chain of simple launches (csrc/disc_bn.h), pinned by the
+    reference-generated g26; every exp_spec of the reference sets `disc_use_bn: false`, which keeps the fused kernels;
+  * `num_layer_blocks` outside 1..3 raises (every exp_spec sets 2, which runs the fused kernel; 1 and 3 run the same mathematics as a
+    chain of per-layer launches).
 """
 import ctypes as C
 from collections import OrderedDict
@@ -34,19 +36,20 @@ class MLPDisc:
 
     def __init__(self, input_dim, num_layer_blocks=2, hid_dim=100, hid_act="relu", use_bn=True, clamp_magnitude=10.0, *,
                  ctx=None, seed=None):
-        if use_bn:
-            raise NotImplementedError("MLPDisc(use_bn=True) — the reference's default — is not implemented by libilsx (no batch-norm "
-                                      "double backward); pass use_bn=False explicitly (every exp_spec does: gail_walker.yaml:27)")
+        # use_bn=True (the reference's default, simple_disc_models.py:15): Linear -> BatchNorm1d -> act blocks, train mode in the discriminator
+        # step (batch statistics, the gradient penalty's double backward through them), eval mode for the policy's rewards — a chain of
+        # simple launches in the library (csrc/disc_bn.h), any hid_dim, no padding; use_bn=False (every exp_spec) keeps the fused kernels
+        self.use_bn = bool(use_bn)
         if num_layer_blocks not in (1, 2, 3):
             raise NotImplementedError("libilsx implements num_layer_blocks 1..3 (gail_walker.yaml:24 uses 2); got %r" % (num_layer_blocks,))
         self.num_layer_blocks = int(num_layer_blocks)
         if hid_act not in _ACT:
             raise NotImplementedError()   # simple_disc_models.py:24-25
-        if hid_dim > _WIDTHS[-1]:
+        if hid_dim > _WIDTHS[-1] and not self.use_bn:
             raise NotImplementedError("hid_dim > 256")
         self.ctx = ctx or get_context()
         self.input_dim, self.hid_dim, self.hid_act = int(input_dim), int(hid_dim), hid_act
-        self._Hp = next(w for w in _WIDTHS if w >= self.hid_dim)
+        self._Hp = self.hid_dim if self.use_bn else next(w for w in _WIDTHS if w >= self.hid_dim)
         self.clamp_magnitude = clamp_magnitude
         # torch nn.Linear default init: W, b ~ U(+-1/sqrt(fan_in))
         rng = np.random.default_rng(np.random.randint(0, 2**31 - 1) if seed is None else seed)
@@ -55,6 +58,8 @@ class MLPDisc:
         for fan_in, out in [(D, H)] + [(H, H)] * (self.num_layer_blocks - 1) + [(H, 1)]:
             b = 1.0 / np.sqrt(fan_in)
             parts += [rng.uniform(-b, b, (out, fan_in)).ravel(), rng.uniform(-b, b, out)]
+            if self.use_bn and out == H:   # nn.BatchNorm1d: weight (gamma) = 1, bias (beta) = 0 — parameters() lists them after the Linear's
+                parts += [np.ones(H), np.zeros(H)]
         self._flat = np.concatenate(parts).astype(np.float32)
         self.num_params = self._flat.size
         self.h, self._bound = None, None
@@ -96,7 +101,22 @@ class MLPDisc:
 
     @property
     def _nphys(self):
+        if self.use_bn:
+            return self.num_params
         return sum(pr * pc for _, _, pr, pc in self._shapes())
+
+    def get_bn_stats(self):
+        """(running_mean, running_var) [num_layer_blocks, hid_dim] of a use_bn discriminator: module buffers, saved beside the parameters"""
+        self._need()
+        n = self.num_layer_blocks * self.hid_dim
+        rm, rv = np.empty(n, np.float32), np.empty(n, np.float32)
+        _lib.check(self.ctx.lib.ilsx_disc_get_bn_stats(self.h, rm.ctypes.data_as(C.c_void_p), rv.ctypes.data_as(C.c_void_p), n))
+        return rm.reshape(self.num_layer_blocks, self.hid_dim), rv.reshape(self.num_layer_blocks, self.hid_dim)
+
+    def set_bn_stats(self, running_mean, running_var):
+        self._need()
+        rm, rv = np.ascontiguousarray(running_mean, np.float32).ravel(), np.ascontiguousarray(running_var, np.float32).ravel()
+        _lib.check(self.ctx.lib.ilsx_disc_set_bn_stats(self.h, rm.ctypes.data_as(C.c_void_p), rv.ctypes.data_as(C.c_void_p), rm.size))
 
     def bind(self, obs_dim, second_dim=None, state_only=False, disc_lr=1e-3, disc_momentum=0.0, use_grad_pen=True,
              grad_pen_weight=10.0, max_batch=1024):
@@ -110,14 +130,17 @@ class MLPDisc:
                float(grad_pen_weight), int(max_batch))
         if self._bound == key:
             return self
-        opt = None
+        opt = bn = None
+        if self.h is not None and self.use_bn:
+            bn = self.get_bn_stats()
         if self.h is not None:   # re-bind (e.g. a forward on an unbound discriminator bound it with default settings): parameters AND the
             from .snapshot import get_opt   # optimiser's moments / step count move to the new library object
             self._flat = self.get_flat_params()
             opt = get_opt(self.ctx.lib, "disc", self.h, self._nphys)
             _lib.check(self.ctx.lib.ilsx_disc_destroy(self.h))
         cfg = _lib.DiscCfg(obs_dim, second_dim, self._Hp, _ACT[self.hid_act], int(bool(use_grad_pen)), self.clamp_magnitude,
-                           disc_lr, disc_momentum, grad_pen_weight, int(max_batch), int(bool(state_only)), self.num_layer_blocks)
+                           disc_lr, disc_momentum, grad_pen_weight, int(max_batch), int(bool(state_only)), self.num_layer_blocks,
+                           int(self.use_bn))
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_disc_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
         self._bound = key
@@ -127,6 +150,8 @@ class MLPDisc:
         if opt is not None:
             from .snapshot import set_opt
             set_opt(self.ctx.lib, "disc", self.h, opt)
+        if bn is not None:
+            self.set_bn_stats(*bn)
         return self
 
     def _need(self):
@@ -193,7 +218,8 @@ class MLPDisc:
         self.reward_dev(po, pa, n, mode, rew_clip_min, rew_clip_max, rew, lg)
         return rew.numpy().reshape(n, 1), lg.numpy().reshape(n, 1)
 
-    def __call__(self, x):  # MLPDisc.forward: clamped logits of disc-input rows (simple_disc_models.py:42-48)
+    def __call__(self, x):  # MLPDisc.forward: clamped logits of disc-input rows (simple_disc_models.py:42-48); use_bn: the EVAL-mode forward
+        # (running statistics), which is how the reference calls a trained discriminator outside its training step (adv_irl.py:268-274)
         if self.h is None:
             self.bind(self.input_dim - 1, 1)   # any split of the input will do for a forward
         x = np.ascontiguousarray(x, np.float32)
@@ -325,6 +351,8 @@ class AdvIRLTrainer:
         snap = dict(self.policy_trainer.get_snapshot())
         snap["disc"] = self.disc.get_flat_params()
         snap["disc_optimizer"] = get_opt(self.disc.ctx.lib, "disc", self.disc.h, self.disc._nphys)
+        if self.disc.use_bn:   # BatchNorm buffers (state_dict entries of the reference's module, not parameters)
+            snap["disc_bn_running_mean"], snap["disc_bn_running_var"] = self.disc.get_bn_stats()
         return snap
 
     def load_snapshot(self, snap):
@@ -333,6 +361,8 @@ class AdvIRLTrainer:
         self.disc.set_flat_params(snap["disc"])
         if "disc_optimizer" in snap:
             set_opt(self.disc.ctx.lib, "disc", self.disc.h, snap["disc_optimizer"])
+        if self.disc.use_bn and "disc_bn_running_mean" in snap:
+            self.disc.set_bn_stats(snap["disc_bn_running_mean"], snap["disc_bn_running_var"])
 
     def _last_disc_rewards(self):
         """The relabelled rewards of the most recent policy batch (still on the device), or None before the first policy step."""

@@ -16,6 +16,7 @@
 #include <cmath>
 
 #include "host_common.h"
+#include "disc_bn_step.h"
 
 struct DiscScalars {
   float ce_loss, grad_pen, accuracy, pad;
@@ -332,6 +333,29 @@ __global__ void k_disc_reward(PartVal raw, int n, float clamp, int mode, int has
   if (logits) logits[r] = x;
 }
 
+// ------------------------------------------------------------------------------------------------ BatchNorm discriminator (use_bn)
+// The phases of csrc/disc_bn.h in the order of csrc/disc_bn_step.h, every phase one launch on the ctx stream (the host test harness
+// runs the same two headers as serial loops: tests/test_disc_bn_host.py).
+template <class F> __global__ __launch_bounds__(256) void k_dbn_par(int n, F f) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) f(i);
+}
+template <class F> __global__ __launch_bounds__(64) void k_dbn_col(F f) { f((int)blockIdx.x, (int)threadIdx.x); }   // one wavefront per feature column
+struct DbnLaunch {
+  hipStream_t st;
+  template <class F> void par(int n, F f) { if (n > 0) hipLaunchKernelGGL(k_dbn_par<F>, dim3((n + 255) / 256), dim3(256), 0, st, n, f); }
+  template <class F> void col(int H, F f) { if (H > 0) hipLaunchKernelGGL(k_dbn_col<F>, dim3(H), dim3(64), 0, st, f); }
+};
+struct DiscBn {
+  DbnNet N;
+  DbnWs W;
+  float* stats3 = nullptr;   // device: mean BCE, accuracy, mean (|g| - 1)^2 of the last step
+  float* xcat = nullptr;     // [rows][D] cat(obs, second) of a reward call
+  float* lg = nullptr;       // [rows] eval-mode logits of a reward call
+  int rows = 0;              // workspace rows (3 * max_batch)
+  int t = 0;                 // Adam step count
+};
+
 // ------------------------------------------------------------------------------------------------ host
 struct ilsx_disc {
   ilsx_ctx* ctx = nullptr;
@@ -353,6 +377,7 @@ struct ilsx_disc {
   uint32_t rng_stream = 0;
   unsigned long long step_ctr = 0;
   float* snap = nullptr;   // checkpoint of P | M | V | scalars for a window that is rolled back (ilsx_advirl_train)
+  DiscBn* bn = nullptr;    // use_bn: natural-layout parameters + the phase workspace (P / G / M / V above are its arenas)
   PartVal pv() const { return PartVal{raw, cs, 3 * cfg.max_batch}; }
 };
 
@@ -374,6 +399,52 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
   d->ctx = ctx; d->cfg = *cfg; d->o = cfg->obs_dim; d->a = cfg->act_dim; d->D = d->o + d->a;
   d->nblk = cfg->num_layer_blocks ? cfg->num_layer_blocks : 2;
   if (d->nblk < 1 || d->nblk > ILSX_MAX_HID) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "num_layer_blocks=%d: 1..%d", d->nblk, ILSX_MAX_HID);
+  if (cfg->use_bn) {   // Linear -> BatchNorm1d -> act blocks: natural layout, any width, the phase chain of csrc/disc_bn_step.h
+    if (cfg->hid_dim < 1 || cfg->hid_dim > 1024) { delete d; ILSX_FAIL(ILSX_ERR_ARG, "hid_dim=%d out of range", cfg->hid_dim); }
+    if (cfg->hid_act != ILSX_ACT_RELU && cfg->hid_act != ILSX_ACT_TANH) { delete d; ILSX_FAIL(ILSX_ERR_ARG, "hid_act=%d unknown", cfg->hid_act); }
+    DiscBn* b = d->bn = new DiscBn();
+    DbnNet& N = b->N;
+    N.D = d->D; N.H = cfg->hid_dim; N.nblk = d->nblk; N.act = cfg->hid_act == ILSX_ACT_TANH ? DBN_TANH : DBN_RELU; N.clampv = cfg->clamp_magnitude;
+    const size_t np = (size_t)N.n_params(), H = (size_t)N.H, rows = 3 * (size_t)cfg->max_batch, wd = std::max(H, (size_t)d->D);
+    b->rows = (int)rows;
+    d->L.n_flat = np; d->L.n_int = np;   // flat ABI order == storage order (torch's parameters(): per block W | b | gamma | beta, then the output layer)
+    d->cs = 1;
+    d->rng_stream = ctx->next_rng_stream++;
+    auto A = [&](float** p, size_t cnt) { return ctx_alloc(ctx, cnt * sizeof(float), (void**)p, true); };
+    int rc = A(&d->P, np);
+    if (rc == ILSX_OK) rc = A(&d->G, np);
+    if (rc == ILSX_OK) rc = A(&d->M, np);
+    if (rc == ILSX_OK) rc = A(&d->V, np);
+    if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(DiscScalars), (void**)&d->scal);
+    if (rc == ILSX_OK) rc = A(&d->X, rows * d->D);
+    if (rc == ILSX_OK) rc = A(&d->eps_used, (size_t)cfg->max_batch);
+    if (rc == ILSX_OK) rc = A(&N.rmean, (size_t)N.nblk * H);
+    if (rc == ILSX_OK) rc = A(&N.rvar, (size_t)N.nblk * H);
+    N.P = d->P; N.G = d->G; N.M = d->M; N.V = d->V;
+    DbnWs& W = b->W;
+    for (int l = 0; l < N.nblk && rc == ILSX_OK; ++l) {
+      float** mats[] = {&W.ch[l], &W.ah[l], &W.h[l], &W.p[l], &W.uh[l], &W.uy[l], &W.uah[l], &W.tt[l], &W.ua[l], &W.ybar[l], &W.ahbar[l]};
+      for (float** m : mats) if (rc == ILSX_OK) rc = A(m, rows * H);
+      float** vecs[] = {&W.s[l], &W.m2[l], &W.sbar[l]};
+      for (float** v : vecs) if (rc == ILSX_OK) rc = A(v, H);
+    }
+    if (rc == ILSX_OK) rc = A(&W.t0, rows * wd);
+    if (rc == ILSX_OK) rc = A(&W.t1, rows * wd);
+    float** rowv[] = {&W.logit, &W.dlogit, &W.gate, &W.ce_row, &W.correct, &W.gp_row, &b->lg};
+    for (float** v : rowv) if (rc == ILSX_OK) rc = A(v, rows);
+    if (rc == ILSX_OK) rc = A(&b->stats3, 4);
+    if (rc == ILSX_OK) rc = A(&b->xcat, rows * d->D);
+    if (rc == ILSX_OK) {   // running_var starts at 1 (torch.nn.BatchNorm1d), running_mean at 0
+      std::vector<float> ones((size_t)N.nblk * H, 1.0f);
+      hipError_t e = hipMemcpyAsync(N.rvar, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { ilsx_set_err("ilsx_disc_create: %s", hipGetErrorString(e)); rc = ILSX_ERR_HIP; }
+    }
+    if (rc != ILSX_OK) { delete b; delete d; return rc; }
+    W.X = d->X; W.XH = d->X + 2 * (size_t)cfg->max_batch * d->D;   // re-pointed per step (the interpolates follow the 2B stacked rows)
+    *out = d;
+    return ILSX_OK;
+  }
   ilsx_mlp_cfg mc = {d->D, d->nblk, cfg->hid_dim, 1, 1, cfg->hid_act};
   int rc = net_layout_build(mc, &d->L);
   if (rc != ILSX_OK) { delete d; return rc; }
@@ -424,6 +495,14 @@ extern "C" int ilsx_disc_destroy(ilsx_disc* d) {
   if (d->gdx) ctx_free(d->ctx, d->gdx);
   if (d->dhead4) ctx_free(d->ctx, d->dhead4);
   if (d->snap) ctx_free(d->ctx, d->snap);
+  if (d->bn) {
+    DiscBn* b = d->bn;
+    DbnWs& W = b->W;
+    for (int l = 0; l < b->N.nblk; ++l)
+      for (float* p : {W.ch[l], W.ah[l], W.h[l], W.p[l], W.uh[l], W.uy[l], W.uah[l], W.tt[l], W.ua[l], W.ybar[l], W.ahbar[l], W.s[l], W.m2[l], W.sbar[l]}) ctx_free(d->ctx, p);
+    for (float* p : {W.t0, W.t1, W.logit, W.dlogit, W.gate, W.ce_row, W.correct, W.gp_row, b->lg, b->stats3, b->xcat, b->N.rmean, b->N.rvar}) ctx_free(d->ctx, p);
+    delete b;
+  }
   delete d;
   return ILSX_OK;
 }
@@ -433,20 +512,47 @@ extern "C" int ilsx_disc_num_params(const ilsx_disc* d, size_t* out) {
   *out = d->L.n_flat;
   return ILSX_OK;
 }
+// use_bn: the flat ABI order is the storage order — a plain copy
+static int bn_copy(ilsx_disc* d, float* dev, float* host, size_t n, size_t want, bool to_dev) {
+  if (n != want) ILSX_FAIL(ILSX_ERR_ARG, "count %zu != expected %zu", n, want);
+  HIPCHK(hipMemcpyAsync(to_dev ? (void*)dev : (void*)host, to_dev ? (const void*)host : (const void*)dev, n * sizeof(float),
+                        to_dev ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, d->ctx->stream));
+  HIPCHK(hipStreamSynchronize(d->ctx->stream));
+  return ILSX_OK;
+}
 extern "C" int ilsx_disc_set_params(ilsx_disc* d, const float* src, size_t n) {
   if (!d || !src) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
   HIPCHK(hipSetDevice(d->ctx->device));
+  if (d->bn) return bn_copy(d, d->P, const_cast<float*>(src), n, d->L.n_flat, true);
   return net_upload_flat(d->ctx, d->L, d->P, src, n, 0);
 }
 extern "C" int ilsx_disc_get_params(ilsx_disc* d, float* dst, size_t n) {
   if (!d || !dst) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
   HIPCHK(hipSetDevice(d->ctx->device));
+  if (d->bn) return bn_copy(d, d->P, dst, n, d->L.n_flat, false);
   return net_download_flat(d->ctx, d->L, d->P, dst, n, 0);
 }
 extern "C" int ilsx_disc_get_grads(ilsx_disc* d, float* dst, size_t n) {
   if (!d || !dst) ILSX_FAIL(ILSX_ERR_ARG, "NULL argument");
   HIPCHK(hipSetDevice(d->ctx->device));
+  if (d->bn) return bn_copy(d, d->G, dst, n, d->L.n_flat, false);
   return net_download_flat(d->ctx, d->L, d->G, dst, n, 0);
+}
+extern "C" int ilsx_disc_get_bn_stats(ilsx_disc* d, float* rm_host, float* rv_host, size_t n) {
+  if (!d || !rm_host || !rv_host) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_disc_get_bn_stats: NULL argument");
+  if (!d->bn) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_disc_get_bn_stats: this discriminator has no batch norm (use_bn = 0)");
+  HIPCHK(hipSetDevice(d->ctx->device));
+  const size_t want = (size_t)d->bn->N.nblk * d->bn->N.H;
+  ILSX_TRY(bn_copy(d, d->bn->N.rmean, rm_host, n, want, false));
+  return bn_copy(d, d->bn->N.rvar, rv_host, n, want, false);
+}
+extern "C" int ilsx_disc_set_bn_stats(ilsx_disc* d, const float* rm_host, const float* rv_host, size_t n) {
+  if (!d || !rm_host || !rv_host) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_disc_set_bn_stats: NULL argument");
+  if (!d->bn) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_disc_set_bn_stats: this discriminator has no batch norm (use_bn = 0)");
+  HIPCHK(hipSetDevice(d->ctx->device));
+  const size_t want = (size_t)d->bn->N.nblk * d->bn->N.H;
+  ILSX_TRY(bn_copy(d, d->bn->N.rmean, const_cast<float*>(rm_host), n, want, true));
+  return bn_copy(d, d->bn->N.rvar, const_cast<float*>(rv_host), n, want, true);
 }
 
 // disc_optimizer state (adv_irl.py:75-77) for snapshots / resume: Adam moments in the flat ABI layout, step count, Philox counter
@@ -454,6 +560,12 @@ static int disc_opt(ilsx_disc* d, bool set, float* m_host, float* v_host, size_t
   if (!d || !m_host || !v_host) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_disc_*_opt: NULL argument");
   HIPCHK(hipSetDevice(d->ctx->device));
   hipStream_t st = d->ctx->stream;
+  if (d->bn) {   // natural layout; the Adam step count is the host's
+    ILSX_TRY(bn_copy(d, d->M, m_host, n, d->L.n_flat, set));
+    ILSX_TRY(bn_copy(d, d->V, v_host, n, d->L.n_flat, set));
+    if (meta) { if (set) { d->bn->t = (int)meta->t; d->step_ctr = meta->rng_step; } else { meta->t = d->bn->t; meta->rng_step = d->step_ctr; meta->n_train_steps = 0; } }
+    return ILSX_OK;
+  }
   if (set) { ILSX_TRY(net_upload_flat(d->ctx, d->L, d->M, m_host, n, 0)); ILSX_TRY(net_upload_flat(d->ctx, d->L, d->V, v_host, n, 0)); }
   else { ILSX_TRY(net_download_flat(d->ctx, d->L, d->M, m_host, n, 0)); ILSX_TRY(net_download_flat(d->ctx, d->L, d->V, v_host, n, 0)); }
   if (!meta) return ILSX_OK;
@@ -681,7 +793,30 @@ static int disc_train_step_from_rings(ilsx_disc* d, ilsx_replay* expert_rb, ilsx
   return disc_step_after_prep(d, B, stats);
 }
 
+// use_bn: d->X holds [expert ; policy ; interpolates] (k_disc_prep / k_disc_prep_rings), row stride D
+static int discbn_step(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
+  DiscBn* b = d->bn;
+  if (3 * B > b->rows) ILSX_FAIL(ILSX_ERR_ARG, "batch %d exceeds the workspace", B);
+  if (B < 2) ILSX_FAIL(ILSX_ERR_ARG, "a BatchNorm discriminator needs at least 2 rows per class (torch raises on a single-row training batch)");
+  DbnLaunch L{d->ctx->stream};
+  DbnWs W = b->W;
+  W.X = d->X; W.XH = d->X + 2 * (size_t)B * d->D;
+  const int gp = d->cfg.use_grad_pen ? 1 : 0;
+  dbn_backward(L, b->N, W, B, gp, d->cfg.grad_pen_weight);
+  dbn_stats(L, W, B, gp, b->stats3);
+  dbn_adam_step(L, b->N, d->cfg.disc_lr, d->cfg.disc_momentum, ++b->t);
+  HIPCHK(hipGetLastError());
+  if (stats) {
+    float h3[3];
+    HIPCHK(hipMemcpyAsync(h3, b->stats3, sizeof h3, hipMemcpyDeviceToHost, d->ctx->stream));
+    HIPCHK(hipStreamSynchronize(d->ctx->stream));
+    stats->ce_loss = h3[0]; stats->accuracy = h3[1]; stats->grad_pen = h3[2];
+  }
+  return ILSX_OK;
+}
+
 static int disc_step_after_prep(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
+  if (d->bn) return discbn_step(d, B, stats);
   if (d->nblk != 2) return disc_step_blocks(d, B, stats);
   ilsx_ctx* ctx = d->ctx;
   ILSX_TRY(disc_build_jobs(d, B));
@@ -737,6 +872,19 @@ extern "C" int ilsx_disc_reward(ilsx_disc* d, const float* obs, const float* act
   if (n < 1 || n > 3 * d->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "n=%d not in 1..3*max_batch", n);
   if (mode < 0 || mode > 3) ILSX_FAIL(ILSX_ERR_ARG, "unknown reward mode %d", mode);
   HIPCHK(hipSetDevice(d->ctx->device));
+  if (d->bn) {   // eval mode (adv_irl.py:268-274): the running statistics
+    DiscBn* b = d->bn;
+    if (n > b->rows) ILSX_FAIL(ILSX_ERR_ARG, "n=%d exceeds the workspace", n);
+    DbnLaunch L{d->ctx->stream};
+    float* xc = b->xcat;
+    const int o = d->o, a = d->a, D = d->D;
+    L.par(n * D, [=] __device__(int idx) { const int r = idx / D, k = idx - r * D; xc[idx] = k < o ? obs[(size_t)r * o + k] : act[(size_t)r * a + (k - o)]; });
+    dbn_logits_eval(L, b->N, b->W, xc, n, b->lg);
+    hipLaunchKernelGGL(k_disc_reward, dim3((n + 255) / 256), dim3(256), 0, d->ctx->stream, PartVal{b->lg, 1, n}, n, d->cfg.clamp_magnitude,
+                       mode, has_min, rmin, has_max, rmax, rew, logits);
+    HIPCHK(hipGetLastError());
+    return ILSX_OK;
+  }
   ILSX_TRY(disc_forward(d, obs, d->o, d->o, act, d->a, d->a, n, false));
   hipLaunchKernelGGL(k_disc_reward, dim3((n + 255) / 256), dim3(256), 0, d->ctx->stream, d->pv(), n, d->cfg.clamp_magnitude,
                      mode, has_min, rmin, has_max, rmax, rew, logits);
@@ -763,7 +911,7 @@ extern "C" int ilsx_advirl_train(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* exper
   if (!d || !sac || !expert_rb || !policy_rb || loops < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_advirl_train: bad argument");
   HIPCHK(hipSetDevice(d->ctx->device));
   static const bool no_window = getenv("ILSX_ADVIRL_NO_WINDOW") != nullptr;
-  const bool checkpoint = !no_window && policy_batch >= 1 && sac_window_may_use_phase(sac, policy_batch);
+  const bool checkpoint = !no_window && !d->bn && policy_batch >= 1 && sac_window_may_use_phase(sac, policy_batch);
   const size_t n = d->L.n_int;
   const unsigned long long c_e = expert_rb->sample_ctr, c_p = policy_rb->sample_ctr, c_d = d->step_ctr;
   if (checkpoint) {
@@ -804,7 +952,8 @@ static int advirl_train_once(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* expert_rb
   if (expert_rb->o != o || policy_rb->o != o || expert_rb->a != a || (!so && a != d->cfg.act_dim))
     ILSX_FAIL(ILSX_ERR_ARG, "replay dims do not match the discriminator");
   bool first_disc = true, first_pol = true, in_window = false;
-  static const bool no_window = getenv("ILSX_ADVIRL_NO_WINDOW") != nullptr;
+  static const bool no_window_env = getenv("ILSX_ADVIRL_NO_WINDOW") != nullptr;
+  const bool no_window = no_window_env || d->bn != nullptr;   // (the BatchNorm discriminator's state is not part of the window checkpoint)
   struct WindowGuard { ilsx_sac* s; bool* on; ~WindowGuard() { if (*on) sac_window_end(s); } } window_guard{sac, &in_window};   // error paths
   for (int it = 0; it < loops; ++it) {
     for (int k = 0; k < disc_updates; ++k) {   // adv_irl.py:133-216

@@ -280,7 +280,7 @@ int ilsx_debug_rng_stream(const void* object, int kind, uint32_t* stream, uint64
 int ilsx_debug_philox(ilsx_ctx* ctx, uint64_t seed, uint64_t step, uint32_t stream, int n_rows, int a, uint32_t* raw, float* normals);
 
 /* ---------------------------------------------------------------- adversarial-IRL discriminator
- * Replaces rlkit/torch/algorithms/adv_irl/disc_models/simple_disc_models.py:8-48 (MLPDisc, use_bn=False),
+ * Replaces rlkit/torch/algorithms/adv_irl/disc_models/simple_disc_models.py:8-48 (MLPDisc, with and without batch norm),
  * AdvIRL._do_reward_training (adv_irl.py:133-216: BCE-with-logits on [expert; policy] + WGAN-GP gradient
  * penalty, the double backward derived by hand) and the reward modes of _do_policy_training (:277-298).
  * cfg fields == the YAML keys (exp_specs/gail/gail_walker.yaml:24-28,55-59). */
@@ -295,6 +295,12 @@ typedef struct {
                                      every `act` row pointer of the entry points below carries next_obs rows */
   int32_t num_layer_blocks;       /* simple_disc_models.py:11,29-39: hidden (Linear, act) blocks, 1..3; 0 = 2.  2 runs the fused
                                      double-backward kernel, 1 and 3 the same mathematics as a chain of per-layer launches */
+  int32_t use_bn;                 /* simple_disc_models.py:15,30-31,36-37 (the constructor's default): every block is Linear -> BatchNorm1d ->
+                                     act.  Train mode in both forwards of a step (cross-entropy rows and penalty interpolates, each with its
+                                     own batch statistics, running statistics updated by both), the penalty's double backward through the
+                                     batch statistics; ilsx_disc_reward uses the running statistics (eval mode, adv_irl.py:268-274).  Any
+                                     hid_dim; parameters in torch's order: per block W | b | gamma | beta, then the output layer.  A chain of
+                                     simple launches (csrc/disc_bn.h), not the fused MFMA kernels of use_bn = 0 */
 } ilsx_disc_cfg;
 typedef struct { float ce_loss, grad_pen, accuracy; } ilsx_disc_stats;   /* "Disc CE Loss", "Grad Pen", "Disc Acc" */
 int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_disc** out);
@@ -304,6 +310,10 @@ int ilsx_disc_num_params(const ilsx_disc* disc, size_t* out);
 int ilsx_disc_set_params(ilsx_disc* disc, const float* src_host, size_t n);
 int ilsx_disc_get_params(ilsx_disc* disc, float* dst_host, size_t n);
 int ilsx_disc_get_grads(ilsx_disc* disc, float* dst_host, size_t n);
+/* use_bn discriminators: the BatchNorm running statistics (module buffers, not parameters: snapshots carry them beside the parameters),
+ * HOST arrays [num_layer_blocks * hid_dim] each, block-major */
+int ilsx_disc_get_bn_stats(ilsx_disc* disc, float* running_mean_host, float* running_var_host, size_t n);
+int ilsx_disc_set_bn_stats(ilsx_disc* disc, const float* running_mean_host, const float* running_var_host, size_t n);
 /* one _do_reward_training step; inputs are device rows exp_obs[B,o] exp_act[B,a] pol_obs[B,o] pol_act[B,a];
  * eps (device [B], U[0,1) interpolation weights) or NULL = Philox. */
 int ilsx_disc_train_step(ilsx_disc* disc, const float* exp_obs, const float* exp_act, const float* pol_obs,

@@ -251,8 +251,8 @@ def test_ctor_signatures_are_the_references():
 
 def test_unimplemented_disc_options_fail_loudly():
     from ilswiss_amd.adv_irl import MLPDisc
-    with pytest.raises(NotImplementedError, match="use_bn"):
-        MLPDisc(23, ctx=object())                      # the reference's default network has BatchNorm: never silently something else
+    d = MLPDisc(23, ctx=object())                      # the reference's default network HAS BatchNorm (simple_disc_models.py:15) and is built as such
+    assert d.use_bn and d.hid_dim == 100 and d.num_params == (23 * 100 + 3 * 100) + (100 * 100 + 3 * 100) + 100 + 1
     with pytest.raises(NotImplementedError, match="num_layer_blocks"):
         MLPDisc(23, num_layer_blocks=4, use_bn=False, ctx=object())
 
@@ -314,3 +314,122 @@ def test_hip_policy_batch_from_expert_and_state_only_relabel_golden(ctx):
         assert (src[: Bp - nfe] < Bp - nfe).all() and (src[Bp - nfe:] >= Bp - nfe).all(), (path, src)   # policy rows first, expert rows last
         np.testing.assert_allclose(rew, g["pt_rewards"][src, 0], rtol=1e-4, atol=2e-5)
         np.testing.assert_array_equal(nobs, np.concatenate([pol["next_observations"], exp["next_observations"]])[src])
+
+
+BN_CASES = ["tanh2", "relu2", "tanh3", "relu1"]
+
+
+def _bn_check_final(g, tag, disc, steps, lr):
+    dead = g[f"{tag}_dead_bias_mask"].astype(bool)
+    d = np.abs(disc.get_flat_params() - g[f"{tag}_params_final"])
+    # Linear biases under a BatchNorm have gradient exactly 0; what any implementation holds there is rounding noise that Adam turns into
+    # +-lr steps (they do not influence the function).  Every other parameter: 5e-5 after the chained steps
+    assert d[~dead].max() < 5e-5 and d[dead].max() <= steps * 2.02 * lr, (tag, d[~dead].max(), d[dead].max())
+    rm, rv = disc.get_bn_stats()
+    np.testing.assert_allclose(rv, g[f"{tag}_running_var"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rm, g[f"{tag}_running_mean"], rtol=0, atol=steps * 2.02 * lr + 1e-5)
+    np.testing.assert_allclose(disc(g[f"{tag}_probe"]), g[f"{tag}_probe_logits_eval"], rtol=1e-3, atol=3e-3)   # eval mode: running statistics
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", BN_CASES)
+def test_hip_disc_bn_golden(ctx, tag):
+    """MLPDisc(use_bn=True) — the reference constructor's default — on the HIP path vs the reference's own numbers (g26: AdvIRL._do_reward_training
+    with the module in train mode, then the eval-mode logits of _do_policy_training): chained steps, tanh / relu, 1-3 blocks, hid_dim 100."""
+    from ilswiss_amd.adv_irl import MLPDisc
+    g = load_golden("g26_disc_bn")
+    D, Hd, B, steps, o, L = [int(v) for v in g[f"{tag}_dims"]]
+    disc = MLPDisc(D, num_layer_blocks=L, hid_dim=Hd, hid_act=tag[:4], use_bn=True, ctx=ctx).bind(o, max_batch=max(B, 20), **KW)
+    assert disc.num_params == g[f"{tag}_params0"].size
+    disc.set_flat_params(g[f"{tag}_params0"])
+    np.testing.assert_array_equal(disc.get_flat_params(), g[f"{tag}_params0"])
+    for s in range(steps):
+        xe, xp = g[f"{tag}_s{s}_x_exp"], g[f"{tag}_s{s}_x_pol"]
+        st = disc.train_step(xe[:, :o], xe[:, o:], xp[:, :o], xp[:, o:], eps=g[f"{tag}_s{s}_eps"])
+        np.testing.assert_allclose(st["Disc CE Loss"], g[f"{tag}_s{s}_ce"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(st["Grad Pen"], g[f"{tag}_s{s}_gp"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(st["Disc Acc"], g[f"{tag}_s{s}_acc"])
+        if s == 0:
+            ref, got, live = g[f"{tag}_s0_grad"], disc.get_flat_grads(), ~g[f"{tag}_dead_bias_mask"].astype(bool)
+            assert np.abs(got - ref)[live].max() <= 1e-4 * np.abs(ref).max(), (np.abs(got - ref)[live].max(), np.abs(ref).max())
+    _bn_check_final(g, tag, disc, steps, KW["disc_lr"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("o,a,Hd,B,act,L,gp", [(17, 6, 128, 256, "tanh", 2, True), (11, 3, 100, 64, "relu", 2, True), (17, 6, 64, 48, "tanh", 3, False)])
+def test_hip_disc_bn_vs_oracle(ctx, o, a, Hd, B, act, L, gp):
+    """the same at the configs' sizes (GAIL Walker2d: 23 -> 128 -> 128 -> 1, B = 256) against oracle.DiscBNOracle, three chained steps,
+    with the relabelled rewards of the eval-mode forward (adv_irl.py:268-301) after them"""
+    from ilswiss_amd.adv_irl import MLPDisc
+    from oracle.disc import DiscBNOracle, disc_reward
+    rng = np.random.default_rng(o + Hd + B)
+    D = o + a
+    flat = DiscBNOracle.init(rng, D, Hd, L)
+    kw = dict(KW, use_grad_pen=gp)
+    disc = MLPDisc(D, num_layer_blocks=L, hid_dim=Hd, hid_act=act, use_bn=True, ctx=ctx).bind(o, max_batch=B, **kw)
+    disc.set_flat_params(flat)
+    orc = DiscBNOracle(D, Hd, flat, act=TANH if act == "tanh" else RELU, num_layer_blocks=L, **kw)
+    live = ~orc.dead_bias_mask()
+    for s in range(3):
+        xe = rng.normal(0, 1, (B, D)).astype(np.float32)
+        xp = (rng.normal(0, 1, (B, D)) * 1.5 + 0.3).astype(np.float32)
+        eps = rng.random((B, 1)).astype(np.float32)
+        st = disc.train_step(xe[:, :o], xe[:, o:], xp[:, :o], xp[:, o:], eps=eps)
+        res = orc.train_step(xe, xp, eps)
+        np.testing.assert_allclose(st["Disc CE Loss"], res["ce_loss"], rtol=1e-4, atol=1e-6)
+        if gp:
+            np.testing.assert_allclose(st["Grad Pen"] * kw["grad_pen_weight"], res["grad_pen_loss"], rtol=2e-4, atol=1e-6)
+        got, ref = disc.get_flat_grads(), res["grad"]
+        assert np.abs(got - ref)[live].max() <= 1e-4 * np.abs(ref).max(), (s, np.abs(got - ref)[live].max() / np.abs(ref).max())
+    d = np.abs(disc.get_flat_params() - orc.p)
+    assert d[live].max() < 5e-5, d[live].max()
+    x = (rng.normal(0, 1, (B, D)) * 1.2).astype(np.float32)
+    rew, lg = disc.rewards(x[:, :o], x[:, o:], "gail2", rew_clip_min=-8.0)
+    np.testing.assert_allclose(lg, orc.logits(x), rtol=1e-3, atol=3e-3)
+    np.testing.assert_allclose(rew, disc_reward(orc.logits(x), "gail2", rew_clip_min=-8.0), rtol=1e-3, atol=3e-3)
+
+
+@pytest.mark.gpu
+def test_hip_gail_loop_with_the_default_bn_discriminator(ctx):
+    """AdvIRL around MLPDisc's DEFAULT constructor arguments (use_bn=True, hid_dim=100, relu): the device loop (ilsx_advirl_train) runs,
+    statistics are finite, the discriminator learns to separate two shifted clouds, and a snapshot round trip (parameters, Adam state,
+    running statistics) continues bit-exactly."""
+    import ilswiss_amd as ia
+    from ilswiss_amd.adv_irl import AdvIRLTrainer, MLPDisc
+    o, a, B = 11, 3, 64
+    rng = np.random.default_rng(5)
+
+    def ring(n, shift, seed):
+        rb = ia.SimpleReplayBuffer(n, o, a, random_seed=seed, ctx=ctx)
+        rb.add_rows(rng.normal(shift, 1, (n, o)).astype(np.float32), np.tanh(rng.normal(shift, 1, (n, a))).astype(np.float32),
+                    rng.normal(0, 1, n).astype(np.float32), np.zeros(n, np.uint8), rng.normal(shift, 1, (n, o)).astype(np.float32))
+        return rb
+    erb, prb = ring(2000, 0.8, 1), ring(4000, -0.8, 2)
+
+    def build(seed):
+        pol = ia.ReparamTanhMultivariateGaussianPolicy([64, 64], o, a, ctx=ctx, seed=seed)
+        q1, q2 = ia.FlattenMlp([64, 64], 1, o + a, ctx=ctx, seed=seed + 1), ia.FlattenMlp([64, 64], 1, o + a, ctx=ctx, seed=seed + 2)
+        sac = ia.SoftActorCritic(pol, q1, q2, max_batch=B, policy_lr=3e-4, qf_lr=3e-4)
+        disc = MLPDisc(o + a, ctx=ctx, seed=seed + 3)                  # every default: 2 blocks of 100, relu, batch norm, clamp 10
+        return AdvIRLTrainer("gail2", disc, sac, erb, disc_optim_batch_size=B, policy_optim_batch_size=B, num_update_loops_per_train_call=5,
+                             num_disc_updates_per_loop_iter=1, num_policy_updates_per_loop_iter=1, replay_buffer=prb, disc_lr=3e-3, disc_momentum=0.9,
+                             use_grad_pen=True, grad_pen_weight=4.0)
+    irl = build(10)
+    assert irl.disc.use_bn and irl.disc.hid_dim == 100
+    irl.train(1)
+    st0 = dict(irl.get_eval_statistics())
+    for _ in range(30):
+        irl.train(1)
+    irl.end_epoch()
+    irl.train(1)
+    st1 = dict(irl.get_eval_statistics())
+    for st in (st0, st1):
+        assert all(np.isfinite(v) for v in st.values()), st
+    assert st1["Disc Acc"] > 0.9 and st1["Disc CE Loss"] < st0["Disc CE Loss"], (st0, st1)
+    rm, rv = irl.disc.get_bn_stats()
+    assert np.isfinite(rm).all() and (rv > 0).all() and np.abs(rm).max() > 1e-3
+    snap = irl.get_snapshot()
+    irl2 = build(99)                     # different initial weights
+    irl2.load_snapshot(snap)
+    np.testing.assert_array_equal(irl2.disc.get_flat_params(), irl.disc.get_flat_params())
+    np.testing.assert_array_equal(irl2.disc.get_bn_stats()[1], rv)
