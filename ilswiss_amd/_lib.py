@@ -15,7 +15,7 @@ vp = C.c_void_p
 
 class MlpCfg(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("n_hidden", C.c_int32), ("hidden", C.c_int32),
-                ("out_dim", C.c_int32), ("n_heads", C.c_int32), ("act", C.c_int32)]
+                ("out_dim", C.c_int32), ("n_heads", C.c_int32), ("act", C.c_int32), ("hidden_sizes", C.c_int32 * 3)]
 
 
 class SacCfg(C.Structure):

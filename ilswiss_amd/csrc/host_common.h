@@ -119,7 +119,9 @@ struct NetLayout {
   int off_Wh = 0, off_bh = 0;
   size_t n_int = 0;   // internal floats (multiple of 4)
   size_t n_flat = 0;  // ABI floats
-  int in_of(int l) const { return l == 0 ? cfg.in_dim : cfg.hidden; }
+  int hl[ILSX_MAX_HID] = {0, 0, 0};   // logical width of hidden layer l (<= cfg.hidden: ilsx_mlp_cfg::hidden_sizes)
+  int out_of(int l) const { return hl[l] > 0 ? hl[l] : cfg.hidden; }
+  int in_of(int l) const { return l == 0 ? cfg.in_dim : out_of(l - 1); }   // LOGICAL inputs of layer l (flat ABI sizes)
 };
 int net_layout_build(const ilsx_mlp_cfg& cfg, NetLayout* L);
 void net_flat_to_internal(const NetLayout& L, const float* flat, float* internal);

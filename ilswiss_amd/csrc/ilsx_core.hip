@@ -196,6 +196,12 @@ int net_layout_build(const ilsx_mlp_cfg& cfg, NetLayout* L) {
               cfg.out_dim, ILSX_MAX_NO);
   if (cfg.act != ILSX_ACT_RELU && cfg.act != ILSX_ACT_TANH) ILSX_FAIL(ILSX_ERR_ARG, "act=%d unknown", cfg.act);
   L->cfg = cfg;
+  for (int l = 0; l < ILSX_MAX_HID; ++l) {
+    const int hs = l < cfg.n_hidden ? cfg.hidden_sizes[l] : 0;
+    if (hs < 0 || hs > cfg.hidden) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "hidden_sizes[%d]=%d: 1..hidden=%d (0 = hidden)", l, hs, cfg.hidden);
+    L->hl[l] = hs > 0 ? hs : (l < cfg.n_hidden ? cfg.hidden : 0);
+    L->cfg.hidden_sizes[l] = l < cfg.n_hidden ? L->hl[l] : 0;   // canonical form: two layouts of the same network compare equal
+  }
   L->KP = round_up(cfg.in_dim, 16);
   L->NO = cfg.n_heads * cfg.out_dim;
   const int H = cfg.hidden;
@@ -211,13 +217,13 @@ int net_layout_build(const ilsx_mlp_cfg& cfg, NetLayout* L) {
     }
     L->off_b[l] = (int)off;
     off += H;
-    nflat += (size_t)H * L->in_of(l) + H;
+    nflat += (size_t)L->out_of(l) * L->in_of(l) + L->out_of(l);
   }
   L->off_Wh = (int)off;
   off += (size_t)L->NO * H;
   L->off_bh = (int)off;
   off += round_up(L->NO, 4);
-  nflat += (size_t)L->NO * H + L->NO;
+  nflat += (size_t)L->NO * L->out_of(cfg.n_hidden - 1) + L->NO;
   L->n_int = off;
   L->n_flat = nflat;
   return ILSX_OK;
@@ -227,23 +233,23 @@ void net_flat_to_internal(const NetLayout& L, const float* flat, float* in) {
   std::fill(in, in + L.n_int, 0.0f);
   const int H = L.cfg.hidden;
   size_t f = 0;
-  for (int l = 0; l < L.cfg.n_hidden; ++l) {
-    const int ind = L.in_of(l);
-    for (int n = 0; n < H; ++n)
+  for (int l = 0; l < L.cfg.n_hidden; ++l) {   // logical rows / columns only: everything else stays the structural zero of the fill above
+    const int ind = L.in_of(l), outd = L.out_of(l);
+    for (int n = 0; n < outd; ++n)
       for (int k = 0; k < ind; ++k) {
         const float v = flat[f + (size_t)n * ind + k];
         in[L.off_W[l] + pack_f(n, k, L.ld[l])] = v;
         if (l > 0) in[L.off_Wb[l] + pack_b(n, k, H)] = v;
       }
-    f += (size_t)H * ind;
-    for (int n = 0; n < H; ++n) in[L.off_b[l] + n] = flat[f + n];
-    f += H;
+    f += (size_t)outd * ind;
+    for (int n = 0; n < outd; ++n) in[L.off_b[l] + n] = flat[f + n];
+    f += outd;
   }
-  const int od = L.cfg.out_dim;
+  const int od = L.cfg.out_dim, hlast = L.out_of(L.cfg.n_hidden - 1);
   for (int h = 0; h < L.cfg.n_heads; ++h) {
     for (int j = 0; j < od; ++j)
-      for (int k = 0; k < H; ++k) in[L.off_Wh + (size_t)(h * od + j) * H + k] = flat[f + (size_t)j * H + k];
-    f += (size_t)od * H;
+      for (int k = 0; k < hlast; ++k) in[L.off_Wh + (size_t)(h * od + j) * H + k] = flat[f + (size_t)j * hlast + k];
+    f += (size_t)od * hlast;
     for (int j = 0; j < od; ++j) in[L.off_bh + h * od + j] = flat[f + j];
     f += od;
   }
@@ -253,18 +259,18 @@ void net_internal_to_flat(const NetLayout& L, const float* in, float* flat) {
   const int H = L.cfg.hidden;
   size_t f = 0;
   for (int l = 0; l < L.cfg.n_hidden; ++l) {
-    const int ind = L.in_of(l);
-    for (int n = 0; n < H; ++n)
+    const int ind = L.in_of(l), outd = L.out_of(l);
+    for (int n = 0; n < outd; ++n)
       for (int k = 0; k < ind; ++k) flat[f + (size_t)n * ind + k] = in[L.off_W[l] + pack_f(n, k, L.ld[l])];
-    f += (size_t)H * ind;
-    for (int n = 0; n < H; ++n) flat[f + n] = in[L.off_b[l] + n];
-    f += H;
+    f += (size_t)outd * ind;
+    for (int n = 0; n < outd; ++n) flat[f + n] = in[L.off_b[l] + n];
+    f += outd;
   }
-  const int od = L.cfg.out_dim;
+  const int od = L.cfg.out_dim, hlast = L.out_of(L.cfg.n_hidden - 1);
   for (int h = 0; h < L.cfg.n_heads; ++h) {
     for (int j = 0; j < od; ++j)
-      for (int k = 0; k < H; ++k) flat[f + (size_t)j * H + k] = in[L.off_Wh + (size_t)(h * od + j) * H + k];
-    f += (size_t)od * H;
+      for (int k = 0; k < hlast; ++k) flat[f + (size_t)j * hlast + k] = in[L.off_Wh + (size_t)(h * od + j) * H + k];
+    f += (size_t)od * hlast;
     for (int j = 0; j < od; ++j) flat[f + j] = in[L.off_bh + h * od + j];
     f += od;
   }
@@ -789,15 +795,15 @@ extern "C" int ilsx_net_init(ilsx_net* n, uint64_t seed, float init_w, float b_i
   std::mt19937_64 gen(seed);
   std::vector<float> flat(L.n_flat);
   size_t f = 0;
-  const int H = L.cfg.hidden;
   for (int l = 0; l < L.cfg.n_hidden; ++l) {
-    const float bound = 1.0f / std::sqrt((float)H);
+    const int outd = L.out_of(l);
+    const float bound = 1.0f / std::sqrt((float)outd);   // fanin_init: 1 / sqrt(weight.size(0)) — the layer's LOGICAL width
     std::uniform_real_distribution<float> u(-bound, bound);
-    const size_t nw = (size_t)H * L.in_of(l);
+    const size_t nw = (size_t)outd * L.in_of(l);
     for (size_t i = 0; i < nw; ++i) flat[f + i] = u(gen);
     f += nw;
-    for (int i = 0; i < H; ++i) flat[f + i] = b_init;
-    f += H;
+    for (int i = 0; i < outd; ++i) flat[f + i] = b_init;
+    f += outd;
   }
   std::uniform_real_distribution<float> uh(-init_w, init_w);
   for (; f < L.n_flat; ++f) flat[f] = uh(gen);

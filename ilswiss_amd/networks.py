@@ -11,6 +11,7 @@ from . import _lib
 from .device import DevArray, as_dev, get_context
 
 _ACT = {"relu": 0, "tanh": 1}
+_WIDTHS = (64, 128, 256)   # hidden widths the kernels are instantiated for
 
 
 def _act_code(fn):
@@ -44,14 +45,20 @@ class Mlp:
         kwargs.pop("layer_norm_kwargs", None)   # only read when layer_norm is on
         if kwargs:
             raise TypeError(f"{type(self).__name__}: unexpected keyword arguments {sorted(kwargs)}")
-        hidden_sizes = list(hidden_sizes)
-        if len(set(hidden_sizes)) != 1:
-            raise ValueError("libilsx needs equal hidden widths")
+        hidden_sizes = [int(h) for h in hidden_sizes]
+        # networks.py:23-60 takes any list of widths.  The kernels run at 64 / 128 / 256: a narrower (or unequal) layer is embedded as structural
+        # zeros by the library (include/ilsx.h ilsx_mlp_cfg::hidden_sizes) — the padded network IS the hidden_sizes network, and every flat
+        # parameter / gradient / optimiser vector keeps the logical sizes.  Wider than 256 has no kernel.
+        if not 1 <= len(hidden_sizes) <= 3 or min(hidden_sizes) < 1:
+            raise NotImplementedError(f"hidden_sizes={hidden_sizes}: libilsx runs 1..3 hidden layers")
+        if max(hidden_sizes) > _WIDTHS[-1]:
+            raise NotImplementedError(f"hidden_sizes={hidden_sizes}: the widest kernel instantiation is {_WIDTHS[-1]}")
         self.ctx = ctx or get_context()
         self.hidden_sizes, self.input_size, self.output_size = hidden_sizes, int(input_size), int(output_size)
+        self.kernel_width = next(w for w in _WIDTHS if w >= max(hidden_sizes))
         self.init_w, self.b_init_value = float(init_w), float(b_init_value)
         self.act = _act_code(hidden_activation)
-        cfg = _lib.MlpCfg(self.input_size, len(hidden_sizes), hidden_sizes[0], self.output_size, self.n_heads, self.act)
+        cfg = self._cfg()
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_net_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
         n = C.c_size_t()
@@ -60,6 +67,10 @@ class Mlp:
         if seed is None:
             seed = int(np.random.randint(0, 2**31 - 1))  # like torch's global RNG, follows np.random.seed / set_seed
         _lib.check(self.ctx.lib.ilsx_net_init(self.h, C.c_uint64(seed), self.init_w, self.b_init_value))
+
+    def _cfg(self):
+        hs = (C.c_int32 * 3)(*(self.hidden_sizes + [0] * (3 - len(self.hidden_sizes))))
+        return _lib.MlpCfg(self.input_size, len(self.hidden_sizes), self.kernel_width, self.output_size, self.n_heads, self.act, hs)
 
     # -- parameters
     def get_flat_params(self):
@@ -74,8 +85,7 @@ class Mlp:
     def copy(self):  # PyTorchModule.copy (rlkit/torch/core.py:32-35)
         c = type(self).__new__(type(self))
         c.__dict__.update({k: v for k, v in self.__dict__.items() if k != "h"})
-        cfg = _lib.MlpCfg(self.input_size, len(self.hidden_sizes), self.hidden_sizes[0], self.output_size,
-                          self.n_heads, self.act)
+        cfg = self._cfg()
         c.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_net_create(self.ctx.h, C.byref(cfg), C.byref(c.h)))
         c.set_flat_params(self.get_flat_params())

@@ -63,6 +63,9 @@ class PPO(Trainer):
             raise ValueError("PPO networks use tanh hidden units (ppo_exp_script.py:82-96)")
         if vf.hidden_sizes != policy.hidden_sizes:
             raise ValueError("policy and value net share net_size / num_hidden_layers (ppo_exp_script.py:79-80)")
+        if len(set(policy.hidden_sizes)) != 1 or policy.hidden_sizes[0] != policy.kernel_width:
+            raise NotImplementedError(f"PPO(hidden_sizes={policy.hidden_sizes}): the PPO trainer builds its networks from ONE width of 64 / 128 / 256 "
+                                      "(ppo_exp_script.py:79-80 passes num_hidden_layers * [net_size]); unequal widths run in every other trainer")
         self.mini_batch_size, self.update_epoch, self.max_samples = int(mini_batch_size), int(update_epoch), int(max_samples)
         self.o, self.a = policy.obs_dim, policy.action_dim
         cfg = _lib.PpoCfg(self.o, self.a, len(policy.hidden_sizes), policy.hidden_sizes[0], reward_scale, discount,

@@ -112,11 +112,16 @@ int ilsx_debug_set_stamp_buffer(ilsx_ctx* ctx, void* dev_trace, int max_launches
  * rlkit/torch/common/policies.py:191-345 (n_heads = 2: mean | log_std). */
 typedef struct {
   int32_t in_dim;      /* FlattenMlp: sum of the concatenated input dims */
-  int32_t n_hidden;    /* 1..3 hidden layers, all `hidden` wide */
-  int32_t hidden;      /* 64, 128 or 256 */
+  int32_t n_hidden;    /* 1..3 hidden layers */
+  int32_t hidden;      /* the width the kernels run at: 64, 128 or 256 */
   int32_t out_dim;     /* per head */
   int32_t n_heads;     /* 1 (Mlp) or 2 (Gaussian policy: last_fc, last_fc_log_std) */
   int32_t act;         /* ILSX_ACT_* hidden activation */
+  int32_t hidden_sizes[3];   /* networks.py:23-60 takes ANY list of widths: hidden_sizes[l] = the logical width of hidden layer l, 1..hidden
+                                (0 = hidden).  A layer narrower than `hidden` is embedded in the `hidden`-wide kernels as structural zeros:
+                                units past its width have zero weights and bias, hence pre-activation 0, output 0 (relu and tanh), gradient 0,
+                                and Adam / Polyak / L2 never move them — the padded network IS the hidden_sizes network.  Every flat parameter /
+                                gradient / optimiser-state vector that crosses this ABI has the LOGICAL sizes (torch's parameters() order). */
 } ilsx_mlp_cfg;
 
 int ilsx_net_create(ilsx_ctx* ctx, const ilsx_mlp_cfg* cfg, ilsx_net** out);

@@ -11,10 +11,13 @@ def test_shape_and_state_errors_are_reported(ctx):
     from ilswiss_amd.ppo import PPO, ReparamMultivariateGaussianPolicy
     from ilswiss_amd.replay import SimpleReplayBuffer
     from ilswiss_amd.td3 import TD3, MlpGaussianNoisePolicy
-    with pytest.raises(RuntimeError, match="supported widths"):
-        ia.FlattenMlp([100, 100], 1, 14, ctx=ctx)
-    with pytest.raises(ValueError, match="equal hidden widths"):
-        ia.FlattenMlp([128, 256], 1, 14, ctx=ctx)
+    with pytest.raises(NotImplementedError, match="widest kernel"):
+        ia.FlattenMlp([400, 300], 1, 14, ctx=ctx)            # any widths up to 256 run (embedded as structural zeros); wider has no kernel
+    assert ia.FlattenMlp([100, 100], 1, 14, ctx=ctx).num_params == 14 * 100 + 100 + 100 * 100 + 100 + 100 + 1
+    assert ia.FlattenMlp([128, 256], 1, 14, ctx=ctx).kernel_width == 256
+    with pytest.raises(NotImplementedError, match="PPO"):
+        PPO(ReparamMultivariateGaussianPolicy([128, 64], 11, 3, conditioned_std=False, hidden_activation="tanh", ctx=ctx),
+            ia.Mlp([128, 64], 1, 11, hidden_activation="tanh", ctx=ctx))
     net = ia.FlattenMlp([64, 64], 1, 14, ctx=ctx)
     with pytest.raises(RuntimeError, match="libilsx error"):
         net.set_flat_params(np.zeros(net.num_params + 1, np.float32))

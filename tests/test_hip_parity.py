@@ -624,3 +624,60 @@ def test_deferred_tail_is_bitwise_the_tail_launch():
         outs[tag] = json.loads(r.stdout.strip().splitlines()[-1])
     assert outs["defer"] == outs["plain"], outs
     assert outs["defer"] == outs["defer_nograph"], outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["relu_200_100", "tanh_200_100", "relu_48_160_96", "tanh_100"])
+def test_mlp_unequal_widths_forward_golden(ctx, tag):
+    """networks.py:23-60 takes ANY hidden_sizes; the kernels run at 64 / 128 / 256 and the library embeds a narrower or unequal layer as
+    structural zeros (include/ilsx.h ilsx_mlp_cfg::hidden_sizes).  The reference's own forward of [200, 100], [48, 160, 96] and [100] nets
+    (g2b, reference-generated) must come out of FlattenMlp(hidden_sizes=...) with the LOGICAL parameter vector set and read back unchanged."""
+    import ilswiss_amd as ia
+    g = load_golden("g2b_mlp_unequal")
+    Hh = [int(v) for v in g[f"{tag}_hidden"]]
+    net = ia.FlattenMlp(Hh, 1, 14, hidden_activation=tag.split("_")[0], ctx=ctx)
+    assert net.num_params == g[f"{tag}_params"].size and net.kernel_width == (256 if max(Hh) > 128 else 128)
+    net.set_flat_params(g[f"{tag}_params"])
+    np.testing.assert_array_equal(net.get_flat_params(), g[f"{tag}_params"])
+    np.testing.assert_allclose(net(g[f"{tag}_obs"], g[f"{tag}_act"]), g[f"{tag}_y"], rtol=1e-5, atol=2e-6)
+    fresh = ia.FlattenMlp(Hh, 1, 14, ctx=ctx, seed=4)       # the init rule on LOGICAL sizes: fanin bound 1 / sqrt(out features), biases 0.1
+    omlp, _ = _oracle()
+    lay = omlp.unpack(fresh.get_flat_params(), 14, Hh, 1)
+    for l, h in enumerate(Hh):
+        assert lay[l][0].shape == (h, 14 if l == 0 else Hh[l - 1]) and 0.85 / np.sqrt(h) < np.abs(lay[l][0]).max() <= 1 / np.sqrt(h) and np.allclose(lay[l][1], 0.1)
+
+
+@pytest.mark.gpu
+def test_sac_steps_with_unequal_widths_vs_oracle(ctx):
+    """SAC on [200, 100] networks (policy and critics): five chained train steps land on the oracle's parameters — the structural zeros stay
+    zero through Adam and the Polyak update (a unit that moved would show up as a parameter error), gradients within 1e-4 of the oracle's."""
+    import ilswiss_amd as ia
+    from oracle.sac_alpha import SacAlphaOracle
+    omlp, _ = _oracle()
+    o, a, Hh, B = 11, 3, [200, 100], 64
+    rng = np.random.default_rng(71)
+    pi0 = omlp.init_mlp(rng, o, Hh, a, init_w=1e-3, n_heads=2)
+    q10, q20 = omlp.init_mlp(rng, o + a, Hh, 1), omlp.init_mlp(rng, o + a, Hh, 1)
+    kw = dict(policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005)
+    pol = ia.ReparamTanhMultivariateGaussianPolicy(Hh, o, a, ctx=ctx)
+    q1, q2 = ia.FlattenMlp(Hh, 1, o + a, ctx=ctx), ia.FlattenMlp(Hh, 1, o + a, ctx=ctx)
+    pol.set_flat_params(pi0), q1.set_flat_params(q10), q2.set_flat_params(q20)
+    tr = ia.SoftActorCritic(pol, q1, q2, max_batch=B, **kw)
+    orc = SacAlphaOracle(o, a, Hh, pi0, q10, q20, **kw)
+    for s in range(5):
+        batch = dict(observations=rng.normal(0, 1, (B, o)).astype(np.float32), actions=np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32),
+                     rewards=rng.normal(0, 1, (B, 1)).astype(np.float32), terminals=(rng.random((B, 1)) < 0.1).astype(np.float32),
+                     next_observations=rng.normal(0, 1, (B, o)).astype(np.float32))
+        e1, e2 = rng.normal(0, 1, (B, a)).astype(np.float32), rng.normal(0, 1, (B, a)).astype(np.float32)
+        tr.eval_statistics = None
+        tr.train_step(batch, e1, e2)
+        res = orc.train_step(batch, e1, e2)
+        for nm, key in (("qf1", "q1_grad"), ("qf2", "q2_grad"), ("policy", "pi_grad")):
+            got, ref = tr.get_grads(nm), res[key]
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (s, nm, np.abs(got - ref).max() / np.abs(ref).max())
+    st = tr.get_eval_statistics()
+    np.testing.assert_allclose(st["QF1 Loss"], res["qf1_loss"], rtol=2e-4, atol=2e-6)
+    for nm, ov in (("policy", orc.pi), ("qf1", orc.q1), ("qf2", orc.q2), ("target_qf1", orc.tq1), ("target_qf2", orc.tq2)):
+        np.testing.assert_allclose(tr.get_params(nm), ov, rtol=0, atol=5e-5, err_msg=nm)
+    snap = tr.get_snapshot()                          # optimiser state crosses the ABI in logical sizes too
+    assert snap["qf1_optimizer"]["exp_avg"].size == q10.size

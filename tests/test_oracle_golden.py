@@ -49,6 +49,19 @@ def test_mlp_forward_backward():
         np.testing.assert_allclose(dx, g[f"{tag}_dx"], rtol=1e-4, atol=1e-6)
 
 
+def test_mlp_unequal_widths_forward_backward():
+    """g2b: the reference's Mlp with hidden_sizes the kernels have no width for ([200, 100], [48, 160, 96], [100]; networks.py:23-60)"""
+    g = load_golden("g2b_mlp_unequal")
+    for tag in ("relu_200_100", "tanh_200_100", "relu_48_160_96", "tanh_100"):
+        act, Hh = (omlp.RELU if tag.startswith("relu") else omlp.TANH), [int(v) for v in g[f"{tag}_hidden"]]
+        x = np.concatenate([g[f"{tag}_obs"], g[f"{tag}_act"]], 1)
+        outs, hs = omlp.forward(g[f"{tag}_params"], x, 14, Hh, 1, act=act)
+        np.testing.assert_allclose(outs[0], g[f"{tag}_y"], rtol=1e-5, atol=1e-6)
+        grad, dx = omlp.backward(g[f"{tag}_params"], hs, [g[f"{tag}_gy"]], 14, Hh, 1, act=act)
+        np.testing.assert_allclose(grad, g[f"{tag}_grad"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(dx, g[f"{tag}_dx"], rtol=1e-4, atol=1e-6)
+
+
 def test_init_rule_bounds():
     g = load_golden("g2_mlp")
     # reference: hidden W ~ U(+-1/sqrt(out_features)) = 1/16 for H=256 whatever the fan-in; b = 0.1

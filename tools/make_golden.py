@@ -146,6 +146,34 @@ def gen_mlp():
     save("g2_mlp", **out)
 
 
+def gen_mlp_unequal():
+    """G2b: Mlp / FlattenMlp with hidden_sizes the kernels have no width for (networks.py:23-60 takes any list): [200, 100] and
+    [48, 160, 96]: forward, parameter gradients, input gradients, relu and tanh — what the library's structural-zero embedding has to match."""
+    import torch.nn.functional as F
+    from rlkit.torch.common.networks import FlattenMlp
+    rng = np.random.default_rng(2020)
+    out = {}
+    for tag, act, fn, Hh in (("relu_200_100", omlp.RELU, F.relu, [200, 100]), ("tanh_200_100", omlp.TANH, torch.tanh, [200, 100]),
+                             ("relu_48_160_96", omlp.RELU, F.relu, [48, 160, 96]), ("tanh_100", omlp.TANH, torch.tanh, [100])):
+        o, a, B = 11, 3, 24
+        flat = omlp.init_mlp(rng, o + a, Hh, 1, init_w=0.3)
+        net = FlattenMlp(hidden_sizes=Hh, input_size=o + a, output_size=1, hidden_activation=fn)
+        set_flat(net, flat)
+        obs = rng.normal(0, 1, (B, o)).astype(np.float32)
+        actn = np.tanh(rng.normal(0, 1, (B, a))).astype(np.float32)
+        to, ta = t(obs).requires_grad_(True), t(actn).requires_grad_(True)
+        y = net(to, ta)
+        gy = rng.normal(0, 1, (B, 1)).astype(np.float32)
+        (y * t(gy)).sum().backward()
+        out.update({f"{tag}_params": flat, f"{tag}_obs": obs, f"{tag}_act": actn, f"{tag}_y": n(y), f"{tag}_gy": gy, f"{tag}_grad": get_flat_grad(net),
+                    f"{tag}_dx": np.concatenate([n(to.grad), n(ta.grad)], 1), f"{tag}_hidden": np.array(Hh)})
+        outs, hs = omlp.forward(flat, np.concatenate([obs, actn], 1), o + a, Hh, 1, act=act)
+        assert np.allclose(outs[0], out[f"{tag}_y"], rtol=1e-5, atol=1e-6)
+        g, dx = omlp.backward(flat, hs, [gy], o + a, Hh, 1, act=act)
+        assert np.allclose(g, out[f"{tag}_grad"], rtol=1e-4, atol=1e-6) and np.allclose(dx, out[f"{tag}_dx"], rtol=1e-4, atol=1e-6)
+    save("g2b_mlp_unequal", **out)
+
+
 class _Env:  # dummy `env` kwarg for sac_alpha.py:55-58
     def __init__(self, a):
         self.action_space = type("S", (), {"shape": (a,)})()
@@ -1330,7 +1358,7 @@ def gen_her():
     save("g22_her_buffer", **rec)
 
 
-GROUPS = dict(disc_bn=gen_disc_bn, disc_blocks=gen_disc_blocks, disc_branches=gen_disc_branches, replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
+GROUPS = dict(mlp_unequal=gen_mlp_unequal, disc_bn=gen_disc_bn, disc_blocks=gen_disc_blocks, disc_branches=gen_disc_branches, replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
               rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
 
 if __name__ == "__main__":
