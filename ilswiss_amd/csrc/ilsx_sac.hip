@@ -324,6 +324,7 @@ extern "C" int ilsx_sac_create(ilsx_ctx* ctx, const ilsx_sac_cfg* cfg, ilsx_net*
   ILSX_TRY(build_dw_jobs(s->Lp, s->gbase(W_PI), s->ws.xp, s->ws.hp, s->ws.dp, s->ws.dhp, &s->jobs_p));
   s->jobs_q.zero_flags = s->phase_flags;   // each dW launch re-arms the arrival counters of the phase launch that follows it
   s->jobs_p.zero_flags = s->phase_flags;
+  s->jobs_q.zero_err = s->phase_err; s->jobs_p.zero_err = s->phase_err;
   *out = s;
   return ILSX_OK;
 }
@@ -929,6 +930,11 @@ extern "C" int ilsx_sac_phase_state(ilsx_sac* s, int* fallbacks, int* disabled, 
 }
 extern "C" int ilsx_sac_debug_break_phase(ilsx_sac* s) {   // test aid: the next window finds a "timed out" mark and takes the roll-back path
   if (!s) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_debug_break_phase: NULL agent");
+  // the mark is set on the DEVICE, as a wait that gave up would set it: the window's weight-gradient launches then arm the arrival counters
+  // satisfied (PHASE_FLAG_DEAD) and its later phase launches run through without waiting — on stale data, which the roll-back discards
+  static const int one = 1;
+  HIPCHK(hipSetDevice(s->ctx->device));
+  HIPCHK(hipMemcpyAsync(s->phase_err, &one, sizeof one, hipMemcpyHostToDevice, s->ctx->stream));
   s->debug_break = true;
   return ILSX_OK;
 }

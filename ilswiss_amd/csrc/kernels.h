@@ -1046,11 +1046,14 @@ __device__ __forceinline__ void xch_arrive(unsigned* flag) {   // every thread o
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// dead: a wait of an EARLIER launch of this window already gave up (read once at kernel entry: *err != 0) — the host will roll the window
-// back and re-run it on one launch per stage (ilsx_sac.hip sac_phase_check), so the rest of the window does not sit out the bound again
-// in every wait; it just runs through.
-__device__ __forceinline__ void xch_wait(const unsigned* flag, unsigned target, int* err, bool dead) {
-  if (threadIdx.x == 0 && !dead) {
+// Once a wait has given up (*err set), the host will roll the window back and re-run it on one launch per stage (ilsx_sac.hip
+// sac_phase_check); so that the REST of the window does not sit out the bound again in every wait, the weight-gradient launch that re-arms
+// the counters for the next phase launch arms them SATISFIED (PHASE_FLAG_DEAD, k_mlp_bwd_dw) when it finds *err set: later phase
+// launches of the window run straight through.  (Reading *err inside the phase kernels instead — at entry, scalar or vector load — cost
+// 0.8 us per phase launch: tools/ab_r03.sh.)
+#define PHASE_FLAG_DEAD 0x40000000u
+__device__ __forceinline__ void xch_wait(const unsigned* flag, unsigned target, int* err) {
+  if (threadIdx.x == 0) {
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
@@ -1134,7 +1137,6 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const FwdGroup* GP = nullptr;
   const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;
-  const bool dead = *P.err != 0;   // uniform scalar load, requested with the descriptors
   unsigned* tflag = P.flags + PHASE_TAIL_FLAG * 32;
   if (y == 4) {
     if (bx == 0 && cs == 0) {
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
       const FwdArgs& A = P.f2;
       const FwdTask& T = A.t[y == 0 ? 0 : 1];
       const bool first_task = y == 0;
-#define XCH_HOOK_STAGE ILSX_STAMP_SYNC(P.dbg, 7); xch_wait(f0, CS, P.err, dead); ILSX_STAMP(P.dbg, 3);
+#define XCH_HOOK_STAGE ILSX_STAMP_SYNC(P.dbg, 7); xch_wait(f0, CS, P.err); ILSX_STAMP(P.dbg, 3);
 #define XCH_HOOK_FIN
 #define XCH_FINE_DBG P.dbg
 #include "fwd_split_tile.inc"
@@ -1196,16 +1198,16 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
     xch_arrive(f2);
     ILSX_STAMP(P.dbg, 5);
   } else {
-    xch_wait(f1, 4 * CS, P.err, dead);   // the other slices' layer-1 activations, the lead slice's layer 0
+    xch_wait(f1, 4 * CS, P.err);   // the other slices' layer-1 activations, the lead slice's layer 0
     if (P.fin_pi_on && y == 1 && cs == 0) {   // workgroup-uniform
-      xch_wait(tflag, 1u, P.err, dead);   // the pending tail of the previous step reads that step's log pi: it has to be through before this one's lands
+      xch_wait(tflag, 1u, P.err);   // the pending tail of the previous step reads that step's log pi: it has to be through before this one's lands
       policy_fin_tile(P.fin_pi, bx * 16, P.f1.rows, smem, 4 * H / CS);
     }
     {
       const BwdArgs& A = P.b1;
       const BwdTask& T = A.t[y - 1];
 #define XCH_HOOK_ACT
-#define XCH_HOOK_HEAD xch_wait(f2, 2 * CS, P.err, dead); xch_wait(tflag, 1u, P.err, dead); ILSX_STAMP(P.dbg, 3);
+#define XCH_HOOK_HEAD xch_wait(f2, 2 * CS, P.err); xch_wait(tflag, 1u, P.err); ILSX_STAMP(P.dbg, 3);
 #include "bwd_split_tile.inc"
 #undef XCH_HOOK_ACT
 #undef XCH_HOOK_HEAD
@@ -1227,7 +1229,6 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const FwdGroup* GP = nullptr;
   const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;
-  const bool dead = *P.err != 0;   // uniform scalar load, requested with the descriptors
   if (y == 3) {
     if (bx == 0 && cs == 0 && threadIdx.x == 0) P.f3.tail[0].scal->gather_step += 1;
     const float tau = P.polyak_tau;
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) 
       const BwdArgs& A = P.b3;
       const BwdTask& T = A.t[0];
 #define XCH_HOOK_ACT
-#define XCH_HOOK_HEAD xch_wait(f2, 2 * CS, P.err, dead); ILSX_STAMP(P.dbg, 4);
+#define XCH_HOOK_HEAD xch_wait(f2, 2 * CS, P.err); ILSX_STAMP(P.dbg, 4);
 #include "bwd_split_tile.inc"
 #undef XCH_HOOK_ACT
 #undef XCH_HOOK_HEAD
@@ -1275,7 +1276,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) 
   {
     const BwdArgs& A = P.b2;
     const BwdTask& T = A.t[y];
-#define XCH_HOOK_ACT xch_wait(f1, 2 * CS, P.err, dead); ILSX_STAMP(P.dbg, 2);
+#define XCH_HOOK_ACT xch_wait(f1, 2 * CS, P.err); ILSX_STAMP(P.dbg, 2);
 #define XCH_HOOK_HEAD
 #include "bwd_split_tile.inc"
 #undef XCH_HOOK_ACT
@@ -1326,6 +1327,7 @@ struct DwArgs {
   // grouped launch: one self-contained record per output tile (its matrix and its agent's optimiser) in device memory
   const struct DwTileG* gtiles;
   unsigned* zero_flags;   // non-null: workgroup 0 zeroes the PHASE_NFLAGS arrival counters of the phase kernel that follows this launch
+  const int* zero_err;    //   ... or arms them satisfied (PHASE_FLAG_DEAD) when *zero_err says a wait of this window already gave up
   int tile_nh, tile_kt;   // grouped launches: the tile shape the gtiles table was built for (0 = 2 x 4); host-side only
   int strip;              // grouped launches: the table is one record per 16 x 64 output strip of k_dw_strip (one wavefront each); host-side only
 };
@@ -1371,7 +1373,8 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
   float* bpart = smem + NW * 4 * KT * 64;     // [NW waves][16]
   if (blockIdx.x & ((1u << D.xs) - 1u)) return;
   const int bx = blockIdx.x >> D.xs;
-  if (D.zero_flags && bx == 0 && blockIdx.y == 0 && threadIdx.x < PHASE_NFLAGS) D.zero_flags[threadIdx.x * 32] = 0u;
+  if (D.zero_flags && bx == 0 && blockIdx.y == 0 && threadIdx.x < PHASE_NFLAGS)
+    D.zero_flags[threadIdx.x * 32] = (D.zero_err && *D.zero_err) ? PHASE_FLAG_DEAD : 0u;
   int mi = 0;
   if (!GRP) {
 #pragma unroll
