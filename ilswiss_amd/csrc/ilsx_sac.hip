@@ -74,6 +74,10 @@ struct ilsx_sac {
   ilsx_replay* graph_rb = nullptr;
   int graph_B = 0;
   bool graph_defer = false, graph_phase = false;
+  // split runs: the step as three captured segments with the two all-reduces between them (sac_split_segments)
+  hipGraphExec_t seg_graph[3] = {nullptr, nullptr, nullptr};
+  ilsx_replay* seg_rb = nullptr;
+  int seg_B = 0;
   // deferred tail (TailLite, kernels.h): active inside ilsx_sac_train_from_replay on the column-split path
   bool defer_tail = false;
   TailLite* tail_dev = nullptr;
@@ -334,6 +338,7 @@ extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
   hipSetDevice(s->ctx->device);
   hipStreamSynchronize(s->ctx->stream);
   if (s->graph) hipGraphExecDestroy(s->graph);
+  for (hipGraphExec_t& g : s->seg_graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
   if (s->tail_dev) ctx_free(s->ctx, s->tail_dev);
   if (s->snap) ctx_free(s->ctx, s->snap);
   // give the networks private storage back so their handles stay usable
@@ -907,6 +912,48 @@ static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
 }
 
 static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats);
+// Split run (one run over G GPUs): the step's launches between the two gradient all-reduces are captured ONCE as three graph segments
+//   [draw + critic backward]  all-reduce(critic gradients)  [critic Adam + Polyak ; actor backward]  all-reduce(actor | alpha)  [actor Adam ; tail]
+// and replayed with the two ncclAllReduce calls enqueued directly between them: ~13 kernel launches per step become 3 graph launches,
+// while the collective itself stays OUT of the capture (RCCL inside a stream capture is the one thing a single-GPU box cannot exercise
+// with more than one rank; ILSX_SPLIT_GRAPH=1 captures the whole step including it, ILSX_SPLIT_SEGMENTS=0 launches everything directly).
+static int sac_split_segment(ilsx_sac* s, ilsx_replay* rb, int B, int seg) {
+  s->fuse_now = false;
+  if (seg == 0) {
+    if (s->cs > 1) s->gather_rb = rb;   // rows drawn inside the first forward launch
+    else { const SacWs& w = s->ws; ILSX_TRY(replay_launch_sample(rb, B, nullptr, s->scal, 0, w.s, w.a, w.r, w.d, w.s2, nullptr)); }
+    const int rc = sac_critic_backward(s);
+    s->gather_rb = nullptr;
+    return rc;
+  }
+  if (seg == 1) { ILSX_TRY(sac_critic_update(s)); return sac_actor_backward(s); }
+  return sac_actor_update(s);
+}
+static int sac_split_segments_step(ilsx_sac* s, ilsx_replay* rb, int B) {
+  hipStream_t st = s->ctx->stream;
+  if (s->seg_rb != rb || s->seg_B != B || !s->seg_graph[0]) {
+    for (hipGraphExec_t& g : s->seg_graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+    for (int seg = 0; seg < 3; ++seg) {
+      hipGraph_t g = nullptr;
+      HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int rc = sac_split_segment(s, rb, B, seg);
+      const hipError_t e = hipStreamEndCapture(st, &g);
+      if (rc != ILSX_OK) { if (g) hipGraphDestroy(g); return rc; }
+      if (e != hipSuccess) ILSX_FAIL(ILSX_ERR_HIP, "hipStreamEndCapture (split segment %d) failed: %s", seg, hipGetErrorString(e));
+      const hipError_t e2 = hipGraphInstantiate(&s->seg_graph[seg], g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      if (e2 != hipSuccess) { s->seg_graph[seg] = nullptr; ILSX_FAIL(ILSX_ERR_HIP, "hipGraphInstantiate (split segment %d) failed: %s", seg, hipGetErrorString(e2)); }
+    }
+    s->seg_rb = rb; s->seg_B = B;
+  }
+  HIPCHK(hipGraphLaunch(s->seg_graph[0], st));
+  ILSX_TRY(sac_allreduce(s, 0));
+  HIPCHK(hipGraphLaunch(s->seg_graph[1], st));
+  ILSX_TRY(sac_allreduce(s, 1));
+  HIPCHK(hipGraphLaunch(s->seg_graph[2], st));
+  return ILSX_OK;
+}
+
 extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats) {
   int rc = sac_train_from_replay_once(s, rb, n_steps, B, stats);
   if (rc == ILSX_RETRY_WINDOW) {   // the phase kernels' hand-offs broke (shared GPU): back to the checkpoint, same steps on one launch per stage
@@ -958,7 +1005,13 @@ static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps,
   struct DeferGuard { ilsx_sac* s; ~DeferGuard() { s->defer_tail = false; } } guard{s};   // never left on, whatever path returns
   const bool deferred = s->defer_tail;
   if (deferred && sac_window_may_use_phase(s, B)) ILSX_TRY(sac_snapshot_take(s));   // the roll-back point of this window
-  if (no_graph || s->ctx->prof_on) {
+  static const bool no_segments = []() { const char* e = getenv("ILSX_SPLIT_SEGMENTS"); return e && atoi(e) == 0; }();
+  if (sac_is_split(s) && !split_graph && !no_graph_env && !no_segments && !s->ctx->prof_on) {
+    for (int i = 0; i < n_steps; ++i) {
+      if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
+      ILSX_TRY(sac_split_segments_step(s, rb, B));
+    }
+  } else if (no_graph || s->ctx->prof_on) {
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
       const int rc = sac_sample_and_step(s, rb, B);
