@@ -153,6 +153,10 @@ bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks);
 int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P, int H, int act, int KPmax, int cs);
 int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P, int H, int act, int KPmax, int cs);
 int device_cus(ilsx_ctx* ctx);   // compute units of the context's device
+// constant-memory descriptor tables of grouped launches (kernels.h g_fwd_tab / g_bwd_tab): slots per device, first fit; -1 = none free
+int grp_const_alloc(int device, bool fwd, int n, int* base);
+void grp_const_free(int device, bool fwd, int base);
+int grp_const_upload(ilsx_ctx* ctx, bool fwd, int base, const void* host_records, size_t count);
 struct ilsx_sac;
 int sac_staged_batch(ilsx_sac* s, int B, float** obs, float** act, float** rew, float** done, float** nobs);   // ilsx_sac.hip
 int sac_step_staged(ilsx_sac* s, ilsx_sac_stats* stats);

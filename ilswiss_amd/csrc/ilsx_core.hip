@@ -317,18 +317,14 @@ static int kernels_init_once() {
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_RELU, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, ACT_TANH, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+#define SET_G(HH, AA, CC, GG) HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<HH, AA, CC, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
+  SET_G(256, ACT_RELU, 4, 0); SET_G(256, ACT_RELU, 4, 1); SET_G(256, ACT_RELU, 4, 2); SET_G(256, ACT_TANH, 4, 0); SET_G(256, ACT_TANH, 4, 1); SET_G(256, ACT_TANH, 4, 2);
 #define SET_PH(AA, GG) HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, GG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, GG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
-  SET_PH(ACT_RELU, false); SET_PH(ACT_RELU, true); SET_PH(ACT_TANH, false); SET_PH(ACT_TANH, true);
+  SET_PH(ACT_RELU, 0); SET_PH(ACT_RELU, 1); SET_PH(ACT_RELU, 2); SET_PH(ACT_TANH, 0); SET_PH(ACT_TANH, 1); SET_PH(ACT_TANH, 2);
 #undef SET_PH
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_RELU, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-  HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<128, ACT_TANH, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  SET_G(128, ACT_RELU, 2, 0); SET_G(128, ACT_RELU, 2, 1); SET_G(128, ACT_RELU, 2, 2); SET_G(128, ACT_TANH, 2, 0); SET_G(128, ACT_TANH, 2, 1); SET_G(128, ACT_TANH, 2, 2);
+#undef SET_G
 #define SET_MT(AA, MM) HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, true, 0, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, true, 1, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, true, 2, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
@@ -365,6 +361,33 @@ extern "C" int ilsx_debug_set_stamp_buffer(ilsx_ctx* c, void* dev_trace, int max
   c->dbg_stamps = (unsigned long long*)dev_trace;
   c->dbg_max_launches = dev_trace ? max_launches : 0;
   c->dbg_launches = 0;
+  return ILSX_OK;
+}
+
+// ---- constant-memory descriptor tables of grouped launches (kernels.h g_fwd_tab / g_bwd_tab): slot allocation, first fit, per device
+struct ConstSlots { std::vector<std::pair<int, int>> used; };   // (base, count), sorted by base
+static ConstSlots g_slots[2][16];   // [forward | backward][device]
+int grp_const_alloc(int device, bool fwd, int n, int* base) {
+  if (device < 0 || device >= 16 || n < 1 || n > GRP_CONST_SLOTS) return -1;
+  auto& u = g_slots[fwd ? 0 : 1][device].used;
+  int at = 0;
+  size_t i = 0;
+  for (; i < u.size(); ++i) { if (u[i].first - at >= n) break; at = u[i].first + u[i].second; }
+  if (at + n > GRP_CONST_SLOTS) return -1;
+  u.insert(u.begin() + i, {at, n});
+  *base = at;
+  return 0;
+}
+void grp_const_free(int device, bool fwd, int base) {
+  if (device < 0 || device >= 16) return;
+  auto& u = g_slots[fwd ? 0 : 1][device].used;
+  for (size_t i = 0; i < u.size(); ++i) if (u[i].first == base) { u.erase(u.begin() + i); return; }
+}
+int grp_const_upload(ilsx_ctx* ctx, bool fwd, int base, const void* host, size_t count) {   // synchronous w.r.t. the host table
+  const size_t rec = fwd ? sizeof(FwdTaskG) : sizeof(BwdTask);
+  if (fwd) HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fwd_tab), host, count * rec, (size_t)base * rec, hipMemcpyHostToDevice, ctx->stream));
+  else HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bwd_tab), host, count * rec, (size_t)base * rec, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return ILSX_OK;
 }
 
@@ -406,7 +429,7 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
   ProfScope ps(ctx, ILSX_K_MLP_FWD);
   if (cs > 1 && A.tasks && A.mt > 1) {   // grouped launch on macro tiles: 1-D grid, (agent, tile) -> XCD fixed across the lock-step's launches
     if (!(H == 256 && cs == 4) || (A.mt != 2 && A.mt != 4)) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "macro-tile forward: H=%d cs=%d mt=%d", H, cs, A.mt);
-    A.xs = 0; A.rt = 1;
+    A.xs = 0; A.rt = 1; A.ctab = 0;
     ILSX_TRY(grp_swizzle_fill(&A.swz, A.ntasks, A.swz.agents, A.rows, A.mt));
     const unsigned nwork = 8u * A.swz.np8 * A.swz.tpa * cs;
     if (A.tail_mode && (!A.tail || A.tail_n < 1)) ILSX_FAIL(ILSX_ERR_ARG, "deferred tail: bad record table");
@@ -442,15 +465,18 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
       dim3 grid2(grid.x, A.ntasks, cs);
 #define L0_CALL(AA, GG) do { ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, AA, 4, GG, 1>), grid, block, lds, ctx->stream, A); \
                              ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, AA, 4, GG, 2>), grid2, block, lds, ctx->stream, A2); } while (0)
-      if (act == ILSX_ACT_RELU) { if (A.tasks) L0_CALL(ACT_RELU, true); else L0_CALL(ACT_RELU, false); }
-      else { if (A.tasks) L0_CALL(ACT_TANH, true); else L0_CALL(ACT_TANH, false); }
+      const int gg = A.tasks ? (A.ctab ? 2 : 1) : 0;
+      if (act == ILSX_ACT_RELU) { if (gg == 2) L0_CALL(ACT_RELU, 2); else if (gg == 1) L0_CALL(ACT_RELU, 1); else L0_CALL(ACT_RELU, 0); }
+      else { if (gg == 2) L0_CALL(ACT_TANH, 2); else if (gg == 1) L0_CALL(ACT_TANH, 1); else L0_CALL(ACT_TANH, 0); }
 #undef L0_CALL
     } else if (H == 256 && cs == 4) {
-      if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
-      else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
+#define FWD_GRP_CALL(HH, AA, CC) do { if (A.tasks && A.ctab) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<HH, AA, CC, 2>), grid, block, lds, ctx->stream, A); \
+        else if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<HH, AA, CC, 1>), grid, block, lds, ctx->stream, A); \
+        else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<HH, AA, CC, 0>), grid, block, lds, ctx->stream, A); } while (0)
+      if (act == ILSX_ACT_RELU) FWD_GRP_CALL(256, ACT_RELU, 4); else FWD_GRP_CALL(256, ACT_TANH, 4);
     } else if (H == 128 && cs == 2) {
-      if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<128, ACT_RELU, 2, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<128, ACT_RELU, 2, false>), grid, block, lds, ctx->stream, A); }
-      else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<128, ACT_TANH, 2, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<128, ACT_TANH, 2, false>), grid, block, lds, ctx->stream, A); }
+      if (act == ILSX_ACT_RELU) FWD_GRP_CALL(128, ACT_RELU, 2); else FWD_GRP_CALL(128, ACT_TANH, 2);
+#undef FWD_GRP_CALL
     } else {
       ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "no column-split forward kernel for H=%d cs=%d", H, cs);
     }
@@ -553,7 +579,7 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
   ProfScope ps(ctx, ILSX_K_MLP_BWD_DX);
   if (cs > 1 && A.tasks && A.mt > 1) {   // grouped launch on macro tiles (see launch_fwd)
     if (!(H == 256 && cs == 4) || (A.mt != 2 && A.mt != 4)) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "macro-tile backward: H=%d cs=%d mt=%d", H, cs, A.mt);
-    A.xs = 0;
+    A.xs = 0; A.ctab = 0;
     ILSX_TRY(grp_swizzle_fill(&A.swz, A.ntasks, A.swz.agents, A.rows, A.mt));
     const dim3 grid(8u * A.swz.np8 * A.swz.tpa * cs), block(4 * H / cs);
     const size_t lds = bwd_split_lds_bytes(H, cs, A.mt);
@@ -568,11 +594,13 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
     A.xs = ctx->xcd_shift;
     dim3 grid(((((A.rows + 15) / 16) + 7) & ~7) << A.xs, A.ntasks, cs), block(4 * H / cs);   // same tile -> XCD mapping as launch_fwd
     if (H == 256 && cs == 4) {
-      if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_RELU, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_RELU, 4, false>), grid, block, lds, ctx->stream, A); }
-      else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_TANH, 4, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<256, ACT_TANH, 4, false>), grid, block, lds, ctx->stream, A); }
+#define BWD_GRP_CALL(HH, AA, CC) do { if (A.tasks && A.ctab) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<HH, AA, CC, 2>), grid, block, lds, ctx->stream, A); \
+        else if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<HH, AA, CC, 1>), grid, block, lds, ctx->stream, A); \
+        else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<HH, AA, CC, 0>), grid, block, lds, ctx->stream, A); } while (0)
+      if (act == ILSX_ACT_RELU) BWD_GRP_CALL(256, ACT_RELU, 4); else BWD_GRP_CALL(256, ACT_TANH, 4);
     } else if (H == 128 && cs == 2) {
-      if (act == ILSX_ACT_RELU) { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<128, ACT_RELU, 2, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<128, ACT_RELU, 2, false>), grid, block, lds, ctx->stream, A); }
-      else { if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<128, ACT_TANH, 2, true>), grid, block, lds, ctx->stream, A); else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<128, ACT_TANH, 2, false>), grid, block, lds, ctx->stream, A); }
+      if (act == ILSX_ACT_RELU) BWD_GRP_CALL(128, ACT_RELU, 2); else BWD_GRP_CALL(128, ACT_TANH, 2);
+#undef BWD_GRP_CALL
     } else {
       ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "no column-split backward kernel for H=%d cs=%d", H, cs);
     }

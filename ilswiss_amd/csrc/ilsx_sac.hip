@@ -1239,6 +1239,7 @@ struct ilsx_sac_group {
     int kind = 0, KP = 0, ntasks = 0;
     FwdArgs f; BwdArgs b; DwArgs d;
     void *tasks = nullptr, *gtiles = nullptr, *tails = nullptr;
+    int cslot = -1;   // first slot of this stage's records in the constant-memory table (kernels.h g_fwd_tab / g_bwd_tab), -1 = none
   };
   std::vector<Stage> stages;
   TailLite* tails_lite = nullptr;   // deferred tail: one record per agent (see TailLite, kernels.h)
@@ -1254,9 +1255,11 @@ static int upload_table(ilsx_ctx* ctx, const std::vector<T>& v, void** dev) {
 }
 
 static void group_release_tables(ilsx_sac_group* g) {
-  for (auto& st : g->stages)
+  for (auto& st : g->stages) {
     for (void* p : {st.tasks, st.gtiles, st.tails})
       if (p) ctx_free(g->ctx, p);
+    if (st.cslot >= 0) grp_const_free(g->ctx->device, st.kind == 0, st.cslot);
+  }
   g->stages.clear();
   if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
 }
@@ -1275,6 +1278,8 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
     if (cols[k].L.size() != cols[0].L.size()) ILSX_FAIL(ILSX_ERR_STATE, "agents of a group must produce the same launch sequence");
   }
   group_release_tables(g);
+  const char* ce = getenv("ILSX_GRP_CONST");   // 0: descriptor records from the device-memory tables only (A/B)
+  const bool use_const = !(ce && atoi(ce) == 0);
   const size_t nst = cols[0].L.size();
   g->stages.resize(nst);
   for (size_t i = 0; i < nst; ++i) {
@@ -1298,6 +1303,10 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
       st.ntasks = (int)tasks.size();
       ILSX_TRY(upload_table(g->ctx, tasks, &st.tasks));
       st.f.tasks = (const FwdTaskG*)st.tasks; st.f.ntasks = st.ntasks;
+      if (use_const && grp_const_alloc(g->ctx->device, true, st.ntasks, &st.cslot) == 0) {   // the same records in constant memory (kernels.h GRP == 2)
+        ILSX_TRY(grp_const_upload(g->ctx, true, st.cslot, tasks.data(), tasks.size()));
+        st.f.ctab = st.cslot + 1;
+      }
     } else if (st.kind == 1) {
       std::vector<BwdTask> tasks;
       st.b = cols[0].L[i].b;
@@ -1311,6 +1320,10 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
       st.ntasks = (int)tasks.size();
       ILSX_TRY(upload_table(g->ctx, tasks, &st.tasks));
       st.b.tasks = (const BwdTask*)st.tasks; st.b.ntasks = st.ntasks;
+      if (use_const && grp_const_alloc(g->ctx->device, false, st.ntasks, &st.cslot) == 0) {
+        ILSX_TRY(grp_const_upload(g->ctx, false, st.cslot, tasks.data(), tasks.size()));
+        st.b.ctab = st.cslot + 1;
+      }
     } else if (st.kind == 2) {
       std::vector<DwTileG> gt;
       st.d = cols[0].L[i].d;

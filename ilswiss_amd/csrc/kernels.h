@@ -371,6 +371,7 @@ struct FwdArgs {
   int mt;                        // grouped launches: 16-row tiles per workgroup processed together (macro tile; 0 / 1 = one) — host side: picks the instantiation
   int mt_not, mt_a;              //   host side (LDS sizing): the widest head of the launch's tasks in 16-output tiles, the widest finished policy
   GrpSwizzle swz;                // grouped launches with a 1-D grid (see GrpSwizzle)
+  int ctab;                      // grouped launches, descriptor records in CONSTANT memory (g_fwd_tab, below): 1 + first slot of this launch's table; 0 = device table `tasks`
 };
 struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
 // one self-contained record per grid row: the task and its agent's per-launch state side by side, so a workgroup reaches
@@ -642,6 +643,7 @@ struct BwdArgs {
   const BwdTask* tasks;     // grouped launch: descriptor table in device memory, indexed by blockIdx.y
   int mt;                   // grouped launches: row tiles per workgroup (see FwdArgs::mt)
   GrpSwizzle swz;
+  int ctab;                 // grouped launches: 1 + first slot in g_bwd_tab, 0 = device table `tasks` (see FwdArgs::ctab)
 };
 
 // dL/d(head output j) of row gr for the loss functor of task T (shared by the generic and the column-split
@@ -885,12 +887,23 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
 // Head outputs leave as CS partial sums per row (FwdTask::part) and are combined in the consumer's
 // prologue (PartVal) or by k_policy_finish; backward input-gradients leave as CS partial slabs likewise.
 // block = 4*H/CS threads; wave w owns column tile(s) [w*CS, (w+1)*CS) of layer 0 and tile cs*NWV+w of layer 1.
+// Descriptor records of grouped launches in CONSTANT address space.  Copied by value at kernel entry out of a device-memory table (GRP == 1)
+// a record is ~130 / ~100 scalar registers live at once — more than a wave has — and the compiler parks the overflow in VGPR lanes: ~370 of
+// the ~2.6k instructions a grouped forward workgroup executes were v_writelane / v_readlane.  A `__constant__` table is read like the
+// kernel-argument segment of the single-run launches: a field is a scalar load where it is used (the address space tells the compiler
+// that no store of the kernel can alias it), loaded again instead of parked when registers run short.  GRP == 2 selects it; slots are
+// handed out by the host (grp_const_alloc, ilsx_core.hip), a group that finds none falls back to GRP == 1.
+#define GRP_CONST_SLOTS 768
+#ifdef ILSX_KERNEL_IMPL
+__constant__ FwdTaskG g_fwd_tab[GRP_CONST_SLOTS];
+__constant__ BwdTask g_bwd_tab[GRP_CONST_SLOTS];
+#endif
 #ifdef ILSX_KERNEL_IMPL
 // PH: 0 = the whole forward in one launch, every slice recomputing layer 0 (K = KP is tiny for the planar tasks); for wide inputs
 // (Humanoid: KP = 396) that recomputation is 6x the slice's own layer-1 work, so the forward runs as two launches of the same grid:
 // PH = 1 stages x (gather / policy epilogue as in PH 0) and computes THIS slice's 64 columns of layer 0 into hsave[0];
 // PH = 2 starts from hsave[0] (16 KB per tile, L2-resident) and does layer 1 + heads.
-template <int H, int ACT, int CS, bool GRP, int PH = 0, int MT = 1>
+template <int H, int ACT, int CS, int GRP, int PH = 0, int MT = 1>   // GRP: 0 = tasks in the kernel arguments, 1 = device table, 2 = constant table
 __global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_mlp2_fwd_split(const FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(MT == 1 || GRP, "macro tiles are a grouped-launch shape");
@@ -925,9 +938,10 @@ __global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_ml
   // made ~100 scalars live at once: 196 v_writelane + 369 v_readlane in this kernel (a quarter of a wave's issue slots in the prologue).
   FwdTaskG Rg;
   const int ty = (GRP && MT > 1) ? sw_task : (int)blockIdx.y;
-  if (GRP) Rg = A.tasks[ty];
-  const FwdTask& T = GRP ? Rg.t : A.t[ty];
-  const FwdGroup* GP = GRP ? &Rg.g : nullptr;
+  if (GRP == 1) Rg = A.tasks[ty];
+  const FwdTaskG& Rc = g_fwd_tab[GRP == 2 ? A.ctab - 1 + ty : 0];
+  const FwdTask& T = GRP == 2 ? Rc.t : GRP == 1 ? Rg.t : A.t[ty];
+  const FwdGroup* GP = GRP == 2 ? &Rc.g : GRP == 1 ? &Rg.g : nullptr;
   // the body is shared as TEXT with the merged phase kernels (see fwd_split_tile.inc for why it is not a device function)
   constexpr bool XCH = false;
   const int bx = (GRP && MT > 1) ? sw_bx : (int)blockIdx.x, cs = (GRP && MT > 1) ? sw_cs : (int)blockIdx.z;
@@ -981,7 +995,7 @@ __global__ __launch_bounds__(64) void k_policy_finish(const PolicyFinishArgs P) 
   if (P.logp) P.logp[gr] = -0.5f * lp_quad - (lp_ls + HALF_LOG_2PI) - lp_jac;
 }
 
-template <int H, int ACT, int CS, bool GRP, int MT = 1>
+template <int H, int ACT, int CS, int GRP, int MT = 1>
 __global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_mlp2_bwd_split(const BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(MT == 1 || GRP, "macro tiles are a grouped-launch shape");
@@ -991,8 +1005,8 @@ __global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_ml
   }
   const int ty = (GRP && MT > 1) ? sw_task : (int)blockIdx.y;
   BwdTask Tg;
-  if (GRP) Tg = A.tasks[ty];   // by value at entry (see k_mlp2_fwd_split)
-  const BwdTask& T = GRP ? Tg : A.t[ty];   // !GRP: read in place from the kernel-argument segment
+  if (GRP == 1) Tg = A.tasks[ty];   // by value at entry (see k_mlp2_fwd_split)
+  const BwdTask& T = GRP == 2 ? g_bwd_tab[A.ctab - 1 + ty] : GRP == 1 ? Tg : A.t[ty];   // GRP 0 / 2: read in place (kernel arguments / constant table)
   constexpr bool XCH = false;
   const int bx = (GRP && MT > 1) ? sw_bx : (int)blockIdx.x, cs = (GRP && MT > 1) ? sw_cs : (int)blockIdx.z;
 #define XCH_HOOK_ACT
@@ -1132,7 +1146,7 @@ __device__ __forceinline__ void policy_fin_tile(const PolicyFinishArgs& P, int r
 //          stage 3 = bwd{Q1, Q2 <- TD target} on the workgroups of y = 1 / 2;  y = 4: the deferred tail of the previous step.
 template <int H, int ACT, int CS>
 __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) {
-  constexpr bool GRP = false, XCH = true;
+  constexpr int GRP = 0; constexpr bool XCH = true;
   constexpr int PH = 0, MT = 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const FwdGroup* GP = nullptr;
@@ -1224,7 +1238,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
 //          y = 3: advance the replay-draw counter (nothing in this launch reads it).
 template <int H, int ACT, int CS>
 __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) {
-  constexpr bool GRP = false, XCH = true;
+  constexpr int GRP = 0; constexpr bool XCH = true;
   constexpr int PH = 0, MT = 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const FwdGroup* GP = nullptr;
