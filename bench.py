@@ -586,6 +586,9 @@ def main():
                         parallelism=f"{world} independent replicas (seed sharding, no collective)"),
             env_steps_per_s=env_total / dt, env_steps_per_s_sample_phase=env_total / t_sample,
             grad_steps_per_s_train_phase=grad_total / t_train, roofline=roofline, roofline_replay=roofline_replay,
+            # which step path the timed loop ran on: the merged phase kernels (4 launches per step) unless a window had to be rolled back
+            # (another process's kernels on this GPU) and the agent fell back to one launch per stage (include/ilsx.h ilsx_sac_phase_state)
+            phase_kernels=tr.phase_state(),
             # per-rank step times behind the max-over-ranks `value` (the driver computes efficiency itself from its per-N runs); the
             # replica leg has NO data-path collective, so a slow rank is a placement / clock matter, not a communication one
             scaling_detail=dict(per_rank_ms=per_rank_ms, max_over_min=max(per_rank_ms) / min(per_rank_ms), numa_rank0=numa,

@@ -3,7 +3,7 @@
 # graph launches here), the PMC passes (regenerated every round: bench.py reads the newest summary for roofline.traffic), the
 # per-launch timeline of the SAC step and the stage timers of the 3-D stepper -> gpurun_out/prof_<tag>/; copy into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -14,6 +14,12 @@ timeout 200 python tools/phase_gantt.py > $OUT/phase_gantt.txt 2>&1
 timeout 200 python tools/rollout_overhead.py 4096 > $OUT/rollout_overhead.txt 2>&1
 timeout 100 python tools/rollout_overhead.py 8192 >> $OUT/rollout_overhead.txt 2>&1
 (cd tools/ubench && timeout 60 ./tilesync) > $OUT/tilesync.txt 2>&1
+# the split-run leg on a one-rank communicator (three graph segments + two all-reduces), and the same with direct launches
+ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='graph segments', **(d.get('split_run') or {}))))" > $OUT/split_run_1rank.jsonl 2>&1
+ILSX_SPLIT_SEGMENTS=0 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='direct launches', **(d.get('split_run') or {}))))" >> $OUT/split_run_1rank.jsonl 2>&1
+timeout 120 python tools/discbn_rate.py > $OUT/discbn_rate.txt 2>&1
+timeout 120 python tools/step_gantt.py 8 > $OUT/step_gantt_K8.txt 2>&1
+(timeout 100 python tools/env3d_rate.py humanoid 1024 40; timeout 100 python tools/env3d_rate.py ant 1024 40) > $OUT/env3d_rate.txt 2>&1
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC tools/ubench/env3d_phases.hip -o /tmp/libe3p.so 2> /dev/null
 (python tools/ubench/env3d_phases.py humanoid 1024 8; python tools/ubench/env3d_phases.py ant 1024 8) > $OUT/env3d_phases.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -24,6 +30,9 @@ python tools/rocpd_summary.py "$f" > $OUT/kernel_stats.csv 2> $OUT/summary.err
 rm -rf $OUT/rocprof
 bash tools/pmc_collect.sh $TAG > $OUT/pmc.log 2>&1
 bash tools/pmc_env.sh $TAG > $OUT/envpmc.log 2>&1
+bash tools/pmc_env3d.sh $TAG > $OUT/env3dpmc.log 2>&1
+cp gpurun_out/env3dpmc_$TAG/summary.json $OUT/env3dpmc_summary.json 2> /dev/null
+rm -rf gpurun_out/env3dpmc_$TAG/*/ 2> /dev/null
 cp gpurun_out/envpmc_$TAG/summary.json $OUT/envpmc_summary.json 2> /dev/null
 rm -rf gpurun_out/envpmc_$TAG/*/ 2> /dev/null
 cp gpurun_out/pmc_$TAG/summary.json $OUT/pmc_summary.json 2> /dev/null
