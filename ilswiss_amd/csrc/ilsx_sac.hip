@@ -916,7 +916,9 @@ static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps,
 //   [draw + critic backward]  all-reduce(critic gradients)  [critic Adam + Polyak ; actor backward]  all-reduce(actor | alpha)  [actor Adam ; tail]
 // and replayed with the two ncclAllReduce calls enqueued directly between them: ~13 kernel launches per step become 3 graph launches,
 // while the collective itself stays OUT of the capture (RCCL inside a stream capture is the one thing a single-GPU box cannot exercise
-// with more than one rank; ILSX_SPLIT_GRAPH=1 captures the whole step including it, ILSX_SPLIT_SEGMENTS=0 launches everything directly).
+// with more than one rank; ILSX_SPLIT_GRAPH=1 captures the whole step including it).  OPT-IN (ILSX_SPLIT_SEGMENTS=1): measured at one rank
+// (profiles/r04_split_run_1rank.jsonl) the three small graphs are SLOWER than launching the 13 kernels directly — 107 us against 90 us per
+// step: a hipGraphLaunch costs more than the four launches it replaces — so the default stays direct launches.
 static int sac_split_segment(ilsx_sac* s, ilsx_replay* rb, int B, int seg) {
   s->fuse_now = false;
   if (seg == 0) {
@@ -1005,8 +1007,8 @@ static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps,
   struct DeferGuard { ilsx_sac* s; ~DeferGuard() { s->defer_tail = false; } } guard{s};   // never left on, whatever path returns
   const bool deferred = s->defer_tail;
   if (deferred && sac_window_may_use_phase(s, B)) ILSX_TRY(sac_snapshot_take(s));   // the roll-back point of this window
-  static const bool no_segments = []() { const char* e = getenv("ILSX_SPLIT_SEGMENTS"); return e && atoi(e) == 0; }();
-  if (sac_is_split(s) && !split_graph && !no_graph_env && !no_segments && !s->ctx->prof_on) {
+  static const bool segments = []() { const char* e = getenv("ILSX_SPLIT_SEGMENTS"); return e && atoi(e) != 0; }();   // measured slower: see sac_split_segments_step
+  if (sac_is_split(s) && !split_graph && !no_graph_env && segments && !s->ctx->prof_on) {
     for (int i = 0; i < n_steps; ++i) {
       if (stats && i == n_steps - 1) ILSX_TRY(sac_request_stats(s));
       ILSX_TRY(sac_split_segments_step(s, rb, B));

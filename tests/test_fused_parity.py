@@ -249,16 +249,16 @@ def test_split_run_phases_with_rccl_on_the_ctx_stream_equal_the_fused_step():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    # split: the default form — three captured segments with the two all-reduces enqueued between them; split_direct: every launch direct;
+    # split: the default form — every launch direct; split_segments: three captured segments with the two all-reduces enqueued between them;
     # split_graph: the whole step, collective included, in one capture
-    for tag, extra in (("fused", {}), ("split", {"ILSX_SPLIT_FORCE": "1"}), ("split_direct", {"ILSX_SPLIT_FORCE": "1", "ILSX_SPLIT_SEGMENTS": "0"}),
+    for tag, extra in (("fused", {}), ("split", {"ILSX_SPLIT_FORCE": "1"}), ("split_segments", {"ILSX_SPLIT_FORCE": "1", "ILSX_SPLIT_SEGMENTS": "1"}),
                        ("split_graph", {"ILSX_SPLIT_FORCE": "1", "ILSX_SPLIT_GRAPH": "1"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", _SPLIT_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (tag, r.stderr[-3000:])
         outs[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])   # RCCL prints its own banner lines
     assert outs["split"] == outs["fused"], outs
-    assert outs["split_direct"] == outs["fused"], outs
+    assert outs["split_segments"] == outs["fused"], outs
     assert outs["split_graph"] == outs["fused"], outs
 
 
