@@ -318,12 +318,12 @@ static int kernels_init_once() {
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
 #define SET_G(HH, AA, CC, GG) HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<HH, AA, CC, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
-  SET_G(256, ACT_RELU, 4, 0); SET_G(256, ACT_RELU, 4, 1); SET_G(256, ACT_RELU, 4, 2); SET_G(256, ACT_TANH, 4, 0); SET_G(256, ACT_TANH, 4, 1); SET_G(256, ACT_TANH, 4, 2);
+  SET_G(256, ACT_RELU, 4, 0); SET_G(256, ACT_RELU, 4, 1); SET_G(256, ACT_RELU, 4, 2); SET_G(256, ACT_RELU, 4, 3); SET_G(256, ACT_TANH, 4, 0); SET_G(256, ACT_TANH, 4, 1); SET_G(256, ACT_TANH, 4, 2); SET_G(256, ACT_TANH, 4, 3);
 #define SET_PH(AA, GG) HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, GG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, GG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
   SET_PH(ACT_RELU, 0); SET_PH(ACT_RELU, 1); SET_PH(ACT_RELU, 2); SET_PH(ACT_TANH, 0); SET_PH(ACT_TANH, 1); SET_PH(ACT_TANH, 2);
 #undef SET_PH
-  SET_G(128, ACT_RELU, 2, 0); SET_G(128, ACT_RELU, 2, 1); SET_G(128, ACT_RELU, 2, 2); SET_G(128, ACT_TANH, 2, 0); SET_G(128, ACT_TANH, 2, 1); SET_G(128, ACT_TANH, 2, 2);
+  SET_G(128, ACT_RELU, 2, 0); SET_G(128, ACT_RELU, 2, 1); SET_G(128, ACT_RELU, 2, 2); SET_G(128, ACT_RELU, 2, 3); SET_G(128, ACT_TANH, 2, 0); SET_G(128, ACT_TANH, 2, 1); SET_G(128, ACT_TANH, 2, 2); SET_G(128, ACT_TANH, 2, 3);
 #undef SET_G
 #define SET_MT(AA, MM) HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, true, 0, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp2_fwd_split<256, AA, 4, true, 1, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
@@ -459,6 +459,7 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
     // consume their activations 2.9 us each.)  Padding workgroups exit at once.
     dim3 grid(((((tiles + A.rt - 1) / A.rt) + 7) & ~7) << A.xs, A.ntasks, cs), block(4 * H / cs);
     if (A.tail_mode) { if (!A.tail || A.tail_n < 1 || A.tail_n > (int)(grid.x * grid.z)) ILSX_FAIL(ILSX_ERR_ARG, "deferred tail: bad record table"); grid.y += 1; }
+    if (A.late < 0) A.late = (long)tiles * A.ntasks * cs > 2L * device_cus(ctx);   // more workgroups than two per CU: the 4-waves-per-SIMD shape (kernels.h GRP == 3)
     if (H == 256 && cs == 4 && A.l0_split) {   // wide inputs: layer 0 (column-split) in its own launch, then layer 1 + heads from hsave[0]
       FwdArgs A2 = A;
       A2.tail_mode = 0; A2.tail = nullptr; A2.tail_n = 0; A2.dbg = ctx->dbg_next();
@@ -470,7 +471,8 @@ int launch_fwd(ilsx_ctx* ctx, const FwdArgs& A0, int H, int act, int KPmax, int 
       else { if (gg == 2) L0_CALL(ACT_TANH, 2); else if (gg == 1) L0_CALL(ACT_TANH, 1); else L0_CALL(ACT_TANH, 0); }
 #undef L0_CALL
     } else if (H == 256 && cs == 4) {
-#define FWD_GRP_CALL(HH, AA, CC) do { if (A.tasks && A.ctab) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<HH, AA, CC, 2>), grid, block, lds, ctx->stream, A); \
+#define FWD_GRP_CALL(HH, AA, CC) do { if (A.tasks && A.ctab && A.late) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<HH, AA, CC, 3>), grid, block, lds, ctx->stream, A); \
+        else if (A.tasks && A.ctab) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<HH, AA, CC, 2>), grid, block, lds, ctx->stream, A); \
         else if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_fwd_split<HH, AA, CC, 1>), grid, block, lds, ctx->stream, A); \
         else ILSX_LAUNCH(ps, (k_mlp2_fwd_split<HH, AA, CC, 0>), grid, block, lds, ctx->stream, A); } while (0)
       if (act == ILSX_ACT_RELU) FWD_GRP_CALL(256, ACT_RELU, 4); else FWD_GRP_CALL(256, ACT_TANH, 4);
@@ -593,8 +595,10 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A0, int H, int act, int cs) {
     const size_t lds = bwd_split_lds_bytes(H, cs);
     A.xs = ctx->xcd_shift;
     dim3 grid(((((A.rows + 15) / 16) + 7) & ~7) << A.xs, A.ntasks, cs), block(4 * H / cs);   // same tile -> XCD mapping as launch_fwd
+    if (A.late < 0) A.late = (long)((A.rows + 15) / 16) * A.ntasks * cs > 2L * device_cus(ctx);   // as in launch_fwd
     if (H == 256 && cs == 4) {
-#define BWD_GRP_CALL(HH, AA, CC) do { if (A.tasks && A.ctab) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<HH, AA, CC, 2>), grid, block, lds, ctx->stream, A); \
+#define BWD_GRP_CALL(HH, AA, CC) do { if (A.tasks && A.ctab && A.late) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<HH, AA, CC, 3>), grid, block, lds, ctx->stream, A); \
+        else if (A.tasks && A.ctab) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<HH, AA, CC, 2>), grid, block, lds, ctx->stream, A); \
         else if (A.tasks) ILSX_LAUNCH(ps, (k_mlp2_bwd_split<HH, AA, CC, 1>), grid, block, lds, ctx->stream, A); \
         else ILSX_LAUNCH(ps, (k_mlp2_bwd_split<HH, AA, CC, 0>), grid, block, lds, ctx->stream, A); } while (0)
       if (act == ILSX_ACT_RELU) BWD_GRP_CALL(256, ACT_RELU, 4); else BWD_GRP_CALL(256, ACT_TANH, 4);

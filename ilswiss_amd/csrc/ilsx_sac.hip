@@ -1247,6 +1247,7 @@ struct ilsx_sac_group {
   TailLite* tails_lite = nullptr;   // deferred tail: one record per agent (see TailLite, kernels.h)
   bool defer = false;
   int mt = 1;                       // 16-row tiles per workgroup of the forward / backward launches (macro tiles, fwd_split_tile.inc)
+  int late = -1;                    // "late weights" launch shape of the forward / backward launches: -1 per launch by size, 0 / 1 pinned (ILSX_GRP_LATE)
 };
 
 template <class T>
@@ -1388,6 +1389,8 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
   g->rbs.assign(rbs, rbs + K);
   g->B = B;
   g->mt = group_pick_mt(g, B);
+  // ILSX_GRP_LATE = 0 | 1 pins the "late weights" launch shape off / on (kernels.h GRP == 3); by default each launch decides from its size
+  if (const char* e = getenv("ILSX_GRP_LATE")) g->late = atoi(e) ? 1 : 0; else g->late = -1;
   return ILSX_OK;
 }
 
@@ -1421,11 +1424,11 @@ static int group_launch_step(ilsx_sac_group* g) {
       FwdArgs A = st.f;
       if (g->defer && nfwd < 2) { A.tail = g->tails_lite; A.tail_mode = nfwd + 1; A.tail_n = K; }   // tail of the previous step / gather_step
       ++nfwd;
-      A.mt = g->mt; A.swz.agents = K; A.mt_a = s0->a;
+      A.mt = g->mt; A.swz.agents = K; A.mt_a = s0->a; A.late = g->late;
       A.mt_not = std::max((s0->Lp.NO + 15) / 16, (s0->Lq.NO + 15) / 16);
       ILSX_TRY(launch_fwd(g->ctx, A, H, act, st.KP, cs));
     }
-    else if (st.kind == 1) { BwdArgs A = st.b; A.mt = g->mt; A.swz.agents = K; ILSX_TRY(launch_bwd_dx(g->ctx, A, H, act, cs)); }
+    else if (st.kind == 1) { BwdArgs A = st.b; A.mt = g->mt; A.swz.agents = K; A.late = g->late; ILSX_TRY(launch_bwd_dx(g->ctx, A, H, act, cs)); }
     else if (st.kind == 2) { AdamFuse on; memset(&on, 0, sizeof on); on.on = 1; ILSX_TRY(launch_bwd_dw(g->ctx, st.d, g->B, &on)); }
     else if (!g->defer) ILSX_TRY(group_launch_tail(g, st.tails, 0));
   }

@@ -20,6 +20,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define ILSX_LDS_PAD 4
+#ifndef ILSX_LATE_WAVES
+#define ILSX_LATE_WAVES 4   // waves per SIMD the "late weights" grouped instantiations (GRP == 3) are compiled for
+#endif
 #ifndef ILSX_MT_WAVES
 #define ILSX_MT_WAVES 2   // waves per SIMD the macro-tile instantiations are compiled for (register budget 512 / this)
 #endif
@@ -372,6 +375,7 @@ struct FwdArgs {
   int mt_not, mt_a;              //   host side (LDS sizing): the widest head of the launch's tasks in 16-output tiles, the widest finished policy
   GrpSwizzle swz;                // grouped launches with a 1-D grid (see GrpSwizzle)
   int ctab;                      // grouped launches, descriptor records in CONSTANT memory (g_fwd_tab, below): 1 + first slot of this launch's table; 0 = device table `tasks`
+  int late;                      // with ctab: the GRP == 3 instantiation (layer-1 weight slice fetched right before its MFMA phase, 4 waves per SIMD)
 };
 struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* scal; int fin_on; };
 // one self-contained record per grid row: the task and its agent's per-launch state side by side, so a workgroup reaches
@@ -644,6 +648,7 @@ struct BwdArgs {
   int mt;                   // grouped launches: row tiles per workgroup (see FwdArgs::mt)
   GrpSwizzle swz;
   int ctab;                 // grouped launches: 1 + first slot in g_bwd_tab, 0 = device table `tasks` (see FwdArgs::ctab)
+  int late;                 // see FwdArgs::late
 };
 
 // dL/d(head output j) of row gr for the loss functor of task T (shared by the generic and the column-split
@@ -893,6 +898,11 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
 // kernel-argument segment of the single-run launches: a field is a scalar load where it is used (the address space tells the compiler
 // that no store of the kernel can alias it), loaded again instead of parked when registers run short.  GRP == 2 selects it; slots are
 // handed out by the host (grp_const_alloc, ilsx_core.hip), a group that finds none falls back to GRP == 1.
+// GRP == 3 is GRP == 2 with the wave's 64-register slice of the hidden->hidden matrix fetched right before the MFMA phase that consumes
+// it instead of at entry: the prologue (staging, layer 0 / head gradient, delta_1) then runs in <= 128 registers and the kernel is
+// compiled for FOUR waves per SIMD instead of two.  Each workgroup waits out one exposed L2 burst (slower alone), twice as many are
+// resident: it pays when a launch has more workgroups than 2 per CU (K = 8 seeds: 1024), and loses when it has not (K = 4: 512) — the
+// host picks per launch (FwdArgs::late).  Same MFMA chains in the same order: bit-identical.
 #define GRP_CONST_SLOTS 768
 #ifdef ILSX_KERNEL_IMPL
 __constant__ FwdTaskG g_fwd_tab[GRP_CONST_SLOTS];
@@ -904,7 +914,7 @@ __constant__ BwdTask g_bwd_tab[GRP_CONST_SLOTS];
 // PH = 1 stages x (gather / policy epilogue as in PH 0) and computes THIS slice's 64 columns of layer 0 into hsave[0];
 // PH = 2 starts from hsave[0] (16 KB per tile, L2-resident) and does layer 1 + heads.
 template <int H, int ACT, int CS, int GRP, int PH = 0, int MT = 1>   // GRP: 0 = tasks in the kernel arguments, 1 = device table, 2 = constant table
-__global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_mlp2_fwd_split(const FwdArgs A) {
+__global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : GRP == 3 ? ILSX_LATE_WAVES : 1)) void k_mlp2_fwd_split(const FwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(MT == 1 || GRP, "macro tiles are a grouped-launch shape");
   int sw_bx = 0, sw_task = 0, sw_cs = 0;
@@ -939,9 +949,9 @@ __global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_ml
   FwdTaskG Rg;
   const int ty = (GRP && MT > 1) ? sw_task : (int)blockIdx.y;
   if (GRP == 1) Rg = A.tasks[ty];
-  const FwdTaskG& Rc = g_fwd_tab[GRP == 2 ? A.ctab - 1 + ty : 0];
-  const FwdTask& T = GRP == 2 ? Rc.t : GRP == 1 ? Rg.t : A.t[ty];
-  const FwdGroup* GP = GRP == 2 ? &Rc.g : GRP == 1 ? &Rg.g : nullptr;
+  const FwdTaskG& Rc = g_fwd_tab[GRP >= 2 ? A.ctab - 1 + ty : 0];
+  const FwdTask& T = GRP >= 2 ? Rc.t : GRP == 1 ? Rg.t : A.t[ty];
+  const FwdGroup* GP = GRP >= 2 ? &Rc.g : GRP == 1 ? &Rg.g : nullptr;
   // the body is shared as TEXT with the merged phase kernels (see fwd_split_tile.inc for why it is not a device function)
   constexpr bool XCH = false;
   const int bx = (GRP && MT > 1) ? sw_bx : (int)blockIdx.x, cs = (GRP && MT > 1) ? sw_cs : (int)blockIdx.z;
@@ -996,7 +1006,7 @@ __global__ __launch_bounds__(64) void k_policy_finish(const PolicyFinishArgs P) 
 }
 
 template <int H, int ACT, int CS, int GRP, int MT = 1>
-__global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_mlp2_bwd_split(const BwdArgs A) {
+__global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : GRP == 3 ? ILSX_LATE_WAVES : 1)) void k_mlp2_bwd_split(const BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(MT == 1 || GRP, "macro tiles are a grouped-launch shape");
   int sw_bx = 0, sw_task = 0, sw_cs = 0;
@@ -1006,7 +1016,7 @@ __global__ __launch_bounds__(4 * H / CS, (MT > 1 ? ILSX_MT_WAVES : 1)) void k_ml
   const int ty = (GRP && MT > 1) ? sw_task : (int)blockIdx.y;
   BwdTask Tg;
   if (GRP == 1) Tg = A.tasks[ty];   // by value at entry (see k_mlp2_fwd_split)
-  const BwdTask& T = GRP == 2 ? g_bwd_tab[A.ctab - 1 + ty] : GRP == 1 ? Tg : A.t[ty];   // GRP 0 / 2: read in place (kernel arguments / constant table)
+  const BwdTask& T = GRP >= 2 ? g_bwd_tab[A.ctab - 1 + ty] : GRP == 1 ? Tg : A.t[ty];   // GRP 0 / 2: read in place (kernel arguments / constant table)
   constexpr bool XCH = false;
   const int bx = (GRP && MT > 1) ? sw_bx : (int)blockIdx.x, cs = (GRP && MT > 1) ? sw_cs : (int)blockIdx.z;
 #define XCH_HOOK_ACT
