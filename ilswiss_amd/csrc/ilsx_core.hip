@@ -640,8 +640,12 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
   bool stacked = false;
   for (int i = 0; i < D.nmat && !D.gtiles; ++i) stacked = stacked || D.m[i].rows > 0;
   if (rows >= DW_SPLIT_MIN_ROWS && D.g_lo && !stacked) {   // large batch: split the contraction over row ranges
+    // >= DW_BIG_MIN_ROWS rows: the LDS-staged 128 x 128 block kernel (k_dw_big), row ranges of >= 512 rows, up to 64 of them (its heavy
+    // blocks — the hidden -> hidden matrix — are 4 per range: 256 of them fill the chip).  ILSX_DW_BIG = 0 keeps the tile kernel (A/B, tests)
+    static const int big_env = []() { const char* e = getenv("ILSX_DW_BIG"); return e ? atoi(e) : 1; }();
+    const bool big = big_env && rows >= DW_BIG_MIN_ROWS;
     int splits = rows / 512;
-    if (splits > 32) splits = 32;
+    if (splits > (big ? 64 : 32)) splits = big ? 64 : 32;
     const size_t span = (size_t)(D.g_hi - D.g_lo);
     const size_t need = (size_t)splits * span * sizeof(float);
     if (ctx->dw_scratch_bytes < need) {
@@ -654,15 +658,25 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     D.scratch = (float*)ctx->dw_scratch; D.span = span; D.xs = 0;
     const AdamFuse keep = D.F;
     D.F.on = 0;
-    {
+    if (big) {
+      D.rows_per_split = ((rows + splits - 1) / splits + DWB_RC - 1) / DWB_RC * DWB_RC;
+      D.ntiles = 0;
+      for (int i = 0; i < D.nmat; ++i) {   // the table again in 128 x 128 blocks
+        D.m[i].ktiles = (D.m[i].NB + 127) / 128;
+        D.m[i].tile0 = D.ntiles;
+        D.ntiles += ((D.m[i].NA + 127) / 128) * D.m[i].ktiles;
+      }
+      ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
+      ILSX_LAUNCH(ps, k_dw_big, dim3(D.ntiles * splits), dim3(256), 0, ctx->stream, D);
+    } else {
       ProfScope ps(ctx, ILSX_K_MLP_BWD_DW);
       ILSX_LAUNCH(ps, (k_mlp_bwd_dw<false, 2, 4>), dim3(D.ntiles, splits), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
     }
     DwReduceArgs R;
     R.scratch = D.scratch; R.splits = splits; R.span = span; R.g_lo = D.g_lo; R.F = keep;
     R.off0 = keep.on ? (size_t)(D.g_lo - keep.Gbase) : 0;
-    int blocks = (int)((span / 4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((span / 4 + 63) / 64);
+    if (blocks > 4096) blocks = 4096;
     ProfScope ps(ctx, ILSX_K_ADAM);
     ILSX_LAUNCH(ps, k_dw_reduce, dim3(blocks), dim3(256), 0, ctx->stream, R);
     HIPCHK(hipGetLastError());

@@ -1357,6 +1357,7 @@ struct DwArgs {
 };
 struct DwTileG { DwMat J; AdamFuse F; };
 #define DW_SPLIT_MIN_ROWS 1024
+#define DW_BIG_MIN_ROWS 4096
 #define DW_TILE_N 32
 #define DW_TILE_K 64
 
@@ -1534,6 +1535,143 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
     if (F.on) adam_apply(F, ad_step, ad_bc2s, aob, (size_t)(gbp - F.Gbase), 0, false, s);
   }
   ILSX_STAMP(D.dbg, 7);
+}
+
+// ---- the weight gradients of LARGE batches (PPO's 32768-row minibatches; split mode of launch_bwd_dw).  k_mlp_bwd_dw feeds every MFMA
+// with one 4-byte global load per lane and operand (64-byte runs of four different rows per instruction): at thousands of rows per wave
+// it is bound by the vector-memory path, not by the MFMA pipe (26 % of the fp32 peak).  Here a 256-thread workgroup owns a 128 (n) x 128 (k)
+// block of one matrix over one row range: 32-row chunks of delta[:, n-block] and activations[:, k-block] are fetched with 16-byte
+// loads (whole 512-byte row segments per 32 lanes), parked in registers while the previous chunk is consumed, and staged in LDS
+// (row stride 144 floats: the four rows a 16x16x4 step reads fall in different banks); each wave owns 64 x 64 outputs = 16 accumulator
+// tiles and issues 16 MFMAs per 8 LDS reads.  Per row a block moves 1 KiB for 32 kFLOP.  Partial gradients go to this row range's
+// slab in the arena layout (k_dw_reduce sums the slabs in a fixed order and applies Adam): deterministic, no atomics.
+#define DWB_RC 32      // rows per staged chunk
+#define DWB_LD 144     // LDS row stride (floats)
+template <bool FULL>   // FULL: the block's 128 columns exist and rows are 16-byte aligned — one float4 per (row, column quad), no column guards
+__device__ __forceinline__ void dwb_fetch(const float* __restrict__ X, int ld, int c0, int ncols, int rc, int r_end, int tid, float (&p)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q, r = rc + (idx >> 5), c = c0 + 4 * (idx & 31);
+    const bool r_ok = r < r_end;
+    const float* src = X + (size_t)(r_ok ? r : r_end - 1) * ld + c;
+    if constexpr (FULL) {
+      const float4 v = *reinterpret_cast<const float4*>(src);
+      p[4 * q] = r_ok ? v.x : 0.0f; p[4 * q + 1] = r_ok ? v.y : 0.0f; p[4 * q + 2] = r_ok ? v.z : 0.0f; p[4 * q + 3] = r_ok ? v.w : 0.0f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = c + j < ncols;
+        const float v = src[ok ? j : -c];   // a column past the matrix reads the row's first element instead (in bounds), and is zeroed
+        p[4 * q + j] = (r_ok && ok) ? v : 0.0f;
+      }
+    }
+  }
+}
+__device__ __forceinline__ void dwb_park(float* S, int tid, const float (&p)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q;
+    *reinterpret_cast<float4*>(S + (idx >> 5) * DWB_LD + 4 * (idx & 31)) = make_float4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
+  }
+}
+// one staged chunk: 8 steps of 4 rows; NTI x NKI accumulator tiles of this wave are live (4 x 4 in the hidden -> hidden blocks)
+template <int NTI, int NKI>
+__device__ __forceinline__ void dwb_chunk(const float* ap, const float* bp, f32x4 (&acc)[4][4], float (&bs)[4]) {
+#pragma unroll
+  for (int s = 0; s < DWB_RC / 4; ++s) {
+    float a[NTI], b[NKI];
+#pragma unroll
+    for (int i = 0; i < NTI; ++i) a[i] = ap[4 * s * DWB_LD + 16 * i];
+#pragma unroll
+    for (int t = 0; t < NKI; ++t) b[t] = bp[4 * s * DWB_LD + 16 * t];
+#pragma unroll
+    for (int i = 0; i < NTI; ++i) {
+#pragma unroll
+      for (int t = 0; t < NKI; ++t) acc[i][t] = MFMA16(a[i], b[t], acc[i][t]);
+      bs[i] += a[i];
+    }
+  }
+}
+__global__ __launch_bounds__(256, 2) void k_dw_big(const DwArgs D) {
+  __shared__ __attribute__((aligned(16))) float As[DWB_RC * DWB_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[DWB_RC * DWB_LD];
+  // 1-D grid, block-major: the `splits` row ranges of one block are consecutive workgroups, so the heavy blocks (hidden -> hidden: 8 k
+  // tiles per wave against 1 for the first layer and the heads) are dealt round-robin over all 8 XCDs.  (Block index on grid.x with 8
+  // blocks per range put every heavy block on the same four XCDs: 90 us per launch.)
+  const int bx = blockIdx.x / D.splits, by = blockIdx.x - bx * D.splits;
+  int mi = 0;
+#pragma unroll
+  for (int i = 1; i < DW_MAX_MATS; ++i)
+    if (i < D.nmat && bx >= D.m[i].tile0) mi = i;
+  const DwMat& J = D.m[mi];   // tile0 / ktiles in 128 x 128 blocks here (launch_bwd_dw re-tiles its copy of the table)
+  const int local = bx - J.tile0;
+  const int n0 = (local / J.ktiles) * 128, k0 = (local % J.ktiles) * 128;
+  const int r_begin = by * D.rows_per_split, r_end = min(D.rows_all, r_begin + D.rows_per_split);
+  float* const slab = D.scratch + (size_t)by * D.span;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: say so, the tile counts below steer scalar branches
+  const int wn = wave & 1, wk = wave >> 1;
+  const int nw0 = n0 + 64 * wn, kw0 = k0 + 64 * wk;
+  const int nti = max(0, min(4, (J.NA - nw0 + 15) >> 4)), nki = max(0, min(4, (J.NB - kw0 + 15) >> 4));
+  const bool fa = (J.lda & 3) == 0 && (reinterpret_cast<size_t>(J.A) & 15) == 0 && n0 + 128 <= J.NA;
+  const bool fb = (J.ldb & 3) == 0 && (reinterpret_cast<size_t>(J.Bm) & 15) == 0 && k0 + 128 <= J.NB;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  float pa[16], pb[16];
+  if (r_begin >= r_end) return;   // (a trailing row range past the batch: workgroup-uniform)
+  if (fa) dwb_fetch<true>(J.A, J.lda, n0, J.NA, r_begin, r_end, tid, pa); else dwb_fetch<false>(J.A, J.lda, n0, J.NA, r_begin, r_end, tid, pa);
+  if (fb) dwb_fetch<true>(J.Bm, J.ldb, k0, J.NB, r_begin, r_end, tid, pb); else dwb_fetch<false>(J.Bm, J.ldb, k0, J.NB, r_begin, r_end, tid, pb);
+  const float* ap = As + g * DWB_LD + 64 * wn + li;
+  const float* bp = Bs + g * DWB_LD + 64 * wk + li;
+  for (int rc = r_begin; rc < r_end; rc += DWB_RC) {
+    lds_barrier();   // the previous chunk has been consumed
+    dwb_park(As, tid, pa);
+    dwb_park(Bs, tid, pb);
+    lds_barrier();
+    if (rc + DWB_RC < r_end) {   // the next chunk travels while this one is multiplied
+      if (fa) dwb_fetch<true>(J.A, J.lda, n0, J.NA, rc + DWB_RC, r_end, tid, pa); else dwb_fetch<false>(J.A, J.lda, n0, J.NA, rc + DWB_RC, r_end, tid, pa);
+      if (fb) dwb_fetch<true>(J.Bm, J.ldb, k0, J.NB, rc + DWB_RC, r_end, tid, pb); else dwb_fetch<false>(J.Bm, J.ldb, k0, J.NB, rc + DWB_RC, r_end, tid, pb);
+    }
+    // the shapes that occur: hidden -> hidden 4 x 4; first layer 4 x 1 (K padded to 16 .. 64: 4 x NKI); heads 1 x 4; anything else 4 x 4 on
+    // the zero padding the staging wrote (correct, some idle MFMAs)
+    if (nti == 4 && nki == 4) dwb_chunk<4, 4>(ap, bp, acc, bs);
+    else if (nti == 4 && nki == 1) dwb_chunk<4, 1>(ap, bp, acc, bs);
+    else if (nti == 1 && nki == 4) dwb_chunk<1, 4>(ap, bp, acc, bs);
+    else if (nti == 0 || nki == 0) {}
+    else dwb_chunk<4, 4>(ap, bp, acc, bs);
+  }
+  // ---- this row range's partial block -> its slab (arena layout).  D[n = 4g + v][k = li] per accumulator tile
+  const size_t off_w = (size_t)(J.dW - D.g_lo), off_wb = J.mode == DW_OUT_PACK_FB ? (size_t)(J.dWb - D.g_lo) : 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (i >= nti || t >= nki) continue;
+      const int nb = nw0 + 16 * i + 4 * g, k = kw0 + 16 * t + li;
+      if (k >= J.NB) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int n = nb + v;
+        if (n < J.NA) slab[off_w + (J.mode == DW_OUT_NATURAL ? (size_t)n * J.ldw + k : (size_t)pack_f(n, k, J.ldw))] = acc[i][t][v];
+      }
+      if (J.mode == DW_OUT_PACK_FB)   // hidden -> hidden: NA is a multiple of 16, the four n of a lane are one 16-byte word of the backward packing
+        *reinterpret_cast<float4*>(slab + off_wb + pack_b(nb, k, J.NA)) = make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
+    }
+  if (J.db && k0 == 0 && wk == 0) {
+    const size_t off_b = (size_t)(J.db - D.g_lo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float b = bs[i];
+      b += __shfl_xor(b, 16, 64);
+      b += __shfl_xor(b, 32, 64);
+      const int n = nw0 + 16 * i + li;
+      if (g == 0 && n < J.NA) slab[off_b + n] = b;
+    }
+  }
 }
 
 // ---- the weight gradients in throughput shape (grouped launches: K co-resident runs).  ONE wavefront (a 64-thread workgroup) owns a
@@ -1747,27 +1885,49 @@ __global__ __launch_bounds__(64, 2) void k_dw_strip(const DwArgs D) {
 // gradients and moments, so they stay identical.
 struct DwReduceArgs { const float* scratch; int splits; size_t span; float* g_lo; AdamFuse F; size_t off0; };
 __global__ __launch_bounds__(256) void k_dw_reduce(const DwReduceArgs R) {
+  // wave w of a workgroup sums slabs [w q, (w+1) q) of one run of 64 float4 (loads batched eight at a time), the four partial sums are
+  // added in wave order: a fixed order for every element whatever the grid
+  __shared__ float4 part[3][64];
   const AdamFuse& F = R.F;
   float step = 0.f, bc2s = 1.f;
   if (F.on) { step = *F.step_size; bc2s = *F.bc2_sqrt; }
   const size_t n4 = R.span >> 2;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    float4 s = reinterpret_cast<const float4*>(R.scratch)[i];
-    for (int y = 1; y < R.splits; ++y) {
-      const float4 v = reinterpret_cast<const float4*>(R.scratch + (size_t)y * R.span)[i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    reinterpret_cast<float4*>(R.g_lo)[i] = s;
-    if (F.on) {
-      const float gs[4] = {s.x, s.y, s.z, s.w};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = (R.splits + 3) >> 2, y0 = wave * q, y1 = min(R.splits, y0 + q);
+  for (size_t base = (size_t)blockIdx.x * 64; base < n4; base += (size_t)gridDim.x * 64) {   // workgroup-uniform trip count
+    const size_t i = base + lane;
+    const bool ok = i < n4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      const float4* src = reinterpret_cast<const float4*>(R.scratch) + i;
+      int y = y0;
+      for (; y + 8 <= y1; y += 8) {
+        float4 v[8];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const size_t j = R.off0 + 4 * i + c;
-        AdamOperands o;
-        o.p = F.P[j]; o.m = F.M[j]; o.v = F.V[j]; o.t = F.T ? F.T[j] : 0.0f;
-        adam_apply(F, step, bc2s, o, j, 0, false, gs[c]);
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(y + u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; y < y1; ++y) { const float4 v = src[(size_t)y * n4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    }
+    if (wave) part[wave - 1][lane] = s;
+    lds_barrier();
+    if (wave == 0 && ok) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w) { const float4 v = part[w][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+      reinterpret_cast<float4*>(R.g_lo)[i] = s;
+      if (F.on) {
+        const float gs[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const size_t j = R.off0 + 4 * i + c;
+          AdamOperands o;
+          o.p = F.P[j]; o.m = F.M[j]; o.v = F.V[j]; o.t = F.T ? F.T[j] : 0.0f;
+          adam_apply(F, step, bc2s, o, j, 0, false, gs[c]);
+        }
       }
     }
+    lds_barrier();
   }
 }
 #endif  // ILSX_KERNEL_IMPL

@@ -229,6 +229,36 @@ def test_hip_train_step_large_minibatch_row_split_dw(ctx):
     np.testing.assert_allclose(tr.get_flat_params(0), orc.pi, rtol=0, atol=5e-5)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("hid,mb", [([256, 256], 5003), ([64, 64], 4096), ([128, 128], 6000)])
+def test_hip_train_step_big_minibatch_block_dw(ctx, hid, mb):
+    """Minibatches >= 4096 rows take the LDS-staged 128 x 128 block weight-gradient kernel (k_dw_big): 32-row chunks, row ranges that are
+    not whole chunks (5003 rows), blocks wider than the matrix (H = 64, the 16-wide first layer, the 3-wide head) == the oracle."""
+    from oracle import mlp as omlp
+    from ilswiss_amd.networks import FlattenMlp
+    from ilswiss_amd.ppo import PPO, ReparamMultivariateGaussianPolicy
+    rng = np.random.default_rng(321)
+    o, a = 11, 3
+    kw = dict(KW, mini_batch_size=mb, update_epoch=2)
+    vf0 = omlp.init_mlp(rng, o, hid, 1)
+    pi0 = np.concatenate([omlp.init_mlp(rng, o, hid, a, init_w=1e-3, last_scale=(0.1, 0.0)), rng.normal(-0.5, 0.2, a).astype(np.float32)])
+    lens = (3000, 2500, 4000, 1900)
+    trajs = [dict(observations=rng.normal(0, 1, (L, o)).astype(np.float32), actions=rng.normal(0, 0.7, (L, a)).astype(np.float32),
+                  rewards=rng.normal(0.5, 1.0, (L, 1)).astype(np.float32)) for L in lens]
+    N = sum(lens)   # 11400: two big minibatches and a ragged last one
+    perms = np.stack([rng.permutation(N) for _ in range(2)])
+    orc = PPOOracle(o, a, hid, pi0, vf0, **kw)
+    pol = ReparamMultivariateGaussianPolicy(hid, o, a, conditioned_std=False, hidden_activation="tanh", ctx=ctx, seed=3)
+    vf = FlattenMlp(hid, 1, o, hidden_activation="tanh", ctx=ctx, seed=4)
+    tr = PPO(pol, vf, max_samples=12000, **kw)
+    tr.set_flat_params(pi0, vf0)
+    orc.train_step(trajs, list(perms))
+    tr.train_step(trajs, perms)
+    np.testing.assert_allclose(tr.get_flat_params(1), orc.vf, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(tr.get_flat_params(0), orc.pi, rtol=0, atol=5e-5)
+    assert np.abs(tr.get_flat_params(0) - pi0).max() > 1e-4
+
+
 def test_policy_ctor_defaults_are_the_references():
     """policies.py:131-140 (MlpGaussianNoisePolicy), :349-356 (ReparamMultivariateGaussianPolicy) over networks.py:24-32 (Mlp), typed in:
     a caller that relies on the class defaults gets the reference's network — or an explicit NotImplementedError, never another one."""
