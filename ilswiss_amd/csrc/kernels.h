@@ -383,6 +383,132 @@ struct FwdGroup { PolicyFinishArgs fin; GatherSpec gather; const DevScalars* sca
 struct FwdTaskG { FwdTask t; FwdGroup g; };
 
 #ifdef ILSX_KERNEL_IMPL
+// ---- the NO head outputs of one row: one wave, lanes split K (lane owns H/64 consecutive features), 4 outputs in flight
+template <int H>
+__device__ __forceinline__ void fwd_heads_row(const float* hrow, const float* Wh, const float* bh, int NO, float* hout_row, int lane) {
+  constexpr int KPL = H / 64;
+  float hv[KPL];
+  load_vec<KPL>(hrow + KPL * lane, hv);
+  for (int j0 = 0; j0 < NO; j0 += 4) {
+    float s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, NO - 1);
+      float wv[KPL];
+      load_vec<KPL>(Wh + (size_t)j * H + KPL * lane, wv);
+      float t = 0.0f;
+#pragma unroll
+      for (int c = 0; c < KPL; ++c) t = fmaf(hv[c], wv[c], t);
+      s[u] = t;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = wave_sum(s[u]);
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u < NO) hout_row[j0 + u] = s[u] + bh[j0 + u];
+    }
+  }
+}
+// ---- head epilogue of one row (shared by the generic and the large-batch forward kernels): one wave per row, lane <-> output /
+// action dim; `ho` = the row's NO raw head outputs (LDS), gr = its global row
+__device__ __forceinline__ void fwd_head_row(const FwdTask& T, const FwdArgs& A, const float* ho, int gr, int lane, int NO) {
+  const int oc = T.out_cols > 0 ? T.out_cols : NO;
+  if (T.out && lane < oc) T.out[(size_t)gr * oc + lane] = ho[lane];
+  if (T.head == HEAD_RAW) return;
+  if (T.head == HEAD_DET_TANH_NOISE || T.head == HEAD_DET_LIN_NOISE) {
+    // MlpGaussianNoisePolicy.forward (policies.py:166-188): the result is NOT re-clipped to [-max_act, max_act]
+    const int j = lane;
+    if (j < NO && T.action) {
+      float act = T.max_act * (T.head == HEAD_DET_LIN_NOISE ? ho[j] : tanhf(ho[j]));
+      if (T.noise != 0.0f) {
+        float e;
+        if (T.eps) {
+          e = T.eps[(size_t)gr * NO + j];
+        } else {
+          float z4[4];
+          philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+          const int qd = j & 3;
+          e = qd == 0 ? z4[0] : qd == 1 ? z4[1] : qd == 2 ? z4[2] : z4[3];
+        }
+        act += fminf(fmaxf(T.noise * e, -T.noise_clip), T.noise_clip);
+      }
+      T.action[(size_t)gr * NO + j] = act;
+    }
+    return;
+  }
+  if (T.head >= HEAD_GAUSS_SAMPLE) {
+    // ReparamMultivariateGaussianPolicy (policies.py:398-417,462-478 + distributions.py:43-50): log_std is the state-independent
+    // parameter (conditioned_std=False, T.log_std) or, with T.log_std null, the net's second head clamped to [LOG_SIG_MIN, LOG_SIG_MAX]
+    // (conditioned_std=True, :401-405: NO = 2a outputs, mean | log_std)
+    const bool cond = T.log_std == nullptr;
+    const int a = cond ? NO >> 1 : NO, j = lane;
+    float q = 0.f, l = 0.f;
+    if (j < a) {
+      const float mu = ho[j], ls = cond ? fminf(fmaxf(ho[a + j], LOG_SIG_MIN), LOG_SIG_MAX) : T.log_std[j];
+      float act;
+      if (T.head == HEAD_GAUSS_LOGP_OF_ACT) {
+        const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;
+        act = T.act_in[sr * a + j];
+      } else {
+        float e;
+        if (T.eps) {
+          e = T.eps[(size_t)gr * a + j];
+        } else {
+          float z4[4];
+          philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+          const int qd = j & 3;
+          e = qd == 0 ? z4[0] : qd == 1 ? z4[1] : qd == 2 ? z4[2] : z4[3];
+        }
+        act = e * expf(ls) + mu;
+        if (T.action) T.action[(size_t)gr * a + j] = act;
+      }
+      const float dm = mu - act;
+      q = dm * dm / expf(2.0f * ls);
+      l = ls;
+    }
+    if (T.logp) {
+      q = wave_sum(q); l = wave_sum(l);
+      if (lane == 0) T.logp[gr] = -0.5f * q - (l + HALF_LOG_2PI);
+    }
+    return;
+  }
+  const int a = NO >> 1, j = lane;
+  float lp_quad = 0.f, lp_ls = 0.f, lp_jac = 0.f;
+  if (j < a) {
+    const float mu = ho[j];
+    const float ls = fminf(fmaxf(ho[a + j], LOG_SIG_MIN), LOG_SIG_MAX);
+    const float sd = expf(ls);
+    float e = 0.f, z, act;
+    if (T.head == HEAD_TANH_DET) {
+      z = mu; act = tanhf(mu);
+    } else if (T.head == HEAD_TANH_LOGP_OF_ACT) {
+      act = T.act_in[(size_t)gr * a + j];
+      z = 0.5f * (logf(1.0f + act + TANH_EPS) - logf(1.0f - act + TANH_EPS));  // distributions.py:85-88
+    } else {
+      if (T.eps) {
+        e = T.eps[(size_t)gr * a + j];
+      } else {
+        float z4[4];
+        philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+        const int q = j & 3;
+        e = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
+      }
+      z = e * sd + mu;        // distributions.py:27
+      act = tanhf(z);
+    }
+    const float dm = mu - z;
+    lp_quad = dm * dm / expf(2.0f * ls);                 // distributions.py:45-47
+    lp_ls = ls;
+    lp_jac = logf(1.0f - act * act + TANH_EPS);          // distributions.py:91-93
+    if (T.action) T.action[(size_t)gr * a + j] = act;
+    if (T.eps_save) T.eps_save[(size_t)gr * a + j] = e;
+  }
+  if (T.logp) {  // wave-uniform
+    lp_quad = wave_sum(lp_quad); lp_ls = wave_sum(lp_ls); lp_jac = wave_sum(lp_jac);
+    if (lane == 0) T.logp[gr] = -0.5f * lp_quad - (lp_ls + HALF_LOG_2PI) - lp_jac;
+  }
+}
 template <int H, int ACT>
 __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
   constexpr int NW = H / 16, NTH = 4 * H, NC = H / 16, KPL = H / 64, RPW = 16 / NW;
@@ -476,28 +602,7 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
 #pragma unroll
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = wave * RPW + rr;
-    float hv[KPL];
-    load_vec<KPL>(cur + row * LDH + KPL * lane, hv);
-    for (int j0 = 0; j0 < NO; j0 += 4) {
-      float s[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = min(j0 + u, NO - 1);
-        float wv[KPL];
-        load_vec<KPL>(Wh + (size_t)j * H + KPL * lane, wv);
-        float t = 0.0f;
-#pragma unroll
-        for (int c = 0; c < KPL; ++c) t = fmaf(hv[c], wv[c], t);
-        s[u] = t;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) s[u] = wave_sum(s[u]);
-      if (lane == 0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (j0 + u < NO) hout[row * ILSX_MAX_NO + j0 + u] = s[u] + bh[j0 + u];
-      }
-    }
+    fwd_heads_row<H>(cur + row * LDH, Wh, bh, NO, hout + row * ILSX_MAX_NO, lane);
   }
   lds_barrier();
   ILSX_STAMP(A.dbg, 6);
@@ -507,106 +612,30 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = wave * RPW + rr, gr = r0 + row;
     if (gr >= rows) continue;  // wave-uniform
-    const float* ho = hout + row * ILSX_MAX_NO;
-    const int oc = T.out_cols > 0 ? T.out_cols : NO;
-    if (T.out && lane < oc) T.out[(size_t)gr * oc + lane] = ho[lane];
-    if (T.head == HEAD_RAW) continue;
-    if (T.head == HEAD_DET_TANH_NOISE || T.head == HEAD_DET_LIN_NOISE) {
-      // MlpGaussianNoisePolicy.forward (policies.py:166-188): the result is NOT re-clipped to [-max_act, max_act]
-      const int j = lane;
-      if (j < NO && T.action) {
-        float act = T.max_act * (T.head == HEAD_DET_LIN_NOISE ? ho[j] : tanhf(ho[j]));
-        if (T.noise != 0.0f) {
-          float e;
-          if (T.eps) {
-            e = T.eps[(size_t)gr * NO + j];
-          } else {
-            float z4[4];
-            philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
-            const int qd = j & 3;
-            e = qd == 0 ? z4[0] : qd == 1 ? z4[1] : qd == 2 ? z4[2] : z4[3];
-          }
-          act += fminf(fmaxf(T.noise * e, -T.noise_clip), T.noise_clip);
-        }
-        T.action[(size_t)gr * NO + j] = act;
-      }
-      continue;
-    }
-    if (T.head >= HEAD_GAUSS_SAMPLE) {
-      // ReparamMultivariateGaussianPolicy (policies.py:398-417,462-478 + distributions.py:43-50): log_std is the state-independent
-      // parameter (conditioned_std=False, T.log_std) or, with T.log_std null, the net's second head clamped to [LOG_SIG_MIN, LOG_SIG_MAX]
-      // (conditioned_std=True, :401-405: NO = 2a outputs, mean | log_std)
-      const bool cond = T.log_std == nullptr;
-      const int a = cond ? NO >> 1 : NO, j = lane;
-      float q = 0.f, l = 0.f;
-      if (j < a) {
-        const float mu = ho[j], ls = cond ? fminf(fmaxf(ho[a + j], LOG_SIG_MIN), LOG_SIG_MAX) : T.log_std[j];
-        float act;
-        if (T.head == HEAD_GAUSS_LOGP_OF_ACT) {
-          const size_t sr = T.rows_idx ? (size_t)T.rows_idx[gr] : (size_t)gr;
-          act = T.act_in[sr * a + j];
-        } else {
-          float e;
-          if (T.eps) {
-            e = T.eps[(size_t)gr * a + j];
-          } else {
-            float z4[4];
-            philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
-            const int qd = j & 3;
-            e = qd == 0 ? z4[0] : qd == 1 ? z4[1] : qd == 2 ? z4[2] : z4[3];
-          }
-          act = e * expf(ls) + mu;
-          if (T.action) T.action[(size_t)gr * a + j] = act;
-        }
-        const float dm = mu - act;
-        q = dm * dm / expf(2.0f * ls);
-        l = ls;
-      }
-      if (T.logp) {
-        q = wave_sum(q); l = wave_sum(l);
-        if (lane == 0) T.logp[gr] = -0.5f * q - (l + HALF_LOG_2PI);
-      }
-      continue;
-    }
-    const int a = NO >> 1, j = lane;
-    float lp_quad = 0.f, lp_ls = 0.f, lp_jac = 0.f;
-    if (j < a) {
-      const float mu = ho[j];
-      const float ls = fminf(fmaxf(ho[a + j], LOG_SIG_MIN), LOG_SIG_MAX);
-      const float sd = expf(ls);
-      float e = 0.f, z, act;
-      if (T.head == HEAD_TANH_DET) {
-        z = mu; act = tanhf(mu);
-      } else if (T.head == HEAD_TANH_LOGP_OF_ACT) {
-        act = T.act_in[(size_t)gr * a + j];
-        z = 0.5f * (logf(1.0f + act + TANH_EPS) - logf(1.0f - act + TANH_EPS));  // distributions.py:85-88
-      } else {
-        if (T.eps) {
-          e = T.eps[(size_t)gr * a + j];
-        } else {
-          float z4[4];
-          philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
-          const int q = j & 3;
-          e = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
-        }
-        z = e * sd + mu;        // distributions.py:27
-        act = tanhf(z);
-      }
-      const float dm = mu - z;
-      lp_quad = dm * dm / expf(2.0f * ls);                 // distributions.py:45-47
-      lp_ls = ls;
-      lp_jac = logf(1.0f - act * act + TANH_EPS);          // distributions.py:91-93
-      if (T.action) T.action[(size_t)gr * a + j] = act;
-      if (T.eps_save) T.eps_save[(size_t)gr * a + j] = e;
-    }
-    if (T.logp) {  // wave-uniform
-      lp_quad = wave_sum(lp_quad); lp_ls = wave_sum(lp_ls); lp_jac = wave_sum(lp_jac);
-      if (lane == 0) T.logp[gr] = -0.5f * lp_quad - (lp_ls + HALF_LOG_2PI) - lp_jac;
-    }
+    fwd_head_row(T, A, hout + row * ILSX_MAX_NO, gr, lane, NO);
   }
   ILSX_STAMP(A.dbg, 7);
 }
 #endif  // ILSX_KERNEL_IMPL
+
+// ---- LARGE batches (PPO's 32768-row minibatches) run on k_mlp_fwd / k_mlp_bwd_dx too: 76 us per 32768-row forward of a plain Q net
+// (38 % of the fp32 MFMA peak; 99 us = 29 % with PPO's gather, saved activations and log-prob epilogue).  Three large-batch forward
+// kernels were built in round 4, each bit-identical to k_mlp_fwd, each measured at the SAME 72 .. 81 us, and removed again
+// (profiles/r04_ppo_fwd.txt has the diagnostic breakdowns): (a) the whole hidden -> hidden matrix resident in the registers of one
+// 8-wave workgroup per CU walking 32-row macro tiles (no weight traffic; MFMA phase 35 us, everything else in sequence behind it);
+// (b) 4-wave workgroups, three per CU, streaming the weights with two row tiles per fetched fragment (256 MB per launch across the
+// L2s; the layer-1 phase alone 51 us); (c) kernel (a) software-pipelined across the two waves of each SIMD — waves 0-3 and 4-7
+// alternating, half a period apart, between an MFMA slot (layer 1, 256 MFMAs out of registers) and a VALU slot (activation epilogue,
+// layer 0 of a later tile, heads of an earlier one), one barrier per slot: MFMA slots alone 140 us, VALU slots alone 151 us, together
+// 267 us at 131072 rows.  The reason is a property of the part (tools/ubench/mfma_valu_overlap.hip, profiles/r04_mfma_overlap.txt):
+// a wave issuing back-to-back v_mfma_f32_16x16x4_f32 and a second wave of the same SIMD doing VALU, LDS or even dependent global
+// loads take the SUM of their times, not the maximum (94 + 127 -> 214 us; two VALU waves overlap perfectly, 167 + 167 -> 166), and
+// within one wave two fmas between consecutive MFMAs cost +34 %, one ds_read_b128 +93 %.  For these fp32 MLPs the attainable ceiling
+// is therefore MFMA time PLUS the VALU / LDS issue time of everything around it, and kernel shape does not move it; what moves it is
+// instruction count (the large-batch weight-gradient kernel below is nearly pure MFMA + 4-byte LDS reads: 41 %).
+#define BIG_MIN_ROWS 4096   // (kept for reference by the tests: the batch size the large-batch shapes were taken from)
+
+
 
 // ================================================================================================
 // Fused backward-to-activations over 16-row tiles.  Produces the head gradient from a loss functor,
