@@ -1333,7 +1333,8 @@ static int group_build(ilsx_sac_group* g, ilsx_replay* const* rbs, int B) {
       int tiles = 0, nmat = 0;
       // tile shape: as for single launches (launch_bwd_dw) the smallest that keeps the launch within ~3 workgroups per CU — it only
       // matters for small groups (K = 1, 2: +4 %); at K >= 4 the launch is bound elsewhere and every shape measures the same
-      static const int gshape = []() { const char* e = getenv("ILSX_DW_TILE_GRP"); return e ? atoi(e) : 0; }();   // "NH KT" digits, 0 = by size
+      const char* gse = getenv("ILSX_DW_TILE_GRP");   // "NH KT" digits (24, 14, 12, 11), unset / 0 = by size; read per group build
+      const int gshape = gse ? atoi(gse) : 0;
       int gnh = 2, gkt = 4;
       // ILSX_DW_GRP_STRIP = 1: the strip shape (k_dw_strip: one wavefront per 16 x 64 output strip, no cross-wave reduction).  Measured
       // (K = 8 Hopper runs): 42 us per launch against 23 us for the 8-wave tiles — one wave walking 8 row-eighths and 8 optimiser

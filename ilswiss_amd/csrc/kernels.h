@@ -1566,6 +1566,12 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
   ILSX_STAMP(D.dbg, 7);
 }
 
+// (Measured and rejected, round 4: a 64 x 64 block shape for SAC-sized batches — k_dw_blk: eight waves = the eight row-eighths, every
+//  wave covering the whole block with one 16-byte load per lane and dimension feeding 16 MFMAs per 4-row step, tile j = columns
+//  n0 + 4 i + j; bit-identical to this kernel and 5x fewer load instructions per MFMA, but 19.4 us against 6.4 us for the single-run
+//  launch (48 workgroups instead of 576: the launch is made of latency and of the optimiser epilogue's parallelism, not of MFMAs)
+//  and 31.4 against 22.9 us for K = 8 grouped seeds (the 64 accumulator registers leave no room to request a trip's operands and the
+//  optimiser streams up front at four waves per SIMD: 136 bytes of scratch and four dependent load rounds per trip).)
 // ---- the weight gradients of LARGE batches (PPO's 32768-row minibatches; split mode of launch_bwd_dw).  k_mlp_bwd_dw feeds every MFMA
 // with one 4-byte global load per lane and operand (64-byte runs of four different rows per instruction): at thousands of rows per wave
 // it is bound by the vector-memory path, not by the MFMA pipe (26 % of the fp32 peak).  Here a 256-thread workgroup owns a 128 (n) x 128 (k)
