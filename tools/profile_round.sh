@@ -18,6 +18,9 @@ timeout 100 python tools/rollout_overhead.py 8192 >> $OUT/rollout_overhead.txt 2
 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='graph segments', **(d.get('split_run') or {}))))" > $OUT/split_run_1rank.jsonl 2>&1
 ILSX_SPLIT_SEGMENTS=0 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='direct launches', **(d.get('split_run') or {}))))" >> $OUT/split_run_1rank.jsonl 2>&1
 timeout 120 python tools/discbn_rate.py > $OUT/discbn_rate.txt 2>&1
+timeout 200 bash tools/ppo_ab.sh ILSX_DW_BIG=1 ILSX_DW_BIG=0 > $OUT/ppo_ab.txt 2>&1
+(timeout 60 tools/ubench/mfma_peak; timeout 60 tools/ubench/mfma_valu_overlap) > $OUT/mfma_ubench.txt 2>&1
+timeout 60 python tools/fwd_rate.py 32768 > $OUT/fwd_rate.txt 2>&1
 timeout 120 python tools/step_gantt.py 8 > $OUT/step_gantt_K8.txt 2>&1
 (timeout 100 python tools/env3d_rate.py humanoid 1024 40; timeout 100 python tools/env3d_rate.py ant 1024 40) > $OUT/env3d_rate.txt 2>&1
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC tools/ubench/env3d_phases.hip -o /tmp/libe3p.so 2> /dev/null
