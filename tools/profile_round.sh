@@ -15,7 +15,7 @@ timeout 200 python tools/rollout_overhead.py 4096 > $OUT/rollout_overhead.txt 2>
 timeout 100 python tools/rollout_overhead.py 8192 >> $OUT/rollout_overhead.txt 2>&1
 (cd tools/ubench && timeout 60 ./tilesync) > $OUT/tilesync.txt 2>&1
 # the split-run leg on a one-rank communicator (three graph segments + two all-reduces), and the same with direct launches
-ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='graph segments', **(d.get('split_run') or {}))))" > $OUT/split_run_1rank.jsonl 2>&1
+ILSX_SPLIT_SEGMENTS=1 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='graph segments', **(d.get('split_run') or {}))))" > $OUT/split_run_1rank.jsonl 2>&1
 ILSX_SPLIT_SEGMENTS=0 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='direct launches', **(d.get('split_run') or {}))))" >> $OUT/split_run_1rank.jsonl 2>&1
 timeout 120 python tools/discbn_rate.py > $OUT/discbn_rate.txt 2>&1
 timeout 200 bash tools/ppo_ab.sh ILSX_DW_BIG=1 ILSX_DW_BIG=0 > $OUT/ppo_ab.txt 2>&1
