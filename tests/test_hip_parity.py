@@ -531,8 +531,9 @@ def test_train_from_replay_graph_equals_direct_and_learns(ctx, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", [{}, {"ILSX_GRP_MT": "2", "ILSX_DW_GRP_STRIP": "1"}, {"ILSX_GRP_MT": "4"}, {"ILSX_DW_GRP_STRIP": "1"},
-                                   {"ILSX_GRP_LATE": "1"}, {"ILSX_GRP_LATE": "0"}, {"ILSX_DW_TILE_GRP": "12"}],
-                         ids=["default", "mt2_strip", "mt4", "strip", "late", "early", "dw_tile12"])
+                                   {"ILSX_GRP_LATE": "1"}, {"ILSX_GRP_LATE": "0"}, {"ILSX_DW_TILE_GRP": "12"},
+                                   {"ILSX_GRP_LATE": "1", "_hid": "128"}, {"_hid": "128"}],
+                         ids=["default", "mt2_strip", "mt4", "strip", "late", "early", "dw_tile12", "late_h128", "h128"])
 @pytest.mark.parametrize("o,a,B", [(11, 3, 256), (111, 8, 256), (17, 6, 100)])   # narrow: one-launch forward ; Ant widths: the two-phase forward (kernels.h PH 1 / 2) ; a ragged batch
 def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx, o, a, B, knobs, monkeypatch):
     """K=3 co-resident seeds stepped by ONE launch per stage (ilsx_sac_group) == each agent stepped alone with
@@ -542,8 +543,9 @@ def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx, o, a, B, knobs,
     import ilswiss_amd as ia
     from ilswiss_amd.replay import SimpleReplayBuffer
     for k_, v_ in knobs.items():
-        monkeypatch.setenv(k_, v_)
-    hid, K, n = [256, 256], 3, 7
+        if not k_.startswith("_"):
+            monkeypatch.setenv(k_, v_)
+    hid, K, n = ([128, 128] if knobs.get("_hid") == "128" else [256, 256]), 3, 7
     rng = np.random.default_rng(5)
     N = 5000
     data = [(rng.normal(0, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),
