@@ -660,6 +660,8 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     D.F.on = 0;
     if (big) {
       D.rows_per_split = ((rows + splits - 1) / splits + DWB_RC - 1) / DWB_RC * DWB_RC;
+      splits = (rows + D.rows_per_split - 1) / D.rows_per_split;   // rounding the range up to whole chunks can leave trailing ranges empty: drop them
+      D.splits = splits;
       D.ntiles = 0;
       for (int i = 0; i < D.nmat; ++i) {   // the table again in 128 x 128 blocks
         D.m[i].ktiles = (D.m[i].NB + 127) / 128;

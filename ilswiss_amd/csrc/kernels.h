@@ -1657,7 +1657,6 @@ __global__ __launch_bounds__(256, 2) void k_dw_big(const DwArgs D) {
     for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
   float pa[16], pb[16];
-  if (r_begin >= r_end) return;   // (a trailing row range past the batch: workgroup-uniform)
   if (fa) dwb_fetch<true>(J.A, J.lda, n0, J.NA, r_begin, r_end, tid, pa); else dwb_fetch<false>(J.A, J.lda, n0, J.NA, r_begin, r_end, tid, pa);
   if (fb) dwb_fetch<true>(J.Bm, J.ldb, k0, J.NB, r_begin, r_end, tid, pb); else dwb_fetch<false>(J.Bm, J.ldb, k0, J.NB, r_begin, r_end, tid, pb);
   const float* ap = As + g * DWB_LD + 64 * wn + li;

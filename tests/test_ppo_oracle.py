@@ -230,7 +230,7 @@ def test_hip_train_step_large_minibatch_row_split_dw(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hid,mb", [([256, 256], 5003), ([64, 64], 4096), ([128, 128], 6000)])
+@pytest.mark.parametrize("hid,mb", [([256, 256], 5003), ([64, 64], 4096), ([128, 128], 6000), ([64, 64], 10241)])   # 10241 = 20 x 512 + 1: whole-chunk row ranges would leave the last one empty
 def test_hip_train_step_big_minibatch_block_dw(ctx, hid, mb):
     """Minibatches >= 4096 rows take the LDS-staged 128 x 128 block weight-gradient kernel (k_dw_big): 32-row chunks, row ranges that are
     not whole chunks (5003 rows), blocks wider than the matrix (H = 64, the 16-wide first layer, the 3-wide head) == the oracle."""
