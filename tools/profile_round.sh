@@ -19,6 +19,7 @@ ILSX_SPLIT_SEGMENTS=1 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-a
 ILSX_SPLIT_SEGMENTS=0 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='direct launches', **(d.get('split_run') or {}))))" >> $OUT/split_run_1rank.jsonl 2>&1
 timeout 120 python tools/discbn_rate.py > $OUT/discbn_rate.txt 2>&1
 timeout 200 bash tools/ppo_ab.sh ILSX_DW_BIG=1 ILSX_DW_BIG=0 > $OUT/ppo_ab.txt 2>&1
+for u in mfma_peak mfma_valu_overlap; do [ -x tools/ubench/$u ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2> /dev/null; done
 (timeout 60 tools/ubench/mfma_peak; timeout 60 tools/ubench/mfma_valu_overlap) > $OUT/mfma_ubench.txt 2>&1
 timeout 60 python tools/fwd_rate.py 32768 > $OUT/fwd_rate.txt 2>&1
 timeout 120 python tools/step_gantt.py 8 > $OUT/step_gantt_K8.txt 2>&1
