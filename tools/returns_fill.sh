@@ -1,0 +1,25 @@
+#!/bin/bash
+# Re-run the seeds of the reference-schedule SAC Hopper spec that the 16-way shared call of tools/returns_run.sh cut short, two side by side on
+# one GPU:   bash tools/returns_fill.sh <cap_seconds> <seed> [<seed> ...]   ->  gpurun_out/r04_returns_fill/seed<k>.csv
+set -u
+CAP=${1:-1400}; shift
+SEEDS=$(echo "$@" | tr ' ' ',')
+N=$#
+OUT=gpurun_out/r04_returns_fill
+mkdir -p $OUT
+rm -rf logs
+sed -e "s/seed: \[0, 1, 2, 3, 4\]/seed: [$SEEDS]/" -e "s/num_workers: 5/num_workers: $N/" exp_specs/sac/sac_hopper_refschedule_hip.yaml > /tmp/ret_fill.yaml
+timeout $CAP python run_experiment.py -e /tmp/ret_fill.yaml -g 0 > $OUT/run.log 2>&1
+for f in $(find logs -name progress.csv); do
+  d=$(dirname $f)
+  s=$(echo $d | sed -n 's/.*--s-\([0-9]*\).*/\1/p')
+  cp $f $OUT/seed$s.csv
+done
+python - <<'PY'
+import csv, glob
+import numpy as np
+for f in sorted(glob.glob("gpurun_out/r04_returns_fill/seed*.csv")):
+    rows = list(csv.DictReader(open(f)))
+    r = [float(x["Test Returns Mean"]) for x in rows]
+    print(f, "epochs", len(rows), "env steps", rows[-1].get("Number of env steps total"), "last-10 %.0f" % np.mean(r[-10:]), "best %.0f" % max(r))
+PY
