@@ -1,14 +1,16 @@
 #!/bin/bash
-# Re-run the seeds of the reference-schedule SAC Hopper spec that the 16-way shared call of tools/returns_run.sh cut short, two side by side on
-# one GPU:   bash tools/returns_fill.sh <cap_seconds> <seed> [<seed> ...]   ->  gpurun_out/r04_returns_fill/seed<k>.csv
+# Re-run the seeds that the 16-way shared call of tools/returns_run.sh cut short, side by side on one GPU:
+#   [SPEC=exp_specs/sac/sac_walker_hip.yaml] bash tools/returns_fill.sh <cap_seconds> <seed> [<seed> ...]   ->  gpurun_out/r04_returns_fill/seed<k>.csv
+# (default SPEC: the reference-schedule SAC Hopper spec)
 set -u
 CAP=${1:-1400}; shift
 SEEDS=$(echo "$@" | tr ' ' ',')
 N=$#
 OUT=gpurun_out/r04_returns_fill
 mkdir -p $OUT
-rm -rf logs
-sed -e "s/seed: \[0, 1, 2, 3, 4\]/seed: [$SEEDS]/" -e "s/num_workers: 5/num_workers: $N/" exp_specs/sac/sac_hopper_refschedule_hip.yaml > /tmp/ret_fill.yaml
+rm -rf logs $OUT/seed*.csv
+SPEC=${SPEC:-exp_specs/sac/sac_hopper_refschedule_hip.yaml}
+sed -e "s/seed: \[[0-9, ]*\]/seed: [$SEEDS]/" -e "s/num_workers: [0-9]*/num_workers: $N/" $SPEC > /tmp/ret_fill.yaml
 timeout $CAP python run_experiment.py -e /tmp/ret_fill.yaml -g 0 > $OUT/run.log 2>&1
 for f in $(find logs -name progress.csv); do
   d=$(dirname $f)
