@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Large-batch forward of a 256-256 net: HIP-event time per launch for relu / tanh hidden layers and the tile / large-batch kernels.
+"""Large-batch forward of a 256-256 net: HIP-event time per launch for relu / tanh hidden layers (k_mlp_fwd; the large-batch kernels this
+tool compared it with in round 4 are gone: DESIGN 3g, profiles/r04_ppo_fwd.txt).
 
-    python tools/fwd_rate.py [rows] [obs_dim]
+    [ACTS="relu tanh"] python tools/fwd_rate.py [rows] [obs_dim]
 """
 import os
 import sys
@@ -21,10 +22,8 @@ keep, p = as_dev(ctx, x)
 flop = 2.0 * n * (16 * 256 + 256 * 256 + 256)
 for act in (os.environ.get("ACTS", "relu tanh").split()):
     net = ia.FlattenMlp([256, 256], 1, o, hidden_activation=act, ctx=ctx, seed=3)
-    for big in (os.environ.get("BIGS", "0 1").split()):
-        os.environ["ILSX_BIG_FWD"] = big
-        net.forward_dev(p, n); ctx.sync()
-        prof = prof_slots(ctx, lambda: ([net.forward_dev(p, n) for _ in range(50)], ctx.sync()))
-        for kid, (name, nl, ms) in prof.items():
-            us = 1e3 * ms / nl
-            print(f"{act} big={big} {name}: {us:.1f} us/launch, {flop / us / 1e6:.1f} TFLOP/s ({flop / us / 1e6 / 157.3:.3f} of fp32 MFMA peak)")
+    net.forward_dev(p, n); ctx.sync()
+    prof = prof_slots(ctx, lambda: ([net.forward_dev(p, n) for _ in range(50)], ctx.sync()))
+    for kid, (name, nl, ms) in prof.items():
+        us = 1e3 * ms / nl
+        print(f"{act} {name}: {us:.1f} us/launch, {flop / us / 1e6:.1f} TFLOP/s ({flop / us / 1e6 / 157.3:.3f} of fp32 MFMA peak)")
