@@ -10,7 +10,9 @@
 Each prints one JSON line.  Synthetic inputs of the configs' shapes, random-init networks.
 """
 import ctypes as C
+import glob
 import json
+import os
 import sys
 import time
 
@@ -154,6 +156,16 @@ def bench_ppo(ctx):
           2: steps * 2.0 * 32768 * (Wv + Wp)}
     roof = mfma_roofline(prof, fl, "slot FLOPs: forward = 2N(Wv+Wp) [calc_adv] + 320 minibatches x 2*32768*(Wv+Wp); backward-to-activations and "
                                    "weight gradients per minibatch likewise (Wv = oH+HH+H, Wp = oH+HH+Ha)")
+    # memory-side bytes per launch of that kernel at 32768-row minibatches, from the newest committed counter summary (tools/pmc_ppo.sh)
+    try:
+        src = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_ppopmc_summary.json")))[-1]
+        rows = json.load(open(src)).get(roof["kernel"].split("<")[0], [])
+        if rows:
+            mb = min(rows, key=lambda r: r["grid"])     # the minibatch launches (calc_adv's 1M-row forwards have the larger grid)
+            roof["traffic"] = mb["read_bytes"] + mb["written_bytes"]
+            roof["traffic_source"] = "profiles/" + os.path.basename(src)
+    except Exception:
+        pass
     g = out["gae"]
     return dict(roofline=roof,
                 roofline_gae=dict(bound="hbm", kernel="k_ppo_gae", achieved=g["achieved_GBps"], peak=PEAK_HBM_GBS, unit="GB/s",
