@@ -633,7 +633,6 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
 // within one wave two fmas between consecutive MFMAs cost +34 %, one ds_read_b128 +93 %.  For these fp32 MLPs the attainable ceiling
 // is therefore MFMA time PLUS the VALU / LDS issue time of everything around it, and kernel shape does not move it; what moves it is
 // instruction count (the large-batch weight-gradient kernel below is nearly pure MFMA + 4-byte LDS reads: 41 %).
-#define BIG_MIN_ROWS 4096   // (kept for reference by the tests: the batch size the large-batch shapes were taken from)
 
 
 

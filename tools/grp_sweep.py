@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Grouped (co-resident seeds) SAC lock-step: time and per-kernel averages for one setting of the macro-tile knobs.
 
-    ILSX_GRP_MT=4 [ILSX_LIB=ilswiss_amd/libilsx_w1.so] python tools/grp_sweep.py hopper 8 [n_steps]
+    ILSX_GRP_MT=4 [ILSX_LIB=ilswiss_amd/libilsx_<variant>.so] python tools/grp_sweep.py hopper 8 [n_steps]
     python tools/grp_sweep.py humanoid 4
 
 One JSON line: K, dims, us per lock-step, aggregate grad-steps/s, and the HIP-event average of every kernel class of the step

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The macro-tile knobs of the grouped SAC lock-step, one process per setting -> gpurun_out/grp_sweep.jsonl
-# (ILSX_GRP_MT = row tiles per workgroup; libilsx_w1.so = the same library with the macro-tile kernels compiled for one wave per SIMD)
+# (ILSX_GRP_MT = row tiles per workgroup; libilsx_w1.so = the same library with the macro-tile kernels compiled for one wave per SIMD:
+#  make -C ilswiss_amd/csrc VAR=w1 VARFLAGS=-DILSX_MT_WAVES=1 — skipped when it has not been built)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/grp_sweep.jsonl
