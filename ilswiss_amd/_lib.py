@@ -233,6 +233,7 @@ PROTOTYPES = {
     "ilsx_prof_kernel": (C.c_char_p, [vp, C.c_int]),
     "ilsx_kernel_name": (C.c_char_p, [C.c_int]),
     "ilsx_debug_set_stamp_buffer": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "ilsx_debug_dw_split": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ilsx_net_create": (C.c_int, [vp, C.POINTER(MlpCfg), C.POINTER(vp)]),
     "ilsx_net_destroy": (C.c_int, [vp]),
     "ilsx_net_num_params": (C.c_int, [vp, C.POINTER(C.c_size_t)]),

@@ -628,6 +628,23 @@ int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P) {
   return ILSX_OK;
 }
 
+// Row ranges of a large-batch weight-gradient launch: `splits` ranges of `rows_per_split` rows (a whole number of the kernel's row steps:
+// 128 for the tile kernel, DWB_RC for k_dw_big), none of them empty, together covering [0, rows).
+void dw_split_plan(int rows, bool big, int* splits, int* rows_per_split) {
+  const int unit = big ? DWB_RC : 128, cap = big ? 64 : 32;
+  int s = rows / 512;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  const int rps = ((rows + s - 1) / s + unit - 1) / unit * unit;
+  *rows_per_split = rps;
+  *splits = (rows + rps - 1) / rps;   // rounding a range up to whole steps can leave trailing ranges empty: they are dropped
+}
+extern "C" int ilsx_debug_dw_split(int rows, int big, int* splits, int* rows_per_split) {
+  if (rows < 1 || !splits || !rows_per_split) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_debug_dw_split: bad argument");
+  dw_split_plan(rows, big != 0, splits, rows_per_split);
+  return ILSX_OK;
+}
+
 int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* fuse) {
   if (table.ntiles <= 0 || rows <= 0) return ILSX_OK;
   DwArgs D = table;
@@ -644,8 +661,8 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     // blocks — the hidden -> hidden matrix — are 4 per range: 256 of them fill the chip).  ILSX_DW_BIG = 0 keeps the tile kernel (A/B, tests)
     static const int big_env = []() { const char* e = getenv("ILSX_DW_BIG"); return e ? atoi(e) : 1; }();
     const bool big = big_env && rows >= DW_BIG_MIN_ROWS;
-    int splits = rows / 512;
-    if (splits > (big ? 64 : 32)) splits = big ? 64 : 32;
+    int splits, rps;
+    dw_split_plan(rows, big, &splits, &rps);
     const size_t span = (size_t)(D.g_hi - D.g_lo);
     const size_t need = (size_t)splits * span * sizeof(float);
     if (ctx->dw_scratch_bytes < need) {
@@ -654,14 +671,11 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
       ILSX_TRY(ctx_alloc(ctx, need, (void**)&ctx->dw_scratch, true));   // zeroed: padding words are never written
       ctx->dw_scratch_bytes = need;
     }
-    D.splits = splits; D.rows_per_split = ((rows + splits - 1) / splits + 127) / 128 * 128;
+    D.splits = splits; D.rows_per_split = rps;
     D.scratch = (float*)ctx->dw_scratch; D.span = span; D.xs = 0;
     const AdamFuse keep = D.F;
     D.F.on = 0;
     if (big) {
-      D.rows_per_split = ((rows + splits - 1) / splits + DWB_RC - 1) / DWB_RC * DWB_RC;
-      splits = (rows + D.rows_per_split - 1) / D.rows_per_split;   // rounding the range up to whole chunks can leave trailing ranges empty: drop them
-      D.splits = splits;
       D.ntiles = 0;
       for (int i = 0; i < D.nmat; ++i) {   // the table again in 128 x 128 blocks
         D.m[i].ktiles = (D.m[i].NB + 127) / 128;

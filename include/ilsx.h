@@ -106,6 +106,10 @@ const char* ilsx_kernel_name(int kernel_id);
  * max_launches; slot 0 = workgroup start, 7 = end, 1..3 = phase boundaries).  NULL = off; launches_so_far (nullable)
  * receives the number of launches recorded into the PREVIOUS buffer. */
 int ilsx_debug_set_stamp_buffer(ilsx_ctx* ctx, void* dev_trace, int max_launches, int* launches_so_far);
+/* Host arithmetic only (no device needed): how a weight-gradient launch over `rows` batch rows is cut into row ranges (`big` != 0: the
+ * large-batch block kernel).  Every range is non-empty and a whole number of the kernel's row steps; together they cover [0, rows).
+ * The reference has no counterpart (torch.autograd sums the batch in one GEMM, e.g. ppo.py:145-153): test hook for the split plan. */
+int ilsx_debug_dw_split(int rows, int big, int* splits, int* rows_per_split);
 
 /* ---------------------------------------------------------------- networks
  * Replaces rlkit/torch/common/networks.py:23-115 (Mlp / FlattenMlp) and the heads of

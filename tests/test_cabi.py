@@ -75,3 +75,18 @@ def test_product_path_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
+
+
+def test_weight_gradient_row_ranges_cover_the_batch(built):
+    """Host arithmetic of the large-batch weight-gradient launches (ilsx_debug_dw_split): whatever the batch size, the row ranges are whole
+    numbers of the kernel's row steps, none is empty, and together they cover the batch exactly once.  (An empty trailing range — e.g.
+    10241 rows in 20 ranges of 544 — once left a stale slab in the sum.)"""
+    lib = built.load()
+    for big, unit, cap in ((1, 32, 64), (0, 128, 32)):
+        for rows in list(range(1024, 12000, 37)) + [10241, 16500, 32768, 32769, 65536, 100003, 1 << 20]:
+            s, rps = ctypes.c_int(), ctypes.c_int()
+            assert lib.ilsx_debug_dw_split(rows, big, ctypes.byref(s), ctypes.byref(rps)) == 0
+            s, rps = s.value, rps.value
+            assert 1 <= s <= cap and rps % unit == 0
+            assert (s - 1) * rps < rows <= s * rps, (rows, big, s, rps)     # the last range starts inside the batch, the ranges reach its end
+    assert lib.ilsx_debug_dw_split(0, 1, ctypes.byref(ctypes.c_int()), ctypes.byref(ctypes.c_int())) != 0
