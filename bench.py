@@ -44,7 +44,10 @@ def _latest_pmc_summary():
     """Newest committed counter summary (profiles/rNN_*_pmc_summary.json, written by tools/profile_round.sh); the bench line
     names the file it read so that a stale one is visible."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_summary.json")))
+    import re
+    # rNN_pmc_summary.json / rNN_x_pmc_summary.json only: the stepper / grouped / PPO counter summaries (rNN_envpmc_..., rNN_grppmc_..., rNN_ppopmc_...) have other contents
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_summary.json"))
+                   if re.fullmatch(r"r\d\d(_[a-z0-9]+)?_pmc_summary\.json", os.path.basename(f)))
     return files[-1] if files else None
 
 
