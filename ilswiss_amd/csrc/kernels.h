@@ -523,6 +523,7 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
   float* hout = bufB + 16 * LDH;  // [16][ILSX_MAX_NO]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
   const int r0 = blockIdx.x * 16, rows = A.rows, n0 = wave * 16;
+  const bool full_tile = r0 + 16 <= rows;   // workgroup-uniform
   ILSX_STAMP(A.dbg, 0);
 
   // ---- stage the (concatenated, zero-padded) input tile
@@ -568,12 +569,13 @@ __global__ __launch_bounds__(4 * H) void k_mlp_fwd(const FwdArgs A) {
     {
       const float bv = (N.base + N.off_b[l])[n0 + li];
       float* hs = T.hsave[l];
+      float* const hsp = hs ? hs + (size_t)(r0 + 4 * g) * H + n0 + li : nullptr;   // one address, rows as immediate offsets; no row guards on a whole tile
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int row = 4 * g + v;
         const float h = act_fn<ACT>(acc0[v] + acc1[v] + bv);
         cur[row * LDH + n0 + li] = h;
-        if (hs && r0 + row < rows) hs[(size_t)(r0 + row) * H + n0 + li] = h;
+        if (hs && (full_tile || r0 + row < rows)) hsp[(size_t)v * H] = h;
       }
     }
     lds_barrier();
@@ -825,6 +827,20 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
     for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
   }
 
+  // Whole tile inside the batch (workgroup-uniform): loads and stores of the saved activations / deltas go without row guards (guarded, each
+  // was a compare, an EXEC branch and three address instructions).  The saved activations the two delta phases multiply by are requested
+  // HERE, before the head gradient, instead of behind the contraction that needs them (a dependent global load per phase, exposed on a
+  // workgroup whose 16 waves all wait at the same barrier).
+  const bool full_tile = r0 + 16 <= rows;
+  constexpr int RG = NTH / H, EPT = 16 / RG;   // delta_{L-1}: thread <-> column kq, rows rq + RG i
+  const int kq = tid % H, rq = tid / H;
+  float hlv[EPT];
+  {
+    const float* const hlp = T.hsave[L - 1] + (size_t)(r0 + rq) * H + kq;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) hlv[i] = (full_tile || r0 + rq + RG * i < rows) ? hlp[(size_t)(RG * i) * H] : 0.0f;
+  }
+
   // ---- head gradient: thread <-> (row, output)
   for (int e = tid; e < 16 * NO; e += NTH) {
     const int row = e / NO, j = e - row * NO, gr = r0 + row;
@@ -837,21 +853,27 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
   }
   lds_barrier();
 
-  // ---- delta_{L-1} = (dout Wh) * act'(h_{L-1}): small contraction (NO <= 64) on the VALU
+  // ---- delta_{L-1} = (dout Wh) * act'(h_{L-1}): small contraction (NO <= 64) on the VALU.  A thread's EPT rows share its column: one
+  //      head-weight load per output feeds all of them (the same fma chain over j per element as one element at a time)
   {
     const float* Wh = N.base + N.off_Wh;
-    const float* hl = T.hsave[L - 1];
     float* ds = T.dsave[L - 1];
-    for (int e = tid; e < 16 * H; e += NTH) {
-      const int row = e / H, k = e - row * H, gr = r0 + row;
-      float s = 0.0f;
-      for (int j = 0; j < NO; ++j) s = fmaf(dout[row * ILSX_MAX_NO + j], Wh[(size_t)j * H + k], s);
-      float dv = 0.0f;
-      if (gr < rows) {
-        dv = s * act_grad_from_out<ACT>(hl[(size_t)gr * H + k]);
-        if (ds) ds[(size_t)gr * H + k] = dv;
-      }
-      bufA[row * LDH + k] = dv;
+    float sv[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) sv[i] = 0.0f;
+    for (int j = 0; j < NO; ++j) {
+      const float w = Wh[(size_t)j * H + kq];
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) sv[i] = fmaf(dout[(rq + RG * i) * ILSX_MAX_NO + j], w, sv[i]);
+    }
+    float* const dsp = ds ? ds + (size_t)(r0 + rq) * H + kq : nullptr;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int row = rq + RG * i;
+      const bool ok = full_tile || r0 + row < rows;
+      const float dv = ok ? sv[i] * act_grad_from_out<ACT>(hlv[i]) : 0.0f;
+      if (ds && ok) dsp[(size_t)(RG * i) * H] = dv;
+      bufA[row * LDH + kq] = dv;
     }
   }
   lds_barrier();
@@ -860,6 +882,14 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
   float* cur = bufA;
   for (int l = L - 1; l >= 1; --l) {
     float* nxt = (cur == bufA) ? bufB : bufA;
+    const int col = c0 + li;
+    // the activations this layer's delta is multiplied by, requested before the MFMAs that produce it
+    float hpv[4];
+    {
+      const float* const hpp = T.hsave[l - 1] + (size_t)(r0 + 4 * g) * H + col;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) hpv[v] = (full_tile || r0 + 4 * g + v < rows) ? hpp[(size_t)v * H] : 0.0f;
+    }
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     const float* ap = cur + li * LDH + 4 * g;
 #pragma unroll
@@ -873,17 +903,14 @@ __global__ __launch_bounds__(4 * H) void k_mlp_bwd_dx(const BwdArgs A) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) wreg[c] = *reinterpret_cast<const float4*>(wp + 256 * c);
     }
-    const float* hp = T.hsave[l - 1];
     float* ds = T.dsave[l - 1];
-    const int col = c0 + li;
+    float* const dsp = ds ? ds + (size_t)(r0 + 4 * g) * H + col : nullptr;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int row = 4 * g + v, gr = r0 + row;
-      float dv = 0.0f;
-      if (gr < rows) {
-        dv = (acc0[v] + acc1[v]) * act_grad_from_out<ACT>(hp[(size_t)gr * H + col]);
-        if (ds) ds[(size_t)gr * H + col] = dv;
-      }
+      const int row = 4 * g + v;
+      const bool ok = full_tile || r0 + row < rows;
+      const float dv = ok ? (acc0[v] + acc1[v]) * act_grad_from_out<ACT>(hpv[v]) : 0.0f;
+      if (ds && ok) dsp[(size_t)v * H] = dv;
       nxt[row * LDH + col] = dv;
     }
     lds_barrier();
@@ -1500,8 +1527,34 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
   for (int t = 0; t < KT; ++t) k_ok[t] = k0 + 16 * t + li < J.NB;
   // two 128-row steps per trip: both steps' operands are requested before the first MFMA (a 256-row batch is one round of
   // loads per wave instead of two dependent ones); accumulation order is unchanged
+  // A tile whose 16 NH x 16 KT block lies inside the matrix, on a trip whose 256 rows lie inside the batch, loads without guards off two
+  // base addresses (workgroup-uniform test; guarded, each of a trip's 8 + 8 KT loads was a compare, an EXEC branch and three address
+  // instructions — most of what this kernel issued beside its MFMAs); the values and the order of the MFMAs are the same
+  const bool tile_in = n0 + TN <= J.NA && k0 + TK <= J.NB;
   for (int rc = r_begin + 16 * wr; rc < rows; rc += 256) {
     float a[2][4], b[2][KT][4];
+    const int rbase = rc - 16 * wr;   // first row of the trip (wave-independent)
+    if (tile_in && rbase + 256 <= rows && rbase + 256 <= brows) {
+      const float* const pa = J.A + (size_t)(rc + 4 * g) * J.lda + nsub + li;
+      const float* const pb = J.Bm + (size_t)(rc + 4 * g) * J.ldb + k0 + li;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          a[u][s] = pa[(size_t)(128 * u + s) * J.lda];
+#pragma unroll
+          for (int t = 0; t < KT; ++t) b[u][t][s] = pb[(size_t)(128 * u + s) * J.ldb + 16 * t];
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int t = 0; t < KT; ++t) acc[t] = MFMA16(a[u][s], b[u][t][s], acc[t]);
+          bsum += a[u][s];
+        }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
