@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
     for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * NH + on) * 4 * KT + t * 4 + v) * 64 + ol];
     if (live[h]) {
       ILSX_ST(g0p[h], s);
-      if (g1p[h]) ILSX_ST(g1p[h], s);
+      if (g1p[h] && !F.on) ILSX_ST(g1p[h], s);   // with the optimiser fused nobody reads the gradient's second packing (get_grads and the flat views read the first): one of the hidden -> hidden matrices' 14 streams less
       if (F.on) adam_apply(F, ad_step, ad_bc2s, ao[h], (size_t)(g0p[h] - F.Gbase), g1p[h] ? (size_t)(g1p[h] - F.Gbase) : 0,
                            g1p[h] != nullptr, s);
     }
