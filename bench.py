@@ -57,6 +57,28 @@ PMC_NAMES = {0: ("k_mlp2_fwd_split", "k_mlp_fwd"), 1: ("k_mlp2_bwd_split", "k_ml
 MLP_SLOTS = (0, 1, 2, 13, 14)   # library profiling slots of the step's MFMA kernels (13 / 14: the merged phase kernels)
 
 
+def csrc_sha256():
+    """Hash of the library's sources, as tools/pmc_summary.py records it in a counter summary's `_meta`."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ilswiss_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ilswiss_amd", "csrc", "*.h"))
+                    + glob.glob(os.path.join(ROOT, "ilswiss_amd", "csrc", "*.inc")) + [os.path.join(ROOT, "include", "ilsx.h")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def pmc_traffic_stale():
+    """True when the committed counter summary was collected on other kernel sources than the ones this run executes (or does not say):
+    `roofline.traffic` then describes older kernels and the line says so."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            return json.load(f).get("_meta", {}).get("csrc_sha256") != csrc_sha256()
+    except (OSError, TypeError):
+        return None
+
+
 def pmc_traffic(kid):
     """HBM bytes per launch of profiling id `kid` from the committed rocprofv3 counter passes (tools/pmc_collect.sh ->
     profiles/r01_g_pmc_summary.json): FETCH_SIZE x 1024 x 2 (gfx950 correction of MI355X_MICROARCH.md §HBM) + WRITE_SIZE x
@@ -139,7 +161,7 @@ def synth_rows(rng, n):
             rng.standard_normal((n, O), dtype=np.float32))
 
 
-def cpu_baseline(budget_s=18.0):
+def cpu_baseline(budget_s=18.0, full=False):
     """SURVEY §8d's CPU legs on the GPU box's host cores, same synthetic inputs as the GPU run (C2):
       * `value`: the numpy oracle (oracle/sac_alpha.py, hand-written backward) — replay gather + train_step, all BLAS threads;
       * `torch_cpu`: the PyTorch-CPU restatement (oracle/sac_alpha_torch.py: autograd + torch.optim.Adam, the reference's own
@@ -183,16 +205,28 @@ def cpu_baseline(budget_s=18.0):
     eps = lambda: rng.standard_normal((B, A), dtype=np.float32)   # noqa: E731
     # protocol (BASELINE.md §3 asks 1k warm-up + 10k timed steps, median of 3; that is ~3 minutes of host time at ~200 steps/s, more
     # than the bounded sample this line may take): 200 warm-up steps, then 3 timed windows of budget_s / 3 seconds each, MEDIAN rate
-    for _ in range(200):
-        orc.train_step(batch(), eps(), eps())
-    runs = [timed(lambda: orc.train_step(batch(), eps(), eps()), budget_s / 3.0) for _ in range(3)]
+    def counted(fn, steps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        return steps, time.perf_counter() - t0
+    if full:   # --full-cpu-baseline: BASELINE.md §3's protocol to the letter — 1k warm-up steps, 10k timed steps, median of 3 repeats
+        for _ in range(1000):
+            orc.train_step(batch(), eps(), eps())
+        runs = [counted(lambda: orc.train_step(batch(), eps(), eps()), 10000) for _ in range(3)]
+        label = "BASELINE.md §3 protocol (--full-cpu-baseline): 1000 warm-up steps, 3 repeats of 10000 timed steps, median rate"
+    else:
+        for _ in range(200):
+            orc.train_step(batch(), eps(), eps())
+        runs = [timed(lambda: orc.train_step(batch(), eps(), eps()), budget_s / 3.0) for _ in range(3)]
+        label = (f"short protocol (default): 200 warm-up steps, 3 windows of {budget_s / 3.0:.1f} s, median rate; BASELINE.md §3's 1k + 10k x 3 "
+                 "protocol (~3 min of host time) runs under --full-cpu-baseline")
     rates = sorted(kk / dd for kk, dd in runs)
     k, dt = sum(r[0] for r in runs), sum(r[1] for r in runs)
     out = dict(value=rates[1], unit="grad-steps/s", cores=int(cores), kind="port",
                sample=f"{k} SAC-alpha grad steps (replay gather + train_step, B={B}, H={H}, Hopper dims) in {dt:.1f} s, "
                       "oracle/sac_alpha.py numpy fp32",
-               protocol=f"200 warm-up steps, 3 windows of {budget_s / 3.0:.1f} s, median rate (min {rates[0]:.1f}, max {rates[2]:.1f}); "
-                        "BASELINE.md §3's 1k + 10k x 3 protocol would take ~3 min of host time")
+               protocol=f"{label} (min {rates[0]:.1f}, max {rates[2]:.1f})", protocol_name="baseline_md_3" if full else "short")
     tc = {}
     ncpu = os.cpu_count() or 1
     fixed = batch()
@@ -426,6 +460,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-cpu-baseline", action="store_true",
+                    help="time the CPU leg on BASELINE.md §3's protocol (1k warm-up + 3 x 10k timed steps, ~3 min) instead of the short one")
     ap.add_argument("--no-seeds", action="store_true", help="skip the co-resident seeds leg")
     ap.add_argument("--no-aux", action="store_true", help="skip the config 3 / 4 / 5 legs (PPO 8192x128, GAIL Walker2d, Humanoid 4x1024)")
     ap.add_argument("--no-split-run", action="store_true", help="skip the split-run (RCCL all-reduce) leg at N > 1")
@@ -540,7 +576,7 @@ def main():
         achieved = flops_per_launch / avg_s / 1e12
         roofline = dict(bound="mfma", kernel=name, achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=achieved / PEAK_F32_MFMA_TFLOPS, traffic=pmc_traffic(dom),
-                        traffic_source=os.path.relpath(PMC_SUMMARY, ROOT) if PMC_SUMMARY else None, avg_launch_us=avg_s * 1e6,
+                        traffic_source=os.path.relpath(PMC_SUMMARY, ROOT) if PMC_SUMMARY else None, traffic_stale=pmc_traffic_stale(), avg_launch_us=avg_s * 1e6,
                         algorithmic_flop_per_launch=flops_per_launch,
                         selection="most time per step; slots within 3 % of the maximum are tied and the one with more algorithmic work is named",
                         kernels=per_kernel,
@@ -619,7 +655,7 @@ def main():
             result["extra_keys"] = ["co_resident_seeds", "ppo_8192x128", "gail_walker", "humanoid_4x1024", "roofline_replay", "cpu_baseline"]
         if not args.no_cpu_baseline and world == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline()
+                result["cpu_baseline"] = cpu_baseline(full=args.full_cpu_baseline)
             except Exception as e:   # noqa: BLE001 — the line must come out; an absent baseline is visible as such
                 result["cpu_baseline"] = dict(error=repr(e)[:300])
     if want_split:

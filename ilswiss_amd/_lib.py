@@ -114,7 +114,8 @@ class PpoCfg(C.Structure):  # ilsx_ppo_cfg
                 ("reward_scale", C.c_float), ("discount", C.c_float), ("clip_eps", C.c_float),
                 ("policy_lr", C.c_float), ("value_lr", C.c_float), ("gae_tau", C.c_float),
                 ("value_l2_reg", C.c_float), ("mini_batch_size", C.c_int32), ("update_epoch", C.c_int32),
-                ("max_samples", C.c_int32), ("use_value_clip", C.c_int32), ("conditioned_std", C.c_int32)]
+                ("max_samples", C.c_int32), ("use_value_clip", C.c_int32), ("conditioned_std", C.c_int32),
+                ("hidden_sizes", C.c_int32 * 3)]
 
 
 class DiscCfg(C.Structure):  # ilsx_disc_cfg

@@ -55,10 +55,11 @@ class MLPDisc:
         rng = np.random.default_rng(np.random.randint(0, 2**31 - 1) if seed is None else seed)
         D, H = self.input_dim, self.hid_dim
         parts = []
-        for fan_in, out in [(D, H)] + [(H, H)] * (self.num_layer_blocks - 1) + [(H, 1)]:
+        layers = [(D, H)] + [(H, H)] * (self.num_layer_blocks - 1) + [(H, 1)]
+        for li, (fan_in, out) in enumerate(layers):
             b = 1.0 / np.sqrt(fan_in)
             parts += [rng.uniform(-b, b, (out, fan_in)).ravel(), rng.uniform(-b, b, out)]
-            if self.use_bn and out == H:   # nn.BatchNorm1d: weight (gamma) = 1, bias (beta) = 0 — parameters() lists them after the Linear's
+            if self.use_bn and li < len(layers) - 1:   # every block, never the output layer (by index: hid_dim == 1 has out == H there too); nn.BatchNorm1d: weight (gamma) = 1, bias (beta) = 0 — parameters() lists them after the Linear's
                 parts += [np.ones(H), np.zeros(H)]
         self._flat = np.concatenate(parts).astype(np.float32)
         self.num_params = self._flat.size

@@ -30,7 +30,7 @@ struct DbnNet {
   int off_c() const { return off_w() + H; }
   int n_params() const { return off_c() + 1; }
 };
-// workspace for up to `rows` = 2 * max_batch rows
+// workspace for up to `rows` = 3 * max_batch rows (2B stacked expert | policy rows of the CE pass + B interpolates of the gradient penalty)
 struct DbnWs {
   float *X, *XH;                                        // [2B][D] stacked CE input, [B][D] interpolates
   float *ch[DBN_MAX_BLK], *ah[DBN_MAX_BLK], *h[DBN_MAX_BLK], *p[DBN_MAX_BLK], *s[DBN_MAX_BLK];          // forward tape of the pass in flight

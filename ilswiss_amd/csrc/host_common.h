@@ -48,8 +48,11 @@ struct ilsx_ctx {
   void* stage = nullptr;
   size_t stage_bytes = 0;
   // optional per-kernel HIP-event timing (include/ilsx.h "kernel timing")
-  void* dw_scratch = nullptr;   // row-range slabs of split weight-gradient launches (large batches)
-  size_t dw_scratch_bytes = 0;
+  // row-range slabs of split weight-gradient launches (large batches): ONE region per gradient arena (keyed by the table's g_lo).  The kernels
+  // write only the live words of a slab and rely on the padding words staying zero — true as long as no table with another layout ever
+  // writes the same region (PPO's value and policy tables used to share one: ADVICE r4)
+  struct DwScratch { const float* key; size_t span; void* p; size_t bytes; };   // key + span name the table's gradient range
+  std::vector<DwScratch> dw_scratch;
   int rt_single = 1, rt_grouped = 1;   // 16-row tiles per workgroup in the column-split kernels (ILSX_RT / ILSX_RT_GROUPED)
   int xcd_shift = 0;  // ILSX_XCD_SHIFT: confine the split-MLP / dW kernels to every 2^k-th workgroup slot (3 = one XCD)
   unsigned long long* dbg_stamps = nullptr;  // device trace buffer for ILSX_STAMP (debug): [launch][ILSX_TRACE_MAXWG][ILSX_TRACE_SLOTS]

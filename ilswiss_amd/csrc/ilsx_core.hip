@@ -665,14 +665,17 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     dw_split_plan(rows, big, &splits, &rps);
     const size_t span = (size_t)(D.g_hi - D.g_lo);
     const size_t need = (size_t)splits * span * sizeof(float);
-    if (ctx->dw_scratch_bytes < need) {
-      if (ctx->dw_scratch) ILSX_TRY(ctx_free(ctx, ctx->dw_scratch));
-      ctx->dw_scratch = nullptr; ctx->dw_scratch_bytes = 0;
-      ILSX_TRY(ctx_alloc(ctx, need, (void**)&ctx->dw_scratch, true));   // zeroed: padding words are never written
-      ctx->dw_scratch_bytes = need;
+    ilsx_ctx::DwScratch* reg = nullptr;
+    for (auto& r : ctx->dw_scratch) if (r.key == D.g_lo && r.span == span) reg = &r;
+    if (!reg) { ctx->dw_scratch.push_back({D.g_lo, span, nullptr, 0}); reg = &ctx->dw_scratch.back(); }
+    if (reg->bytes < need) {
+      if (reg->p) ILSX_TRY(ctx_free(ctx, reg->p));
+      reg->p = nullptr; reg->bytes = 0;
+      ILSX_TRY(ctx_alloc(ctx, need, &reg->p, true));   // zeroed: padding words are never written, and no other table writes this region
+      reg->bytes = need;
     }
     D.splits = splits; D.rows_per_split = rps;
-    D.scratch = (float*)ctx->dw_scratch; D.span = span; D.xs = 0;
+    D.scratch = (float*)reg->p; D.span = span; D.xs = 0;
     const AdamFuse keep = D.F;
     D.F.on = 0;
     if (big) {

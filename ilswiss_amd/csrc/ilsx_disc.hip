@@ -398,7 +398,7 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
   ilsx_disc* d = new ilsx_disc();
   d->ctx = ctx; d->cfg = *cfg; d->o = cfg->obs_dim; d->a = cfg->act_dim; d->D = d->o + d->a;
   d->nblk = cfg->num_layer_blocks ? cfg->num_layer_blocks : 2;
-  if (d->nblk < 1 || d->nblk > ILSX_MAX_HID) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "num_layer_blocks=%d: 1..%d", d->nblk, ILSX_MAX_HID);
+  if (d->nblk < 1 || d->nblk > ILSX_MAX_HID) { const int nb = d->nblk; delete d; ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "num_layer_blocks=%d: 1..%d", nb, ILSX_MAX_HID); }
   if (cfg->use_bn) {   // Linear -> BatchNorm1d -> act blocks: natural layout, any width, the phase chain of csrc/disc_bn_step.h
     if (cfg->hid_dim < 1 || cfg->hid_dim > 1024) { delete d; ILSX_FAIL(ILSX_ERR_ARG, "hid_dim=%d out of range", cfg->hid_dim); }
     if (cfg->hid_act != ILSX_ACT_RELU && cfg->hid_act != ILSX_ACT_TANH) { delete d; ILSX_FAIL(ILSX_ERR_ARG, "hid_act=%d unknown", cfg->hid_act); }
@@ -440,14 +440,14 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) { ilsx_set_err("ilsx_disc_create: %s", hipGetErrorString(e)); rc = ILSX_ERR_HIP; }
     }
-    if (rc != ILSX_OK) { delete b; delete d; return rc; }
+    if (rc != ILSX_OK) { ilsx_disc_destroy(d); return rc; }   // releases every buffer allocated so far (the destroy path takes nulls)
     W.X = d->X; W.XH = d->X + 2 * (size_t)cfg->max_batch * d->D;   // re-pointed per step (the interpolates follow the 2B stacked rows)
     *out = d;
     return ILSX_OK;
   }
   ilsx_mlp_cfg mc = {d->D, d->nblk, cfg->hid_dim, 1, 1, cfg->hid_act};
   int rc = net_layout_build(mc, &d->L);
-  if (rc != ILSX_OK) { delete d; return rc; }
+  if (rc != ILSX_OK) { delete d; return rc; }   // nothing allocated yet
   d->cs = (getenv("ILSX_NO_SPLIT") || d->nblk != 2) ? 1 : mlp2_split_factor(2, cfg->hid_dim);
   d->rng_stream = ctx->next_rng_stream++;
   const size_t n = d->L.n_int, B = (size_t)cfg->max_batch, H = (size_t)cfg->hid_dim, KP = (size_t)d->L.KP;
@@ -480,7 +480,7 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
     if (rc == ILSX_OK) rc = A(&d->dhead4, 4 * B);
   }
   if (rc == ILSX_OK) rc = disc_refresh(d);
-  if (rc != ILSX_OK) { delete d; return rc; }
+  if (rc != ILSX_OK) { ilsx_disc_destroy(d); return rc; }
   *out = d;
   return ILSX_OK;
 }

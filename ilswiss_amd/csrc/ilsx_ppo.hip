@@ -242,8 +242,9 @@ extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo*
   HIPCHK(hipSetDevice(ctx->device));
   ilsx_ppo* p = new ilsx_ppo();
   p->ctx = ctx; p->cfg = *cfg; p->o = cfg->obs_dim; p->a = cfg->act_dim;
-  ilsx_mlp_cfg mp = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, cfg->act_dim, cfg->conditioned_std ? 2 : 1, ILSX_ACT_TANH};
-  ilsx_mlp_cfg mv = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, 1, 1, ILSX_ACT_TANH};
+  ilsx_mlp_cfg mp = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, cfg->act_dim, cfg->conditioned_std ? 2 : 1, ILSX_ACT_TANH,
+                     {cfg->hidden_sizes[0], cfg->hidden_sizes[1], cfg->hidden_sizes[2]}};
+  ilsx_mlp_cfg mv = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, 1, 1, ILSX_ACT_TANH, {cfg->hidden_sizes[0], cfg->hidden_sizes[1], cfg->hidden_sizes[2]}};
   int rc = net_layout_build(mp, &p->Lp);
   if (rc == ILSX_OK) rc = net_layout_build(mv, &p->Lv);
   if (rc != ILSX_OK) { delete p; return rc; }

@@ -90,6 +90,7 @@ struct ilsx_sac {
   bool phase_last = false;           // the last window of steps ran on the phase kernels
   bool debug_break = false;          // ilsx_sac_debug_break_phase
   int phase_fallbacks = 0;           // windows rolled back and re-run (ilsx_sac_phase_state)
+  bool snap_valid = false;           // the checkpoint belongs to the window now running (set by sac_snapshot_take, cleared when the window ends)
   void* snap = nullptr;              // checkpoint of [scal | P | G | M | V] taken at the start of every window that may run on the phase kernels
   size_t snap_bytes = 0;
   float* base(int which) const {
@@ -858,10 +859,13 @@ int sac_snapshot_take(ilsx_sac* s) {
   const size_t n = sac_snap_range(s);
   if (!s->snap) { ILSX_TRY(ctx_alloc(s->ctx, n, &s->snap, false)); s->snap_bytes = n; }
   HIPCHK(hipMemcpyAsync(s->snap, s->scal, n, hipMemcpyDeviceToDevice, s->ctx->stream));
+  s->snap_valid = true;
   return ILSX_OK;
 }
 int sac_snapshot_restore(ilsx_sac* s) {
-  if (!s->snap) ILSX_FAIL(ILSX_ERR_STATE, "no checkpoint to roll back to");
+  // only the checkpoint of THIS window: one left over from an earlier call would roll the agent back to some other point in its history
+  if (!s->snap || !s->snap_valid) ILSX_FAIL(ILSX_ERR_STATE, "no checkpoint of this window to roll back to");
+  s->snap_valid = false;
   HIPCHK(hipMemcpyAsync(s->scal, s->snap, s->snap_bytes, hipMemcpyDeviceToDevice, s->ctx->stream));
   HIPCHK(hipMemsetAsync(s->phase_flags, 0, (size_t)PHASE_FLAG_WORDS * sizeof(unsigned), s->ctx->stream));
   return ILSX_OK;
@@ -872,7 +876,7 @@ bool sac_window_may_use_phase(ilsx_sac* s, int B) { return !s->phase_broken && s
 // back (sac_snapshot_restore) and runs it again; the agent stays on one launch per stage from here on.
 static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who) {
   hipStream_t st = s->ctx->stream;
-  if (deferred && !s->phase_broken && sac_phase_possible(s, B)) {
+  if (deferred && s->snap_valid) {   // == the window began with sac_window_may_use_phase (the one predicate: the checkpoint is taken under it)
     // a phase-kernel workgroup that gave up waiting left a mark: the steps of this call are not to be trusted
     int err = 0;
     unsigned masks[PHASE_MAX_TILES * 32];
@@ -890,9 +894,10 @@ static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who) {
         fprintf(stderr, "[ilsx] %s: a merged phase kernel %s; the window is rolled back and re-run, this agent stays on one launch per stage\n", who,
                 (err & 1) ? "timed out waiting for the workgroups of its tile (other kernels sharing this GPU?)" : "found the workgroups of one row tile on different XCDs");
       s->phase_fallbacks += 1;
-      return ILSX_RETRY_WINDOW;
+      return ILSX_RETRY_WINDOW;   // snap_valid stays set: sac_snapshot_restore consumes it
     }
   }
+  s->snap_valid = false;   // the window is over: its checkpoint is nobody's roll-back point any more
   return ILSX_OK;
 }
 

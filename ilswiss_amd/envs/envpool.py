@@ -9,7 +9,8 @@ import numpy as np
 
 from .vecenv import HipVectorEnv
 
-ENVPOOL_NAMES = {"Hopper": "hopper", "Walker2d": "walker2d", "HalfCheetah": "halfcheetah"}
+# every MuJoCo task the steppers model: planar (csrc/env2d_group.h) and 3-D (csrc/env3d_wave.h)
+ENVPOOL_NAMES = {"Hopper": "hopper", "Walker2d": "walker2d", "HalfCheetah": "halfcheetah", "Ant": "ant", "Humanoid": "humanoid"}
 
 
 def _model_name(envpool_name):

@@ -63,14 +63,14 @@ class PPO(Trainer):
             raise ValueError("PPO networks use tanh hidden units (ppo_exp_script.py:82-96)")
         if vf.hidden_sizes != policy.hidden_sizes:
             raise ValueError("policy and value net share net_size / num_hidden_layers (ppo_exp_script.py:79-80)")
-        if len(set(policy.hidden_sizes)) != 1 or policy.hidden_sizes[0] != policy.kernel_width:
-            raise NotImplementedError(f"PPO(hidden_sizes={policy.hidden_sizes}): the PPO trainer builds its networks from ONE width of 64 / 128 / 256 "
-                                      "(ppo_exp_script.py:79-80 passes num_hidden_layers * [net_size]); unequal widths run in every other trainer")
+        # any list of widths up to 256 (networks.py:23-60): narrower / unequal layers are structural zeros of the kernel width, as in every other
+        # trainer (include/ilsx.h ilsx_mlp_cfg::hidden_sizes); flat parameter vectors keep the logical sizes
         self.mini_batch_size, self.update_epoch, self.max_samples = int(mini_batch_size), int(update_epoch), int(max_samples)
         self.o, self.a = policy.obs_dim, policy.action_dim
-        cfg = _lib.PpoCfg(self.o, self.a, len(policy.hidden_sizes), policy.hidden_sizes[0], reward_scale, discount,
+        hs = (C.c_int32 * 3)(*(list(policy.hidden_sizes) + [0] * (3 - len(policy.hidden_sizes))))
+        cfg = _lib.PpoCfg(self.o, self.a, len(policy.hidden_sizes), policy.kernel_width, reward_scale, discount,
                           clip_eps, policy_lr, value_lr, gae_tau, value_l2_reg, self.mini_batch_size,
-                          self.update_epoch, self.max_samples, int(bool(use_value_clip)), int(bool(getattr(policy, "conditioned_std", False))))
+                          self.update_epoch, self.max_samples, int(bool(use_value_clip)), int(bool(getattr(policy, "conditioned_std", False))), hs)
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_ppo_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
         self.set_flat_params(policy.ppo_flat(), vf.get_flat_params())

@@ -457,6 +457,8 @@ typedef struct {
   int32_t use_value_clip;         /* ppo.py:24,137-143: value loss = mean(max((v-R)^2, (v_old + clamp(v-v_old, +-clip_eps) - R)^2)) */
   int32_t conditioned_std;        /* policies.py:354,368-374,401-405: log_std = clamp(last_fc_log_std(h), -20, 2), a second head of the policy net
                                    * (flat: fc.. | last_fc | last_fc_log_std) instead of the action_log_std parameter behind the mean net */
+  int32_t hidden_sizes[3];        /* networks.py:23-60 takes any list of widths: logical width of hidden layer l (1..hidden; 0 = hidden), for the
+                                   * policy and the value net alike (ppo_exp_script.py:79-96 builds both from one list) — ilsx_mlp_cfg::hidden_sizes */
 } ilsx_ppo_cfg;
 int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo** out);
 int ilsx_ppo_destroy(ilsx_ppo* ppo);

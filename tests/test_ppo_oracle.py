@@ -57,7 +57,7 @@ def _kw_of(g):
 
 
 # g7b: clip_grad_norm_(20) active; g7c: use_value_clip=True (ppo.py:137-143), clip_eps 0.1, value_lr 3e-3 (rows cross the clip window)
-@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip", "g7c_ppo_vclip", "g7d_ppo_condstd"])
+@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip", "g7c_ppo_vclip", "g7d_ppo_condstd", "g7e_ppo_unequal"])
 def test_train_step(name):
     g = load_golden(name)
     o, a = int(g["dims"][0]), int(g["dims"][1])
@@ -103,7 +103,7 @@ def test_hip_gae_and_fixed_log_probs_golden(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip", "g7c_ppo_vclip", "g7d_ppo_condstd"])
+@pytest.mark.parametrize("name", ["g7_ppo", "g7b_ppo_clip", "g7c_ppo_vclip", "g7d_ppo_condstd", "g7e_ppo_unequal"])
 def test_hip_train_step_golden(ctx, name):
     g = load_golden(name)
     tr = _hip_ppo(ctx, g)

@@ -35,8 +35,9 @@ def test_name_rule():
 def test_envpool_task_names():
     from ilswiss_amd.envs.envpool import _model_name
     assert _model_name("Hopper-v3") == "hopper" and _model_name("Walker2d-v4") == "walker2d" and _model_name("HalfCheetah-v2") == "halfcheetah"
+    assert _model_name("Ant-v3") == "ant" and _model_name("Humanoid-v4") == "humanoid"    # the 3-D steppers (csrc/env3d_wave.h)
     with pytest.raises(KeyError):
-        _model_name("Ant-v3")
+        _model_name("Swimmer-v3")
 
 
 def test_envpool_adapter_info_conversion_without_a_device():
@@ -105,6 +106,18 @@ def test_stepper_done_flag_agrees_with_terminal_func(ctx):
             np.testing.assert_array_equal(get_terminal_func(name)(obs, None, obs.astype(np.float32), ctx=ctx).ravel(), done)
             seen += int(done.sum())
         assert (seen > 0) == (name != "halfcheetah")
+        env.close()
+
+
+@pytest.mark.gpu
+def test_envpool_adapter_3d_tasks(ctx):
+    """envpool_name Ant-* / Humanoid-* reach the 3-D steppers (the reference hands any task id to envpool.make, rlkit/envs/envpool.py:4-11)."""
+    from ilswiss_amd.envs import get_envs
+    for name, o, a in (("Ant-v3", 111, 8), ("Humanoid-v4", 376, 17)):
+        env = get_envs(dict(use_envpool=True, envpool_name=name, env_type="gym", env_name="x", env_kwargs={}, env_num=4, training_env_seed=1), ctx=ctx)
+        assert env.reset().shape == (4, o)
+        ob, rew, done, info = env.step(np.zeros((4, a), np.float32))
+        assert ob.shape == (4, o) and np.all(np.isfinite(ob)) and np.all(np.isfinite(rew)) and [i["env_id"] for i in info] == [0, 1, 2, 3]
         env.close()
 
 

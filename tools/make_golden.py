@@ -27,7 +27,9 @@ H.install()
 from oracle import mlp as omlp  # noqa: E402
 from oracle import tanh_gaussian as otg  # noqa: E402
 
-GOLD = os.path.join(ROOT, "tests", "golden")
+# ILSX_GOLDEN_OUT=<dir>: write somewhere else (tests/test_make_golden.py regenerates every fixture into a temp dir and compares it with
+# tests/golden/ array for array)
+GOLD = os.environ.get("ILSX_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
 torch.set_num_threads(1)
 
@@ -136,7 +138,8 @@ def gen_mlp():
         g, dx = omlp.backward(flat, hs, [gy], o + a, Hh, 1, act=act)
         assert np.allclose(g, out[f"{tag}_grad"], rtol=1e-4, atol=1e-6)
         assert np.allclose(dx, out[f"{tag}_dx"], rtol=1e-4, atol=1e-6)
-    # G3 init statistics of the reference rule (bounds, not bit values)
+    # G3 init statistics of the reference rule (bounds, not bit values); torch's generator is seeded so that the file reproduces
+    torch.manual_seed(20240)
     net = FlattenMlp(hidden_sizes=[256, 256], input_size=14, output_size=1)
     ps = [n(p) for p in net.parameters()]
     out["init_fc0_w_absmax"] = np.abs(ps[0]).max()
@@ -727,6 +730,8 @@ def gen_ppo():
     # g7d: the policy class's DEFAULT head, conditioned_std=True (policies.py:368-374): log_std from a second head, clamped; the head's
     # bias is set so that some rows sit outside [LOG_SIG_MIN, LOG_SIG_MAX] = [-20, 2] (the clamp's gate is exercised)
     _gen_ppo_case("g7d_ppo_condstd", 710, -0.3, 2, conditioned_std=True)
+    # g7e: hidden_sizes the kernels have no width for, unequal ([48, 24]: networks.py:23-60 takes any list) — policy and value net
+    _gen_ppo_case("g7e_ppo_unequal", 711, -0.3, 2, hidden_sizes=[48, 24])
 
 
 def _gen_ppo_case(name, seed, ls_mean, epochs, **extra):
@@ -735,7 +740,7 @@ def _gen_ppo_case(name, seed, ls_mean, epochs, **extra):
     from rlkit.torch.common.policies import ReparamMultivariateGaussianPolicy
     from oracle.ppo import PPOOracle, gae_one_traj
     rng = np.random.default_rng(seed)
-    o, a, Hh = 11, 3, [64, 64]
+    o, a, Hh = 11, 3, list(extra.pop("hidden_sizes", [64, 64]))
     kw = dict(reward_scale=1.0, discount=0.99, clip_eps=0.2, policy_lr=3e-4, value_lr=3e-4, gae_tau=0.95,
               value_l2_reg=1e-3, mini_batch_size=16, update_epoch=epochs)
     kw.update(extra)
@@ -1358,8 +1363,11 @@ def gen_her():
     save("g22_her_buffer", **rec)
 
 
-GROUPS = dict(mlp_unequal=gen_mlp_unequal, disc_bn=gen_disc_bn, disc_blocks=gen_disc_blocks, disc_branches=gen_disc_branches, replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, td3=gen_td3, sac_v=gen_sac_v, ppo=gen_ppo, disc=gen_disc, head=gen_head, mlp=gen_mlp, sac_alpha=gen_sac_alpha, replay=gen_replay,
-              rms=gen_rms_actionmap, terminals=gen_terminals, eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
+# generation order: a group that reads another group's file comes after it (replay_trajs loads g10_replay.npz, written by replay)
+GROUPS = dict(mlp=gen_mlp, mlp_unequal=gen_mlp_unequal, head=gen_head, sac_alpha=gen_sac_alpha, sac_v=gen_sac_v, td3=gen_td3, ppo=gen_ppo,
+              disc=gen_disc, disc_bn=gen_disc_bn, disc_blocks=gen_disc_blocks, disc_branches=gen_disc_branches, replay=gen_replay,
+              replay_trajs=gen_replay_trajs, her=gen_her, absorbing=gen_absorbing, bc=gen_bc, rms=gen_rms_actionmap, terminals=gen_terminals,
+              eval_stats=gen_eval_stats, variants=gen_variants, logger_csv=gen_logger_csv, logdir=gen_logdir)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)

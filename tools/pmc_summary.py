@@ -31,4 +31,12 @@ for k, cs in acc.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("SQ_BUSY_CU_CYCLES"):
         d["mfma_busy_over_cu_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_BUSY_CU_CYCLES"]
     out[k] = d
+# which kernels these counters describe: a hash of the library's sources (bench.py recomputes it and flags `traffic_stale` when the tree moved on)
+import hashlib
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(repo, "ilswiss_amd", "csrc", "*.hip")) + glob.glob(os.path.join(repo, "ilswiss_amd", "csrc", "*.h"))
+                + glob.glob(os.path.join(repo, "ilswiss_amd", "csrc", "*.inc")) + [os.path.join(repo, "include", "ilsx.h")]):
+    h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+out["_meta"] = dict(csrc_sha256=h.hexdigest())
 json.dump(out, sys.stdout, indent=1, sort_keys=True)
