@@ -448,8 +448,18 @@ def split_run_leg(R, n=400):
     # every replica must have taken identical optimiser steps
     chk = float(np.abs(tr.get_params("qf1")).sum())
     lo, hi = -R.max_over_ranks([-chk])[0], R.max_over_ranks([chk])[0]
+    # the communicator's own size, read back from the library on EVERY rank (the smallest over ranks is reported: all must say G)
+    import ctypes as C
+    nr, rk = C.c_int(), C.c_int()
+    ctx.lib.ilsx_comm_info(ctx.h, C.byref(nr), C.byref(rk))
+    rccl_ranks = int(-R.max_over_ranks([-float(nr.value)])[0])
+    fb, dis, last, oa, oc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ctx.lib.ilsx_sac_phase_state(tr.h, C.byref(fb), C.byref(dis), C.byref(last), C.byref(oa), C.byref(oc))
     ctx.close()
-    return dict(ranks=G, local_batch=B // G, grad_steps_per_s=n / dt, us_per_step=1e6 * dt / n, replicas_identical=bool(lo == hi),
+    return dict(ranks=G, rccl_ranks=rccl_ranks, rccl_rank_of_rank0=int(rk.value), phase_kernels=bool(last.value) and not dis.value,
+                step_form=("A, dW{Q}, all-reduce, Adam{Q}, C, dW{pi}, all-reduce, Adam{pi} (merged phase kernels, deferred tail)" if last.value and not dis.value
+                           else "one launch per stage, all-reduce x2, k_sac_stats / k_sac_finish"),
+                local_batch=B // G, grad_steps_per_s=n / dt, us_per_step=1e6 * dt / n, replicas_identical=bool(lo == hi),
                 allreduce_bytes_per_step=4 * (tr.qf1.num_params * 2 + tr.policy.num_params + 4),
                 collective="ncclAllReduce(float32, sum) x2 per step on the ctx stream (librccl via dlopen)")
 

@@ -29,10 +29,12 @@
 
 #ifdef DBN_HOST_EMU
 #define DBN_HD inline
+#define DBN_HOST inline
 #define DBN_LANES 1
 static inline float dbn_wsum(float v) { return v; }
 #else
 #define DBN_HD __device__ __forceinline__
+#define DBN_HOST inline   // descriptors are built by the host-side step sequence (disc_bn_step.h)
 #define DBN_LANES 64
 __device__ __forceinline__ float dbn_wsum(float v) {   // all 64 lanes active
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -48,30 +50,35 @@ DBN_HD float dbn_act(float z, int act) { return act == DBN_RELU ? fmaxf(z, 0.0f)
 DBN_HD float dbn_dact(float h, int act) { return act == DBN_RELU ? (h > 0.0f ? 1.0f : 0.0f) : 1.0f - h * h; }
 DBN_HD float dbn_d2act(float h, int act) { return act == DBN_RELU ? 0.0f : -2.0f * h * (1.0f - h * h); }   // phi''(y) written with h
 
-// ---- dense phases (one output element per index)
-// out[r][j] = sum_k x[r][k] W[j][k] (+ b[j])                     idx in [0, n * H)
-DBN_HD void dbn_dense(int idx, const float* x, int ldx, const float* W, const float* b, float* out, int H, int K) {
-  const int r = idx / H, j = idx - r * H;
-  const float* xr = x + (size_t)r * ldx;
-  const float* wj = W + (size_t)j * K;
-  float s = 0.0f;
-  for (int k = 0; k < K; ++k) s = fmaf(xr[k], wj[k], s);
-  out[(size_t)r * H + j] = s + (b ? b[j] : 0.0f);
+// ---- dense phases: every matrix product of the step is ONE shape, C (+)= op(A) op(B) (+ bias), stated with element strides
+//        C[i][j] = sum_k A[i sai + k sak] * B[k sbk + j sbj]        i < M, j < N, k < Kd ascending, one fmaf chain from 0.0f
+//   forward / uabar = xbar W^T   out[r][j] = sum_k x[r][k] W[j][k] + b[j]     A = x (sai ldx, sak 1)   B = W (sbk 1, sbj K)
+//   dx                           out[r][k] = sum_j d[r][j] W[j][k]            A = d (sai H, sak 1)     B = W (sbk K, sbj 1)
+//   weight gradient              G[j][k] (+)= sum_r a[r][j] x[r][k]           A = a (sai 1, sak H)     B = x (sbk ldx, sbj 1)
+// The launcher's `gemm` phase runs it: LDS-tiled on the device (k_dbn_gemm, ilsx_disc.hip), a serial loop of dbn_gemm_elem on the host; the
+// chain of one element is the same in both (k ascending, one accumulator), so the two give the same bits.
+struct DbnGemm {
+  const float* A; int sai, sak;
+  const float* B; int sbk, sbj;
+  float* C; int ldc;
+  const float* bias;   // nullable, per column j
+  int M, N, Kd, acc;   // acc: C += (the penalty's weight gradients land on the cross-entropy pass's)
+};
+DBN_HOST DbnGemm dbn_g_dense(const float* x, int ldx, const float* W, const float* b, float* out, int n, int H, int K) {
+  return DbnGemm{x, ldx, 1, W, 1, K, out, H, b, n, H, K, 0};
 }
-// out[r][k] = sum_j d[r][j] W[j][k]                               idx in [0, n * K)
-DBN_HD void dbn_dense_t(int idx, const float* d, const float* W, float* out, int H, int K) {
-  const int r = idx / K, k = idx - r * K;
-  const float* dr = d + (size_t)r * H;
-  float s = 0.0f;
-  for (int j = 0; j < H; ++j) s = fmaf(dr[j], W[(size_t)j * K + k], s);
-  out[(size_t)r * K + k] = s;
+DBN_HOST DbnGemm dbn_g_dense_t(const float* d, const float* W, float* out, int n, int H, int K) {
+  return DbnGemm{d, H, 1, W, K, 1, out, K, nullptr, n, K, H, 0};
 }
-// G[j][k] (+)= sum_r a[r][j] x[r][k]                               idx in [0, H * K)
-DBN_HD void dbn_outer(int idx, const float* a, const float* x, int ldx, float* G, int n, int H, int K, int acc) {
-  const int j = idx / K, k = idx - j * K;
+DBN_HOST DbnGemm dbn_g_outer(const float* a, const float* x, int ldx, float* G, int n, int H, int K, int acc) {
+  return DbnGemm{a, 1, H, x, ldx, 1, G, K, nullptr, H, K, n, acc};
+}
+DBN_HD void dbn_gemm_elem(const DbnGemm& g, int i, int j) {
   float s = 0.0f;
-  for (int r = 0; r < n; ++r) s = fmaf(a[(size_t)r * H + j], x[(size_t)r * ldx + k], s);
-  G[(size_t)j * K + k] = acc ? G[(size_t)j * K + k] + s : s;
+  for (int k = 0; k < g.Kd; ++k) s = fmaf(g.A[(size_t)i * g.sai + (size_t)k * g.sak], g.B[(size_t)k * g.sbk + (size_t)j * g.sbj], s);
+  float* c = g.C + (size_t)i * g.ldc + j;
+  if (g.bias) s = s + g.bias[j];
+  *c = g.acc ? *c + s : s;
 }
 
 // ---- column phases: one wavefront per feature column j; lanes split the rows (host emulation: one lane)
@@ -107,10 +114,10 @@ DBN_HD void dbn_col_fwd(int j, int lane, float* ch, float* ah, float* h, float* 
 }
 // backward through act -> BN (the CE backward, and the FIRST backward of the penalty): cotangent uh of h -> ua of the dense output.
 // uh == null: the top block, uh[r][j] = top[r] * w[j].  Optional outputs uy / uah / tt (the penalty's tape), m2 ; optional gradient
-// accumulations dgamma += sum(uy ah), dbeta += sum(uy), db += sum(ua)  (CE backward only).
+// accumulations dgamma (+)= sum(uy ah), dbeta (+)= sum(uy), db (+)= sum(ua)  (CE backward only; `acc` = add to what is there).
 DBN_HD void dbn_col_bwd(int j, int lane, const float* uh, const float* top, const float* w, const float* p, const float* ah, const float* s,
                         const float* gamma, float* ua, float* uh_out, float* uy, float* uah, float* tt, float* m2_out, float* dgamma, float* dbeta,
-                        float* db, int n, int H) {
+                        float* db, int n, int H, int acc) {
   const float g = gamma[j], sj = s[j], wj = w ? w[j] : 0.0f;
   float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
   for (int r = lane; r < n; r += DBN_LANES) {
@@ -134,7 +141,9 @@ DBN_HD void dbn_col_bwd(int j, int lane, const float* uh, const float* top, cons
   sa = dbn_wsum(sa);
   if (lane == 0) {
     if (m2_out) m2_out[j] = m2;
-    if (dgamma) { dgamma[j] += a3; dbeta[j] += a4; db[j] += sa; }
+    if (dgamma) {   // acc == 0: the cross-entropy pass comes first and ASSIGNS (no zeroing launch in front of the step)
+      dgamma[j] = acc ? dgamma[j] + a3 : a3; dbeta[j] = acc ? dbeta[j] + a4 : a4; db[j] = acc ? db[j] + sa : sa;
+    }
   }
 }
 // reverse of the first backward for one block: uabar (adjoint of ua) -> ybar, ahbar, sbar[j], xbar_up (adjoint of this block's uh) ; dgamma
@@ -203,6 +212,14 @@ DBN_HD void dbn_col_dot(int j, int lane, const float* v, const float* m, float* 
   for (int r = lane; r < n; r += DBN_LANES) a += v[r] * m[(size_t)r * H + j];
   a = dbn_wsum(a);
   if (lane == 0) out[j] = acc ? out[j] + a : a;
+}
+
+// sum of a vector as a column phase of ONE column (lanes split the rows): out[0] = sum_r v[r]
+DBN_HD void dbn_vec_sum(int lane, const float* v, int n, float* out) {
+  float a = 0.0f;
+  for (int r = lane; r < n; r += DBN_LANES) a += v[r];
+  a = dbn_wsum(a);
+  if (lane == 0) out[0] = a;
 }
 
 // ---- row phases

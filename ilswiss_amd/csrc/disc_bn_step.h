@@ -1,8 +1,9 @@
 // disc_bn_step.h — the ORDER of the phases of disc_bn.h: one discriminator step with BatchNorm blocks (train mode) and the eval-mode forward.
 // Written once against a launcher `LN` so that the device build (ilsx_disc.hip: every phase one kernel launch on the ctx stream) and the
 // host emulation (tests/harness/disc_bn_host.cpp: every phase a serial loop) run the SAME sequence:
-//   LN::par(count, f)   f(idx) for idx in [0, count)                      (rows x features / matrix elements)
+//   LN::par(count, f)   f(idx) for idx in [0, count)                      (rows / elements)
 //   LN::col(H, f)       f(j, lane) for every feature column j             (one wavefront per column on the device)
+//   LN::gemm(g)         C (+)= op(A) op(B) (+ bias), DbnGemm of disc_bn.h    (LDS-tiled on the device; up to two independent products per launch)
 // Reference: adv_irl.py:133-216 (_do_reward_training), :268-274 (eval-mode logits), simple_disc_models.py:8-48.
 #pragma once
 #include "disc_bn.h"
@@ -51,7 +52,7 @@ void dbn_forward(LN& L, const DbnNet& N, const DbnWs& W, const float* x, int n, 
     float *ch = W.ch[l], *ah = tape ? W.ah[l] : nullptr, *h = W.h[l], *p = tape ? W.p[l] : nullptr, *s = tape ? W.s[l] : nullptr;
     float *rm = N.rmean + (size_t)l * H, *rv = N.rvar + (size_t)l * H;
     const int Kl = K;
-    L.par(n * H, DBN_LAMBDA(int idx) { dbn_dense(idx, in, Kl, Wl, bl, ch, H, Kl); });
+    L.gemm(dbn_g_dense(in, Kl, Wl, bl, ch, n, H, Kl));
     L.col(H, DBN_LAMBDA(int j, int lane) { dbn_col_fwd(j, lane, ch, ah, h, p, s, gl, bel, rm, rv, n, H, act, train, update_running); });
     in = h; K = H;
   }
@@ -74,7 +75,7 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
   const int H = N.H, D = N.D, nb = N.nblk, act = N.act, n1 = 2 * B, np = N.n_params();
   const float clampv = N.clampv;
   float* G = N.G;
-  L.par(np, DBN_LAMBDA(int i) { G[i] = 0.0f; });
+  (void)np;   // no zeroing launch: the cross-entropy pass ASSIGNS every gradient word (W, b, gamma, beta of every block, w, c), the penalty adds
   // ---- cross-entropy pass: train-mode forward of the 2B rows (running statistics move), backward
   dbn_forward(L, N, W, W.X, n1, 1, 1, true);
   {
@@ -82,9 +83,11 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
     float *lg = W.logit, *dl = W.dlogit, *ce = W.ce_row, *co = W.correct;
     L.par(n1, DBN_LAMBDA(int r) { dbn_head_ce(r, hL, w, cp[0], clampv, B, H, lg, dl, ce, co); });
     float* gw = G + N.off_w();
-    L.col(H, DBN_LAMBDA(int j, int lane) { dbn_col_dot(j, lane, dl, hL, gw, n1, H, 0); });
     float* gc = G + N.off_c();
-    L.par(1, DBN_LAMBDA(int) { float s = 0.0f; for (int r = 0; r < n1; ++r) s += dl[r]; gc[0] = s; });
+    L.col(H + 1, DBN_LAMBDA(int j, int lane) {   // column H: the output bias, dc = sum_r dlogit
+      if (j < H) dbn_col_dot(j, lane, dl, hL, gw, n1, H, 0);
+      else dbn_vec_sum(lane, dl, n1, gc);
+    });
     const float* uh = nullptr;
     for (int l = nb - 1; l >= 0; --l) {
       const float *gl = N.P + N.off_g(l), *Wl = N.P + N.off_W(l);
@@ -93,13 +96,14 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
       const int K = N.in_of(l);
       const float* uhl = uh;
       L.col(H, DBN_LAMBDA(int j, int lane) {
-        dbn_col_bwd(j, lane, uhl, dl, w, p, ah, s, gl, ua, nullptr, nullptr, nullptr, nullptr, nullptr, dg, dbe, db, n1, H);
+        dbn_col_bwd(j, lane, uhl, dl, w, p, ah, s, gl, ua, nullptr, nullptr, nullptr, nullptr, nullptr, dg, dbe, db, n1, H, 0);
       });
-      L.par(H * K, DBN_LAMBDA(int idx) { dbn_outer(idx, ua, xin, K, dW, n1, H, K, 1); });
-      if (l > 0) {
+      if (l > 0) {   // the weight gradient and the cotangent for the block below read the same ua: one launch
         float* nxt = W.t1;
-        L.par(n1 * H, DBN_LAMBDA(int idx) { dbn_dense_t(idx, ua, Wl, nxt, H, K); });   // K == H here
+        L.gemm(dbn_g_outer(ua, xin, K, dW, n1, H, K, 0), dbn_g_dense_t(ua, Wl, nxt, n1, H, K));   // K == H here
         uh = nxt;   // the block below reads it in its column phase (writing ua into t0) before its own dx lands in t1 again
+      } else {
+        L.gemm(dbn_g_outer(ua, xin, K, dW, n1, H, K, 0));
       }
     }
   }
@@ -121,10 +125,10 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
       const int K = N.in_of(l);
       const float* uhl = uh;
       L.col(H, DBN_LAMBDA(int j, int lane) {
-        dbn_col_bwd(j, lane, uhl, gt, w, p, ah, s, gl, ua, uho, uy, uah, tt, m2, nullptr, nullptr, nullptr, B, H);
+        dbn_col_bwd(j, lane, uhl, gt, w, p, ah, s, gl, ua, uho, uy, uah, tt, m2, nullptr, nullptr, nullptr, B, H, 1);
       });
       float* ux = l > 0 ? W.t1 : W.t0;   // l == 0: dD/dx [B][D] in t0
-      L.par(B * K, DBN_LAMBDA(int idx) { dbn_dense_t(idx, ua, Wl, ux, H, K); });
+      L.gemm(dbn_g_dense_t(ua, Wl, ux, B, H, K));
       uh = ux;                            // read by the block below's column phase (which stores its own copy in W.uh[l-1]) before t1 is rewritten
     }
   }
@@ -142,9 +146,9 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
       const int K = N.in_of(l);
       float *dW = G + N.off_W(l), *dg = G + N.off_g(l);
       const float *ua = W.ua[l], *xbl = xb;
-      L.par(H * K, DBN_LAMBDA(int idx) { dbn_outer(idx, ua, xbl, K, dW, B, H, K, 1); });          // ux = ua W
       float* uabar = W.t0;
-      L.par(B * H, DBN_LAMBDA(int idx) { dbn_dense(idx, xbl, K, Wl, nullptr, uabar, H, K); });   // uabar = xbar W^T
+      L.gemm(dbn_g_outer(ua, xbl, K, dW, B, H, K, 1),               // ux = ua W: its weight gradient
+             dbn_g_dense(xbl, K, Wl, nullptr, uabar, B, H, K));      // uabar = xbar W^T   (both read xbar only: one launch)
       const float *tt = W.tt[l], *s = W.s[l], *ah = W.ah[l], *uah = W.uah[l], *uy = W.uy[l], *uhl = W.uh[l], *p = W.p[l], *h = W.h[l], *m2 = W.m2[l];
       float *yb = W.ybar[l], *ahb = W.ahbar[l], *sb = W.sbar[l], *up = W.t1;   // xbar (t1) was consumed by the two phases above
       L.col(H, DBN_LAMBDA(int j, int lane) { dbn_col_rev(j, lane, uabar, tt, s, ah, uah, uy, uhl, p, h, m2, gl, yb, ahb, sb, up, dg, B, H, act); });
@@ -165,11 +169,12 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
       const int K = N.in_of(l);
       const float* hb = hbar;
       L.col(H, DBN_LAMBDA(int j, int lane) { dbn_col_down(j, lane, yb, hb, p, ah, ahb, ch, s, sb, gl, ab, dg, dbe, db, B, H); });
-      L.par(H * K, DBN_LAMBDA(int idx) { dbn_outer(idx, ab, xin, K, dW, B, H, K, 1); });
       if (l > 0) {
         float* nxt = W.t1;
-        L.par(B * H, DBN_LAMBDA(int idx) { dbn_dense_t(idx, ab, Wl, nxt, H, K); });
+        L.gemm(dbn_g_outer(ab, xin, K, dW, B, H, K, 1), dbn_g_dense_t(ab, Wl, nxt, B, H, K));
         hbar = nxt;
+      } else {
+        L.gemm(dbn_g_outer(ab, xin, K, dW, B, H, K, 1));
       }
     }
   }
@@ -179,11 +184,12 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
 template <class LN>
 void dbn_stats(LN& L, const DbnWs& W, int B, int use_gp, float* stats) {
   const float *ce = W.ce_row, *co = W.correct, *gp = W.gp_row;
-  L.par(1, DBN_LAMBDA(int) {
+  L.col(1, DBN_LAMBDA(int, int lane) {   // one wavefront: lanes split the rows
     float a = 0.0f, b = 0.0f, c = 0.0f;
-    for (int r = 0; r < 2 * B; ++r) { a += ce[r]; b += co[r]; }
-    if (use_gp) for (int r = 0; r < B; ++r) c += gp[r];
-    stats[0] = a / (float)(2 * B); stats[1] = b / (float)(2 * B); stats[2] = use_gp ? c / (float)B : 0.0f;
+    for (int r = lane; r < 2 * B; r += DBN_LANES) { a += ce[r]; b += co[r]; }
+    if (use_gp) for (int r = lane; r < B; r += DBN_LANES) c += gp[r];
+    a = dbn_wsum(a); b = dbn_wsum(b); c = dbn_wsum(c);
+    if (lane == 0) { stats[0] = a / (float)(2 * B); stats[1] = b / (float)(2 * B); stats[2] = use_gp ? c / (float)B : 0.0f; }
   });
 }
 // Adam(lr, betas = (b1, 0.999)) over every parameter, step count t (1-based) — adv_irl.py:75-77

@@ -37,6 +37,7 @@ struct StatsArgs {
   float gamma, reward_scale, w_mu, w_std, target_entropy, inv_B;
   DevScalars* scal;
   float* alpha_grad_slot;  // G arena slot: -(sum(logp + target_entropy)) * inv_B
+  int slot_given;          // split run on the phase kernels: the slot already holds the all-reduced gradient (PhaseCArgs::aslot) — leave it
 };
 
 // A grouped step (ilsx_sac_group) is assembled by running every agent's ordinary step in "collect" mode: the launch sites
@@ -82,6 +83,7 @@ struct ilsx_sac {
   bool defer_tail = false;
   TailLite* tail_dev = nullptr;
   int tail_B = 0;
+  bool tail_split = false;           // the uploaded TailLite record was built for a split run (slot_given)
   // merged phase kernels (kernels.h k_sac_phase_a / _c): F1 F2 B1 and F3 B2 B3 as one launch each inside train_from_replay
   unsigned* phase_flags = nullptr;   // PHASE_NFLAGS arrival counters, one 128-byte line each (zeroed by the dW launches)
   int* phase_err = nullptr;          // set by a workgroup whose wait timed out
@@ -119,8 +121,10 @@ __device__ __forceinline__ void sac_alpha_grad_dev(const StatsArgs& S) {
   if (threadIdx.x == 0) {
     S.scal->alpha_used = S.scal->alpha;
     S.scal->log_alpha_used = S.scal->log_alpha;
-    S.alpha_grad_slot[0] = -lpe * S.inv_B;
-    S.alpha_grad_slot[1] = 0.f; S.alpha_grad_slot[2] = 0.f; S.alpha_grad_slot[3] = 0.f;
+    if (!S.slot_given) {
+      S.alpha_grad_slot[0] = -lpe * S.inv_B;
+      S.alpha_grad_slot[1] = 0.f; S.alpha_grad_slot[2] = 0.f; S.alpha_grad_slot[3] = 0.f;
+    }
   }
 }
 
@@ -194,8 +198,10 @@ __device__ __forceinline__ void sac_stats_dev(const StatsArgs& S) {
     }
     sc->alpha_used = alpha;
     sc->log_alpha_used = sc->log_alpha;
-    S.alpha_grad_slot[0] = -lpe * S.inv_B;  // d(alpha_loss)/d(log_alpha), summed over ranks by the all-reduce
-    S.alpha_grad_slot[1] = 0.f; S.alpha_grad_slot[2] = 0.f; S.alpha_grad_slot[3] = 0.f;
+    if (!S.slot_given) {
+      S.alpha_grad_slot[0] = -lpe * S.inv_B;  // d(alpha_loss)/d(log_alpha), summed over ranks by the all-reduce
+      S.alpha_grad_slot[1] = 0.f; S.alpha_grad_slot[2] = 0.f; S.alpha_grad_slot[3] = 0.f;
+    }
   }
 }
 
@@ -577,6 +583,9 @@ static int sac_actor_backward(ilsx_sac* s) {
     if (s->phase_now) {
       PC.b3 = A; PC.flags = s->phase_flags; PC.err = s->phase_err;
       if (s->fuse_now) { PC.polyak_T = s->base(W_TQ1); PC.polyak_P = s->base(W_Q1); PC.polyak_n = (int)(2 * s->nq); PC.polyak_tau = s->cfg.soft_target_tau; }
+      else {   // split run: this rank's alpha-gradient partial lands in the arena's slot before the actor all-reduce (the tail is deferred)
+        PC.aslot = s->G + 2 * s->nq + s->np; PC.aslot_logp = w.logp; PC.aslot_B = B; PC.aslot_te = s->target_entropy; PC.aslot_invB = sac_inv_B(s);
+      }
       ILSX_TRY(launch_phase_c(s->ctx, PC, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
     } else {
       ILSX_TRY(sac_bwd(s, A, H, act, cs));
@@ -593,6 +602,7 @@ static int sac_actor_backward(ilsx_sac* s) {
     ILSX_TRY(sac_dw(s, s->jobs_p, B, &F));
   }
   if (s->fuse_now) return ILSX_OK;  // stats run inside k_sac_tail (sac_actor_update)
+  if (s->phase_now && s->defer_tail) return ILSX_OK;   // split run on the phase kernels: the slot came from phase C, statistics from the flushed tail
   StatsArgs S = sac_stats_args(s);
   ProfScope ps(s->ctx, ILSX_K_SAC_STATS);
   ILSX_LAUNCH(ps, k_sac_stats, dim3(1), dim3(256), 0, s->ctx->stream, S);
@@ -612,6 +622,7 @@ static StatsArgs sac_stats_args(ilsx_sac* s) {
   S.w_mu = s->cfg.policy_mean_reg_weight; S.w_std = s->cfg.policy_std_reg_weight;
   S.target_entropy = s->target_entropy; S.inv_B = sac_inv_B(s);
   S.scal = s->scal; S.alpha_grad_slot = s->G + 2 * s->nq + s->np;
+  S.slot_given = 0;
   return S;
 }
 
@@ -638,6 +649,7 @@ static int sac_actor_update(ilsx_sac* s) {
     return ILSX_OK;
   }
   ILSX_TRY(launch_adam(s->ctx, A));
+  if (s->phase_now && s->defer_tail) return ILSX_OK;   // split run on the phase kernels: the next step's phase A (or sac_flush_tail) finishes
   ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
   ILSX_LAUNCH(ps, k_sac_finish, dim3(1), dim3(1), 0, s->ctx->stream, s->scal, (const float*)(s->G + 2 * s->nq + s->np),
                      s->cfg.train_alpha, s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr);
@@ -655,6 +667,7 @@ static int sac_refresh_adam(ilsx_sac* s) {
 // Deferred tail: see TailLite in kernels.h.  Enabled for the duration of one train_from_replay call when the whole step runs on
 // the fused column-split path (no gradient all-reduce between the phases, no XCD confinement); the last step's tail is flushed
 // by the ordinary tail kernel, so no tail is ever pending when the call returns.
+static bool sac_is_split(const ilsx_sac* s);
 static TailLite sac_tail_lite(ilsx_sac* s, int B) {
   TailLite t;
   memset(&t, 0, sizeof t);
@@ -665,19 +678,29 @@ static TailLite sac_tail_lite(ilsx_sac* s, int B) {
   t.alpha_grad_slot = s->G + 2 * s->nq + s->np; t.scal = s->scal;
   t.train_alpha = s->cfg.train_alpha; t.lr = s->cfg.alpha_lr; t.b1 = s->cfg.beta_1; t.b2 = 0.999f; t.eps = 1e-8f;
   t.qf_lr = s->cfg.qf_lr; t.policy_lr = s->cfg.policy_lr;
+  t.slot_given = sac_is_split(s) ? 1 : 0;
   return t;
 }
-static bool sac_is_split(const ilsx_sac* s);
+// A split run (gradient all-reduce between backward and update) defers its tail only when the step runs on the merged phase kernels
+//   A , dW{Q} , all-reduce , Adam{Q} + Polyak , C (+ this rank's alpha-gradient partial) , dW{pi} , all-reduce , Adam{pi}
+// (6 launches + 2 collectives; the tail rides in the next step's A and applies the all-reduced alpha gradient, TailLite::slot_given).
+// Without the phase kernels (ILSX_NO_PHASE, ILSX_SPLIT_NO_PHASE, graph segments, a grid that does not fit) it keeps the un-deferred
+// one-launch-per-stage sequence with k_sac_stats / k_sac_finish.
+static bool sac_split_on_phase(ilsx_sac* s, int B) {
+  static const bool segments = []() { const char* e = getenv("ILSX_SPLIT_SEGMENTS"); return e && atoi(e) != 0; }();
+  return getenv("ILSX_SPLIT_NO_PHASE") == nullptr && !segments && sac_window_may_use_phase(s, B);
+}
 static int sac_defer_begin(ilsx_sac* s, int B) {
   static const bool off = getenv("ILSX_NO_DEFER_TAIL") != nullptr || getenv("ILSX_NO_FUSE") != nullptr;
   s->defer_tail = false;
-  if (off || s->cs <= 1 || sac_is_split(s) || s->col) return ILSX_OK;
+  const bool split = sac_is_split(s);
+  if (off || s->cs <= 1 || s->col || (split && !sac_split_on_phase(s, B))) return ILSX_OK;
   if (!s->tail_dev) ILSX_TRY(ctx_alloc(s->ctx, sizeof(TailLite), (void**)&s->tail_dev));
-  if (s->tail_B != B) {
+  if (s->tail_B != B || s->tail_split != split) {
     const TailLite t = sac_tail_lite(s, B);
     HIPCHK(hipMemcpyAsync(s->tail_dev, &t, sizeof t, hipMemcpyHostToDevice, s->ctx->stream));
     HIPCHK(hipStreamSynchronize(s->ctx->stream));   // `t` lives on this stack frame
-    s->tail_B = B;
+    s->tail_B = B; s->tail_split = split;
   }
   s->defer_tail = true;
   return ILSX_OK;
@@ -685,7 +708,9 @@ static int sac_defer_begin(ilsx_sac* s, int B) {
 static int sac_flush_tail(ilsx_sac* s, bool deferred) {   // the pending tail of the call's last step (+ its statistics if requested)
   if (!deferred) return ILSX_OK;
   ProfScope ps(s->ctx, ILSX_K_SAC_FINISH);
-  ILSX_LAUNCH(ps, k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, sac_stats_args(s), s->cfg.train_alpha,
+  StatsArgs S = sac_stats_args(s);
+  S.slot_given = sac_is_split(s) ? 1 : 0;   // split run: the last step's alpha gradient was all-reduced into the slot (sac_actor_backward)
+  ILSX_LAUNCH(ps, k_sac_tail, dim3(1), dim3(256), 0, s->ctx->stream, S, s->cfg.train_alpha,
               s->cfg.alpha_lr, s->cfg.beta_1, 0.999f, 1e-8f, s->cfg.qf_lr, s->cfg.policy_lr, /*deferred=*/1);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
@@ -843,12 +868,12 @@ extern "C" int ilsx_sac_train_step(ilsx_sac* s, const float* obs, const float* a
 // gradient all-reduce between the phases, no per-workgroup stamps, and every workgroup of a phase launch resident at once.
 static bool sac_phase_ok(ilsx_sac* s, int B) {
   const bool off = getenv("ILSX_NO_PHASE") != nullptr;
-  return !off && !s->phase_broken && s->cs > 1 && !s->h0scr && !s->col && s->defer_tail && !sac_is_split(s) &&
-         s->ctx->xcd_shift == 0 && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
+  return !off && !s->phase_broken && s->cs > 1 && !s->h0scr && !s->col && s->defer_tail &&
+         s->ctx->xcd_shift == 0 && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);   // (a split run defers its tail only for the phase kernels: sac_defer_begin)
 }
 static bool sac_phase_possible(ilsx_sac* s, int B) {   // as sac_phase_ok, for the state a train_from_replay call ran in (defer_tail already cleared)
   const bool off = getenv("ILSX_NO_PHASE") != nullptr;   // read per call: tests switch between the two paths in one process
-  return !off && s->cs > 1 && !s->h0scr && !sac_is_split(s) && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
+  return !off && s->cs > 1 && !s->h0scr && phase_fits(s->ctx, B, s->Lq.cfg.hidden, s->cs, 4);
 }
 // Checkpoint / roll-back of everything a gradient step mutates — device scalars (log alpha and its moments, step / Philox counters,
 // Adam scalars), parameters + targets, gradients, Adam moments: one contiguous range of the agent's slab (ilsx_sac_create adds them

@@ -164,17 +164,30 @@ __device__ __forceinline__ void sac_finish_dev(DevScalars* sc, const float* alph
 struct TailLite {
   const float* logp; int B; float target_entropy, inv_B; float* alpha_grad_slot; DevScalars* scal;
   int train_alpha; float lr, b1, b2, eps, qf_lr, policy_lr;
+  int slot_given;   // split run: the alpha-gradient slot was written by the policy phase launch (PhaseCArgs::aslot) and summed over the ranks
+                    // by the actor all-reduce — the tail applies it, it does not recompute this rank's partial
 };
+// d(alpha_loss)/d(log_alpha) of the rows this rank holds, into the gradient arena's alpha slot (one 256-thread workgroup)
+__device__ __forceinline__ void alpha_slot_run(const float* logp, int B, float target_entropy, float inv_B, float* slot, float* sh4) {
+  float lpe = 0.f;
+  for (int r = threadIdx.x; r < B; r += 256) lpe += logp[r] + target_entropy;
+  lpe = block256_sum(lpe, sh4);
+  if (threadIdx.x == 0) { slot[0] = -lpe * inv_B; slot[1] = 0.f; slot[2] = 0.f; slot[3] = 0.f; }
+}
 __device__ __forceinline__ void tail_lite_run(const TailLite& T, float* sh4) {   // one 256-thread workgroup
   if (T.scal->gather_step != T.scal->step + 1) return;   // nothing pending (first step of a call); workgroup-uniform
   float lpe = 0.f;
-  for (int r = threadIdx.x; r < T.B; r += 256) lpe += T.logp[r] + T.target_entropy;
-  lpe = block256_sum(lpe, sh4);
+  if (!T.slot_given) {
+    for (int r = threadIdx.x; r < T.B; r += 256) lpe += T.logp[r] + T.target_entropy;
+    lpe = block256_sum(lpe, sh4);
+  }
   if (threadIdx.x == 0) {
     T.scal->alpha_used = T.scal->alpha;
     T.scal->log_alpha_used = T.scal->log_alpha;
-    T.alpha_grad_slot[0] = -lpe * T.inv_B;
-    T.alpha_grad_slot[1] = 0.f; T.alpha_grad_slot[2] = 0.f; T.alpha_grad_slot[3] = 0.f;
+    if (!T.slot_given) {
+      T.alpha_grad_slot[0] = -lpe * T.inv_B;
+      T.alpha_grad_slot[1] = 0.f; T.alpha_grad_slot[2] = 0.f; T.alpha_grad_slot[3] = 0.f;
+    }
     sac_finish_dev(T.scal, T.alpha_grad_slot, T.train_alpha, T.lr, T.b1, T.b2, T.eps, T.qf_lr, T.policy_lr, 1);
   }
 }
@@ -1115,6 +1128,9 @@ struct PhaseCArgs {
   // Polyak update of the target critics (pytorch_util.py:10-12), run by the otherwise idle bookkeeping row while the policy phase
   // computes: polyak_n > 0 = the critics' dW launch of this step left it out (AdamFuse::T null); same expression, same operands
   float* polyak_T; const float* polyak_P; int polyak_n; float polyak_tau;
+  // split run: the same row writes this rank's alpha-gradient partial into the gradient arena's slot (log pi of this step is final since
+  // phase A), so that the actor all-reduce that follows carries it and the deferred tail finds the sum (TailLite::slot_given)
+  float* aslot; const float* aslot_logp; int aslot_B; float aslot_te, aslot_invB;
 };
 
 static_assert(sizeof(PhaseAArgs) <= 4096 && sizeof(PhaseCArgs) <= 4096, "phase-kernel descriptors travel in the kernel-argument segment (4 KB)");
@@ -1310,6 +1326,7 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) 
   const int bx = blockIdx.x, cs = blockIdx.z, y = blockIdx.y;
   if (y == 3) {
     if (bx == 0 && cs == 0 && threadIdx.x == 0) P.f3.tail[0].scal->gather_step += 1;
+    if (P.aslot && bx == 1 && cs == 0) alpha_slot_run(P.aslot_logp, P.aslot_B, P.aslot_te, P.aslot_invB, P.aslot, smem);   // workgroup-uniform
     const float tau = P.polyak_tau;
     for (int i = ((int)(cs * gridDim.x + bx) * (int)blockDim.x + (int)threadIdx.x) * 4; i < P.polyak_n; i += (int)(gridDim.x * gridDim.z * blockDim.x) * 4) {
       const float4 p = *reinterpret_cast<const float4*>(P.polyak_P + i);

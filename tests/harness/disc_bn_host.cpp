@@ -10,6 +10,8 @@
 struct HostLaunch {
   template <class F> void par(int n, F f) { for (int i = 0; i < n; ++i) f(i); }
   template <class F> void col(int H, F f) { for (int j = 0; j < H; ++j) f(j, 0); }
+  void gemm(const DbnGemm& g) { for (int i = 0; i < g.M; ++i) for (int j = 0; j < g.N; ++j) dbn_gemm_elem(g, i, j); }
+  void gemm(const DbnGemm& g1, const DbnGemm& g2) { gemm(g1); gemm(g2); }
 };
 
 struct HostDisc {

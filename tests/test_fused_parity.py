@@ -234,7 +234,9 @@ tr.train_from_replay(rb, 1, B)
 h = hashlib.sha256()
 for name in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
     h.update(np.ascontiguousarray(tr.get_params(name)).tobytes())
+import sys
 print(json.dumps(dict(params=h.hexdigest(), log_alpha=repr(tr.log_alpha), qf1=repr(float(tr.eval_statistics["QF1 Loss"])))))
+print("PHASE", int(tr.phase_state()["last_window_on_phase"]), file=sys.stderr)
 ctx.close()
 '''
 
@@ -251,13 +253,20 @@ def test_split_run_phases_with_rccl_on_the_ctx_stream_equal_the_fused_step():
     outs = {}
     # split: the default form — every launch direct; split_segments: three captured segments with the two all-reduces enqueued between them;
     # split_graph: the whole step, collective included, in one capture
-    for tag, extra in (("fused", {}), ("split", {"ILSX_SPLIT_FORCE": "1"}), ("split_segments", {"ILSX_SPLIT_FORCE": "1", "ILSX_SPLIT_SEGMENTS": "1"}),
+    # (round 5: the default split step runs on the merged phase kernels — A, dW, all-reduce, Adam, C, dW, all-reduce, Adam, the tail deferred
+    #  and fed the all-reduced alpha gradient; split_nophase keeps one launch per stage with k_sac_stats / k_sac_finish)
+    on_phase = {}
+    for tag, extra in (("fused", {}), ("split", {"ILSX_SPLIT_FORCE": "1"}), ("split_nophase", {"ILSX_SPLIT_FORCE": "1", "ILSX_SPLIT_NO_PHASE": "1"}),
+                       ("split_segments", {"ILSX_SPLIT_FORCE": "1", "ILSX_SPLIT_SEGMENTS": "1"}),
                        ("split_graph", {"ILSX_SPLIT_FORCE": "1", "ILSX_SPLIT_GRAPH": "1"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", _SPLIT_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (tag, r.stderr[-3000:])
         outs[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])   # RCCL prints its own banner lines
+        on_phase[tag] = [l for l in r.stderr.splitlines() if l.startswith("PHASE")][-1] == "PHASE 1"
+    assert on_phase["fused"] and on_phase["split"] and on_phase["split_graph"] and not on_phase["split_nophase"] and not on_phase["split_segments"], on_phase
     assert outs["split"] == outs["fused"], outs
+    assert outs["split_nophase"] == outs["fused"], outs
     assert outs["split_segments"] == outs["fused"], outs
     assert outs["split_graph"] == outs["fused"], outs
 
