@@ -29,11 +29,13 @@
 
 #ifdef DBN_HOST_EMU
 #define DBN_HD inline
+#define DBN_HDH inline
 #define DBN_HOST inline
 #define DBN_LANES 1
 static inline float dbn_wsum(float v) { return v; }
 #else
 #define DBN_HD __device__ __forceinline__
+#define DBN_HDH __host__ __device__ __forceinline__
 #define DBN_HOST inline   // descriptors are built by the host-side step sequence (disc_bn_step.h)
 #define DBN_LANES 64
 __device__ __forceinline__ float dbn_wsum(float v) {   // all 64 lanes active
@@ -73,9 +75,19 @@ DBN_HOST DbnGemm dbn_g_dense_t(const float* d, const float* W, float* out, int n
 DBN_HOST DbnGemm dbn_g_outer(const float* a, const float* x, int ldx, float* G, int n, int H, int K, int acc) {
   return DbnGemm{a, 1, H, x, ldx, 1, G, K, nullptr, H, K, n, acc};
 }
+// the contraction runs in FOUR consecutive ranges of dbn_kq(Kd) terms (one per wave of the device tile), each an fmaf chain from 0.0f in
+// ascending k; the four partial sums are added in range order: c = ((p0 + p1) + p2) + p3 (+ bias).  dbn_gemm_elem states that chain for the
+// host emulation, k_dbn_gemm (ilsx_disc.hip) runs it on a 16 x 16 tile: the two give the same bits.
+DBN_HDH int dbn_kq(int Kd) { return (((Kd + 3) / 4) + 31) & ~31; }
 DBN_HD void dbn_gemm_elem(const DbnGemm& g, int i, int j) {
+  const int kq = dbn_kq(g.Kd);
   float s = 0.0f;
-  for (int k = 0; k < g.Kd; ++k) s = fmaf(g.A[(size_t)i * g.sai + (size_t)k * g.sak], g.B[(size_t)k * g.sbk + (size_t)j * g.sbj], s);
+  for (int q = 0; q < 4; ++q) {
+    float p = 0.0f;
+    const int k1 = (q + 1) * kq < g.Kd ? (q + 1) * kq : g.Kd;
+    for (int k = q * kq; k < k1; ++k) p = fmaf(g.A[(size_t)i * g.sai + (size_t)k * g.sak], g.B[(size_t)k * g.sbk + (size_t)j * g.sbj], p);
+    s = q == 0 ? p : s + p;
+  }
   float* c = g.C + (size_t)i * g.ldc + j;
   if (g.bias) s = s + g.bias[j];
   *c = g.acc ? *c + s : s;
@@ -222,13 +234,18 @@ DBN_HD void dbn_vec_sum(int lane, const float* v, int n, float* out) {
   if (lane == 0) out[0] = a;
 }
 
-// ---- row phases
+// ---- row phases: one wavefront per ROW r, lanes split the features (coalesced; host emulation: one lane); dot = sum_j h[r][j] w[j]
+DBN_HD float dbn_row_dot(int lane, const float* hr, const float* w, int H) {
+  float a = 0.0f;
+  for (int j = lane; j < H; j += DBN_LANES) a = fmaf(hr[j], w[j], a);
+  return dbn_wsum(a);
+}
 // head of the cross-entropy pass (2B rows: the first B are expert rows, target 1): raw = h w + c ; clamp ; BCE-with-logits row term, accuracy,
-// dlogit = (sigmoid(logit) - t) / (2B) * gate          idx in [0, 2B)
-DBN_HD void dbn_head_ce(int r, const float* h, const float* w, float c, float clampv, int B, int H, float* logit_out, float* dlogit,
+// dlogit = (sigmoid(logit) - t) / (2B) * gate          r in [0, 2B)
+DBN_HD void dbn_head_ce(int r, int lane, const float* h, const float* w, float c, float clampv, int B, int H, float* logit_out, float* dlogit,
                         float* ce_row, float* correct) {
-  float raw = c;
-  for (int j = 0; j < H; ++j) raw = fmaf(h[(size_t)r * H + j], w[j], raw);
+  const float raw = dbn_row_dot(lane, h + (size_t)r * H, w, H) + c;
+  if (lane != 0) return;
   const float x = fminf(fmaxf(raw, -clampv), clampv), t = r < B ? 1.0f : 0.0f;
   const float gate = (raw >= -clampv && raw <= clampv) ? 1.0f : 0.0f;
   ce_row[r] = fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x)));
@@ -237,9 +254,9 @@ DBN_HD void dbn_head_ce(int r, const float* h, const float* w, float c, float cl
   if (logit_out) logit_out[r] = x;
 }
 // head of a plain forward: clamped logit (+ the clamp's gate)
-DBN_HD void dbn_head(int r, const float* h, const float* w, float c, float clampv, int H, float* logit, float* gate) {
-  float raw = c;
-  for (int j = 0; j < H; ++j) raw = fmaf(h[(size_t)r * H + j], w[j], raw);
+DBN_HD void dbn_head(int r, int lane, const float* h, const float* w, float c, float clampv, int H, float* logit, float* gate) {
+  const float raw = dbn_row_dot(lane, h + (size_t)r * H, w, H) + c;
+  if (lane != 0) return;
   if (logit) logit[r] = fminf(fmaxf(raw, -clampv), clampv);
   if (gate) gate[r] = (raw >= -clampv && raw <= clampv) ? 1.0f : 0.0f;
 }
@@ -252,14 +269,14 @@ DBN_HD void dbn_prep(int idx, const float* eo, const float* ea, const float* po,
   X[(size_t)(B + r) * D + k] = xp;
   if (XH) { const float e = eps[r]; XH[(size_t)r * D + k] = e * xe + (1.0f - e) * xp; }
 }
-// penalty rows: n = |g_r| ; row term (n - 1)^2 ; xbar = w_gp / B * 2 (n - 1) / n * g  (0 where n == 0)        idx in [0, B)
-DBN_HD void dbn_gp_row(int r, const float* g, float* xbar, float* gp_row, int B, int D, float gp_w) {
-  float ss = 0.0f;
-  for (int k = 0; k < D; ++k) ss = fmaf(g[(size_t)r * D + k], g[(size_t)r * D + k], ss);
+// penalty rows: n = |g_r| ; row term (n - 1)^2 ; xbar = w_gp / B * 2 (n - 1) / n * g  (0 where n == 0)        one wavefront per row r in [0, B)
+DBN_HD void dbn_gp_row(int r, int lane, const float* g, float* xbar, float* gp_row, int B, int D, float gp_w) {
+  const float* gr = g + (size_t)r * D;
+  const float ss = dbn_row_dot(lane, gr, gr, D);
   const float nn = sqrtf(ss);
-  gp_row[r] = (nn - 1.0f) * (nn - 1.0f);
+  if (lane == 0) gp_row[r] = (nn - 1.0f) * (nn - 1.0f);
   const float coef = nn > 0.0f ? gp_w / (float)B * 2.0f * (nn - 1.0f) / nn : 0.0f;
-  for (int k = 0; k < D; ++k) xbar[(size_t)r * D + k] = coef * g[(size_t)r * D + k];
+  for (int k = lane; k < D; k += DBN_LANES) xbar[(size_t)r * D + k] = coef * gr[k];
 }
 // torch 1.9 Adam (no weight decay): elementwise                  idx in [0, n_params)
 DBN_HD void dbn_adam(int i, float* P, const float* G, float* M, float* V, float lr_over_bc1, float bc2_sqrt, float b1, float b2, float eps) {

@@ -2,7 +2,7 @@
 // Written once against a launcher `LN` so that the device build (ilsx_disc.hip: every phase one kernel launch on the ctx stream) and the
 // host emulation (tests/harness/disc_bn_host.cpp: every phase a serial loop) run the SAME sequence:
 //   LN::par(count, f)   f(idx) for idx in [0, count)                      (rows / elements)
-//   LN::col(H, f)       f(j, lane) for every feature column j             (one wavefront per column on the device)
+//   LN::col(H, f)       f(j, lane) for every feature column j — or row r  (one wavefront per column / row on the device)
 //   LN::gemm(g)         C (+)= op(A) op(B) (+ bias), DbnGemm of disc_bn.h    (LDS-tiled on the device; up to two independent products per launch)
 // Reference: adv_irl.py:133-216 (_do_reward_training), :268-274 (eval-mode logits), simple_disc_models.py:8-48.
 #pragma once
@@ -65,7 +65,7 @@ void dbn_logits_eval(LN& L, const DbnNet& N, const DbnWs& W, const float* x, int
   const int H = N.H;
   const float *hL = W.h[N.nblk - 1], *w = N.P + N.off_w(), *cp = N.P + N.off_c();
   const float clampv = N.clampv;
-  L.par(n, DBN_LAMBDA(int r) { dbn_head(r, hL, w, cp[0], clampv, H, logits, nullptr); });
+  L.col(n, DBN_LAMBDA(int r, int lane) { dbn_head(r, lane, hL, w, cp[0], clampv, H, logits, nullptr); });
 }
 
 // AdvIRL._do_reward_training: gradients of BCE(2B rows) + gp_w * penalty(B interpolates) into N.G (no optimiser step).
@@ -81,7 +81,7 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
   {
     const float *hL = W.h[nb - 1], *w = N.P + N.off_w(), *cp = N.P + N.off_c();
     float *lg = W.logit, *dl = W.dlogit, *ce = W.ce_row, *co = W.correct;
-    L.par(n1, DBN_LAMBDA(int r) { dbn_head_ce(r, hL, w, cp[0], clampv, B, H, lg, dl, ce, co); });
+    L.col(n1, DBN_LAMBDA(int r, int lane) { dbn_head_ce(r, lane, hL, w, cp[0], clampv, B, H, lg, dl, ce, co); });
     float* gw = G + N.off_w();
     float* gc = G + N.off_c();
     L.col(H + 1, DBN_LAMBDA(int j, int lane) {   // column H: the output bias, dc = sum_r dlogit
@@ -114,7 +114,7 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
   {
     const float* hL = W.h[nb - 1];
     float* gt = W.gate;
-    L.par(B, DBN_LAMBDA(int r) { dbn_head(r, hL, w, cp[0], clampv, H, nullptr, gt); });
+    L.col(B, DBN_LAMBDA(int r, int lane) { dbn_head(r, lane, hL, w, cp[0], clampv, H, nullptr, gt); });
   }
   // first backward: g = d(sum_r D(xh_r)) / d xh through the batch statistics, tape kept
   {
@@ -136,7 +136,7 @@ void dbn_backward(LN& L, const DbnNet& N, const DbnWs& W, int B, int use_gp, flo
   {
     const float* g = W.t0;
     float* gpr = W.gp_row;
-    L.par(B, DBN_LAMBDA(int r) { dbn_gp_row(r, g, xbar, gpr, B, D, gp_w); });
+    L.col(B, DBN_LAMBDA(int r, int lane) { dbn_gp_row(r, lane, g, xbar, gpr, B, D, gp_w); });
   }
   // reverse of the first backward, bottom block first
   {

@@ -341,59 +341,73 @@ template <class F> __global__ __launch_bounds__(256) void k_dbn_par(int n, F f) 
   if (i < n) f(i);
 }
 template <class F> __global__ __launch_bounds__(64) void k_dbn_col(F f) { f((int)blockIdx.x, (int)threadIdx.x); }   // one wavefront per feature column
-// The matrix products of the step (DbnGemm, disc_bn.h): 32 x 32 output tiles, 256 threads with 2 x 2 outputs each, the contraction staged
-// through LDS in chunks of 32 — every global operand word is read once per tile instead of once per output element (the first form, one
-// thread per element with a strided walk over the other operand, spent 50-100 us per weight gradient: 2300 threads x 512 dependent trips).
-// One accumulator per output, k ascending: the fmaf chain of dbn_gemm_elem, bit for bit.  Two independent products can share a launch.
+// The matrix products of the step (DbnGemm, disc_bn.h): a 256-thread workgroup owns a 16 x 16 output tile; its four waves split the
+// contraction into the four consecutive ranges of dbn_kq(Kd) terms, each wave staging its own 32-term chunks of both operands in its own
+// LDS region (every global operand word is read once per tile, consecutive lanes along the operand's unit stride) and holding 2 x 2 outputs
+// per lane; the four partial tiles are added in range order — the chain of dbn_gemm_elem, bit for bit.  Small tiles on purpose: the weight
+// gradients contract over all rows into few outputs (128 x 128 outputs over 512 rows = 64 workgroups); 32 x 32 tiles without the split ran
+// 23 us per launch (16 workgroups, 16 serial load -> LDS -> multiply rounds), one thread per element with a strided walk 50-100 us.
+// Two independent products can share a launch.
 struct DbnGemm2 { DbnGemm g[2]; int tiles0, tn[2]; };
 __global__ __launch_bounds__(256) void k_dbn_gemm(const DbnGemm2 G2) {
-  __shared__ float As[32][33], Bs[32][33];   // [k][i], [k][j]
+  __shared__ __attribute__((aligned(16))) float As[4][32][18], Bs[4][32][18];   // per wave: [k][i], [k][j] (row stride 18: 8-byte aligned pairs)
+  __shared__ float red[4][256];
   const int which = (int)blockIdx.x >= G2.tiles0 ? 1 : 0;
   const DbnGemm& g = G2.g[which];
   const int tile = (int)blockIdx.x - (which ? G2.tiles0 : 0), tn = G2.tn[which];
-  const int i0 = (tile / tn) * 32, j0 = (tile % tn) * 32, t = threadIdx.x;
-  const int ti = t >> 4, tj = t & 15;
+  const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int li = lane >> 3, lj = lane & 7;
+  const int kq = dbn_kq(g.Kd), kbeg = wave * kq, kend = kbeg + kq < g.Kd ? kbeg + kq : g.Kd;
   float c00 = 0.0f, c01 = 0.0f, c10 = 0.0f, c11 = 0.0f;
-  for (int k0 = 0; k0 < g.Kd; k0 += 32) {
-    // staging: consecutive threads walk the operand's unit-stride direction
+  for (int k0 = kbeg; k0 < kbeg + kq; k0 += 32) {   // the same trip count in every wave (workgroup barriers inside)
+    float va[8], vb[8];
 #pragma unroll
-    for (int e = t; e < 1024; e += 256) {
+    for (int u = 0; u < 8; ++u) {   // all 16 loads of the chunk in flight before the first LDS store
+      const int e = lane + 64 * u;
       int ii, kk;
-      if (g.sak == 1) { kk = e & 31; ii = e >> 5; } else { ii = e & 31; kk = e >> 5; }
+      if (g.sak == 1) { kk = e & 31; ii = e >> 5; } else { ii = e & 15; kk = e >> 4; }
       const int gi = i0 + ii, gk = k0 + kk;
-      As[kk][ii] = (gi < g.M && gk < g.Kd) ? g.A[(size_t)gi * g.sai + (size_t)gk * g.sak] : 0.0f;
+      va[u] = (gi < g.M && gk < kend) ? g.A[(size_t)gi * g.sai + (size_t)gk * g.sak] : 0.0f;
       int jj, kb;
-      if (g.sbj == 1) { jj = e & 31; kb = e >> 5; } else { kb = e & 31; jj = e >> 5; }
+      if (g.sbj == 1) { jj = e & 15; kb = e >> 4; } else { kb = e & 31; jj = e >> 5; }
       const int gj = j0 + jj, gkb = k0 + kb;
-      Bs[kb][jj] = (gj < g.N && gkb < g.Kd) ? g.B[(size_t)gkb * g.sbk + (size_t)gj * g.sbj] : 0.0f;
+      vb[u] = (gj < g.N && gkb < kend) ? g.B[(size_t)gkb * g.sbk + (size_t)gj * g.sbj] : 0.0f;
+    }
+    __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = lane + 64 * u;
+      int ii, kk;
+      if (g.sak == 1) { kk = e & 31; ii = e >> 5; } else { ii = e & 15; kk = e >> 4; }
+      As[wave][kk][ii] = va[u];
+      int jj, kb;
+      if (g.sbj == 1) { jj = e & 15; kb = e >> 4; } else { kb = e & 31; jj = e >> 5; }
+      Bs[wave][kb][jj] = vb[u];
     }
     __syncthreads();
-    const int kend = g.Kd - k0 < 32 ? g.Kd - k0 : 32;   // never past Kd: a padded fmaf(0, 0, s) would be harmless, but the chain is stated exactly
-    for (int kk = 0; kk < kend; ++kk) {
-      const float a0 = As[kk][2 * ti], a1 = As[kk][2 * ti + 1], b0 = Bs[kk][2 * tj], b1 = Bs[kk][2 * tj + 1];
-      c00 = fmaf(a0, b0, c00); c01 = fmaf(a0, b1, c01); c10 = fmaf(a1, b0, c10); c11 = fmaf(a1, b1, c11);
+    const int kn = kend - k0 < 32 ? (kend - k0 > 0 ? kend - k0 : 0) : 32;   // exactly the range's terms: the chain is stated without padding terms
+    for (int kk = 0; kk < kn; ++kk) {
+      const float2 a = *reinterpret_cast<const float2*>(&As[wave][kk][2 * li]);
+      const float2 b = *reinterpret_cast<const float2*>(&Bs[wave][kk][2 * lj]);
+      c00 = fmaf(a.x, b.x, c00); c01 = fmaf(a.x, b.y, c01); c10 = fmaf(a.y, b.x, c10); c11 = fmaf(a.y, b.y, c11);
     }
-    __syncthreads();
   }
-  const float cs[2][2] = {{c00, c01}, {c10, c11}};
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int gi = i0 + 2 * ti + a, gj = j0 + 2 * tj + b;
-      if (gi < g.M && gj < g.N) {
-        float v = cs[a][b];
-        if (g.bias) v = v + g.bias[gj];
-        float* c = g.C + (size_t)gi * g.ldc + gj;
-        *c = g.acc ? *c + v : v;
-      }
-    }
+  red[wave][(2 * li) * 16 + 2 * lj] = c00; red[wave][(2 * li) * 16 + 2 * lj + 1] = c01;
+  red[wave][(2 * li + 1) * 16 + 2 * lj] = c10; red[wave][(2 * li + 1) * 16 + 2 * lj + 1] = c11;
+  __syncthreads();
+  const int gi = i0 + (t >> 4), gj = j0 + (t & 15);
+  if (gi < g.M && gj < g.N) {
+    float v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    if (g.bias) v = v + g.bias[gj];
+    float* c = g.C + (size_t)gi * g.ldc + gj;
+    *c = g.acc ? *c + v : v;
+  }
 }
 struct DbnLaunch {
   hipStream_t st;
   template <class F> void par(int n, F f) { if (n > 0) hipLaunchKernelGGL(k_dbn_par<F>, dim3((n + 255) / 256), dim3(256), 0, st, n, f); }
   template <class F> void col(int H, F f) { if (H > 0) hipLaunchKernelGGL(k_dbn_col<F>, dim3(H), dim3(64), 0, st, f); }
-  static int tiles(const DbnGemm& g, int* tn) { *tn = (g.N + 31) / 32; return ((g.M + 31) / 32) * *tn; }
+  static int tiles(const DbnGemm& g, int* tn) { *tn = (g.N + 15) / 16; return ((g.M + 15) / 16) * *tn; }
   void gemm(const DbnGemm& g1) {
     DbnGemm2 G2;
     G2.g[0] = g1; G2.g[1] = g1;

@@ -15,9 +15,13 @@ def test_shape_and_state_errors_are_reported(ctx):
         ia.FlattenMlp([400, 300], 1, 14, ctx=ctx)            # any widths up to 256 run (embedded as structural zeros); wider has no kernel
     assert ia.FlattenMlp([100, 100], 1, 14, ctx=ctx).num_params == 14 * 100 + 100 + 100 * 100 + 100 + 100 + 1
     assert ia.FlattenMlp([128, 256], 1, 14, ctx=ctx).kernel_width == 256
-    with pytest.raises(NotImplementedError, match="PPO"):
+    # (round 5: PPO takes any list of widths up to 256 like every other trainer — g7e; what it still refuses is a value net of another shape)
+    tr_ppo = PPO(ReparamMultivariateGaussianPolicy([128, 64], 11, 3, conditioned_std=False, hidden_activation="tanh", ctx=ctx),
+                 ia.Mlp([128, 64], 1, 11, hidden_activation="tanh", ctx=ctx))
+    assert tr_ppo.get_flat_params(1).size == 11 * 128 + 128 + 128 * 64 + 64 + 64 + 1
+    with pytest.raises(ValueError, match="share net_size"):
         PPO(ReparamMultivariateGaussianPolicy([128, 64], 11, 3, conditioned_std=False, hidden_activation="tanh", ctx=ctx),
-            ia.Mlp([128, 64], 1, 11, hidden_activation="tanh", ctx=ctx))
+            ia.Mlp([64, 64], 1, 11, hidden_activation="tanh", ctx=ctx))
     net = ia.FlattenMlp([64, 64], 1, 14, ctx=ctx)
     with pytest.raises(RuntimeError, match="libilsx error"):
         net.set_flat_params(np.zeros(net.num_params + 1, np.float32))
