@@ -94,6 +94,14 @@ DBN_HD void dbn_gemm_elem(const DbnGemm& g, int i, int j) {
 }
 
 // ---- column phases: one wavefront per feature column j; lanes split the rows (host emulation: one lane)
+// A lane's rows are walked in BATCHES of DBN_U: every load of a batch is issued before the first value is used (a plain loop around
+// load + use waited for memory on every trip: 8 serial L2 round trips per pass and array at 512 rows — the column launches ran 9 us each).
+// The order in which a lane adds its rows is unchanged (ascending), so are the results.
+#define DBN_U 8
+#define DBN_BATCH(rb) for (int rb = lane; rb < n; rb += DBN_LANES * DBN_U)
+#define DBN_EACH(u, r, rb) _Pragma("unroll") for (int u = 0, r = rb; u < DBN_U; ++u, r += DBN_LANES)
+// v[u] = x[r][j] for the batch's rows (0 past the end)
+#define DBN_LOAD(v, x, rb) float v[DBN_U]; DBN_EACH(u_, r_, rb) v[u_] = r_ < n ? (x)[(size_t)r_ * H + j] : 0.0f
 // forward of a block after the dense phase: a (in buf `ch`, overwritten by a - mu) -> s[j], ah, h, p; train: batch statistics (+ running
 // update), eval: running statistics
 DBN_HD void dbn_col_fwd(int j, int lane, float* ch, float* ah, float* h, float* p, float* s_out, const float* gamma, const float* beta,
@@ -101,10 +109,10 @@ DBN_HD void dbn_col_fwd(int j, int lane, float* ch, float* ah, float* h, float* 
   float mu, var;
   if (train) {
     float sm = 0.0f;
-    for (int r = lane; r < n; r += DBN_LANES) sm += ch[(size_t)r * H + j];
+    DBN_BATCH(rb) { DBN_LOAD(x, ch, rb); DBN_EACH(u, r, rb) if (r < n) sm += x[u]; }
     mu = dbn_wsum(sm) / (float)n;
     float sv = 0.0f;
-    for (int r = lane; r < n; r += DBN_LANES) { const float c = ch[(size_t)r * H + j] - mu; sv += c * c; }
+    DBN_BATCH(rb) { DBN_LOAD(x, ch, rb); DBN_EACH(u, r, rb) if (r < n) { const float c = x[u] - mu; sv += c * c; } }
     var = dbn_wsum(sv) / (float)n;
     if (update_running && lane == 0) {   // torch: running = (1 - momentum) running + momentum batch, the variance UNBIASED
       rmean[j] = (1.0f - DBN_MOM) * rmean[j] + DBN_MOM * mu;
@@ -115,13 +123,16 @@ DBN_HD void dbn_col_fwd(int j, int lane, float* ch, float* ah, float* h, float* 
   }
   const float s = 1.0f / sqrtf(var + DBN_EPS), g = gamma[j], be = beta[j];
   if (lane == 0 && s_out) s_out[j] = s;
-  for (int r = lane; r < n; r += DBN_LANES) {
-    const size_t at = (size_t)r * H + j;
-    const float c = ch[at] - mu, a_ = c * s, hh = dbn_act(g * a_ + be, act);
-    ch[at] = c;
-    if (ah) ah[at] = a_;
-    h[at] = hh;
-    if (p) p[at] = dbn_dact(hh, act);
+  DBN_BATCH(rb) {
+    DBN_LOAD(x, ch, rb);
+    DBN_EACH(u, r, rb) if (r < n) {
+      const size_t at = (size_t)r * H + j;
+      const float c = x[u] - mu, a_ = c * s, hh = dbn_act(g * a_ + be, act);
+      ch[at] = c;
+      if (ah) ah[at] = a_;
+      h[at] = hh;
+      if (p) p[at] = dbn_dact(hh, act);
+    }
   }
 }
 // backward through act -> BN (the CE backward, and the FIRST backward of the penalty): cotangent uh of h -> ua of the dense output.
@@ -132,23 +143,30 @@ DBN_HD void dbn_col_bwd(int j, int lane, const float* uh, const float* top, cons
                         float* db, int n, int H, int acc) {
   const float g = gamma[j], sj = s[j], wj = w ? w[j] : 0.0f;
   float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
-  for (int r = lane; r < n; r += DBN_LANES) {
-    const size_t at = (size_t)r * H + j;
-    const float u = uh ? uh[at] : top[r] * wj;
-    const float y_ = u * p[at], q = y_ * g;
-    a1 += q; a2 += q * ah[at]; a3 += y_ * ah[at]; a4 += y_;
-    if (uh_out) uh_out[at] = u;
+  DBN_BATCH(rb) {
+    float u_[DBN_U];
+    DBN_EACH(u, r, rb) u_[u] = r < n ? (uh ? uh[(size_t)r * H + j] : top[r] * wj) : 0.0f;
+    DBN_LOAD(pp, p, rb); DBN_LOAD(aa, ah, rb);
+    DBN_EACH(u, r, rb) if (r < n) {
+      const float y_ = u_[u] * pp[u], q = y_ * g;
+      a1 += q; a2 += q * aa[u]; a3 += y_ * aa[u]; a4 += y_;
+      if (uh_out) uh_out[(size_t)r * H + j] = u_[u];
+    }
   }
   const float m1 = dbn_wsum(a1) / (float)n, m2 = dbn_wsum(a2) / (float)n;
   a3 = dbn_wsum(a3); a4 = dbn_wsum(a4);
   float sa = 0.0f;
-  for (int r = lane; r < n; r += DBN_LANES) {
-    const size_t at = (size_t)r * H + j;
-    const float u = uh ? uh[at] : top[r] * wj;
-    const float y_ = u * p[at], q = y_ * g, t = q - m1 - ah[at] * m2, a_ = sj * t;
-    ua[at] = a_;
-    sa += a_;
-    if (uy) { uy[at] = y_; uah[at] = q; tt[at] = t; }
+  DBN_BATCH(rb) {
+    float u_[DBN_U];
+    DBN_EACH(u, r, rb) u_[u] = r < n ? (uh ? uh[(size_t)r * H + j] : top[r] * wj) : 0.0f;
+    DBN_LOAD(pp, p, rb); DBN_LOAD(aa, ah, rb);
+    DBN_EACH(u, r, rb) if (r < n) {
+      const size_t at = (size_t)r * H + j;
+      const float y_ = u_[u] * pp[u], q = y_ * g, t = q - m1 - aa[u] * m2, a_ = sj * t;
+      ua[at] = a_;
+      sa += a_;
+      if (uy) { uy[at] = y_; uah[at] = q; tt[at] = t; }
+    }
   }
   sa = dbn_wsum(sa);
   if (lane == 0) {
@@ -164,22 +182,28 @@ DBN_HD void dbn_col_rev(int j, int lane, const float* uabar, const float* tt, co
                         float* sbar, float* xbar_up, float* dgamma, int n, int H, int act) {
   const float sj = s[j], g = gamma[j], m2j = m2[j];
   float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-  for (int r = lane; r < n; r += DBN_LANES) {
-    const size_t at = (size_t)r * H + j;
-    const float ub = uabar[at], tb = ub * sj;
-    a1 += ub * tt[at]; a2 += tb; a3 += tb * ah[at];
+  DBN_BATCH(rb) {
+    DBN_LOAD(ub, uabar, rb); DBN_LOAD(t_, tt, rb); DBN_LOAD(aa, ah, rb);
+    DBN_EACH(u, r, rb) if (r < n) {
+      const float tb = ub[u] * sj;
+      a1 += ub[u] * t_[u]; a2 += tb; a3 += tb * aa[u];
+    }
   }
   const float sb = dbn_wsum(a1), m1bar = -dbn_wsum(a2), m2bar = -dbn_wsum(a3);
   float dg = 0.0f;
-  for (int r = lane; r < n; r += DBN_LANES) {
-    const size_t at = (size_t)r * H + j;
-    const float tb = uabar[at] * sj;
-    const float uahb = tb + m1bar / (float)n + (m2bar / (float)n) * ah[at];
-    ahbar[at] = -tb * m2j + (m2bar / (float)n) * uah[at];
-    dg += uahb * uy[at];
-    const float uyb = uahb * g;
-    ybar[at] = uyb * uh[at] * dbn_d2act(h[at], act);
-    xbar_up[at] = uyb * p[at];
+  DBN_BATCH(rb) {
+    DBN_LOAD(ub, uabar, rb); DBN_LOAD(aa, ah, rb); DBN_LOAD(ua_, uah, rb); DBN_LOAD(uy_, uy, rb);
+    DBN_LOAD(uh_, uh, rb); DBN_LOAD(hh, h, rb); DBN_LOAD(pp, p, rb);
+    DBN_EACH(u, r, rb) if (r < n) {
+      const size_t at = (size_t)r * H + j;
+      const float tb = ub[u] * sj;
+      const float uahb = tb + m1bar / (float)n + (m2bar / (float)n) * aa[u];
+      ahbar[at] = -tb * m2j + (m2bar / (float)n) * ua_[u];
+      dg += uahb * uy_[u];
+      const float uyb = uahb * g;
+      ybar[at] = uyb * uh_[u] * dbn_d2act(hh[u], act);
+      xbar_up[at] = uyb * pp[u];
+    }
   }
   dg = dbn_wsum(dg);
   if (lane == 0) { sbar[j] = sb; dgamma[j] += dg; }
@@ -190,30 +214,40 @@ DBN_HD void dbn_col_down(int j, int lane, const float* ybar, const float* hbar, 
                          float* db, int n, int H) {
   const float sj = s[j], g = gamma[j];
   float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-  for (int r = lane; r < n; r += DBN_LANES) {
-    const size_t at = (size_t)r * H + j;
-    const float yb = ybar[at] + (hbar ? hbar[at] * p[at] : 0.0f);
-    const float ahb = ahbar[at] + yb * g;
-    a1 += yb * ah[at]; a2 += yb; a3 += ahb * ch[at];
+  DBN_BATCH(rb) {
+    DBN_LOAD(yb_, ybar, rb); DBN_LOAD(aa, ah, rb); DBN_LOAD(ab_, ahbar, rb); DBN_LOAD(cc, ch, rb);
+    float hp[DBN_U];
+    DBN_EACH(u, r, rb) hp[u] = (hbar && r < n) ? hbar[(size_t)r * H + j] * p[(size_t)r * H + j] : 0.0f;
+    DBN_EACH(u, r, rb) if (r < n) {
+      const float yb = yb_[u] + (hbar ? hp[u] : 0.0f);
+      const float ahb = ab_[u] + yb * g;
+      a1 += yb * aa[u]; a2 += yb; a3 += ahb * cc[u];
+    }
   }
   a1 = dbn_wsum(a1); a2 = dbn_wsum(a2);
   const float sb = sbar[j] + dbn_wsum(a3), vb = -0.5f * sb * sj * sj * sj;
   float cm = 0.0f;
-  for (int r = lane; r < n; r += DBN_LANES) {
-    const size_t at = (size_t)r * H + j;
-    const float yb = ybar[at] + (hbar ? hbar[at] * p[at] : 0.0f);
-    const float ahb = ahbar[at] + yb * g;
-    const float chb = ahb * sj + vb * 2.0f * ch[at] / (float)n;
-    ab[at] = chb;
-    cm += chb;
+  DBN_BATCH(rb) {
+    DBN_LOAD(yb_, ybar, rb); DBN_LOAD(ab_, ahbar, rb); DBN_LOAD(cc, ch, rb);
+    float hp[DBN_U];
+    DBN_EACH(u, r, rb) hp[u] = (hbar && r < n) ? hbar[(size_t)r * H + j] * p[(size_t)r * H + j] : 0.0f;
+    DBN_EACH(u, r, rb) if (r < n) {
+      const float yb = yb_[u] + (hbar ? hp[u] : 0.0f);
+      const float ahb = ab_[u] + yb * g;
+      const float chb = ahb * sj + vb * 2.0f * cc[u] / (float)n;
+      ab[(size_t)r * H + j] = chb;
+      cm += chb;
+    }
   }
   cm = dbn_wsum(cm) / (float)n;
   float sa = 0.0f;
-  for (int r = lane; r < n; r += DBN_LANES) {
-    const size_t at = (size_t)r * H + j;
-    const float v = ab[at] - cm;
-    ab[at] = v;
-    sa += v;
+  DBN_BATCH(rb) {
+    DBN_LOAD(x, ab, rb);
+    DBN_EACH(u, r, rb) if (r < n) {
+      const float v = x[u] - cm;
+      ab[(size_t)r * H + j] = v;
+      sa += v;
+    }
   }
   sa = dbn_wsum(sa);
   if (lane == 0) { dgamma[j] += a1; dbeta[j] += a2; db[j] += sa; }
@@ -221,11 +255,13 @@ DBN_HD void dbn_col_down(int j, int lane, const float* ybar, const float* hbar, 
 // column sums for the head: gw[j] (+)= sum_r v[r] * m[r][j]       (v = dlogit with m = h_L ; v = gate with m = xbar_up)
 DBN_HD void dbn_col_dot(int j, int lane, const float* v, const float* m, float* out, int n, int H, int acc) {
   float a = 0.0f;
-  for (int r = lane; r < n; r += DBN_LANES) a += v[r] * m[(size_t)r * H + j];
+  DBN_BATCH(rb) {
+    DBN_LOAD(x, m, rb);
+    DBN_EACH(u, r, rb) if (r < n) a += v[r] * x[u];
+  }
   a = dbn_wsum(a);
   if (lane == 0) out[j] = acc ? out[j] + a : a;
 }
-
 // sum of a vector as a column phase of ONE column (lanes split the rows): out[0] = sum_r v[r]
 DBN_HD void dbn_vec_sum(int lane, const float* v, int n, float* out) {
   float a = 0.0f;
