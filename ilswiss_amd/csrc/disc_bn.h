@@ -96,35 +96,45 @@ DBN_HD void dbn_gemm_elem(const DbnGemm& g, int i, int j) {
 // ---- column phases: one wavefront per feature column j; lanes split the rows (host emulation: one lane)
 // A lane's rows are walked in BATCHES of DBN_U: every load of a batch is issued before the first value is used (a plain loop around
 // load + use waited for memory on every trip: 8 serial L2 round trips per pass and array at 512 rows — the column launches ran 9 us each).
-// The order in which a lane adds its rows is unchanged (ascending), so are the results.
+// When the column is ONE batch (n <= DBN_LANES * DBN_U: 512 rows on the device) the values stay in registers across the phase's passes — one
+// memory round trip per launch instead of one per pass.  The order in which a lane adds its rows is unchanged (ascending), so are the results.
+#ifdef DBN_HOST_EMU
+#define DBN_U 64   // the host's single lane holds 64 rows per batch: the reference vectors (<= 40 rows) take the one-batch path, the oracle sizes the general one
+#else
 #define DBN_U 8
+#endif
 #define DBN_BATCH(rb) for (int rb = lane; rb < n; rb += DBN_LANES * DBN_U)
 #define DBN_EACH(u, r, rb) _Pragma("unroll") for (int u = 0, r = rb; u < DBN_U; ++u, r += DBN_LANES)
 // v[u] = x[r][j] for the batch's rows (0 past the end)
-#define DBN_LOAD(v, x, rb) float v[DBN_U]; DBN_EACH(u_, r_, rb) v[u_] = r_ < n ? (x)[(size_t)r_ * H + j] : 0.0f
+#define DBN_LD(v, x, rb) DBN_EACH(u_, r_, rb) v[u_] = r_ < n ? (x)[(size_t)r_ * H + j] : 0.0f
 // forward of a block after the dense phase: a (in buf `ch`, overwritten by a - mu) -> s[j], ah, h, p; train: batch statistics (+ running
 // update), eval: running statistics
+// bstat (nullable, train): the column's batch mean and BIASED variance are parked at bstat[j], bstat[H + j] for dbn_running_update — the
+// training step runs its two forward passes side by side and applies their running-statistics updates afterwards, in the reference's order
 DBN_HD void dbn_col_fwd(int j, int lane, float* ch, float* ah, float* h, float* p, float* s_out, const float* gamma, const float* beta,
-                        float* rmean, float* rvar, int n, int H, int act, int train, int update_running) {
+                        float* rmean, float* rvar, int n, int H, int act, int train, int update_running, float* bstat) {
+  const bool one = n <= DBN_LANES * DBN_U;
+  float x[DBN_U];
   float mu, var;
   if (train) {
     float sm = 0.0f;
-    DBN_BATCH(rb) { DBN_LOAD(x, ch, rb); DBN_EACH(u, r, rb) if (r < n) sm += x[u]; }
+    DBN_BATCH(rb) { DBN_LD(x, ch, rb); DBN_EACH(u, r, rb) if (r < n) sm += x[u]; }
     mu = dbn_wsum(sm) / (float)n;
     float sv = 0.0f;
-    DBN_BATCH(rb) { DBN_LOAD(x, ch, rb); DBN_EACH(u, r, rb) if (r < n) { const float c = x[u] - mu; sv += c * c; } }
+    DBN_BATCH(rb) { if (!one) DBN_LD(x, ch, rb); DBN_EACH(u, r, rb) if (r < n) { const float c = x[u] - mu; sv += c * c; } }
     var = dbn_wsum(sv) / (float)n;
     if (update_running && lane == 0) {   // torch: running = (1 - momentum) running + momentum batch, the variance UNBIASED
       rmean[j] = (1.0f - DBN_MOM) * rmean[j] + DBN_MOM * mu;
       rvar[j] = (1.0f - DBN_MOM) * rvar[j] + DBN_MOM * var * ((float)n / (float)(n - 1));
     }
+    if (bstat && lane == 0) { bstat[j] = mu; bstat[H + j] = var; }
   } else {
     mu = rmean[j]; var = rvar[j];
   }
   const float s = 1.0f / sqrtf(var + DBN_EPS), g = gamma[j], be = beta[j];
   if (lane == 0 && s_out) s_out[j] = s;
   DBN_BATCH(rb) {
-    DBN_LOAD(x, ch, rb);
+    if (!one || !train) DBN_LD(x, ch, rb);
     DBN_EACH(u, r, rb) if (r < n) {
       const size_t at = (size_t)r * H + j;
       const float c = x[u] - mu, a_ = c * s, hh = dbn_act(g * a_ + be, act);
@@ -141,12 +151,13 @@ DBN_HD void dbn_col_fwd(int j, int lane, float* ch, float* ah, float* h, float* 
 DBN_HD void dbn_col_bwd(int j, int lane, const float* uh, const float* top, const float* w, const float* p, const float* ah, const float* s,
                         const float* gamma, float* ua, float* uh_out, float* uy, float* uah, float* tt, float* m2_out, float* dgamma, float* dbeta,
                         float* db, int n, int H, int acc) {
+  const bool one = n <= DBN_LANES * DBN_U;
   const float g = gamma[j], sj = s[j], wj = w ? w[j] : 0.0f;
+  float u_[DBN_U], pp[DBN_U], aa[DBN_U];
   float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
   DBN_BATCH(rb) {
-    float u_[DBN_U];
     DBN_EACH(u, r, rb) u_[u] = r < n ? (uh ? uh[(size_t)r * H + j] : top[r] * wj) : 0.0f;
-    DBN_LOAD(pp, p, rb); DBN_LOAD(aa, ah, rb);
+    DBN_LD(pp, p, rb); DBN_LD(aa, ah, rb);
     DBN_EACH(u, r, rb) if (r < n) {
       const float y_ = u_[u] * pp[u], q = y_ * g;
       a1 += q; a2 += q * aa[u]; a3 += y_ * aa[u]; a4 += y_;
@@ -157,9 +168,10 @@ DBN_HD void dbn_col_bwd(int j, int lane, const float* uh, const float* top, cons
   a3 = dbn_wsum(a3); a4 = dbn_wsum(a4);
   float sa = 0.0f;
   DBN_BATCH(rb) {
-    float u_[DBN_U];
-    DBN_EACH(u, r, rb) u_[u] = r < n ? (uh ? uh[(size_t)r * H + j] : top[r] * wj) : 0.0f;
-    DBN_LOAD(pp, p, rb); DBN_LOAD(aa, ah, rb);
+    if (!one) {
+      DBN_EACH(u, r, rb) u_[u] = r < n ? (uh ? uh[(size_t)r * H + j] : top[r] * wj) : 0.0f;
+      DBN_LD(pp, p, rb); DBN_LD(aa, ah, rb);
+    }
     DBN_EACH(u, r, rb) if (r < n) {
       const size_t at = (size_t)r * H + j;
       const float y_ = u_[u] * pp[u], q = y_ * g, t = q - m1 - aa[u] * m2, a_ = sj * t;
@@ -180,10 +192,13 @@ DBN_HD void dbn_col_bwd(int j, int lane, const float* uh, const float* top, cons
 DBN_HD void dbn_col_rev(int j, int lane, const float* uabar, const float* tt, const float* s, const float* ah, const float* uah, const float* uy,
                         const float* uh, const float* p, const float* h, const float* m2, const float* gamma, float* ybar, float* ahbar,
                         float* sbar, float* xbar_up, float* dgamma, int n, int H, int act) {
+  const bool one = n <= DBN_LANES * DBN_U;
   const float sj = s[j], g = gamma[j], m2j = m2[j];
+  float ub[DBN_U], t_[DBN_U], aa[DBN_U], ua_[DBN_U], uy_[DBN_U], uh_[DBN_U], hh[DBN_U], pp[DBN_U];
   float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
   DBN_BATCH(rb) {
-    DBN_LOAD(ub, uabar, rb); DBN_LOAD(t_, tt, rb); DBN_LOAD(aa, ah, rb);
+    DBN_LD(ub, uabar, rb); DBN_LD(t_, tt, rb); DBN_LD(aa, ah, rb);
+    if (one) { DBN_LD(ua_, uah, rb); DBN_LD(uy_, uy, rb); DBN_LD(uh_, uh, rb); DBN_LD(hh, h, rb); DBN_LD(pp, p, rb); }   // the second pass's operands ride along
     DBN_EACH(u, r, rb) if (r < n) {
       const float tb = ub[u] * sj;
       a1 += ub[u] * t_[u]; a2 += tb; a3 += tb * aa[u];
@@ -192,8 +207,10 @@ DBN_HD void dbn_col_rev(int j, int lane, const float* uabar, const float* tt, co
   const float sb = dbn_wsum(a1), m1bar = -dbn_wsum(a2), m2bar = -dbn_wsum(a3);
   float dg = 0.0f;
   DBN_BATCH(rb) {
-    DBN_LOAD(ub, uabar, rb); DBN_LOAD(aa, ah, rb); DBN_LOAD(ua_, uah, rb); DBN_LOAD(uy_, uy, rb);
-    DBN_LOAD(uh_, uh, rb); DBN_LOAD(hh, h, rb); DBN_LOAD(pp, p, rb);
+    if (!one) {
+      DBN_LD(ub, uabar, rb); DBN_LD(aa, ah, rb); DBN_LD(ua_, uah, rb); DBN_LD(uy_, uy, rb);
+      DBN_LD(uh_, uh, rb); DBN_LD(hh, h, rb); DBN_LD(pp, p, rb);
+    }
     DBN_EACH(u, r, rb) if (r < n) {
       const size_t at = (size_t)r * H + j;
       const float tb = ub[u] * sj;
@@ -212,11 +229,12 @@ DBN_HD void dbn_col_rev(int j, int lane, const float* uabar, const float* tt, co
 DBN_HD void dbn_col_down(int j, int lane, const float* ybar, const float* hbar, const float* p, const float* ah, const float* ahbar,
                          const float* ch, const float* s, const float* sbar, const float* gamma, float* ab, float* dgamma, float* dbeta,
                          float* db, int n, int H) {
+  const bool one = n <= DBN_LANES * DBN_U;
   const float sj = s[j], g = gamma[j];
+  float yb_[DBN_U], aa[DBN_U], ab_[DBN_U], cc[DBN_U], hp[DBN_U], cb[DBN_U];
   float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
   DBN_BATCH(rb) {
-    DBN_LOAD(yb_, ybar, rb); DBN_LOAD(aa, ah, rb); DBN_LOAD(ab_, ahbar, rb); DBN_LOAD(cc, ch, rb);
-    float hp[DBN_U];
+    DBN_LD(yb_, ybar, rb); DBN_LD(aa, ah, rb); DBN_LD(ab_, ahbar, rb); DBN_LD(cc, ch, rb);
     DBN_EACH(u, r, rb) hp[u] = (hbar && r < n) ? hbar[(size_t)r * H + j] * p[(size_t)r * H + j] : 0.0f;
     DBN_EACH(u, r, rb) if (r < n) {
       const float yb = yb_[u] + (hbar ? hp[u] : 0.0f);
@@ -228,23 +246,25 @@ DBN_HD void dbn_col_down(int j, int lane, const float* ybar, const float* hbar, 
   const float sb = sbar[j] + dbn_wsum(a3), vb = -0.5f * sb * sj * sj * sj;
   float cm = 0.0f;
   DBN_BATCH(rb) {
-    DBN_LOAD(yb_, ybar, rb); DBN_LOAD(ab_, ahbar, rb); DBN_LOAD(cc, ch, rb);
-    float hp[DBN_U];
-    DBN_EACH(u, r, rb) hp[u] = (hbar && r < n) ? hbar[(size_t)r * H + j] * p[(size_t)r * H + j] : 0.0f;
+    if (!one) {
+      DBN_LD(yb_, ybar, rb); DBN_LD(ab_, ahbar, rb); DBN_LD(cc, ch, rb);
+      DBN_EACH(u, r, rb) hp[u] = (hbar && r < n) ? hbar[(size_t)r * H + j] * p[(size_t)r * H + j] : 0.0f;
+    }
     DBN_EACH(u, r, rb) if (r < n) {
       const float yb = yb_[u] + (hbar ? hp[u] : 0.0f);
       const float ahb = ab_[u] + yb * g;
       const float chb = ahb * sj + vb * 2.0f * cc[u] / (float)n;
-      ab[(size_t)r * H + j] = chb;
+      if (!one) ab[(size_t)r * H + j] = chb;
+      cb[u] = chb;
       cm += chb;
     }
   }
   cm = dbn_wsum(cm) / (float)n;
   float sa = 0.0f;
   DBN_BATCH(rb) {
-    DBN_LOAD(x, ab, rb);
+    if (!one) DBN_LD(cb, ab, rb);
     DBN_EACH(u, r, rb) if (r < n) {
-      const float v = x[u] - cm;
+      const float v = cb[u] - cm;
       ab[(size_t)r * H + j] = v;
       sa += v;
     }
@@ -254,9 +274,10 @@ DBN_HD void dbn_col_down(int j, int lane, const float* ybar, const float* hbar, 
 }
 // column sums for the head: gw[j] (+)= sum_r v[r] * m[r][j]       (v = dlogit with m = h_L ; v = gate with m = xbar_up)
 DBN_HD void dbn_col_dot(int j, int lane, const float* v, const float* m, float* out, int n, int H, int acc) {
+  float x[DBN_U];
   float a = 0.0f;
   DBN_BATCH(rb) {
-    DBN_LOAD(x, m, rb);
+    DBN_LD(x, m, rb);
     DBN_EACH(u, r, rb) if (r < n) a += v[r] * x[u];
   }
   a = dbn_wsum(a);
@@ -268,6 +289,21 @@ DBN_HD void dbn_vec_sum(int lane, const float* v, int n, float* out) {
   for (int r = lane; r < n; r += DBN_LANES) a += v[r];
   a = dbn_wsum(a);
   if (lane == 0) out[0] = a;
+}
+
+// the running-statistics updates of a training step, after the fact: per (block, column) the cross-entropy pass's (n1 rows), then the
+// penalty pass's (n2 rows; n2 = 0: no penalty pass) — the same two expressions, in the same order, as dbn_col_fwd(update_running = 1) applies
+// them.  bstat = [pass][block][mean | var][H].        idx in [0, nblk * H)
+DBN_HD void dbn_running_update(int idx, float* rmean, float* rvar, const float* bstat, int nblk, int H, int n1, int n2) {
+  const int l = idx / H, j = idx - l * H;
+  float rm = rmean[idx], rv = rvar[idx];
+  for (int ps = 0; ps < (n2 > 0 ? 2 : 1); ++ps) {
+    const float* bs = bstat + (size_t)((ps * nblk + l) * 2) * H;
+    const int n = ps == 0 ? n1 : n2;
+    rm = (1.0f - DBN_MOM) * rm + DBN_MOM * bs[j];
+    rv = (1.0f - DBN_MOM) * rv + DBN_MOM * bs[H + j] * ((float)n / (float)(n - 1));
+  }
+  rmean[idx] = rm; rvar[idx] = rv;
 }
 
 // ---- row phases: one wavefront per ROW r, lanes split the features (coalesced; host emulation: one lane); dot = sum_j h[r][j] w[j]

@@ -348,13 +348,13 @@ template <class F> __global__ __launch_bounds__(64) void k_dbn_col(F f) { f((int
 // gradients contract over all rows into few outputs (128 x 128 outputs over 512 rows = 64 workgroups); 32 x 32 tiles without the split ran
 // 23 us per launch (16 workgroups, 16 serial load -> LDS -> multiply rounds), one thread per element with a strided walk 50-100 us.
 // Two independent products can share a launch.
-struct DbnGemm2 { DbnGemm g[2]; int tiles0, tn[2]; };
+struct DbnGemm2 { DbnGemm g[3]; int start[4], tn[3]; };   // start[i]: first workgroup of product i (start[3] = grid size)
 __global__ __launch_bounds__(256) void k_dbn_gemm(const DbnGemm2 G2) {
   __shared__ __attribute__((aligned(16))) float As[4][32][18], Bs[4][32][18];   // per wave: [k][i], [k][j] (row stride 18: 8-byte aligned pairs)
   __shared__ float red[4][256];
-  const int which = (int)blockIdx.x >= G2.tiles0 ? 1 : 0;
+  const int which = (int)blockIdx.x >= G2.start[2] ? 2 : (int)blockIdx.x >= G2.start[1] ? 1 : 0;
   const DbnGemm& g = G2.g[which];
-  const int tile = (int)blockIdx.x - (which ? G2.tiles0 : 0), tn = G2.tn[which];
+  const int tile = (int)blockIdx.x - G2.start[which], tn = G2.tn[which];
   const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16, t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int li = lane >> 3, lj = lane & 7;
   const int kq = dbn_kq(g.Kd), kbeg = wave * kq, kend = kbeg + kq < g.Kd ? kbeg + kq : g.Kd;
@@ -407,20 +407,22 @@ struct DbnLaunch {
   hipStream_t st;
   template <class F> void par(int n, F f) { if (n > 0) hipLaunchKernelGGL(k_dbn_par<F>, dim3((n + 255) / 256), dim3(256), 0, st, n, f); }
   template <class F> void col(int H, F f) { if (H > 0) hipLaunchKernelGGL(k_dbn_col<F>, dim3(H), dim3(64), 0, st, f); }
-  static int tiles(const DbnGemm& g, int* tn) { *tn = (g.N + 15) / 16; return ((g.M + 15) / 16) * *tn; }
-  void gemm(const DbnGemm& g1) {
+  static int tiles(const DbnGemm& g, int* tn) { *tn = (g.N + 15) / 16; return g.Kd > 0 ? ((g.M + 15) / 16) * *tn : 0; }
+  void launch(const DbnGemm* gs, int n) {   // up to three products nobody of which reads what another one writes
     DbnGemm2 G2;
-    G2.g[0] = g1; G2.g[1] = g1;
-    G2.tiles0 = tiles(g1, &G2.tn[0]); G2.tn[1] = G2.tn[0];
-    if (G2.tiles0 > 0 && g1.Kd > 0) hipLaunchKernelGGL(k_dbn_gemm, dim3(G2.tiles0), dim3(256), 0, st, G2);
+    int at = 0;
+    for (int i = 0; i < 3; ++i) {
+      G2.g[i] = gs[i < n ? i : 0];
+      G2.start[i] = at;
+      G2.tn[i] = 1;
+      if (i < n) at += tiles(gs[i], &G2.tn[i]);
+    }
+    G2.start[3] = at;
+    if (at > 0) hipLaunchKernelGGL(k_dbn_gemm, dim3(at), dim3(256), 0, st, G2);
   }
-  void gemm(const DbnGemm& g1, const DbnGemm& g2) {   // two products nobody of which reads what the other writes
-    DbnGemm2 G2;
-    G2.g[0] = g1; G2.g[1] = g2;
-    G2.tiles0 = tiles(g1, &G2.tn[0]);
-    const int t1 = tiles(g2, &G2.tn[1]);
-    if (G2.tiles0 + t1 > 0) hipLaunchKernelGGL(k_dbn_gemm, dim3(G2.tiles0 + t1), dim3(256), 0, st, G2);
-  }
+  void gemm(const DbnGemm& g1) { launch(&g1, 1); }
+  void gemm(const DbnGemm& g1, const DbnGemm& g2) { const DbnGemm gs[2] = {g1, g2}; launch(gs, 2); }
+  void gemm(const DbnGemm& g1, const DbnGemm& g2, const DbnGemm& g3) { const DbnGemm gs[3] = {g1, g2, g3}; launch(gs, 3); }
 };
 struct DiscBn {
   DbnNet N;
@@ -499,13 +501,17 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
     N.P = d->P; N.G = d->G; N.M = d->M; N.V = d->V;
     DbnWs& W = b->W;
     for (int l = 0; l < N.nblk && rc == ILSX_OK; ++l) {
-      float** mats[] = {&W.ch[l], &W.ah[l], &W.h[l], &W.p[l], &W.uh[l], &W.uy[l], &W.uah[l], &W.tt[l], &W.ua[l], &W.ybar[l], &W.ahbar[l]};
+      float** mats[] = {&W.ch[l], &W.ah[l], &W.h[l], &W.p[l], &W.gch[l], &W.gah[l], &W.gh[l], &W.gp[l], &W.uh[l], &W.uy[l], &W.uah[l], &W.tt[l], &W.ua[l],
+                        &W.ybar[l], &W.ahbar[l]};
       for (float** m : mats) if (rc == ILSX_OK) rc = A(m, rows * H);
-      float** vecs[] = {&W.s[l], &W.m2[l], &W.sbar[l]};
+      float** vecs[] = {&W.s[l], &W.gs[l], &W.m2[l], &W.sbar[l]};
       for (float** v : vecs) if (rc == ILSX_OK) rc = A(v, H);
     }
     if (rc == ILSX_OK) rc = A(&W.t0, rows * wd);
     if (rc == ILSX_OK) rc = A(&W.t1, rows * wd);
+    if (rc == ILSX_OK) rc = A(&W.gt0, rows * wd);
+    if (rc == ILSX_OK) rc = A(&W.gt1, rows * wd);
+    if (rc == ILSX_OK) rc = A(&W.bstat, (size_t)2 * N.nblk * 2 * H);
     float** rowv[] = {&W.logit, &W.dlogit, &W.gate, &W.ce_row, &W.correct, &W.gp_row, &b->lg};
     for (float** v : rowv) if (rc == ILSX_OK) rc = A(v, rows);
     if (rc == ILSX_OK) rc = A(&b->stats3, 4);
@@ -575,8 +581,9 @@ extern "C" int ilsx_disc_destroy(ilsx_disc* d) {
     DiscBn* b = d->bn;
     DbnWs& W = b->W;
     for (int l = 0; l < b->N.nblk; ++l)
-      for (float* p : {W.ch[l], W.ah[l], W.h[l], W.p[l], W.uh[l], W.uy[l], W.uah[l], W.tt[l], W.ua[l], W.ybar[l], W.ahbar[l], W.s[l], W.m2[l], W.sbar[l]}) ctx_free(d->ctx, p);
-    for (float* p : {W.t0, W.t1, W.logit, W.dlogit, W.gate, W.ce_row, W.correct, W.gp_row, b->lg, b->stats3, b->xcat, b->N.rmean, b->N.rvar}) ctx_free(d->ctx, p);
+      for (float* p : {W.ch[l], W.ah[l], W.h[l], W.p[l], W.gch[l], W.gah[l], W.gh[l], W.gp[l], W.gs[l], W.uh[l], W.uy[l], W.uah[l], W.tt[l], W.ua[l], W.ybar[l],
+                       W.ahbar[l], W.s[l], W.m2[l], W.sbar[l]}) ctx_free(d->ctx, p);
+    for (float* p : {W.t0, W.t1, W.gt0, W.gt1, W.bstat, W.logit, W.dlogit, W.gate, W.ce_row, W.correct, W.gp_row, b->lg, b->stats3, b->xcat, b->N.rmean, b->N.rvar}) ctx_free(d->ctx, p);
     delete b;
   }
   delete d;
@@ -879,8 +886,7 @@ static int discbn_step(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
   W.X = d->X; W.XH = d->X + 2 * (size_t)B * d->D;
   const int gp = d->cfg.use_grad_pen ? 1 : 0;
   dbn_backward(L, b->N, W, B, gp, d->cfg.grad_pen_weight);
-  dbn_stats(L, W, B, gp, b->stats3);
-  dbn_adam_step(L, b->N, d->cfg.disc_lr, d->cfg.disc_momentum, ++b->t);
+  dbn_finish(L, b->N, W, B, gp, b->stats3, d->cfg.disc_lr, d->cfg.disc_momentum, ++b->t);
   HIPCHK(hipGetLastError());
   if (stats) {
     float h3[3];

@@ -12,6 +12,7 @@ struct HostLaunch {
   template <class F> void col(int H, F f) { for (int j = 0; j < H; ++j) f(j, 0); }
   void gemm(const DbnGemm& g) { for (int i = 0; i < g.M; ++i) for (int j = 0; j < g.N; ++j) dbn_gemm_elem(g, i, j); }
   void gemm(const DbnGemm& g1, const DbnGemm& g2) { gemm(g1); gemm(g2); }
+  void gemm(const DbnGemm& g1, const DbnGemm& g2, const DbnGemm& g3) { gemm(g1); gemm(g2); gemm(g3); }
 };
 
 struct HostDisc {
@@ -36,10 +37,12 @@ extern "C" void* dbnh_create(int D, int H, int nblk, int act, float clampv, int 
   W.X = d->buf(n2 * D); W.XH = d->buf(n2 * D);
   for (int l = 0; l < nblk; ++l) {
     W.ch[l] = d->buf(n2 * H); W.ah[l] = d->buf(n2 * H); W.h[l] = d->buf(n2 * H); W.p[l] = d->buf(n2 * H); W.s[l] = d->buf(H);
+    W.gch[l] = d->buf(n2 * H); W.gah[l] = d->buf(n2 * H); W.gh[l] = d->buf(n2 * H); W.gp[l] = d->buf(n2 * H); W.gs[l] = d->buf(H);
     W.uh[l] = d->buf(n2 * H); W.uy[l] = d->buf(n2 * H); W.uah[l] = d->buf(n2 * H); W.tt[l] = d->buf(n2 * H); W.ua[l] = d->buf(n2 * H); W.m2[l] = d->buf(H);
     W.ybar[l] = d->buf(n2 * H); W.ahbar[l] = d->buf(n2 * H); W.sbar[l] = d->buf(H);
   }
-  W.t0 = d->buf(n2 * w); W.t1 = d->buf(n2 * w);
+  W.t0 = d->buf(n2 * w); W.t1 = d->buf(n2 * w); W.gt0 = d->buf(n2 * w); W.gt1 = d->buf(n2 * w);
+  W.bstat = d->buf((size_t)2 * nblk * 2 * H);
   W.logit = d->buf(n2); W.dlogit = d->buf(n2); W.gate = d->buf(n2); W.ce_row = d->buf(n2); W.correct = d->buf(n2); W.gp_row = d->buf(n2);
   return d;
 }
@@ -63,8 +66,7 @@ extern "C" int dbnh_train_step(void* h, const float* eo, const float* ea, const 
   float *X = d->W.X, *XH = use_gp ? d->W.XH : nullptr;
   L.par(B * d->N.D, [=](int idx) { dbn_prep(idx, eo, ea, po, pa, eps, X, XH, B, o, a); });
   dbn_backward(L, d->N, d->W, B, use_gp, gp_w);
-  dbn_stats(L, d->W, B, use_gp, stats3);
-  dbn_adam_step(L, d->N, lr, b1, ++d->t);
+  dbn_finish(L, d->N, d->W, B, use_gp, stats3, lr, b1, ++d->t);
   return 0;
 }
 extern "C" int dbnh_logits_eval(void* h, const float* x, int n, float* logits) {

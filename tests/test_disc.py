@@ -356,7 +356,8 @@ def test_hip_disc_bn_golden(ctx, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("o,a,Hd,B,act,L,gp", [(17, 6, 128, 256, "tanh", 2, True), (11, 3, 100, 64, "relu", 2, True), (17, 6, 64, 48, "tanh", 3, False)])
+@pytest.mark.parametrize("o,a,Hd,B,act,L,gp", [(17, 6, 128, 256, "tanh", 2, True), (11, 3, 100, 64, "relu", 2, True), (17, 6, 64, 48, "tanh", 3, False),
+                                             (11, 3, 64, 300, "tanh", 2, True)])   # 600 CE rows: a column is more than one 512-row batch (disc_bn.h DBN_U)
 def test_hip_disc_bn_vs_oracle(ctx, o, a, Hd, B, act, L, gp):
     """the same at the configs' sizes (GAIL Walker2d: 23 -> 128 -> 128 -> 1, B = 256) against oracle.DiscBNOracle, three chained steps,
     with the relabelled rewards of the eval-mode forward (adv_irl.py:268-301) after them"""

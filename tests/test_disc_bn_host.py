@@ -108,3 +108,40 @@ def test_device_phases_on_the_host_match_the_reference(hostlib, tag):
     assert lib.dbnh_logits_eval(h, p(probe), probe.shape[0], p(lg)) == 0
     _check_final(tag, params, rm, rv, steps, lg.reshape(-1, 1))
     lib.dbnh_destroy(h)
+
+
+@pytest.mark.parametrize("act,L,B,gp", [("tanh", 2, 70, True), ("relu", 3, 50, True), ("tanh", 1, 90, False)])
+def test_device_phases_on_the_host_match_the_oracle_on_multi_batch_columns(hostlib, act, L, B, gp):
+    """The column phases keep a column's rows in registers when they are ONE batch (n <= lanes x DBN_U; the host's single lane holds 64) and
+    walk them in batches otherwise: the reference vectors (<= 40 rows) take the first path, these sizes (2B = 100 .. 180 rows, B = 50 .. 90
+    interpolates) the second — against oracle.DiscBNOracle over three chained steps, with and without the gradient penalty."""
+    lib = hostlib
+    rng = np.random.default_rng(B + L)
+    o_dim, a_dim, Hd = 7, 3, 24
+    D = o_dim + a_dim
+    code = TANH if act == "tanh" else RELU
+    p0 = DiscBNOracle.init(rng, D, Hd, L)
+    kw = dict(KW, use_grad_pen=gp)
+    orc = DiscBNOracle(D, Hd, p0, act=code, num_layer_blocks=L, **kw)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    h = lib.dbnh_create(D, Hd, L, code, 10.0, B)
+    lib.dbnh_set_params(h, p(np.ascontiguousarray(p0, np.float32)))
+    for st in range(3):
+        xe, xp = rng.normal(0, 1, (B, D)).astype(np.float32), rng.normal(0.3, 1.4, (B, D)).astype(np.float32)
+        eps = rng.random(B).astype(np.float32)
+        eo, ea = np.ascontiguousarray(xe[:, :o_dim]), np.ascontiguousarray(xe[:, o_dim:])
+        po, pa = np.ascontiguousarray(xp[:, :o_dim]), np.ascontiguousarray(xp[:, o_dim:])
+        stats = np.zeros(3, np.float32)
+        assert lib.dbnh_train_step(h, p(eo), p(ea), p(po), p(pa), p(eps), B, o_dim, a_dim, int(gp), KW["grad_pen_weight"], KW["disc_lr"],
+                                   KW["disc_momentum"], p(stats)) == 0
+        grad = np.empty(p0.size, np.float32)
+        lib.dbnh_get(h, None, p(grad), None, None)
+        res = orc.train_step(xe, xp, eps.reshape(B, 1))
+        live = ~orc.dead_bias_mask()
+        assert np.abs(grad - res["grad"])[live].max() <= 1e-4 * np.abs(res["grad"]).max(), (act, L, B, st)
+    params, rm, rv = np.empty(p0.size, np.float32), np.empty((L, Hd), np.float32), np.empty((L, Hd), np.float32)
+    lib.dbnh_get(h, p(params), None, p(rm), p(rv))
+    live = ~orc.dead_bias_mask()
+    assert np.abs(params - orc.p)[live].max() < 5e-5
+    np.testing.assert_allclose(rv, np.stack(orc.rv), rtol=1e-4, atol=1e-5)
+    lib.dbnh_destroy(h)
