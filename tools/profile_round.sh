@@ -3,10 +3,11 @@
 # graph launches here), the PMC passes (regenerated every round: bench.py reads the newest summary for roofline.traffic), the
 # per-launch timeline of the SAC step and the stage timers of the 3-D stepper -> gpurun_out/prof_<tag>/; copy into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
+python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
 timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 600 python bench_aux.py td3 seeds > $OUT/bench_aux.log 2>&1
 ILSX_NO_PHASE=1 timeout 200 python tools/step_gantt.py > $OUT/step_gantt_8launch.txt 2>&1
@@ -14,9 +15,13 @@ timeout 200 python tools/phase_gantt.py > $OUT/phase_gantt.txt 2>&1
 timeout 200 python tools/rollout_overhead.py 4096 > $OUT/rollout_overhead.txt 2>&1
 timeout 100 python tools/rollout_overhead.py 8192 >> $OUT/rollout_overhead.txt 2>&1
 (cd tools/ubench && timeout 60 ./tilesync) > $OUT/tilesync.txt 2>&1
-# the split-run leg on a one-rank communicator (three graph segments + two all-reduces), and the same with direct launches
-ILSX_SPLIT_SEGMENTS=1 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='graph segments', **(d.get('split_run') or {}))))" > $OUT/split_run_1rank.jsonl 2>&1
-ILSX_SPLIT_SEGMENTS=0 ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='direct launches', **(d.get('split_run') or {}))))" >> $OUT/split_run_1rank.jsonl 2>&1
+# the split-run leg on a one-rank communicator in its four forms: merged phase kernels (default since round 5), one launch per stage, graph
+# segments between the two all-reduces, the whole step with the collective in one capture
+: > $OUT/split_run_1rank.jsonl
+for form in "phase_kernels:ILSX_SPLIT_SEGMENTS=0" "one_launch_per_stage:ILSX_SPLIT_NO_PHASE=1" "graph_segments:ILSX_SPLIT_SEGMENTS=1" "whole_step_graph:ILSX_SPLIT_GRAPH=1"; do
+  label=${form%%:*}; kv=${form#*:}
+  env $kv ILSX_BENCH_FORCE_DIST=1 timeout 300 python bench.py --no-aux --no-cpu-baseline --no-seeds --steps 5 --warmup 2 2> /dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(form='$label', **(d.get('split_run') or {}))))" >> $OUT/split_run_1rank.jsonl 2>&1
+done
 timeout 120 python tools/discbn_rate.py > $OUT/discbn_rate.txt 2>&1
 timeout 200 bash tools/ppo_ab.sh ILSX_DW_BIG=1 ILSX_DW_BIG=0 > $OUT/ppo_ab.txt 2>&1
 for u in mfma_peak mfma_valu_overlap; do [ -x tools/ubench/$u ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2> /dev/null; done
