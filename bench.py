@@ -95,6 +95,32 @@ def pmc_traffic(kid):
     return None
 
 
+def grouped_insts_per_mfma():
+    """Non-MFMA instructions a wave of the grouped (K = 8) lock-step kernels issues per MFMA, per kernel family, from the newest committed
+    counter summary of tools/pmc_grp.sh (profiles/rNN_grppmc_summary.json: SQ_INSTS_{VALU, SALU, LDS, SMEM, VMEM_RD, VMEM_WR, MFMA} summed over
+    all waves of all launches).  On this part fp32 MFMA time and the VALU / LDS / memory issue of the same SIMD ADD, so this
+    ratio — not occupancy — is what the launches' length is made of."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_grppmc_summary.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+    except OSError:
+        return None
+    out = dict(source=os.path.relpath(files[-1], ROOT), stale=d.get("_meta", {}).get("csrc_sha256") != csrc_sha256())
+    for k in ("k_mlp2_fwd_split", "k_mlp2_bwd_split", "k_mlp_bwd_dw"):
+        v = d.get(k)
+        if not v or not v.get("SQ_INSTS_MFMA"):
+            continue
+        mf = v["SQ_INSTS_MFMA"]
+        other = v.get("SQ_INSTS_VALU", 0.0) - mf + sum(v.get(c, 0.0) for c in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+        out[k] = dict(non_mfma_per_mfma=other / mf, salu_per_wave=v.get("SQ_INSTS_SALU", 0.0) / max(1.0, v.get("SQ_WAVES", 1.0)),
+                      mfma_per_wave=mf / max(1.0, v.get("SQ_WAVES", 1.0)))
+    return out
+
+
 def co_resident_seeds(K=8, n=1500):
     """SURVEY config 5's per-GPU shape ("several seeds per GPU"): K independent SAC runs of the same config stepped in
     lock-step by ilsx_sac_group (one launch per stage for all of them).  Reported beside the headline, never as `value`.
@@ -132,6 +158,7 @@ def co_resident_seeds(K=8, n=1500):
     fl = K * flops_per_step()[0] / (nl.value / 100.0)
     avg_s = ms.value * 1e-3 / nl.value
     out = dict(K=K, aggregate_grad_steps_per_s=K * n / dt, per_run_grad_steps_per_s=n / dt, us_per_lockstep=1e6 * dt / n,
+               insts_per_mfma=grouped_insts_per_mfma(),
                roofline=dict(bound="mfma", kernel=kernel_spelling(c.lib, c, 0), achieved=fl / avg_s / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
                              unit="TFLOP/s", frac=fl / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_us=avg_s * 1e6,
                              algorithmic_flop_per_launch=fl))

@@ -159,7 +159,13 @@ def bench_ppo(ctx):
     # memory-side bytes per launch of that kernel at 32768-row minibatches, from the newest committed counter summary (tools/pmc_ppo.sh)
     try:
         src = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_ppopmc_summary.json")))[-1]
-        rows = json.load(open(src)).get(roof["kernel"].split("<")[0], [])
+        summ = json.load(open(src))
+        rows = summ.get(roof["kernel"].split("<")[0], [])
+        try:   # do the counters describe the kernels this run executes?  (tools/pmc_ppo.sh records the hash of the library's sources)
+            from bench import csrc_sha256
+            roof["traffic_stale"] = summ.get("_meta", {}).get("csrc_sha256") != csrc_sha256()
+        except Exception:
+            roof["traffic_stale"] = None
         if rows:
             mb = min(rows, key=lambda r: r["grid"])     # the minibatch launches (calc_adv's 1M-row forwards have the larger grid)
             roof["traffic"] = mb["read_bytes"] + mb["written_bytes"]

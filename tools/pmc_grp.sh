@@ -4,7 +4,7 @@
 # r04_mfma_overlap.txt), so instructions per wave, not occupancy, are what the launch time is made of.
 #   bash tools/pmc_grp.sh <tag> [task] [K]   (on the GPU box, from the repo root)  ->  gpurun_out/grppmc_<tag>/summary.json
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 TASK=${2:-hopper}
 K=${3:-8}
 ROOT=$(pwd)
