@@ -16,6 +16,8 @@ for f in $(find logs -name progress.csv); do
   d=$(dirname $f)
   s=$(echo $d | sed -n 's/.*--s-\([0-9]*\).*/\1/p')
   cp $f $OUT/seed$s.csv
+  # KEEP_SNAPSHOTS=1: the run's last periodic snapshot (policy, critics, optimiser state) too — tools/eval_snapshot_cpu.py plays its policy in the CPU stepper
+  if [ "${KEEP_SNAPSHOTS:-0}" = 1 ] && [ -f $d/params.pkl ]; then cp $d/params.pkl $OUT/seed$s.params.pkl; fi
 done
 OUT=$OUT python - <<'PY'
 import csv, glob, os
