@@ -92,6 +92,7 @@ struct ilsx_sac {
   bool phase_last = false;           // the last window of steps ran on the phase kernels
   bool debug_break = false;          // ilsx_sac_debug_break_phase
   int phase_fallbacks = 0;           // windows rolled back and re-run (ilsx_sac_phase_state)
+  float* vote = nullptr;             // split run: the ranks' agreement on a roll-back (sac_phase_check), one device float
   bool snap_valid = false;           // the checkpoint belongs to the window now running (set by sac_snapshot_take, cleared when the window ends)
   void* snap = nullptr;              // checkpoint of [scal | P | G | M | V] taken at the start of every window that may run on the phase kernels
   size_t snap_bytes = 0;
@@ -348,6 +349,7 @@ extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
   for (hipGraphExec_t& g : s->seg_graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
   if (s->tail_dev) ctx_free(s->ctx, s->tail_dev);
   if (s->snap) ctx_free(s->ctx, s->snap);
+  if (s->vote) ctx_free(s->ctx, s->vote);
   // give the networks private storage back so their handles stay usable
   ilsx_net* nets[3] = {s->pi, s->q1, s->q2};
   const int wh[3] = {W_PI, W_Q1, W_Q2};
@@ -911,13 +913,25 @@ static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who) {
     for (int t = 0; t < PHASE_MAX_TILES; ++t)
       if (masks[t * 32] & (masks[t * 32] - 1)) err |= 2;   // a tile's workgroups ran on more than one XCD: its exchange went through two L2s
     if (s->debug_break) { err |= 1; s->debug_break = false; }
+    if (sac_is_split(s) && s->ctx->comm && s->ctx->comm_n > 1) {
+      // a split run rolls back on EVERY rank or on none: a window re-run on one rank alone would issue collectives the others never join.
+      // One float per rank through the run's own communicator, once per window (not per step); nothing to vote on at one rank.
+      if (!s->vote) ILSX_TRY(ctx_alloc(s->ctx, 4 * sizeof(float), (void**)&s->vote, true));
+      float v = err ? 1.0f : 0.0f;
+      HIPCHK(hipMemcpyAsync(s->vote, &v, sizeof v, hipMemcpyHostToDevice, st));
+      ILSX_TRY(comm_allreduce_sum(s->ctx, s->vote, 1));
+      HIPCHK(hipMemcpyAsync(&v, s->vote, sizeof v, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (v > 0.0f) err |= 4;   // some rank's hand-offs broke: this rank rolls back with it (the two paths are bit-identical)
+    }
     if (err) {
       s->phase_broken = true;
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
       HIPCHK(hipMemsetAsync(s->phase_err, 0, sizeof(int), st));
       if (getenv("ILSX_PHASE_VERBOSE"))
         fprintf(stderr, "[ilsx] %s: a merged phase kernel %s; the window is rolled back and re-run, this agent stays on one launch per stage\n", who,
-                (err & 1) ? "timed out waiting for the workgroups of its tile (other kernels sharing this GPU?)" : "found the workgroups of one row tile on different XCDs");
+                (err & 1) ? "timed out waiting for the workgroups of its tile (other kernels sharing this GPU?)"
+                : (err & 2) ? "found the workgroups of one row tile on different XCDs" : "broke on another rank of this split run");
       s->phase_fallbacks += 1;
       return ILSX_RETRY_WINDOW;   // snap_valid stays set: sac_snapshot_restore consumes it
     }
