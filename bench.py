@@ -75,7 +75,7 @@ def pmc_traffic_stale():
     try:
         with open(PMC_SUMMARY) as f:
             return json.load(f).get("_meta", {}).get("csrc_sha256") != csrc_sha256()
-    except (OSError, TypeError):
+    except (OSError, TypeError, ValueError, AttributeError):   # absent, unreadable or malformed: the line must come out
         return None
 
 
@@ -86,7 +86,9 @@ def pmc_traffic(kid):
     try:
         with open(PMC_SUMMARY) as f:
             d = json.load(f)
-    except (OSError, TypeError):
+    except (OSError, TypeError, ValueError):
+        return None
+    if not isinstance(d, dict):
         return None
     for name in PMC_NAMES.get(kid, ()):
         k = d.get(name)
@@ -107,7 +109,9 @@ def grouped_insts_per_mfma():
     try:
         with open(files[-1]) as f:
             d = json.load(f)
-    except OSError:
+    except (OSError, ValueError):
+        return None
+    if not isinstance(d, dict):
         return None
     out = dict(source=os.path.relpath(files[-1], ROOT), stale=d.get("_meta", {}).get("csrc_sha256") != csrc_sha256())
     for k in ("k_mlp2_fwd_split", "k_mlp2_bwd_split", "k_mlp_bwd_dw"):

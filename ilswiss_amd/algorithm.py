@@ -162,6 +162,23 @@ class DeviceRLAlgorithm:
             self._t_eval = time.perf_counter() - t0
             self.trainer.end_epoch()
 
+    # ---- the pieces of one off-policy epoch (base_algorithm.py:183-286), shared by train() and DeviceRLAlgorithmGroup
+    def _vec_step(self):
+        """One sampling iteration of all envs: policy -> physics -> replay record -> auto-reset, enqueued (no host wait)."""
+        random_actions = self.replay_buffer.num_steps_can_sample() < self.min_steps_before_training
+        self.training_env.rollout_step(self.exploration_policy, self.replay_buffer, self.max_path_length,
+                                       random_actions=random_actions, no_terminal=self.no_terminal,
+                                       label_policy=getattr(self.trainer, "expert_policy", None))
+        self._n_env_steps_total += self.env_num
+
+    def _train_due(self):
+        return self._n_env_steps_total - self._n_prev_train_env_steps >= self.num_steps_between_train_calls
+
+    def _count_train_call(self):
+        self._n_prev_train_env_steps = self._n_env_steps_total   # _try_to_train (base_algorithm.py:293-299): the gate only advances when training ran
+        self._n_train_steps_total += 1                                   # the reference counts CALLS here (:298)
+        self._n_grad_steps_total += self.num_train_steps_per_train_call
+
     def train(self, start_epoch=0):
         if self.on_policy:
             return self._train_on_policy(start_epoch)
@@ -173,20 +190,14 @@ class DeviceRLAlgorithm:
             self.training_env.rollout_stats(reset=True)
             for _ in range(self.num_env_steps_per_epoch // self.env_num):
                 t0 = time.perf_counter()
-                random_actions = self.replay_buffer.num_steps_can_sample() < self.min_steps_before_training
-                self.training_env.rollout_step(self.exploration_policy, self.replay_buffer, self.max_path_length,
-                                               random_actions=random_actions, no_terminal=self.no_terminal,
-                                               label_policy=getattr(self.trainer, "expert_policy", None))
-                self._n_env_steps_total += self.env_num
-                if self._n_env_steps_total - self._n_prev_train_env_steps >= self.num_steps_between_train_calls:
+                self._vec_step()
+                if self._train_due():
                     ctx.sync()
                     t1 = time.perf_counter()
                     self._t_sample += t1 - t0
-                    if self._can_train():   # _try_to_train (base_algorithm.py:293-299): the gate only advances when training ran
-                        self._n_prev_train_env_steps = self._n_env_steps_total
+                    if self._can_train():
+                        self._count_train_call()
                         self.trainer.train_from_replay(self.replay_buffer, self.num_train_steps_per_train_call, self.batch_size)
-                        self._n_train_steps_total += 1                                   # the reference counts CALLS here (:298)
-                        self._n_grad_steps_total += self.num_train_steps_per_train_call
                         ctx.sync()
                     self._t_train += time.perf_counter() - t1
                 else:
@@ -275,6 +286,108 @@ class DeviceRLAlgorithm:
                   "_n_prev_train_env_steps", "best_statistic_so_far"):
             if k in extra:
                 setattr(self, k, extra[k])
+
+
+class DeviceRLAlgorithmGroup:
+    """K independent off-policy runs (seeds) of one experiment advanced in lock-step by ONE process on ONE GPU — what the reference does with K
+    worker processes per GPU (run_experiment.py:57-78), here with every stage of the gradient step being one launch for all K runs
+    (SoftActorCriticGroup / ilsx_sac_group, SURVEY section 8e "co-resident seeds").  Every run stays an ordinary DeviceRLAlgorithm with its own
+    envs, replay ring, trainer, sibling context (its own Philox key and stream ids) and log directory: progress.csv / variant.json / params.pkl
+    per seed, as K separate processes would write them (launcher_util.py:209-297).  The arithmetic of a run does not depend on its company
+    (tests/test_hip_parity.py::test_sac_group_lockstep_is_bitwise_the_independent_runs), so the non-time columns of every progress.csv are the
+    ones its single-process run writes (tests/test_loop_hip.py::test_grouped_run_script_writes_the_single_run_logs).
+
+    The K runs share the schedule (epochs, steps per epoch, env_num, train trigger); whether a run CAN train at a trigger is its own matter
+    (`insert_at_episode_end`: its ring fills when ITS episodes end) — runs that cannot yet are skipped, exactly as their own process would.
+    Trainers that are not SoftActorCritic (or differ in shape) are stepped one after the other on the shared stream.  The time columns are the
+    group's wall time for the phase (all K runs advance in it)."""
+
+    SCHEDULE = ("num_epochs", "num_env_steps_per_epoch", "env_num", "num_steps_between_train_calls", "num_train_steps_per_train_call",
+                "batch_size", "on_policy")
+
+    def __init__(self, algorithms):
+        self.algs = list(algorithms)
+        if not self.algs:
+            raise ValueError("DeviceRLAlgorithmGroup: no runs")
+        a0 = self.algs[0]
+        for a in self.algs[1:]:
+            for k in self.SCHEDULE:
+                if getattr(a, k) != getattr(a0, k):
+                    raise ValueError(f"DeviceRLAlgorithmGroup: the runs of a group share one schedule; {k} differs ({getattr(a, k)} vs {getattr(a0, k)})")
+        if a0.on_policy:
+            raise NotImplementedError("DeviceRLAlgorithmGroup steps off-policy runs (the on-policy branch is one device pipeline per run)")
+        self.ctx = a0.trainer.ctx
+        self._groups = {}   # subset of run indices -> SoftActorCriticGroup (the whole set in steady state; subsets only while rings fill)
+
+    def _groupable(self, idx):
+        from .sac import SoftActorCritic
+        trs = [self.algs[i].trainer for i in idx]
+        if len(trs) < 2 or not all(type(t) is SoftActorCritic for t in trs):
+            return False
+        t0 = trs[0]
+        sig = lambda t: (t.policy.obs_dim, t.policy.action_dim, tuple(t.policy.hidden_sizes), tuple(t.qf1.hidden_sizes), t.max_batch,  # noqa: E731
+                         t.reward_scale, t.discount)
+        return all(sig(t) == sig(t0) for t in trs) and len(t0.policy.hidden_sizes) == 2 and getattr(t0, "grad_world", 1) == 1
+
+    def _train(self, idx):
+        a0 = self.algs[0]
+        n, B = a0.num_train_steps_per_train_call, a0.batch_size
+        key = tuple(idx)
+        if key not in self._groups:
+            grp = None
+            if self._groupable(idx):
+                from .sac import SoftActorCriticGroup
+                try:
+                    grp = SoftActorCriticGroup([self.algs[i].trainer for i in idx], ctx=self.ctx)
+                except Exception as e:   # noqa: BLE001 — shapes the grouped kernels do not take: one run after the other, and say so
+                    print(f"DeviceRLAlgorithmGroup: runs {list(idx)} are stepped one by one ({e})", flush=True)
+            self._groups[key] = grp
+        grp = self._groups[key]
+        for i in idx:
+            self.algs[i]._count_train_call()
+        if grp is not None:
+            grp.train_from_replay([self.algs[i].replay_buffer for i in idx], n, B)
+        else:
+            for i in idx:
+                self.algs[i].trainer.train_from_replay(self.algs[i].replay_buffer, n, B)
+
+    def train(self, start_epoch=0):
+        algs, ctx, a0 = self.algs, self.ctx, self.algs[0]
+        t_start = time.perf_counter()
+        for epoch in range(start_epoch, a0.num_epochs + 1):
+            t_epoch = time.perf_counter()
+            t_sample = t_train = 0.0
+            for a in algs:
+                a.training_env.rollout_stats(reset=True)
+            for _ in range(a0.num_env_steps_per_epoch // a0.env_num):
+                t0 = time.perf_counter()
+                for a in algs:
+                    a._vec_step()
+                due = [i for i, a in enumerate(algs) if a._train_due()]
+                if due:
+                    ctx.sync()
+                    t1 = time.perf_counter()
+                    t_sample += t1 - t0
+                    can = [i for i in due if algs[i]._can_train()]
+                    if can:
+                        self._train(can)
+                        ctx.sync()
+                    t_train += time.perf_counter() - t1
+                else:
+                    t_sample += time.perf_counter() - t0
+            ctx.sync()
+            for a in algs:
+                a._t_sample, a._t_train = t_sample, t_train
+                t0 = time.perf_counter()
+                a.evaluate(epoch, time.perf_counter() - t_epoch, time.perf_counter() - t_start)
+                a._t_eval = time.perf_counter() - t0
+                a.trainer.end_epoch()
+
+    def close(self):
+        for g in self._groups.values():
+            if g is not None:
+                g.close()
+        self._groups = {}
 
 
 def setup_log_dir(exp_name, exp_id, seed, variant, base_dir="logs"):

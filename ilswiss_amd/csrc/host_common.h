@@ -43,6 +43,7 @@ struct ilsx_ctx {
   bool own_stream = false;
   uint64_t seed = 0;
   uint32_t next_rng_stream = 1;
+  unsigned long long act_calls = 0, ppo_act_calls = 0;   // Philox counters of ilsx_policy_act / ilsx_ppo_policy_act (one draw per call)
   std::vector<void*> allocs;
   // small reusable staging buffer for host->device row uploads
   void* stage = nullptr;
@@ -166,7 +167,7 @@ int sac_step_staged(ilsx_sac* s, ilsx_sac_stats* stats);
 int sac_dims(const ilsx_sac* s, int* o, int* a);
 int sac_window_begin(ilsx_sac* s, int B);   // steps on staged batches with the deferred tail + phase kernels (ilsx_sac.hip)
 int sac_window_step(ilsx_sac* s);
-int sac_window_end(ilsx_sac* s);            // ILSX_RETRY_WINDOW: the window's phase kernels reported a broken hand-off — roll back and re-run
+int sac_window_end(ilsx_sac* s, bool teardown = false);   // teardown: closing on an error path (no roll-back vote, no retry); ILSX_RETRY_WINDOW: the window's phase kernels reported a broken hand-off — roll back and re-run
 // internal status (never crosses the C ABI): a window of steps that ran on the merged phase kernels has to be rolled back
 // (sac_snapshot_restore) and run again; the agent has switched itself to one launch per stage
 #define ILSX_RETRY_WINDOW (-1000)

@@ -39,6 +39,24 @@ int ctx_free(ilsx_ctx* c, void* p) {
   if (it == c->allocs.end()) ILSX_FAIL(ILSX_ERR_ARG, "ctx_free: pointer not owned by this ctx");
   c->allocs.erase(it);
   HIPCHK(hipStreamSynchronize(c->stream));
+  // row-range slabs of split weight-gradient launches are keyed by the gradient range they belong to (launch_bwd_dw): when the allocation
+  // holding that range goes, so do they — hipMalloc hands the address to the next trainer, whose table (same span, another live / padding
+  // layout) must not inherit this one's nonzero words, and a destroyed trainer's slabs should not stay allocated until the ctx goes
+  hipDeviceptr_t base = nullptr; size_t size = 0;
+  if (!c->dw_scratch.empty() && hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess) {
+    for (size_t i = 0; i < c->dw_scratch.size();) {
+      const char* k = (const char*)c->dw_scratch[i].key;
+      if (k >= (const char*)base && k < (const char*)base + size) {
+        void* sp = c->dw_scratch[i].p;
+        c->dw_scratch.erase(c->dw_scratch.begin() + i);
+        if (sp) {
+          auto js = std::find(c->allocs.begin(), c->allocs.end(), sp);
+          if (js != c->allocs.end()) c->allocs.erase(js);
+          HIPCHK(hipFree(sp));
+        }
+      } else ++i;
+    }
+  }
   HIPCHK(hipFree(p));
   return ILSX_OK;
 }
@@ -895,7 +913,6 @@ extern "C" int ilsx_policy_act(ilsx_net* pi, const float* obs, int nrows, int de
   if (pi->lay.cfg.n_heads != 2 && !pi->noise_policy)
     ILSX_FAIL(ILSX_ERR_ARG, "ilsx_policy_act: network has %d heads (need mean|log_std, or a noise policy)", pi->lay.cfg.n_heads);
   HIPCHK(hipSetDevice(pi->ctx->device));
-  static unsigned long long act_calls = 0;
   FwdArgs A;
   memset(&A, 0, sizeof A);
   FwdTask& t = A.t[0];
@@ -913,7 +930,7 @@ extern "C" int ilsx_policy_act(ilsx_net* pi, const float* obs, int nrows, int de
   t.rng_stream = 0x41435400u;  // 'ACT'
   A.rows = nrows; A.ntasks = 1; A.seed = pi->ctx->seed;
   A.scal = nullptr;
-  A.step_host = ++act_calls;
+  A.step_host = ++pi->ctx->act_calls;   // per ctx, not per process: a run keeps its noise stream whatever else lives in the process (grouped runs)
   return launch_fwd(pi->ctx, A, pi->lay.cfg.hidden, pi->lay.cfg.act, pi->lay.KP);
 }
 

@@ -1036,7 +1036,7 @@ static int advirl_train_once(ilsx_disc* d, ilsx_sac* sac, ilsx_replay* expert_rb
   bool first_disc = true, first_pol = true, in_window = false;
   static const bool no_window_env = getenv("ILSX_ADVIRL_NO_WINDOW") != nullptr;
   const bool no_window = no_window_env || d->bn != nullptr;   // (the BatchNorm discriminator's state is not part of the window checkpoint)
-  struct WindowGuard { ilsx_sac* s; bool* on; ~WindowGuard() { if (*on) sac_window_end(s); } } window_guard{sac, &in_window};   // error paths
+  struct WindowGuard { ilsx_sac* s; bool* on; ~WindowGuard() { if (*on) sac_window_end(s, /*teardown=*/true); } } window_guard{sac, &in_window};   // error paths
   for (int it = 0; it < loops; ++it) {
     for (int k = 0; k < disc_updates; ++k) {   // adv_irl.py:133-216
       ILSX_TRY(disc_train_step_from_rings(d, expert_rb, policy_rb, disc_batch, first_disc ? disc_stats : nullptr));

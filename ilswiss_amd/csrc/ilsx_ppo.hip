@@ -537,10 +537,9 @@ extern "C" int ilsx_ppo_policy_act(ilsx_ppo* p, const float* obs, int n, int det
                                    float* logp) {
   if (!p || !obs || !act || n < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_policy_act: bad argument");
   HIPCHK(hipSetDevice(p->ctx->device));
-  static unsigned long long calls = 0;
   FwdArgs A;
   memset(&A, 0, sizeof A);
-  A.rows = n; A.ntasks = 1; A.seed = p->ctx->seed; A.step_host = ++calls;
+  A.rows = n; A.ntasks = 1; A.seed = p->ctx->seed; A.step_host = ++p->ctx->ppo_act_calls;
   FwdTask& t = A.t[0];
   ppo_fwd_task(t, p->Lp, p->Pp, obs, p->o);
   if (deterministic) { t.head = HEAD_RAW; t.out = act; t.out_cols = p->a; }   // action = mean (policies.py:407-408): the first a head outputs

@@ -83,6 +83,7 @@ struct ilsx_sac {
   bool defer_tail = false;
   TailLite* tail_dev = nullptr;
   int tail_B = 0;
+  ilsx_sac_stats stats_cache; bool stats_cached = false;   // last statistics read from the device (sac_read_stats), for ilsx_sac_last_stats
   bool tail_split = false;           // the uploaded TailLite record was built for a split run (slot_given)
   // merged phase kernels (kernels.h k_sac_phase_a / _c): F1 F2 B1 and F3 B2 B3 as one launch each inside train_from_replay
   unsigned* phase_flags = nullptr;   // PHASE_NFLAGS arrival counters, one 128-byte line each (zeroed by the dW launches)
@@ -688,15 +689,37 @@ static TailLite sac_tail_lite(ilsx_sac* s, int B) {
 // (6 launches + 2 collectives; the tail rides in the next step's A and applies the all-reduced alpha gradient, TailLite::slot_given).
 // Without the phase kernels (ILSX_NO_PHASE, ILSX_SPLIT_NO_PHASE, graph segments, a grid that does not fit) it keeps the un-deferred
 // one-launch-per-stage sequence with k_sac_stats / k_sac_finish.
-static bool sac_split_on_phase(ilsx_sac* s, int B) {
+// Above one rank the phase-kernel form is OPT-IN (ILSX_SPLIT_PHASE=1): its deferred tail fed from the all-reduced alpha slot and its
+// per-window roll-back vote have only ever run on a one-rank communicator (ILSX_SPLIT_FORCE), so a multi-rank run takes the plain
+// one-launch-per-stage sequence unless asked.  When asked, the ranks AGREE on it once per window — the predicate rests on device_cus, kernel
+// occupancy and environment variables, which need not match across ranks, and one rank deciding differently would deadlock the job inside
+// RCCL: every rank contributes "I cannot" (0 / 1) to a one-float all-reduce and the window runs on the phase kernels only if nobody said so.
+static int sac_split_on_phase(ilsx_sac* s, int B, bool* on) {
   static const bool segments = []() { const char* e = getenv("ILSX_SPLIT_SEGMENTS"); return e && atoi(e) != 0; }();
-  return getenv("ILSX_SPLIT_NO_PHASE") == nullptr && !segments && sac_window_may_use_phase(s, B);
+  const bool mine = getenv("ILSX_SPLIT_NO_PHASE") == nullptr && !segments && sac_window_may_use_phase(s, B);
+  *on = mine;
+  if (!(s->ctx->comm && s->ctx->comm_n > 1)) return ILSX_OK;
+  if (getenv("ILSX_SPLIT_PHASE") == nullptr) { *on = false; return ILSX_OK; }
+  hipStream_t st = s->ctx->stream;
+  if (!s->vote) ILSX_TRY(ctx_alloc(s->ctx, 4 * sizeof(float), (void**)&s->vote, true));
+  float v = mine ? 0.0f : 1.0f;
+  HIPCHK(hipMemcpyAsync(s->vote, &v, sizeof v, hipMemcpyHostToDevice, st));
+  ILSX_TRY(comm_allreduce_sum(s->ctx, s->vote, 1));
+  HIPCHK(hipMemcpyAsync(&v, s->vote, sizeof v, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *on = v == 0.0f;
+  return ILSX_OK;
 }
 static int sac_defer_begin(ilsx_sac* s, int B) {
   static const bool off = getenv("ILSX_NO_DEFER_TAIL") != nullptr || getenv("ILSX_NO_FUSE") != nullptr;
   s->defer_tail = false;
   const bool split = sac_is_split(s);
-  if (off || s->cs <= 1 || s->col || (split && !sac_split_on_phase(s, B))) return ILSX_OK;
+  if (off || s->cs <= 1 || s->col) return ILSX_OK;
+  if (split) {
+    bool on = false;
+    ILSX_TRY(sac_split_on_phase(s, B, &on));
+    if (!on) return ILSX_OK;
+  }
   if (!s->tail_dev) ILSX_TRY(ctx_alloc(s->ctx, sizeof(TailLite), (void**)&s->tail_dev));
   if (s->tail_B != B || s->tail_split != split) {
     const TailLite t = sac_tail_lite(s, B);
@@ -768,6 +791,7 @@ static int sac_read_stats(ilsx_sac* s, ilsx_sac_stats* out) {
   out->policy_mu_mean = h.mu_mean; out->policy_log_std_mean = h.log_std_mean;
   out->log_alpha = h.log_alpha;
   for (int i = 0; i < 5; ++i) { out->ext_std[i] = h.ext_std[i]; out->ext_max[i] = h.ext_max[i]; out->ext_min[i] = h.ext_min[i]; }
+  s->stats_cache = *out; s->stats_cached = true;   // what ilsx_sac_last_stats hands out: the statistics as they stood right after THEIR step
   return ILSX_OK;
 }
 
@@ -816,7 +840,7 @@ int sac_dims(const ilsx_sac* s, int* o, int* a) { *o = s->o; *a = s->a; return I
 // A window of steps on batches the caller stages in place (sac_staged_batch): the deferred tail and the merged phase kernels, as inside
 // one ilsx_sac_train_from_replay call — the rows just come from the batch arrays instead of the in-kernel replay draw.
 static bool sac_phase_ok(ilsx_sac* s, int B);
-static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who);
+static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who, bool teardown = false);
 int sac_window_begin(ilsx_sac* s, int B) {
   ILSX_TRY(sac_check_world(s, "ilsx_advirl_train"));
   s->B = B; s->eps_explicit = false;
@@ -830,11 +854,11 @@ int sac_window_step(ilsx_sac* s) {
   s->phase_now = false;
   return rc;
 }
-int sac_window_end(ilsx_sac* s) {
+int sac_window_end(ilsx_sac* s, bool teardown) {
   const bool deferred = s->defer_tail;
   s->defer_tail = false;
   ILSX_TRY(sac_flush_tail(s, deferred));
-  return sac_phase_check(s, s->B, deferred, "ilsx_advirl_train");
+  return sac_phase_check(s, s->B, deferred, "ilsx_advirl_train", teardown);
 }
 
 #define SAC_PHASE(name, fn)                                                        \
@@ -842,6 +866,7 @@ int sac_window_end(ilsx_sac* s) {
     if (!s) ILSX_FAIL(ILSX_ERR_ARG, #name ": NULL agent");                         \
     if (s->B < 1) ILSX_FAIL(ILSX_ERR_STATE, #name ": no batch staged (ilsx_sac_set_batch)"); \
     HIPCHK(hipSetDevice(s->ctx->device));                                          \
+    s->stats_cached = false; /* phases driven by hand: ilsx_sac_last_stats reads the device */ \
     return fn(s);                                                                  \
   }
 SAC_PHASE(ilsx_sac_critic_backward, sac_critic_backward)
@@ -852,6 +877,9 @@ SAC_PHASE(ilsx_sac_actor_update, sac_actor_update)
 extern "C" int ilsx_sac_last_stats(ilsx_sac* s, ilsx_sac_stats* stats) {
   if (!s || !stats) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_last_stats: NULL argument");
   HIPCHK(hipSetDevice(s->ctx->device));
+  // the statistics of the step that was asked for them (the first batch of a grouped call), not whatever later steps left in the device
+  // scalars: "Alpha" is the temperature after that step's own update (sac_alpha.py:160-166,208-212), and every later step moves it
+  if (s->stats_cached) { *stats = s->stats_cache; return ILSX_OK; }
   return sac_read_stats(s, stats);
 }
 
@@ -901,9 +929,13 @@ bool sac_window_may_use_phase(ilsx_sac* s, int B) { return !s->phase_broken && s
 // After a window of steps that may have run on the merged phase kernels: a workgroup that gave up waiting, or a row tile whose workgroups
 // sat on two XCDs, left a mark — the window's updates are then not to be trusted.  Returns ILSX_RETRY_WINDOW: the caller rolls the window
 // back (sac_snapshot_restore) and runs it again; the agent stays on one launch per stage from here on.
-static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who) {
+static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who, bool teardown) {
   hipStream_t st = s->ctx->stream;
-  if (deferred && s->snap_valid) {   // == the window began with sac_window_may_use_phase (the one predicate: the checkpoint is taken under it)
+  // every exit but the retry ends the window: its checkpoint is then nobody's roll-back point any more (also when a copy or the vote fails)
+  struct SnapGuard { ilsx_sac* s; bool keep = false; ~SnapGuard() { if (!keep) s->snap_valid = false; } } snap_guard{s};
+  // teardown: the window is being closed on an error path (ilsx_advirl_train's guard) — this rank's peers are inside some other collective,
+  // so no vote is issued (a mismatched all-reduce hangs instead of returning the error) and nothing is re-run: the caller already fails
+  if (deferred && s->snap_valid && !teardown) {   // == the window began with sac_window_may_use_phase (the one predicate: the checkpoint is taken under it)
     // a phase-kernel workgroup that gave up waiting left a mark: the steps of this call are not to be trusted
     int err = 0;
     unsigned masks[PHASE_MAX_TILES * 32];
@@ -933,10 +965,10 @@ static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who) {
                 (err & 1) ? "timed out waiting for the workgroups of its tile (other kernels sharing this GPU?)"
                 : (err & 2) ? "found the workgroups of one row tile on different XCDs" : "broke on another rank of this split run");
       s->phase_fallbacks += 1;
-      return ILSX_RETRY_WINDOW;   // snap_valid stays set: sac_snapshot_restore consumes it
+      snap_guard.keep = true;   // sac_snapshot_restore consumes it
+      return ILSX_RETRY_WINDOW;
     }
   }
-  s->snap_valid = false;   // the window is over: its checkpoint is nobody's roll-back point any more
   return ILSX_OK;
 }
 
@@ -1001,6 +1033,14 @@ static int sac_split_segments_step(ilsx_sac* s, ilsx_replay* rb, int B) {
 }
 
 extern "C" int ilsx_sac_train_from_replay(ilsx_sac* s, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats) {
+  // The reference records eval_statistics on the FIRST train_step after end_epoch (sac_alpha.py:185-190: `if self.eval_statistics is
+  // None`), i.e. on the first batch of the call that asks for them.  The deferred tail has no statistics branch, so the call is cut there:
+  // one step with the ordinary tail (which computes them), then the other n - 1 steps as a window of their own.  A call boundary does not
+  // change any parameter (tests/test_hip_parity.py _DEFER_SCRIPT), so the split is invisible except for which batch the statistics describe.
+  if (stats && n_steps > 1) {
+    ILSX_TRY(ilsx_sac_train_from_replay(s, rb, 1, B, stats));
+    return ilsx_sac_train_from_replay(s, rb, n_steps - 1, B, nullptr);
+  }
   int rc = sac_train_from_replay_once(s, rb, n_steps, B, stats);
   if (rc == ILSX_RETRY_WINDOW) {   // the phase kernels' hand-offs broke (shared GPU): back to the checkpoint, same steps on one launch per stage
     ILSX_TRY(sac_snapshot_restore(s));
@@ -1484,7 +1524,10 @@ extern "C" int ilsx_sac_group_create(ilsx_ctx* ctx, ilsx_sac* const* agents, int
   if (!ctx || !agents || !out || n_agents < 1 || n_agents > 64) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_group_create: bad argument");
   for (int k = 0; k < n_agents; ++k) {
     ilsx_sac* s = agents[k];
-    if (!s || s->ctx != ctx) ILSX_FAIL(ILSX_ERR_ARG, "every agent of a group must live in the group's ctx");
+    // the group's launches go on ctx->stream; an agent's own objects (env, replay, rollout inference) are ordered with them as long as its
+    // ctx enqueues on the same stream — the same ctx, or a sibling created on it (per-run Philox key + stream ids, include/ilsx.h)
+    if (!s || s->ctx->device != ctx->device || s->ctx->stream != ctx->stream)
+      ILSX_FAIL(ILSX_ERR_ARG, "every agent of a group must live in the group's ctx or in a sibling ctx on the same device and stream");
     if (s->cs <= 1) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "grouped steps use the column-split kernels (2 hidden layers of 128 or 256)");
     if (s->cfg.grad_world != 1) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "grouped agents are whole runs (grad_world == 1)");
     if (memcmp(&s->Lq.cfg, &agents[0]->Lq.cfg, sizeof s->Lq.cfg) || memcmp(&s->Lp.cfg, &agents[0]->Lp.cfg, sizeof s->Lp.cfg) ||
@@ -1509,7 +1552,7 @@ extern "C" int ilsx_sac_group_destroy(ilsx_sac_group* g) {
 }
 
 // n_steps lock-step gradient steps of every agent, agent k sampling from rbs[k] (TorchRLAlgorithm._do_training of K
-// independent runs).  want_stats: the last step also computes every agent's statistics (read with ilsx_sac_last_stats).
+// independent runs).  want_stats: the first step also computes every agent's statistics (read with ilsx_sac_last_stats).
 extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* const* rbs, int n_steps, int B, int want_stats) {
   if (!g || !rbs || n_steps < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_sac_group_train_from_replay: bad argument");
   const int K = (int)g->agents.size();
@@ -1520,6 +1563,10 @@ extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* 
     if (rbs[k]->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "replay buffer %d is empty", k);
   }
   if (B < 1 || B > g->agents[0]->cfg.max_batch) ILSX_FAIL(ILSX_ERR_ARG, "batch %d not in 1..max_batch", B);
+  if (want_stats && n_steps > 1) {   // statistics describe the FIRST batch of the call (sac_alpha.py:185-190), as in ilsx_sac_train_from_replay
+    ILSX_TRY(ilsx_sac_group_train_from_replay(g, rbs, 1, B, 1));
+    return ilsx_sac_group_train_from_replay(g, rbs, n_steps - 1, B, 0);
+  }
   bool rebuild = g->stages.empty() || g->B != B || (int)g->rbs.size() != K;
   for (int k = 0; k < K && !rebuild; ++k) rebuild = g->rbs[k] != rbs[k];
   if (rebuild) ILSX_TRY(group_build(g, rbs, B));
@@ -1550,5 +1597,7 @@ extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* 
   if (g->defer)
     for (auto& stg : g->stages)
       if (stg.kind == 3) ILSX_TRY(group_launch_tail(g, stg.tails, 1));
+  if (want_stats)   // (n_steps == 1 here) keep every agent's statistics as they stand now: the rest of the call moves alpha on
+    for (int k = 0; k < K; ++k) { ilsx_sac_stats tmp; ILSX_TRY(sac_read_stats(g->agents[k], &tmp)); }
   return ILSX_OK;
 }

@@ -16,11 +16,22 @@ _gpu_id = 0
 
 
 class Context:
-    def __init__(self, device=0, seed=0):
+    """One libilsx context: device, HIP stream, Philox key (`seed`) and the per-object stream-id counter.
+    `stream`: an existing hipStream_t to enqueue on (include/ilsx.h ilsx_ctx_create) — `Context.sibling(seed)` uses it to give every
+    co-resident run of a grouped launch (run_experiment.py --group) the key and stream ids it would have in a process of its own."""
+
+    def __init__(self, device=0, seed=0, stream=None):
         lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(lib.ilsx_ctx_create(int(device), None, C.c_uint64(int(seed) & (2**64 - 1)), C.byref(h)))
+        _lib.check(lib.ilsx_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.c_uint64(int(seed) & (2**64 - 1)), C.byref(h)))
         self.lib, self.h, self.device, self.seed = lib, h, int(device), int(seed)
+        self.parent = None
+
+    def sibling(self, seed):
+        """A context on the same device and stream with its own Philox key and object counter (everything still runs in stream order)."""
+        c = Context(self.device, seed, stream=self.stream)
+        c.parent = self     # the stream's owner must outlive it
+        return c
 
     def sync(self):
         _lib.check(self.lib.ilsx_ctx_sync(self.h))
@@ -107,6 +118,13 @@ def set_gpu_mode(mode=True, gpu_id=0, seed=0):
     _gpu_id = int(gpu_id)
     _default_ctx = Context(_gpu_id, seed)
     return _default_ctx
+
+
+def set_default_context(ctx):
+    """Make `ctx` the context objects built without an explicit `ctx=` land in (grouped runs: one sibling context per run)."""
+    global _default_ctx
+    _default_ctx = ctx
+    return ctx
 
 
 def get_context():

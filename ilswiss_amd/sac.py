@@ -74,7 +74,7 @@ class SoftActorCritic(Trainer):
                           int(target_entropy is not None), float(target_entropy or 0.0), int(max_batch),
                           int(grad_world))
         self.target_entropy = target_entropy if target_entropy is not None else -policy.action_dim / 2.0
-        self.max_batch = int(max_batch)
+        self.max_batch, self.grad_world = int(max_batch), int(grad_world)
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_sac_create(self.ctx.h, C.byref(cfg), policy.h, qf1.h, qf2.h, C.byref(self.h)))
         self.eval_statistics = None
@@ -282,20 +282,22 @@ class SoftActorCriticGroup:
     """K independent SoftActorCritic runs (seeds) of identical shape stepped in lock-step on one GPU, every stage of the
     step being ONE launch for all of them (ilsx_sac_group).  The trainers stay ordinary objects."""
 
-    def __init__(self, trainers):
-        self.trainers, self.ctx = list(trainers), trainers[0].ctx
+    def __init__(self, trainers, ctx=None):
+        # ctx: the context whose stream the grouped launches go on; the trainers live in it or in siblings of it (Context.sibling)
+        self.trainers, self.ctx = list(trainers), ctx or trainers[0].ctx
         arr = (C.c_void_p * len(self.trainers))(*[t.h for t in self.trainers])
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_sac_group_create(self.ctx.h, arr, len(self.trainers), C.byref(self.h)))
 
     def train_from_replay(self, replay_buffers, n_steps, batch_size):
-        want = any(t.eval_statistics is None for t in self.trainers)
+        """TorchRLAlgorithm._do_training of every run; the statistics (first batch of the call, sac_alpha.py:185-190) go to the trainers
+        that have none since their last end_epoch."""
+        want = [t for t in self.trainers if t.eval_statistics is None]
         arr = (C.c_void_p * len(self.trainers))(*[rb.h for rb in replay_buffers])
-        _lib.check(self.ctx.lib.ilsx_sac_group_train_from_replay(self.h, arr, int(n_steps), int(batch_size), int(want)))
-        if want:
-            for t in self.trainers:
-                _lib.check(self.ctx.lib.ilsx_sac_last_stats(t.h, C.byref(t._stats)))
-                t._fill_stats()
+        _lib.check(self.ctx.lib.ilsx_sac_group_train_from_replay(self.h, arr, int(n_steps), int(batch_size), int(bool(want))))
+        for t in want:
+            _lib.check(self.ctx.lib.ilsx_sac_last_stats(t.h, C.byref(t._stats)))
+            t._fill_stats()
 
     def close(self):
         if self.h:

@@ -228,7 +228,9 @@ int ilsx_sac_train_step(ilsx_sac* sac, const float* obs, const float* act, const
                         const float* done, const float* nobs, int B, const float* eps_next,
                         const float* eps_cur, ilsx_sac_stats* stats);
 /* TorchRLAlgorithm._do_training (torch_rl_algorithm.py:28-34): n_steps x (random_batch + train_step)
- * with on-device sampling; one hipGraph replay per step, no host round trip. */
+ * with on-device sampling; one hipGraph replay per step, no host round trip.  stats (nullable): the statistics of the
+ * FIRST batch of the call — the reference fills eval_statistics on the first train_step after end_epoch
+ * (sac_alpha.py:185-190) and the caller passes `stats` exactly then. */
 int ilsx_sac_train_from_replay(ilsx_sac* sac, ilsx_replay* rb, int n_steps, int B, ilsx_sac_stats* stats);
 /* A single run's steps inside ilsx_sac_train_from_replay / ilsx_advirl_train run on merged "phase" kernels whose workgroups hand data to
  * each other inside one launch; that needs the GPU to this process.  The reference's launcher starts every worker of a sweep on the SAME
@@ -250,6 +252,8 @@ int ilsx_sac_critic_backward(ilsx_sac* sac);
 int ilsx_sac_critic_update(ilsx_sac* sac);
 int ilsx_sac_actor_backward(ilsx_sac* sac);
 int ilsx_sac_actor_update(ilsx_sac* sac);
+/* The statistics most recently asked for (a train call with `stats` / a grouped call with want_stats), as they stood right after their
+ * step; after hand-driven phases: the device scalars as they are now. */
 int ilsx_sac_last_stats(ilsx_sac* sac, ilsx_sac_stats* stats);
 /* flat fp32 views: which = 0 pi, 1 q1, 2 q2, 3 target_q1, 4 target_q2 */
 int ilsx_sac_get_params(ilsx_sac* sac, int which, float* dst, size_t n, int dst_is_device);
@@ -339,8 +343,11 @@ int ilsx_disc_reward(ilsx_disc* disc, const float* obs, const float* act, int n,
  * points); results are bit-identical to stepping each agent alone with ilsx_sac_train_from_replay. */
 int ilsx_sac_group_create(ilsx_ctx* ctx, ilsx_sac* const* agents, int n_agents, ilsx_sac_group** out);
 int ilsx_sac_group_destroy(ilsx_sac_group* group);
-/* n_steps gradient steps of every agent; agent k samples its batch from rbs[k].  want_stats: the last step also
- * computes every agent's statistics (read them with ilsx_sac_last_stats). */
+/* n_steps gradient steps of every agent; agent k samples its batch from rbs[k].  want_stats: the FIRST step of the call also
+ * computes every agent's statistics (sac_alpha.py:185-190; read them with ilsx_sac_last_stats).
+ * The agents may live in sibling contexts of the group's ctx — contexts created on the SAME device and HIP stream
+ * (ilsx_ctx_create(device, ilsx_ctx_stream(ctx), seed_k, ...)): each run then keeps the Philox key and per-object stream ids it would have in a
+ * process of its own, which is what makes K grouped seeds reproduce K single-process runs (run_experiment.py --group). */
 int ilsx_sac_group_train_from_replay(ilsx_sac_group* group, ilsx_replay* const* rbs, int n_steps, int B, int want_stats);
 
 /* AdvIRL._do_training (adv_irl.py:126-131) for one train call: `loops` x { disc_updates discriminator steps ;

@@ -38,10 +38,24 @@ def make_envs(variant, ctx, **vec_kwargs):
     return training_env, eval_env, training_env.single_env_view()
 
 
+# ---- several variants in ONE process (run_experiment.py --group K / meta_data.seeds_per_process): `-e a.yaml b.yaml ...`.  Every variant
+# goes through the run script's own experiment() unchanged; start() hands run k a sibling context of run 0's (same device and stream, its own
+# Philox key and object counter — what it would have in a process of its own) and train() collects the built algorithms instead of training
+# them; main() then advances them in lock-step (ilswiss_amd.algorithm.DeviceRLAlgorithmGroup).
+_GROUP = None
+
+
 def start(variant, gpu):
     seed = int(variant.get("seed", 0))
     np.random.seed(seed)
-    return ia.set_gpu_mode(True, gpu, seed=seed)
+    if _GROUP is not None and _GROUP["ctx"] is not None:
+        ctx = _GROUP["ctx"].sibling(seed)
+        ia.device.set_default_context(ctx)
+        return ctx
+    ctx = ia.set_gpu_mode(True, gpu, seed=seed)
+    if _GROUP is not None:
+        _GROUP["ctx"] = ctx
+    return ctx
 
 
 def train(algorithm, variant):
@@ -51,20 +65,41 @@ def train(algorithm, variant):
     if variant.get("load_params"):
         algorithm, epoch = load_from_file(algorithm, **variant["load_params"])
     print("Start from epoch", epoch)
+    if _GROUP is not None:
+        _GROUP["runs"].append((algorithm, epoch))
+        return algorithm
     algorithm.train(start_epoch=epoch)
     return algorithm
 
 
-def main(experiment, default_name):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("-e", "--experiment", required=True, help="experiment specification file")
-    ap.add_argument("-g", "--gpu", type=int, default=0, help="gpu id")
-    args = ap.parse_args()
-    with open(args.experiment) as f:
-        variant = flatten_spec(yaml.safe_load(f))
+def _log_dir(variant, default_name):
     load_path = (variant.get("load_params") or {}).get("load_path")
     if load_path:   # a resumed run keeps logging into the directory it resumes from (sac_alpha_exp_script.py:142-146)
-        log_dir = load_path
-    else:
-        log_dir = setup_log_dir(variant.get("exp_name", default_name), int(variant.get("exp_id", 0)), int(variant.get("seed", 0)), variant)
-    return experiment(variant, args.gpu, log_dir)
+        return load_path
+    return setup_log_dir(variant.get("exp_name", default_name), int(variant.get("exp_id", 0)), int(variant.get("seed", 0)), variant)
+
+
+def main(experiment, default_name):
+    global _GROUP
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-e", "--experiment", required=True, nargs="+",
+                    help="experiment specification file; several files = that many runs in this one process, stepped in lock-step")
+    ap.add_argument("-g", "--gpu", type=int, default=0, help="gpu id")
+    args = ap.parse_args()
+    variants_ = []
+    for path in args.experiment:
+        with open(path) as f:
+            variants_.append(flatten_spec(yaml.safe_load(f)))
+    if len(variants_) == 1:
+        return experiment(variants_[0], args.gpu, _log_dir(variants_[0], default_name))
+    from ilswiss_amd.algorithm import DeviceRLAlgorithmGroup
+    _GROUP = dict(ctx=None, runs=[])
+    for v in variants_:
+        experiment(v, args.gpu, _log_dir(v, default_name))
+    runs, _GROUP = _GROUP["runs"], None
+    epochs = {e for _, e in runs}
+    if len(epochs) != 1:
+        raise SystemExit(f"grouped runs must resume from the same epoch (found {sorted(epochs)})")
+    group = DeviceRLAlgorithmGroup([a for a, _ in runs])
+    group.train(start_epoch=epochs.pop())
+    return group

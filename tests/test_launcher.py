@@ -179,3 +179,33 @@ def test_trainers_refuse_another_optimiser_or_criterion():
     with pytest.raises(NotImplementedError, match="qf_criterion"):
         check_swallowed_kwargs(dict(qf_criterion=SGD()), "X")
 
+
+
+def test_run_experiment_group_hands_each_child_k_variant_files(tmp_path):
+    """run_experiment.py --group K / meta_data.seeds_per_process: one child per K consecutive variants (`-e a.yaml b.yaml ...`), children dealt
+    round-robin over --gpus; every variant keeps its own file (run_experiment.py:39-66 of the reference writes one per grid point)."""
+    import json
+    import subprocess
+    import sys
+    fake = tmp_path / "fake_script.py"
+    fake.write_text("import json, sys\nopen(sys.argv[0] + '.calls', 'a').write(json.dumps(sys.argv[1:]) + '\\n')\n")
+    spec = dict(meta_data=dict(script_path=str(fake), exp_name="grp", num_workers=1, seeds_per_process=4),
+                variables=dict(seed=list(range(10))), constants=dict(env_specs=dict(env_name="hopper")))
+    path = tmp_path / "spec.yaml"
+    path.write_text(yaml.dump(spec))
+
+    def calls(*extra):
+        if os.path.exists(str(fake) + ".calls"):
+            os.remove(str(fake) + ".calls")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "run_experiment.py"), "-e", str(path), "--log-root", str(tmp_path / "logs"), *extra],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        cs = [json.loads(line) for line in open(str(fake) + ".calls")]
+        return sorted(cs, key=lambda c: yaml.safe_load(open(c[1]))["exp_id"])      # children run concurrently: order by their first variant
+    cs = calls("--gpus", "2", "-g", "3")
+    files = [[a for a in c[1:c.index("-g")]] for c in cs]
+    assert [len(f) for f in files] == [4, 4, 2] and all(c[0] == "-e" for c in cs)
+    assert [c[c.index("-g") + 1] for c in cs] == ["3", "4", "3"]                # children round-robin over the two GPUs
+    seeds = [yaml.safe_load(open(p))["seed"] for f in files for p in f]
+    assert seeds == list(range(10))                                              # consecutive variants, each its own file
+    assert [len(c[1:c.index("-g")]) for c in calls("--group", "1")] == [1] * 10  # the flag overrides the spec

@@ -316,3 +316,111 @@ def test_bc_run_script_with_generated_demos(tmp_path, ctx):
     assert len(rows) == 2 and float(rows[-1]["Number of train steps total"]) == 80
     assert float(rows[-1]["Log-Likelihood"]) > float(rows[0]["Log-Likelihood"])      # the clone's likelihood of the demos rises
     assert np.isfinite(float(rows[-1]["AverageReturn"])) and os.path.exists(tmp_path / "log" / "best.pkl")
+
+
+# ------------------------------------------------------------------------------------------- grouped runs behind run_experiment.py
+def _launch(tmp, spec, group, tag):
+    """`python run_experiment.py -e spec.yaml --group <group>` with cwd = tmp/<tag>; returns {seed: log dir}."""
+    import glob
+    import subprocess
+    import sys
+    wd = tmp / tag
+    wd.mkdir()
+    path = wd / "spec.yaml"
+    path.write_text(yaml.dump(spec))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run_experiment.py"), "-e", str(path), "--group", str(group)], cwd=wd,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    dirs = {}
+    for d in glob.glob(str(wd / "logs" / "*" / "*--s-*")):
+        dirs[int(d.rsplit("--s-", 1)[1])] = d
+    return dirs, r.stdout
+
+
+def _rows_without_time(d):
+    rows = list(csv.DictReader(open(os.path.join(d, "progress.csv"))))
+    return [{k: v for k, v in r.items() if "Time" not in k} for r in rows]
+
+
+@pytest.mark.parametrize("path_mode", [False, True], ids=["insert_every_step", "insert_at_episode_end"])
+def test_grouped_run_script_writes_the_single_run_logs(tmp_path, path_mode):
+    """`run_experiment.py --group 4` runs the four seeds of a spec in ONE process — lock-step vec-env steps, one
+    ilsx_sac_group launch per stage of the gradient step — and writes four ordinary log directories whose progress.csv (every column that is
+    not a wall-clock time) and parameters are exactly the ones four single processes write.  With insert_at_episode_end the rings of the seeds
+    fill at different moments (their own episodes), so the first train triggers find only a subset able to train: the subset path too."""
+    import pickle
+    spec = yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "sac", "sac_hopper_hip.yaml")))
+    spec["meta_data"].update(script_path=os.path.join(ROOT, "run_scripts", "sac_alpha_exp_script.py"), num_workers=1, exp_name="grp_test")
+    spec["variables"] = dict(seed=[0, 1, 2, 3])
+    c = spec["constants"]
+    c["env_specs"].update(env_num=8, eval_env_num=4)
+    c["rl_alg_params"].update(num_epochs=2, num_steps_per_epoch=800, num_steps_between_train_calls=80, num_train_steps_per_train_call=12,
+                              num_steps_per_eval=200, max_path_length=60, min_steps_before_training=0 if path_mode else 160, batch_size=256,
+                              replay_buffer_size=20000, freq_saving=1, insert_at_episode_end=path_mode)
+    solo, _ = _launch(tmp_path, spec, 1, "solo")
+    grp, out = _launch(tmp_path, spec, 4, "grouped")
+    assert sorted(solo) == sorted(grp) == [0, 1, 2, 3]
+    assert out.count("sac_alpha_exp_script.py") == 1       # ONE child process for the four variants
+    for seed in range(4):
+        a, b = _rows_without_time(solo[seed]), _rows_without_time(grp[seed])
+        assert len(a) == 3
+        for ra, rb_ in zip(a, b):
+            assert ra == rb_, (seed, ra["Epoch"], {k: (ra[k], rb_.get(k)) for k in ra if ra[k] != rb_.get(k)})
+        assert float(a[-1]["Number of gradient steps total"]) > 0
+        pa, pb = (pickle.load(open(os.path.join(d[seed], "params.pkl"), "rb")) for d in (solo, grp))
+        for k in ("policy", "qf1", "target_qf2"):
+            np.testing.assert_array_equal(pa[k], pb[k], err_msg=f"seed {seed} {k}")
+        assert pa["log_alpha"] == pb["log_alpha"]
+        assert os.path.exists(os.path.join(grp[seed], "variant.json")) and os.path.exists(os.path.join(grp[seed], "debug.log"))
+    assert _rows_without_time(grp[0]) != _rows_without_time(grp[1])     # the seeds differ
+
+
+def test_statistics_are_those_of_the_first_batch_after_end_epoch():
+    """sac_alpha.py:185-190: eval_statistics are filled by the FIRST train_step after end_epoch.  A 50-step train call that asks for them
+    reports what a 1-step call from the same state reports (epoch-0 Alpha = the initial 0.2), and ends with the parameters of 50 plain steps;
+    the grouped call does the same for every run."""
+    import ilswiss_amd as ia
+    from ilswiss_amd.replay import SimpleReplayBuffer
+    o, a, hid, B, N = 11, 3, [256, 256], 256, 4000
+    rng = np.random.default_rng(3)
+    data = (rng.normal(0, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),
+            rng.normal(0, 1, N).astype(np.float32), rng.random(N) < 0.01, rng.normal(0, 1, (N, o)).astype(np.float32))
+
+    def make(c, k=0):
+        rb = SimpleReplayBuffer(8192, o, a, random_seed=5 + k, ctx=c)
+        rb.add_rows(*data)
+        tr = ia.SoftActorCritic(ia.ReparamTanhMultivariateGaussianPolicy(hid, o, a, ctx=c, seed=10 + k), ia.FlattenMlp(hid, 1, o + a, ctx=c, seed=20 + k),
+                                ia.FlattenMlp(hid, 1, o + a, ctx=c, seed=30 + k), policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+        return rb, tr
+    c1, c2, c3 = ia.Context(0, seed=9), ia.Context(0, seed=9), ia.Context(0, seed=9)
+    rb1, one = make(c1)
+    rb2, many = make(c2)
+    rb3, plain = make(c3)
+    one.train_from_replay(rb1, 1, B)
+    many.train_from_replay(rb2, 50, B)
+    plain.eval_statistics = {}
+    plain.train_from_replay(rb3, 50, B)
+    s1, s50 = one.get_eval_statistics(), many.get_eval_statistics()
+    assert dict(s1) == dict(s50)
+    assert abs(s50["Alpha"] - 0.2) < 1e-3      # the reference logs alpha AFTER the step's own update (sac_alpha.py:165,208-212): 0.2 less one Adam step
+    np.testing.assert_array_equal(many.get_params("qf1"), plain.get_params("qf1"))
+    np.testing.assert_array_equal(many.get_params("policy"), plain.get_params("policy"))
+    # a later epoch: statistics after end_epoch come from the first batch of the next call
+    one.end_epoch(); many.end_epoch()
+    one.eval_statistics = {}
+    one.train_from_replay(rb1, 49, B)       # catch up to 50 steps, no statistics
+    one.eval_statistics = None
+    one.train_from_replay(rb1, 1, B)
+    many.train_from_replay(rb2, 30, B)
+    assert dict(one.get_eval_statistics()) == dict(many.get_eval_statistics())
+    assert many.get_eval_statistics()["Alpha"] < 0.2
+    for c in (c1, c2, c3):
+        c.close()
+    # grouped: K = 2 runs in sibling contexts
+    base = ia.Context(0, seed=9)
+    sib = base.sibling(9)
+    (rba, ta), (rbb, tb) = make(base), make(sib)
+    g = ia.SoftActorCriticGroup([ta, tb], ctx=base)
+    g.train_from_replay([rba, rbb], 50, B)
+    assert dict(ta.get_eval_statistics()) == dict(s50) and dict(tb.get_eval_statistics()) == dict(s50)
+    g.close(); sib.close(); base.close()
