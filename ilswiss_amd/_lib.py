@@ -202,6 +202,9 @@ PROTOTYPES = {
     "ilsx_vecenv_set_state": (C.c_int, [vp, vp, vp]),
     "ilsx_vecenv_cur_obs": (C.c_int, [vp, C.POINTER(vp)]),
     "ilsx_rollout_step": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ilsx_rollout_step_begin": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ilsx_rollout_step_end": (C.c_int, [vp]),
+    "ilsx_rollout_steps_lockstep": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "ilsx_rollout_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "ilsx_abi_version": (C.c_int, []),
     "ilsx_last_error": (C.c_char_p, []),

@@ -163,13 +163,21 @@ class DeviceRLAlgorithm:
             self.trainer.end_epoch()
 
     # ---- the pieces of one off-policy epoch (base_algorithm.py:183-286), shared by train() and DeviceRLAlgorithmGroup
-    def _vec_step(self):
-        """One sampling iteration of all envs: policy -> physics -> replay record -> auto-reset, enqueued (no host wait)."""
+    def _vec_step(self, begin_only=False):
+        """One sampling iteration of all envs: policy -> physics -> replay record -> auto-reset.  begin_only: enqueue it and return; the
+        caller ends it with _vec_step_end() (which, with insert_at_episode_end, waits for the step and inserts the finished episodes)."""
         random_actions = self.replay_buffer.num_steps_can_sample() < self.min_steps_before_training
+        label = getattr(self.trainer, "expert_policy", None)
+        self._vec_step_open = bool(begin_only) and label is None and hasattr(self.training_env, "rollout_step_end")
+        kw = dict(begin_only=True) if self._vec_step_open else {}
         self.training_env.rollout_step(self.exploration_policy, self.replay_buffer, self.max_path_length,
-                                       random_actions=random_actions, no_terminal=self.no_terminal,
-                                       label_policy=getattr(self.trainer, "expert_policy", None))
+                                       random_actions=random_actions, no_terminal=self.no_terminal, label_policy=label, **kw)
         self._n_env_steps_total += self.env_num
+
+    def _vec_step_end(self):
+        if getattr(self, "_vec_step_open", False):
+            self.training_env.rollout_step_end()
+            self._vec_step_open = False
 
     def _train_due(self):
         return self._n_env_steps_total - self._n_prev_train_env_steps >= self.num_steps_between_train_calls
@@ -208,17 +216,25 @@ class DeviceRLAlgorithm:
             self._t_eval = time.perf_counter() - t0
             self.trainer.end_epoch()
 
-    def evaluate(self, epoch, epoch_time, total_time):
+    def _eval_collect(self):
+        """The evaluation rollouts (device work + host waits, no logging): what evaluate() reduces and logs."""
+        if isinstance(self.eval_sampler, DeviceEvalSampler):
+            return self.eval_sampler.obtain_statistics(stat_prefix="Test")
+        return self.eval_sampler.obtain_samples()
+
+    def evaluate(self, epoch, epoch_time, total_time, collected=None):
         st = OrderedDict()
         ts = self.trainer.get_eval_statistics()
         if ts:
             st.update(ts)
+        if collected is None:
+            collected = self._eval_collect()
         if isinstance(self.eval_sampler, DeviceEvalSampler):
-            dev_stats = self.eval_sampler.obtain_statistics(stat_prefix="Test")
+            dev_stats = collected
             average_return = dev_stats.pop("AverageReturn")
             st.update(dev_stats)
         else:
-            test_paths = self.eval_sampler.obtain_samples()
+            test_paths = collected
             st.update(get_generic_path_information(test_paths, stat_prefix="Test"))
             average_return = get_average_returns(test_paths)
         episodes, ret_sum = self.training_env.rollout_stats(reset=True)
@@ -317,7 +333,27 @@ class DeviceRLAlgorithmGroup:
         if a0.on_policy:
             raise NotImplementedError("DeviceRLAlgorithmGroup steps off-policy runs (the on-policy branch is one device pipeline per run)")
         self.ctx = a0.trainer.ctx
+        self._lockstep_args = self._plain_rollouts()
         self._groups = {}   # subset of run indices -> SoftActorCriticGroup (the whole set in steady state; subsets only while rings fill)
+
+    def _plain_rollouts(self):
+        """ctypes arrays for ilsx_rollout_steps_lockstep when every run samples through the plain fused rollout (a HIP vec env, a device
+        policy, a device ring, no expert relabelling, one max_path_length / no_terminal for all); None otherwise."""
+        import ctypes as C
+        algs, a0 = self.algs, self.algs[0]
+        ok = all(hasattr(a.training_env, "h") and hasattr(a.exploration_policy, "h") and hasattr(a.replay_buffer, "h") and
+                 getattr(a.trainer, "expert_policy", None) is None and a.max_path_length == a0.max_path_length and
+                 a.no_terminal == a0.no_terminal and type(a.training_env).rollout_step is type(a0.training_env).rollout_step and
+                 not hasattr(a.exploration_policy, "_ppo") for a in algs)
+        if not ok or not hasattr(a0.trainer.ctx.lib, "ilsx_rollout_steps_lockstep"):
+            return None
+        from .envs.vecenv import HipVectorEnv
+        if not all(type(a.training_env) is HipVectorEnv for a in algs):
+            return None
+        K = len(algs)
+        arr = lambda xs: (C.c_void_p * K)(*[x.h for x in xs])  # noqa: E731
+        return (arr([a.training_env for a in algs]), arr([a.exploration_policy for a in algs]), arr([a.replay_buffer for a in algs]),
+                (C.c_int64 * K)(*[int(a.min_steps_before_training) for a in algs]), a0.trainer.ctx.lib)
 
     def _groupable(self, idx):
         from .sac import SoftActorCritic
@@ -351,37 +387,66 @@ class DeviceRLAlgorithmGroup:
             for i in idx:
                 self.algs[i].trainer.train_from_replay(self.algs[i].replay_buffer, n, B)
 
+    def sync(self):
+        for a in self.algs:
+            a.trainer.ctx.sync()
+        self.ctx.sync()
+
     def train(self, start_epoch=0):
-        algs, ctx, a0 = self.algs, self.ctx, self.algs[0]
+        from concurrent.futures import ThreadPoolExecutor
+        algs, a0 = self.algs, self.algs[0]
+        # the runs' evaluation rollouts are host-driven loops of small launches (one C call per rollout round, a wait every 32 vec steps): one
+        # thread per run, each on its run's stream — ctypes drops the GIL inside the calls, the K evaluations overlap on the GPU
+        pool = ThreadPoolExecutor(max_workers=len(algs)) if len(algs) > 1 else None
         t_start = time.perf_counter()
         for epoch in range(start_epoch, a0.num_epochs + 1):
             t_epoch = time.perf_counter()
             t_sample = t_train = 0.0
             for a in algs:
                 a.training_env.rollout_stats(reset=True)
-            for _ in range(a0.num_env_steps_per_epoch // a0.env_num):
+            left = a0.num_env_steps_per_epoch // a0.env_num
+            while left > 0:
                 t0 = time.perf_counter()
-                for a in algs:
-                    a._vec_step()
+                # vec steps until the first run's train trigger (at least one): one library call for the whole stretch when every run
+                # samples through the plain fused rollout, else step by step from here
+                n = max(1, min(left, min(-(-(a.num_steps_between_train_calls - (a._n_env_steps_total - a._n_prev_train_env_steps)) // a.env_num)
+                                         for a in algs)))
+                if self._lockstep_args is not None:
+                    envs, pis, rbs, mins, lib = self._lockstep_args
+                    from . import _lib
+                    _lib.check(lib.ilsx_rollout_steps_lockstep(envs, pis, rbs, len(algs), n, int(a0.max_path_length), mins, 0, int(a0.no_terminal)))
+                    for a in algs:
+                        a._n_env_steps_total += n * a.env_num
+                else:
+                    n = 1
+                    for a in algs:          # enqueue every run's vec step on its own stream ...
+                        a._vec_step(begin_only=True)
+                    for a in algs:          # ... then do the host part of each (insert_at_episode_end: wait + insert the finished episodes)
+                        a._vec_step_end()
+                left -= n
                 due = [i for i, a in enumerate(algs) if a._train_due()]
                 if due:
-                    ctx.sync()
+                    self.sync()
                     t1 = time.perf_counter()
                     t_sample += t1 - t0
                     can = [i for i in due if algs[i]._can_train()]
                     if can:
                         self._train(can)
-                        ctx.sync()
+                        self.sync()
                     t_train += time.perf_counter() - t1
                 else:
                     t_sample += time.perf_counter() - t0
-            ctx.sync()
-            for a in algs:
+            self.sync()
+            t_eval0 = time.perf_counter()
+            collected = list(pool.map(lambda a: a._eval_collect(), algs)) if pool else [algs[0]._eval_collect()]
+            t_eval = time.perf_counter() - t_eval0
+            for a, c in zip(algs, collected):
                 a._t_sample, a._t_train = t_sample, t_train
-                t0 = time.perf_counter()
-                a.evaluate(epoch, time.perf_counter() - t_epoch, time.perf_counter() - t_start)
-                a._t_eval = time.perf_counter() - t0
+                a.evaluate(epoch, t_eval0 - t_epoch, t_eval0 - t_start, collected=c)
+                a._t_eval = t_eval
                 a.trainer.end_epoch()
+        if pool:
+            pool.shutdown()
 
     def close(self):
         for g in self._groups.values():

@@ -56,7 +56,9 @@ struct ilsx_vecenv {
   unsigned char* ev_frozen = nullptr; double* ev_ret = nullptr; int* ev_len = nullptr; double* ev_stats = nullptr; int* ev_alive = nullptr;
   bool norm_obs = false, update_rms = false;
   // path mode (ilsx_vecenv_set_path_mode): whole episodes are staged and enter the ring when they end (base_algorithm.py:509-519)
-  bool path_mode = false; float* stage = nullptr; int stage_len = 0, stage_rec = 0; int* flush_len = nullptr; std::vector<int> flush_host;
+  bool path_mode = false; float* stage = nullptr; int stage_len = 0, stage_rec = 0; int* flush_len = nullptr;
+  int* flush_host = nullptr;            // pinned: the per-step read-back of the episode-end flags is a true asynchronous copy
+  ilsx_replay* paths_pending = nullptr; // ilsx_rollout_step_begin enqueued a step whose finished episodes are not in the ring yet (ilsx_rollout_step_end)
   // 3-D engine (Ant / Humanoid, env3d.h): model, its device copy, and the per-env working set [E3Off::TOTAL][n_env]
   int engine = 0, nq = 0, nv = 0;
   bool wave3 = true;   // wave-per-env kernels (env3d_wave.h); ILSX_ENV3D_LANE=1 selects the lane-per-env form (env3d.h) for A/B runs
@@ -1038,6 +1040,7 @@ extern "C" int ilsx_vecenv_destroy(ilsx_vecenv* e) {
   if (!e) return ILSX_OK;
   void* ps[] = {e->dm, e->qpos, e->qvel, e->obs_cur, e->act, e->nobs, e->rew, e->done, e->ep_len, e->ep_ret, e->stats, e->ids, e->dm3, e->scr3, e->stage, e->flush_len};
   for (void* p : ps) if (p) ctx_free(e->ctx, p);
+  if (e->flush_host) hipHostFree(e->flush_host);
   delete e->hm3;
   delete e;
   return ILSX_OK;
@@ -1235,9 +1238,21 @@ static int env_after_step_norm(ilsx_vecenv* e) {
 
 // One iteration of BaseAlgorithm's sampling loop (base_algorithm.py:183-277) for ALL envs, on the device:
 // actions (policy or uniform random) -> physics -> transition record into the replay ring -> auto-reset.
+// path mode, second half of a step: wait for the step, move the episodes that ended in it from the staging area into the ring
+static int rollout_paths_finish(ilsx_vecenv* e) {
+  ilsx_replay* rb = e->paths_pending;
+  if (!rb) return ILSX_OK;
+  e->paths_pending = nullptr;
+  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  std::vector<int> envs, lens; std::vector<uint8_t> term;
+  for (int i = 0; i < e->n_env; ++i)
+    if (e->flush_host[i]) { envs.push_back(i); lens.push_back(e->flush_host[i] & ((1 << 30) - 1)); term.push_back((e->flush_host[i] >> 30) & 1); }
+  return replay_insert_paths(rb, e->stage, e->stage_len, envs.data(), lens.data(), term.data(), (int)envs.size());
+}
 static int rollout_step_impl(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* label_pi, int label_deterministic, ilsx_replay* rb,
-                             int max_path_length, int random_actions, int deterministic, int no_terminal) {
+                             int max_path_length, int random_actions, int deterministic, int no_terminal, bool defer_paths = false) {
   if (!e || (!pi && !random_actions)) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_step: need a policy or random_actions");
+  if (e->paths_pending) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_rollout_step: the previous step was begun with ilsx_rollout_step_begin and never ended (ilsx_rollout_step_end)");
   ilsx_ctx* ctx = e->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   if (rb && (rb->o != e->o || rb->a != e->a)) ILSX_FAIL(ILSX_ERR_ARG, "replay dims (%d,%d) != env dims (%d,%d)", rb->o, rb->a, e->o, e->a);
@@ -1280,18 +1295,16 @@ static int rollout_step_impl(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* label_pi, i
       if (max_path_length < 1 || max_path_length >= rb->cap) ILSX_FAIL(ILSX_ERR_ARG, "path mode needs 1 <= max_path_length < replay capacity");
       ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * max_path_length * rb->rec * 4, (void**)&e->stage));
       ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * 4, (void**)&e->flush_len));
-      e->stage_len = max_path_length; e->stage_rec = rb->rec; e->flush_host.resize(e->n_env);
+      e->stage_len = max_path_length; e->stage_rec = rb->rec;
+      HIPCHK(hipHostMalloc((void**)&e->flush_host, (size_t)e->n_env * sizeof(int), hipHostMallocDefault));
     }
     A.stage = e->stage; A.stage_len = e->stage_len; A.flush_len = e->flush_len;
   }
   ILSX_TRY(launch_env_step(e, A));
   if (paths) {
-    HIPCHK(hipMemcpyAsync(e->flush_host.data(), e->flush_len, (size_t)e->n_env * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    std::vector<int> envs, lens; std::vector<uint8_t> term;
-    for (int i = 0; i < e->n_env; ++i)
-      if (e->flush_host[i]) { envs.push_back(i); lens.push_back(e->flush_host[i] & ((1 << 30) - 1)); term.push_back((e->flush_host[i] >> 30) & 1); }
-    ILSX_TRY(replay_insert_paths(rb, e->stage, e->stage_len, envs.data(), lens.data(), term.data(), (int)envs.size()));
+    HIPCHK(hipMemcpyAsync(e->flush_host, e->flush_len, (size_t)e->n_env * 4, hipMemcpyDeviceToHost, ctx->stream));
+    e->paths_pending = rb;
+    if (!defer_paths) ILSX_TRY(rollout_paths_finish(e));
   } else if (rb) {
     ILSX_TRY(replay_advance_device_rows(rb, e->n_env));
   }
@@ -1301,6 +1314,39 @@ static int rollout_step_impl(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* label_pi, i
 extern "C" int ilsx_rollout_step(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
                                  int deterministic, int no_terminal) {
   return rollout_step_impl(e, pi, nullptr, 0, rb, max_path_length, random_actions, deterministic, no_terminal);
+}
+// The same step in two halves, for a host that advances several runs side by side (each on its own ctx / stream): _begin only ENQUEUES
+// (actions, physics, record, and in path mode the read-back of the episode-end flags), _end does what needs the host — in path mode it waits
+// for the step and inserts the finished episodes (base_algorithm.py:509-519); otherwise nothing.  begin(all runs) ; end(all runs) lets the
+// runs' launches overlap on the GPU instead of serialising on one host wait per run.
+extern "C" int ilsx_rollout_step_begin(ilsx_vecenv* e, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
+                                       int deterministic, int no_terminal) {
+  return rollout_step_impl(e, pi, nullptr, 0, rb, max_path_length, random_actions, deterministic, no_terminal, /*defer_paths=*/true);
+}
+extern "C" int ilsx_rollout_step_end(ilsx_vecenv* e) {
+  if (!e) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_step_end: NULL env");
+  HIPCHK(hipSetDevice(e->ctx->device));
+  return rollout_paths_finish(e);
+}
+// n_steps lock-step sampling iterations of K runs (the inner loop of DeviceRLAlgorithmGroup between two train triggers): per iteration every
+// run's step is enqueued on its own stream, then every run's host part is done — K x n_steps x 2 calls through the binding become one.
+// Run k acts at random while its ring holds fewer than min_steps_before_training[k] samples (base_algorithm.py:186-188), exactly as the
+// per-step form decides it.
+extern "C" int ilsx_rollout_steps_lockstep(ilsx_vecenv* const* envs, ilsx_net* const* pis, ilsx_replay* const* rbs, int n_runs, int n_steps,
+                                           int max_path_length, const int64_t* min_steps_before_training, int deterministic, int no_terminal) {
+  if (!envs || !pis || !rbs || !min_steps_before_training || n_runs < 1 || n_steps < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_steps_lockstep: bad argument");
+  for (int k = 0; k < n_runs; ++k)
+    if (!envs[k] || !pis[k] || !rbs[k]) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_steps_lockstep: run %d has a NULL env / policy / replay", k);
+  for (int t = 0; t < n_steps; ++t) {
+    for (int k = 0; k < n_runs; ++k)
+      ILSX_TRY(rollout_step_impl(envs[k], pis[k], nullptr, 0, rbs[k], max_path_length, rbs[k]->size < min_steps_before_training[k] ? 1 : 0,
+                                 deterministic, no_terminal, /*defer_paths=*/true));
+    for (int k = 0; k < n_runs; ++k) {
+      HIPCHK(hipSetDevice(envs[k]->ctx->device));
+      ILSX_TRY(rollout_paths_finish(envs[k]));
+    }
+  }
+  return ILSX_OK;
 }
 extern "C" int ilsx_rollout_step_relabel(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* expert, int expert_deterministic, ilsx_replay* rb,
                                          int max_path_length, int no_terminal) {

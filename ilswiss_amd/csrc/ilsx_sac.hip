@@ -775,9 +775,9 @@ static int sac_full_step(ilsx_sac* s) {
   return rc;
 }
 
-static int sac_request_stats(ilsx_sac* s) {  // ordered on the stream before the step that must produce them
+static int sac_request_stats(ilsx_sac* s, hipStream_t st = nullptr) {  // ordered on the stream before the step that must produce them
   static const int one = 1;
-  HIPCHK(hipMemcpyAsync(&s->scal->want_stats, &one, sizeof(int), hipMemcpyHostToDevice, s->ctx->stream));
+  HIPCHK(hipMemcpyAsync(&s->scal->want_stats, &one, sizeof(int), hipMemcpyHostToDevice, st ? st : s->ctx->stream));
   return ILSX_OK;
 }
 
@@ -1329,6 +1329,9 @@ struct ilsx_sac_group {
   };
   std::vector<Stage> stages;
   TailLite* tails_lite = nullptr;   // deferred tail: one record per agent (see TailLite, kernels.h)
+  // agents living in contexts with a stream of their own (one per co-resident run: their rollouts overlap): the grouped launches go on
+  // ctx->stream, fenced against every such stream at both ends of a train call (group_fence_in / group_fence_out)
+  std::vector<hipStream_t> peer_streams; std::vector<hipEvent_t> peer_events; hipEvent_t done_event = nullptr;
   bool defer = false;
   int mt = 1;                       // 16-row tiles per workgroup of the forward / backward launches (macro tiles, fwd_split_tile.inc)
   int late = -1;                    // "late weights" launch shape of the forward / backward launches: -1 per launch by size, 0 / 1 pinned (ILSX_GRP_LATE)
@@ -1526,8 +1529,8 @@ extern "C" int ilsx_sac_group_create(ilsx_ctx* ctx, ilsx_sac* const* agents, int
     ilsx_sac* s = agents[k];
     // the group's launches go on ctx->stream; an agent's own objects (env, replay, rollout inference) are ordered with them as long as its
     // ctx enqueues on the same stream — the same ctx, or a sibling created on it (per-run Philox key + stream ids, include/ilsx.h)
-    if (!s || s->ctx->device != ctx->device || s->ctx->stream != ctx->stream)
-      ILSX_FAIL(ILSX_ERR_ARG, "every agent of a group must live in the group's ctx or in a sibling ctx on the same device and stream");
+    if (!s || s->ctx->device != ctx->device)
+      ILSX_FAIL(ILSX_ERR_ARG, "every agent of a group must live on the group's device");
     if (s->cs <= 1) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "grouped steps use the column-split kernels (2 hidden layers of 128 or 256)");
     if (s->cfg.grad_world != 1) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "grouped agents are whole runs (grad_world == 1)");
     if (memcmp(&s->Lq.cfg, &agents[0]->Lq.cfg, sizeof s->Lq.cfg) || memcmp(&s->Lp.cfg, &agents[0]->Lp.cfg, sizeof s->Lp.cfg) ||
@@ -1537,7 +1540,40 @@ extern "C" int ilsx_sac_group_create(ilsx_ctx* ctx, ilsx_sac* const* agents, int
   ilsx_sac_group* g = new ilsx_sac_group();
   g->ctx = ctx;
   g->agents.assign(agents, agents + n_agents);
+  HIPCHK(hipSetDevice(ctx->device));
+  for (int k = 0; k < n_agents; ++k) {
+    hipStream_t st = agents[k]->ctx->stream;
+    if (st == ctx->stream || std::find(g->peer_streams.begin(), g->peer_streams.end(), st) != g->peer_streams.end()) continue;
+    hipEvent_t ev = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    g->peer_streams.push_back(st); g->peer_events.push_back(ev);
+  }
+  if (!g->peer_streams.empty()) HIPCHK(hipEventCreateWithFlags(&g->done_event, hipEventDisableTiming));
   *out = g;
+  return ILSX_OK;
+}
+// everything the agents' own streams have enqueued (rollout records in the rings, parameter uploads) happens before the grouped launches ...
+// HOST fences by default (ILSX_GROUP_FENCE unset / 2): wait for the peer streams before the first grouped launch, for the group stream after
+// the last.  Event fences (ILSX_GROUP_FENCE=1: hipEventRecord on each peer + hipStreamWaitEvent on the group stream, and the reverse at the
+// end — no host wait) were measured and rejected: a stream that has waited on another stream's event runs every LATER graph launch slower on
+// this stack — K = 10 Hopper runs, B = 512, 1000 steps per call: 275 us per lock-step with host fences or one shared stream, 284-320 us with
+// event fences (tools/grp_streams_ab.py, profiles/r06_grp_streams.txt).  The lock-step loop waits for every stream around a train call anyway.
+static int group_fence_mode() { static const int m = []() { const char* e = getenv("ILSX_GROUP_FENCE"); return e ? atoi(e) : 2; }(); return m; }
+static int group_fence_in(ilsx_sac_group* g) {
+  if (group_fence_mode() == 0) return ILSX_OK;
+  if (group_fence_mode() == 2) { for (hipStream_t st : g->peer_streams) HIPCHK(hipStreamSynchronize(st)); return ILSX_OK; }
+  for (size_t i = 0; i < g->peer_streams.size(); ++i) {
+    HIPCHK(hipEventRecord(g->peer_events[i], g->peer_streams[i]));
+    HIPCHK(hipStreamWaitEvent(g->ctx->stream, g->peer_events[i], 0));
+  }
+  return ILSX_OK;
+}
+// ... and whatever they enqueue next (rollout inference on the updated policy) happens after them
+static int group_fence_out(ilsx_sac_group* g) {
+  if (g->peer_streams.empty() || group_fence_mode() == 0) return ILSX_OK;
+  if (group_fence_mode() == 2) { HIPCHK(hipStreamSynchronize(g->ctx->stream)); return ILSX_OK; }
+  HIPCHK(hipEventRecord(g->done_event, g->ctx->stream));
+  for (hipStream_t st : g->peer_streams) HIPCHK(hipStreamWaitEvent(st, g->done_event, 0));
   return ILSX_OK;
 }
 
@@ -1547,6 +1583,8 @@ extern "C" int ilsx_sac_group_destroy(ilsx_sac_group* g) {
   hipStreamSynchronize(g->ctx->stream);
   group_release_tables(g);
   if (g->tails_lite) ctx_free(g->ctx, g->tails_lite);
+  for (hipEvent_t ev : g->peer_events) hipEventDestroy(ev);
+  if (g->done_event) hipEventDestroy(g->done_event);
   delete g;
   return ILSX_OK;
 }
@@ -1569,6 +1607,8 @@ extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* 
   }
   bool rebuild = g->stages.empty() || g->B != B || (int)g->rbs.size() != K;
   for (int k = 0; k < K && !rebuild; ++k) rebuild = g->rbs[k] != rbs[k];
+  ILSX_TRY(group_fence_in(g));
+  struct FenceOut { ilsx_sac_group* g; ~FenceOut() { group_fence_out(g); } } fence_out{g};   // on every path out of this call
   if (rebuild) ILSX_TRY(group_build(g, rbs, B));
   hipStream_t st = g->ctx->stream;
   static const bool no_graph = getenv("ILSX_NO_GRAPH") != nullptr;
@@ -1590,14 +1630,16 @@ extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* 
   }
   for (int i = 0; i < n_steps; ++i) {
     if (want_stats && i == n_steps - 1)
-      for (int k = 0; k < K; ++k) ILSX_TRY(sac_request_stats(g->agents[k]));
+      for (int k = 0; k < K; ++k) ILSX_TRY(sac_request_stats(g->agents[k], st));
     if (use_graph) HIPCHK(hipGraphLaunch(g->graph, st));
     else ILSX_TRY(group_launch_step(g));
   }
   if (g->defer)
     for (auto& stg : g->stages)
       if (stg.kind == 3) ILSX_TRY(group_launch_tail(g, stg.tails, 1));
-  if (want_stats)   // (n_steps == 1 here) keep every agent's statistics as they stand now: the rest of the call moves alpha on
+  if (want_stats) {   // (n_steps == 1 here) keep every agent's statistics as they stand now: the rest of the call moves alpha on
+    ILSX_TRY(group_fence_out(g));   // sac_read_stats copies on the agent's own stream
     for (int k = 0; k < K; ++k) { ilsx_sac_stats tmp; ILSX_TRY(sac_read_stats(g->agents[k], &tmp)); }
+  }
   return ILSX_OK;
 }

@@ -17,8 +17,10 @@ _gpu_id = 0
 
 class Context:
     """One libilsx context: device, HIP stream, Philox key (`seed`) and the per-object stream-id counter.
-    `stream`: an existing hipStream_t to enqueue on (include/ilsx.h ilsx_ctx_create) — `Context.sibling(seed)` uses it to give every
-    co-resident run of a grouped launch (run_experiment.py --group) the key and stream ids it would have in a process of its own."""
+    `stream`: an existing hipStream_t to enqueue on (include/ilsx.h ilsx_ctx_create).  `Context.sibling(seed)`: the context of another run
+    in the same process (run_experiment.py --group): same device, a stream, key and object counter of its own — exactly what the run would
+    have in a process of its own, so its random streams do not depend on its company; grouped launches are fenced against the runs' streams
+    by the library (ilsx_sac_group_train_from_replay)."""
 
     def __init__(self, device=0, seed=0, stream=None):
         lib = _lib.load()
@@ -27,10 +29,9 @@ class Context:
         self.lib, self.h, self.device, self.seed = lib, h, int(device), int(seed)
         self.parent = None
 
-    def sibling(self, seed):
-        """A context on the same device and stream with its own Philox key and object counter (everything still runs in stream order)."""
-        c = Context(self.device, seed, stream=self.stream)
-        c.parent = self     # the stream's owner must outlive it
+    def sibling(self, seed, share_stream=False):
+        c = Context(self.device, seed, stream=self.stream if share_stream else None)
+        c.parent = self     # a shared stream's owner must outlive it
         return c
 
     def sync(self):

@@ -251,16 +251,21 @@ class HipVectorEnv:
 
     # ---- fused device loop (BaseAlgorithm's sampling iteration, base_algorithm.py:183-277)
     def rollout_step(self, policy=None, replay=None, max_path_length=1000, random_actions=False, deterministic=False,
-                     no_terminal=False, label_policy=None):
+                     no_terminal=False, label_policy=None, begin_only=False):
+        """begin_only: only enqueue the step (ilsx_rollout_step_begin); the caller finishes it with rollout_step_end() — lets a lock-step loop
+        over several runs overlap their launches (DeviceRLAlgorithmGroup)."""
         if label_policy is not None:      # DAgger: store the expert's action (dagger.py:45-71)
             det = hasattr(label_policy, "stochastic_policy")
             lp = label_policy.stochastic_policy if det else label_policy
             _lib.check(self.ctx.lib.ilsx_rollout_step_relabel(self.h, policy.h, lp.h, int(det), replay.h if replay is not None else None,
                                                               int(max_path_length), int(bool(no_terminal))))
             return
-        _lib.check(self.ctx.lib.ilsx_rollout_step(self.h, policy.h if policy is not None else None,
-                                                  replay.h if replay is not None else None, int(max_path_length),
-                                                  int(bool(random_actions)), int(bool(deterministic)), int(bool(no_terminal))))
+        fn = self.ctx.lib.ilsx_rollout_step_begin if begin_only else self.ctx.lib.ilsx_rollout_step
+        _lib.check(fn(self.h, policy.h if policy is not None else None, replay.h if replay is not None else None, int(max_path_length),
+                      int(bool(random_actions)), int(bool(deterministic)), int(bool(no_terminal))))
+
+    def rollout_step_end(self):
+        _lib.check(self.ctx.lib.ilsx_rollout_step_end(self.h))
 
     def set_path_mode(self, on=True):
         """Fused rollouts insert whole episodes when they end, contiguously and registered in `_traj_endpoints` (the reference's

@@ -609,6 +609,16 @@ int ilsx_rollout_step(ilsx_vecenv* env, ilsx_net* pi, ilsx_replay* rb, int max_p
 #define ILSX_EVAL_NSTATS 18
 int ilsx_eval_rollout(ilsx_vecenv* env, ilsx_net* pi, ilsx_ppo* ppo, int max_path_length, int deterministic, int reset_stats,
                       double* stats_host);
+/* ilsx_rollout_step in two halves, for a host that advances several runs side by side, each on its own ctx / stream (the lock-step loop of
+ * co-resident seeds): _begin only enqueues the step; _end does the part that needs the host — with path mode on it waits for the step and
+ * inserts the episodes that ended in it, otherwise nothing.  begin(run 0..K-1) ; end(run 0..K-1) overlaps the K runs' launches on the GPU. */
+int ilsx_rollout_step_begin(ilsx_vecenv* env, ilsx_net* pi, ilsx_replay* rb, int max_path_length, int random_actions,
+                            int deterministic, int no_terminal);
+int ilsx_rollout_step_end(ilsx_vecenv* env);
+/* n_steps lock-step iterations of n_runs runs: per iteration begin(run 0..K-1) ; end(run 0..K-1).  Run k acts at random while its ring holds
+ * fewer than min_steps_before_training[k] samples (base_algorithm.py:186-188).  One call per stretch between two train triggers. */
+int ilsx_rollout_steps_lockstep(ilsx_vecenv* const* envs, ilsx_net* const* pis, ilsx_replay* const* rbs, int n_runs, int n_steps,
+                                int max_path_length, const int64_t* min_steps_before_training, int deterministic, int no_terminal);
 /* DAgger's sampling iteration (dagger/dagger.py:45-71): the envs are driven by `pi`, the action stored in the replay record is
  * `expert`'s action for the observation acted on. */
 int ilsx_rollout_step_relabel(ilsx_vecenv* env, ilsx_net* pi, ilsx_net* expert, int expert_deterministic, ilsx_replay* rb,

@@ -49,7 +49,9 @@ def start(variant, gpu):
     seed = int(variant.get("seed", 0))
     np.random.seed(seed)
     if _GROUP is not None and _GROUP["ctx"] is not None:
-        ctx = _GROUP["ctx"].sibling(seed)
+        # ILSX_GROUP_SHARE_STREAM=1 (A/B): every run of the group on run 0's stream — the runs' small rollout launches then queue up behind
+        # each other (measured on ten 4-env Hopper runs: 4.9 s of sampling per epoch against 1.7 s on a stream per run)
+        ctx = _GROUP["ctx"].sibling(seed, share_stream=bool(os.environ.get("ILSX_GROUP_SHARE_STREAM")))
         ia.device.set_default_context(ctx)
         return ctx
     ctx = ia.set_gpu_mode(True, gpu, seed=seed)
