@@ -125,16 +125,18 @@ def grouped_insts_per_mfma():
     return out
 
 
-def co_resident_seeds(K=8, n=1500):
+def co_resident_seeds(K=8, n=1500, R=None):
     """SURVEY config 5's per-GPU shape ("several seeds per GPU"): K independent SAC runs of the same config stepped in
     lock-step by ilsx_sac_group (one launch per stage for all of them).  Reported beside the headline, never as `value`.
-    The MFMA roofline entry is the grouped forward launch (K x 4 tasks x 16 row tiles x 4 column slices workgroups)."""
+    The MFMA roofline entry is the grouped forward launch (K x 4 tasks x 16 row tiles x 4 column slices workgroups).
+    R (N > 1): every rank runs the leg on its own GPU between two barriers; `aggregate_over_ranks` = all ranks' steps / the slowest rank's time."""
     import ctypes as C
 
     import ilswiss_amd as ia
     from ilswiss_amd import _lib
-    c = ia.Context(0, seed=4242)
-    rng = np.random.default_rng(7)
+    rank, world, local = (R.rank, R.world, R.local) if R is not None else (0, 1, 0)
+    c = ia.Context(local, seed=4242 + rank)
+    rng = np.random.default_rng(7 + rank)
     cap = 200_000
     rows = synth_rows(rng, cap)
     rbs, trs = [], []
@@ -149,10 +151,13 @@ def co_resident_seeds(K=8, n=1500):
     grp = ia.SoftActorCriticGroup(trs)
     grp.train_from_replay(rbs, 200, B)
     c.sync()
+    if R is not None:
+        R.barrier(c)
     t0 = time.perf_counter()
     grp.train_from_replay(rbs, n, B)
     c.sync()
     dt = time.perf_counter() - t0
+    dt_max = R.max_over_ranks([dt])[0] if R is not None else dt
     _lib.check(c.lib.ilsx_prof_reset(c.h))
     _lib.check(c.lib.ilsx_prof_enable(c.h, 1))
     grp.train_from_replay(rbs, 100, B)
@@ -162,7 +167,7 @@ def co_resident_seeds(K=8, n=1500):
     fl = K * flops_per_step()[0] / (nl.value / 100.0)
     avg_s = ms.value * 1e-3 / nl.value
     out = dict(K=K, aggregate_grad_steps_per_s=K * n / dt, per_run_grad_steps_per_s=n / dt, us_per_lockstep=1e6 * dt / n,
-               insts_per_mfma=grouped_insts_per_mfma(),
+               ranks=world, aggregate_over_ranks=world * K * n / dt_max, insts_per_mfma=grouped_insts_per_mfma(),
                roofline=dict(bound="mfma", kernel=kernel_spelling(c.lib, c, 0), achieved=fl / avg_s / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
                              unit="TFLOP/s", frac=fl / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_us=avg_s * 1e6,
                              algorithmic_flop_per_launch=fl))
@@ -580,6 +585,22 @@ def main():
     dt, t_sample, t_train = R.max_over_ranks([dt, t_sample, t_train])
     want_split = (world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST")) and not args.no_split_run
 
+    # config 5's per-GPU shapes on EVERY rank (N > 1: 8 GPUs x grouped seeds — what north_star's "32 seeds x 1024 envs over 8 GPUs" means):
+    # K = 8 grouped Hopper runs and 4 x 1024 grouped Humanoid runs, each rank on its own GPU, no collective in the data path
+    legs = {}
+    if not args.no_seeds:
+        try:
+            legs["co_resident_seeds"] = co_resident_seeds(R=R if world > 1 else None)
+        except Exception as e:   # noqa: BLE001 — secondary leg
+            legs["co_resident_seeds"] = dict(error=repr(e)[:300])
+            if world > 1:
+                raise            # a rank that skipped the leg's barriers would hang the others: fail the run instead
+    if world > 1 and not args.no_aux:
+        import bench_aux
+        hctx = ia.Context(local, seed=77 + rank)
+        legs["humanoid_4x1024"] = bench_aux.bench_humanoid(hctx, R=R)
+        hctx.close()
+
     result = None
     if rank == 0:
         grad_total = world * args.steps * GRAD_PER_CALL
@@ -676,11 +697,7 @@ def main():
                                 note="RCCL is used for the barrier + max-time of this leg and for the gradient all-reduce of `split_run` "
                                      "only; message sizes there are 0.55 MB (critics) and 0.28 MB (actor | alpha): latency-bound on "
                                      "xGMI, so NCCL_ALGO / NCCL_PROTO are left to RCCL's tuner unless set in the environment"))
-        if world == 1 and not args.no_seeds:
-            try:
-                result["co_resident_seeds"] = co_resident_seeds()
-            except Exception as e:   # noqa: BLE001 — secondary leg
-                result["co_resident_seeds"] = dict(error=repr(e)[:300])
+        result.update(legs)
         if world == 1 and not args.no_aux:
             # BASELINE.json configs 3, 4, 5 (their single-GPU shapes) beside the headline, each with the roofline block of its dominant
             # kernel (live HIP-event timing, kernel named as rocprofv3 lists it); never `value`

@@ -338,7 +338,7 @@ def bench_seeds(_ctx):
                 detail=res)
 
 
-def bench_humanoid(ctx):
+def bench_humanoid(ctx, R=None):
     """BASELINE config 5's share of ONE GPU: 4 seeds x 1024 Humanoid-v2 envs (obs 376 / act 17 / 256-256 SAC, batch 256), the four
     runs stepped in lockstep by ilsx_sac_group.  Reports the 3-D stepper alone, the grouped SAC step alone, and the loop
     (1 vec-env step per seed : 250 grad steps per seed — the 4096 : 1000 ratio of the headline config at 1024 envs)."""
@@ -382,6 +382,8 @@ def bench_humanoid(ctx):
     res["grouped_grad_steps_per_s"] = K * n / dt
     res["us_per_lockstep"] = 1e6 * dt / n
     iters, per = 6, 250
+    if R is not None:     # bench.py --gpus N: every rank runs this leg on its own GPU; the loop is timed between two barriers
+        R.barrier(ctx)
     t0 = time.perf_counter()
     for _ in range(iters):
         for env, rb, p in zip(envs, rbs, pols):
@@ -391,6 +393,11 @@ def bench_humanoid(ctx):
     dt = time.perf_counter() - t0
     res["loop_grad_steps_per_s"] = K * per * iters / dt
     res["loop_env_steps_per_s"] = K * N * iters / dt
+    if R is not None:
+        dt_max = R.max_over_ranks([dt])[0]
+        res["ranks"] = R.world
+        res["loop_grad_steps_per_s_over_ranks"] = R.world * K * per * iters / dt_max
+        res["loop_env_steps_per_s_over_ranks"] = R.world * K * N * iters / dt_max
     ep, ret = 0, 0.0
     for env in envs:
         e_, r_ = env.rollout_stats()

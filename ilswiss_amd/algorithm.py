@@ -88,7 +88,8 @@ class DeviceRLAlgorithm:
                  eval_deterministic=False, freq_saving=1, save_best=False, save_replay_buffer=False, replay_buffer=None, log_dir=None,
                  best_key="AverageReturn", bootstrap_open_segments=True, eval_on_device=True, insert_at_episode_end=False,
                  eval_policy=None, eval_sampler=None, save_epoch=False, save_best_starting_from_epoch=0, eval_no_terminal=False,
-                 wrap_absorbing=False, render=False, render_kwargs=None, freq_log_visuals=1, eval_preprocess_func=None):
+                 wrap_absorbing=False, render=False, render_kwargs=None, freq_log_visuals=1, eval_preprocess_func=None,
+                 split_world=1, split_agree=None):
         # keyword names and DEFAULTS are BaseAlgorithm's (base_algorithm.py:21-54); batch_size and num_train_steps_per_train_call have
         # none there either (torch_rl_algorithm.py:8-10).  Every shipped spec states all of them; log_dir / bootstrap_open_segments /
         # eval_on_device / insert_at_episode_end are ilswiss_amd keys.
@@ -101,6 +102,10 @@ class DeviceRLAlgorithm:
                           ("eval_preprocess_func", eval_preprocess_func)):
             if val:
                 raise NotImplementedError(f"DeviceRLAlgorithm({name}={val!r}) is not implemented (base_algorithm.py:46-53)")
+        # split_world / split_agree (ilswiss_amd keys, set by the run scripts for rl_alg_params.split_ranks): this loop is one rank of a run
+        # split over split_world GPUs — its counts are this rank's share, the logged env-step total is the run's, and a train call happens
+        # only when EVERY rank can train (split_agree: an all-reduce of the local answer)
+        self.split_world, self.split_agree = int(split_world), split_agree
         self.save_epoch, self.save_best_starting_from_epoch = bool(save_epoch), int(save_best_starting_from_epoch)
         if insert_at_episode_end and hasattr(training_env, "set_path_mode"):
             training_env.set_path_mode(True)
@@ -133,7 +138,8 @@ class DeviceRLAlgorithm:
 
     # base_algorithm.py:364-367
     def _can_train(self):
-        return self.replay_buffer.num_steps_can_sample() >= max(self.min_steps_before_training, 1)
+        ok = self.replay_buffer.num_steps_can_sample() >= max(self.min_steps_before_training, 1)
+        return self.split_agree(ok) if self.split_agree is not None else ok
 
     def _train_on_policy(self, start_epoch):
         """The on-policy branch (torch_rl_algorithm.py:30-32): every `num_steps_between_train_calls` env steps the trainer
@@ -249,7 +255,7 @@ class DeviceRLAlgorithm:
         # base_algorithm.py:322-343
         lg.record_tabular("Number of train calls total", self._n_train_steps_total)   # the reference's column and counter
         lg.record_tabular("Number of gradient steps total", self._n_grad_steps_total)  # ours: calls x steps per call
-        lg.record_tabular("Number of env steps total", self._n_env_steps_total)
+        lg.record_tabular("Number of env steps total", self._n_env_steps_total * self.split_world)
         lg.record_tabular("Number of rollouts total", self._n_rollouts_total)
         lg.record_tabular("Train Time (s)", self._t_train)
         lg.record_tabular("(Previous) Eval Time (s)", self._t_eval)

@@ -52,6 +52,36 @@ def comm_init(ctx, group=None):
     return world, rank
 
 
+class SplitInfo:
+    """What a run script needs to build its share of a split run: `world`, `rank`, and the `rl_alg_params` / trainer kwargs scaled to it."""
+
+    def __init__(self, world, rank, dist):
+        self.world, self.rank, self.dist = int(world), int(rank), dist
+
+    def scale(self, alg):
+        """This rank's share of the loop: counts that the reference states in env steps / rows of the whole run are divided by G (every rank
+        steps env_num / G envs and counts ITS env steps); the batch is B / G rows; the keys are removed that only rank 0 acts on."""
+        G, out = self.world, dict(alg)
+        out.pop("split_ranks", None)
+        for k in ("batch_size", "num_steps_per_epoch", "num_steps_between_train_calls", "min_steps_before_training", "replay_buffer_size"):
+            if k in out:
+                if int(out[k]) % G:
+                    raise ValueError(f"rl_alg_params.{k}={out[k]} does not split over split_ranks={G}")
+                out[k] = int(out[k]) // G
+        out["split_world"] = G
+        out["split_agree"] = self.agree
+        return out
+
+    def agree(self, flag):
+        """True only if every rank says so (a rank that trained alone would wait in the all-reduce for ever)."""
+        if self.dist is None or self.world == 1:
+            return bool(flag)
+        import torch
+        t = torch.tensor([1.0 if flag else 0.0], device="cuda" if self.dist.get_backend() == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+
 class SplitRunStep:
     """Drives one split-run SAC step on this rank.
 

@@ -30,6 +30,11 @@ def make_envs(variant, ctx, **vec_kwargs):
     env_specs = dict(variant["env_specs"])
     n_train = int(env_specs.get("env_num", env_specs.get("training_env_num", 1)))
     n_eval = int(env_specs.get("eval_env_num", min(n_train, 16)))
+    if _SPLIT is not None:       # a rank of a split run steps its share of the envs, seeded apart from the other ranks' shares
+        if n_train % _SPLIT.world:
+            raise ValueError(f"env_num={n_train} does not split over split_ranks={_SPLIT.world}")
+        n_train //= _SPLIT.world
+        seed += 1000003 * _SPLIT.rank
     training_env = get_envs(dict(env_specs, env_num=n_train, training_env_seed=seed), ctx=ctx, **vec_kwargs)
     eval_kwargs = dict(vec_kwargs)
     if vec_kwargs.get("norm_obs"):   # ppo_exp_script.py:68-75: the eval env shares the statistics and does not update them
@@ -54,7 +59,9 @@ def start(variant, gpu):
         ctx = _GROUP["ctx"].sibling(seed, share_stream=bool(os.environ.get("ILSX_GROUP_SHARE_STREAM")))
         ia.device.set_default_context(ctx)
         return ctx
-    ctx = ia.set_gpu_mode(True, gpu, seed=seed)
+    # a split run: the ctx key drives the policy noise of this rank's rows — the rank is mixed in, or every shard would draw the same eps rows
+    # (G-fold correlated noise in the batch); the networks' init seeds come from np.random and stay identical on all ranks
+    ctx = ia.set_gpu_mode(True, gpu, seed=seed + (7919 * _SPLIT.rank if _SPLIT else 0))
     if _GROUP is not None:
         _GROUP["ctx"] = ctx
     return ctx
@@ -72,6 +79,71 @@ def train(algorithm, variant):
         return algorithm
     algorithm.train(start_epoch=epoch)
     return algorithm
+
+
+# ---- one run split over G GPUs (rl_alg_params.split_ranks: G; SURVEY section 8e, BASELINE config 5 "RCCL grad all-reduce per run").  Every rank is a
+# process with a full replica of the networks, env_num / G envs, a ring of replay_buffer_size / G rows and B / G rows of every batch; the
+# library all-reduces the gradient arena between backward and update (ilswiss_amd.parallel.SplitRunStep).  The ranks come from a launcher
+# (`torchrun --nproc-per-node G run_scripts/sac_alpha_exp_script.py -e v.yaml`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env) or, when
+# there is no RANK in the env, from main() itself: it re-executes the script G times, rank r on GPU g + r, rendezvous on 127.0.0.1.
+def split_ranks_of(variant):
+    g = int((variant.get("rl_alg_params") or {}).get("split_ranks", 1) or 1)
+    return g if (g > 1 or os.environ.get("ILSX_SPLIT_FORCE")) else 0     # ILSX_SPLIT_FORCE: the split path on a one-rank communicator (tests)
+
+
+from ilswiss_amd.parallel import SplitInfo  # noqa: E402
+
+
+_SPLIT = None
+
+
+def split_info():
+    return _SPLIT
+
+
+def _split_spawn(world, gpu):
+    """No launcher: `world` copies of this command, rank r on GPU gpu + r.  A failing rank stops the others."""
+    import socket
+    import subprocess
+    import time
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ILSX_SPLIT_GPU0=str(gpu))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            rc = bad[0].returncode
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()          # exactly the PIDs started above
+            break
+        time.sleep(0.2)
+    return rc or max(p.wait() for p in procs)
+
+
+def _split_join(world, gpu):
+    """This process is rank RANK of `world`: process group (RCCL), GPU, and the SplitInfo the run script reads."""
+    global _SPLIT
+    import torch
+    import torch.distributed as dist
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541")):
+        os.environ.setdefault(k, v)
+    rank, have = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if have != max(world, 1):
+        raise SystemExit(f"rl_alg_params.split_ranks={world} but WORLD_SIZE={have}")
+    local = int(os.environ.get("ILSX_SPLIT_GPU0", gpu)) + int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    _SPLIT = SplitInfo(have, rank, dist)
+    return local
 
 
 def _log_dir(variant, default_name):
@@ -93,7 +165,21 @@ def main(experiment, default_name):
         with open(path) as f:
             variants_.append(flatten_spec(yaml.safe_load(f)))
     if len(variants_) == 1:
-        return experiment(variants_[0], args.gpu, _log_dir(variants_[0], default_name))
+        v, gpu = variants_[0], args.gpu
+        world = split_ranks_of(v)
+        if world:
+            if "RANK" not in os.environ and world > 1:
+                raise SystemExit(_split_spawn(world, gpu))
+            gpu = _split_join(world, gpu)
+        try:
+            # only rank 0 of a split run logs (the replicas are identical by construction)
+            return experiment(v, gpu, _log_dir(v, default_name) if not _SPLIT or _SPLIT.rank == 0 else None)
+        finally:
+            if _SPLIT is not None and _SPLIT.dist is not None:
+                _SPLIT.dist.barrier()
+                _SPLIT.dist.destroy_process_group()
+    if any(split_ranks_of(v) for v in variants_):
+        raise SystemExit("split_ranks and several runs per process (--group) do not combine: a split run owns its GPUs")
     from ilswiss_amd.algorithm import DeviceRLAlgorithmGroup
     _GROUP = dict(ctx=None, runs=[])
     for v in variants_:

@@ -424,3 +424,38 @@ def test_statistics_are_those_of_the_first_batch_after_end_epoch():
     g.train_from_replay([rba, rbb], 50, B)
     assert dict(ta.get_eval_statistics()) == dict(s50) and dict(tb.get_eval_statistics()) == dict(s50)
     g.close(); sib.close(); base.close()
+
+
+def test_split_run_from_the_run_script_at_one_forced_rank(tmp_path):
+    """rl_alg_params.split_ranks behind the reference's entry point: the run script joins the process group, scales the
+    loop to its rank's share, gives the ctx an RCCL communicator and trains through the library's backward -> all-reduce -> update sequence.
+    A one-GPU box can only run it on a ONE-rank communicator (ILSX_SPLIT_FORCE=1, split_ranks: 1): the log it writes must then be the plain
+    run's, number for number (the split arithmetic at G = 1 is the un-split arithmetic, and the five step forms are bit-identical)."""
+    import subprocess
+    import sys
+    spec = yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "sac", "sac_hopper_hip.yaml")))
+    sys.path.insert(0, os.path.join(ROOT, "run_scripts"))
+    from _common import flatten_spec
+    v = flatten_spec(spec)
+    v["env_specs"].update(env_num=8, eval_env_num=4)
+    v["rl_alg_params"].update(num_epochs=1, num_steps_per_epoch=800, num_steps_between_train_calls=80, num_train_steps_per_train_call=10,
+                              num_steps_per_eval=200, max_path_length=60, min_steps_before_training=160, batch_size=256, replay_buffer_size=20000)
+    rows = {}
+    for tag, extra_env, split in (("plain", {}, None), ("split", {"ILSX_SPLIT_FORCE": "1"}, 1)):
+        wd = tmp_path / tag
+        wd.mkdir()
+        vv = yaml.safe_load(yaml.dump(v))
+        if split is not None:
+            vv["rl_alg_params"]["split_ranks"] = split
+        (wd / "v.yaml").write_text(yaml.dump(vv))
+        env = dict(os.environ, **extra_env)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "run_scripts", "sac_alpha_exp_script.py"), "-e", str(wd / "v.yaml"), "-g", "0"],
+                           cwd=wd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        import glob
+        (d,) = glob.glob(str(wd / "logs" / "*" / "*--s-*"))
+        rows[tag] = _rows_without_time(d)
+    assert len(rows["plain"]) == 2 and float(rows["plain"][-1]["Number of gradient steps total"]) > 0
+    assert rows["plain"] == rows["split"]

@@ -183,3 +183,40 @@ def test_two_rank_train_from_replay_shards_is_the_stratified_batch_step():
         np.testing.assert_allclose(r[2], single.o.q1, rtol=0, atol=2e-6)
         np.testing.assert_allclose(r[3], single.o.tq2, rtol=0, atol=2e-6)
         np.testing.assert_allclose(r[4], single.o.log_alpha[0], rtol=0, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------- the run scripts' split plumbing (rl_alg_params.split_ranks)
+def _agree_worker(rank, world, port, q):
+    from ilswiss_amd.parallel import SplitInfo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sp = SplitInfo(world, rank, dist)
+    q.put((rank, sp.agree(True), sp.agree(rank == 0), sp.agree(False)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_info_scales_the_loop_and_ranks_agree_on_training():
+    """rl_alg_params of a split run: every count stated for the whole run is this rank's share, the batch is B / G rows; a train call happens
+    only when every rank can train (one rank alone in the gradient all-reduce would wait for ever)."""
+    from ilswiss_amd.parallel import SplitInfo
+    alg = dict(batch_size=256, num_steps_per_epoch=10240, num_steps_between_train_calls=1024, min_steps_before_training=10240,
+               replay_buffer_size=1000000, num_train_steps_per_train_call=250, num_epochs=3, split_ranks=2, max_path_length=1000)
+    out = SplitInfo(2, 1, None).scale(alg)
+    assert (out["batch_size"], out["num_steps_per_epoch"], out["num_steps_between_train_calls"], out["min_steps_before_training"],
+            out["replay_buffer_size"]) == (128, 5120, 512, 5120, 500000)
+    assert out["num_train_steps_per_train_call"] == 250 and out["num_epochs"] == 3 and out["max_path_length"] == 1000   # not counts of rows / env steps
+    assert "split_ranks" not in out and out["split_world"] == 2 and callable(out["split_agree"])
+    with pytest.raises(ValueError):
+        SplitInfo(3, 0, None).scale(alg)
+    world, port = 2, _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, False, False), (1, True, False, False)]
