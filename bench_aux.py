@@ -348,36 +348,55 @@ def bench_humanoid(ctx, R=None):
     from ilswiss_amd.sac import SoftActorCritic, SoftActorCriticGroup
     o, a, H, B, K, N, CAP = 376, 17, 256, 256, 4, 1024, 200_000
     envs, rbs, trs, pols = [], [], [], []
-    for k in range(K):
-        env = HipVectorEnv("humanoid", N, seed=10 + k, ctx=ctx)
-        rb = SimpleReplayBuffer(CAP, o, a, random_seed=k, ctx=ctx)
-        pol = ReparamTanhMultivariateGaussianPolicy([H, H], o, a, ctx=ctx, seed=k)
-        tr = SoftActorCritic(pol, FlattenMlp([H, H], 1, o + a, ctx=ctx, seed=k + 1), FlattenMlp([H, H], 1, o + a, ctx=ctx, seed=k + 2),
+    # every run in a context of its own (same device, its own stream and Philox key), as run_experiment.py --group 4 builds them: the four
+    # 1024-env stepper launches (one wavefront per env, 6 envs per CU: 1536 slots) then overlap instead of queueing on one stream
+    ctxs = [ctx] + [ctx.sibling(ctx.seed + 1 + k) for k in range(K - 1)]
+    for k, c in enumerate(ctxs):
+        env = HipVectorEnv("humanoid", N, seed=10 + k, ctx=c)
+        rb = SimpleReplayBuffer(CAP, o, a, random_seed=k, ctx=c)
+        pol = ReparamTanhMultivariateGaussianPolicy([H, H], o, a, ctx=c, seed=k)
+        tr = SoftActorCritic(pol, FlattenMlp([H, H], 1, o + a, ctx=c, seed=k + 1), FlattenMlp([H, H], 1, o + a, ctx=c, seed=k + 2),
                              policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
         tr.eval_statistics = {}
         envs.append(env), rbs.append(rb), trs.append(tr), pols.append(pol)
-    grp = SoftActorCriticGroup(trs)
+    grp = SoftActorCriticGroup(trs, ctx=ctx)
+    _sync1 = ctx.sync
+
+    def sync_all():
+        for c in ctxs:
+            c.sync() if c is not ctx else _sync1()
+    import ctypes as C
+    _arr = lambda xs: (C.c_void_p * K)(*[x.h for x in xs])   # noqa: E731
+    _envs, _pols, _rbs, _mins = _arr(envs), _arr(pols), _arr(rbs), (C.c_int64 * K)(*([0] * K))
+
+    def lockstep(n=1):   # n lock-step vec steps of the four runs: what DeviceRLAlgorithmGroup calls between two train triggers
+        from ilswiss_amd import _lib
+        _lib.check(ctx.lib.ilsx_rollout_steps_lockstep(_envs, _pols, _rbs, K, n, 1000, _mins, 0, 0))
     for t in range(12):     # fill: 12 x 1024 transitions per seed, random actions (min_steps_before_training)
         for env, rb in zip(envs, rbs):
             env.rollout_step(policy=None, replay=rb, max_path_length=1000, random_actions=True)
-    ctx.sync()
+    sync_all()
     res = {}
     n_env_steps = 30
-    nl, ms = _kernel_time(ctx, 9, lambda: [env.rollout_step(policy=p, replay=rb, max_path_length=1000)
-                                                              for _ in range(n_env_steps) for env, rb, p in zip(envs, rbs, pols)] and ctx.sync())
+    nl, ms = _kernel_time(ctx, 9, lambda: [envs[0].rollout_step(policy=pols[0], replay=rbs[0], max_path_length=1000) for _ in range(n_env_steps)] and ctx.sync())
     res["env_step_kernel_ms_1024_envs"] = ms / max(nl, 1)
     t0 = time.perf_counter()
     for _ in range(n_env_steps):
         for env, rb, p in zip(envs, rbs, pols):
             env.rollout_step(policy=p, replay=rb, max_path_length=1000)
-    ctx.sync()
+        sync_all()
+    dt = time.perf_counter() - t0
+    res["rollout_env_steps_per_s_one_run_at_a_time"] = K * N * n_env_steps / dt
+    t0 = time.perf_counter()
+    lockstep(n_env_steps)
+    sync_all()
     dt = time.perf_counter() - t0
     res["rollout_env_steps_per_s"] = K * N * n_env_steps / dt
-    grp.train_from_replay(rbs, 100, B); ctx.sync()
+    grp.train_from_replay(rbs, 100, B); sync_all()
     n = 1000
     t0 = time.perf_counter()
     grp.train_from_replay(rbs, n, B)
-    ctx.sync()
+    sync_all()
     dt = time.perf_counter() - t0
     res["grouped_grad_steps_per_s"] = K * n / dt
     res["us_per_lockstep"] = 1e6 * dt / n
@@ -386,10 +405,10 @@ def bench_humanoid(ctx, R=None):
         R.barrier(ctx)
     t0 = time.perf_counter()
     for _ in range(iters):
-        for env, rb, p in zip(envs, rbs, pols):
-            env.rollout_step(policy=p, replay=rb, max_path_length=1000)
+        lockstep(1)
+        sync_all()                      # the group loop waits for every run's stream before a train call (algorithm.py)
         grp.train_from_replay(rbs, per, B)
-    ctx.sync()
+    sync_all()
     dt = time.perf_counter() - t0
     res["loop_grad_steps_per_s"] = K * per * iters / dt
     res["loop_env_steps_per_s"] = K * N * iters / dt
@@ -410,6 +429,11 @@ def bench_humanoid(ctx, R=None):
                          "grouped launches carry all 4 seeds; wide inputs run the forward as two launches (layer 0, then layer 1 + heads)")
     res["stepper_kernel"] = dict(kernel="k_env3dw_step<23>", avg_launch_ms_1024_envs=res["env_step_kernel_ms_1024_envs"],
                                  bound="neither (fp64 issue-bound, one wavefront per env; DESIGN 3b)")
+    grp.close()
+    for e_ in envs:
+        e_.close()
+    for c in ctxs[1:]:
+        c.close()
     return dict(roofline=roof, metric="SAC Humanoid-v2 share of one GPU: 4 seeds x 1024 envs, aggregate grad-steps/s in the loop", unit="grad-steps/s (aggregate)",
                 value=res["loop_grad_steps_per_s"], dtype="f32 (networks) / f64 (stepper)", data="synthetic",
                 config=dict(workload="4 co-resident SAC runs, Humanoid-v2 model (obs 376, act 17), 1024 envs each, 256-256 MLP, batch 256, "

@@ -44,3 +44,12 @@ def test_compare_table(tmp_path):
                         "--hip-old", str(tmp_path / "none")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "| CPU restatement | 4 |" in r.stdout and "| HIP engine | 4 |" in r.stdout and "Welch t" in r.stdout and "epoch 25 of 25" in r.stdout
+
+
+def test_grouped_acceptance_runs_reproduce_round_5_cell_for_cell():
+    """profiles/r06_returns_grouped (ten / fourteen seeds of the reference schedule in ONE process, lock-step, through run_experiment.py --group)
+    against profiles/r05_returns_hip (the same seeds as single-run processes, round 5): every rollout column of every epoch is identical."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import returns_compare
+    seeds, bad = returns_compare.same(os.path.join(ROOT, "profiles", "r06_returns_grouped"), os.path.join(ROOT, "profiles", "r05_returns_hip"))
+    assert len(seeds) >= 10 and bad == 0, (seeds, bad)

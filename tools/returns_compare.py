@@ -36,12 +36,37 @@ def summary(name, runs, n_epochs):
                 dead=int((fin < 1000).sum()))
 
 
+ROLLOUT_COLUMNS = ("Test ", "Num Paths", "AverageReturn", "Exploration ")   # what the rollouts produce (not trainer statistics, not wall-clock times)
+
+
+def same(dir_a, dir_b):
+    """`--same A B`: are the rollout columns of the runs both directories hold identical, cell for cell?  (The acceptance check of the grouped
+    entry point: profiles/r06_returns_grouped vs profiles/r05_returns_hip.)  Returns (seeds compared, differing cells)."""
+    seeds, bad = [], 0
+    for fa in sorted(glob.glob(os.path.join(dir_a, "seed*.csv")), key=lambda p: int(os.path.basename(p)[4:-4])):
+        fb = os.path.join(dir_b, os.path.basename(fa))
+        if not os.path.exists(fb):
+            continue
+        a, b = list(csv.DictReader(open(fa))), list(csv.DictReader(open(fb)))
+        cols = [k for k in a[0] if k.startswith(ROLLOUT_COLUMNS) or k in ROLLOUT_COLUMNS]
+        d = abs(len(a) - len(b)) * len(cols) + sum(1 for ra, rb in zip(a, b) for k in cols if ra[k] != rb.get(k))
+        print(f"seed {os.path.basename(fa)[4:-4]}: {len(a)} / {len(b)} epochs, {len(cols)} rollout columns, {d} differing cells")
+        seeds.append(int(os.path.basename(fa)[4:-4]))
+        bad += d
+    print(f"{len(seeds)} seeds compared, {bad} differing cells")
+    return seeds, bad
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--same", nargs=2, metavar=("A", "B"), help="compare the rollout columns of two run directories cell for cell and exit")
     ap.add_argument("--cpu", default="profiles/r05_returns_cpu")
     ap.add_argument("--hip", default="profiles/r05_returns_hip")
     ap.add_argument("--hip-old", default="profiles/r04_returns", help="round 4's HIP runs (per-step insert, 16 eval envs), for the record")
     args = ap.parse_args()
+    if args.same:
+        seeds, bad = same(*args.same)
+        raise SystemExit(0 if seeds and not bad else 1)
     cpu, hip = load(args.cpu), load(args.hip)
     if not cpu or not hip:
         raise SystemExit("no runs found")

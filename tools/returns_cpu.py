@@ -140,7 +140,7 @@ def run(seed, out_csv, epochs=102, steps_per_epoch=10000, between=1000, per_call
     obs = env.reset(ids)
     paths = [[] for _ in range(env_num)]
     n_env_steps = n_prev_train = n_grad = 0
-    t_start, last = time.time(), {}
+    t_start, last = time.time(), None   # `last`: the epoch's eval_statistics — filled by the FIRST train_step after end_epoch (sac_alpha.py:185-190)
 
     def end_paths(which):   # _handle_vec_rollout_ending (:509-519)
         done_rets = []
@@ -173,13 +173,17 @@ def run(seed, out_csv, epochs=102, steps_per_epoch=10000, between=1000, per_call
                 n_prev_train = n_env_steps
                 for _ in range(per_call):
                     b = buf.gather(buf.draw_indices(batch))
-                    last = sac.train_step(b, r_train.standard_normal((batch, a)).astype(np.float32),
-                                          r_train.standard_normal((batch, a)).astype(np.float32))
+                    res = sac.train_step(b, r_train.standard_normal((batch, a)).astype(np.float32),
+                                         r_train.standard_normal((batch, a)).astype(np.float32))
+                    if last is None:   # "Alpha" is the temperature after that step's own update (sac_alpha.py:160-166,208-212)
+                        last = dict(res, alpha=float(sac.alpha))
                 n_grad += per_call
         rets, lens = evaluate()
+        st = last or {}
         w.writerow([epoch, n_env_steps, n_grad, rets.mean(), rets.std(), len(rets), lens.mean(), np.mean(expl) if expl else "", len(expl),
-                    buf.size, float(sac.alpha), last.get("qf1_loss", ""), last.get("policy_loss", ""), time.time() - t_start])
+                    buf.size, st.get("alpha", float(sac.alpha)), st.get("qf1_loss", ""), st.get("policy_loss", ""), time.time() - t_start])
         f.flush()
+        last = None   # end_epoch
         if not quiet:
             print(f"seed {seed} epoch {epoch} env {n_env_steps} grad {n_grad} test {rets.mean():.1f} ({len(rets)} paths) "
                   f"expl {np.mean(expl) if expl else float('nan'):.1f} alpha {float(sac.alpha):.4f} t {time.time() - t_start:.0f}s", flush=True)

@@ -40,6 +40,39 @@ __global__ __launch_bounds__(256) void k_tilesync(float* slab, unsigned* flags, 
         if (MODE == 6) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
+        if (MODE == 8) {   // PIPELINED poll: three looks in flight, each consumed as it lands (s_waitcnt vmcnt(2)) and re-issued at once
+          unsigned a, b, c, n;
+          asm volatile(
+              "global_load_dword %[a], %[p], off sc1\n\t"
+              "s_sleep 1\n\t"
+              "global_load_dword %[b], %[p], off sc1\n\t"
+              "s_sleep 1\n\t"
+              "global_load_dword %[c], %[p], off sc1\n\t"
+              "s_mov_b32 %[n], 0\n"
+              ".Lpoll_%=:\n\t"
+              "s_waitcnt vmcnt(2)\n\t"
+              "v_cmp_le_u32_e32 vcc, %[t], %[a]\n\t"
+              "s_cbranch_vccnz .Ldone_%=\n\t"
+              "global_load_dword %[a], %[p], off sc1\n\t"
+              "s_waitcnt vmcnt(2)\n\t"
+              "v_cmp_le_u32_e32 vcc, %[t], %[b]\n\t"
+              "s_cbranch_vccnz .Ldone_%=\n\t"
+              "global_load_dword %[b], %[p], off sc1\n\t"
+              "s_waitcnt vmcnt(2)\n\t"
+              "v_cmp_le_u32_e32 vcc, %[t], %[c]\n\t"
+              "s_cbranch_vccnz .Ldone_%=\n\t"
+              "global_load_dword %[c], %[p], off sc1\n\t"
+              "s_add_u32 %[n], %[n], 1\n\t"
+              "s_cmp_lt_u32 %[n], 0x100000\n\t"
+              "s_cbranch_scc1 .Lpoll_%=\n\t"
+              "s_mov_b32 %[n], -1\n"
+              ".Ldone_%=:\n\t"
+              "s_waitcnt vmcnt(0)"
+              : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [n] "=&s"(n)
+              : [p] "v"(flag), [t] "v"(target)
+              : "vcc", "scc", "memory");
+          if (n == 0xffffffffu) *err = 1;
+        } else
         if (MODE == 7) {   // the poll on the SCALAR memory path (glc: past the scalar cache, from the L2): no vector-memory counter involved
           unsigned v;
           do {
@@ -80,7 +113,7 @@ __global__ __launch_bounds__(256) void k_tilesync(float* slab, unsigned* flags, 
     // the neighbour's line was written by another CU: read it past this CU's vector L1 (agent-scope load)
     const float* theirs = slab + ((size_t)(r & 1) * NWG + nb) * 256 + t;
     if (MODE == 4) asm volatile("buffer_inv sc1" ::: "memory");
-    if (MODE == 5 || MODE == 6 || MODE == 7) asm volatile("buffer_inv sc0" ::: "memory");
+    if (MODE >= 5) asm volatile("buffer_inv sc0" ::: "memory");
     if (MODE >= 4) acc = *(volatile const float*)theirs;
     else
     acc = MODE == 2 ? __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -112,7 +145,7 @@ int main() {
   unsigned base = 0;
   // mode 2 (workgroup-scope atomics on the DATA, no invalidate) is not run by default: its first launch can spin on a stale L1 line
   // until the bound trips (4 s)
-  for (int mode = 3; mode < 8; ++mode) {
+  for (int mode = 3; mode < 9; ++mode) {
     CHK(hipMemset(err, 0, 4));
     for (int rep = 0; rep < 3; ++rep) {
       CHK(hipEventRecord(e0, st));
@@ -123,7 +156,8 @@ int main() {
       else if (mode == 4) hipLaunchKernelGGL(k_tilesync<4>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
       else if (mode == 5) hipLaunchKernelGGL(k_tilesync<5>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
       else if (mode == 6) hipLaunchKernelGGL(k_tilesync<6>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
-      else hipLaunchKernelGGL(k_tilesync<7>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
+      else if (mode == 7) hipLaunchKernelGGL(k_tilesync<7>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
+      else hipLaunchKernelGGL(k_tilesync<8>, dim3(TILES, MEMBERS), dim3(256), 0, st, slab, flags, base, out, clk, err);
       CHK(hipEventRecord(e1, st));
       CHK(hipStreamSynchronize(st));
       base += ROUNDS * MEMBERS;
@@ -132,7 +166,7 @@ int main() {
       CHK(hipMemcpy(h, clk, sizeof h, hipMemcpyDeviceToHost)); CHK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost)); CHK(hipMemcpy(ho, out, 16, hipMemcpyDeviceToHost));
       unsigned long long mx = 0; for (auto v : h) mx = v > mx ? v : mx;
       printf("tile-local hand-off, %s: %.2f us per round (kernel %.1f us / %d rounds; slowest workgroup %.2f us per round)  err=%d out=%g\n",
-             mode == 0 ? "release/acquire atomics" : mode == 1 ? "relaxed atomics + __threadfence" : mode == 2 ? "WORKGROUP-scope relaxed atomics, no fence (same-XCD L2)" : mode == 3 ? "AGENT-scope relaxed atomics, no fence" : mode == 4 ? "plain data + agent flag + buffer_inv sc1" : mode == 5 ? "plain data + agent flag + buffer_inv sc0" : mode == 6 ? "plain data + WORKGROUP flag + buffer_inv sc0" : "plain data + agent flag polled by s_load glc + buffer_inv sc0", 1e3 * ms / ROUNDS, 1e3 * ms, ROUNDS, mx * 0.01 / ROUNDS, herr, ho[0]);
+             mode == 0 ? "release/acquire atomics" : mode == 1 ? "relaxed atomics + __threadfence" : mode == 2 ? "WORKGROUP-scope relaxed atomics, no fence (same-XCD L2)" : mode == 3 ? "AGENT-scope relaxed atomics, no fence" : mode == 4 ? "plain data + agent flag + buffer_inv sc1" : mode == 5 ? "plain data + agent flag + buffer_inv sc0" : mode == 6 ? "plain data + WORKGROUP flag + buffer_inv sc0" : mode == 7 ? "plain data + agent flag polled by s_load glc + buffer_inv sc0" : "plain data + agent flag, PIPELINED poll (3 looks in flight) + buffer_inv sc0", 1e3 * ms / ROUNDS, 1e3 * ms, ROUNDS, mx * 0.01 / ROUNDS, herr, ho[0]);
     }
   }
   hipGraph_t g; hipGraphExec_t ge;
