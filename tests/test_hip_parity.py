@@ -684,3 +684,41 @@ def test_sac_steps_with_unequal_widths_vs_oracle(ctx):
         np.testing.assert_allclose(tr.get_params(nm), ov, rtol=0, atol=5e-5, err_msg=nm)
     snap = tr.get_snapshot()                          # optimiser state crosses the ABI in logical sizes too
     assert snap["qf1_optimizer"]["exp_avg"].size == q10.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("o,a,B,nb", [(11, 3, 256, 8), (11, 3, 100, 3), (17, 6, 256, 5), (17, 6, 37, 7), (111, 8, 64, 3), (376, 17, 50, 2)],
+                         ids=["hopper", "hopper_ragged", "walker", "walker_ragged", "ant_generic", "humanoid_generic"])
+def test_replay_sample_many_draws_what_the_sample_kernel_draws(o, a, B, nb):
+    """The bandwidth form (one index draw per row, shared across the row's 16-byte pieces through lane exchanges; 8- and 16-piece records as
+    unrolled instances, any other width one record at a time) returns, batch by batch, exactly the rows ilsx_replay_sample draws call by call —
+    same Philox counters — and whole records, also when the row count is not a multiple of a wavefront's 64."""
+    import ctypes as C
+
+    import ilswiss_amd as ia
+    rng = np.random.default_rng(3)
+    cap = 3000
+    data = (rng.normal(0, 1, (cap, o)).astype(np.float32), rng.normal(0, 1, (cap, a)).astype(np.float32), np.arange(cap, dtype=np.float32),
+            (rng.random(cap) < 0.1).astype(np.uint8), rng.normal(0, 1, (cap, o)).astype(np.float32))
+    c1, c2 = ia.Context(0, seed=5), ia.Context(0, seed=5)
+    rb1, rb2 = ia.SimpleReplayBuffer(cap, o, a, random_seed=9, ctx=c1), ia.SimpleReplayBuffer(cap, o, a, random_seed=9, ctx=c2)
+    rb1.add_rows(*data), rb2.add_rows(*data)
+    rec = C.c_int()
+    ia._lib.check(c1.lib.ilsx_replay_record_floats(rb1.h, C.byref(rec)))
+    bufs = [c1.empty((B, o)), c1.empty((B, a)), c1.empty((B,)), c1.empty((B,)), c1.empty((B, o)), c1.empty((B,), np.int64)]
+    idx = []
+    for _ in range(nb):
+        ia._lib.check(c1.lib.ilsx_replay_sample(rb1.h, B, None, *[b.ptr for b in bufs]))
+        idx.append(bufs[5].numpy().copy())
+    idx = np.concatenate(idx)
+    out = c2.empty((nb * B + 5, rec.value))
+    out.copy_from(np.full((nb * B + 5, rec.value), -7.0, np.float32))
+    ia._lib.check(c2.lib.ilsx_replay_sample_many(rb2.h, nb, B, out.ptr))
+    r = out.numpy()
+    np.testing.assert_array_equal(r[:nb * B, o + a].astype(np.int64), idx)                 # the reward column holds the row id
+    np.testing.assert_array_equal(r[:nb * B, :o], data[0][idx])
+    np.testing.assert_array_equal(r[:nb * B, o:o + a], data[1][idx])
+    np.testing.assert_array_equal(r[:nb * B, o + a + 1], data[3][idx].astype(np.float32))
+    np.testing.assert_array_equal(r[:nb * B, o + a + 2:2 * o + a + 2], data[4][idx])
+    assert (r[nb * B:] == -7.0).all()                                                       # nothing written past the last row
+    c1.close(); c2.close()
