@@ -588,14 +588,15 @@ def main():
     # config 5's per-GPU shapes on EVERY rank (N > 1: 8 GPUs x grouped seeds — what north_star's "32 seeds x 1024 envs over 8 GPUs" means):
     # K = 8 grouped Hopper runs and 4 x 1024 grouped Humanoid runs, each rank on its own GPU, no collective in the data path
     legs = {}
+    multi = world > 1 or bool(os.environ.get("ILSX_BENCH_FORCE_DIST"))   # the override runs the every-rank form of the legs on a one-rank group
     if not args.no_seeds:
         try:
-            legs["co_resident_seeds"] = co_resident_seeds(R=R if world > 1 else None)
+            legs["co_resident_seeds"] = co_resident_seeds(R=R if multi else None)
         except Exception as e:   # noqa: BLE001 — secondary leg
             legs["co_resident_seeds"] = dict(error=repr(e)[:300])
             if world > 1:
                 raise            # a rank that skipped the leg's barriers would hang the others: fail the run instead
-    if world > 1 and not args.no_aux:
+    if multi and not args.no_aux:
         import bench_aux
         hctx = ia.Context(local, seed=77 + rank)
         legs["humanoid_4x1024"] = bench_aux.bench_humanoid(hctx, R=R)
@@ -705,6 +706,8 @@ def main():
             actx = ia.Context(local, seed=77)
             for key, fn in (("ppo_8192x128", bench_aux.bench_ppo), ("gail_walker", bench_aux.bench_gail),
                             ("humanoid_4x1024", bench_aux.bench_humanoid)):
+                if key in legs:
+                    continue     # already run in its every-rank form above
                 try:
                     result[key] = fn(actx)
                 except Exception as e:   # noqa: BLE001 — the headline line must come out whatever a secondary leg does

@@ -367,7 +367,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
 
 // One vec-env step; the arguments, the reward / termination / record / auto-reset rules are those of k_env_step.
 template <int NB, int MR>
-__global__ __launch_bounds__(64) void k_envg_step(const EnvStepArgs A) {
+__device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
   constexpr int N = NB + 2;
   using O = EgOff<NB, MR>;
   extern __shared__ __attribute__((aligned(16))) double smd_all[];
@@ -494,3 +494,15 @@ __global__ __launch_bounds__(64) void k_envg_step(const EnvStepArgs A) {
     if (dof) { A.qpos[(size_t)l * A.n_env + env] = q; A.qvel[(size_t)l * A.n_env + env] = v; }
   }
 }
+
+template <int NB, int MR>
+__global__ __launch_bounds__(64) void k_envg_step(const EnvStepArgs A) { envg_step_dev<NB, MR>(A); }
+
+// The same step for several RUNS in one launch (the lock-step rollout of co-resident seeds, ilsx_rollout_steps_lockstep): blockIdx.y = run,
+// every run with its own state, model record, actions, ring / staging area, Philox key and step counter — a row of the grid is exactly the
+// launch that run would make alone (same arithmetic, same draws).  Ten 4-env runs are ten single-wavefront launches otherwise.
+#define ENVG_MAX_RUNS 16
+struct EnvStepGroupArgs { EnvStepArgs a[ENVG_MAX_RUNS]; };
+static_assert(sizeof(EnvStepGroupArgs) <= 4096, "the runs' records travel in the kernel-argument segment (4 KB)");
+template <int NB, int MR>
+__global__ __launch_bounds__(64) void k_envg_step_runs(const EnvStepGroupArgs G) { envg_step_dev<NB, MR>(G.a[blockIdx.y]); }

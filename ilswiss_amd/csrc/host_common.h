@@ -192,6 +192,7 @@ struct ilsx_replay {
   int o = 0, a = 0, rec = 0;  // rec = floats per record (multiple of 32)
   float* data = nullptr;      // [cap][rec]
   DevReplayState* dstate = nullptr;
+  bool dstate_stale = false;   // the host cursors moved (fused rollout) since {size, top} were last written to `dstate`: replay_flush_state
   uint64_t seed = 0;
   uint32_t rng_stream = 0;
   unsigned long long sample_ctr = 0;  // host-side Philox step for standalone sample calls
@@ -200,6 +201,8 @@ struct ilsx_replay {
   std::deque<std::pair<int64_t, int64_t>> trajs;  // insertion-ordered (start,end)
   std::vector<uint8_t> start_flag;                // slot is a key of `trajs`
 };
+// bring the device copy of {size, top} up to date (enqueued on the ring's stream) before a kernel that draws from the ring reads it
+int replay_flush_state(ilsx_replay* rb);
 // n rows were written into the ring at [top, top+n) by a device kernel: advance the cursors.
 int replay_advance_device_rows(ilsx_replay* rb, int n);
 // n_paths whole episodes staged at stage[env][t][rec] enter the ring contiguously, in the order given (path mode of the fused rollout)

@@ -867,6 +867,8 @@ static int disc_train_step_from_rings(ilsx_disc* d, ilsx_replay* expert_rb, ilsx
   if (expert_rb->size < 1 || policy_rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_advirl_train: a replay buffer is empty");
   ilsx_ctx* ctx = d->ctx;
   const int gp = d->cfg.use_grad_pen ? 1 : 0, tot = B * d->D;
+  ILSX_TRY(replay_flush_state(expert_rb));
+  ILSX_TRY(replay_flush_state(policy_rb));
   // the counters advance exactly as ilsx_replay_sample(expert) ; ilsx_replay_sample(policy) would advance them
   const DiscRing E = {expert_rb->data, expert_rb->dstate, expert_rb->seed, expert_rb->rng_stream, expert_rb->rec, ++expert_rb->sample_ctr};
   const DiscRing P = {policy_rb->data, policy_rb->dstate, policy_rb->seed, policy_rb->rng_stream, policy_rb->rec, ++policy_rb->sample_ctr};

@@ -1238,12 +1238,40 @@ static int env_after_step_norm(ilsx_vecenv* e) {
 
 // One iteration of BaseAlgorithm's sampling loop (base_algorithm.py:183-277) for ALL envs, on the device:
 // actions (policy or uniform random) -> physics -> transition record into the replay ring -> auto-reset.
+// The stepper's arguments for one fused rollout step of `e` (auto-reset, record into `rb`'s ring — or, with path mode on, into the per-env
+// episode staging area, allocated on first use).
+static int rollout_env_args(ilsx_vecenv* e, ilsx_replay* rb, int max_path_length, int no_terminal, unsigned long long step, EnvStepArgs* out) {
+  ilsx_ctx* ctx = e->ctx;
+  EnvStepArgs& A = *out;
+  memset(&A, 0, sizeof A);
+  A.m = e->dm; A.qpos = e->qpos; A.qvel = e->qvel; A.n_env = e->n_env;
+  A.ids = nullptr; A.n_ids = e->n_env; A.act = e->act;
+  A.obs = e->nobs; A.rew = e->rew; A.done = e->done;
+  A.obs_cur = e->obs_cur; A.auto_reset = 1; A.max_path_length = max_path_length;
+  A.ep_len = e->ep_len; A.ep_ret = e->ep_ret; A.stats = e->stats;
+  if (rb) { A.replay = rb->data; A.rec = rb->rec; A.cap = rb->cap; A.top = rb->top; }
+  A.seed = e->seed; A.stream = e->rng_stream; A.step = step; A.no_terminal = no_terminal;
+  if (rb && e->path_mode) {
+    if (e->stage && (e->stage_rec != rb->rec || e->stage_len < max_path_length))
+      ILSX_FAIL(ILSX_ERR_ARG, "path mode: staging holds %d-step episodes of %d-float records, asked for %d / %d", e->stage_len, e->stage_rec,
+                max_path_length, rb->rec);
+    if (!e->stage) {
+      if (max_path_length < 1 || max_path_length >= rb->cap) ILSX_FAIL(ILSX_ERR_ARG, "path mode needs 1 <= max_path_length < replay capacity");
+      ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * max_path_length * rb->rec * 4, (void**)&e->stage));
+      ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * 4, (void**)&e->flush_len));
+      e->stage_len = max_path_length; e->stage_rec = rb->rec;
+      HIPCHK(hipHostMalloc((void**)&e->flush_host, (size_t)e->n_env * sizeof(int), hipHostMallocDefault));
+    }
+    A.stage = e->stage; A.stage_len = e->stage_len; A.flush_len = e->flush_len;
+  }
+  return ILSX_OK;
+}
 // path mode, second half of a step: wait for the step, move the episodes that ended in it from the staging area into the ring
-static int rollout_paths_finish(ilsx_vecenv* e) {
+static int rollout_paths_finish(ilsx_vecenv* e, bool synced = false) {   // synced: the caller has already waited for the stream the step ran on
   ilsx_replay* rb = e->paths_pending;
   if (!rb) return ILSX_OK;
   e->paths_pending = nullptr;
-  HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  if (!synced) HIPCHK(hipStreamSynchronize(e->ctx->stream));
   std::vector<int> envs, lens; std::vector<uint8_t> term;
   for (int i = 0; i < e->n_env; ++i)
     if (e->flush_host[i]) { envs.push_back(i); lens.push_back(e->flush_host[i] & ((1 << 30) - 1)); term.push_back((e->flush_host[i] >> 30) & 1); }
@@ -1273,33 +1301,13 @@ static int rollout_step_impl(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* label_pi, i
     ILSX_TRY(ilsx_policy_act(pi, e->policy_obs(), e->n_env, deterministic, nullptr, e->act, nullptr));
   }
   EnvStepArgs A;
-  memset(&A, 0, sizeof A);
-  A.m = e->dm; A.qpos = e->qpos; A.qvel = e->qvel; A.n_env = e->n_env;
-  A.ids = nullptr; A.n_ids = e->n_env; A.act = e->act;
-  A.obs = e->nobs; A.rew = e->rew; A.done = e->done;
-  A.obs_cur = e->obs_cur; A.auto_reset = 1; A.max_path_length = max_path_length;
-  A.ep_len = e->ep_len; A.ep_ret = e->ep_ret; A.stats = e->stats;
-  if (rb) { A.replay = rb->data; A.rec = rb->rec; A.cap = rb->cap; A.top = rb->top; }
-  A.seed = e->seed; A.stream = e->rng_stream; A.step = step; A.no_terminal = no_terminal;
+  ILSX_TRY(rollout_env_args(e, rb, max_path_length, no_terminal, step, &A));
   if (label_pi) {   // DAgger._handle_step (dagger.py:45-71): the stored action is the expert's for the observation acted on
     if (!e->act_label) ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * e->a * 4, (void**)&e->act_label));
     ILSX_TRY(ilsx_policy_act(label_pi, e->policy_obs(), e->n_env, label_deterministic, nullptr, e->act_label, nullptr));
     A.rec_act = e->act_label;
   }
   const bool paths = rb && e->path_mode;
-  if (paths) {
-    if (e->stage && (e->stage_rec != rb->rec || e->stage_len < max_path_length))
-      ILSX_FAIL(ILSX_ERR_ARG, "path mode: staging holds %d-step episodes of %d-float records, asked for %d / %d", e->stage_len, e->stage_rec,
-                max_path_length, rb->rec);
-    if (!e->stage) {
-      if (max_path_length < 1 || max_path_length >= rb->cap) ILSX_FAIL(ILSX_ERR_ARG, "path mode needs 1 <= max_path_length < replay capacity");
-      ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * max_path_length * rb->rec * 4, (void**)&e->stage));
-      ILSX_TRY(ctx_alloc(ctx, (size_t)e->n_env * 4, (void**)&e->flush_len));
-      e->stage_len = max_path_length; e->stage_rec = rb->rec;
-      HIPCHK(hipHostMalloc((void**)&e->flush_host, (size_t)e->n_env * sizeof(int), hipHostMallocDefault));
-    }
-    A.stage = e->stage; A.stage_len = e->stage_len; A.flush_len = e->flush_len;
-  }
   ILSX_TRY(launch_env_step(e, A));
   if (paths) {
     HIPCHK(hipMemcpyAsync(e->flush_host, e->flush_len, (size_t)e->n_env * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1332,11 +1340,122 @@ extern "C" int ilsx_rollout_step_end(ilsx_vecenv* e) {
 // run's step is enqueued on its own stream, then every run's host part is done — K x n_steps x 2 calls through the binding become one.
 // Run k acts at random while its ring holds fewer than min_steps_before_training[k] samples (base_algorithm.py:186-188), exactly as the
 // per-step form decides it.
+// Can the K runs' steps go out as ONE launch per stage?  Planar steppers of one kernel instantiation with the same env count, plain
+// observations, policies of one shape (the generic forward takes up to four tasks per launch), everything on one device.
+static bool rollout_runs_groupable(ilsx_vecenv* const* envs, ilsx_net* const* pis, int n_runs) {
+  static const bool off = getenv("ILSX_ROLLOUT_NO_GROUP") != nullptr || getenv("ILSX_ENV2D_LANE") != nullptr;
+  if (off || n_runs < 2) return false;
+  const ilsx_vecenv* e0 = envs[0];
+  const ilsx_net* p0 = pis[0];
+  if (e0->engine != 0 || e0->ctx->prof_on) return false;
+  for (int k = 0; k < n_runs; ++k) {
+    const ilsx_vecenv* e = envs[k];
+    const ilsx_net* p = pis[k];
+    if (e->engine != 0 || e->norm_obs || e->n_env != e0->n_env || e->hm.nb != e0->hm.nb || (e->hm.max_rows > 12) != (e0->hm.max_rows > 12) ||
+        e->o != e0->o || e->a != e0->a || e->ctx->device != e0->ctx->device)
+      return false;
+    if (memcmp(&p->lay.cfg, &p0->lay.cfg, sizeof p->lay.cfg) || p->noise_policy != p0->noise_policy || p->out_linear != p0->out_linear ||
+        (p->lay.cfg.n_heads != 2 && !p->noise_policy))
+      return false;
+  }
+  return true;
+}
+template <int NB, int MR>
+static int launch_envg_step_runs_t(ilsx_ctx* ctx, const EnvStepGroupArgs& G, int n, int n_env) {
+  const size_t lds = (((sizeof(PlanarModelDev) + 7) / 8) + (size_t)EG_ENVS * EgOff<NB, MR>::TOTAL) * sizeof(double);
+  hipLaunchKernelGGL((k_envg_step_runs<NB, MR>), dim3((n_env + EG_ENVS - 1) / EG_ENVS, n), dim3(64), lds, ctx->stream, G);
+  HIPCHK(hipGetLastError());
+  return ILSX_OK;
+}
+// One lock-step iteration of K groupable runs on ONE stream (run 0's): the runs' actions — policy inference as launches of up to four tasks,
+// each task on its run's Philox key and call counter, or uniform draws while a run is still filling its ring —, ONE stepper launch whose grid
+// rows are the runs (k_envg_step_runs), the read-back of the episode-end flags with path mode on.  Per run the launches do exactly what its own
+// ilsx_rollout_step would do: same arithmetic, same draws.
+static int rollout_lockstep_grouped(ilsx_vecenv* const* envs, ilsx_net* const* pis, ilsx_replay* const* rbs, int n_runs, int max_path_length,
+                                    const int64_t* min_steps, int deterministic, int no_terminal) {
+  ilsx_ctx* gctx = envs[0]->ctx;
+  hipStream_t gs = gctx->stream;
+  std::vector<int> pol;   // runs that act through their policy this step
+  for (int k = 0; k < n_runs; ++k) {
+    ilsx_vecenv* e = envs[k];
+    if (e->paths_pending) ILSX_FAIL(ILSX_ERR_STATE, "ilsx_rollout_steps_lockstep: run %d has an unfinished step (ilsx_rollout_step_end)", k);
+    if (rbs[k]->o != e->o || rbs[k]->a != e->a || e->n_env > rbs[k]->cap) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_steps_lockstep: replay %d does not match its env", k);
+    if (rbs[k]->size < min_steps[k]) {
+      const int tot = e->n_env * e->a;
+      hipLaunchKernelGGL(k_random_actions, dim3((tot + 255) / 256), dim3(256), 0, gs, e->act, e->n_env, e->seed, e->rng_stream ^ 0x5A5A5A5Au,
+                         e->step_ctr + 1, e->a);
+    } else pol.push_back(k);
+  }
+  for (size_t i = 0; i < pol.size(); i += 4) {
+    FwdArgs A;
+    memset(&A, 0, sizeof A);
+    const int nt = (int)std::min<size_t>(4, pol.size() - i);
+    for (int j = 0; j < nt; ++j) {
+      ilsx_vecenv* e = envs[pol[i + j]];
+      ilsx_net* pi = pis[pol[i + j]];
+      FwdTask& t = A.t[j];
+      t.net = net_view(pi->lay, pi->base);
+      t.x0 = e->policy_obs(); t.d0 = pi->lay.cfg.in_dim; t.s0 = pi->lay.cfg.in_dim;
+      t.head = deterministic ? HEAD_TANH_DET : HEAD_TANH_SAMPLE;
+      if (pi->noise_policy) {
+        t.head = pi->out_linear ? HEAD_DET_LIN_NOISE : HEAD_DET_TANH_NOISE;
+        t.noise = deterministic ? 0.0f : pi->noise; t.noise_clip = pi->noise_clip; t.max_act = pi->max_act;
+      }
+      t.action = e->act;
+      t.rng_stream = 0x41435400u;  // 'ACT' (ilsx_policy_act)
+      t.seed_t = pi->ctx->seed; t.step_t = ++pi->ctx->act_calls;   // (>= 1: the task's own key)
+    }
+    A.rows = envs[0]->n_env; A.ntasks = nt; A.seed = gctx->seed;
+    ILSX_TRY(launch_fwd(gctx, A, pis[0]->lay.cfg.hidden, pis[0]->lay.cfg.act, pis[0]->lay.KP));
+  }
+  for (int k0 = 0; k0 < n_runs; k0 += ENVG_MAX_RUNS) {
+    EnvStepGroupArgs G;
+    const int n = std::min(ENVG_MAX_RUNS, n_runs - k0);
+    for (int j = 0; j < n; ++j) {
+      ilsx_vecenv* e = envs[k0 + j];
+      ILSX_TRY(rollout_env_args(e, rbs[k0 + j], max_path_length, no_terminal, ++e->step_ctr, &G.a[j]));
+    }
+    const ilsx_vecenv* e0 = envs[0];
+    if (e0->hm.nb == 4) ILSX_TRY((launch_envg_step_runs_t<4, 8>(gctx, G, n, e0->n_env)));
+    else if (e0->hm.max_rows > 12) ILSX_TRY((launch_envg_step_runs_t<7, 16>(gctx, G, n, e0->n_env)));
+    else ILSX_TRY((launch_envg_step_runs_t<7, 12>(gctx, G, n, e0->n_env)));
+  }
+  bool any_paths = false;
+  for (int k = 0; k < n_runs; ++k) {
+    ilsx_vecenv* e = envs[k];
+    if (e->path_mode) {
+      HIPCHK(hipMemcpyAsync(e->flush_host, e->flush_len, (size_t)e->n_env * 4, hipMemcpyDeviceToHost, gs));
+      e->paths_pending = rbs[k];
+      any_paths = true;
+    } else ILSX_TRY(replay_advance_device_rows(rbs[k], e->n_env));
+  }
+  if (any_paths) {
+    HIPCHK(hipStreamSynchronize(gs));
+    for (int k = 0; k < n_runs; ++k) ILSX_TRY(rollout_paths_finish(envs[k], /*synced=*/true));
+  }
+  return ILSX_OK;
+}
+// n_steps lock-step sampling iterations of K runs (the inner loop of DeviceRLAlgorithmGroup between two train triggers): K x n_steps x 2 calls
+// through the binding become one.  Run k acts at random while its ring holds fewer than min_steps_before_training[k] samples
+// (base_algorithm.py:186-188), exactly as the per-step form decides it.  Runs of one shape (rollout_runs_groupable: the reference's regime of a
+// few envs per run and many seeds) go out as one launch per stage on run 0's stream; otherwise every run's step is enqueued on its own stream
+// and then every run's host part is done.
 extern "C" int ilsx_rollout_steps_lockstep(ilsx_vecenv* const* envs, ilsx_net* const* pis, ilsx_replay* const* rbs, int n_runs, int n_steps,
                                            int max_path_length, const int64_t* min_steps_before_training, int deterministic, int no_terminal) {
   if (!envs || !pis || !rbs || !min_steps_before_training || n_runs < 1 || n_steps < 0) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_steps_lockstep: bad argument");
   for (int k = 0; k < n_runs; ++k)
     if (!envs[k] || !pis[k] || !rbs[k]) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_rollout_steps_lockstep: run %d has a NULL env / policy / replay", k);
+  if (rollout_runs_groupable(envs, pis, n_runs)) {
+    HIPCHK(hipSetDevice(envs[0]->ctx->device));
+    // everything the runs' own streams still hold (an evaluation, a train call, a ring insert) happens before the grouped launches, and they
+    // are complete when this call returns: host waits (an event wait would slow the stream's later graph launches, profiles/r06_grp_streams.txt)
+    for (int k = 1; k < n_runs; ++k)
+      if (envs[k]->ctx->stream != envs[0]->ctx->stream) HIPCHK(hipStreamSynchronize(envs[k]->ctx->stream));
+    for (int t = 0; t < n_steps; ++t)
+      ILSX_TRY(rollout_lockstep_grouped(envs, pis, rbs, n_runs, max_path_length, min_steps_before_training, deterministic, no_terminal));
+    HIPCHK(hipStreamSynchronize(envs[0]->ctx->stream));
+    return ILSX_OK;
+  }
   for (int t = 0; t < n_steps; ++t) {
     for (int k = 0; k < n_runs; ++k)
       ILSX_TRY(rollout_step_impl(envs[k], pis[k], nullptr, 0, rbs[k], max_path_length, rbs[k]->size < min_steps_before_training[k] ? 1 : 0,

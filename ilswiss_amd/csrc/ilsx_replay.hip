@@ -160,12 +160,20 @@ __global__ __launch_bounds__(256) void k_replay_sample_many(const float4* __rest
   }
 }
 
+// The device copy of {size, top} is only read by kernels that DRAW from the ring (the fused gather of a train step, the sample kernels, the
+// discriminator's prep).  The fused rollout advances the cursors every vec step; pushing the pair with a launch of its own each time was a
+// third launch per rollout step for nothing — the rollout paths now only mark the state stale (replay_mark_state) and every consumer
+// brings it up to date first (replay_flush_state, on the ring's stream, ahead of its own launches).
+int replay_flush_state(ilsx_replay* rb);
+static int replay_mark_state(ilsx_replay* rb) { rb->dstate_stale = true; return ILSX_OK; }
 static int replay_push_state(ilsx_replay* rb) {
+  rb->dstate_stale = false;
   hipLaunchKernelGGL(k_replay_set_state, dim3(1), dim3(1), 0, rb->ctx->stream, rb->dstate, (long long)rb->size,
                      (long long)rb->top);
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
+int replay_flush_state(ilsx_replay* rb) { return rb->dstate_stale ? replay_push_state(rb) : ILSX_OK; }
 
 extern "C" int ilsx_replay_create(ilsx_ctx* ctx, int64_t capacity, int obs_dim, int act_dim, uint64_t seed,
                                   ilsx_replay** out) {
@@ -322,7 +330,7 @@ int replay_insert_paths(ilsx_replay* rb, const float* stage, int stage_len, cons
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));   // `table` and the staging buffer are reused by the next call
-  return replay_push_state(rb);
+  return replay_mark_state(rb);
 }
 
 int replay_advance_device_rows(ilsx_replay* rb, int n) {
@@ -330,7 +338,7 @@ int replay_advance_device_rows(ilsx_replay* rb, int n) {
   // uniformly over rows, simple_replay_buffer.py:242); overwritten trajectory starts are still dropped.
   for (int i = 0; i < n; ++i) host_advance(rb);
   rb->cur_start = rb->top;
-  return replay_push_state(rb);
+  return replay_mark_state(rb);
 }
 
 // _absorbing [cap, 2] (simple_replay_buffer.py:66-67,91-92) lives in the two floats behind next_obs of every record; add_sample
@@ -379,6 +387,7 @@ int replay_launch_sample(ilsx_replay* rb, int B, const int64_t* idx, const DevSc
                          unsigned long long step_host, float* obs, float* act, float* rew, float* done, float* nobs,
                          int64_t* idx_out) {
   const int total = B * rb->rec;
+  ILSX_TRY(replay_flush_state(rb));
   ProfScope ps(rb->ctx, ILSX_K_REPLAY_SAMPLE);
   ILSX_LAUNCH(ps, k_replay_sample, dim3((total + 255) / 256), dim3(256), 0, rb->ctx->stream, rb->data, rb->rec,
                      rb->dstate, (const long long*)idx, rb->seed, rb->rng_stream, scal, step_host, B, rb->o, rb->a, obs,
@@ -401,6 +410,7 @@ extern "C" int ilsx_replay_sample_many(ilsx_replay* rb, int n_batches, int B, fl
   HIPCHK(hipSetDevice(rb->ctx->device));
   const long long rows = (long long)n_batches * B;
   const int rec4 = rb->rec / 4;
+  ILSX_TRY(replay_flush_state(rb));
   const int rpt = (rec4 == 8 || rec4 == 16) ? 64 : 8;
   long long blocks = (rows + 4 * rpt - 1) / (4 * rpt);   // four wavefronts of `rpt` rows per workgroup
   if (blocks > 256 * 16) blocks = 256 * 16;  // >> 256 CUs, grid-stride the rest

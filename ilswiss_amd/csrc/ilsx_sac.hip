@@ -1078,6 +1078,7 @@ static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps,
   if (rb->size < 1) ILSX_FAIL(ILSX_ERR_STATE, "replay buffer is empty");
   ILSX_TRY(sac_check_world(s, "ilsx_sac_train_from_replay"));
   HIPCHK(hipSetDevice(s->ctx->device));
+  ILSX_TRY(replay_flush_state(rb));   // the fused gather reads {size} from the ring's device state
   hipStream_t st = s->ctx->stream;
   s->B = B;
   s->eps_explicit = false;
@@ -1607,6 +1608,7 @@ extern "C" int ilsx_sac_group_train_from_replay(ilsx_sac_group* g, ilsx_replay* 
   }
   bool rebuild = g->stages.empty() || g->B != B || (int)g->rbs.size() != K;
   for (int k = 0; k < K && !rebuild; ++k) rebuild = g->rbs[k] != rbs[k];
+  for (int k = 0; k < K; ++k) ILSX_TRY(replay_flush_state(rbs[k]));   // on each ring's own stream, ahead of the fence
   ILSX_TRY(group_fence_in(g));
   struct FenceOut { ilsx_sac_group* g; ~FenceOut() { group_fence_out(g); } } fence_out{g};   // on every path out of this call
   if (rebuild) ILSX_TRY(group_build(g, rbs, B));

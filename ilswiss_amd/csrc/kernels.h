@@ -293,8 +293,16 @@ struct FwdTask {
   float* eps_save;                   // [rows][a] nullable
   float* action;                     // [rows][a] nullable
   float* logp;                       // [rows] nullable
-  float* part;                       // column-split kernels: partial head sums [CS][part_stride][NO]
-  int g0_off, g1_off, publish;       // GatherSpec: record offsets of the x0 / x1 segments; 1 = publish s,a,r,d ; 2 = s2
+  union {   // 16 bytes with two readings — the phase-kernel descriptors (two FwdArgs + a BwdArgs) fill the 4 KB kernel-argument segment to 112 bytes
+    struct {
+      float* part;                   // column-split kernels: partial head sums [CS][part_stride][NO]
+      int g0_off, g1_off;            // GatherSpec (column-split kernels): record offsets of the x0 / x1 segments
+    };
+    struct {                         // GENERIC kernel (k_mlp_fwd, which reads neither of the above), step_t != 0: this task's noise is keyed by
+      uint64_t seed_t, step_t;       //   (seed_t, step_t) instead of the launch's (FwdArgs::seed, step) — several runs' rollout inference in ONE launch,
+    };                               //   each run on its own Philox key and call counter (>= 1): ilsx_rollout_steps_lockstep
+  };
+  int publish;                       // GatherSpec: 1 = publish s,a,r,d ; 2 = s2
   const int* rows_idx;               // nullable: row r of this launch reads source row rows_idx[r] (minibatch gather)
   const float* log_std;              // HEAD_GAUSS_*: state-independent log-std parameter [a]
   float noise, noise_clip, max_act;  // HEAD_DET_TANH_NOISE (noise == 0: deterministic)
@@ -302,6 +310,7 @@ struct FwdTask {
   int agent, first;                  // grouped launches (FwdArgs::tasks): owning agent, 1 = the agent's publishing task
   int out_cols;                      // generic kernel: `out` takes only the first out_cols head outputs, row stride out_cols (0 = all NO)
 };
+static_assert(offsetof(FwdTask, step_t) == offsetof(FwdTask, g0_off) && sizeof(float*) == 8, "FwdTask: the generic kernel's per-task key overlays part | g0_off | g1_off");
 // In-kernel exchange (the merged phase kernels, k_sac_phase_a / _c below): data one workgroup of a launch writes and ANOTHER workgroup
 // of the SAME launch reads.  All workgroups that exchange sit on ONE XCD (same row tile), so the data travels through that XCD's L2:
 // the producer's ordinary stores are acknowledged by the L2 (the vector L1 is write-through) before it signals; the consumer drops its
@@ -440,7 +449,7 @@ __device__ __forceinline__ void fwd_head_row(const FwdTask& T, const FwdArgs& A,
           e = T.eps[(size_t)gr * NO + j];
         } else {
           float z4[4];
-          philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+          philox_normal4(T.step_t ? T.seed_t : A.seed, T.step_t ? T.step_t : (A.scal ? A.scal->step : A.step_host), T.rng_stream, gr, j >> 2, z4);
           const int qd = j & 3;
           e = qd == 0 ? z4[0] : qd == 1 ? z4[1] : qd == 2 ? z4[2] : z4[3];
         }
@@ -469,7 +478,7 @@ __device__ __forceinline__ void fwd_head_row(const FwdTask& T, const FwdArgs& A,
           e = T.eps[(size_t)gr * a + j];
         } else {
           float z4[4];
-          philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+          philox_normal4(T.step_t ? T.seed_t : A.seed, T.step_t ? T.step_t : (A.scal ? A.scal->step : A.step_host), T.rng_stream, gr, j >> 2, z4);
           const int qd = j & 3;
           e = qd == 0 ? z4[0] : qd == 1 ? z4[1] : qd == 2 ? z4[2] : z4[3];
         }
@@ -503,7 +512,7 @@ __device__ __forceinline__ void fwd_head_row(const FwdTask& T, const FwdArgs& A,
         e = T.eps[(size_t)gr * a + j];
       } else {
         float z4[4];
-        philox_normal4(A.seed, A.scal ? A.scal->step : A.step_host, T.rng_stream, gr, j >> 2, z4);
+        philox_normal4(T.step_t ? T.seed_t : A.seed, T.step_t ? T.step_t : (A.scal ? A.scal->step : A.step_host), T.rng_stream, gr, j >> 2, z4);
         const int q = j & 3;
         e = q == 0 ? z4[0] : q == 1 ? z4[1] : q == 2 ? z4[2] : z4[3];
       }

@@ -209,3 +209,79 @@ def test_run_experiment_group_hands_each_child_k_variant_files(tmp_path):
     seeds = [yaml.safe_load(open(p))["seed"] for f in files for p in f]
     assert seeds == list(range(10))                                              # consecutive variants, each its own file
     assert [len(c[1:c.index("-g")]) for c in calls("--group", "1")] == [1] * 10  # the flag overrides the spec
+
+
+def test_group_loop_schedule_on_stub_runs():
+    """DeviceRLAlgorithmGroup's lock-step schedule (host logic, no device): every run takes steps_per_epoch / env_num vec steps per epoch, a
+    train call happens at the runs' train trigger (base_algorithm.py:293-299) for exactly the runs that are due AND can train — a run whose
+    ring is still empty is skipped and its gate does not advance — and every run is evaluated and ends its epoch once per epoch."""
+    from ilswiss_amd.algorithm import DeviceRLAlgorithm, DeviceRLAlgorithmGroup
+
+    class Ctx:
+        def sync(self):
+            pass
+
+    class Trainer:
+        def __init__(self):
+            self.ctx, self.calls, self.epochs_ended = Ctx(), [], 0
+
+        def train_from_replay(self, rb, n, B):
+            self.calls.append((rb.size, n, B))
+
+        def end_epoch(self):
+            self.epochs_ended += 1
+
+    class Ring:
+        size = 0
+
+    class Env:
+        def rollout_stats(self, reset=True):
+            return 0, 0.0
+
+    class Run:   # the attributes and pieces of DeviceRLAlgorithm the group drives
+        _train_due = DeviceRLAlgorithm._train_due
+        _count_train_call = DeviceRLAlgorithm._count_train_call
+
+        def __init__(self, fills_after):
+            self.trainer, self.replay_buffer, self.training_env = Trainer(), Ring(), Env()
+            self.num_epochs, self.num_env_steps_per_epoch, self.env_num, self.on_policy = 1, 400, 4, False
+            self.num_steps_between_train_calls, self.num_train_steps_per_train_call, self.batch_size = 100, 7, 32
+            self.max_path_length, self.no_terminal, self.min_steps_before_training = 50, False, 0
+            self._n_env_steps_total = self._n_prev_train_env_steps = self._n_train_steps_total = self._n_grad_steps_total = 0
+            self.fills_after, self.vec_steps, self.evals = fills_after, 0, []
+
+        def _vec_step(self, begin_only=False):
+            self.vec_steps += 1
+            self._n_env_steps_total += self.env_num
+            if self._n_env_steps_total >= self.fills_after:    # insert_at_episode_end: the ring fills when ITS first episode ends
+                self.replay_buffer.size = self._n_env_steps_total
+
+        def _vec_step_end(self):
+            pass
+
+        def _can_train(self):
+            return self.replay_buffer.size >= 1
+
+        def _eval_collect(self):
+            return dict(AverageReturn=1.0)
+
+        def evaluate(self, epoch, epoch_time, total_time, collected=None):
+            self.evals.append((epoch, collected))
+
+    runs = [Run(fills_after=40), Run(fills_after=250), Run(fills_after=40)]
+    grp = DeviceRLAlgorithmGroup(runs)
+    assert grp._lockstep_args is None          # stubs: the per-step path
+    grp.train()
+    for r in runs:
+        assert r.vec_steps == 2 * 100 and r._n_env_steps_total == 800            # epochs 0 and 1 (num_epochs + 1, base_algorithm.py:64)
+        assert [e for e, _ in r.evals] == [0, 1] and r.trainer.epochs_ended == 2
+    # runs 0 and 2 train at every 100-step trigger (8 calls); run 1 cannot at 100 and 200 (ring empty), its gate stays open, so it trains at
+    # the very next vec step after its ring fills (252 env steps) and then every 100 from there: 252, 352, ..., 752 = 6 calls
+    assert [len(r.trainer.calls) for r in runs] == [8, 6, 8]
+    assert runs[1].trainer.calls[0][0] == 252 and runs[0].trainer.calls[0] == (100, 7, 32)
+    assert runs[1]._n_train_steps_total == 6 and runs[1]._n_grad_steps_total == 42
+    import pytest as _pt
+    bad = Run(40)
+    bad.batch_size = 64
+    with _pt.raises(ValueError):
+        DeviceRLAlgorithmGroup([runs[0], bad])

@@ -459,3 +459,23 @@ def test_split_run_from_the_run_script_at_one_forced_rank(tmp_path):
         rows[tag] = _rows_without_time(d)
     assert len(rows["plain"]) == 2 and float(rows["plain"][-1]["Number of gradient steps total"]) > 0
     assert rows["plain"] == rows["split"]
+
+
+def test_grouped_runs_of_another_trainer_are_stepped_one_by_one(tmp_path):
+    """`--group K` with a trainer the grouped kernels do not take (TD3): the K runs still share one process and advance in lock-step, their
+    train calls go one after the other on the shared schedule — and every log is the single-process run's."""
+    spec = yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "td3", "td3_hopper_hip.yaml")))
+    spec["meta_data"].update(script_path=os.path.join(ROOT, "run_scripts", "td3_exp_script.py"), num_workers=1, exp_name="grp_td3")
+    spec["variables"] = dict(seed=[0, 1])
+    c = spec["constants"]
+    c["env_specs"].update(env_num=8, eval_env_num=4)
+    c["rl_alg_params"].update(num_epochs=1, num_steps_per_epoch=800, num_steps_between_train_calls=80, num_train_steps_per_train_call=10,
+                              num_steps_per_eval=200, max_path_length=60, min_steps_before_training=160, batch_size=256, replay_buffer_size=20000,
+                              freq_saving=1)
+    solo, _ = _launch(tmp_path, spec, 1, "solo")
+    grp, out = _launch(tmp_path, spec, 2, "grouped")
+    assert sorted(solo) == sorted(grp) == [0, 1] and out.count("td3_exp_script.py") == 1
+    for seed in (0, 1):
+        a, b = _rows_without_time(solo[seed]), _rows_without_time(grp[seed])
+        assert len(a) == 2 and a == b, seed
+        assert float(a[-1]["Number of gradient steps total"]) > 0

@@ -3,7 +3,7 @@
 # graph launches here), the PMC passes (regenerated every round: bench.py reads the newest summary for roofline.traffic), the
 # per-launch timeline of the SAC step and the stage timers of the 3-D stepper -> gpurun_out/prof_<tag>/; copy into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd)
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -26,6 +26,12 @@ timeout 120 python tools/discbn_rate.py > $OUT/discbn_rate.txt 2>&1
 timeout 200 bash tools/ppo_ab.sh ILSX_DW_BIG=1 ILSX_DW_BIG=0 > $OUT/ppo_ab.txt 2>&1
 for u in mfma_peak mfma_valu_overlap; do [ -x tools/ubench/$u ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2> /dev/null; done
 (timeout 60 tools/ubench/mfma_peak; timeout 60 tools/ubench/mfma_valu_overlap) > $OUT/mfma_ubench.txt 2>&1
+[ -x tools/ubench/mfma_32x32 ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/ubench/mfma_32x32 tools/ubench/mfma_32x32.hip 2> /dev/null
+timeout 60 tools/ubench/mfma_32x32 > $OUT/mfma_32x32.txt 2>&1
+timeout 120 python tools/replay_rate.py > $OUT/replay_rate.txt 2>&1
+timeout 200 python tools/grp_streams_ab.py abcd > $OUT/grp_streams_ab.txt 2>&1
+timeout 300 python tools/grouped_entry_rate.py exp_specs/sac/sac_humanoid_hip.yaml --group 4 --epochs 4 > $OUT/grouped_entry_humanoid.json 2>&1
+timeout 300 python tools/grouped_entry_rate.py exp_specs/sac/sac_hopper_refloop_hip.yaml --group 10 --epochs 3 > $OUT/grouped_entry_refloop_3ep.json 2>&1
 timeout 60 python tools/fwd_rate.py 32768 > $OUT/fwd_rate.txt 2>&1
 timeout 120 python tools/step_gantt.py 8 > $OUT/step_gantt_K8.txt 2>&1
 (timeout 100 python tools/env3d_rate.py humanoid 1024 40; timeout 100 python tools/env3d_rate.py ant 1024 40) > $OUT/env3d_rate.txt 2>&1
