@@ -204,6 +204,7 @@ PROTOTYPES = {
     "ilsx_rollout_step": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ilsx_rollout_step_begin": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ilsx_rollout_step_end": (C.c_int, [vp]),
+    "ilsx_eval_rollouts_lockstep": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_double)]),
     "ilsx_rollout_steps_lockstep": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int]),
     "ilsx_rollout_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "ilsx_abi_version": (C.c_int, []),
@@ -307,6 +308,9 @@ def load():
         raise RuntimeError(f"libilsx ABI {lib.ilsx_abi_version()} != 1")
     _lib = lib
     return lib
+
+
+ILSX_ERR_UNSUPPORTED = -5   # include/ilsx.h
 
 
 def check(rc):

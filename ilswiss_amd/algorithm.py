@@ -361,6 +361,30 @@ class DeviceRLAlgorithmGroup:
         return (arr([a.training_env for a in algs]), arr([a.exploration_policy for a in algs]), arr([a.replay_buffer for a in algs]),
                 (C.c_int64 * K)(*[int(a.min_steps_before_training) for a in algs]), a0.trainer.ctx.lib)
 
+    def _eval_lockstep(self):
+        """All runs' evaluation rollouts in one library call (ilsx_eval_rollouts_lockstep: one launch per stage for the runs' small eval envs);
+        None when the runs do not evaluate through the same device sampler or cannot share launches."""
+        import ctypes as C
+
+        from . import _lib
+        algs, a0 = self.algs, self.algs[0]
+        ss = [getattr(a, "eval_sampler", None) for a in algs]
+        if len(algs) < 2 or not all(type(s_) is DeviceEvalSampler for s_ in ss) or not hasattr(a0.trainer.ctx.lib, "ilsx_eval_rollouts_lockstep"):
+            return None
+        hs = [s_._handles() for s_ in ss]
+        if any(h[0] is None for h in hs) or len({(s_.num_steps, s_.max_path_length, h[2]) for s_, h in zip(ss, hs)}) != 1:
+            return None
+        K = len(algs)
+        envs = (C.c_void_p * K)(*[s_.env.h for s_ in ss])
+        pis = (C.c_void_p * K)(*[h[0] for h in hs])
+        st = (C.c_double * (18 * K))()
+        lib = a0.trainer.ctx.lib
+        rc = lib.ilsx_eval_rollouts_lockstep(envs, pis, K, int(ss[0].max_path_length), int(hs[0][2]), int(ss[0].num_steps), st)
+        if rc == _lib.ILSX_ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc)
+        return [s_.stats_dict(st[18 * k:18 * (k + 1)], stat_prefix="Test") for k, s_ in enumerate(ss)]
+
     def _groupable(self, idx):
         from .sac import SoftActorCritic
         trs = [self.algs[i].trainer for i in idx]
@@ -444,7 +468,9 @@ class DeviceRLAlgorithmGroup:
                     t_sample += time.perf_counter() - t0
             self.sync()
             t_eval0 = time.perf_counter()
-            collected = list(pool.map(lambda a: a._eval_collect(), algs)) if pool else [algs[0]._eval_collect()]
+            collected = self._eval_lockstep()
+            if collected is None:
+                collected = list(pool.map(lambda a: a._eval_collect(), algs)) if pool else [algs[0]._eval_collect()]
             t_eval = time.perf_counter() - t_eval0
             for a, c in zip(algs, collected):
                 a._t_sample, a._t_train = t_sample, t_train

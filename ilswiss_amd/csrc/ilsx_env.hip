@@ -59,6 +59,9 @@ struct ilsx_vecenv {
   bool path_mode = false; float* stage = nullptr; int stage_len = 0, stage_rec = 0; int* flush_len = nullptr;
   int* flush_host = nullptr;            // pinned: the per-step read-back of the episode-end flags is a true asynchronous copy
   ilsx_replay* paths_pending = nullptr; // ilsx_rollout_step_begin enqueued a step whose finished episodes are not in the ring yet (ilsx_rollout_step_end)
+  // run 0 of a lock-step group (ilsx_rollout_steps_lockstep): ONE array of episode-end flags for all K runs, so that a lock-step reads them back
+  // with one copy instead of K (each a serialised 8 us on the stream)
+  int* grp_flush_dev = nullptr; int* grp_flush_host = nullptr; int grp_flush_n = 0;
   // 3-D engine (Ant / Humanoid, env3d.h): model, its device copy, and the per-env working set [E3Off::TOTAL][n_env]
   int engine = 0, nq = 0, nv = 0;
   bool wave3 = true;   // wave-per-env kernels (env3d_wave.h); ILSX_ENV3D_LANE=1 selects the lane-per-env form (env3d.h) for A/B runs
@@ -1041,6 +1044,8 @@ extern "C" int ilsx_vecenv_destroy(ilsx_vecenv* e) {
   void* ps[] = {e->dm, e->qpos, e->qvel, e->obs_cur, e->act, e->nobs, e->rew, e->done, e->ep_len, e->ep_ret, e->stats, e->ids, e->dm3, e->scr3, e->stage, e->flush_len};
   for (void* p : ps) if (p) ctx_free(e->ctx, p);
   if (e->flush_host) hipHostFree(e->flush_host);
+  if (e->grp_flush_host) hipHostFree(e->grp_flush_host);
+  if (e->grp_flush_dev) ctx_free(e->ctx, e->grp_flush_dev);
   delete e->hm3;
   delete e;
   return ILSX_OK;
@@ -1267,14 +1272,16 @@ static int rollout_env_args(ilsx_vecenv* e, ilsx_replay* rb, int max_path_length
   return ILSX_OK;
 }
 // path mode, second half of a step: wait for the step, move the episodes that ended in it from the staging area into the ring
-static int rollout_paths_finish(ilsx_vecenv* e, bool synced = false) {   // synced: the caller has already waited for the stream the step ran on
+// synced: the caller has already waited for the stream the step ran on; flags: where the step's episode-end flags were read back to (default: the env's own buffer)
+static int rollout_paths_finish(ilsx_vecenv* e, bool synced = false, const int* flags = nullptr) {
   ilsx_replay* rb = e->paths_pending;
   if (!rb) return ILSX_OK;
   e->paths_pending = nullptr;
   if (!synced) HIPCHK(hipStreamSynchronize(e->ctx->stream));
+  if (!flags) flags = e->flush_host;
   std::vector<int> envs, lens; std::vector<uint8_t> term;
   for (int i = 0; i < e->n_env; ++i)
-    if (e->flush_host[i]) { envs.push_back(i); lens.push_back(e->flush_host[i] & ((1 << 30) - 1)); term.push_back((e->flush_host[i] >> 30) & 1); }
+    if (flags[i]) { envs.push_back(i); lens.push_back(flags[i] & ((1 << 30) - 1)); term.push_back((flags[i] >> 30) & 1); }
   return replay_insert_paths(rb, e->stage, e->stage_len, envs.data(), lens.data(), term.data(), (int)envs.size());
 }
 static int rollout_step_impl(ilsx_vecenv* e, ilsx_net* pi, ilsx_net* label_pi, int label_deterministic, ilsx_replay* rb,
@@ -1408,12 +1415,25 @@ static int rollout_lockstep_grouped(ilsx_vecenv* const* envs, ilsx_net* const* p
     A.rows = envs[0]->n_env; A.ntasks = nt; A.seed = gctx->seed;
     ILSX_TRY(launch_fwd(gctx, A, pis[0]->lay.cfg.hidden, pis[0]->lay.cfg.act, pis[0]->lay.KP));
   }
+  ilsx_vecenv* e0m = envs[0];
+  bool all_paths = true;
+  for (int k = 0; k < n_runs; ++k) all_paths = all_paths && envs[k]->path_mode;
+  const int ne = e0m->n_env;
+  if (all_paths && e0m->grp_flush_n < n_runs * ne) {   // the group's flag array (owned by run 0's env, freed with it)
+    if (e0m->grp_flush_dev) ILSX_TRY(ctx_free(gctx, e0m->grp_flush_dev));
+    if (e0m->grp_flush_host) HIPCHK(hipHostFree(e0m->grp_flush_host));
+    e0m->grp_flush_dev = nullptr; e0m->grp_flush_host = nullptr; e0m->grp_flush_n = 0;
+    ILSX_TRY(ctx_alloc(gctx, (size_t)n_runs * ne * sizeof(int), (void**)&e0m->grp_flush_dev));
+    HIPCHK(hipHostMalloc((void**)&e0m->grp_flush_host, (size_t)n_runs * ne * sizeof(int), hipHostMallocDefault));
+    e0m->grp_flush_n = n_runs * ne;
+  }
   for (int k0 = 0; k0 < n_runs; k0 += ENVG_MAX_RUNS) {
     EnvStepGroupArgs G;
     const int n = std::min(ENVG_MAX_RUNS, n_runs - k0);
     for (int j = 0; j < n; ++j) {
       ilsx_vecenv* e = envs[k0 + j];
       ILSX_TRY(rollout_env_args(e, rbs[k0 + j], max_path_length, no_terminal, ++e->step_ctr, &G.a[j]));
+      if (all_paths) G.a[j].flush_len = e0m->grp_flush_dev + (size_t)(k0 + j) * ne;
     }
     const ilsx_vecenv* e0 = envs[0];
     if (e0->hm.nb == 4) ILSX_TRY((launch_envg_step_runs_t<4, 8>(gctx, G, n, e0->n_env)));
@@ -1421,17 +1441,24 @@ static int rollout_lockstep_grouped(ilsx_vecenv* const* envs, ilsx_net* const* p
     else ILSX_TRY((launch_envg_step_runs_t<7, 12>(gctx, G, n, e0->n_env)));
   }
   bool any_paths = false;
-  for (int k = 0; k < n_runs; ++k) {
-    ilsx_vecenv* e = envs[k];
-    if (e->path_mode) {
-      HIPCHK(hipMemcpyAsync(e->flush_host, e->flush_len, (size_t)e->n_env * 4, hipMemcpyDeviceToHost, gs));
-      e->paths_pending = rbs[k];
-      any_paths = true;
-    } else ILSX_TRY(replay_advance_device_rows(rbs[k], e->n_env));
+  if (all_paths) {
+    HIPCHK(hipMemcpyAsync(e0m->grp_flush_host, e0m->grp_flush_dev, (size_t)n_runs * ne * sizeof(int), hipMemcpyDeviceToHost, gs));
+    for (int k = 0; k < n_runs; ++k) envs[k]->paths_pending = rbs[k];
+    any_paths = true;
+  } else {
+    for (int k = 0; k < n_runs; ++k) {
+      ilsx_vecenv* e = envs[k];
+      if (e->path_mode) {
+        HIPCHK(hipMemcpyAsync(e->flush_host, e->flush_len, (size_t)e->n_env * 4, hipMemcpyDeviceToHost, gs));
+        e->paths_pending = rbs[k];
+        any_paths = true;
+      } else ILSX_TRY(replay_advance_device_rows(rbs[k], e->n_env));
+    }
   }
   if (any_paths) {
     HIPCHK(hipStreamSynchronize(gs));
-    for (int k = 0; k < n_runs; ++k) ILSX_TRY(rollout_paths_finish(envs[k], /*synced=*/true));
+    for (int k = 0; k < n_runs; ++k)
+      ILSX_TRY(rollout_paths_finish(envs[k], /*synced=*/true, all_paths ? e0m->grp_flush_host + (size_t)k * ne : nullptr));
   }
   return ILSX_OK;
 }
@@ -1626,6 +1653,151 @@ extern "C" int ilsx_eval_rollout(ilsx_vecenv* e, ilsx_net* pi, ilsx_ppo* ppo, in
   if (stats_host) {
     HIPCHK(hipMemcpyAsync(stats_host, e->ev_stats, EV_N * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+  }
+  return ILSX_OK;
+}
+
+// ---- the evaluation rollouts of K runs in lock-step (DeviceRLAlgorithmGroup: K small eval envs, one per run)
+struct EvalAccumRun { const float* rew; const unsigned char* done; const float* act; unsigned char* frozen; double* ret; int* len; double* st; int* alive; };
+struct EvalAccumRuns { EvalAccumRun r[ENVG_MAX_RUNS]; int n, a, max_path_length; };
+__global__ void k_eval_accum_runs(const EvalAccumRuns G) {   // blockIdx.y = run; a row of the grid is that run's k_eval_accum launch
+  const EvalAccumRun& R = G.r[blockIdx.y];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= G.n || R.frozen[e]) return;
+  const double r = (double)R.rew[e];
+  const double Rt = R.ret[e] + r;
+  const int L = R.len[e] + 1;
+  R.ret[e] = Rt; R.len[e] = L;
+  double* st = R.st;
+  atomicAdd(&st[EV_STEPS], 1.0);
+  atomicAdd(&st[EV_REW_S], r); atomicAdd(&st[EV_REW_SS], r * r); atomic_max_d(&st[EV_REW_MAX], r); atomic_min_d(&st[EV_REW_MIN], r);
+  for (int k = 0; k < G.a; ++k) {
+    const double x = (double)R.act[(size_t)e * G.a + k];
+    atomicAdd(&st[EV_ACT_S], x); atomicAdd(&st[EV_ACT_SS], x * x); atomic_max_d(&st[EV_ACT_MAX], x); atomic_min_d(&st[EV_ACT_MIN], x);
+  }
+  if (R.done[e] || L >= G.max_path_length) {
+    R.frozen[e] = 1;
+    atomicAdd(&st[EV_PATHS], 1.0);
+    atomicAdd(&st[EV_RET_S], Rt); atomicAdd(&st[EV_RET_SS], Rt * Rt); atomic_max_d(&st[EV_RET_MAX], Rt); atomic_min_d(&st[EV_RET_MIN], Rt);
+    const double l = (double)L;
+    atomicAdd(&st[EV_LEN_S], l); atomicAdd(&st[EV_LEN_SS], l * l); atomic_max_d(&st[EV_LEN_MAX], l); atomic_min_d(&st[EV_LEN_MIN], l);
+    atomicSub(R.alive, 1);
+  }
+}
+static int eval_buffers(ilsx_vecenv* e) {
+  if (e->ev_frozen) return ILSX_OK;
+  ilsx_ctx* ctx = e->ctx;
+  const int n = e->n_env;
+  ILSX_TRY(ctx_alloc(ctx, n, (void**)&e->ev_frozen)); ILSX_TRY(ctx_alloc(ctx, (size_t)n * 8, (void**)&e->ev_ret));
+  ILSX_TRY(ctx_alloc(ctx, (size_t)n * 4, (void**)&e->ev_len)); ILSX_TRY(ctx_alloc(ctx, EV_N * 8, (void**)&e->ev_stats));
+  ILSX_TRY(ctx_alloc(ctx, 4, (void**)&e->ev_alive));
+  return ILSX_OK;
+}
+// VecPathSampler.obtain_samples (vec_sampler.py:126-146) of K runs at once: every run rolls whole rounds (one episode per env, frozen at its
+// end) until ITS statistics hold >= num_steps steps; the runs of one shape step in lock-step as one launch per stage on run 0's stream — a run
+// leaves a round at the very check (every 32 vec steps) at which its own ilsx_eval_rollout would, so its policy-call counter, env step counter
+// and statistics are those of evaluating it alone.  stats_host: [K][18] doubles (the layout ilsx_eval_rollout fills).  ILSX_ERR_UNSUPPORTED when
+// the runs cannot share launches (the caller evaluates them one by one).
+extern "C" int ilsx_eval_rollouts_lockstep(ilsx_vecenv* const* envs, ilsx_net* const* pis, int n_runs, int max_path_length, int deterministic,
+                                           int64_t num_steps, double* stats_host) {
+  if (!envs || !pis || !stats_host || n_runs < 1 || max_path_length < 1) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_eval_rollouts_lockstep: bad argument");
+  for (int k = 0; k < n_runs; ++k)
+    if (!envs[k] || !pis[k]) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_eval_rollouts_lockstep: run %d has a NULL env / policy", k);
+  if (n_runs > ENVG_MAX_RUNS || !rollout_runs_groupable(envs, pis, n_runs)) ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "ilsx_eval_rollouts_lockstep: the runs cannot share launches");
+  ilsx_vecenv* e0 = envs[0];
+  ilsx_ctx* gctx = e0->ctx;
+  hipStream_t gs = gctx->stream;
+  HIPCHK(hipSetDevice(gctx->device));
+  const int ne = e0->n_env;
+  for (int k = 0; k < n_runs; ++k) {
+    ILSX_TRY(eval_buffers(envs[k]));
+    if (envs[k]->ctx->stream != gs) HIPCHK(hipStreamSynchronize(envs[k]->ctx->stream));
+  }
+  if (e0->grp_flush_n < n_runs) {   // the group's small int array (alive counters here, episode-end flags in the training rollouts)
+    if (e0->grp_flush_dev) ILSX_TRY(ctx_free(gctx, e0->grp_flush_dev));
+    if (e0->grp_flush_host) HIPCHK(hipHostFree(e0->grp_flush_host));
+    e0->grp_flush_dev = nullptr; e0->grp_flush_host = nullptr; e0->grp_flush_n = 0;
+    const int cnt = std::max(n_runs, n_runs * ne);
+    ILSX_TRY(ctx_alloc(gctx, (size_t)cnt * sizeof(int), (void**)&e0->grp_flush_dev));
+    HIPCHK(hipHostMalloc((void**)&e0->grp_flush_host, (size_t)cnt * sizeof(int), hipHostMallocDefault));
+    e0->grp_flush_n = cnt;
+  }
+  int* alive_dev = e0->grp_flush_dev;
+  int* alive_host = e0->grp_flush_host;
+  std::vector<int> active(n_runs);
+  for (int k = 0; k < n_runs; ++k) active[k] = k;
+  {   // fresh statistics for every run
+    double h[EV_N];
+    for (int i = 0; i < EV_N; ++i) h[i] = 0.0;
+    h[EV_RET_MAX] = h[EV_LEN_MAX] = h[EV_REW_MAX] = h[EV_ACT_MAX] = -INFINITY;
+    h[EV_RET_MIN] = h[EV_LEN_MIN] = h[EV_REW_MIN] = h[EV_ACT_MIN] = INFINITY;
+    for (int k = 0; k < n_runs; ++k) HIPCHK(hipMemcpyAsync(envs[k]->ev_stats, h, sizeof h, hipMemcpyHostToDevice, gs));
+    HIPCHK(hipStreamSynchronize(gs));
+  }
+  while (!active.empty()) {
+    for (int k : active) {   // rollout() starts with env.reset(ready_env_ids) (vec_sampler.py:33): on the run's own stream, waited for below
+      ilsx_vecenv* e = envs[k];
+      ILSX_TRY(ilsx_vecenv_reset(e, nullptr, e->n_env, nullptr));
+      if (e->ctx->stream != gs) HIPCHK(hipStreamSynchronize(e->ctx->stream));
+      hipLaunchKernelGGL(k_eval_begin, dim3((ne + 255) / 256), dim3(256), 0, gs, e->ev_frozen, e->ev_ret, e->ev_len, ne, alive_dev + k);
+    }
+    std::vector<int> live = active;
+    for (int t = 0; t < max_path_length && !live.empty(); ++t) {
+      for (size_t i = 0; i < live.size(); i += 4) {
+        FwdArgs A;
+        memset(&A, 0, sizeof A);
+        const int nt = (int)std::min<size_t>(4, live.size() - i);
+        for (int j = 0; j < nt; ++j) {
+          ilsx_vecenv* e = envs[live[i + j]];
+          ilsx_net* pi = pis[live[i + j]];
+          FwdTask& ft = A.t[j];
+          ft.net = net_view(pi->lay, pi->base);
+          ft.x0 = e->policy_obs(); ft.d0 = pi->lay.cfg.in_dim; ft.s0 = pi->lay.cfg.in_dim;
+          ft.head = deterministic ? HEAD_TANH_DET : HEAD_TANH_SAMPLE;
+          if (pi->noise_policy) {
+            ft.head = pi->out_linear ? HEAD_DET_LIN_NOISE : HEAD_DET_TANH_NOISE;
+            ft.noise = deterministic ? 0.0f : pi->noise; ft.noise_clip = pi->noise_clip; ft.max_act = pi->max_act;
+          }
+          ft.action = e->act;
+          ft.rng_stream = 0x41435400u;
+          ft.seed_t = pi->ctx->seed; ft.step_t = ++pi->ctx->act_calls;
+        }
+        A.rows = ne; A.ntasks = nt; A.seed = gctx->seed;
+        ILSX_TRY(launch_fwd(gctx, A, pis[0]->lay.cfg.hidden, pis[0]->lay.cfg.act, pis[0]->lay.KP));
+      }
+      EnvStepGroupArgs G;
+      EvalAccumRuns Q;
+      memset(&Q, 0, sizeof Q);
+      Q.n = ne; Q.a = e0->a; Q.max_path_length = max_path_length;
+      const int n = (int)live.size();
+      for (int j = 0; j < n; ++j) {
+        ilsx_vecenv* e = envs[live[j]];
+        EnvStepArgs& A = G.a[j];
+        memset(&A, 0, sizeof A);
+        A.m = e->dm; A.qpos = e->qpos; A.qvel = e->qvel; A.n_env = ne;
+        A.ids = nullptr; A.n_ids = ne; A.act = e->act;
+        A.obs = e->nobs; A.rew = e->rew; A.done = e->done; A.obs_cur = e->obs_cur; A.frozen = e->ev_frozen;
+        A.seed = e->seed; A.stream = e->rng_stream; A.step = ++e->step_ctr;
+        Q.r[j] = EvalAccumRun{e->rew, e->done, e->act, e->ev_frozen, e->ev_ret, e->ev_len, e->ev_stats, alive_dev + live[j]};
+      }
+      if (e0->hm.nb == 4) ILSX_TRY((launch_envg_step_runs_t<4, 8>(gctx, G, n, ne)));
+      else if (e0->hm.max_rows > 12) ILSX_TRY((launch_envg_step_runs_t<7, 16>(gctx, G, n, ne)));
+      else ILSX_TRY((launch_envg_step_runs_t<7, 12>(gctx, G, n, ne)));
+      hipLaunchKernelGGL(k_eval_accum_runs, dim3((ne + 255) / 256, n), dim3(256), 0, gs, Q);
+      HIPCHK(hipGetLastError());
+      if ((t & 31) == 31) {   // every env of a run done? (ilsx_eval_rollout's check, for all runs in one read-back)
+        HIPCHK(hipMemcpyAsync(alive_host, alive_dev, (size_t)n_runs * sizeof(int), hipMemcpyDeviceToHost, gs));
+        HIPCHK(hipStreamSynchronize(gs));
+        std::vector<int> still;
+        for (int k : live) if (alive_host[k] > 0) still.push_back(k);
+        live.swap(still);
+      }
+    }
+    for (int k : active) HIPCHK(hipMemcpyAsync(stats_host + (size_t)k * EV_N, envs[k]->ev_stats, EV_N * 8, hipMemcpyDeviceToHost, gs));
+    HIPCHK(hipStreamSynchronize(gs));
+    std::vector<int> more;
+    for (int k : active) if (stats_host[(size_t)k * EV_N + EV_STEPS] < (double)num_steps) more.push_back(k);
+    active.swap(more);
   }
   return ILSX_OK;
 }

@@ -148,6 +148,10 @@ class DeviceEvalSampler:
         while first or st[1] < self.num_steps:
             _lib.check(self.env.ctx.lib.ilsx_eval_rollout(self.env.h, pi, ppo, int(self.max_path_length), int(det), int(first), st))
             first = False
+        return self.stats_dict(st, stat_prefix)
+
+    def stats_dict(self, st, stat_prefix="Test"):
+        """The path statistics (get_generic_path_information's keys, eval_util.py:15-80) from ilsx_eval_rollout's 18 sums / extrema."""
         n_paths, n_steps = st[0], st[1]
         out = OrderedDict()
 

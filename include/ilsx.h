@@ -609,6 +609,12 @@ int ilsx_rollout_step(ilsx_vecenv* env, ilsx_net* pi, ilsx_replay* rb, int max_p
 #define ILSX_EVAL_NSTATS 18
 int ilsx_eval_rollout(ilsx_vecenv* env, ilsx_net* pi, ilsx_ppo* ppo, int max_path_length, int deterministic, int reset_stats,
                       double* stats_host);
+/* The same for K runs at once (one small eval env per run, the lock-step loop of co-resident seeds): every run rolls whole rounds until ITS
+ * statistics hold >= num_steps steps (VecPathSampler.obtain_samples, vec_sampler.py:126-146); runs of one shape step as one launch per stage, and
+ * a run leaves a round at the check at which its own ilsx_eval_rollout would, so its counters and statistics are those of evaluating it alone.
+ * stats_host: [n_runs][18] doubles, ilsx_eval_rollout's layout.  ILSX_ERR_UNSUPPORTED: the runs cannot share launches (evaluate them one by one). */
+int ilsx_eval_rollouts_lockstep(ilsx_vecenv* const* envs, ilsx_net* const* pis, int n_runs, int max_path_length, int deterministic,
+                                int64_t num_steps, double* stats_host);
 /* ilsx_rollout_step in two halves, for a host that advances several runs side by side, each on its own ctx / stream (the lock-step loop of
  * co-resident seeds): _begin only enqueues the step; _end does the part that needs the host — with path mode on it waits for the step and
  * inserts the episodes that ended in it, otherwise nothing.  begin(run 0..K-1) ; end(run 0..K-1) overlaps the K runs' launches on the GPU. */
