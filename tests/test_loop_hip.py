@@ -375,6 +375,27 @@ def test_grouped_run_script_writes_the_single_run_logs(tmp_path, path_mode):
     assert _rows_without_time(grp[0]) != _rows_without_time(grp[1])     # the seeds differ
 
 
+@pytest.mark.parametrize("spec_name", ["sac_walker_hip.yaml", "sac_halfcheetah_hip.yaml"])
+def test_grouped_runs_on_the_seven_body_steppers(tmp_path, spec_name):
+    """The lock-step rollout / evaluation launches of grouped runs (k_envg_step_runs) in their Walker2d (12 constraint rows) and HalfCheetah (16)
+    instantiations, three seeds — one policy launch of three tasks —, both replay-insertion modes' worth of machinery: logs identical to the
+    single-process runs'."""
+    spec = yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "sac", spec_name)))
+    spec["meta_data"].update(script_path=os.path.join(ROOT, "run_scripts", "sac_alpha_exp_script.py"), num_workers=1, exp_name="grp7")
+    spec["variables"] = dict(seed=[0, 1, 2])
+    c = spec["constants"]
+    c["env_specs"].update(env_num=4, eval_env_num=4)
+    c["rl_alg_params"].update(num_epochs=1, num_steps_per_epoch=400, num_steps_between_train_calls=80, num_train_steps_per_train_call=6,
+                              num_steps_per_eval=150, max_path_length=40, min_steps_before_training=0, batch_size=128, replay_buffer_size=20000,
+                              freq_saving=1, insert_at_episode_end=True)
+    solo, _ = _launch(tmp_path, spec, 1, "solo")
+    grp, out = _launch(tmp_path, spec, 3, "grouped")
+    assert sorted(solo) == sorted(grp) == [0, 1, 2]
+    for seed in range(3):
+        a, b = _rows_without_time(solo[seed]), _rows_without_time(grp[seed])
+        assert len(a) == 2 and a == b, seed
+
+
 def test_statistics_are_those_of_the_first_batch_after_end_epoch():
     """sac_alpha.py:185-190: eval_statistics are filled by the FIRST train_step after end_epoch.  A 50-step train call that asks for them
     reports what a 1-step call from the same state reports (epoch-0 Alpha = the initial 0.2), and ends with the parameters of 50 plain steps;
