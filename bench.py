@@ -402,6 +402,7 @@ class Ranks:
         self.local = int(os.environ.get("LOCAL_RANK", 0))
         self.world = int(os.environ.get("WORLD_SIZE", 1))
         self.dist, self.dry = None, dry_run
+        self.ncoll = 0      # one-word collectives issued so far (barrier / max_over_ranks of one value): what `leg` catches up on
         if self.world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST"):   # the override exercises the path with one rank
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
                 os.environ.setdefault(k, v)
@@ -415,17 +416,36 @@ class Ranks:
             self.dist = dist
 
     def barrier(self, ctx=None):
+        """device work of this rank finished, then every rank here.  The rendezvous is an all-reduce of ONE float64 — the same collective as
+        `max_over_ranks([x])` — so that a rank whose leg failed can stand in for the barriers it did not reach (`leg`)."""
         if ctx is not None:
             ctx.sync()
         if self.dist is not None:
             if not self.dry:
                 import torch
                 torch.cuda.synchronize()
-            self.dist.barrier()
+            self.max_over_ranks([0.0])
+
+    def leg(self, fn, n_coll):
+        """A secondary leg holding `n_coll` one-word collectives (barriers, `max_over_ranks` of one value).  An exception on this rank is
+        recorded in the leg's place and the collectives it did not reach are joined with neutral values: the other ranks are not left
+        waiting inside RCCL, their numbers and the headline line still come out."""
+        c0 = self.ncoll
+        try:
+            return fn()
+        except Exception as e:   # noqa: BLE001 — secondary leg
+            out = dict(error=repr(e)[:300])
+            try:
+                while self.dist is not None and self.ncoll < c0 + n_coll:
+                    self.max_over_ranks([0.0])
+            except Exception as e2:   # noqa: BLE001 — the communicator itself is gone: nothing left to keep in step
+                out["catch_up_error"] = repr(e2)[:200]
+            return out
 
     def max_over_ranks(self, values):
         if self.dist is None:
             return list(values)
+        self.ncoll += len(values) == 1
         import torch
         t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if self.dry else "cuda")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -530,8 +550,16 @@ def main():
         mine = time.perf_counter() - t0
         dt = R.max_over_ranks([mine])[0]
         per_rank = R.gather(1e3 * mine / args.steps)
+
+        def dry_leg():     # the shape of a secondary leg: barrier, timed part, max over ranks; ILSX_BENCH_DRY_FAIL_RANK raises on one rank first
+            if os.environ.get("ILSX_BENCH_DRY_FAIL_RANK") == str(rank):
+                raise RuntimeError("dry-run leg failed on this rank")
+            R.barrier()
+            return dict(dt_max=R.max_over_ranks([0.001 * (1 + rank)])[0])
+        leg = R.leg(dry_leg, 2 if world > 1 else 0)
+        leg_errors = R.gather(1.0 if "error" in leg else 0.0)
         if rank == 0:
-            print(json.dumps(dict(metric="dry-run", dry_run=True, n_gpus=world, steps=args.steps, warmup=args.warmup,
+            print(json.dumps(dict(metric="dry-run", dry_run=True, n_gpus=world, steps=args.steps, warmup=args.warmup, leg=leg, leg_errors=leg_errors,
                                   ms_per_step=1e3 * dt / args.steps, value=world * args.steps / dt,
                                   scaling_detail=dict(per_rank_ms=per_rank, max_over_min=max(per_rank) / min(per_rank)))))
         R.close()
@@ -589,18 +617,20 @@ def main():
     # K = 8 grouped Hopper runs and 4 x 1024 grouped Humanoid runs, each rank on its own GPU, no collective in the data path
     legs = {}
     multi = world > 1 or bool(os.environ.get("ILSX_BENCH_FORCE_DIST"))   # the override runs the every-rank form of the legs on a one-rank group
+    # each leg holds two one-word collectives (a barrier in front of its timed loop, the max of the ranks' times behind it): Ranks.leg keeps a
+    # rank whose leg raised in step with the others
     if not args.no_seeds:
-        try:
-            legs["co_resident_seeds"] = co_resident_seeds(R=R if multi else None)
-        except Exception as e:   # noqa: BLE001 — secondary leg
-            legs["co_resident_seeds"] = dict(error=repr(e)[:300])
-            if world > 1:
-                raise            # a rank that skipped the leg's barriers would hang the others: fail the run instead
+        legs["co_resident_seeds"] = R.leg(lambda: co_resident_seeds(R=R if multi else None), 2 if multi else 0)
     if multi and not args.no_aux:
         import bench_aux
-        hctx = ia.Context(local, seed=77 + rank)
-        legs["humanoid_4x1024"] = bench_aux.bench_humanoid(hctx, R=R)
-        hctx.close()
+
+        def humanoid_leg():
+            hctx = ia.Context(local, seed=77 + rank)
+            try:
+                return bench_aux.bench_humanoid(hctx, R=R)
+            finally:
+                hctx.close()
+        legs["humanoid_4x1024"] = R.leg(humanoid_leg, 2)
 
     result = None
     if rank == 0:

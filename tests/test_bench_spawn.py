@@ -42,3 +42,13 @@ def test_bench_under_a_launcher_uses_its_ranks():
 def test_bench_single_rank_dry_run():
     d = _run(["--steps", "3", "--dry-run"])
     assert d["n_gpus"] == 1
+
+
+def test_a_leg_that_fails_on_one_rank_does_not_hang_the_others():
+    """Ranks.leg: rank 1 raises before the leg's barrier; rank 0 must come through both of the leg's collectives and print the line"""
+    d = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"], env={"ILSX_BENCH_DRY_FAIL_RANK": "1"})
+    assert d["leg_errors"] == [0.0, 1.0] and abs(d["leg"]["dt_max"] - 0.001) < 1e-9
+    d = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"], env={"ILSX_BENCH_DRY_FAIL_RANK": "0"})
+    assert d["leg_errors"] == [1.0, 0.0] and "error" in d["leg"]
+    d = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert d["leg_errors"] == [0.0, 0.0] and abs(d["leg"]["dt_max"] - 0.002) < 1e-9
