@@ -213,6 +213,7 @@ PROTOTYPES = {
     "ilsx_ctx_sync": (C.c_int, [vp]),
     "ilsx_ctx_destroy": (C.c_int, [vp]),
     "ilsx_ctx_stream": (vp, [vp]),
+    "ilsx_ctx_rng_stream_cursor": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ilsx_ctx_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "ilsx_ctx_free": (C.c_int, [vp, vp]),
     "ilsx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),

@@ -89,7 +89,7 @@ class DeviceRLAlgorithm:
                  best_key="AverageReturn", bootstrap_open_segments=True, eval_on_device=True, insert_at_episode_end=False,
                  eval_policy=None, eval_sampler=None, save_epoch=False, save_best_starting_from_epoch=0, eval_no_terminal=False,
                  wrap_absorbing=False, render=False, render_kwargs=None, freq_log_visuals=1, eval_preprocess_func=None,
-                 split_world=1, split_agree=None):
+                 split_world=1, split_agree=None, eval_async=False):
         # keyword names and DEFAULTS are BaseAlgorithm's (base_algorithm.py:21-54); batch_size and num_train_steps_per_train_call have
         # none there either (torch_rl_algorithm.py:8-10).  Every shipped spec states all of them; log_dir / bootstrap_open_segments /
         # eval_on_device / insert_at_episode_end are ilswiss_amd keys.
@@ -132,6 +132,13 @@ class DeviceRLAlgorithm:
         sampler_cls = DeviceEvalSampler if (eval_on_device and hasattr(eval_env, "h")) else VecPathSampler
         self.eval_sampler = eval_sampler if eval_sampler is not None else sampler_cls(eval_env, eval_policy, num_steps_per_eval, max_path_length)
         self.logger = TabularLogger(log_dir)
+        # eval_async (an ilswiss_amd key, default off): the evaluation of epoch e runs on a FROZEN copy of the policy, on the eval env's own
+        # context (stream), while epoch e + 1 samples and trains; its row is written when it is in (before the next evaluation starts).
+        # Same statistics, same snapshots, the same evaluation-env sequence as the blocking form; what differs is (1) the time columns and
+        # (2) the exploration-noise stream from epoch 1 on: a blocking evaluation advances the policy context's act-call counter
+        # (ilsx_policy_act keys its Philox draw with it), the frozen copy advances its own context's — same distribution, other draws.
+        self.eval_async = self._eval_async_setup() if eval_async else None
+        self._eval_pending = None
         self._n_env_steps_total = self._n_train_steps_total = self._n_prev_train_env_steps = self._n_grad_steps_total = 0
         self._n_rollouts_total, self.best_statistic_so_far = 0, -np.inf
         self._t_sample = self._t_train = self._t_eval = 0.0
@@ -197,6 +204,7 @@ class DeviceRLAlgorithm:
         if self.on_policy:
             return self._train_on_policy(start_epoch)
         ctx = self.trainer.ctx
+        pool = None
         t_start = time.perf_counter()
         for epoch in range(start_epoch, self.num_epochs + 1):  # num_epochs + 1 (base_algorithm.py:64)
             t_epoch = time.perf_counter()
@@ -218,9 +226,18 @@ class DeviceRLAlgorithm:
                     self._t_sample += time.perf_counter() - t0
             ctx.sync()
             t0 = time.perf_counter()
-            self.evaluate(epoch, time.perf_counter() - t_epoch, time.perf_counter() - t_start)
-            self._t_eval = time.perf_counter() - t0
+            if self.eval_async is not None:
+                if pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    pool = ThreadPoolExecutor(max_workers=1)
+                self._eval_async_start(pool, epoch, t0 - t_epoch, t0 - t_start)
+            else:
+                self.evaluate(epoch, time.perf_counter() - t_epoch, time.perf_counter() - t_start)
+                self._t_eval = time.perf_counter() - t0
             self.trainer.end_epoch()
+        if pool is not None:
+            self._eval_async_join()
+            pool.shutdown()
 
     def _eval_collect(self):
         """The evaluation rollouts (device work + host waits, no logging): what evaluate() reduces and logs."""
@@ -228,13 +245,84 @@ class DeviceRLAlgorithm:
             return self.eval_sampler.obtain_statistics(stat_prefix="Test")
         return self.eval_sampler.obtain_samples()
 
+    # ---- eval_async: the evaluation of an epoch overlapped with the next epoch's sampling and training
+    def _eval_async_setup(self):
+        """(frozen policy copy, sampler on it) when this run can evaluate beside its training: a deterministic device evaluation
+        (MakeDeterministic over a network of this library) whose env lives on a context — a stream — of its own (the run scripts build it
+        there when rl_alg_params.eval_async is set).  None, with the reason printed, otherwise: the evaluation then blocks as always."""
+        s = self.eval_sampler
+        why = None
+        if type(s) is not DeviceEvalSampler:
+            why = "the evaluation is not a DeviceEvalSampler"
+        else:
+            pi, ppo, det = s._handles()
+            if pi is None or not det:
+                why = "the evaluation policy is not MakeDeterministic over a device network (eval_deterministic: true)"
+            elif s.env.ctx is self.trainer.ctx or s.env.ctx.stream == self.trainer.ctx.stream:
+                why = "the eval env shares the training stream"
+        if why is not None:
+            print(f"DeviceRLAlgorithm(eval_async=True): {why}; evaluating between epochs", flush=True)
+            return None
+        frozen = s.policy.stochastic_policy.copy(ctx=s.env.ctx)
+        return dict(live=s.policy.stochastic_policy, frozen=frozen,
+                    sampler=DeviceEvalSampler(s.env, MakeDeterministic(frozen), s.num_steps, s.max_path_length))
+
+    def _eval_freeze(self):
+        """the policy as it is now -> the frozen copy (the caller has waited for the training stream)"""
+        a = self.eval_async
+        a["frozen"].set_flat_params(a["live"].get_flat_params())
+
+    def _eval_begin(self, epoch, epoch_time, total_time):
+        """Everything evaluate() logs that is NOT the evaluation rollouts, read at the end of the epoch: trainer statistics, the epoch's
+        exploration episodes, counters, times, and the snapshot an asynchronous evaluation will save under its own result."""
+        pre = dict(epoch=epoch, epoch_time=epoch_time, total_time=total_time, ts=self.trainer.get_eval_statistics())
+        pre["exploration"] = self.training_env.rollout_stats(reset=True)
+        self._n_rollouts_total += int(pre["exploration"][0])
+        pre["counters"] = (self._n_train_steps_total, self._n_grad_steps_total, self._n_env_steps_total * self.split_world, self._n_rollouts_total)
+        pre["times"] = (self._t_train, self._t_eval, self._t_sample)
+        return pre
+
+    def _eval_async_start(self, pool, epoch, epoch_time, total_time):
+        """End of an epoch in the asynchronous form: log the evaluation that ran beside this epoch, freeze the policy, take what the row and
+        the snapshots need, start this epoch's evaluation.  Returns after the hand-over; the training loop goes on."""
+        self._eval_async_join()
+        self._eval_freeze()
+        pre = self._eval_begin(epoch, epoch_time, total_time)
+        pre["snapshot"] = self.get_epoch_snapshot()
+        pre["extra"] = self.get_extra_data_to_save(epoch)
+        pre["t0"] = time.perf_counter()
+        sampler = self.eval_async["sampler"]
+
+        def run():
+            out = sampler.obtain_statistics(stat_prefix="Test")
+            return out, time.perf_counter() - pre["t0"]
+        self._eval_pending = (pre, pool.submit(run))
+
+    def _eval_async_join(self):
+        if self._eval_pending is not None:
+            pre, fut = self._eval_pending
+            self._eval_pending = None
+            collected, self._t_eval = fut.result()
+            self._eval_finish(pre, collected)
+
     def evaluate(self, epoch, epoch_time, total_time, collected=None):
-        st = OrderedDict()
-        ts = self.trainer.get_eval_statistics()
-        if ts:
-            st.update(ts)
+        pre = dict(epoch=epoch, epoch_time=epoch_time, total_time=total_time, ts=self.trainer.get_eval_statistics())
         if collected is None:
             collected = self._eval_collect()
+        pre["exploration"] = self.training_env.rollout_stats(reset=True)
+        self._n_rollouts_total += int(pre["exploration"][0])
+        pre["counters"] = (self._n_train_steps_total, self._n_grad_steps_total, self._n_env_steps_total * self.split_world, self._n_rollouts_total)
+        pre["times"] = (self._t_train, self._t_eval, self._t_sample)
+        return self._eval_finish(pre, collected)
+
+    def _eval_finish(self, pre, collected):
+        """Reduce and log one epoch's row, save its snapshots (base_algorithm.py:302-348, 599-656).  pre: _eval_begin's dict (+ "snapshot" /
+        "extra" taken at the end of the epoch when the evaluation ran beside the next one)."""
+        epoch, epoch_time, total_time = pre["epoch"], pre["epoch_time"], pre["total_time"]
+        st = OrderedDict()
+        ts = pre["ts"]
+        if ts:
+            st.update(ts)
         if isinstance(self.eval_sampler, DeviceEvalSampler):
             dev_stats = collected
             average_return = dev_stats.pop("AverageReturn")
@@ -243,8 +331,7 @@ class DeviceRLAlgorithm:
             test_paths = collected
             st.update(get_generic_path_information(test_paths, stat_prefix="Test"))
             average_return = get_average_returns(test_paths)
-        episodes, ret_sum = self.training_env.rollout_stats(reset=True)
-        self._n_rollouts_total += int(episodes)
+        episodes, ret_sum = pre["exploration"]
         if episodes > 0:
             st["Exploration Returns Mean"] = ret_sum / episodes
             st["Exploration Num Paths"] = episodes
@@ -253,27 +340,33 @@ class DeviceRLAlgorithm:
         for k, v in st.items():
             lg.record_tabular(k, float(np.mean(v)))
         # base_algorithm.py:322-343
-        lg.record_tabular("Number of train calls total", self._n_train_steps_total)   # the reference's column and counter
-        lg.record_tabular("Number of gradient steps total", self._n_grad_steps_total)  # ours: calls x steps per call
-        lg.record_tabular("Number of env steps total", self._n_env_steps_total * self.split_world)
-        lg.record_tabular("Number of rollouts total", self._n_rollouts_total)
-        lg.record_tabular("Train Time (s)", self._t_train)
-        lg.record_tabular("(Previous) Eval Time (s)", self._t_eval)
-        lg.record_tabular("Sample Time (s)", self._t_sample)
+        n_calls, n_grad, n_env, n_roll = pre["counters"]
+        t_train, t_eval, t_sample = pre["times"]
+        lg.record_tabular("Number of train calls total", n_calls)   # the reference's column and counter
+        lg.record_tabular("Number of gradient steps total", n_grad)  # ours: calls x steps per call
+        lg.record_tabular("Number of env steps total", n_env)
+        lg.record_tabular("Number of rollouts total", n_roll)
+        lg.record_tabular("Train Time (s)", t_train)
+        lg.record_tabular("(Previous) Eval Time (s)", t_eval)
+        lg.record_tabular("Sample Time (s)", t_sample)
         lg.record_tabular("Epoch Time (s)", epoch_time)
         lg.record_tabular("Total Train Time (s)", total_time)
         lg.record_tabular("Epoch", epoch)
         lg.dump_tabular()
         snap = dict(epoch=epoch, statistics=dict(st))
+        snapshot = (lambda: pre["snapshot"]) if "snapshot" in pre else self.get_epoch_snapshot   # the state the evaluated policy belongs to
         if self.freq_saving and epoch % self.freq_saving == 0:
-            lg.save("params.pkl", dict(snap, **self.get_epoch_snapshot()))
+            lg.save("params.pkl", dict(snap, **snapshot()))
         if self.save_epoch:   # base_algorithm.py:647-649
-            lg.save(f"epoch{epoch}.pkl", dict(snap, **self.get_epoch_snapshot()))
+            lg.save(f"epoch{epoch}.pkl", dict(snap, **snapshot()))
         if st[self.best_key] > self.best_statistic_so_far:
             self.best_statistic_so_far = st[self.best_key]
             if self.save_best and epoch >= self.save_best_starting_from_epoch:   # :650-656
-                lg.save("best.pkl", dict(snap, **self.get_epoch_snapshot()))
-        lg.save("extra_data.pkl", self.get_extra_data_to_save(epoch))
+                lg.save("best.pkl", dict(snap, **snapshot()))
+        extra = pre["extra"] if "extra" in pre else self.get_extra_data_to_save(epoch)
+        if "extra" in pre:
+            extra["best_statistic_so_far"] = self.best_statistic_so_far
+        lg.save("extra_data.pkl", extra)
         return st
 
     # ---- snapshots / resume (base_algorithm.py:560-597; logger.load_from_file -> ilswiss_amd/snapshot.py)
@@ -361,14 +454,14 @@ class DeviceRLAlgorithmGroup:
         return (arr([a.training_env for a in algs]), arr([a.exploration_policy for a in algs]), arr([a.replay_buffer for a in algs]),
                 (C.c_int64 * K)(*[int(a.min_steps_before_training) for a in algs]), a0.trainer.ctx.lib)
 
-    def _eval_lockstep(self):
+    def _eval_lockstep(self, samplers=None):
         """All runs' evaluation rollouts in one library call (ilsx_eval_rollouts_lockstep: one launch per stage for the runs' small eval envs);
         None when the runs do not evaluate through the same device sampler or cannot share launches."""
         import ctypes as C
 
         from . import _lib
         algs, a0 = self.algs, self.algs[0]
-        ss = [getattr(a, "eval_sampler", None) for a in algs]
+        ss = samplers if samplers is not None else [getattr(a, "eval_sampler", None) for a in algs]
         if len(algs) < 2 or not all(type(s_) is DeviceEvalSampler for s_ in ss) or not hasattr(a0.trainer.ctx.lib, "ilsx_eval_rollouts_lockstep"):
             return None
         hs = [s_._handles() for s_ in ss]
@@ -428,6 +521,20 @@ class DeviceRLAlgorithmGroup:
         # the runs' evaluation rollouts are host-driven loops of small launches (one C call per rollout round, a wait every 32 vec steps): one
         # thread per run, each on its run's stream — ctypes drops the GIL inside the calls, the K evaluations overlap on the GPU
         pool = ThreadPoolExecutor(max_workers=len(algs)) if len(algs) > 1 else None
+        # eval_async on every run: the K evaluations of an epoch run (in lock-step, on the frozen copies and the eval envs' own streams) beside
+        # the next epoch's sampling and training; their K rows are written when they are in
+        use_async = all(getattr(a, "eval_async", None) is not None for a in algs)
+        apool = ThreadPoolExecutor(max_workers=1) if use_async else None
+        pending = None
+
+        def join(pending):
+            if pending is not None:
+                pres, fut = pending
+                collected, t_ev = fut.result()
+                for a, pre, c in zip(algs, pres, collected):
+                    a._t_eval = t_ev
+                    a._eval_finish(pre, c)
+            return None
         t_start = time.perf_counter()
         for epoch in range(start_epoch, a0.num_epochs + 1):
             t_epoch = time.perf_counter()
@@ -468,6 +575,26 @@ class DeviceRLAlgorithmGroup:
                     t_sample += time.perf_counter() - t0
             self.sync()
             t_eval0 = time.perf_counter()
+            if use_async:
+                pending = join(pending)
+                pres = []
+                for a in algs:
+                    a._t_sample, a._t_train = t_sample, t_train
+                    a._eval_freeze()
+                    pre = a._eval_begin(epoch, t_eval0 - t_epoch, t_eval0 - t_start)
+                    pre["snapshot"], pre["extra"] = a.get_epoch_snapshot(), a.get_extra_data_to_save(epoch)
+                    pres.append(pre)
+                    a.trainer.end_epoch()
+                samplers = [a.eval_async["sampler"] for a in algs]
+
+                def run(samplers=samplers, t0=t_eval0):
+                    collected = self._eval_lockstep(samplers)
+                    if collected is None:
+                        collected = list(pool.map(lambda s_: s_.obtain_statistics(stat_prefix="Test"), samplers)) if pool else \
+                            [samplers[0].obtain_statistics(stat_prefix="Test")]
+                    return collected, time.perf_counter() - t0
+                pending = (pres, apool.submit(run))
+                continue
             collected = self._eval_lockstep()
             if collected is None:
                 collected = list(pool.map(lambda a: a._eval_collect(), algs)) if pool else [algs[0]._eval_collect()]
@@ -477,6 +604,9 @@ class DeviceRLAlgorithmGroup:
                 a.evaluate(epoch, t_eval0 - t_epoch, t_eval0 - t_start, collected=c)
                 a._t_eval = t_eval
                 a.trainer.end_epoch()
+        join(pending)
+        if apool:
+            apool.shutdown()
         if pool:
             pool.shutdown()
 

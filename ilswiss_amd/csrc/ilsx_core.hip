@@ -108,6 +108,12 @@ extern "C" int ilsx_ctx_sync(ilsx_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return ILSX_OK;
 }
+extern "C" int ilsx_ctx_rng_stream_cursor(ilsx_ctx* c, uint32_t set_to, uint32_t* current) {
+  if (!c) ILSX_FAIL(ILSX_ERR_ARG, "ctx is NULL");
+  if (current) *current = c->next_rng_stream;
+  if (set_to > 0) c->next_rng_stream = set_to;
+  return ILSX_OK;
+}
 extern "C" int ilsx_ctx_destroy(ilsx_ctx* c) {
   if (!c) return ILSX_OK;
   hipSetDevice(c->device);

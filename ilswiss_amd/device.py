@@ -34,6 +34,12 @@ class Context:
         c.parent = self     # a shared stream's owner must outlive it
         return c
 
+    def rng_stream_cursor(self, set_to=0):
+        """the Philox stream id the next random-drawing object of this context takes (include/ilsx.h ilsx_ctx_rng_stream_cursor); set_to > 0 moves it"""
+        cur = C.c_uint32()
+        _lib.check(self.lib.ilsx_ctx_rng_stream_cursor(self.h, int(set_to), C.byref(cur)))
+        return cur.value
+
     def sync(self):
         _lib.check(self.lib.ilsx_ctx_sync(self.h))
 

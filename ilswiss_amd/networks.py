@@ -82,12 +82,14 @@ class Mlp:
         flat = np.ascontiguousarray(flat, np.float32)
         _lib.check(self.ctx.lib.ilsx_net_set_params(self.h, flat.ctypes.data_as(C.c_void_p), flat.size, 0))
 
-    def copy(self):  # PyTorchModule.copy (rlkit/torch/core.py:32-35)
+    def copy(self, ctx=None):  # PyTorchModule.copy (rlkit/torch/core.py:32-35); ctx: the copy lives in another context of the same device
         c = type(self).__new__(type(self))
         c.__dict__.update({k: v for k, v in self.__dict__.items() if k != "h"})
+        if ctx is not None:
+            c.ctx = ctx
         cfg = self._cfg()
         c.h = C.c_void_p()
-        _lib.check(self.ctx.lib.ilsx_net_create(self.ctx.h, C.byref(cfg), C.byref(c.h)))
+        _lib.check(c.ctx.lib.ilsx_net_create(c.ctx.h, C.byref(cfg), C.byref(c.h)))
         c.set_flat_params(self.get_flat_params())
         return c
 

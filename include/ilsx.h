@@ -61,6 +61,11 @@ int ilsx_ctx_create(int hip_device, void* hip_stream, uint64_t seed, ilsx_ctx** 
 int ilsx_ctx_sync(ilsx_ctx* ctx);
 int ilsx_ctx_destroy(ilsx_ctx* ctx);
 void* ilsx_ctx_stream(ilsx_ctx* ctx);
+/* Every object that draws random numbers (vec env, replay ring, trainer, discriminator) takes the ctx's next Philox stream id when it is
+   created.  Reads the cursor into *current (nullable) and, when set_to > 0, moves it: an object built on ANOTHER ctx of the same run (the eval
+   env of rl_alg_params.eval_async lives on a stream of its own) can then take the id it would have had on this one, and this ctx skips it, so
+   the run's other objects keep their streams.  The reference has one global torch / numpy generator per process (no counterpart). */
+int ilsx_ctx_rng_stream_cursor(ilsx_ctx* ctx, uint32_t set_to, uint32_t* current);
 /* Device scratch owned by the ctx (freed with it); used by the Python adapters for staging. */
 int ilsx_ctx_alloc(ilsx_ctx* ctx, size_t bytes, void** out);
 int ilsx_ctx_free(ilsx_ctx* ctx, void* ptr);

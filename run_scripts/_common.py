@@ -39,7 +39,15 @@ def make_envs(variant, ctx, **vec_kwargs):
     eval_kwargs = dict(vec_kwargs)
     if vec_kwargs.get("norm_obs"):   # ppo_exp_script.py:68-75: the eval env shares the statistics and does not update them
         eval_kwargs.update(obs_rms=training_env.obs_rms, update_obs_rms=False)
-    eval_env = get_envs(dict(env_specs, env_num=n_eval, training_env_seed=seed + 10007), ctx=ctx, **eval_kwargs)
+    # rl_alg_params.eval_async: the eval env gets a context (a HIP stream) of its own, so that DeviceRLAlgorithm can evaluate an epoch on a
+    # frozen policy copy beside the next epoch's sampling and training (the env's own seed drives its resets: the context only carries the stream)
+    use_async = bool((variant.get("rl_alg_params") or {}).get("eval_async")) and hasattr(ctx, "rng_stream_cursor")
+    ectx = ctx.sibling(seed + 10007) if use_async else ctx
+    if use_async:
+        ectx.rng_stream_cursor(set_to=ctx.rng_stream_cursor())    # the eval env takes the Philox stream id it would have had on the run's ctx ...
+    eval_env = get_envs(dict(env_specs, env_num=n_eval, training_env_seed=seed + 10007), ctx=ectx, **eval_kwargs)
+    if use_async:
+        ctx.rng_stream_cursor(set_to=ectx.rng_stream_cursor())    # ... and the run's ctx skips it: ring and trainer keep their streams
     return training_env, eval_env, training_env.single_env_view()
 
 

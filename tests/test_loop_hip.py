@@ -375,6 +375,39 @@ def test_grouped_run_script_writes_the_single_run_logs(tmp_path, path_mode):
     assert _rows_without_time(grp[0]) != _rows_without_time(grp[1])     # the seeds differ
 
 
+def test_eval_async_overlaps_the_next_epoch_and_logs_the_same_rows(tmp_path):
+    """rl_alg_params.eval_async: the evaluation of epoch e runs on a frozen policy copy (eval env on a stream of its own) beside epoch e + 1 and
+    its row is written when it is in.  (1) every epoch gets its row (the last one after the loop); (2) row 0 — everything before the first
+    evaluation — is the blocking run's row 0, evaluation columns included: the frozen copy IS the policy at the end of the epoch; (3) later
+    rows differ from the blocking run's only through the exploration-noise counter (the blocking evaluation advances it), so they are compared
+    between the single-process and the grouped form of the ASYNCHRONOUS run instead: cell for cell, parameters bit for bit; (4) params.pkl is
+    the snapshot of the evaluated epoch, not of the epoch that trained beside the evaluation."""
+    import pickle
+    spec = yaml.safe_load(open(os.path.join(ROOT, "exp_specs", "sac", "sac_hopper_hip.yaml")))
+    spec["meta_data"].update(script_path=os.path.join(ROOT, "run_scripts", "sac_alpha_exp_script.py"), num_workers=1, exp_name="async_test")
+    spec["variables"] = dict(seed=[0, 1])
+    c = spec["constants"]
+    c["env_specs"].update(env_num=8, eval_env_num=4)
+    c["rl_alg_params"].update(num_epochs=2, num_steps_per_epoch=800, num_steps_between_train_calls=80, num_train_steps_per_train_call=12,
+                              num_steps_per_eval=200, max_path_length=60, min_steps_before_training=0, batch_size=256, replay_buffer_size=20000,
+                              freq_saving=1, insert_at_episode_end=True, eval_deterministic=True)
+    sync, _ = _launch(tmp_path, spec, 1, "sync")
+    c["rl_alg_params"]["eval_async"] = True
+    solo, out1 = _launch(tmp_path, spec, 1, "async_solo")
+    grp, out2 = _launch(tmp_path, spec, 2, "async_grouped")
+    assert "evaluating between epochs" not in out1 + out2      # the asynchronous form was taken, not its fallback
+    for seed in range(2):
+        s_, a, b = (_rows_without_time(d[seed]) for d in (sync, solo, grp))
+        assert len(s_) == len(a) == len(b) == 3
+        assert [r["Epoch"] for r in a] == ["0", "1", "2"]
+        assert s_[0] == a[0], {k: (s_[0][k], a[0].get(k)) for k in s_[0] if s_[0][k] != a[0].get(k)}
+        assert a == b, seed
+        pa, pb = (pickle.load(open(os.path.join(d[seed], "params.pkl"), "rb")) for d in (solo, grp))
+        assert pa["epoch"] == pb["epoch"] == 2
+        for k in ("policy", "qf1", "target_qf2"):
+            np.testing.assert_array_equal(pa[k], pb[k], err_msg=f"seed {seed} {k}")
+
+
 @pytest.mark.parametrize("spec_name", ["sac_walker_hip.yaml", "sac_halfcheetah_hip.yaml"])
 def test_grouped_runs_on_the_seven_body_steppers(tmp_path, spec_name):
     """The lock-step rollout / evaluation launches of grouped runs (k_envg_step_runs) in their Walker2d (12 constraint rows) and HalfCheetah (16)
