@@ -115,14 +115,14 @@ class PpoCfg(C.Structure):  # ilsx_ppo_cfg
                 ("policy_lr", C.c_float), ("value_lr", C.c_float), ("gae_tau", C.c_float),
                 ("value_l2_reg", C.c_float), ("mini_batch_size", C.c_int32), ("update_epoch", C.c_int32),
                 ("max_samples", C.c_int32), ("use_value_clip", C.c_int32), ("conditioned_std", C.c_int32),
-                ("hidden_sizes", C.c_int32 * 3)]
+                ("hidden_sizes", C.c_int32 * 3), ("grad_world", C.c_int32)]
 
 
 class DiscCfg(C.Structure):  # ilsx_disc_cfg
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("hid_dim", C.c_int32), ("hid_act", C.c_int32),
                 ("use_grad_pen", C.c_int32), ("clamp_magnitude", C.c_float), ("disc_lr", C.c_float),
                 ("disc_momentum", C.c_float), ("grad_pen_weight", C.c_float), ("max_batch", C.c_int32),
-                ("state_only", C.c_int32), ("num_layer_blocks", C.c_int32), ("use_bn", C.c_int32)]
+                ("state_only", C.c_int32), ("num_layer_blocks", C.c_int32), ("use_bn", C.c_int32), ("grad_world", C.c_int32)]
 
 
 class OptMeta(C.Structure):  # ilsx_opt_meta
@@ -175,6 +175,7 @@ PROTOTYPES = {
     "ilsx_vecenv_get_obs_rms": (C.c_int, [vp, vp, vp, C.POINTER(C.c_double)]),
     "ilsx_vecenv_set_obs_rms": (C.c_int, [vp, vp, vp, C.c_double]),
     "ilsx_ppo_debug_perm": (C.c_int, [vp, C.c_int, C.c_uint32, vp]),
+    "ilsx_ppo_debug_grad_norm": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "ilsx_ppo_policy_act": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "ilsx_disc_create": (C.c_int, [vp, C.POINTER(DiscCfg), C.POINTER(vp)]),
     "ilsx_advirl_set_policy_batch_from_expert": (C.c_int, [vp, C.c_int]),

@@ -120,7 +120,7 @@ class MLPDisc:
         _lib.check(self.ctx.lib.ilsx_disc_set_bn_stats(self.h, rm.ctypes.data_as(C.c_void_p), rv.ctypes.data_as(C.c_void_p), rm.size))
 
     def bind(self, obs_dim, second_dim=None, state_only=False, disc_lr=1e-3, disc_momentum=0.0, use_grad_pen=True,
-             grad_pen_weight=10.0, max_batch=1024):
+             grad_pen_weight=10.0, max_batch=1024, grad_world=1):
         """Create (or re-create, keeping the parameters) the library object.  The discriminator input is cat(obs, act) —
         or cat(obs, next_obs) when state_only (adv_irl.py:140-162) — so obs_dim + second_dim == input_dim."""
         obs_dim = int(obs_dim)
@@ -128,7 +128,7 @@ class MLPDisc:
         if obs_dim + second_dim != self.input_dim:
             raise ValueError(f"input_dim {self.input_dim} != {obs_dim} + {second_dim}")
         key = (obs_dim, second_dim, bool(state_only), float(disc_lr), float(disc_momentum), bool(use_grad_pen),
-               float(grad_pen_weight), int(max_batch))
+               float(grad_pen_weight), int(max_batch), int(grad_world))
         if self._bound == key:
             return self
         opt = bn = None
@@ -141,7 +141,7 @@ class MLPDisc:
             _lib.check(self.ctx.lib.ilsx_disc_destroy(self.h))
         cfg = _lib.DiscCfg(obs_dim, second_dim, self._Hp, _ACT[self.hid_act], int(bool(use_grad_pen)), self.clamp_magnitude,
                            disc_lr, disc_momentum, grad_pen_weight, int(max_batch), int(bool(state_only)), self.num_layer_blocks,
-                           int(self.use_bn))
+                           int(self.use_bn), int(grad_world))   # grad_world: ilsx_disc_cfg (one run split over G ranks)
         self.h = C.c_void_p()
         _lib.check(self.ctx.lib.ilsx_disc_create(self.ctx.h, C.byref(cfg), C.byref(self.h)))
         self._bound = key
@@ -239,7 +239,9 @@ class AdvIRLTrainer:
                  policy_optim_batch_size=1024, policy_optim_batch_size_from_expert=0, num_update_loops_per_train_call=1,
                  num_disc_updates_per_loop_iter=100, num_policy_updates_per_loop_iter=100, disc_lr=1e-3, disc_momentum=0.0,
                  disc_optimizer_class=None, use_grad_pen=True, grad_pen_weight=10, rew_clip_min=None, rew_clip_max=None,
-                 replay_buffer=None, wrap_absorbing=False, **kwargs):
+                 replay_buffer=None, wrap_absorbing=False, grad_world=1, **kwargs):
+        # grad_world (an ilswiss_amd key): this process is one rank of a run split over G GPUs — the batch sizes are this rank's rows, the
+        # discriminator's and the policy trainer's gradient arenas are all-reduced by the library (include/ilsx.h ilsx_disc_cfg.grad_world)
         assert mode in _MODES, "Invalid adversarial irl algorithm!"
         if disc_optimizer_class is not None and getattr(disc_optimizer_class, "__name__", disc_optimizer_class) != "Adam":
             raise NotImplementedError("the discriminator optimiser is Adam (adv_irl.py:48)")
@@ -259,7 +261,8 @@ class AdvIRLTrainer:
         a = int(expert_replay_buffer._action_dim)
         self.o, self.a = o, a
         discriminator.bind(o, o if self.state_only else a, state_only=self.state_only, disc_lr=disc_lr, disc_momentum=disc_momentum,
-                           use_grad_pen=use_grad_pen, grad_pen_weight=grad_pen_weight, max_batch=max(self.Bd, self.Bp))
+                           use_grad_pen=use_grad_pen, grad_pen_weight=grad_pen_weight, max_batch=max(self.Bd, self.Bp),
+                           grad_world=int(grad_world))
         _lib.check(ctx.lib.ilsx_advirl_set_policy_batch_from_expert(discriminator.h, self.Bpe))
         B = max(self.Bd, self.Bp)
         mk = lambda: [ctx.empty((B, o)), ctx.empty((B, a)), ctx.empty((B,)), ctx.empty((B,)), ctx.empty((B, o))]  # noqa

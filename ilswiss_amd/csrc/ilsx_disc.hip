@@ -27,6 +27,7 @@ struct DiscScalars {
 struct DiscBwdArgs {
   NetView net;
   int B, rows, use_gp, D;
+  int world;     // split run (cfg.grad_world): the means are over B * world rows
   float clamp, gp_w;
   PartVal raw;
   float* hs0;    // [4B][H]  rows < 3B: h1 (read); rows 3B..4B: v1-bar (written)
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(4 * H) void k_disc_bwd(const DiscBwdArgs A) {
       const float l = fminf(fmaxf(raw, -A.clamp), A.clamp);
       if (gr < 2 * B) {
         const float t = gr < B ? 1.0f : 0.0f;
-        dl = gate * (1.0f / (1.0f + expf(-l)) - t) / (float)(2 * B);
+        dl = gate * (1.0f / (1.0f + expf(-l)) - t) / (float)(2 * B * A.world);
         A.ce_row[gr] = fmaxf(l, 0.0f) - l * t + log1pf(expf(-fabsf(l)));
         A.correct[gr] = ((l > 0.0f) == (t > 0.5f)) ? 1.0f : 0.0f;
         A.dhead[gr] = dl;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(4 * H) void k_disc_bwd(const DiscBwdArgs A) {
     const bool gp = rowf[row * 4 + 2] > 0.5f && gr < rows;
     // adv_irl.py:201-202; a clamped interpolate has g == 0: torch's norm backward is 0 there (not 0/0), the row still
     // counts (0 - 1)^2 in the penalty value
-    const float coef = (gp && n > 0.0f) ? A.gp_w / (float)B * 2.0f * (n - 1.0f) / n : 0.0f;
+    const float coef = (gp && n > 0.0f) ? A.gp_w / (float)(B * A.world) * 2.0f * (n - 1.0f) / n : 0.0f;
     const float gb = coef * mine;
     gs[row * 64 + lane] = gb;
     if (gp) {
@@ -475,6 +476,11 @@ extern "C" int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_di
   HIPCHK(hipSetDevice(ctx->device));
   ilsx_disc* d = new ilsx_disc();
   d->ctx = ctx; d->cfg = *cfg; d->o = cfg->obs_dim; d->a = cfg->act_dim; d->D = d->o + d->a;
+  if (d->cfg.grad_world < 1) d->cfg.grad_world = 1;
+  if (d->cfg.grad_world > 1 && cfg->use_bn) {
+    delete d;
+    ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "a BatchNorm discriminator does not split over ranks (grad_world=%d): its batch statistics would have to cross them", cfg->grad_world);
+  }
   d->nblk = cfg->num_layer_blocks ? cfg->num_layer_blocks : 2;
   if (d->nblk < 1 || d->nblk > ILSX_MAX_HID) { const int nb = d->nblk; delete d; ILSX_FAIL(ILSX_ERR_UNSUPPORTED, "num_layer_blocks=%d: 1..%d", nb, ILSX_MAX_HID); }
   if (cfg->use_bn) {   // Linear -> BatchNorm1d -> act blocks: natural layout, any width, the phase chain of csrc/disc_bn_step.h
@@ -710,7 +716,7 @@ static int disc_build_jobs(ilsx_disc* d, int B) {
 //   k_disc_lin_layer   UP the net, l = 0..L-1: u-bar_l = W_l x_{l-1}; v-bar_l = phi'_l u-bar_l -> hsb[l] rows 3B..4B; z-bar_l = (phi''/phi')_l u_l u-bar_l
 //   k_disc_inj_layer   DOWN, l = L-2..0: delta''_l = z-bar_l + phi'_l (delta''_{l+1} W_{l+1}) -> Ab[l] rows 2B..3B
 //   k_mlp_bwd_dw       per layer ONE contraction over the 4B stacked rows (bias from the first 3B) + the head's, Adam in the epilogue
-__global__ void k_disc_head_rows(PartVal raw, int B, int use_gp, float clamp, float* __restrict__ ce_row, float* __restrict__ correct,
+__global__ void k_disc_head_rows(PartVal raw, int B, int world, int use_gp, float clamp, float* __restrict__ ce_row, float* __restrict__ correct,
                                  float* __restrict__ given, float* __restrict__ dhead4) {
   const int gr = blockIdx.x * blockDim.x + threadIdx.x, rows = use_gp ? 3 * B : 2 * B;
   if (gr >= 4 * B) return;
@@ -720,7 +726,7 @@ __global__ void k_disc_head_rows(PartVal raw, int B, int use_gp, float clamp, fl
   const float l = fminf(fmaxf(r, -clamp), clamp);
   if (gr < 2 * B) {
     const float t = gr < B ? 1.0f : 0.0f;
-    const float dl = gate * (1.0f / (1.0f + expf(-l)) - t) / (float)(2 * B);
+    const float dl = gate * (1.0f / (1.0f + expf(-l)) - t) / (float)(2 * B * world);
     ce_row[gr] = fmaxf(l, 0.0f) - l * t + log1pf(expf(-fabsf(l)));
     correct[gr] = ((l > 0.0f) == (t > 0.5f)) ? 1.0f : 0.0f;
     given[gr] = dl; dhead4[gr] = dl;
@@ -728,14 +734,14 @@ __global__ void k_disc_head_rows(PartVal raw, int B, int use_gp, float clamp, fl
     given[gr] = gate; dhead4[gr] = 0.0f;   // GP rows: the u chain starts from the gate; their forward activations feed no head gradient
   }
 }
-__global__ void k_disc_gp_rows(const float* __restrict__ gdx, int B, int D, int KP, float gp_w, float* __restrict__ gbar /* xs rows 3B.. */,
+__global__ void k_disc_gp_rows(const float* __restrict__ gdx, int B, int world, int D, int KP, float gp_w, float* __restrict__ gbar /* xs rows 3B.. */,
                                float* __restrict__ gp_row) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B) return;
   float sq = 0.0f;
   for (int c = 0; c < D; ++c) { const float g = gdx[(size_t)r * D + c]; sq += g * g; }
   const float n = sqrtf(sq);
-  const float coef = n > 0.0f ? gp_w / (float)B * 2.0f * (n - 1.0f) / n : 0.0f;   // adv_irl.py:201-202; norm backward is 0 at 0
+  const float coef = n > 0.0f ? gp_w / (float)(B * world) * 2.0f * (n - 1.0f) / n : 0.0f;   // adv_irl.py:201-202; norm backward is 0 at 0
   for (int c = 0; c < KP; ++c) gbar[(size_t)r * KP + c] = c < D ? coef * gdx[(size_t)r * D + c] : 0.0f;
   gp_row[r] = (n - 1.0f) * (n - 1.0f);
 }
@@ -764,6 +770,33 @@ __global__ void k_disc_inj_layer(const float* __restrict__ Wnext, int H, const f
   dout[(size_t)r * H + k] = zbar[(size_t)r * H + k] + act_grad_from_out<ACT>(hgp[(size_t)r * H + k]) * s;
 }
 
+// Weight gradients + Adam(lr, betas = (disc_momentum, 0.999)).  One rank: Adam in the epilogue of the weight-gradient tiles (kernels.h AdamFuse:
+// same expressions as k_adam_polyak, one launch and one pass over the arena less).  Split run (cfg.grad_world = G, SURVEY section 8e "Disc: same"):
+// backward | all-reduce(gradient arena) | Adam as a launch of its own.  ILSX_SPLIT_FORCE=1 (tests): the split path on a one-rank communicator.
+static bool disc_is_split(const ilsx_disc* d) {
+  return d->cfg.grad_world > 1 || (d->ctx->comm != nullptr && getenv("ILSX_SPLIT_FORCE") != nullptr);
+}
+static int disc_dw_adam(ilsx_disc* d, int rows) {
+  ilsx_ctx* ctx = d->ctx;
+  AdamFuse F;
+  memset(&F, 0, sizeof F);
+  F.on = 1; F.Gbase = d->G; F.P = d->P; F.M = d->M; F.V = d->V; F.T = nullptr;
+  F.b1 = d->cfg.disc_momentum; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
+  F.step_size = &d->scal->adam_step; F.bc2_sqrt = &d->scal->adam_bc2s;
+  if (!disc_is_split(d)) return launch_bwd_dw(ctx, d->jobs, rows, &F);
+  if (d->cfg.grad_world > 1 && (!ctx->comm || ctx->comm_n != d->cfg.grad_world) &&
+      !(ctx->comm && ctx->comm_n == 1 && getenv("ILSX_SPLIT_FORCE")))   // (tests: a one-rank communicator stands in, the arena holds this rank's share)
+    ILSX_FAIL(ILSX_ERR_STATE, "discriminator step: grad_world=%d needs a communicator of that many ranks on the ctx (ilsx_comm_init; found %d)",
+              d->cfg.grad_world, ctx->comm ? ctx->comm_n : 0);
+  ILSX_TRY(launch_bwd_dw(ctx, d->jobs, rows, nullptr));
+  ILSX_TRY(comm_allreduce_sum(ctx, d->G, d->L.n_int));
+  AdamArgs A;
+  memset(&A, 0, sizeof A);
+  A.p = d->P; A.g = d->G; A.m = d->M; A.v = d->V; A.tgt = nullptr; A.n = (int)d->L.n_int;
+  A.b1 = F.b1; A.b2 = F.b2; A.eps = F.eps; A.tau = 0.f; A.step_size = F.step_size; A.bc2_sqrt = F.bc2_sqrt;
+  return launch_adam(ctx, A);
+}
+
 static int disc_step_blocks(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
   ilsx_ctx* ctx = d->ctx;
   hipStream_t st = ctx->stream;
@@ -781,7 +814,7 @@ static int disc_step_blocks(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
     d->jobs_B = B;
   }
   ILSX_TRY(disc_forward(d, d->X, d->D, d->D, nullptr, 0, 0, rows, true));
-  hipLaunchKernelGGL(k_disc_head_rows, dim3((4 * B + 255) / 256), dim3(256), 0, st, d->pv(), B, gp, d->cfg.clamp_magnitude, d->ce_row, d->correct,
+  hipLaunchKernelGGL(k_disc_head_rows, dim3((4 * B + 255) / 256), dim3(256), 0, st, d->pv(), B, d->cfg.grad_world, gp, d->cfg.clamp_magnitude, d->ce_row, d->correct,
                      d->given, d->dhead4);
   HIPCHK(hipGetLastError());
   for (int pass = 0; pass < (gp ? 2 : 1); ++pass) {   // 0: the CE rows ; 1: the interpolates (given = gate: the u chain + dD/dx)
@@ -797,7 +830,7 @@ static int disc_step_blocks(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
     ILSX_TRY(launch_bwd_dx(ctx, A, H, act));
   }
   if (gp) {
-    hipLaunchKernelGGL(k_disc_gp_rows, dim3((B + 255) / 256), dim3(256), 0, st, (const float*)d->gdx, B, d->D, KP, d->cfg.grad_pen_weight,
+    hipLaunchKernelGGL(k_disc_gp_rows, dim3((B + 255) / 256), dim3(256), 0, st, (const float*)d->gdx, B, d->cfg.grad_world, d->D, KP, d->cfg.grad_pen_weight,
                        d->xs + 3 * sB * KP, d->gp_row);
     const dim3 grid((unsigned)((sB * H + 255) / 256)), block(256);
     for (int l = 0; l < L; ++l) {
@@ -823,14 +856,7 @@ static int disc_step_blocks(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
     }
     HIPCHK(hipGetLastError());
   }
-  {
-    AdamFuse F;
-    memset(&F, 0, sizeof F);
-    F.on = 1; F.Gbase = d->G; F.P = d->P; F.M = d->M; F.V = d->V; F.T = nullptr;
-    F.b1 = d->cfg.disc_momentum; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
-    F.step_size = &d->scal->adam_step; F.bc2_sqrt = &d->scal->adam_bc2s;
-    ILSX_TRY(launch_bwd_dw(ctx, d->jobs, gp ? 4 * B : 2 * B, &F));
-  }
+  ILSX_TRY(disc_dw_adam(d, gp ? 4 * B : 2 * B));
   hipLaunchKernelGGL(k_disc_tail, dim3(1), dim3(256), 0, st, d->scal, d->ce_row, d->correct, d->gp_row, B, gp, d->cfg.disc_lr, d->cfg.disc_momentum,
                      0.999f);
   HIPCHK(hipGetLastError());
@@ -910,7 +936,7 @@ static int disc_step_after_prep(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
     DiscBwdArgs A;
     memset(&A, 0, sizeof A);
     A.net = net_view(d->L, d->P);
-    A.B = B; A.rows = rows; A.use_gp = gp; A.D = d->D;
+    A.B = B; A.rows = rows; A.use_gp = gp; A.D = d->D; A.world = d->cfg.grad_world;
     A.clamp = d->cfg.clamp_magnitude; A.gp_w = d->cfg.grad_pen_weight;
     A.raw = d->pv();
     A.hs0 = d->hs0; A.hs1 = d->hs1; A.xs = d->xs; A.A2 = d->A2; A.A1 = d->A1; A.dhead = d->dhead;
@@ -929,15 +955,7 @@ static int disc_step_after_prep(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
     }
     HIPCHK(hipGetLastError());
   }
-  {   // Adam(lr, betas = (disc_momentum, 0.999)) in the epilogue of the weight-gradient tiles (kernels.h AdamFuse): same expressions as
-      // k_adam_polyak, one launch and one pass over the arena less
-    AdamFuse F;
-    memset(&F, 0, sizeof F);
-    F.on = 1; F.Gbase = d->G; F.P = d->P; F.M = d->M; F.V = d->V; F.T = nullptr;
-    F.b1 = d->cfg.disc_momentum; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f;
-    F.step_size = &d->scal->adam_step; F.bc2_sqrt = &d->scal->adam_bc2s;
-    ILSX_TRY(launch_bwd_dw(ctx, d->jobs, rows, &F));
-  }
+  ILSX_TRY(disc_dw_adam(d, rows));
   hipLaunchKernelGGL(k_disc_tail, dim3(1), dim3(256), 0, ctx->stream, d->scal, d->ce_row, d->correct, d->gp_row, B, gp,
                      d->cfg.disc_lr, d->cfg.disc_momentum, 0.999f);
   HIPCHK(hipGetLastError());

@@ -161,15 +161,17 @@ struct PpoClipAdamArgs {
   const float* partial; const float* partial_ls; int nparts;
   float max_norm, b1, b2, eps;
   PpoScalars* sc;
+  int ls_from_G;   // split run: the log_std gradient sits in G already (k_ppo_ls_fold, summed over the ranks); single run: built here from the column sums
 };
 __global__ __launch_bounds__(256) void k_ppo_clip_adam(const PpoClipAdamArgs A) {
   __shared__ float s_coef;
   __shared__ float s_gls[PPO_MAX_A];
   if (threadIdx.x < A.a) {   // every block rebuilds the log_std gradient from the per-block column sums (fixed order)
     float c = 0.0f;
-    for (int i = 0; i < A.nparts; ++i) c += A.partial_ls[i * A.a + threadIdx.x];
+    if (A.ls_from_G) c = A.G[A.n_mean + threadIdx.x];
+    else for (int i = 0; i < A.nparts; ++i) c += A.partial_ls[i * A.a + threadIdx.x];
     s_gls[threadIdx.x] = c;
-    if (blockIdx.x == 0) A.G[A.n_mean + threadIdx.x] = c;
+    if (blockIdx.x == 0 && !A.ls_from_G) A.G[A.n_mean + threadIdx.x] = c;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -190,6 +192,32 @@ __global__ __launch_bounds__(256) void k_ppo_clip_adam(const PpoClipAdamArgs A) 
     const float v = A.V[i] * A.b2 + (1.0f - A.b2) * g * g;
     A.M[i] = m; A.V[i] = v;
     A.P[i] = A.P[i] - step * (m / (sqrtf(v) / bc2s + A.eps));
+  }
+}
+
+// Split run (cfg.grad_world = G): the pieces the fused single-rank minibatch folds into other launches, as launches of their own
+// around the two all-reduces.  k_ppo_ls_fold: this rank's log_std gradient (the column sums k_ppo_norm left per block, added in k_ppo_clip_adam's
+// order) into its slot of the policy arena, so that it rides in the arena's all-reduce.  k_ppo_adam_l2: the value net's Adam with the L2 term
+// (ppo.py:147-148) on the SUMMED gradient — adam_apply's expressions (kernels.h) in its order, elementwise over the arena (both packings of a
+// hidden -> hidden matrix hold the same gradient and the same parameter, hence stay equal).
+__global__ void k_ppo_ls_fold(float* G, int n_mean, int a, const float* partial_ls, int nparts) {
+  const int j = threadIdx.x;
+  if (j >= a) return;
+  float c = 0.0f;
+  for (int i = 0; i < nparts; ++i) c += partial_ls[i * a + j];
+  G[n_mean + j] = c;
+}
+struct PpoAdamL2Args { float* P; const float* G; float* M; float* V; int n; float b1, b2, eps, l2x2; const float* step; const float* bc2s; };
+__global__ __launch_bounds__(256) void k_ppo_adam_l2(const PpoAdamL2Args A) {
+  const float step = *A.step, bc2s = *A.bc2s;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < A.n; i += gridDim.x * 256) {
+    const float p0 = A.P[i];
+    float g = A.G[i];
+    g = g + A.l2x2 * p0;
+    const float m = A.M[i] * A.b1 + (1.0f - A.b1) * g;
+    const float v = A.V[i] * A.b2 + (1.0f - A.b2) * g * g;
+    A.M[i] = m; A.V[i] = v;
+    A.P[i] = p0 - step * (m / (sqrtf(v) / bc2s + A.eps));
   }
 }
 
@@ -242,6 +270,7 @@ extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo*
   HIPCHK(hipSetDevice(ctx->device));
   ilsx_ppo* p = new ilsx_ppo();
   p->ctx = ctx; p->cfg = *cfg; p->o = cfg->obs_dim; p->a = cfg->act_dim;
+  if (p->cfg.grad_world < 1) p->cfg.grad_world = 1;
   ilsx_mlp_cfg mp = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, cfg->act_dim, cfg->conditioned_std ? 2 : 1, ILSX_ACT_TANH,
                      {cfg->hidden_sizes[0], cfg->hidden_sizes[1], cfg->hidden_sizes[2]}};
   ilsx_mlp_cfg mv = {cfg->obs_dim, cfg->n_hidden, cfg->hidden, 1, 1, ILSX_ACT_TANH, {cfg->hidden_sizes[0], cfg->hidden_sizes[1], cfg->hidden_sizes[2]}};
@@ -420,10 +449,25 @@ extern "C" int ilsx_ppo_gae(ilsx_ppo* p, const float* obs, const float* act, con
   return ILSX_OK;
 }
 
+// Split run (cfg.grad_world = G > 1): see ilsx_ppo_cfg.  ILSX_SPLIT_FORCE=1 (tests): an agent with grad_world = 1 whose ctx carries a one-rank
+// communicator takes the split-run code path — dW without the fused optimiser, all-reduce, Adam as launches of their own.
+static bool ppo_is_split(const ilsx_ppo* p) {
+  return p->cfg.grad_world > 1 || (p->ctx->comm != nullptr && getenv("ILSX_SPLIT_FORCE") != nullptr);
+}
+static int ppo_check_world(const ilsx_ppo* p) {
+  if (p->cfg.grad_world == 1) return ILSX_OK;
+  if (p->ctx->comm && p->ctx->comm_n == 1 && getenv("ILSX_SPLIT_FORCE")) return ILSX_OK;   // tests: a one-rank communicator stands in, the arena holds this rank's share
+  if (!p->ctx->comm || p->ctx->comm_n != p->cfg.grad_world)
+    ILSX_FAIL(ILSX_ERR_STATE, "ilsx_ppo_train: grad_world=%d needs a communicator of that many ranks on the ctx (ilsx_comm_init; found %d)",
+              p->cfg.grad_world, p->ctx->comm ? p->ctx->comm_n : 0);
+  return ILSX_OK;
+}
+
 static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const int* idx, int rows) {
   ilsx_ctx* ctx = p->ctx;
   const int H = p->cfg.hidden, nh = p->cfg.n_hidden;
-  const float inv = 1.0f / (float)rows;
+  const bool split = ppo_is_split(p);
+  const float inv = 1.0f / ((float)rows * (float)p->cfg.grad_world);
   // ---- value update (ppo.py:136-153)
   {
     FwdArgs A;
@@ -449,7 +493,15 @@ static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const 
     F.on = 1; F.Gbase = p->Gv; F.P = p->Pv; F.M = p->Mv; F.V = p->Vv; F.T = nullptr;
     F.b1 = 0.9f; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f; F.l2x2 = 2.0f * p->cfg.value_l2_reg;
     F.step_size = &p->sc->v_step; F.bc2_sqrt = &p->sc->v_bc2s;
-    ILSX_TRY(launch_bwd_dw(ctx, p->jobs_v, rows, &F));
+    if (!split) {
+      ILSX_TRY(launch_bwd_dw(ctx, p->jobs_v, rows, &F));
+    } else {   // backward | all-reduce(value arena) | Adam + L2 on the summed gradient
+      ILSX_TRY(launch_bwd_dw(ctx, p->jobs_v, rows, nullptr));
+      ILSX_TRY(comm_allreduce_sum(ctx, p->Gv, p->nv));
+      const PpoAdamL2Args Aa = {p->Pv, p->Gv, p->Mv, p->Vv, (int)p->nv, F.b1, F.b2, F.eps, F.l2x2, F.step_size, F.bc2_sqrt};
+      hipLaunchKernelGGL(k_ppo_adam_l2, dim3(64), dim3(256), 0, ctx->stream, Aa);
+      HIPCHK(hipGetLastError());
+    }
     ILSX_TRY(ppo_refresh(p, 0));
   }
   // ---- policy update (ppo.py:155-170)
@@ -483,7 +535,15 @@ static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const 
     Nn.aux = p->aux; Nn.rows = p->cond() ? 0 : rows; Nn.a = p->n_ls(); Nn.partial = p->partial; Nn.partial_ls = p->partial + 64;
     const int nblk = 32;
     hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
+    if (split) {   // this rank's log_std gradient into the arena | all-reduce(policy arena) | the norm of the SUMMED gradient
+      if (p->n_ls()) hipLaunchKernelGGL(k_ppo_ls_fold, dim3(1), dim3(64), 0, ctx->stream, p->Gp, (int)p->Lp.n_int, p->n_ls(), Nn.partial_ls, nblk);
+      HIPCHK(hipGetLastError());
+      ILSX_TRY(comm_allreduce_sum(ctx, p->Gp, p->np));
+      Nn.rows = 0; Nn.a = 0;
+      hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
+    }
     PpoClipAdamArgs C;
+    C.ls_from_G = split ? 1 : 0;
     C.P = p->Pp; C.G = p->Gp; C.M = p->Mp; C.V = p->Vp; C.n = (int)p->np;
     C.partial = p->partial; C.partial_ls = p->partial + 64; C.nparts = nblk; C.n_mean = (int)p->Lp.n_int; C.a = p->n_ls(); C.max_norm = 20.0f; C.b1 = 0.9f; C.b2 = 0.999f; C.eps = 1e-8f; C.sc = p->sc;
     hipLaunchKernelGGL(k_ppo_clip_adam, dim3(64), dim3(256), 0, ctx->stream, C);
@@ -498,6 +558,8 @@ static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const 
 extern "C" int ilsx_ppo_train(ilsx_ppo* p, const float* obs, const float* act, const float* rew,
                               const int32_t* traj_offsets_host, int n_traj, const float* bootstrap_values,
                               const int32_t* perms_host) {
+  if (!p) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_train: NULL agent");
+  ILSX_TRY(ppo_check_world(p));
   ILSX_TRY(ilsx_ppo_gae(p, obs, act, rew, traj_offsets_host, n_traj, bootstrap_values, nullptr, nullptr, nullptr, nullptr));
   const int N = p->N, mb = p->cfg.mini_batch_size;
   int half_bits = 1;
@@ -515,6 +577,17 @@ extern "C" int ilsx_ppo_train(ilsx_ppo* p, const float* obs, const float* act, c
     }
     for (int s = 0; s < N; s += mb) ILSX_TRY(ppo_minibatch(p, obs, act, p->perm + s, std::min(mb, N - s)));
   }
+  return ILSX_OK;
+}
+
+// the policy gradient's norm of the last minibatch, as clip_grad_norm_ saw it (split run: of the summed gradient), for tests
+extern "C" int ilsx_ppo_debug_grad_norm(ilsx_ppo* p, float* out) {
+  if (!p || !out) ILSX_FAIL(ILSX_ERR_ARG, "ilsx_ppo_debug_grad_norm: NULL argument");
+  HIPCHK(hipSetDevice(p->ctx->device));
+  PpoScalars h;
+  HIPCHK(hipMemcpyAsync(&h, p->sc, sizeof h, hipMemcpyDeviceToHost, p->ctx->stream));
+  HIPCHK(hipStreamSynchronize(p->ctx->stream));
+  *out = h.grad_norm;
   return ILSX_OK;
 }
 

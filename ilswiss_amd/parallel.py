@@ -52,6 +52,15 @@ def comm_init(ctx, group=None):
     return world, rank
 
 
+def ensure_comm(ctx, group=None):
+    """comm_init unless the ctx already carries a communicator (trainers of one run share their ctx — and its communicator)."""
+    import ctypes as C
+    n = C.c_int()
+    ctx.lib.ilsx_comm_info(ctx.h, C.byref(n), None)
+    if n.value == 0:
+        comm_init(ctx, group)
+
+
 class SplitInfo:
     """What a run script needs to build its share of a split run: `world`, `rank`, and the `rl_alg_params` / trainer kwargs scaled to it."""
 
@@ -70,6 +79,17 @@ class SplitInfo:
                 out[k] = int(out[k]) // G
         out["split_world"] = G
         out["split_agree"] = self.agree
+        return out
+
+    def scale_rows(self, params, keys):
+        """`params` with the row counts under `keys` (batch sizes of a trainer: ppo_params.mini_batch_size, adv_irl_params.*_batch_size)
+        divided by G: every rank processes its share of each batch."""
+        G, out = self.world, dict(params)
+        for k in keys:
+            if k in out and out[k]:
+                if int(out[k]) % G:
+                    raise ValueError(f"{k}={out[k]} does not split over split_ranks={G}")
+                out[k] = int(out[k]) // G
         return out
 
     def agree(self, flag):

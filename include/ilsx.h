@@ -319,6 +319,10 @@ typedef struct {
                                      batch statistics; ilsx_disc_reward uses the running statistics (eval mode, adv_irl.py:268-274).  Any
                                      hid_dim; parameters in torch's order: per block W | b | gamma | beta, then the output layer.  A chain of
                                      simple launches (csrc/disc_bn.h), not the fused MFMA kernels of use_bn = 0 */
+  int32_t grad_world;             /* split-run mode (SURVEY section 8e "Disc: same"; 0 / 1 = off): this rank holds B / G rows per class (and B / G
+                                     interpolates); the cross-entropy and penalty means are over B * G rows, the gradient arena is all-reduced
+                                     (sum) on the ctx's communicator before Adam; the logged statistics are this rank's rows'.  use_bn = 1 is
+                                     refused (batch statistics would have to cross ranks) */
 } ilsx_disc_cfg;
 typedef struct { float ce_loss, grad_pen, accuracy; } ilsx_disc_stats;   /* "Disc CE Loss", "Grad Pen", "Disc Acc" */
 int ilsx_disc_create(ilsx_ctx* ctx, const ilsx_disc_cfg* cfg, ilsx_disc** out);
@@ -471,6 +475,12 @@ typedef struct {
                                    * (flat: fc.. | last_fc | last_fc_log_std) instead of the action_log_std parameter behind the mean net */
   int32_t hidden_sizes[3];        /* networks.py:23-60 takes any list of widths: logical width of hidden layer l (1..hidden; 0 = hidden), for the
                                    * policy and the value net alike (ppo_exp_script.py:79-96 builds both from one list) — ilsx_mlp_cfg::hidden_sizes */
+  int32_t grad_world;             /* split-run mode (SURVEY section 8e "PPO split: same, per-minibatch grads"; 0 / 1 = off): this rank holds N / G of the
+                                   * on-policy samples (its own envs' trajectories: GAE and the per-trajectory advantage standardisation stay local)
+                                   * and mini_batch_size / G rows of every minibatch; mean-loss gradients are scaled 1 / (rows * G); the value arena
+                                   * is all-reduced (sum) before its Adam (+ L2, applied once), the policy arena (with the action_log_std gradient)
+                                   * before clip_grad_norm_ + Adam, on the communicator of the ctx (ilsx_comm_init).  Every rank must hold the
+                                   * same number of samples and use the same minibatch size */
 } ilsx_ppo_cfg;
 int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo** out);
 int ilsx_ppo_destroy(ilsx_ppo* ppo);
@@ -493,6 +503,8 @@ int ilsx_ppo_train(ilsx_ppo* ppo, const float* obs, const float* act, const floa
                    int n_traj, const float* bootstrap_values, const int32_t* perms_host);
 /* debug: one library-drawn shuffle of [0,n) (keyed Feistel bijection; the NULL-perms path of ilsx_ppo_train) -> HOST */
 int ilsx_ppo_debug_perm(ilsx_ppo* ppo, int n, uint32_t key, int32_t* perm_host);
+/* test hook: the norm of the last minibatch's policy gradient as clip_grad_norm_ saw it (ppo.py:166; split run: of the all-reduced gradient) */
+int ilsx_ppo_debug_grad_norm(ilsx_ppo* ppo, float* out);
 /* get_actions (policies.py:392-417): act[n,a] = mean + exp(log_std)*eps (eps device [n,a] or NULL = Philox), or the
  * mean when deterministic; logp[n] nullable. */
 int ilsx_ppo_policy_act(ilsx_ppo* ppo, const float* obs, int n, int deterministic, const float* eps, float* act,

@@ -43,6 +43,9 @@ class DiscOracle:
         self.lr, self.b1 = disc_lr, disc_momentum
         self.use_gp, self.gp_w = use_grad_pen, grad_pen_weight
         self.opt = optim.AdamState(flat.size)
+        # split run (SURVEY section 8e "Disc: same"): one of grad_world ranks with B / G rows per class; the means are over B * G rows and the flat
+        # gradient is summed over the ranks (`allreduce`) before Adam.  grad_world = 1, allreduce = None: the reference's single process.
+        self.grad_world, self.allreduce = 1, None
 
     def _layers(self):
         return mlp.unpack(self.p, self.D, [self.H] * self.L, 1)
@@ -72,7 +75,7 @@ class DiscOracle:
         ce = bce_with_logits(logit, t)
         acc = np.mean(((logit > 0).astype(F32) == t).astype(F32))
         gate = ((raw >= -self.clamp) & (raw <= self.clamp)).astype(F32)
-        dlogit = (sigmoid(logit) - t) / F32(2 * B) * gate
+        dlogit = (sigmoid(logit) - t) / F32(2 * B * self.grad_world) * gate
         gW, gb = [None] * (L + 1), [None] * (L + 1)
         gW[L], gb[L] = dlogit.T @ hs[-1], dlogit.sum(0)
         d = (dlogit @ Ws[L]) * _dact(hs[L - 1], act)
@@ -98,7 +101,7 @@ class DiscOracle:
             gp = np.mean((n - F32(1)) ** 2, dtype=F32)
             gp_loss = F32(gp * F32(self.gp_w))
             with np.errstate(divide="ignore", invalid="ignore"):
-                gbar = np.where(n > 0, F32(self.gp_w) / F32(B) * F32(2) * (n - F32(1)) / n * g, F32(0)).astype(F32)
+                gbar = np.where(n > 0, F32(self.gp_w) / F32(B * self.grad_world) * F32(2) * (n - F32(1)) / n * g, F32(0)).astype(F32)
             xs, zb = gbar, [None] * L
             for l in range(L):                                       # up: the linearised forward pass
                 gW[l] = gW[l] + us[l].T @ xs
@@ -117,6 +120,8 @@ class DiscOracle:
         out["grad_pen_loss"] = gp_loss
         grad = mlp.pack([(gW[l].astype(F32), gb[l].astype(F32)) for l in range(L + 1)])
         out["grad"] = grad
+        if self.allreduce is not None:
+            grad = self.allreduce(np.ascontiguousarray(grad, F32))
         optim.adam_step(self.p, grad, self.opt, self.lr, self.b1)
         return out
 
@@ -140,7 +145,7 @@ class DiscOracle:
         ce = bce_with_logits(logit, t)
         acc = np.mean(((logit > 0).astype(F32) == t).astype(F32))
         gate = ((raw >= -self.clamp) & (raw <= self.clamp)).astype(F32)       # torch.clamp passes grad on [min,max]
-        dlogit = (sigmoid(logit) - t) / F32(2 * B) * gate
+        dlogit = (sigmoid(logit) - t) / F32(2 * B * self.grad_world) * gate
         d2 = (dlogit @ W3) * _dact(h2, act)
         d1 = (d2 @ W2) * _dact(h1, act)
         gW3, gb3 = dlogit.T @ h2, dlogit.sum(0)
@@ -163,7 +168,7 @@ class DiscOracle:
             gp_loss = F32(gp * F32(self.gp_w))
             # dGP/dg; a clamped interpolate has g == 0 and torch's norm backward is 0 there (masked_fill), not 0/0
             with np.errstate(divide="ignore", invalid="ignore"):
-                gbar = np.where(n > 0, F32(self.gp_w) / F32(B) * F32(2) * (n - F32(1)) / n * g, F32(0)).astype(F32)
+                gbar = np.where(n > 0, F32(self.gp_w) / F32(B * self.grad_world) * F32(2) * (n - F32(1)) / n * g, F32(0)).astype(F32)
             gW1 += (gt * u1).T @ gbar
             u1b = gt * (gbar @ W1.T)
             v1b, p1b = u1b * p1, u1b * v1
@@ -183,6 +188,8 @@ class DiscOracle:
         grad = mlp.pack([(gW1.astype(F32), gb1.astype(F32)), (gW2.astype(F32), gb2.astype(F32)),
                          (gW3.astype(F32), gb3.astype(F32))])
         out["grad"] = grad
+        if self.allreduce is not None:
+            grad = self.allreduce(np.ascontiguousarray(grad, F32))
         optim.adam_step(self.p, grad, self.opt, self.lr, self.b1)   # adv_irl.py:75-77 betas (disc_momentum, 0.999)
         return out
 

@@ -48,6 +48,10 @@ class PPOOracle:
         self.mb, self.epochs = mini_batch_size, update_epoch
         self.use_value_clip = use_value_clip
         self.opt_pi, self.opt_vf = optim.AdamState(pi_flat.size), optim.AdamState(vf_flat.size)
+        # split run (SURVEY section 8e "PPO split: same, per-minibatch grads"): this instance is one of grad_world ranks, holds mini_batch / G rows of
+        # every minibatch, scales its mean-loss gradients by 1 / (rows * G) and sums them over the ranks (`allreduce`: flat gradient -> summed
+        # flat gradient) before the L2 term, the norm clip and Adam.  grad_world = 1, allreduce = None: the reference's single process.
+        self.grad_world, self.allreduce = 1, None
 
     # ---- networks (tanh hidden)
     def v(self, obs):
@@ -93,12 +97,14 @@ class PPOOracle:
             mse = np.mean(np.maximum(l1, l2), dtype=F32)
             w = np.where(l1 > l2, F32(1), np.where(l1 == l2, F32(0.5), F32(0)))            # torch.max tie rule
             inside = ((dv >= -eps) & (dv <= eps)).astype(F32)                               # clamp passes grad on [-eps, eps]
-            dhead = F32(2) * (w * (v - R) + (F32(1) - w) * (vc - R) * inside) / F32(mbn)
+            dhead = F32(2) * (w * (v - R) + (F32(1) - w) * (vc - R) * inside) / F32(mbn * self.grad_world)
         else:
             mse = np.mean((v - R) ** 2, dtype=F32)
-            dhead = F32(2) * (v - R) / F32(mbn)
+            dhead = F32(2) * (v - R) / F32(mbn * self.grad_world)
         loss = mse + F32(self.l2) * np.sum(self.vf ** 2, dtype=F32)   # ppo.py:145-148
         g, _ = mlp.backward(self.vf, hs, [dhead.astype(F32)], self.o, self.hidden, 1, act=mlp.TANH, need_dx=False)
+        if self.allreduce is not None:
+            g = self.allreduce(np.ascontiguousarray(g, F32))
         g = (g + F32(2 * self.l2) * self.vf).astype(F32)
         optim.adam_step(self.vf, g, self.opt_vf, self.value_lr)
         return loss, g
@@ -112,7 +118,7 @@ class PPOOracle:
         loss = -np.mean(np.minimum(s1, s2), dtype=F32)                                              # ppo.py:158-164
         inside = (ratio >= F32(1 - self.clip_eps)) & (ratio <= F32(1 + self.clip_eps))             # clamp passes grad on [lo,hi]
         w = np.where(s1 < s2, F32(1), np.where(s1 == s2, F32(0.5), F32(0)))                        # torch.min tie rule
-        dratio = -(w * A + (F32(1) - w) * A * inside) / F32(mbn)
+        dratio = -(w * A + (F32(1) - w) * A * inside) / F32(mbn * self.grad_world)
         dlp = dratio * ratio
         var = np.exp(F32(2) * ls)
         dmu = dlp * (ac - mu) / var
@@ -125,6 +131,8 @@ class PPOOracle:
             n = self.pi.size - self.a
             gm, _ = mlp.backward(self.pi[:n], hs, [dmu.astype(F32)], self.o, self.hidden, self.a, act=mlp.TANH, need_dx=False)
             g = np.concatenate([gm, dls.astype(F32)])
+        if self.allreduce is not None:
+            g = self.allreduce(np.ascontiguousarray(g, F32))
         norm = np.sqrt(np.sum(g.astype(np.float64) ** 2))
         coef = 20.0 / (norm + 1e-6)                                                                 # clip_grad_norm_(…, 20)
         gc = (g * F32(coef)).astype(F32) if coef < 1.0 else g

@@ -95,7 +95,7 @@ def train(algorithm, variant):
 # (`torchrun --nproc-per-node G run_scripts/sac_alpha_exp_script.py -e v.yaml`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env) or, when
 # there is no RANK in the env, from main() itself: it re-executes the script G times, rank r on GPU g + r, rendezvous on 127.0.0.1.
 def split_ranks_of(variant):
-    g = int((variant.get("rl_alg_params") or {}).get("split_ranks", 1) or 1)
+    g = int((variant.get("rl_alg_params") or variant.get("adv_irl_params") or {}).get("split_ranks", 1) or 1)   # (adversarial IRL keeps its loop keys in adv_irl_params)
     return g if (g > 1 or os.environ.get("ILSX_SPLIT_FORCE")) else 0     # ILSX_SPLIT_FORCE: the split path on a one-rank communicator (tests)
 
 

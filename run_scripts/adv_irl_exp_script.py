@@ -11,7 +11,7 @@ import random
 
 import numpy as np
 import yaml
-from _common import ia, main, make_envs, start, train  # noqa: F401
+from _common import ia, main, make_envs, split_info, start, train  # noqa: F401
 
 from ilswiss_amd.adv_irl import AdvIRLTrainer, MLPDisc
 from ilswiss_amd.algorithm import DeviceRLAlgorithm
@@ -60,9 +60,19 @@ def experiment(variant, gpu=0, log_dir=None):
     training_env, eval_env, env = make_envs(variant, ctx, env_wrapper=wrapper, wrapper_kwargs=wrapper_kwargs)
     obs_dim, action_dim = training_env.obs_dim, training_env.act_dim
     p = dict(variant["adv_irl_params"])
+    split = split_info()          # adv_irl_params.split_ranks: G — this process is one rank of ONE run split over G GPUs (_common.py): env_num / G envs
+    G = split.world if split else 1   # (make_envs), a policy ring of replay_buffer_size / G rows, every batch and step count of the schedule / G
+    if split is not None:
+        p = split.scale_rows(split.scale(p), ("disc_optim_batch_size", "policy_optim_batch_size", "policy_optim_batch_size_from_expert"))
+        p.pop("batch_size", None)
+        from ilswiss_amd.parallel import ensure_comm
+        ensure_comm(ctx)
+    p.pop("split_ranks", None)
     if p.get("wrap_absorbing"):
         raise NotImplementedError("wrap_absorbing is off in the hot-path config (gail_walker.yaml:49)")
-    expert_rb = EnvReplayBuffer(p["replay_buffer_size"], env, random_seed=int(np.random.randint(10000)), ctx=ctx)
+    # every rank of a split run holds ALL demonstrations and draws its share of each expert batch: its draws are keyed apart from the other ranks'
+    expert_rb = EnvReplayBuffer(variant["adv_irl_params"]["replay_buffer_size"], env,
+                                random_seed=int(np.random.randint(10000)) + (7919 * split.rank if split else 0), ctx=ctx)
     for tj in traj_list:                                           # adv_irl_exp_script.py:135-138
         expert_rb.add_path(tj, absorbing=False, env=env)
     hid = variant["policy_num_hidden_layers"] * [variant["policy_net_size"]]
@@ -73,16 +83,18 @@ def experiment(variant, gpu=0, log_dir=None):
     input_dim = obs_dim + (obs_dim if p.get("state_only") else action_dim)   # adv_irl_exp_script.py:164-166
     disc = MLPDisc(input_dim, num_layer_blocks=variant["disc_num_blocks"], hid_dim=variant["disc_hid_dim"],
                    hid_act=variant["disc_hid_act"], use_bn=variant["disc_use_bn"], clamp_magnitude=variant["disc_clamp_magnitude"], ctx=ctx)
-    sac = ia.SoftActorCritic(policy=policy, qf1=qf1, qf2=qf2, env=env, max_batch=Bp, **variant["sac_params"])
+    sac = ia.SoftActorCritic(policy=policy, qf1=qf1, qf2=qf2, env=env, max_batch=Bp, grad_world=G, **variant["sac_params"])
     irl_keys = ("state_only", "disc_optim_batch_size", "policy_optim_batch_size", "policy_optim_batch_size_from_expert",
                 "num_update_loops_per_train_call", "num_disc_updates_per_loop_iter", "num_policy_updates_per_loop_iter", "disc_lr",
                 "disc_momentum", "use_grad_pen", "grad_pen_weight", "rew_clip_min", "rew_clip_max")
-    trainer = AdvIRLTrainer(p["mode"], disc, sac, expert_rb, **{k: p[k] for k in irl_keys if k in p})   # adv_irl.py:34-54 defaults otherwise
+    trainer = AdvIRLTrainer(p["mode"], disc, sac, expert_rb, grad_world=G, **{k: p[k] for k in irl_keys if k in p})   # adv_irl.py:34-54 defaults otherwise
     loop_keys = ("num_epochs", "num_steps_per_epoch", "num_steps_between_train_calls", "max_path_length", "min_steps_before_training",
                  "eval_deterministic", "num_steps_per_eval", "replay_buffer_size", "no_terminal", "save_best", "freq_saving",
                  "save_epoch", "save_best_starting_from_epoch", "save_replay_buffer", "best_key", "eval_no_terminal", "wrap_absorbing",
                  "render", "freq_log_visuals")   # every BaseAlgorithm key of adv_irl_params (base_algorithm.py:21-54): honoured or refused, never dropped
     alg = {k: p[k] for k in loop_keys if k in p}
+    if split is not None:
+        alg.update(split_world=p["split_world"], split_agree=p["split_agree"])
     algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env, exploration_policy=policy,
                                   log_dir=log_dir, num_train_steps_per_train_call=p.get("num_update_loops_per_train_call", 1),
                                   batch_size=Bp, **alg)

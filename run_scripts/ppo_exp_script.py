@@ -3,7 +3,7 @@
 variant keys env_specs / net_size / num_hidden_layers / ppo_params / rl_alg_params / seed.  Observations are
 normalised by the training env's running statistics, which the eval env shares (:60-75); policy = Gaussian with a
 state-independent log-std, value net and policy use tanh units (:82-96)."""
-from _common import ia, main, make_envs, start, train  # noqa: F401
+from _common import ia, main, make_envs, split_info, start, train  # noqa: F401
 
 from ilswiss_amd.algorithm import DeviceRLAlgorithm
 from ilswiss_amd.ppo import PPO, ReparamMultivariateGaussianPolicy
@@ -18,8 +18,17 @@ def experiment(variant, gpu=0, log_dir=None):
     policy = ReparamMultivariateGaussianPolicy(hidden_sizes=hid, obs_dim=obs_dim, action_dim=action_dim, conditioned_std=False,
                                                hidden_activation="tanh", ctx=ctx)
     alg = dict(variant["rl_alg_params"])
+    ppo_params = dict(variant["ppo_params"])
+    split = split_info()          # rl_alg_params.split_ranks: G — this process is one rank of ONE run split over G GPUs (_common.py): env_num / G envs
+    if split is not None:         # (make_envs), the step counts of the schedule and every minibatch divided by G, both gradient arenas all-reduced
+        alg = split.scale(alg)
+        ppo_params = split.scale_rows(ppo_params, ("mini_batch_size",))
+        from ilswiss_amd.parallel import ensure_comm
+        ensure_comm(ctx)
+    else:
+        alg.pop("split_ranks", None)
     horizon = max(1, alg["num_steps_between_train_calls"] // len(training_env))
-    trainer = PPO(policy=policy, vf=vf, max_samples=horizon * len(training_env), **variant["ppo_params"])
+    trainer = PPO(policy=policy, vf=vf, max_samples=horizon * len(training_env), grad_world=split.world if split else 1, **ppo_params)
     algorithm = DeviceRLAlgorithm(trainer=trainer, env=env, training_env=training_env, eval_env=eval_env,
                                   exploration_policy=policy, log_dir=log_dir, **alg)
     train(algorithm, variant)

@@ -220,3 +220,141 @@ def test_split_info_scales_the_loop_and_ranks_agree_on_training():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, False, False), (1, True, False, False)]
+
+
+# ---------------------------------------------------------------------------------------------- PPO minibatch gradients and the discriminator, split
+# "PPO split: same, per-minibatch grads.  Disc: same": every rank holds mini_batch / G (B / G) rows, scales its mean-loss gradients by
+# 1 / (rows * G), the flat gradient is summed over the ranks before the L2 term / norm clip / Adam.  The engine here is the numpy oracle
+# (grad_world + allreduce hook); on the GPU box the same orchestration runs inside libilsx (ilsx_ppo_cfg.grad_world / ilsx_disc_cfg.grad_world,
+# tests/test_ppo_oracle.py and tests/test_disc.py check the device path on a one-rank communicator).
+PPO_HID, PPO_MB = [32, 32], 48
+
+
+def _gloo_sum(flat):
+    t = torch.from_numpy(flat)      # shares memory
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def _ppo_oracle(world):
+    from oracle.ppo import PPOOracle
+    rng = np.random.default_rng(11)
+    pi = np.concatenate([omlp.init_mlp(rng, O, PPO_HID, A, init_w=1e-2), np.zeros(A, np.float32)])   # mean net | action_log_std
+    o = PPOOracle(O, A, PPO_HID, pi, omlp.init_mlp(rng, O, PPO_HID, 1), mini_batch_size=PPO_MB, update_epoch=1, value_l2_reg=1e-3,
+                  use_value_clip=True)
+    o.grad_world = world
+    return o
+
+
+def _ppo_minibatches(steps):
+    rng = np.random.default_rng(21)
+    n = PPO_MB
+    for _ in range(steps):
+        yield dict(ob=rng.normal(0, 1, (n, O)).astype(np.float32), ac=rng.normal(0, 1, (n, A)).astype(np.float32),
+                   R=rng.normal(0, 1, (n, 1)).astype(np.float32), V=rng.normal(0, 1, (n, 1)).astype(np.float32),
+                   A=rng.normal(0, 1, (n, 1)).astype(np.float32), lp=rng.normal(-3, 0.3, (n, 1)).astype(np.float32))
+
+
+def _ppo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = _ppo_oracle(world)
+    o.allreduce = _gloo_sum
+    norms = []
+    for mb in _ppo_minibatches(4):
+        sl = slice(rank * PPO_MB // world, (rank + 1) * PPO_MB // world)
+        o.value_step(mb["ob"][sl], mb["R"][sl], mb["V"][sl])
+        norms.append(o.policy_step(mb["ob"][sl], mb["ac"][sl], mb["A"][sl], mb["lp"][sl])[2])
+    q.put((rank, o.pi.copy(), o.vf.copy(), norms))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(worker, world=2):
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_ppo_minibatch_split_equals_single_process():
+    """value step (clipped value loss + L2, applied once on the summed gradient) and policy step (clipped surrogate, the action_log_std
+    gradient in the arena, clip_grad_norm_ on the SUMMED gradient) of four minibatches, each rank on its half of the rows"""
+    res = _spawn(_ppo_worker)
+    single = _ppo_oracle(1)
+    norms = []
+    for mb in _ppo_minibatches(4):
+        single.value_step(mb["ob"], mb["R"], mb["V"])
+        norms.append(single.policy_step(mb["ob"], mb["ac"], mb["A"], mb["lp"])[2])
+    for r in res:
+        np.testing.assert_array_equal(r[1], res[0][1])            # replicas took identical optimiser steps
+        np.testing.assert_array_equal(r[2], res[0][2])
+        np.testing.assert_allclose(r[1], single.pi, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r[2], single.vf, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r[3], norms, rtol=1e-5)        # the norm that is clipped is the whole minibatch's, not the shard's
+
+
+DISC_D, DISC_H, DISC_B = O + A, 32, 24
+
+
+def _disc_oracle(world, blocks):
+    from oracle.disc import DiscOracle
+    rng = np.random.default_rng(31)
+    flat = omlp.init_mlp(rng, DISC_D, [DISC_H] * blocks, 1)
+    d = DiscOracle(DISC_D, DISC_H, flat, use_grad_pen=True, grad_pen_weight=8.0, num_layer_blocks=blocks)
+    d.grad_world = world
+    return d
+
+
+def _disc_batches(steps):
+    rng = np.random.default_rng(41)
+    for _ in range(steps):
+        yield (rng.normal(0.3, 1, (DISC_B, DISC_D)).astype(np.float32), rng.normal(-0.3, 1, (DISC_B, DISC_D)).astype(np.float32),
+               rng.random((DISC_B, 1)).astype(np.float32))
+
+
+def _disc_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = [rank]
+    for blocks in (2, 3):
+        d = _disc_oracle(world, blocks)
+        d.allreduce = _gloo_sum
+        for xe, xp, eps in _disc_batches(3):
+            sl = slice(rank * DISC_B // world, (rank + 1) * DISC_B // world)
+            (d.train_step if blocks == 2 else d.train_step_blocks)(xe[sl], xp[sl], eps[sl])
+        out.append(d.p.copy())
+    q.put(tuple(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_discriminator_split_equals_single_process():
+    """BCE over 2B rows + WGAN-GP over B interpolates, each rank on B / 2 rows per class (and its own B / 2 interpolates): the two-block
+    closed form and the any-depth chain"""
+    res = _spawn(_disc_worker)
+    for i, blocks in enumerate((2, 3)):
+        single = _disc_oracle(1, blocks)
+        for xe, xp, eps in _disc_batches(3):
+            (single.train_step if blocks == 2 else single.train_step_blocks)(xe, xp, eps)
+        for r in res:
+            np.testing.assert_array_equal(r[1 + i], res[0][1 + i])
+            np.testing.assert_allclose(r[1 + i], single.p, rtol=0, atol=2e-6)
+
+
+def test_split_info_scales_trainer_rows():
+    from ilswiss_amd.parallel import SplitInfo
+    sp = SplitInfo(4, 2, None)
+    assert sp.scale_rows(dict(mini_batch_size=32768, update_epoch=10), ("mini_batch_size",)) == dict(mini_batch_size=8192, update_epoch=10)
+    out = sp.scale_rows(dict(disc_optim_batch_size=256, policy_optim_batch_size=256, policy_optim_batch_size_from_expert=0, mode="gail2"),
+                        ("disc_optim_batch_size", "policy_optim_batch_size", "policy_optim_batch_size_from_expert"))
+    assert out == dict(disc_optim_batch_size=64, policy_optim_batch_size=64, policy_optim_batch_size_from_expert=0, mode="gail2")
+    with pytest.raises(ValueError):
+        sp.scale_rows(dict(mini_batch_size=30), ("mini_batch_size",))
