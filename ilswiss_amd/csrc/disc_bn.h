@@ -57,8 +57,8 @@ DBN_HD float dbn_d2act(float h, int act) { return act == DBN_RELU ? 0.0f : -2.0f
 //   forward / uabar = xbar W^T   out[r][j] = sum_k x[r][k] W[j][k] + b[j]     A = x (sai ldx, sak 1)   B = W (sbk 1, sbj K)
 //   dx                           out[r][k] = sum_j d[r][j] W[j][k]            A = d (sai H, sak 1)     B = W (sbk K, sbj 1)
 //   weight gradient              G[j][k] (+)= sum_r a[r][j] x[r][k]           A = a (sai 1, sak H)     B = x (sbk ldx, sbj 1)
-// The launcher's `gemm` phase runs it: LDS-tiled on the device (k_dbn_gemm, ilsx_disc.hip), a serial loop of dbn_gemm_elem on the host; the
-// chain of one element is the same in both (k ascending, one accumulator), so the two give the same bits.
+// The launcher's `gemm` phase runs it: 16 x 16 tiles on the exact-fp32 matrix pipe on the device (k_dbn_gemm / dbn_gemm_tile, ilsx_disc.hip), a serial
+// loop of dbn_gemm_elem on the host; the chain of one element is the same in both (four ranges, k ascending), so the two give the same bits.
 struct DbnGemm {
   const float* A; int sai, sak;
   const float* B; int sbk, sbj;
@@ -77,7 +77,8 @@ DBN_HOST DbnGemm dbn_g_outer(const float* a, const float* x, int ldx, float* G, 
 }
 // the contraction runs in FOUR consecutive ranges of dbn_kq(Kd) terms (one per wave of the device tile), each an fmaf chain from 0.0f in
 // ascending k; the four partial sums are added in range order: c = ((p0 + p1) + p2) + p3 (+ bias).  dbn_gemm_elem states that chain for the
-// host emulation, k_dbn_gemm (ilsx_disc.hip) runs it on a 16 x 16 tile: the two give the same bits.
+// host emulation, k_dbn_gemm (ilsx_disc.hip) runs it on a 16 x 16 tile — one v_mfma_f32_16x16x4_f32 per four terms, itself an fmaf chain over its
+// k slots in ascending order: the two give the same bits.
 DBN_HDH int dbn_kq(int Kd) { return (((Kd + 3) / 4) + 31) & ~31; }
 DBN_HD void dbn_gemm_elem(const DbnGemm& g, int i, int j) {
   const int kq = dbn_kq(g.Kd);

@@ -350,60 +350,53 @@ template <class F> __global__ __launch_bounds__(64) void k_dbn_col(F f) { f((int
 // 23 us per launch (16 workgroups, 16 serial load -> LDS -> multiply rounds), one thread per element with a strided walk 50-100 us.
 // Two independent products can share a launch.
 struct DbnGemm2 { DbnGemm g[3]; int start[4], tn[3]; };   // start[i]: first workgroup of product i (start[3] = grid size)
-__global__ __launch_bounds__(256) void k_dbn_gemm(const DbnGemm2 G2) {
-  __shared__ __attribute__((aligned(16))) float As[4][32][18], Bs[4][32][18];   // per wave: [k][i], [k][j] (row stride 18: 8-byte aligned pairs)
-  __shared__ float red[4][256];
-  const int which = (int)blockIdx.x >= G2.start[2] ? 2 : (int)blockIdx.x >= G2.start[1] ? 1 : 0;
-  const DbnGemm& g = G2.g[which];
-  const int tile = (int)blockIdx.x - G2.start[which], tn = G2.tn[which];
+struct DbnGemmLds { float red[4][256]; };   // the four waves' partial tiles
+// One 16 x 16 output tile of one product, by the 256 threads of a workgroup: wave w contracts the w-th of the four consecutive ranges of
+// dbn_kq(Kd) terms on the exact-fp32 matrix pipe — v_mfma_f32_16x16x4_f32 is an fmaf chain over its four k slots in ascending order
+// (tools/ubench/mfma_32x32.hip checks it against a host fmaf chain), so a wave's partial is the chain dbn_gemm_elem states for its range, and
+// the four partials are added in range order: the same bits as the host emulation (padding terms are 0 * 0 products: + 0.0f).  Operands go
+// from memory straight into the fragment layout (lane = (row | column) + 16 x k slot): no LDS staging, no barrier inside the contraction —
+// the round-5 form (every lane 2 x 2 outputs, both operands staged through 18 KB of LDS, two barriers per 32 terms) ran the single-XCD
+// step's product phases twice as long.  Loads are issued DBN_GQ MFMAs ahead.
+#define DBN_GQ 8
+__device__ __forceinline__ void dbn_gemm_tile(const DbnGemm& g, int tile, int tn, DbnGemmLds& S) {
   const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16, t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int li = lane >> 3, lj = lane & 7;
+  const int lr = lane & 15, ks = lane >> 4;   // row of the A fragment / column of the B fragment ; k slot
   const int kq = dbn_kq(g.Kd), kbeg = wave * kq, kend = kbeg + kq < g.Kd ? kbeg + kq : g.Kd;
-  float c00 = 0.0f, c01 = 0.0f, c10 = 0.0f, c11 = 0.0f;
-  for (int k0 = kbeg; k0 < kbeg + kq; k0 += 32) {   // the same trip count in every wave (workgroup barriers inside)
-    float va[8], vb[8];
+  const bool i_ok = i0 + lr < g.M, j_ok = j0 + lr < g.N;
+  const float* pa = g.A + (size_t)(i0 + lr) * g.sai;
+  const float* pb = g.B + (size_t)(j0 + lr) * g.sbj;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kbeg; k0 < kend; k0 += 4 * DBN_GQ) {   // wave-uniform bounds
+    float va[DBN_GQ], vb[DBN_GQ];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {   // all 16 loads of the chunk in flight before the first LDS store
-      const int e = lane + 64 * u;
-      int ii, kk;
-      if (g.sak == 1) { kk = e & 31; ii = e >> 5; } else { ii = e & 15; kk = e >> 4; }
-      const int gi = i0 + ii, gk = k0 + kk;
-      va[u] = (gi < g.M && gk < kend) ? g.A[(size_t)gi * g.sai + (size_t)gk * g.sak] : 0.0f;
-      int jj, kb;
-      if (g.sbj == 1) { jj = e & 15; kb = e >> 4; } else { kb = e & 31; jj = e >> 5; }
-      const int gj = j0 + jj, gkb = k0 + kb;
-      vb[u] = (gj < g.N && gkb < kend) ? g.B[(size_t)gkb * g.sbk + (size_t)gj * g.sbj] : 0.0f;
+    for (int q = 0; q < DBN_GQ; ++q) {
+      const int k = k0 + 4 * q + ks;
+      va[q] = (i_ok && k < kend) ? pa[(size_t)k * g.sak] : 0.0f;
+      vb[q] = (j_ok && k < kend) ? pb[(size_t)k * g.sbk] : 0.0f;
     }
-    __syncthreads();   // the previous chunk has been consumed
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = lane + 64 * u;
-      int ii, kk;
-      if (g.sak == 1) { kk = e & 31; ii = e >> 5; } else { ii = e & 15; kk = e >> 4; }
-      As[wave][kk][ii] = va[u];
-      int jj, kb;
-      if (g.sbj == 1) { jj = e & 15; kb = e >> 4; } else { kb = e & 31; jj = e >> 5; }
-      Bs[wave][kb][jj] = vb[u];
-    }
-    __syncthreads();
-    const int kn = kend - k0 < 32 ? (kend - k0 > 0 ? kend - k0 : 0) : 32;   // exactly the range's terms: the chain is stated without padding terms
-    for (int kk = 0; kk < kn; ++kk) {
-      const float2 a = *reinterpret_cast<const float2*>(&As[wave][kk][2 * li]);
-      const float2 b = *reinterpret_cast<const float2*>(&Bs[wave][kk][2 * lj]);
-      c00 = fmaf(a.x, b.x, c00); c01 = fmaf(a.x, b.y, c01); c10 = fmaf(a.y, b.x, c10); c11 = fmaf(a.y, b.y, c11);
-    }
+    for (int q = 0; q < DBN_GQ; ++q)
+      if (k0 + 4 * q < kend) acc = MFMA16(va[q], vb[q], acc);   // wave-uniform
   }
-  red[wave][(2 * li) * 16 + 2 * lj] = c00; red[wave][(2 * li) * 16 + 2 * lj + 1] = c01;
-  red[wave][(2 * li + 1) * 16 + 2 * lj] = c10; red[wave][(2 * li + 1) * 16 + 2 * lj + 1] = c11;
+  __syncthreads();   // (the previous tile's reduction has been read)
+#pragma unroll
+  for (int v = 0; v < 4; ++v) S.red[wave][(4 * ks + v) * 16 + lr] = acc[v];   // accumulator layout: lane = column + 16 x (row / 4), register = row % 4
   __syncthreads();
   const int gi = i0 + (t >> 4), gj = j0 + (t & 15);
   if (gi < g.M && gj < g.N) {
-    float v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    float v = ((S.red[0][t] + S.red[1][t]) + S.red[2][t]) + S.red[3][t];
     if (g.bias) v = v + g.bias[gj];
     float* c = g.C + (size_t)gi * g.ldc + gj;
     *c = g.acc ? *c + v : v;
   }
 }
+__global__ __launch_bounds__(256) void k_dbn_gemm(const DbnGemm2 G2) {
+  __shared__ __attribute__((aligned(16))) DbnGemmLds S;
+  const int which = (int)blockIdx.x >= G2.start[2] ? 2 : (int)blockIdx.x >= G2.start[1] ? 1 : 0;
+  dbn_gemm_tile(G2.g[which], (int)blockIdx.x - G2.start[which], G2.tn[which], S);
+}
+
 struct DbnLaunch {
   hipStream_t st;
   template <class F> void par(int n, F f) { if (n > 0) hipLaunchKernelGGL(k_dbn_par<F>, dim3((n + 255) / 256), dim3(256), 0, st, n, f); }
@@ -905,6 +898,8 @@ static int disc_train_step_from_rings(ilsx_disc* d, ilsx_replay* expert_rb, ilsx
 }
 
 // use_bn: d->X holds [expert ; policy ; interpolates] (k_disc_prep / k_disc_prep_rings), row stride D
+// (Round 6 ran the whole step as ONE launch on one XCD — the phases called inside a kernel, an arrival-counter barrier between them: correct
+//  and 3-4x slower than the launches, profiles/r06_discbn_one_launch.txt; removed.)
 static int discbn_step(ilsx_disc* d, int B, ilsx_disc_stats* stats) {
   DiscBn* b = d->bn;
   if (3 * B > b->rows) ILSX_FAIL(ILSX_ERR_ARG, "batch %d exceeds the workspace", B);
