@@ -7,11 +7,10 @@
 // Device pipeline for one train_step over N on-policy samples (T trajectories):
 //   forward(vf) over all N rows -> k_ppo_gae (one lane per trajectory: reverse scan, mean/std, normalise)
 //   forward(pi) over all N rows with the Gaussian log-prob head -> fixed log-probs
-//   per minibatch (rows gathered through an index list, nothing is copied):
-//     value : forward(gather) ; backward (LOSS_MSE head) ; dW with Adam + L2 fused in the epilogue
-//     policy: forward(gather, log-prob head) ; backward (LOSS_PPO_POLICY head, also emits d/d log_std rows) ;
-//             dW ; k_ppo_norm (sum of squares of the whole policy gradient, log_std column sums) ;
-//             k_ppo_clip_adam (clip_grad_norm_(20) scale + Adam over the policy arena)
+//   per minibatch (rows gathered through an index list, nothing is copied) — five launches (round 6; ten before):
+//     forward {value ; policy with the log-prob head} ; backward {LOSS_MSE head ; LOSS_PPO_POLICY head, which also emits d/d log_std rows} ;
+//     weight gradients of both nets (one table) ; k_ppo_norm (sum of squares of the whole policy gradient, log_std column sums) ;
+//     k_ppo_update (clip_grad_norm_(20) scale + Adam over the policy arena, Adam + L2 over the value arena, step counters)
 // HBM-bound pieces: k_ppo_gae streams 5 fp32 arrays once (20 B per sample).
 #include <cmath>
 
@@ -155,17 +154,49 @@ __global__ __launch_bounds__(256) void k_ppo_perm(int* __restrict__ perm, int n,
   perm[i] = (int)x;
 }
 
-struct PpoClipAdamArgs {
+// The optimiser launch of a minibatch: clip_grad_norm_(20) + Adam over the policy arena (ppo.py:166-170), Adam + the L2 term over the value arena
+// (ppo.py:145-153: the two updates of a minibatch share nothing — the policy loss reads the advantages, not the value net — so they run side by side),
+// and the step counters.  The bias-correction scalars are computed here, per block, from the host's step counts (double pow, as k_ppo_refresh did):
+// no scalar launch between the minibatches.  Value update: adam_apply's expressions (kernels.h) in its order, element-wise (both packings of a
+// hidden -> hidden matrix hold the same gradient and parameter, hence stay equal).
+struct PpoUpdateArgs {
   float* P; float* G; float* M; float* V; int n;   // whole policy arena incl. log_std (and both W1 packings)
   int n_mean, a;                                    // log_std lives at [n_mean, n_mean + a)
   const float* partial; const float* partial_ls; int nparts;
   float max_norm, b1, b2, eps;
   PpoScalars* sc;
   int ls_from_G;   // split run: the log_std gradient sits in G already (k_ppo_ls_fold, summed over the ranks); single run: built here from the column sums
+  float* Pv; const float* Gv; float* Mv; float* Vv; int nv;   // value arena
+  float l2x2, v_lr, p_lr;
+  int t_v, t_p;    // optimiser steps taken BEFORE this one (the host's counts; sc->t_v / t_p are written for the snapshot getters)
+  int nblk_p;      // blocks [0, nblk_p): policy ; the rest: value
 };
-__global__ __launch_bounds__(256) void k_ppo_clip_adam(const PpoClipAdamArgs A) {
-  __shared__ float s_coef;
+__global__ __launch_bounds__(256) void k_ppo_update(const PpoUpdateArgs A) {
+  __shared__ float s_coef, s_step, s_bc2s;
   __shared__ float s_gls[PPO_MAX_A];
+  const bool policy = (int)blockIdx.x < A.nblk_p;
+  if (threadIdx.x == 0) {
+    const double b1 = 0.9, b2 = 0.999;
+    const int t = policy ? A.t_p : A.t_v;
+    s_step = (float)((double)(policy ? A.p_lr : A.v_lr) / (1.0 - pow(b1, (double)(t + 1))));
+    s_bc2s = (float)sqrt(1.0 - pow(b2, (double)(t + 1)));
+  }
+  if (!policy) {
+    __syncthreads();
+    const float step = s_step, bc2s = s_bc2s;
+    const int nb = (int)gridDim.x - A.nblk_p, b0 = (int)blockIdx.x - A.nblk_p;
+    for (int i = b0 * 256 + threadIdx.x; i < A.nv; i += nb * 256) {
+      const float p0 = A.Pv[i];
+      float g = A.Gv[i];
+      g = g + A.l2x2 * p0;
+      const float m = A.Mv[i] * A.b1 + (1.0f - A.b1) * g;
+      const float v = A.Vv[i] * A.b2 + (1.0f - A.b2) * g * g;
+      A.Mv[i] = m; A.Vv[i] = v;
+      A.Pv[i] = p0 - step * (m / (sqrtf(v) / bc2s + A.eps));
+    }
+    if (b0 == 0 && threadIdx.x == 0) { A.sc->t_v = A.t_v + 1; A.sc->v_step = step; A.sc->v_bc2s = bc2s; }
+    return;
+  }
   if (threadIdx.x < A.a) {   // every block rebuilds the log_std gradient from the per-block column sums (fixed order)
     float c = 0.0f;
     if (A.ls_from_G) c = A.G[A.n_mean + threadIdx.x];
@@ -181,11 +212,11 @@ __global__ __launch_bounds__(256) void k_ppo_clip_adam(const PpoClipAdamArgs A) 
     const double norm = sqrt(tot);
     const double coef = (double)A.max_norm / (norm + 1e-6);   // torch.nn.utils.clip_grad_norm_
     s_coef = coef < 1.0 ? (float)coef : 1.0f;
-    if (blockIdx.x == 0) A.sc->grad_norm = (float)norm;
+    if (blockIdx.x == 0) { A.sc->grad_norm = (float)norm; A.sc->t_p = A.t_p + 1; A.sc->p_step = s_step; A.sc->p_bc2s = s_bc2s; }
   }
   __syncthreads();
-  const float coef = s_coef, step = A.sc->p_step, bc2s = A.sc->p_bc2s;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < A.n; i += gridDim.x * 256) {
+  const float coef = s_coef, step = s_step, bc2s = s_bc2s;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < A.n; i += A.nblk_p * 256) {
     const float graw = (i >= A.n_mean && i < A.n_mean + A.a) ? s_gls[i - A.n_mean] : (i >= A.n_mean ? 0.0f : A.G[i]);
     const float g = graw * coef;
     const float m = A.M[i] * A.b1 + (1.0f - A.b1) * g;
@@ -196,10 +227,8 @@ __global__ __launch_bounds__(256) void k_ppo_clip_adam(const PpoClipAdamArgs A) 
 }
 
 // Split run (cfg.grad_world = G): the pieces the fused single-rank minibatch folds into other launches, as launches of their own
-// around the two all-reduces.  k_ppo_ls_fold: this rank's log_std gradient (the column sums k_ppo_norm left per block, added in k_ppo_clip_adam's
-// order) into its slot of the policy arena, so that it rides in the arena's all-reduce.  k_ppo_adam_l2: the value net's Adam with the L2 term
-// (ppo.py:147-148) on the SUMMED gradient — adam_apply's expressions (kernels.h) in its order, elementwise over the arena (both packings of a
-// hidden -> hidden matrix hold the same gradient and the same parameter, hence stay equal).
+// around the all-reduce.  k_ppo_ls_fold: this rank's log_std gradient (the column sums k_ppo_norm left per block, added in k_ppo_update's order) into
+// its slot of the policy arena, so that it rides in the arena's all-reduce.
 __global__ void k_ppo_ls_fold(float* G, int n_mean, int a, const float* partial_ls, int nparts) {
   const int j = threadIdx.x;
   if (j >= a) return;
@@ -207,20 +236,6 @@ __global__ void k_ppo_ls_fold(float* G, int n_mean, int a, const float* partial_
   for (int i = 0; i < nparts; ++i) c += partial_ls[i * a + j];
   G[n_mean + j] = c;
 }
-struct PpoAdamL2Args { float* P; const float* G; float* M; float* V; int n; float b1, b2, eps, l2x2; const float* step; const float* bc2s; };
-__global__ __launch_bounds__(256) void k_ppo_adam_l2(const PpoAdamL2Args A) {
-  const float step = *A.step, bc2s = *A.bc2s;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < A.n; i += gridDim.x * 256) {
-    const float p0 = A.P[i];
-    float g = A.G[i];
-    g = g + A.l2x2 * p0;
-    const float m = A.M[i] * A.b1 + (1.0f - A.b1) * g;
-    const float v = A.V[i] * A.b2 + (1.0f - A.b2) * g * g;
-    A.M[i] = m; A.V[i] = v;
-    A.P[i] = p0 - step * (m / (sqrtf(v) / bc2s + A.eps));
-  }
-}
-
 // Adam bias-correction scalars of the NEXT value / policy step (which: 0 = a value step just ran, 1 = policy, -1 = init)
 __global__ void k_ppo_refresh(PpoScalars* sc, int which, float v_lr, float p_lr) {
   if (which == 0) sc->t_v += 1;
@@ -248,7 +263,9 @@ struct ilsx_ppo {
   float *xp = nullptr, *hp[ILSX_MAX_HID], *dp[ILSX_MAX_HID], *dhp = nullptr, *mu = nullptr, *lp = nullptr, *aux = nullptr;
   float* partial = nullptr;
   int *offs = nullptr, *perm = nullptr;
-  DwArgs jobs_v, jobs_p;
+  DwArgs jobs_vp;              // both nets' weight-gradient jobs: ONE launch per minibatch (the gradient arenas are one allocation: Gv | Gp)
+  size_t nv_pad = 0;           // floats from Gv to Gp
+  int t_v = 0, t_p = 0;        // optimiser steps taken (host mirror of PpoScalars::t_v / t_p: k_ppo_update gets them as arguments)
   unsigned long long shuffles = 0;   // library-drawn minibatch permutations so far (key of the next one)
   bool cond() const { return cfg.conditioned_std != 0; }   // log-std from the policy net's second head (policies.py:368-374)
   int n_ls() const { return cond() ? 0 : a; }             // trailing action_log_std parameters of the policy arena
@@ -281,12 +298,13 @@ extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo*
   p->nv = p->Lv.n_int;
   const size_t N = (size_t)cfg->max_samples, mb = (size_t)cfg->mini_batch_size, H = (size_t)cfg->hidden;
   auto A = [&](float** q, size_t cnt) { return ctx_alloc(ctx, cnt * sizeof(float), (void**)q, true); };
+  p->nv_pad = (p->nv + 63) / 64 * 64;
   rc = A(&p->Pp, p->np);
-  if (rc == ILSX_OK) rc = A(&p->Gp, p->np);
+  if (rc == ILSX_OK) rc = A(&p->Gv, p->nv_pad + p->np);   // Gv | Gp in one allocation: one weight-gradient table, one all-reduce in a split run
+  if (rc == ILSX_OK) p->Gp = p->Gv + p->nv_pad;
   if (rc == ILSX_OK) rc = A(&p->Mp, p->np);
   if (rc == ILSX_OK) rc = A(&p->Vp, p->np);
   if (rc == ILSX_OK) rc = A(&p->Pv, p->nv);
-  if (rc == ILSX_OK) rc = A(&p->Gv, p->nv);
   if (rc == ILSX_OK) rc = A(&p->Mv, p->nv);
   if (rc == ILSX_OK) rc = A(&p->Vv, p->nv);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, sizeof(PpoScalars), (void**)&p->sc);
@@ -312,10 +330,9 @@ extern "C" int ilsx_ppo_create(ilsx_ctx* ctx, const ilsx_ppo_cfg* cfg, ilsx_ppo*
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, (N + 1) * sizeof(int), (void**)&p->offs);
   if (rc == ILSX_OK) rc = ctx_alloc(ctx, N * sizeof(int), (void**)&p->perm);
   if (rc != ILSX_OK) { delete p; return rc; }
-  memset(&p->jobs_v, 0, sizeof p->jobs_v);
-  memset(&p->jobs_p, 0, sizeof p->jobs_p);
-  ILSX_TRY(build_dw_jobs(p->Lv, p->Gv, p->xv, p->hv, p->dv, p->dhv, &p->jobs_v));
-  ILSX_TRY(build_dw_jobs(p->Lp, p->Gp, p->xp, p->hp, p->dp, p->dhp, &p->jobs_p));
+  memset(&p->jobs_vp, 0, sizeof p->jobs_vp);
+  ILSX_TRY(build_dw_jobs(p->Lv, p->Gv, p->xv, p->hv, p->dv, p->dhv, &p->jobs_vp));
+  ILSX_TRY(build_dw_jobs(p->Lp, p->Gp, p->xp, p->hp, p->dp, p->dhp, &p->jobs_vp));
   ILSX_TRY(ppo_refresh(p, -1));
   *out = p;
   return ILSX_OK;
@@ -381,7 +398,7 @@ static int ppo_opt(ilsx_ppo* p, int which, bool set, float* m_host, float* v_hos
   HIPCHK(hipMemcpyAsync(&h, p->sc, sizeof h, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (!set) { meta->t = which == 0 ? h.t_p : h.t_v; meta->rng_step = p->shuffles; meta->n_train_steps = 0; return ILSX_OK; }
-  if (which == 0) h.t_p = (int)meta->t; else h.t_v = (int)meta->t;
+  if (which == 0) { h.t_p = (int)meta->t; p->t_p = h.t_p; } else { h.t_v = (int)meta->t; p->t_v = h.t_v; }
   p->shuffles = meta->rng_step;
   HIPCHK(hipMemcpyAsync(p->sc, &h, sizeof h, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -463,93 +480,76 @@ static int ppo_check_world(const ilsx_ppo* p) {
   return ILSX_OK;
 }
 
+// One minibatch (ppo.py:136-170) as FIVE launches: forward {value, policy}, backward {value, policy}, weight gradients of both nets, the policy
+// gradient's norm, the optimiser launch (k_ppo_update).  The reference steps the value net, then the policy; the two updates share no operand (the
+// policy loss reads the precomputed advantages), so stepping them side by side gives the same numbers — and at the reference's own minibatch size (64 rows:
+// ppo_hopper.yaml) the update is a chain of dependent launches at ~6 us each, ten of them before round 6.
 static int ppo_minibatch(ilsx_ppo* p, const float* obs, const float* act, const int* idx, int rows) {
   ilsx_ctx* ctx = p->ctx;
   const int H = p->cfg.hidden, nh = p->cfg.n_hidden;
   const bool split = ppo_is_split(p);
   const float inv = 1.0f / ((float)rows * (float)p->cfg.grad_world);
-  // ---- value update (ppo.py:136-153)
   {
     FwdArgs A;
     memset(&A, 0, sizeof A);
-    A.rows = rows; A.ntasks = 1; A.seed = ctx->seed;
-    FwdTask& t = A.t[0];
-    ppo_fwd_task(t, p->Lv, p->Pv, obs, p->o);
-    t.rows_idx = idx; t.xsave = p->xv;
-    for (int l = 0; l < nh; ++l) t.hsave[l] = p->hv[l];
-    t.head = HEAD_RAW; t.out = p->vpred;
-    ILSX_TRY(launch_fwd(ctx, A, H, ILSX_ACT_TANH, p->Lv.KP));
-    BwdArgs Bw;
-    memset(&Bw, 0, sizeof Bw);
-    Bw.rows = rows; Bw.ntasks = 1; Bw.inv_B = inv;
-    BwdTask& b = Bw.t[0];
-    b.net = net_view(p->Lv, p->Pv);
-    for (int l = 0; l < nh; ++l) { b.hsave[l] = p->hv[l]; b.dsave[l] = p->dv[l]; }
-    b.dhead = p->dhv; b.loss = LOSS_MSE; b.rows_idx = idx; b.pred = p->vpred; b.target = p->returns;
-    if (p->cfg.use_value_clip) { b.lp_old = p->values; b.clip_eps = p->cfg.clip_eps; }   // ppo.py:137-143
-    ILSX_TRY(launch_bwd_dx(ctx, Bw, H, ILSX_ACT_TANH));
-    AdamFuse F;
-    memset(&F, 0, sizeof F);
-    F.on = 1; F.Gbase = p->Gv; F.P = p->Pv; F.M = p->Mv; F.V = p->Vv; F.T = nullptr;
-    F.b1 = 0.9f; F.b2 = 0.999f; F.eps = 1e-8f; F.tau = 0.f; F.l2x2 = 2.0f * p->cfg.value_l2_reg;
-    F.step_size = &p->sc->v_step; F.bc2_sqrt = &p->sc->v_bc2s;
-    if (!split) {
-      ILSX_TRY(launch_bwd_dw(ctx, p->jobs_v, rows, &F));
-    } else {   // backward | all-reduce(value arena) | Adam + L2 on the summed gradient
-      ILSX_TRY(launch_bwd_dw(ctx, p->jobs_v, rows, nullptr));
-      ILSX_TRY(comm_allreduce_sum(ctx, p->Gv, p->nv));
-      const PpoAdamL2Args Aa = {p->Pv, p->Gv, p->Mv, p->Vv, (int)p->nv, F.b1, F.b2, F.eps, F.l2x2, F.step_size, F.bc2_sqrt};
-      hipLaunchKernelGGL(k_ppo_adam_l2, dim3(64), dim3(256), 0, ctx->stream, Aa);
-      HIPCHK(hipGetLastError());
-    }
-    ILSX_TRY(ppo_refresh(p, 0));
+    A.rows = rows; A.ntasks = 2; A.seed = ctx->seed;
+    FwdTask& tv = A.t[0];   // value net (ppo.py:136-153)
+    ppo_fwd_task(tv, p->Lv, p->Pv, obs, p->o);
+    tv.rows_idx = idx; tv.xsave = p->xv;
+    for (int l = 0; l < nh; ++l) tv.hsave[l] = p->hv[l];
+    tv.head = HEAD_RAW; tv.out = p->vpred;
+    FwdTask& tp = A.t[1];   // policy (ppo.py:155-170)
+    ppo_fwd_task(tp, p->Lp, p->Pp, obs, p->o);
+    tp.rows_idx = idx; tp.xsave = p->xp;
+    for (int l = 0; l < nh; ++l) tp.hsave[l] = p->hp[l];
+    tp.head = HEAD_GAUSS_LOGP_OF_ACT; tp.act_in = act; tp.log_std = p->log_std(); tp.logp = p->lp; tp.out = p->mu;
+    ILSX_TRY(launch_fwd(ctx, A, H, ILSX_ACT_TANH, std::max(p->Lv.KP, p->Lp.KP)));
   }
-  // ---- policy update (ppo.py:155-170)
   {
-    FwdArgs A;
-    memset(&A, 0, sizeof A);
-    A.rows = rows; A.ntasks = 1; A.seed = ctx->seed;
-    FwdTask& t = A.t[0];
-    ppo_fwd_task(t, p->Lp, p->Pp, obs, p->o);
-    t.rows_idx = idx; t.xsave = p->xp;
-    for (int l = 0; l < nh; ++l) t.hsave[l] = p->hp[l];
-    t.head = HEAD_GAUSS_LOGP_OF_ACT; t.act_in = act; t.log_std = p->log_std(); t.logp = p->lp; t.out = p->mu;
-    ILSX_TRY(launch_fwd(ctx, A, H, ILSX_ACT_TANH, p->Lp.KP));
     BwdArgs Bw;
     memset(&Bw, 0, sizeof Bw);
-    Bw.rows = rows; Bw.ntasks = 1; Bw.inv_B = inv;
-    BwdTask& b = Bw.t[0];
-    b.net = net_view(p->Lp, p->Pp);
-    for (int l = 0; l < nh; ++l) { b.hsave[l] = p->hp[l]; b.dsave[l] = p->dp[l]; }
-    b.dhead = p->dhp; b.loss = LOSS_PPO_POLICY; b.rows_idx = idx;
-    b.pred = p->lp; b.target = p->adv; b.lp_old = p->lp_old; b.act_all = act; b.log_std = p->log_std(); b.mu = p->mu;
-    b.aux = p->cond() ? nullptr : p->aux; b.clip_eps = p->cfg.clip_eps;
+    Bw.rows = rows; Bw.ntasks = 2; Bw.inv_B = inv;
+    BwdTask& bv = Bw.t[0];
+    bv.net = net_view(p->Lv, p->Pv);
+    for (int l = 0; l < nh; ++l) { bv.hsave[l] = p->hv[l]; bv.dsave[l] = p->dv[l]; }
+    bv.dhead = p->dhv; bv.loss = LOSS_MSE; bv.rows_idx = idx; bv.pred = p->vpred; bv.target = p->returns;
+    if (p->cfg.use_value_clip) { bv.lp_old = p->values; bv.clip_eps = p->cfg.clip_eps; }   // ppo.py:137-143
+    BwdTask& bp = Bw.t[1];
+    bp.net = net_view(p->Lp, p->Pp);
+    for (int l = 0; l < nh; ++l) { bp.hsave[l] = p->hp[l]; bp.dsave[l] = p->dp[l]; }
+    bp.dhead = p->dhp; bp.loss = LOSS_PPO_POLICY; bp.rows_idx = idx;
+    bp.pred = p->lp; bp.target = p->adv; bp.lp_old = p->lp_old; bp.act_all = act; bp.log_std = p->log_std(); bp.mu = p->mu;
+    bp.aux = p->cond() ? nullptr : p->aux; bp.clip_eps = p->cfg.clip_eps;
     ILSX_TRY(launch_bwd_dx(ctx, Bw, H, ILSX_ACT_TANH));
-    ILSX_TRY(launch_bwd_dw(ctx, p->jobs_p, rows, nullptr));
-    PpoNormArgs Nn;
-    Nn.G = p->Gp; Nn.n = (int)p->Lp.n_int;
-    for (int l = 1; l <= 2; ++l) {
-      Nn.skip0[l - 1] = l < nh ? p->Lp.off_Wb[l] : 0;
-      Nn.skip1[l - 1] = l < nh ? p->Lp.off_Wb[l] + H * H : 0;
-    }
-    Nn.aux = p->aux; Nn.rows = p->cond() ? 0 : rows; Nn.a = p->n_ls(); Nn.partial = p->partial; Nn.partial_ls = p->partial + 64;
-    const int nblk = 32;
-    hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
-    if (split) {   // this rank's log_std gradient into the arena | all-reduce(policy arena) | the norm of the SUMMED gradient
-      if (p->n_ls()) hipLaunchKernelGGL(k_ppo_ls_fold, dim3(1), dim3(64), 0, ctx->stream, p->Gp, (int)p->Lp.n_int, p->n_ls(), Nn.partial_ls, nblk);
-      HIPCHK(hipGetLastError());
-      ILSX_TRY(comm_allreduce_sum(ctx, p->Gp, p->np));
-      Nn.rows = 0; Nn.a = 0;
-      hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
-    }
-    PpoClipAdamArgs C;
-    C.ls_from_G = split ? 1 : 0;
-    C.P = p->Pp; C.G = p->Gp; C.M = p->Mp; C.V = p->Vp; C.n = (int)p->np;
-    C.partial = p->partial; C.partial_ls = p->partial + 64; C.nparts = nblk; C.n_mean = (int)p->Lp.n_int; C.a = p->n_ls(); C.max_norm = 20.0f; C.b1 = 0.9f; C.b2 = 0.999f; C.eps = 1e-8f; C.sc = p->sc;
-    hipLaunchKernelGGL(k_ppo_clip_adam, dim3(64), dim3(256), 0, ctx->stream, C);
+  }
+  ILSX_TRY(launch_bwd_dw(ctx, p->jobs_vp, rows, nullptr));
+  PpoNormArgs Nn;
+  Nn.G = p->Gp; Nn.n = (int)p->Lp.n_int;
+  for (int l = 1; l <= 2; ++l) {
+    Nn.skip0[l - 1] = l < nh ? p->Lp.off_Wb[l] : 0;
+    Nn.skip1[l - 1] = l < nh ? p->Lp.off_Wb[l] + H * H : 0;
+  }
+  Nn.aux = p->aux; Nn.rows = p->cond() ? 0 : rows; Nn.a = p->n_ls(); Nn.partial = p->partial; Nn.partial_ls = p->partial + 64;
+  const int nblk = 32;
+  hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
+  if (split) {   // this rank's log_std gradient into the arena | ONE all-reduce of both nets' gradients (Gv | Gp) | the norm of the SUMMED policy gradient
+    if (p->n_ls()) hipLaunchKernelGGL(k_ppo_ls_fold, dim3(1), dim3(64), 0, ctx->stream, p->Gp, (int)p->Lp.n_int, p->n_ls(), Nn.partial_ls, nblk);
     HIPCHK(hipGetLastError());
-    ILSX_TRY(ppo_refresh(p, 1));
+    ILSX_TRY(comm_allreduce_sum(ctx, p->Gv, p->nv_pad + p->np));
+    Nn.rows = 0; Nn.a = 0;
+    hipLaunchKernelGGL(k_ppo_norm, dim3(nblk), dim3(256), 0, ctx->stream, Nn);
   }
+  PpoUpdateArgs C;
+  memset(&C, 0, sizeof C);
+  C.ls_from_G = split ? 1 : 0;
+  C.P = p->Pp; C.G = p->Gp; C.M = p->Mp; C.V = p->Vp; C.n = (int)p->np;
+  C.partial = p->partial; C.partial_ls = p->partial + 64; C.nparts = nblk; C.n_mean = (int)p->Lp.n_int; C.a = p->n_ls(); C.max_norm = 20.0f; C.b1 = 0.9f; C.b2 = 0.999f; C.eps = 1e-8f; C.sc = p->sc;
+  C.Pv = p->Pv; C.Gv = p->Gv; C.Mv = p->Mv; C.Vv = p->Vv; C.nv = (int)p->nv;
+  C.l2x2 = 2.0f * p->cfg.value_l2_reg; C.v_lr = p->cfg.value_lr; C.p_lr = p->cfg.policy_lr;
+  C.t_v = p->t_v++; C.t_p = p->t_p++;
+  C.nblk_p = 64;
+  hipLaunchKernelGGL(k_ppo_update, dim3(128), dim3(256), 0, ctx->stream, C);
+  HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
 
