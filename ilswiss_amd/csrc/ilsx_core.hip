@@ -336,6 +336,7 @@ static int kernels_init_once() {
 #undef SET_FWD
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+  HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw_low<true, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   HIPCHK(hipFuncSetAttribute((const void*)k_mlp_bwd_dw<true, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -732,7 +733,12 @@ int launch_bwd_dw(ilsx_ctx* ctx, const DwArgs& table, int rows, const AdamFuse* 
     else ILSX_LAUNCH(ps, (k_dw_strip<true, false>), dim3(D.ntiles), dim3(64), 0, ctx->stream, D);
   } else if (D.gtiles) {
     const int gnh = D.tile_nh ? D.tile_nh : 2, gkt = D.tile_kt ? D.tile_kt : 4;
-    if (gnh == 2 && gkt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 2, 4>), dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
+    // two 16-wave workgroups per CU (the <= 64-register instance) once the launch has more tiles than CUs: ILSX_DW_GRP_LOW = 0 / 1 pins it
+    const char* low_e = getenv("ILSX_DW_GRP_LOW");   // read per launch: tests switch it
+    const int low_env = low_e ? atoi(low_e) : -1;
+    const bool low = low_env >= 0 ? low_env != 0 : D.ntiles > device_cus(ctx);
+    if (gnh == 2 && gkt == 4 && low) ILSX_LAUNCH(ps, (k_mlp_bwd_dw_low<true, 2, 4>), dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
+    else if (gnh == 2 && gkt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 2, 4>), dim3(D.ntiles << D.xs), dim3(1024), DW_LDS_BYTES_OF(2, 4), ctx->stream, D);
     else if (gnh == 1 && gkt == 2) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 1, 2>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 2), ctx->stream, D);
     else if (gnh == 1 && gkt == 1) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 1, 1>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 1), ctx->stream, D);
     else if (gnh == 1 && gkt == 4) ILSX_LAUNCH(ps, (k_mlp_bwd_dw<true, 1, 4>), dim3(D.ntiles << D.xs), dim3(512), DW_LDS_BYTES_OF(1, 4), ctx->stream, D);

@@ -1446,24 +1446,45 @@ struct DwTileG { DwMat J; AdamFuse F; };
 // (Measured and rejected, round 2: nontemporal stores here — no change; system-scope write-through stores — the launch got
 //  1.8 us slower and the step lost 3 %.  The 4 us between this launch and the next one is not the L2 write-back of these lines.)
 #define ILSX_ST(ptr, val) (*(ptr) = (val))
+// Pointers read from a table in device memory (grouped launches) are GENERIC to the compiler, and every access through them a FLAT instruction:
+// a 64-bit address built per access, counted on the LDS counter as well as on the vector-memory one (so an LDS wait also waits for them).  G = true
+// states at the access what the pointer is — global_load / global_store, as in the single-run instances whose pointers arrive in the kernel arguments.
+typedef float __attribute__((address_space(1))) ilsx_gfloat;
+#ifdef ILSX_FLAT_TABLE_PTRS   // A/B build (make VAR=flat VARFLAGS=-DILSX_FLAT_TABLE_PTRS): the accesses as the compiler infers them
+#define ILSX_G(G) false
+#else
+#define ILSX_G(G) (G)
+#endif
+template <bool G>
+__device__ __forceinline__ float ld_f(const float* p) {
+  if (ILSX_G(G)) return *(const ilsx_gfloat*)p;
+  return *p;
+}
+template <bool G>
+__device__ __forceinline__ void st_f(float* p, float v) {
+  if (ILSX_G(G)) *(ilsx_gfloat*)p = v;
+  else ILSX_ST(p, v);
+}
 struct AdamOperands { float p, m, v, t; };
+template <bool G = false>
 __device__ __forceinline__ AdamOperands adam_prefetch(const AdamFuse& F, size_t i0) {
   AdamOperands o;
-  o.p = F.P[i0]; o.m = F.M[i0]; o.v = F.V[i0]; o.t = F.T ? F.T[i0] : 0.0f;
+  o.p = ld_f<G>(F.P + i0); o.m = ld_f<G>(F.M + i0); o.v = ld_f<G>(F.V + i0); o.t = F.T ? ld_f<G>(F.T + i0) : 0.0f;
   return o;
 }
+template <bool G = false>
 __device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float bc2s, const AdamOperands& o, size_t i0,
                                            size_t i1, bool two, float g) {
   g = g + F.l2x2 * o.p;
   const float m = o.m * F.b1 + (1.0f - F.b1) * g;
   const float v = o.v * F.b2 + (1.0f - F.b2) * g * g;
   const float p = o.p - step * (m / (sqrtf(v) / bc2s + F.eps));
-  ILSX_ST(F.M + i0, m); ILSX_ST(F.V + i0, v); ILSX_ST(F.P + i0, p);
+  st_f<G>(F.M + i0, m); st_f<G>(F.V + i0, v); st_f<G>(F.P + i0, p);
   float tg = 0.0f;
-  if (F.T) { tg = o.t * (1.0f - F.tau) + p * F.tau; ILSX_ST(F.T + i0, tg); }
+  if (F.T) { tg = o.t * (1.0f - F.tau) + p * F.tau; st_f<G>(F.T + i0, tg); }
   if (two) {  // second packing of the same matrix
-    ILSX_ST(F.M + i1, m); ILSX_ST(F.V + i1, v); ILSX_ST(F.P + i1, p);
-    if (F.T) ILSX_ST(F.T + i1, tg);
+    st_f<G>(F.M + i1, m); st_f<G>(F.V + i1, v); st_f<G>(F.P + i1, p);
+    if (F.T) st_f<G>(F.T + i1, tg);
   }
 }
 
@@ -1471,9 +1492,12 @@ __device__ __forceinline__ void adam_apply(const AdamFuse& F, float step, float 
 // (wave = row-eighth x n block).  Per-element arithmetic and summation order do not depend on NH / KT (bit-identical results); small
 // tiles spread a small-batch launch over more CUs at fewer waves per SIMD (launch_bwd_dw picks them for the single-run steps).
 #define DW_LDS_BYTES_OF(NH, KT) ((8 * (NH) * 4 * (KT) * 64 + 8 * (NH) * 16) * 4)
-template <bool GRP, int NH, int KT>
-__global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// LOW: the same tile in <= 64 registers, for EIGHT waves per SIMD (two 16-wave workgroups per CU; k_mlp_bwd_dw_low): a trip's two 128-row
+// steps are requested one after the other and the output pointers + optimiser operands after the contraction instead of at entry — what
+// a lone workgroup wins by having everything in flight at once, two resident workgroups win by overlapping their phases.  Same MFMA chain,
+// same sums: bit-identical.
+template <bool GRP, int NH, int KT, bool LOW>
+__device__ __forceinline__ void dw_tile_body(const DwArgs& D, float* smem) {
   constexpr int NW = 8 * NH, NT = 512 * NH, TN = 16 * NH, TK = 16 * KT, EPT = (KT + 1) / 2;   // EPT: output elements per thread (KT = 1: half the threads finish one)
   float* part = smem;                         // [NW waves][4 KT acc regs][64 lanes]
   float* bpart = smem + NW * 4 * KT * 64;     // [NW waves][16]
@@ -1488,8 +1512,9 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
       if (i < D.nmat && bx >= D.m[i].tile0) mi = i;
   }
   DwTileG Rg;
-  if (GRP) Rg = D.gtiles[bx];   // by value at entry (see k_mlp2_fwd_split)
-  else { Rg.J = D.m[mi]; Rg.F = D.F; }
+  if (GRP) {
+    Rg = D.gtiles[bx];   // by value at entry (see k_mlp2_fwd_split)
+  } else { Rg.J = D.m[mi]; Rg.F = D.F; }
   const DwMat& J = Rg.J;
   const AdamFuse& F = Rg.F;
   const int local = bx - J.tile0;
@@ -1510,39 +1535,45 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
   int ntk = (J.NB - k0 + 15) / 16;
   if (ntk > KT) ntk = KT;
   ILSX_STAMP(D.dbg, 0);
-  // ---- the two output elements this thread will finish (and their optimiser operands, requested now)
+  // ---- the two output elements this thread will finish (and their optimiser operands: requested now, or behind the contraction when LOW)
   const bool packed = J.mode != DW_OUT_NATURAL;
   float* g0p[EPT]; float* g1p[EPT]; bool live[EPT];
   AdamOperands ao[EPT];
   float ad_step = 0.f, ad_bc2s = 1.f;
-  if (F.on) { ad_step = *F.step_size; ad_bc2s = *F.bc2_sqrt; }
-#pragma unroll
-  for (int h = 0; h < EPT; ++h) {
-    const int e = tid + NT * h, ee = e % (256 * NH * KT);
-    const int on = ee / (256 * KT), rest = ee % (256 * KT), t = rest >> 8, q = rest & 255;
-    // thread <-> element of the 16 x 16 block: packed outputs in ADDRESS order (consecutive lanes = consecutive floats of the forward
-    // packing and whole 64-byte runs of the backward packing: every optimiser stream of the epilogue moves full lines; the accumulator
-    // order — lane = column, register = row — touched 16 of every 64 bytes per instruction); natural outputs keep the accumulator order
-    const int v = packed ? (q >> 2) & 3 : (q >> 6) & 3;
-    const int ol = packed ? ((q >> 4) & 3) * 16 + 4 * (q >> 6) + (q & 3) : q & 63;
-    const int n = n0 + 16 * on + 4 * (ol >> 4) + v, k = k0 + 16 * t + (ol & 15);
-    live[h] = e < 256 * NH * KT && t < ntk && n < J.NA && k < J.NB;
-    g0p[h] = nullptr; g1p[h] = nullptr;
-    if (live[h]) {
-      g0p[h] = J.mode == DW_OUT_NATURAL ? J.dW + (size_t)n * J.ldw + k : J.dW + pack_f(n, k, J.ldw);
-      g1p[h] = J.mode == DW_OUT_PACK_FB ? J.dWb + pack_b(n, k, J.NA) : nullptr;
-      if (out_shift) {
-        g0p[h] = out_shift + (g0p[h] - D.g_lo);
-        if (g1p[h]) g1p[h] = out_shift + (g1p[h] - D.g_lo);
-      }
-      if (F.on) ao[h] = adam_prefetch(F, (size_t)(g0p[h] - F.Gbase));
-    }
-  }
-  const bool bias_thread = J.db && k0 == 0 && tid < 16 * NH && n0 + 16 * (tid >> 4) + (tid & 15) < J.NA;
-  float* gbp = bias_thread ? J.db + n0 + 16 * (tid >> 4) + (tid & 15) : nullptr;
-  if (gbp && out_shift) gbp = out_shift + (gbp - D.g_lo);
+  bool bias_thread = false;
+  float* gbp = nullptr;
   AdamOperands aob;
-  if (bias_thread && F.on) aob = adam_prefetch(F, (size_t)(gbp - F.Gbase));
+#define DW_OUTPUT_ELEMS()                                                                                                          \
+  {                                                                                                                                \
+    if (F.on) { ad_step = ld_f<GRP>(F.step_size); ad_bc2s = ld_f<GRP>(F.bc2_sqrt); }                                                                   \
+    _Pragma("unroll") for (int h = 0; h < EPT; ++h) {                                                                              \
+      const int e = tid + NT * h, ee = e % (256 * NH * KT);                                                                        \
+      const int on = ee / (256 * KT), rest = ee % (256 * KT), t = rest >> 8, q = rest & 255;                                       \
+      /* thread <-> element of the 16 x 16 block: packed outputs in ADDRESS order (consecutive lanes = consecutive floats of the   \
+         forward packing and whole 64-byte runs of the backward packing: every optimiser stream of the epilogue moves full lines;  \
+         the accumulator order - lane = column, register = row - touched 16 of every 64 bytes per instruction); natural outputs    \
+         keep the accumulator order */                                                                                             \
+      const int v = packed ? (q >> 2) & 3 : (q >> 6) & 3;                                                                          \
+      const int ol = packed ? ((q >> 4) & 3) * 16 + 4 * (q >> 6) + (q & 3) : q & 63;                                               \
+      const int n = n0 + 16 * on + 4 * (ol >> 4) + v, k = k0 + 16 * t + (ol & 15);                                                 \
+      live[h] = e < 256 * NH * KT && t < ntk && n < J.NA && k < J.NB;                                                              \
+      g0p[h] = nullptr; g1p[h] = nullptr;                                                                                          \
+      if (live[h]) {                                                                                                               \
+        g0p[h] = J.mode == DW_OUT_NATURAL ? J.dW + (size_t)n * J.ldw + k : J.dW + pack_f(n, k, J.ldw);                             \
+        g1p[h] = J.mode == DW_OUT_PACK_FB ? J.dWb + pack_b(n, k, J.NA) : nullptr;                                                  \
+        if (out_shift) {                                                                                                           \
+          g0p[h] = out_shift + (g0p[h] - D.g_lo);                                                                                  \
+          if (g1p[h]) g1p[h] = out_shift + (g1p[h] - D.g_lo);                                                                      \
+        }                                                                                                                          \
+        if (F.on) ao[h] = adam_prefetch<GRP>(F, (size_t)(g0p[h] - F.Gbase));                                                            \
+      }                                                                                                                            \
+    }                                                                                                                              \
+    bias_thread = J.db && k0 == 0 && tid < 16 * NH && n0 + 16 * (tid >> 4) + (tid & 15) < J.NA;                                    \
+    gbp = bias_thread ? J.db + n0 + 16 * (tid >> 4) + (tid & 15) : nullptr;                                                        \
+    if (gbp && out_shift) gbp = out_shift + (gbp - D.g_lo);                                                                        \
+    if (bias_thread && F.on) aob = adam_prefetch<GRP>(F, (size_t)(gbp - F.Gbase));                                                      \
+  }
+  if (!LOW) DW_OUTPUT_ELEMS();
 
   f32x4 acc[KT];
 #pragma unroll
@@ -1563,13 +1594,31 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
     if (tile_in && rbase + 256 <= rows && rbase + 256 <= brows) {
       const float* const pa = J.A + (size_t)(rc + 4 * g) * J.lda + nsub + li;
       const float* const pb = J.Bm + (size_t)(rc + 4 * g) * J.ldb + k0 + li;
+      if (LOW) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            a[0][s] = ld_f<GRP>(pa + (size_t)(128 * u + s) * J.lda);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) b[0][t][s] = ld_f<GRP>(pb + (size_t)(128 * u + s) * J.ldb + 16 * t);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[t] = MFMA16(a[0][s], b[0][t][s], acc[t]);
+            bsum += a[0][s];
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          a[u][s] = pa[(size_t)(128 * u + s) * J.lda];
+          a[u][s] = ld_f<GRP>(pa + (size_t)(128 * u + s) * J.lda);
 #pragma unroll
-          for (int t = 0; t < KT; ++t) b[u][t][s] = pb[(size_t)(128 * u + s) * J.ldb + 16 * t];
+          for (int t = 0; t < KT; ++t) b[u][t][s] = ld_f<GRP>(pb + (size_t)(128 * u + s) * J.ldb + 16 * t);
         }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -1581,16 +1630,38 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
         }
       continue;
     }
+    if (LOW) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r = rc + 128 * u + 4 * g + s;
+          const bool r_ok = r < rows;
+          a[0][s] = (r_ok && n_ok) ? ld_f<GRP>(J.A + (size_t)r * J.lda + nsub + li) : 0.0f;
+#pragma unroll
+          for (int t = 0; t < KT; ++t)
+            b[0][t][s] = (r_ok && k_ok[t]) ? ld_f<GRP>(J.Bm + (size_t)r * J.ldb + k0 + 16 * t + li) : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int t = 0; t < KT; ++t)
+            if (t < ntk) acc[t] = MFMA16(a[0][s], b[0][t][s], acc[t]);
+          bsum += (rc + 128 * u + 4 * g + s < brows) ? a[0][s] : 0.0f;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int r = rc + 128 * u + 4 * g + s;
         const bool r_ok = r < rows;
-        a[u][s] = (r_ok && n_ok) ? J.A[(size_t)r * J.lda + nsub + li] : 0.0f;
+        a[u][s] = (r_ok && n_ok) ? ld_f<GRP>(J.A + (size_t)r * J.lda + nsub + li) : 0.0f;
 #pragma unroll
         for (int t = 0; t < KT; ++t)
-          b[u][t][s] = (r_ok && k_ok[t]) ? J.Bm[(size_t)r * J.ldb + k0 + 16 * t + li] : 0.0f;
+          b[u][t][s] = (r_ok && k_ok[t]) ? ld_f<GRP>(J.Bm + (size_t)r * J.ldb + k0 + 16 * t + li) : 0.0f;
       }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -1611,6 +1682,8 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
   bsum += __shfl_xor(bsum, 16, 64);
   bsum += __shfl_xor(bsum, 32, 64);
   if (g == 0) bpart[wave * 16 + li] = bsum;
+  if (LOW) DW_OUTPUT_ELEMS();
+#undef DW_OUTPUT_ELEMS
   lds_barrier();
   ILSX_STAMP(D.dbg, 2);
   // sum the 8 row-partials; thread <-> (n-half, tile, reg, lane)
@@ -1627,9 +1700,9 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) s += part[((r8 * NH + on) * 4 * KT + t * 4 + v) * 64 + ol];
     if (live[h]) {
-      ILSX_ST(g0p[h], s);
-      if (g1p[h] && !F.on) ILSX_ST(g1p[h], s);   // with the optimiser fused nobody reads the gradient's second packing (get_grads and the flat views read the first): one of the hidden -> hidden matrices' 14 streams less
-      if (F.on) adam_apply(F, ad_step, ad_bc2s, ao[h], (size_t)(g0p[h] - F.Gbase), g1p[h] ? (size_t)(g1p[h] - F.Gbase) : 0,
+      st_f<GRP>(g0p[h], s);
+      if (g1p[h] && !F.on) st_f<GRP>(g1p[h], s);   // with the optimiser fused nobody reads the gradient's second packing (get_grads and the flat views read the first): one of the hidden -> hidden matrices' 14 streams less
+      if (F.on) adam_apply<GRP>(F, ad_step, ad_bc2s, ao[h], (size_t)(g0p[h] - F.Gbase), g1p[h] ? (size_t)(g1p[h] - F.Gbase) : 0,
                            g1p[h] != nullptr, s);
     }
   }
@@ -1638,10 +1711,20 @@ __global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
     float s = 0.0f;
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) s += bpart[(r8 * NH + on) * 16 + ol];
-    *gbp = s;
-    if (F.on) adam_apply(F, ad_step, ad_bc2s, aob, (size_t)(gbp - F.Gbase), 0, false, s);
+    st_f<GRP>(gbp, s);
+    if (F.on) adam_apply<GRP>(F, ad_step, ad_bc2s, aob, (size_t)(gbp - F.Gbase), 0, false, s);
   }
   ILSX_STAMP(D.dbg, 7);
+}
+template <bool GRP, int NH, int KT>
+__global__ __launch_bounds__(512 * NH) void k_mlp_bwd_dw(const DwArgs D) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  dw_tile_body<GRP, NH, KT, false>(D, smem);
+}
+template <bool GRP, int NH, int KT>
+__global__ __launch_bounds__(512 * NH) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mlp_bwd_dw_low(const DwArgs D) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  dw_tile_body<GRP, NH, KT, true>(D, smem);
 }
 
 // (Measured and rejected, round 4: a 64 x 64 block shape for SAC-sized batches — k_dw_blk: eight waves = the eight row-eighths, every

@@ -532,14 +532,16 @@ def test_train_from_replay_graph_equals_direct_and_learns(ctx, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", [{}, {"ILSX_GRP_MT": "2", "ILSX_DW_GRP_STRIP": "1"}, {"ILSX_GRP_MT": "4"}, {"ILSX_DW_GRP_STRIP": "1"},
                                    {"ILSX_GRP_LATE": "1"}, {"ILSX_GRP_LATE": "0"}, {"ILSX_DW_TILE_GRP": "12"},
+                                   {"ILSX_DW_TILE_GRP": "24", "ILSX_DW_GRP_LOW": "1"}, {"ILSX_DW_TILE_GRP": "24", "ILSX_DW_GRP_LOW": "0"},
                                    {"ILSX_GRP_LATE": "1", "_hid": "128"}, {"_hid": "128"}],
-                         ids=["default", "mt2_strip", "mt4", "strip", "late", "early", "dw_tile12", "late_h128", "h128"])
+                         ids=["default", "mt2_strip", "mt4", "strip", "late", "early", "dw_tile12", "dw_tile24_low", "dw_tile24_high", "late_h128", "h128"])
 @pytest.mark.parametrize("o,a,B", [(11, 3, 256), (111, 8, 256), (17, 6, 100)])   # narrow: one-launch forward ; Ant widths: the two-phase forward (kernels.h PH 1 / 2) ; a ragged batch
 def test_sac_group_lockstep_is_bitwise_the_independent_runs(ctx, o, a, B, knobs, monkeypatch):
     """K=3 co-resident seeds stepped by ONE launch per stage (ilsx_sac_group) == each agent stepped alone with
     ilsx_sac_train_from_replay: same per-agent Philox streams, and per 16-row tile / per output element the same chain of MFMAs
     whatever the launch shape — macro tiles of 2 or 4 row tiles per workgroup on the XCD-stable 1-D grid (fwd_split_tile.inc MT,
-    GrpSwizzle), weight gradients as one-wavefront strips (k_dw_strip) or as 8-wave tiles — so every parameter is bit-identical."""
+    GrpSwizzle), weight gradients as one-wavefront strips (k_dw_strip) or as 8-wave tiles (the 32 x 64 tile in its 104-register
+    and its 63-register, eight-waves-per-SIMD instance: k_mlp_bwd_dw_low) — so every parameter is bit-identical."""
     import ilswiss_amd as ia
     from ilswiss_amd.replay import SimpleReplayBuffer
     for k_, v_ in knobs.items():
