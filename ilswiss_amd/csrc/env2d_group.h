@@ -29,6 +29,17 @@
 #define EG_LANES 16
 #define EG_ENVS 4    // per wavefront == per workgroup
 #define EG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// ILSX_EG_PROFILE (measurement build: make VAR=egprof VARFLAGS=-DILSX_EG_PROFILE, tools/env2d_phases.py): clock ticks per stage of
+// eg_dynamics, summed over the evaluations of workgroup 0's wavefront into g_eg_prof (read back with ilsx_debug_eg_prof)
+#ifdef ILSX_EG_PROFILE
+__device__ unsigned long long g_eg_prof[16];
+#define EG_PROF_BEGIN() unsigned long long eg_pl = __builtin_amdgcn_s_memtime()
+#define EG_PROF(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_eg_prof[i] += t_ - eg_pl; asm volatile("" ::: "memory"); eg_pl = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EG_PROF_BEGIN() ((void)0)
+#define EG_PROF(i) ((void)0)
+#endif
 
 // value of lane K of this lane's 16-lane row: DPP row_newbcast (gfx90a+: the one DPP control 64-bit operations accept) — a VALU move, or
 // folded into the consuming instruction; the first version went through the LDS crossbar (ds_swizzle bit mode, lane' = (lane & 0x10) | K:
@@ -59,6 +70,36 @@ __device__ __forceinline__ double eg_bcast_k(double x, int k) {
   }
 }
 
+// One Gauss-Seidel sweep over the rows 0 .. nrmax - 1 (nrmax wave-uniform), rows as TEMPLATE recursion: as `#pragma unroll` over t with a
+// `break` the loop stayed rolled for MR = 12 / 16 (the compiler's "loop not unrolled" warning on Walker2d / HalfCheetah: every row step then
+// indexed fcopy / Arow through s_set_gpr_idx and picked its row broadcast in a 16-way switch — 220 clock ticks per row step against 40-75
+// for Hopper's MR = 8, where it did unroll; tools/env2d_phases.py).  Same operations in the same order.
+template <int T, int MR>
+__device__ __forceinline__ void eg_pgs_sweep(double (&fcopy)[MR], const double (&Arow)[MR], double& res, double att, double invden, double lo_a,
+                                             double hi_a, double hi_b, int nrmax) {
+  if constexpr (T < MR) {
+    if (T >= nrmax) return;   // wave-uniform
+    double fi = (res + att * fcopy[T]) * invden;
+    const double fprev = fcopy[T > 0 ? T - 1 : 0];
+    fi = fmin(fmax(fi, lo_a * fprev), hi_a * fprev + hi_b);
+    const double fb = eg_bcast<T>(fi);
+    const double dl = fb - fcopy[T];
+    fcopy[T] = fb;
+    res -= Arow[T] * dl;
+    eg_pgs_sweep<T + 1, MR>(fcopy, Arow, res, att, invden, lo_a, hi_a, hi_b, nrmax);
+  }
+}
+// w = sum_r z_r[l] f_r over the active rows (the same early exit, the same way)
+template <int R, int MR, int N>
+__device__ __forceinline__ void eg_ztf(const double* Zl, const double (&fcopy)[MR], bool dof, int nr, int nrmax, double& w) {
+  if constexpr (R < MR) {
+    if (R >= nrmax) return;
+    const double z = (dof && R < nr) ? Zl[R * N] : 0.0;
+    w += z * fcopy[R];
+    eg_ztf<R + 1, MR, N>(Zl, fcopy, dof, nr, nrmax, w);
+  }
+}
+
 template <int NB, int MR>
 struct EgOff {   // the env's LDS blackboard, in doubles
   static constexpr int N = NB + 2;
@@ -83,6 +124,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   const bool dof = l < N;
   const int jb = l >= 2 && l < N ? l - 2 : 0;        // the body on this lane (lanes 0, 1 and >= N shadow body 0; they publish nothing)
   const bool body = l >= 2 && l < N;
+  EG_PROF_BEGIN();
   // ---- q, v on the blackboard
   if (dof) { E[O::QV + l] = q; E[O::QV + N + l] = v; }
   EG_SYNC();
@@ -129,6 +171,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
     }
   }
   EG_SYNC();
+  EG_PROF(0);
   // ---- mass matrix row l and right-hand side l: bodies in ascending order
   double Mrow[N];
 #pragma unroll
@@ -169,6 +212,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
     rhs -= m.damping[jb] * v + m.stiffness[jb] * q;
     rhs += torque;
   }
+  EG_PROF(1);
   // ---- Cholesky, column steps.  Every lane takes the reciprocal of the broadcast pivot itself (same bits everywhere).
   double invd[N];
 #pragma unroll
@@ -184,6 +228,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
       if (l >= j) Mrow[j] -= Mrow[k] * ljk;
     }
   }
+  EG_PROF(2);
   // L and the reciprocal pivots on the blackboard (the constraint rows read them back); L^T entries this lane needs for the back-substitutions
   if (dof) {
 #pragma unroll
@@ -194,6 +239,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   double LT[N];   // LT[k] = L[k][l] for k > l
 #pragma unroll
   for (int k = 0; k < N; ++k) LT[k] = (k > l && dof) ? E[O::LMAT + k * N + l] : 0.0;
+  EG_PROF(3);
   // ---- qacc0 = M^-1 rhs
   double y = dof ? rhs : 0.0;
 #pragma unroll
@@ -212,6 +258,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   }
   const double qacc0 = dof ? y : 0.0;
   if (dof) E[O::QACC0 + l] = qacc0;
+  EG_PROF(4);
   // ---- constraint rows.  Contacts: candidate c = the capsule end points in the oracle's order (distal geoms first, p1 then p2).
   int ncon = 0, nr = 0;
   {
@@ -269,6 +316,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   // rows of the busiest env of this wavefront (wave-uniform trip counts below)
   int nrmax = max(max(__builtin_amdgcn_readlane(nr, 0), __builtin_amdgcn_readlane(nr, 16)),
                   max(__builtin_amdgcn_readlane(nr, 32), __builtin_amdgcn_readlane(nr, 48)));
+  EG_PROF(5);
   if (nrmax == 0) return qacc0;
   EG_SYNC();
   const bool rowl = l < nr && l < MR;
@@ -300,6 +348,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
     const double bdamp = 2.0 / (dmax * tc), kstiff = 1.0 / (dmax * dmax * tc * tc * dr * dr);
     if (rowl) rhs_c = (-bdamp * jv - kstiff * rd * rres) - ja;
   }
+  EG_PROF(6);
   EG_SYNC();   // every lane has read its J row and L: the rows may be overwritten
   if (rowl) {
     double* Zr = E + O::ROWJ + l * N;
@@ -324,6 +373,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   for (int c = 0; c < MR; ++c)
     if (c == l) att = Arow[c];
   const double invden = rowl ? 1.0 / (att + (1.0 - rd) / rd * att) : 0.0;
+  EG_PROF(7);
   // ---- projected Gauss-Seidel: lane t is row t
   double fcopy[MR];
 #pragma unroll
@@ -333,27 +383,11 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   // (lo_a, hi_a, hi_b) = (-mu, mu, 0), normal / limit rows (0, 0, +inf) — the same values as the two-branch form (a select per bound and
   // per lane), five instructions shorter per row and sweep on the chain that is most of this kernel
   const double lo_a = rkind == 1 ? -rmu : 0.0, hi_a = rkind == 1 ? rmu : 0.0, hi_b = rkind == 1 ? 0.0 : __builtin_huge_val();
-  for (int it = 0; it < m.pgs_iters; ++it) {
-#pragma unroll
-    for (int t = 0; t < MR; ++t) {
-      if (t >= nrmax) break;   // wave-uniform
-      double fi = (res + att * fcopy[t]) * invden;
-      const double fprev = fcopy[t > 0 ? t - 1 : 0];
-      fi = fmin(fmax(fi, lo_a * fprev), hi_a * fprev + hi_b);
-      const double fb = eg_bcast_k(fi, t);
-      const double dl = fb - fcopy[t];
-      fcopy[t] = fb;
-      res -= Arow[t] * dl;
-    }
-  }
+  for (int it = 0; it < m.pgs_iters; ++it) eg_pgs_sweep<0, MR>(fcopy, Arow, res, att, invden, lo_a, hi_a, hi_b, nrmax);
+  EG_PROF(8);
   // ---- q.. = qacc0 + L^-T (Z^T f)
   double w = 0.0;
-#pragma unroll
-  for (int r = 0; r < MR; ++r) {
-    if (r >= nrmax) break;
-    const double z = (dof && r < nr) ? E[O::ROWJ + r * N + l] : 0.0;
-    w += z * fcopy[r];
-  }
+  eg_ztf<0, MR, N>(E + O::ROWJ + l, fcopy, dof, nr, nrmax, w);
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {
     const double t = w * invd[k];
@@ -362,6 +396,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
     else if (l < k) w -= LT[k] * xk;
   }
   EG_SYNC();   // the rows are rewritten by the next evaluation
+  EG_PROF(9);
   return dof ? qacc0 + w : 0.0;
 }
 
@@ -378,6 +413,9 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
     EG_SYNC();
   }
   const PlanarModelDev& m = *reinterpret_cast<const PlanarModelDev*>(smd_all);
+#ifdef ILSX_EG_PROFILE
+  const unsigned long long eg_t0 = __builtin_amdgcn_s_memtime();
+#endif
   const int lane = threadIdx.x, l = lane & 15, grp = lane >> 4;
   double* E = smd_all + MODEL_DOUBLES + grp * O::TOTAL;
   const int t_raw = blockIdx.x * EG_ENVS + grp;
@@ -493,6 +531,9 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
     }
     if (dof) { A.qpos[(size_t)l * A.n_env + env] = q; A.qvel[(size_t)l * A.n_env + env] = v; }
   }
+#ifdef ILSX_EG_PROFILE
+  if (threadIdx.x == 0 && blockIdx.x == 0) { g_eg_prof[15] += __builtin_amdgcn_s_memtime() - eg_t0; g_eg_prof[14] += 1; }
+#endif
 }
 
 template <int NB, int MR>

@@ -195,6 +195,26 @@ __device__ __forceinline__ double e3w_rcp(double a) {
 __device__ __forceinline__ double e3w_readlane(double v, int src) {   // src is wave-uniform
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
+#ifndef E3W_HOST_EMU
+// One Gauss-Seidel sweep over the rows 0 .. nr - 1 (nr wave-uniform), the rows as TEMPLATE recursion.  Written as `#pragma unroll` over
+// r < E3_MAXR with a `break` the loop stayed rolled (the compiler's "loop not unrolled" warning on k_env3dw_step): column c of A — 30
+// doubles a lane — then lived in a 256-byte private segment and every row step of the chain began with a scratch load of Acol[r].
+// Same operations in the same order.
+template <int R>
+__device__ __forceinline__ void e3w_pgs_sweep(const double (&Acol)[E3_MAXR], double& res, double& f, double& fn, double arr, double inv,
+                                              double mu_eff, double open_hi, int lane, int nidx, int nr) {
+  if constexpr (R < E3_MAXR) {
+    if (R >= nr) return;
+    const double lim = mu_eff * fn;
+    const double nw = fmin(fmax((res + arr * f) * inv, -lim), lim + open_hi);
+    const double sd = e3w_readlane(nw - f, R), sn = e3w_readlane(nw, R);
+    res -= Acol[R] * sd;
+    f = lane == R ? sn : f;
+    fn = nidx == R ? sn : fn;
+    e3w_pgs_sweep<R + 1>(Acol, res, f, fn, arr, inv, mu_eff, open_hi, lane, nidx, nr);
+  }
+}
+#endif
 #endif
 
 // Link frames and velocity-product accelerations of the state at (qoff, voff) (oracle kin())
@@ -650,18 +670,8 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
         const int hi = r > lane ? r : lane, lo = r > lane ? lane : r;
         Acol[r] = S[E3WOff::A + ((on && r < nr) ? e3_tri(hi, lo) : 0)];
       }
-      for (int it = 0, n_it = E3W_REGS(0).pgs_iters; it < n_it; ++it) {
-#pragma unroll
-        for (int r = 0; r < E3_MAXR; ++r) {
-          if (r >= nr) break;
-          const double lim = mu_eff * fn;
-          const double nw = fmin(fmax((res + arr * f) * inv, -lim), lim + open_hi);
-          const double sd = e3w_readlane(nw - f, r), sn = e3w_readlane(nw, r);
-          res -= Acol[r] * sd;
-          f = lane == r ? sn : f;
-          fn = nidx == r ? sn : fn;
-        }
-      }
+      for (int it = 0, n_it = E3W_REGS(0).pgs_iters; it < n_it; ++it)
+        e3w_pgs_sweep<0>(Acol, res, f, fn, arr, inv, mu_eff, open_hi, lane, nidx, nr);
       if (on) S[rmc + 2] = f;
     }
     E3W_SYNC();

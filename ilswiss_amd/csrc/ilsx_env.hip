@@ -480,6 +480,13 @@ __device__ __forceinline__ void env_reset_state(const PlanarModelDev& m, uint64_
 }
 
 #include "env2d_group.h"
+#ifdef ILSX_EG_PROFILE
+extern "C" int ilsx_debug_eg_prof(unsigned long long* out16, int reset) {   // measurement build only
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_eg_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_eg_prof), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 template <int NB, int MR, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_env_step(const EnvStepArgs A) {
