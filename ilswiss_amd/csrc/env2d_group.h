@@ -33,10 +33,15 @@
 // eg_dynamics, summed over the evaluations of workgroup 0's wavefront into g_eg_prof (read back with ilsx_debug_eg_prof)
 #ifdef ILSX_EG_PROFILE
 __device__ unsigned long long g_eg_prof[16];
+// the stage sums stay in registers (eg_acc, owned by the step function) and reach memory once, at the end of the step
+#define EG_PROF_PARAM , unsigned long long (&eg_acc)[16]
+#define EG_PROF_ARG , eg_acc
 #define EG_PROF_BEGIN() unsigned long long eg_pl = __builtin_amdgcn_s_memtime()
 #define EG_PROF(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-    if (threadIdx.x == 0 && blockIdx.x == 0) g_eg_prof[i] += t_ - eg_pl; asm volatile("" ::: "memory"); eg_pl = __builtin_amdgcn_s_memtime(); } while (0)
+    eg_acc[i] += t_ - eg_pl; eg_pl = t_; asm volatile("" ::: "memory"); } while (0)
 #else
+#define EG_PROF_PARAM
+#define EG_PROF_ARG
 #define EG_PROF_BEGIN() ((void)0)
 #define EG_PROF(i) ((void)0)
 #endif
@@ -118,7 +123,7 @@ struct EgOff {   // the env's LDS blackboard, in doubles
 // Forward dynamics for the env this 16-lane row serves.  In: this lane's q_l, v_l (0 beyond N), `torque` = gear * ctrl of the actuator
 // on this lane's hinge (0 if none).  Out: this lane's acceleration.  E = the env's blackboard.
 template <int NB, int MR>
-__device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q, double v, double torque, double* E, int l, int grp) {
+__device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q, double v, double torque, double* E, int l, int grp EG_PROF_PARAM) {
   constexpr int N = NB + 2;
   using O = EgOff<NB, MR>;
   const bool dof = l < N;
@@ -133,7 +138,8 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   double phi = 0.0, phid = 0.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    const double sg = ((am >> j) & 1u) ? m.jsign[j] : 0.0;
+    const double jsj = m.jsign[j];   // read whatever the ancestor bit says: no branch around the load
+    const double sg = ((am >> j) & 1u) ? jsj : 0.0;
     phi += sg * E[O::QV + 2 + j];
     phid += sg * E[O::QV + N + 2 + j];
   }
@@ -153,11 +159,17 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   }
   EG_SYNC();
   double ox = E[O::QV + 0], oz = E[O::QV + 1], aox = 0.0, aoz = 0.0;
+  {   // every body's terms are read (no lane-dependent branch around the LDS loads: one round trip for all of them), the ancestors' are kept
+    double t3[NB], t4[NB], t5[NB], t6[NB];
 #pragma unroll
-  for (int j = 1; j < NB; ++j) {
-    if ((am >> j) & 1u) {
+    for (int j = 1; j < NB; ++j) {
       const double* Jm = E + O::BODY + j * O::BODY_F;
-      ox += Jm[3]; oz += Jm[4]; aox -= Jm[5]; aoz -= Jm[6];
+      t3[j] = Jm[3]; t4[j] = Jm[4]; t5[j] = Jm[5]; t6[j] = Jm[6];
+    }
+#pragma unroll
+    for (int j = 1; j < NB; ++j) {
+      const bool anc = (am >> j) & 1u;
+      ox = anc ? ox + t3[j] : ox; oz = anc ? oz + t4[j] : oz; aox = anc ? aox - t5[j] : aox; aoz = anc ? aoz - t6[j] : aoz;
     }
   }
   {
@@ -172,37 +184,54 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   }
   EG_SYNC();
   EG_PROF(0);
-  // ---- mass matrix row l and right-hand side l: bodies in ascending order
+  // ---- mass matrix row l and right-hand side l: bodies in ascending order.  Branch-free: as nested ifs (this lane's dof kind, k <= l, the
+  // ancestor bits) the block compiled to ~120 EXEC / scalar branches for Walker2d, most of them around ONE LDS load each — 119 serialised LDS
+  // round trips, 11.5k clock ticks of a 46k-tick evaluation (tools/env2d_phases.py).  Here every operand is requested up front and lanes / dofs
+  // that do not take part are masked by selects; the expressions and their order are the old ones (same bits).
   double Mrow[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) Mrow[k] = 0.0;
   double rhs = 0.0;
+  {
+    double hox[N], hoz[N], hsg[N];   // dof k >= 2: its hinge's origin and sign
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const double* Cm = E + O::BODY + b * O::BODY_F;
-    const double cx = Cm[9], cz = Cm[10];
-    const unsigned amb = (unsigned)m.ancmask[b];
-    // this lane's Jacobian entries of body b
-    double jxi, jzi, jpi;
-    if (l == 0) { jxi = 1.0; jzi = 0.0; jpi = 0.0; }
-    else if (l == 1) { jxi = 0.0; jzi = 1.0; jpi = 0.0; }
-    else {
-      const double sg = ((amb >> jb) & 1u) ? m.jsign[jb] : 0.0;
-      jxi = -sg * (cz - oz); jzi = sg * (cx - ox); jpi = sg;
+    for (int k = 2; k < N; ++k) {
+      const double* Km = E + O::BODY + (k - 2) * O::BODY_F;
+      hox[k] = Km[7]; hoz[k] = Km[8]; hsg[k] = m.jsign[k - 2];
     }
-    const double mb = m.mass[b], ib = m.inertia[b];
-    rhs += jxi * E[O::FRC + 2 * b] + jzi * E[O::FRC + 2 * b + 1];
+    const double jsl = m.jsign[jb];
+    double bcx[NB], bcz[NB], bf0[NB], bf1[NB], bm[NB], bi[NB];
+    unsigned bam[NB];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      double jxk, jzk, jpk;
-      if (k == 0) { jxk = 1.0; jzk = 0.0; jpk = 0.0; }
-      else if (k == 1) { jxk = 0.0; jzk = 1.0; jpk = 0.0; }
-      else {
-        const double* Km = E + O::BODY + (k - 2) * O::BODY_F;
-        const double sg = ((amb >> (k - 2)) & 1u) ? m.jsign[k - 2] : 0.0;
-        jxk = -sg * (cz - Km[8]); jzk = sg * (cx - Km[7]); jpk = sg;
+    for (int b = 0; b < NB; ++b) {
+      const double* Cm = E + O::BODY + b * O::BODY_F;
+      bcx[b] = Cm[9]; bcz[b] = Cm[10]; bf0[b] = E[O::FRC + 2 * b]; bf1[b] = E[O::FRC + 2 * b + 1];
+      bm[b] = m.mass[b]; bi[b] = m.inertia[b]; bam[b] = (unsigned)m.ancmask[b];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double cx = bcx[b], cz = bcz[b];
+      const unsigned amb = bam[b];
+      // this lane's Jacobian entries of body b
+      const double sgl = ((amb >> jb) & 1u) ? jsl : 0.0;
+      double jxi = -sgl * (cz - oz), jzi = sgl * (cx - ox), jpi = sgl;
+      jxi = l == 0 ? 1.0 : (l == 1 ? 0.0 : jxi);
+      jzi = l == 0 ? 0.0 : (l == 1 ? 1.0 : jzi);
+      jpi = l < 2 ? 0.0 : jpi;
+      const double mb = bm[b], ib = bi[b];
+      rhs += jxi * bf0[b] + jzi * bf1[b];
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double jxk, jzk, jpk;
+        if (k == 0) { jxk = 1.0; jzk = 0.0; jpk = 0.0; }
+        else if (k == 1) { jxk = 0.0; jzk = 1.0; jpk = 0.0; }
+        else {
+          const double sg = ((amb >> (k - 2)) & 1u) ? hsg[k] : 0.0;
+          jxk = -sg * (cz - hoz[k]); jzk = sg * (cx - hox[k]); jpk = sg;
+        }
+        const double add = mb * (jxi * jxk + jzi * jzk) + ib * jpi * jpk;
+        Mrow[k] = (k <= l) ? Mrow[k] + add : Mrow[k];
       }
-      if (k <= l) Mrow[k] += mb * (jxi * jxk + jzi * jzk) + ib * jpi * jpk;
     }
   }
   if (body) {
@@ -415,6 +444,8 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
   const PlanarModelDev& m = *reinterpret_cast<const PlanarModelDev*>(smd_all);
 #ifdef ILSX_EG_PROFILE
   const unsigned long long eg_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long eg_acc[16];
+  for (int i = 0; i < 16; ++i) eg_acc[i] = 0;
 #endif
   const int lane = threadIdx.x, l = lane & 15, grp = lane >> 4;
   double* E = smd_all + MODEL_DOUBLES + grp * O::TOTAL;
@@ -439,12 +470,16 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
   };
   const float obq0 = (l >= 1 && dof) ? obs_q(q) : 0.0f, obv0 = dof ? obs_v(v) : 0.0f;
   const double x0 = eg_bcast<0>(q);
+#ifdef ILSX_EG_PROFILE
+  { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); eg_acc[10] += __builtin_amdgcn_s_memtime() - eg_t0; }
+  const unsigned long long eg_t1 = __builtin_amdgcn_s_memtime();
+#endif
   const double h = m.timestep;
   for (int s = 0; s < m.frame_skip; ++s) {   // RK4, the oracle's accumulation order (env_substep)
     double qs = q, vs = v, qsum = 0.0, vsum = 0.0;
 #pragma unroll 1
     for (int stage = 0; stage < 4; ++stage) {
-      const double a = eg_dynamics<NB, MR>(m, qs, vs, torque, E, l, grp);
+      const double a = eg_dynamics<NB, MR>(m, qs, vs, torque, E, l, grp EG_PROF_ARG);
       const double w = (stage == 1 || stage == 2) ? 2.0 : 1.0;
       const double ch = (stage == 2) ? h : 0.5 * h;
       qsum = stage == 0 ? vs : qsum + w * vs;
@@ -456,6 +491,10 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
     q = q + h / 6.0 * qsum;
     v = v + h / 6.0 * vsum;
   }
+#ifdef ILSX_EG_PROFILE
+  const unsigned long long eg_t2 = __builtin_amdgcn_s_memtime();
+  eg_acc[11] += eg_t2 - eg_t1;   // the 16 evaluations and the integrator around them
+#endif
   const double dt = m.timestep * m.frame_skip;
   const double xq = eg_bcast<0>(q), zq = eg_bcast<1>(q), aq = eg_bcast<2>(q);
   const double reward = (xq - x0) / dt + m.alive - m.ctrl_cost * ctrl_sq;
@@ -532,7 +571,12 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
     if (dof) { A.qpos[(size_t)l * A.n_env + env] = q; A.qvel[(size_t)l * A.n_env + env] = v; }
   }
 #ifdef ILSX_EG_PROFILE
-  if (threadIdx.x == 0 && blockIdx.x == 0) { g_eg_prof[15] += __builtin_amdgcn_s_memtime() - eg_t0; g_eg_prof[14] += 1; }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    eg_acc[12] = t3 - eg_t2; eg_acc[15] = t3 - eg_t0; eg_acc[14] = 1;
+    for (int i = 0; i < 16; ++i) g_eg_prof[i] += eg_acc[i];
+  }
 #endif
 }
 

@@ -42,7 +42,8 @@ def main():
     inside = sum(out[i] for i in range(10))
     for i, nm in enumerate(NAMES):
         print(f"  {nm:28s} {out[i] / steps:9.0f} ticks / env step  {100.0 * out[i] / total:5.1f} %")
-    print(f"  {'outside the evaluations':28s} {(total - inside) / steps:9.0f} ticks / env step  {100.0 * (total - inside) / total:5.1f} %")
+    for nm, v in (("prologue (state, actions)", out[10]), ("integrator glue + stamps", out[11] - inside), ("epilogue (records, reset)", out[12])):
+        print(f"  {nm:28s} {v / steps:9.0f} ticks / env step  {100.0 * v / total:5.1f} %")
     env.close()
 
 
