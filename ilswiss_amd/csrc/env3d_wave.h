@@ -579,13 +579,15 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
       for (int i = 0; i < NV; ++i) z[i] = S[zr + i];
 #pragma unroll
       for (int i = 0; i < NV; ++i) jv += z[i] * S[voff + i];
+      // column by column: once z_t is final every later row takes its term L_it z_t — NV - t - 1 independent loads and multiply-adds, so the
+      // dependent chain is two operations per pivot (276 in the row-by-row form for Humanoid, where every term waited for its own broadcast
+      // load); a row still receives its terms in ascending t: the same sums
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        double sum = z[i];
+      for (int t = 0; t < NV; ++t) {
+        z[t] = z[t] * S[E3WOff::VEC + NVM + t];
+        aii += z[t] * z[t];
 #pragma unroll
-        for (int t = 0; t < i; ++t) sum -= S[E3WOff::M + i * (i + 1) / 2 + t] * z[t];
-        z[i] = sum * S[E3WOff::VEC + NVM + i];
-        aii += z[i] * z[i];
+        for (int i = t + 1; i < NV; ++i) z[i] -= S[E3WOff::M + i * (i + 1) / 2 + t] * z[t];
       }
 #pragma unroll
       for (int i = 0; i < NV; ++i) S[zr + i] = z[i];
