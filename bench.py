@@ -611,7 +611,24 @@ def main():
     dt = time.perf_counter() - t0
     per_rank_ms = R.gather(1e3 * dt / args.steps)
     dt, t_sample, t_train = R.max_over_ranks([dt, t_sample, t_train])
+    phase_timed = tr.phase_state()   # read HERE: the legs below put other contexts' kernels on this GPU, and a window that meets them falls back
     want_split = (world > 1 or os.environ.get("ILSX_BENCH_FORCE_DIST")) and not args.no_split_run
+
+    # ---- roofline leg (rank 0): HIP events around every kernel launch (library instrumentation; graph bypassed).  BEFORE the legs below: they
+    # put other contexts' kernels on this GPU, a train window that meets them is rolled back to one launch per stage and stays there, and the
+    # kernel this leg names would no longer be the one the timed loop ran (round 6's first lines named k_mlp2_fwd_split for that reason)
+    prof = {}
+    if rank == 0:
+        _lib.check(lib.ilsx_prof_reset(ctx.h))
+        _lib.check(lib.ilsx_prof_enable(ctx.h, 1))
+        tr.train_from_replay(rb, 200, B)
+        _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
+        for kid in range(16):
+            nl, ms = C.c_uint64(), C.c_double()
+            _lib.check(lib.ilsx_prof_read(ctx.h, kid, C.byref(nl), C.byref(ms)))
+            if nl.value:
+                prof[kid] = (kernel_spelling(lib, ctx, kid), nl.value, ms.value)
+    phase_roofline = tr.phase_state()
 
     # config 5's per-GPU shapes on EVERY rank (N > 1: 8 GPUs x grouped seeds — what north_star's "32 seeds x 1024 envs over 8 GPUs" means):
     # K = 8 grouped Hopper runs and 4 x 1024 grouped Humanoid runs, each rank on its own GPU, no collective in the data path
@@ -636,17 +653,6 @@ def main():
     if rank == 0:
         grad_total = world * args.steps * GRAD_PER_CALL
         env_total = world * args.steps * N_ENV
-        # ---- roofline leg: HIP events around every kernel launch (library instrumentation; graph bypassed)
-        _lib.check(lib.ilsx_prof_reset(ctx.h))
-        _lib.check(lib.ilsx_prof_enable(ctx.h, 1))
-        tr.train_from_replay(rb, 200, B)
-        _lib.check(lib.ilsx_prof_enable(ctx.h, 0))
-        prof = {}
-        for kid in range(16):
-            nl, ms = C.c_uint64(), C.c_double()
-            _lib.check(lib.ilsx_prof_read(ctx.h, kid, C.byref(nl), C.byref(ms)))
-            if nl.value:
-                prof[kid] = (kernel_spelling(lib, ctx, kid), nl.value, ms.value)
         fl = flops_per_step()
         # a slot's algorithmic FLOPs per step: the merged phase kernels (one launch = three stages) carry their own count
         def slot_flops(k):
@@ -720,7 +726,7 @@ def main():
             grad_steps_per_s_train_phase=grad_total / t_train, roofline=roofline, roofline_replay=roofline_replay,
             # which step path the timed loop ran on: the merged phase kernels (4 launches per step) unless a window had to be rolled back
             # (another process's kernels on this GPU) and the agent fell back to one launch per stage (include/ilsx.h ilsx_sac_phase_state)
-            phase_kernels=tr.phase_state(),
+            phase_kernels=phase_timed, phase_kernels_roofline_leg=phase_roofline, phase_kernels_after_legs=tr.phase_state(),
             # per-rank step times behind the max-over-ranks `value` (the driver computes efficiency itself from its per-N runs); the
             # replica leg has NO data-path collective, so a slow rank is a placement / clock matter, not a communication one
             scaling_detail=dict(per_rank_ms=per_rank_ms, max_over_min=max(per_rank_ms) / min(per_rank_ms), numa_rank0=numa,

@@ -120,10 +120,45 @@ struct EgOff {   // the env's LDS blackboard, in doubles
   static constexpr int TOTAL = ROWS + MR * 4;
 };
 
+// What lane l reads from the model in every evaluation and what depends on nothing but l: read ONCE per step.  A wavefront fence makes the
+// compiler re-read whatever came from memory, the model's LDS copy included, so inside eg_dynamics these were LDS round trips at the head
+// of dependent chains (ancestor mask -> sums; parent -> the parent's frame; geom -> its body -> the body's frame) and, for the constraint
+// rows' damping / stiffness, two fp64 divisions of model constants per evaluation.  Values, not loads; the arithmetic is unchanged.
+struct EgLaneK {
+  unsigned am, amg;
+  int parent, gb, max_rows, pgs_iters;
+  bool is_cand, limited;
+  double ax, az, cmx, cmz, mb, grav, jsl, arm, damp, stiff;
+  double rad, ex, ez, gfric, margin, lo, hi;
+  double bd_c, ks_c, bd_l, ks_l;
+};
+__device__ __forceinline__ void eg_lane_consts(const PlanarModelDev& m, int l, int N, EgLaneK& K) {
+  const int jb = l >= 2 && l < N ? l - 2 : 0;
+  K.am = (unsigned)m.ancmask[jb]; K.parent = m.parent[jb];
+  K.ax = m.anchor[jb][0]; K.az = m.anchor[jb][1]; K.cmx = m.com[jb][0]; K.cmz = m.com[jb][1];
+  K.mb = m.mass[jb]; K.grav = m.gravity; K.jsl = m.jsign[jb];
+  K.arm = m.armature[jb]; K.damp = m.damping[jb]; K.stiff = m.stiffness[jb];
+  K.is_cand = l < 2 * m.ng;
+  const int gi = K.is_cand ? m.ng - 1 - (l >> 1) : 0;
+  K.gb = m.geom_body[gi]; K.amg = (unsigned)m.ancmask[K.gb];
+  K.rad = m.grad[gi];
+  K.ex = (l & 1) == 0 ? m.gp1[gi][0] : m.gp2[gi][0]; K.ez = (l & 1) == 0 ? m.gp1[gi][1] : m.gp2[gi][1];
+  K.gfric = m.gfric[gi]; K.margin = m.margin; K.max_rows = m.max_rows; K.pgs_iters = m.pgs_iters;
+  K.limited = m.limited[jb]; K.lo = m.range[jb][0]; K.hi = m.range[jb][1];
+  {
+    const double tc = m.c_solref[0], dr = m.c_solref[1], dmax = m.c_solimp[1];
+    K.bd_c = 2.0 / (dmax * tc); K.ks_c = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+  }
+  {
+    const double tc = m.l_solref[0], dr = m.l_solref[1], dmax = m.l_solimp[1];
+    K.bd_l = 2.0 / (dmax * tc); K.ks_l = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+  }
+}
+
 // Forward dynamics for the env this 16-lane row serves.  In: this lane's q_l, v_l (0 beyond N), `torque` = gear * ctrl of the actuator
 // on this lane's hinge (0 if none).  Out: this lane's acceleration.  E = the env's blackboard.
 template <int NB, int MR>
-__device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q, double v, double torque, double* E, int l, int grp EG_PROF_PARAM) {
+__device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q, double v, double torque, double* E, int l, int grp, const EgLaneK& K EG_PROF_PARAM) {
   constexpr int N = NB + 2;
   using O = EgOff<NB, MR>;
   const bool dof = l < N;
@@ -134,7 +169,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   if (dof) { E[O::QV + l] = q; E[O::QV + N + l] = v; }
   EG_SYNC();
   // ---- kinematics of body jb: angle and rate = the ancestors' hinge terms, root to leaf
-  const unsigned am = (unsigned)m.ancmask[jb];
+  const unsigned am = K.am;
   double phi = 0.0, phid = 0.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -149,10 +184,10 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   if (body) { Bm[0] = cs; Bm[1] = sn; Bm[2] = phid; }
   EG_SYNC();
   {   // hinge offset from the parent's origin (world frame) and what the origin's acceleration loses there; zero for the root
-    const int p = m.parent[jb];
+    const int p = K.parent;
     const double* Pm = E + O::BODY + (p < 0 ? 0 : p) * O::BODY_F;
     const double pc = Pm[0], ps = Pm[1], pphid = Pm[2];
-    double wx = pc * m.anchor[jb][0] - ps * m.anchor[jb][1], wz = ps * m.anchor[jb][0] + pc * m.anchor[jb][1];
+    double wx = pc * K.ax - ps * K.az, wz = ps * K.ax + pc * K.az;
     double tax = pphid * pphid * wx, taz = pphid * pphid * wz;
     if (p < 0) { wx = 0.0; wz = 0.0; tax = 0.0; taz = 0.0; }
     if (body) { Bm[3] = wx; Bm[4] = wz; Bm[5] = tax; Bm[6] = taz; }
@@ -173,13 +208,13 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
     }
   }
   {
-    const double cwx = cs * m.com[jb][0] - sn * m.com[jb][1], cwz = sn * m.com[jb][0] + cs * m.com[jb][1];
+    const double cwx = cs * K.cmx - sn * K.cmz, cwz = sn * K.cmx + cs * K.cmz;
     const double cx = ox + cwx, cz = oz + cwz;
     const double acx = aox - phid * phid * cwx, acz = aoz - phid * phid * cwz;
-    const double mb = m.mass[jb];
+    const double mb = K.mb;
     if (body) {
       Bm[7] = ox; Bm[8] = oz; Bm[9] = cx; Bm[10] = cz;
-      E[O::FRC + 2 * jb] = mb * (0.0 - acx); E[O::FRC + 2 * jb + 1] = mb * (-m.gravity - acz);
+      E[O::FRC + 2 * jb] = mb * (0.0 - acx); E[O::FRC + 2 * jb + 1] = mb * (-K.grav - acz);
     }
   }
   EG_SYNC();
@@ -199,7 +234,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
       const double* Km = E + O::BODY + (k - 2) * O::BODY_F;
       hox[k] = Km[7]; hoz[k] = Km[8]; hsg[k] = m.jsign[k - 2];
     }
-    const double jsl = m.jsign[jb];
+    const double jsl = K.jsl;
     double bcx[NB], bcz[NB], bf0[NB], bf1[NB], bm[NB], bi[NB];
     unsigned bam[NB];
 #pragma unroll
@@ -237,8 +272,8 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   if (body) {
 #pragma unroll
     for (int k = 2; k < N; ++k)
-      if (k == l) Mrow[k] += m.armature[jb];
-    rhs -= m.damping[jb] * v + m.stiffness[jb] * q;
+      if (k == l) Mrow[k] += K.arm;
+    rhs -= K.damp * v + K.stiff * q;
     rhs += torque;
   }
   EG_PROF(1);
@@ -291,26 +326,24 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   // ---- constraint rows.  Contacts: candidate c = the capsule end points in the oracle's order (distal geoms first, p1 then p2).
   int ncon = 0, nr = 0;
   {
-    const int ng2 = 2 * m.ng;
-    const bool is_cand = l < ng2;
-    const int gi = is_cand ? m.ng - 1 - (l >> 1) : 0;
-    const int gb = m.geom_body[gi];
+    const bool is_cand = K.is_cand;
+    const int gb = K.gb;
     const double* Gm = E + O::BODY + gb * O::BODY_F;
-    const double bc = Gm[0], bs = Gm[1], box = Gm[7], boz = Gm[8], rad = m.grad[gi];
-    const double ex = (l & 1) == 0 ? m.gp1[gi][0] : m.gp2[gi][0], ez = (l & 1) == 0 ? m.gp1[gi][1] : m.gp2[gi][1];
+    const double bc = Gm[0], bs = Gm[1], box = Gm[7], boz = Gm[8], rad = K.rad;
+    const double ex = K.ex, ez = K.ez;
     const double wx = bc * ex - bs * ez, wz = bs * ex + bc * ez;
     const double dist = boz + wz - rad;
-    const bool active = is_cand && dist < m.margin;
+    const bool active = is_cand && dist < K.margin;
     const unsigned bal = (unsigned)((__ballot(active) >> (16 * grp)) & 0xFFFFull);
     const int rank = __popc(bal & ((1u << l) - 1u));
-    const bool accept = active && 2 * rank + 2 <= m.max_rows;
-    ncon = min(__popc(bal), m.max_rows / 2);
+    const bool accept = active && 2 * rank + 2 <= K.max_rows;
+    ncon = min(__popc(bal), K.max_rows / 2);
     if (accept) {
       const double px = box + wx, pz = boz + wz - (rad + 0.5 * dist);
       double* Jn = E + O::ROWJ + (2 * rank) * N;
       double* Jt = Jn + N;
       Jn[0] = 0.0; Jn[1] = 1.0; Jt[0] = 1.0; Jt[1] = 0.0;
-      const unsigned amg = (unsigned)m.ancmask[gb];
+      const unsigned amg = K.amg;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const double* Jm = E + O::BODY + j * O::BODY_F;
@@ -319,13 +352,13 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
       }
       const double d = impedance_d(fabs(dist), m.c_solimp);
       double* Sn = E + O::ROWS + (2 * rank) * 4;
-      Sn[0] = dist; Sn[1] = 0.0; Sn[2] = m.gfric[gi]; Sn[3] = d;
-      Sn[4] = 0.0; Sn[5] = 1.0; Sn[6] = m.gfric[gi]; Sn[7] = d;
+      Sn[0] = dist; Sn[1] = 0.0; Sn[2] = K.gfric; Sn[3] = d;
+      Sn[4] = 0.0; Sn[5] = 1.0; Sn[6] = K.gfric; Sn[7] = d;
     }
     // joint limits, bodies in ascending order
     double r = 0.0, sgn = 0.0;
-    if (body && m.limited[jb]) {
-      const double lo = m.range[jb][0], hi = m.range[jb][1];
+    if (body && K.limited) {
+      const double lo = K.lo, hi = K.hi;
       if (q - lo < 0.0) { r = q - lo; sgn = 1.0; }
       else if (hi - q < 0.0) { r = hi - q; sgn = -1.0; }
     }
@@ -333,14 +366,14 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
     const unsigned lbal = (unsigned)((__ballot(lact) >> (16 * grp)) & 0xFFFFull);
     const int lrank = __popc(lbal & ((1u << l) - 1u));
     const int row = 2 * ncon + lrank;
-    if (lact && row + 1 <= m.max_rows) {
+    if (lact && row + 1 <= K.max_rows) {
       double* Jl = E + O::ROWJ + row * N;
 #pragma unroll
       for (int i = 0; i < N; ++i) Jl[i] = (i == l) ? sgn : 0.0;
       double* Sl = E + O::ROWS + row * 4;
       Sl[0] = r; Sl[1] = 2.0; Sl[2] = 0.0; Sl[3] = impedance_d(fabs(r), m.l_solimp);
     }
-    nr = 2 * ncon + min(__popc(lbal), m.max_rows - 2 * ncon);
+    nr = 2 * ncon + min(__popc(lbal), K.max_rows - 2 * ncon);
   }
   // rows of the busiest env of this wavefront (wave-uniform trip counts below)
   int nrmax = max(max(__builtin_amdgcn_readlane(nr, 0), __builtin_amdgcn_readlane(nr, 16)),
@@ -371,10 +404,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
       for (int t = 0; t < i; ++t) sum -= E[O::LMAT + i * N + t] * x[t];
       x[i] = sum * invd[i];
     }
-    const double* sref = rkind == 2 ? m.l_solref : m.c_solref;
-    const double dmax = rkind == 2 ? m.l_solimp[1] : m.c_solimp[1];
-    const double tc = sref[0], dr = sref[1];
-    const double bdamp = 2.0 / (dmax * tc), kstiff = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+    const double bdamp = rkind == 2 ? K.bd_l : K.bd_c, kstiff = rkind == 2 ? K.ks_l : K.ks_c;   // 2 / (dmax tc), 1 / (dmax^2 tc^2 dr^2) of the row kind's solref / solimp
     if (rowl) rhs_c = (-bdamp * jv - kstiff * rd * rres) - ja;
   }
   EG_PROF(6);
@@ -386,16 +416,26 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   }
   EG_SYNC();
   // ---- row l of A = Z Z^T
+  // four rows of Z per LDS round trip (row by row, each behind its own wave-uniform test, the block was MR serialised round trips); rows of a
+  // batch beyond nrmax read stale blackboard words and are masked like every row beyond this env's nr
   double Arow[MR];
 #pragma unroll
-  for (int c = 0; c < MR; ++c) {
-    double sum = 0.0;
-    if (c < nrmax) {   // wave-uniform
-      const double* Zc = E + O::ROWJ + c * N;
+  for (int c0 = 0; c0 < MR; c0 += 4) {
+    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c0 < nrmax) {   // wave-uniform
+      double zc[4][N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) sum += x[i] * Zc[i];
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < N; ++i) zc[u][i] = (c0 + u < MR) ? E[O::ROWJ + (c0 + u) * N + i] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < N; ++i) sum[u] += x[i] * zc[u][i];
     }
-    Arow[c] = (rowl && c < nr) ? sum : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c0 + u < MR) Arow[c0 + u] = (rowl && c0 + u < nr) ? sum[u] : 0.0;
   }
   double att = 0.0;
 #pragma unroll
@@ -412,7 +452,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   // (lo_a, hi_a, hi_b) = (-mu, mu, 0), normal / limit rows (0, 0, +inf) — the same values as the two-branch form (a select per bound and
   // per lane), five instructions shorter per row and sweep on the chain that is most of this kernel
   const double lo_a = rkind == 1 ? -rmu : 0.0, hi_a = rkind == 1 ? rmu : 0.0, hi_b = rkind == 1 ? 0.0 : __builtin_huge_val();
-  for (int it = 0; it < m.pgs_iters; ++it) eg_pgs_sweep<0, MR>(fcopy, Arow, res, att, invden, lo_a, hi_a, hi_b, nrmax);
+  for (int it = 0; it < K.pgs_iters; ++it) eg_pgs_sweep<0, MR>(fcopy, Arow, res, att, invden, lo_a, hi_a, hi_b, nrmax);
   EG_PROF(8);
   // ---- q.. = qacc0 + L^-T (Z^T f)
   double w = 0.0;
@@ -470,6 +510,8 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
   };
   const float obq0 = (l >= 1 && dof) ? obs_q(q) : 0.0f, obv0 = dof ? obs_v(v) : 0.0f;
   const double x0 = eg_bcast<0>(q);
+  EgLaneK K;
+  eg_lane_consts(m, l, N, K);
 #ifdef ILSX_EG_PROFILE
   { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); eg_acc[10] += __builtin_amdgcn_s_memtime() - eg_t0; }
   const unsigned long long eg_t1 = __builtin_amdgcn_s_memtime();
@@ -479,7 +521,7 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
     double qs = q, vs = v, qsum = 0.0, vsum = 0.0;
 #pragma unroll 1
     for (int stage = 0; stage < 4; ++stage) {
-      const double a = eg_dynamics<NB, MR>(m, qs, vs, torque, E, l, grp EG_PROF_ARG);
+      const double a = eg_dynamics<NB, MR>(m, qs, vs, torque, E, l, grp, K EG_PROF_ARG);
       const double w = (stage == 1 || stage == 2) ? 2.0 : 1.0;
       const double ch = (stage == 2) ? h : 0.5 * h;
       qsum = stage == 0 ? vs : qsum + w * vs;

@@ -35,6 +35,10 @@ timeout 300 python tools/grouped_entry_rate.py exp_specs/sac/sac_hopper_refloop_
 timeout 60 python tools/fwd_rate.py 32768 > $OUT/fwd_rate.txt 2>&1
 timeout 120 python tools/step_gantt.py 8 > $OUT/step_gantt_K8.txt 2>&1
 (timeout 100 python tools/env3d_rate.py humanoid 1024 40; timeout 100 python tools/env3d_rate.py ant 1024 40) > $OUT/env3d_rate.txt 2>&1
+timeout 200 python tools/env_rate.py > $OUT/env2d_rate.txt 2>&1
+# stage clock of the planar stepper (measurement build: make -C ilswiss_amd/csrc VAR=egprof VARFLAGS=-DILSX_EG_PROFILE; skipped when it has not been built)
+[ -f ilswiss_amd/libilsx_egprof.so ] && (for t in hopper walker halfcheetah; do ILSX_LIB=ilswiss_amd/libilsx_egprof.so timeout 100 python tools/env2d_phases.py $t 4096; done) > $OUT/env2d_phases.txt 2>&1
+timeout 300 bash tools/ab_dw_low.sh > $OUT/dw_low_ab.txt 2>&1
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC tools/ubench/env3d_phases.hip -o /tmp/libe3p.so 2> /dev/null
 (python tools/ubench/env3d_phases.py humanoid 1024 8; python tools/ubench/env3d_phases.py ant 1024 8) > $OUT/env3d_phases.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
