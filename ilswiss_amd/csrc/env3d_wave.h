@@ -58,6 +58,7 @@ typedef __attribute__((address_space(3))) double e3w_lds;
 // Per-lane values that live across phases (registers on the device: one instance per lane; an array of 64 under host emulation)
 struct E3WRegs {
   int ri[6], tj[6];   // the lower-triangle entries t = lane + 64 s this lane owns in the factorisation: row base i (i + 1) / 2 and column j (-1: none)
+  int tjt[6];         // tj (tj + 1) / 2: the row base of ROW tj (where the factorisation step k reads M[tj][k])
   // constants of link l == lane (the tree recursions map link l to lane l), so that no phase waits on the model in global memory
   int parent, depth, act, limited;
   unsigned anc;
@@ -103,12 +104,23 @@ __device__ __forceinline__ int e3w_tri_row(int t) {   // row of lower-triangle i
   return r;
 }
 
+// the last ROW of the triangle that slot s (entries 64 s .. 64 s + 63, row-major) holds, for an nv x nv matrix: step k of the factorisation
+// touches entries of rows > k only, so a slot whose last row is <= k has nothing left to do — for every lane, known at compile time
+__device__ constexpr int e3w_slot_last_row(int s, int nv) {
+  int t = 64 * s + 63;
+  const int nt = nv * (nv + 1) / 2;
+  if (t > nt - 1) t = nt - 1;
+  int r = 0;
+  while ((r + 1) * (r + 2) / 2 <= t) ++r;
+  return r;
+}
+
 __device__ __forceinline__ void e3w_regs_init(E3WRegs& R, const Spatial3Dev& m, int ln) {
   const int nv = m.nv;
   for (int s = 0; s < 6; ++s) {
     const int t = ln + 64 * s;
-    R.ri[s] = 0; R.tj[s] = -1;
-    if (t < nv * (nv + 1) / 2) { const int i = e3w_tri_row(t); R.ri[s] = i * (i + 1) / 2; R.tj[s] = t - R.ri[s]; }
+    R.ri[s] = 0; R.tj[s] = -1; R.tjt[s] = 0;
+    if (t < nv * (nv + 1) / 2) { const int i = e3w_tri_row(t); R.ri[s] = i * (i + 1) / 2; R.tj[s] = t - R.ri[s]; R.tjt[s] = R.tj[s] * (R.tj[s] + 1) / 2; }
   }
   const int l = ln < m.nl ? ln : 0;
   R.parent = m.parent[l]; R.depth = ln < m.nl ? m.depth[l] : -1; R.act = m.link_act[l]; R.limited = ln >= 1 && ln < m.nl && m.limited[l];
@@ -131,7 +143,7 @@ __device__ __forceinline__ void e3w_regs_pin(E3WRegs& R) {
   asm volatile("" : "+v"(R.parent), "+v"(R.depth), "+v"(R.act), "+v"(R.anc));
   for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(R.anchor[i]), "+v"(R.axis_p[i]));
   asm volatile("" : "+v"(R.damping), "+v"(R.stiffness), "+v"(R.armature), "+v"(R.gear));
-  for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(R.ri[s]), "+v"(R.tj[s]));
+  for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(R.ri[s]), "+v"(R.tj[s]), "+v"(R.tjt[s]));
   // wave-uniform ones: through readfirstlane, so that they are scalar values
   R.nl = __builtin_amdgcn_readfirstlane(R.nl); R.n_level = __builtin_amdgcn_readfirstlane(R.n_level);
   R.nc = __builtin_amdgcn_readfirstlane(R.nc); R.max_rows = __builtin_amdgcn_readfirstlane(R.max_rows);
@@ -425,6 +437,33 @@ __device__ __forceinline__ void e3w_dynamics(e3w_lds* S, const Spatial3Dev& m, i
   // (M_ik M_jk / M_kk), so a step is one fence-to-fence phase; the columns are scaled by 1 / sqrt(pivot) in one pass at the end.
   E3W_MARK("chol begin");
   constexpr int NSLOT = NV > 0 ? (NV * (NV + 1) / 2 + 63) / 64 : 6;
+  if constexpr (NV > 0) {
+    // the pivot as a compile-time value: slots that hold no row beyond k are skipped for the whole wavefront (Humanoid: 88 slot steps instead
+    // of 115), the test against k is a compare with an immediate and row tj's base comes from a register (E3WRegs::tjt) — the step is a
+    // count of issued instructions (§3b): ~110 per pivot before.  Same operations on the entries that are touched.
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const double pinv = e3w_rcp(S[E3WOff::M + e3_tri(k, k)]);
+      E3W_FOR(ln, 64) {
+        const E3WRegs& R = E3W_REGS(ln);
+        double ci[NSLOT], cj[NSLOT], mt[NSLOT];
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {   // loads are unconditional (every address is inside the triangle), the store is not
+          if (e3w_slot_last_row(sl, NV) <= k) continue;
+          ci[sl] = S[E3WOff::M + R.ri[sl] + k];
+          cj[sl] = S[E3WOff::M + (R.tj[sl] > k ? R.tjt[sl] + k : 0)];
+          mt[sl] = S[E3WOff::M + ln + 64 * sl];
+        }
+        E3W_LOADS_FIRST();
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+          if (e3w_slot_last_row(sl, NV) <= k) continue;
+          if (R.tj[sl] > k) S[E3WOff::M + ln + 64 * sl] = mt[sl] - ci[sl] * cj[sl] * pinv;
+        }
+      }
+      E3W_SYNC();
+    }
+  } else
   for (int k = 0; k < nv; ++k) {
     const double pinv = e3w_rcp(S[E3WOff::M + e3_tri(k, k)]);
     E3W_FOR(ln, 64) {
