@@ -53,3 +53,21 @@ def test_grouped_acceptance_runs_reproduce_round_5_cell_for_cell():
     import returns_compare
     seeds, bad = returns_compare.same(os.path.join(ROOT, "profiles", "r06_returns_grouped"), os.path.join(ROOT, "profiles", "r05_returns_hip"))
     assert len(seeds) >= 10 and bad == 0, (seeds, bad)
+
+def test_last_session_acceptance_run_repeats_the_earlier_one_cell_for_cell():
+    """profiles/r06b_returns_async (ten grouped seeds of the reference schedule with eval_async, run AFTER the steppers' Gauss-Seidel loops, mass
+    matrix, lane constants and the grouped weight-gradient tiles were rewritten — DESIGN §3i) against profiles/r06_returns_async (the same
+    command on the tree before): every rollout column of every epoch both hold is identical — the rewrites did not move a bit of a Hopper run."""
+    import csv
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import returns_compare as rc
+    n_seeds = 0
+    for s in range(10):
+        a = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06b_returns_async", f"seed{s}.csv"))))
+        b = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_returns_async", f"seed{s}.csv"))))
+        cols = [k for k in a[0] if k.startswith(rc.ROLLOUT_COLUMNS) or k in rc.ROLLOUT_COLUMNS]
+        n = min(len(a), len(b))
+        assert n >= 103 and len(cols) >= 10
+        assert all(ra[k] == rb[k] for ra, rb in zip(a[:n], b[:n]) for k in cols), s
+        n_seeds += 1
+    assert n_seeds == 10

@@ -19,6 +19,6 @@ import csv
 rows = list(csv.DictReader(open("gpurun_out/r02_${SPEC}_progress.csv")))
 print(len(rows), "epochs")
 for r in rows[::6] + rows[-3:]:
-    print(r["Epoch"], r["Number of env steps total"], r["Number of train steps total"], round(float(r["AverageReturn"]), 1),
+    print(r["Epoch"], r["Number of env steps total"], r.get("Number of train steps total", r.get("Number of gradient steps total")), round(float(r["AverageReturn"]), 1),
           round(float(r["Test Ep. Len. Mean"]), 1), round(float(r["Disc Acc"]), 3), round(float(r["Disc Rew Mean"]), 3), "alpha", round(float(r["Alpha"]), 3), round(float(r["Total Train Time (s)"]), 1))
 PY
