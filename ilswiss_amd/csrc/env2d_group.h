@@ -169,7 +169,8 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   if (dof) { E[O::QV + l] = q; E[O::QV + N + l] = v; }
   EG_SYNC();
   // ---- kinematics of body jb: angle and rate = the ancestors' hinge terms, root to leaf
-  const unsigned am = K.am;
+  constexpr bool UK = NB <= 4;   // the lane constants in registers (Hopper); the 7-body models keep reading the model: their step must fit 256 registers
+  const unsigned am = UK ? K.am : (unsigned)m.ancmask[jb];
   double phi = 0.0, phid = 0.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -184,10 +185,11 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   if (body) { Bm[0] = cs; Bm[1] = sn; Bm[2] = phid; }
   EG_SYNC();
   {   // hinge offset from the parent's origin (world frame) and what the origin's acceleration loses there; zero for the root
-    const int p = K.parent;
+    const int p = UK ? K.parent : m.parent[jb];
     const double* Pm = E + O::BODY + (p < 0 ? 0 : p) * O::BODY_F;
     const double pc = Pm[0], ps = Pm[1], pphid = Pm[2];
-    double wx = pc * K.ax - ps * K.az, wz = ps * K.ax + pc * K.az;
+    const double anx = UK ? K.ax : m.anchor[jb][0], anz = UK ? K.az : m.anchor[jb][1];
+    double wx = pc * anx - ps * anz, wz = ps * anx + pc * anz;
     double tax = pphid * pphid * wx, taz = pphid * pphid * wz;
     if (p < 0) { wx = 0.0; wz = 0.0; tax = 0.0; taz = 0.0; }
     if (body) { Bm[3] = wx; Bm[4] = wz; Bm[5] = tax; Bm[6] = taz; }
@@ -208,13 +210,14 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
     }
   }
   {
-    const double cwx = cs * K.cmx - sn * K.cmz, cwz = sn * K.cmx + cs * K.cmz;
+    const double cmx = UK ? K.cmx : m.com[jb][0], cmz = UK ? K.cmz : m.com[jb][1];
+    const double cwx = cs * cmx - sn * cmz, cwz = sn * cmx + cs * cmz;
     const double cx = ox + cwx, cz = oz + cwz;
     const double acx = aox - phid * phid * cwx, acz = aoz - phid * phid * cwz;
-    const double mb = K.mb;
+    const double mb = UK ? K.mb : m.mass[jb];
     if (body) {
       Bm[7] = ox; Bm[8] = oz; Bm[9] = cx; Bm[10] = cz;
-      E[O::FRC + 2 * jb] = mb * (0.0 - acx); E[O::FRC + 2 * jb + 1] = mb * (-K.grav - acz);
+      E[O::FRC + 2 * jb] = mb * (0.0 - acx); E[O::FRC + 2 * jb + 1] = mb * (-(UK ? K.grav : m.gravity) - acz);
     }
   }
   EG_SYNC();
@@ -234,7 +237,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
       const double* Km = E + O::BODY + (k - 2) * O::BODY_F;
       hox[k] = Km[7]; hoz[k] = Km[8]; hsg[k] = m.jsign[k - 2];
     }
-    const double jsl = K.jsl;
+    const double jsl = UK ? K.jsl : m.jsign[jb];
     double bcx[NB], bcz[NB], bf0[NB], bf1[NB], bm[NB], bi[NB];
     unsigned bam[NB];
 #pragma unroll
@@ -272,8 +275,8 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   if (body) {
 #pragma unroll
     for (int k = 2; k < N; ++k)
-      if (k == l) Mrow[k] += K.arm;
-    rhs -= K.damp * v + K.stiff * q;
+      if (k == l) Mrow[k] += UK ? K.arm : m.armature[jb];
+    rhs -= (UK ? K.damp : m.damping[jb]) * v + (UK ? K.stiff : m.stiffness[jb]) * q;
     rhs += torque;
   }
   EG_PROF(1);
@@ -326,24 +329,26 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   // ---- constraint rows.  Contacts: candidate c = the capsule end points in the oracle's order (distal geoms first, p1 then p2).
   int ncon = 0, nr = 0;
   {
-    const bool is_cand = K.is_cand;
-    const int gb = K.gb;
+    const bool is_cand = UK ? K.is_cand : l < 2 * m.ng;
+    const int gi = is_cand ? m.ng - 1 - (l >> 1) : 0;   // (unused when the lane constants are)
+    const int gb = UK ? K.gb : m.geom_body[gi];
+    const int max_rows = UK ? K.max_rows : m.max_rows;
     const double* Gm = E + O::BODY + gb * O::BODY_F;
-    const double bc = Gm[0], bs = Gm[1], box = Gm[7], boz = Gm[8], rad = K.rad;
-    const double ex = K.ex, ez = K.ez;
+    const double bc = Gm[0], bs = Gm[1], box = Gm[7], boz = Gm[8], rad = UK ? K.rad : m.grad[gi];
+    const double ex = UK ? K.ex : ((l & 1) == 0 ? m.gp1[gi][0] : m.gp2[gi][0]), ez = UK ? K.ez : ((l & 1) == 0 ? m.gp1[gi][1] : m.gp2[gi][1]);
     const double wx = bc * ex - bs * ez, wz = bs * ex + bc * ez;
     const double dist = boz + wz - rad;
-    const bool active = is_cand && dist < K.margin;
+    const bool active = is_cand && dist < (UK ? K.margin : m.margin);
     const unsigned bal = (unsigned)((__ballot(active) >> (16 * grp)) & 0xFFFFull);
     const int rank = __popc(bal & ((1u << l) - 1u));
-    const bool accept = active && 2 * rank + 2 <= K.max_rows;
-    ncon = min(__popc(bal), K.max_rows / 2);
+    const bool accept = active && 2 * rank + 2 <= max_rows;
+    ncon = min(__popc(bal), max_rows / 2);
     if (accept) {
       const double px = box + wx, pz = boz + wz - (rad + 0.5 * dist);
       double* Jn = E + O::ROWJ + (2 * rank) * N;
       double* Jt = Jn + N;
       Jn[0] = 0.0; Jn[1] = 1.0; Jt[0] = 1.0; Jt[1] = 0.0;
-      const unsigned amg = K.amg;
+      const unsigned amg = UK ? K.amg : (unsigned)m.ancmask[gb];
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const double* Jm = E + O::BODY + j * O::BODY_F;
@@ -352,13 +357,14 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
       }
       const double d = impedance_d(fabs(dist), m.c_solimp);
       double* Sn = E + O::ROWS + (2 * rank) * 4;
-      Sn[0] = dist; Sn[1] = 0.0; Sn[2] = K.gfric; Sn[3] = d;
-      Sn[4] = 0.0; Sn[5] = 1.0; Sn[6] = K.gfric; Sn[7] = d;
+      const double gfr = UK ? K.gfric : m.gfric[gi];
+      Sn[0] = dist; Sn[1] = 0.0; Sn[2] = gfr; Sn[3] = d;
+      Sn[4] = 0.0; Sn[5] = 1.0; Sn[6] = gfr; Sn[7] = d;
     }
     // joint limits, bodies in ascending order
     double r = 0.0, sgn = 0.0;
-    if (body && K.limited) {
-      const double lo = K.lo, hi = K.hi;
+    if (body && (UK ? K.limited : (bool)m.limited[jb])) {
+      const double lo = UK ? K.lo : m.range[jb][0], hi = UK ? K.hi : m.range[jb][1];
       if (q - lo < 0.0) { r = q - lo; sgn = 1.0; }
       else if (hi - q < 0.0) { r = hi - q; sgn = -1.0; }
     }
@@ -366,14 +372,14 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
     const unsigned lbal = (unsigned)((__ballot(lact) >> (16 * grp)) & 0xFFFFull);
     const int lrank = __popc(lbal & ((1u << l) - 1u));
     const int row = 2 * ncon + lrank;
-    if (lact && row + 1 <= K.max_rows) {
+    if (lact && row + 1 <= max_rows) {
       double* Jl = E + O::ROWJ + row * N;
 #pragma unroll
       for (int i = 0; i < N; ++i) Jl[i] = (i == l) ? sgn : 0.0;
       double* Sl = E + O::ROWS + row * 4;
       Sl[0] = r; Sl[1] = 2.0; Sl[2] = 0.0; Sl[3] = impedance_d(fabs(r), m.l_solimp);
     }
-    nr = 2 * ncon + min(__popc(lbal), K.max_rows - 2 * ncon);
+    nr = 2 * ncon + min(__popc(lbal), max_rows - 2 * ncon);
   }
   // rows of the busiest env of this wavefront (wave-uniform trip counts below)
   int nrmax = max(max(__builtin_amdgcn_readlane(nr, 0), __builtin_amdgcn_readlane(nr, 16)),
@@ -404,7 +410,14 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
       for (int t = 0; t < i; ++t) sum -= E[O::LMAT + i * N + t] * x[t];
       x[i] = sum * invd[i];
     }
-    const double bdamp = rkind == 2 ? K.bd_l : K.bd_c, kstiff = rkind == 2 ? K.ks_l : K.ks_c;   // 2 / (dmax tc), 1 / (dmax^2 tc^2 dr^2) of the row kind's solref / solimp
+    double bdamp, kstiff;   // 2 / (dmax tc), 1 / (dmax^2 tc^2 dr^2) of the row kind's solref / solimp
+    if (UK) { bdamp = rkind == 2 ? K.bd_l : K.bd_c; kstiff = rkind == 2 ? K.ks_l : K.ks_c; }
+    else {
+      const double* sref = rkind == 2 ? m.l_solref : m.c_solref;
+      const double dmax = rkind == 2 ? m.l_solimp[1] : m.c_solimp[1];
+      const double tc = sref[0], dr = sref[1];
+      bdamp = 2.0 / (dmax * tc); kstiff = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+    }
     if (rowl) rhs_c = (-bdamp * jv - kstiff * rd * rres) - ja;
   }
   EG_PROF(6);
@@ -416,25 +429,29 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   }
   EG_SYNC();
   // ---- row l of A = Z Z^T
-  // four rows of Z per LDS round trip (row by row, each behind its own wave-uniform test, the block was MR serialised round trips); rows of a
-  // batch beyond nrmax read stale blackboard words and are masked like every row beyond this env's nr
+  // CB rows of Z per LDS round trip (row by row, each behind its own wave-uniform test, the block was MR serialised round trips); rows of a
+  // batch beyond nrmax read stale blackboard words and are masked like every row beyond this env's nr.  CB = 4 for Hopper, 2 for the 7-body
+  // models: their step must stay within 256 registers (two wavefronts per SIMD from 8192 envs on)
+  constexpr int CB = N > 6 ? 2 : 4;
   double Arow[MR];
 #pragma unroll
-  for (int c0 = 0; c0 < MR; c0 += 4) {
-    double sum[4] = {0.0, 0.0, 0.0, 0.0};
-    if (c0 < nrmax) {   // wave-uniform
-      double zc[4][N];
+  for (int c0 = 0; c0 < MR; c0 += CB) {
+    double sum[CB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < CB; ++u) sum[u] = 0.0;
+    if (c0 < nrmax) {   // wave-uniform
+      double zc[CB][N];
+#pragma unroll
+      for (int u = 0; u < CB; ++u)
 #pragma unroll
         for (int i = 0; i < N; ++i) zc[u][i] = (c0 + u < MR) ? E[O::ROWJ + (c0 + u) * N + i] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < CB; ++u)
 #pragma unroll
         for (int i = 0; i < N; ++i) sum[u] += x[i] * zc[u][i];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < CB; ++u)
       if (c0 + u < MR) Arow[c0 + u] = (rowl && c0 + u < nr) ? sum[u] : 0.0;
   }
   double att = 0.0;
@@ -452,7 +469,7 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
   // (lo_a, hi_a, hi_b) = (-mu, mu, 0), normal / limit rows (0, 0, +inf) — the same values as the two-branch form (a select per bound and
   // per lane), five instructions shorter per row and sweep on the chain that is most of this kernel
   const double lo_a = rkind == 1 ? -rmu : 0.0, hi_a = rkind == 1 ? rmu : 0.0, hi_b = rkind == 1 ? 0.0 : __builtin_huge_val();
-  for (int it = 0; it < K.pgs_iters; ++it) eg_pgs_sweep<0, MR>(fcopy, Arow, res, att, invden, lo_a, hi_a, hi_b, nrmax);
+  for (int it = 0, n_it = UK ? K.pgs_iters : m.pgs_iters; it < n_it; ++it) eg_pgs_sweep<0, MR>(fcopy, Arow, res, att, invden, lo_a, hi_a, hi_b, nrmax);
   EG_PROF(8);
   // ---- q.. = qacc0 + L^-T (Z^T f)
   double w = 0.0;
@@ -511,7 +528,7 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
   const float obq0 = (l >= 1 && dof) ? obs_q(q) : 0.0f, obv0 = dof ? obs_v(v) : 0.0f;
   const double x0 = eg_bcast<0>(q);
   EgLaneK K;
-  eg_lane_consts(m, l, N, K);
+  if (NB <= 4) eg_lane_consts(m, l, N, K);
 #ifdef ILSX_EG_PROFILE
   { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); eg_acc[10] += __builtin_amdgcn_s_memtime() - eg_t0; }
   const unsigned long long eg_t1 = __builtin_amdgcn_s_memtime();
@@ -623,7 +640,9 @@ __device__ __forceinline__ void envg_step_dev(const EnvStepArgs& A) {
 }
 
 template <int NB, int MR>
-__global__ __launch_bounds__(64) void k_envg_step(const EnvStepArgs A) { envg_step_dev<NB, MR>(A); }
+// two wavefronts per SIMD must fit (8192 envs and more: 256 registers each, accumulation registers included) — with launch bounds alone the
+// compiler budgets a lone wavefront's 512 and the 7-body instances took 284: 591 against 432 us per 8192-env Walker2d step
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_envg_step(const EnvStepArgs A) { envg_step_dev<NB, MR>(A); }
 
 // The same step for several RUNS in one launch (the lock-step rollout of co-resident seeds, ilsx_rollout_steps_lockstep): blockIdx.y = run,
 // every run with its own state, model record, actions, ring / staging area, Philox key and step counter — a row of the grid is exactly the
@@ -632,4 +651,4 @@ __global__ __launch_bounds__(64) void k_envg_step(const EnvStepArgs A) { envg_st
 struct EnvStepGroupArgs { EnvStepArgs a[ENVG_MAX_RUNS]; };
 static_assert(sizeof(EnvStepGroupArgs) <= 4096, "the runs' records travel in the kernel-argument segment (4 KB)");
 template <int NB, int MR>
-__global__ __launch_bounds__(64) void k_envg_step_runs(const EnvStepGroupArgs G) { envg_step_dev<NB, MR>(G.a[blockIdx.y]); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_envg_step_runs(const EnvStepGroupArgs G) { envg_step_dev<NB, MR>(G.a[blockIdx.y]); }

@@ -1,11 +1,11 @@
-"""Env-stepper throughput (fused rollout_step with random actions), per model."""
-import sys, time
+"""Env-stepper throughput (fused rollout_step with random actions), per model.  ENV_RATE_N = number of envs (default 4096)."""
+import os, sys, time
 sys.path.insert(0, ".")
 import ilswiss_amd as ia
 from ilswiss_amd.envs.vecenv import HipVectorEnv
 ctx = ia.Context()
 for name in sys.argv[1:] or ["hopper", "walker", "halfcheetah"]:
-    n = 4096
+    n = int(os.environ.get("ENV_RATE_N", "4096"))
     env = HipVectorEnv(name, n, seed=1, ctx=ctx)
     rb = ia.SimpleReplayBuffer(64 * n, env.obs_dim, env.act_dim, ctx=ctx)
     env.reset()
