@@ -115,7 +115,7 @@ def grouped_insts_per_mfma():
         return None
     out = dict(source=os.path.relpath(files[-1], ROOT), stale=d.get("_meta", {}).get("csrc_sha256") != csrc_sha256())
     for k in ("k_mlp2_fwd_split", "k_mlp2_bwd_split", "k_mlp_bwd_dw"):
-        v = d.get(k)
+        v = d.get(k) or d.get(k + "_low")   # the grouped weight-gradient tile's eight-waves-per-SIMD instance (k_mlp_bwd_dw_low)
         if not v or not v.get("SQ_INSTS_MFMA"):
             continue
         mf = v["SQ_INSTS_MFMA"]

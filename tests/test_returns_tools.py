@@ -62,12 +62,13 @@ def test_last_session_acceptance_run_repeats_the_earlier_one_cell_for_cell():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import returns_compare as rc
     n_seeds = 0
-    for s in range(10):
-        a = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06b_returns_async", f"seed{s}.csv"))))
-        b = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_returns_async", f"seed{s}.csv"))))
-        cols = [k for k in a[0] if k.startswith(rc.ROLLOUT_COLUMNS) or k in rc.ROLLOUT_COLUMNS]
-        n = min(len(a), len(b))
-        assert n >= 103 and len(cols) >= 10
-        assert all(ra[k] == rb[k] for ra, rb in zip(a[:n], b[:n]) for k in cols), s
-        n_seeds += 1
-    assert n_seeds == 10
+    for run in ("r06b_returns_async", "r06c_returns_async"):   # mid-session tree ; the round's final tree (tools/final_evidence.sh)
+        for s in range(10):
+            a = list(csv.DictReader(open(os.path.join(ROOT, "profiles", run, f"seed{s}.csv"))))
+            b = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_returns_async", f"seed{s}.csv"))))
+            cols = [k for k in a[0] if k.startswith(rc.ROLLOUT_COLUMNS) or k in rc.ROLLOUT_COLUMNS]
+            n = min(len(a), len(b))
+            assert n >= 103 and len(cols) >= 10
+            assert all(ra[k] == rb[k] for ra, rb in zip(a[:n], b[:n]) for k in cols), (run, s)
+            n_seeds += 1
+    assert n_seeds == 20
