@@ -393,6 +393,15 @@ RCCL_ENV_KEYS = ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHA
                  "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")
 
 
+def _flush_c_stdio():
+    """fflush(NULL): whatever native libraries (RCCL) left in the C stdio buffers goes out now, not at process exit"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+
+
 class Ranks:
     """Process-group plumbing shared by the real run and the CPU dry run (tests/test_bench_spawn.py): backend "nccl" (= RCCL)
     on GPUs, "gloo" for --dry-run."""
@@ -776,9 +785,30 @@ def main():
         done.set()
         if rank == 0 and split is not None:
             result["split_run"] = split
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    R.close()
+    # The JSON line is the LAST thing on stdout.  RCCL's version banner (the GPU boxes export NCCL_DEBUG=VERSION) sits in every rank's C stdio
+    # buffer until that process exits — behind a line rank 0 printed earlier; so every rank flushes its C streams, the ranks meet once more
+    # (R.close: barrier + destroy), and only then rank 0 prints.  A final rendezvous that hangs or raises does not keep the line in: a timer emits it.
+    import threading
+    sys.stdout.flush()
+    _flush_c_stdio()
+    line = json.dumps(result) if rank == 0 else None
+    emitted = threading.Event()
+
+    def emit():
+        if rank == 0 and not emitted.is_set():
+            emitted.set()
+            print(line, flush=True)
+    if R.dist is not None:
+        timer = threading.Timer(90.0, lambda: (emit(), os._exit(0)))
+        timer.daemon = True
+        timer.start()
+        try:
+            R.close()
+        except Exception:   # noqa: BLE001 — the communicator is gone; the line still comes out
+            pass
+        timer.cancel()
+        _flush_c_stdio()
+    emit()
     ctx.close()
     return result
 
