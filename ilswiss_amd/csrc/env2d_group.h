@@ -349,11 +349,18 @@ __device__ __forceinline__ double eg_dynamics(const PlanarModelDev& m, double q,
       double* Jt = Jn + N;
       Jn[0] = 0.0; Jn[1] = 1.0; Jt[0] = 1.0; Jt[1] = 0.0;
       const unsigned amg = UK ? K.amg : (unsigned)m.ancmask[gb];
+      {   // every body's origin and hinge sign requested first (no branch on the ancestor bit around a load: one round trip, not NB)
+        double jo7[NB], jo8[NB], jsg[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const double* Jm = E + O::BODY + j * O::BODY_F;
-        const double sg = ((amg >> j) & 1u) ? m.jsign[j] : 0.0;
-        Jn[2 + j] = sg * (px - Jm[7]); Jt[2 + j] = -sg * (pz - Jm[8]);
+        for (int j = 0; j < NB; ++j) {
+          const double* Jm = E + O::BODY + j * O::BODY_F;
+          jo7[j] = Jm[7]; jo8[j] = Jm[8]; jsg[j] = m.jsign[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const double sg = ((amg >> j) & 1u) ? jsg[j] : 0.0;
+          Jn[2 + j] = sg * (px - jo7[j]); Jt[2 + j] = -sg * (pz - jo8[j]);
+        }
       }
       const double d = impedance_d(fabs(dist), m.c_solimp);
       double* Sn = E + O::ROWS + (2 * rank) * 4;
