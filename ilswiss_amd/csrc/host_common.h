@@ -154,8 +154,20 @@ int launch_bwd_dx(ilsx_ctx* ctx, const BwdArgs& A, int H, int act, int cs = 1);
 int launch_policy_finish(ilsx_ctx* ctx, const PolicyFinishArgs& P);
 // merged phase kernels of the single-run SAC step (kernels.h); phase_fits: every workgroup of such a launch is resident at once
 bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks);
-int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P, int H, int act, int KPmax, int cs);
-int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P, int H, int act, int KPmax, int cs);
+// The phase kernels' descriptor blocks in CONSTANT memory (kernels.h g_phase_a_tab / g_phase_c_tab, `CT` instances): one slot per agent, the
+// host's copy of what the slot holds.  slot < 0: none (table full, or ILSX_PHASE_CT=0): the block travels in the kernel arguments as before.
+struct PhaseConst {
+  int slot = -1, device = 0;
+  bool tried = false, valid_a = false, valid_c = false;
+  unsigned long long key_a = 0, key_c = 0;   // what the held blocks were built from (the owner's state key: the blocks are a function of it; their
+                                             // bytes cannot be compared — padding of by-value sub-records is whatever the stack held)
+  PhaseAArgs a; PhaseCArgs c;
+};
+int phase_const_alloc(int device);            // a free slot of that device's tables, or -1
+void phase_const_prepare(ilsx_ctx* ctx, PhaseConst* ct);   // first use: take a slot (once; none free = stays without)
+void phase_const_free(int device, int slot);
+int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P, int H, int act, int KPmax, int cs, PhaseConst* ct = nullptr, unsigned long long key = 0, bool upload_only = false);
+int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P, int H, int act, int KPmax, int cs, PhaseConst* ct = nullptr, unsigned long long key = 0, bool upload_only = false);
 int device_cus(ilsx_ctx* ctx);   // compute units of the context's device
 // constant-memory descriptor tables of grouped launches (kernels.h g_fwd_tab / g_bwd_tab): slots per device, first fit; -1 = none free
 int grp_const_alloc(int device, bool fwd, int n, int* base);

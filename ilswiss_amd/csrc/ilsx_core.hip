@@ -357,6 +357,8 @@ static int kernels_init_once() {
   SET_MT(ACT_RELU, 2); SET_MT(ACT_RELU, 4); SET_MT(ACT_TANH, 2); SET_MT(ACT_TANH, 4);
 #undef SET_MT
 #define SET_PHASE(HH, AA, CC) HIPCHK(hipFuncSetAttribute((const void*)k_sac_phase_a<HH, AA, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+  HIPCHK(hipFuncSetAttribute((const void*)k_sac_phase_a<HH, AA, CC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+  HIPCHK(hipFuncSetAttribute((const void*)k_sac_phase_c<HH, AA, CC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
   HIPCHK(hipFuncSetAttribute((const void*)k_sac_phase_c<HH, AA, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, cap))
   SET_PHASE(256, ACT_RELU, 4); SET_PHASE(256, ACT_TANH, 4); SET_PHASE(128, ACT_RELU, 2); SET_PHASE(128, ACT_TANH, 2);
 #undef SET_PHASE
@@ -561,7 +563,48 @@ bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks) {
   return tiles <= PHASE_MAX_TILES && work <= n_cu && work + 1 <= occ_a * n_cu && tiles * 3 * cs <= occ_c * n_cu;
 }
 
-int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P0, int H, int act, int KPmax, int cs) {
+// ---- the phase kernels' descriptor blocks in constant memory (kernels.h g_phase_a_tab / g_phase_c_tab)
+static std::vector<bool> g_phase_slots[16];   // [device][slot] in use
+int phase_const_alloc(int device) {
+  static const bool off = []() { const char* e = getenv("ILSX_PHASE_CT"); return e && atoi(e) == 0; }();
+  if (off || device < 0 || device >= 16) return -1;
+  auto& u = g_phase_slots[device];
+  if (u.empty()) u.assign(PHASE_CONST_SLOTS, false);
+  for (int i = 0; i < PHASE_CONST_SLOTS; ++i) if (!u[i]) { u[i] = true; return i; }
+  return -1;
+}
+void phase_const_free(int device, int slot) {
+  if (device < 0 || device >= 16 || slot < 0 || slot >= PHASE_CONST_SLOTS || g_phase_slots[device].empty()) return;
+  g_phase_slots[device][slot] = false;
+}
+void phase_const_prepare(ilsx_ctx* ctx, PhaseConst* ct) {
+  if (!ct || ct->tried) return;
+  ct->tried = true;
+  ct->device = ctx->device;
+  ct->slot = phase_const_alloc(ctx->device);
+}
+// Does the slot hold `blk`?  A block that differs from the host's copy is uploaded when `stream` is not capturing (synchronised first: no launch
+// that reads the slot may be in flight; then the copy itself is waited for).  During a capture nothing can be uploaded — a copy would become a
+// node of the graph, replayed with every step, and side-stream work invalidates a thread-local capture on this runtime — so the owner uploads
+// BEFORE it begins the capture (ilsx_sac.hip sac_phase_const_prime builds the blocks in a dry pass); a block that still differs travels as arguments.
+template <class Blk>
+static bool phase_const_ready(ilsx_ctx* ctx, PhaseConst* ct, const Blk& blk, unsigned long long key, Blk& held, bool& valid, unsigned long long& held_key,
+                              const void* symbol) {
+  phase_const_prepare(ctx, ct);
+  if (!ct || ct->slot < 0 || blk.dbg || !key) return false;   // (measurement builds stamp through a per-launch pointer: arguments)
+  if (valid && held_key == key) return true;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+  valid = false;
+  memcpy(&held, &blk, sizeof blk);
+  if (hipMemcpyToSymbolAsync(symbol, &held, sizeof blk, (size_t)ct->slot * sizeof blk, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+  valid = true; held_key = key;
+  return true;
+}
+
+int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P0, int H, int act, int KPmax, int cs, PhaseConst* ct, unsigned long long key, bool upload_only) {
   PhaseAArgs P = P0;
   P.f1.xs = P.f2.xs = P.b1.xs = 0; P.f1.rt = P.f2.rt = 1;
   P.f1.dbg = P.f2.dbg = nullptr; P.b1.dbg = nullptr;
@@ -570,16 +613,25 @@ int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P0, int H, int act, int KPma
   const int tiles = (P.f1.rows + 15) / 16;
   dim3 grid((tiles + 7) & ~7, 5, cs), block(4 * H / cs);
   const size_t lds = phase_lds_bytes(H, KPmax, cs);
+  const bool use_ct = ct && phase_const_ready(ctx, ct, P, key, ct->a, ct->valid_a, ct->key_a, HIP_SYMBOL(g_phase_a_tab));
+  if (upload_only) return ILSX_OK;
+  const int slot = use_ct ? ct->slot : 0;
+  static const bool trace = getenv("ILSX_PHASE_CT_TRACE") != nullptr;
+  if (trace) { hipStreamCaptureStatus cap = hipStreamCaptureStatusNone; hipStreamIsCapturing(ctx->stream, &cap);
+               fprintf(stderr, "launch_phase_a: %s, slot %d, capturing %d\n", use_ct ? "constant table" : "kernel arguments", ct ? ct->slot : -9, (int)cap); }
   ProfScope ps(ctx, ILSX_K_SAC_PHASE_A);
-  if (H == 256 && act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_a<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, P);
-  else if (H == 256) ILSX_LAUNCH(ps, (k_sac_phase_a<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, P);
-  else if (act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_a<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, P);
-  else ILSX_LAUNCH(ps, (k_sac_phase_a<128, ACT_TANH, 2>), grid, block, lds, ctx->stream, P);
+#define PHASE_A(HH, AA, CC) do { if (use_ct) ILSX_LAUNCH(ps, (k_sac_phase_a<HH, AA, CC, true>), grid, block, lds, ctx->stream, P, slot); \
+                                 else ILSX_LAUNCH(ps, (k_sac_phase_a<HH, AA, CC>), grid, block, lds, ctx->stream, P, slot); } while (0)
+  if (H == 256 && act == ILSX_ACT_RELU) PHASE_A(256, ACT_RELU, 4);
+  else if (H == 256) PHASE_A(256, ACT_TANH, 4);
+  else if (act == ILSX_ACT_RELU) PHASE_A(128, ACT_RELU, 2);
+  else PHASE_A(128, ACT_TANH, 2);
+#undef PHASE_A
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }
 
-int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P0, int H, int act, int KPmax, int cs) {
+int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P0, int H, int act, int KPmax, int cs, PhaseConst* ct, unsigned long long key, bool upload_only) {
   PhaseCArgs P = P0;
   P.f3.xs = P.b2.xs = P.b3.xs = 0; P.f3.rt = 1;
   P.f3.dbg = nullptr; P.b2.dbg = P.b3.dbg = nullptr;
@@ -589,11 +641,17 @@ int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P0, int H, int act, int KPma
   const int tiles = (P.f3.rows + 15) / 16;
   dim3 grid((tiles + 7) & ~7, 4, cs), block(4 * H / cs);   // y: Q1, Q2, the policy's backward, the bookkeeping row
   const size_t lds = phase_lds_bytes(H, KPmax, cs);
+  const bool use_ct = ct && phase_const_ready(ctx, ct, P, key, ct->c, ct->valid_c, ct->key_c, HIP_SYMBOL(g_phase_c_tab));
+  if (upload_only) return ILSX_OK;
+  const int slot = use_ct ? ct->slot : 0;
   ProfScope ps(ctx, ILSX_K_SAC_PHASE_C);
-  if (H == 256 && act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_c<256, ACT_RELU, 4>), grid, block, lds, ctx->stream, P);
-  else if (H == 256) ILSX_LAUNCH(ps, (k_sac_phase_c<256, ACT_TANH, 4>), grid, block, lds, ctx->stream, P);
-  else if (act == ILSX_ACT_RELU) ILSX_LAUNCH(ps, (k_sac_phase_c<128, ACT_RELU, 2>), grid, block, lds, ctx->stream, P);
-  else ILSX_LAUNCH(ps, (k_sac_phase_c<128, ACT_TANH, 2>), grid, block, lds, ctx->stream, P);
+#define PHASE_C(HH, AA, CC) do { if (use_ct) ILSX_LAUNCH(ps, (k_sac_phase_c<HH, AA, CC, true>), grid, block, lds, ctx->stream, P, slot); \
+                                 else ILSX_LAUNCH(ps, (k_sac_phase_c<HH, AA, CC>), grid, block, lds, ctx->stream, P, slot); } while (0)
+  if (H == 256 && act == ILSX_ACT_RELU) PHASE_C(256, ACT_RELU, 4);
+  else if (H == 256) PHASE_C(256, ACT_TANH, 4);
+  else if (act == ILSX_ACT_RELU) PHASE_C(128, ACT_RELU, 2);
+  else PHASE_C(128, ACT_TANH, 2);
+#undef PHASE_C
   HIPCHK(hipGetLastError());
   return ILSX_OK;
 }

@@ -88,6 +88,8 @@ struct ilsx_sac {
   // merged phase kernels (kernels.h k_sac_phase_a / _c): F1 F2 B1 and F3 B2 B3 as one launch each inside train_from_replay
   unsigned* phase_flags = nullptr;   // PHASE_NFLAGS arrival counters, one 128-byte line each (zeroed by the dW launches)
   int* phase_err = nullptr;          // set by a workgroup whose wait timed out
+  PhaseConst pct;                    // the phase kernels' descriptor blocks in constant memory (host_common.h)
+  bool phase_args_only = false;      // dry pass: build the two blocks, upload them, launch nothing (sac_phase_const_prime)
   bool phase_now = false;            // this step runs on the phase kernels
   bool phase_broken = false;         // a timeout was seen once: stay on the 8-launch path
   bool phase_last = false;           // the last window of steps ran on the phase kernels
@@ -348,6 +350,7 @@ extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
   hipStreamSynchronize(s->ctx->stream);
   if (s->graph) hipGraphExecDestroy(s->graph);
   for (hipGraphExec_t& g : s->seg_graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
+  if (s->pct.slot >= 0) { phase_const_free(s->pct.device, s->pct.slot); s->pct.slot = -1; }
   if (s->tail_dev) ctx_free(s->ctx, s->tail_dev);
   if (s->snap) ctx_free(s->ctx, s->snap);
   if (s->vote) ctx_free(s->ctx, s->vote);
@@ -440,6 +443,19 @@ static int sac_dw(ilsx_sac* s, const DwArgs& table, int rows, const AdamFuse* F)
   return ILSX_OK;
 }
 
+// What the phase launches' descriptor blocks are built from besides the agent's fixed allocations: the ring they draw from, the batch, and the
+// step-form flags.  Two builds under the same key give the same blocks (PhaseConst::key_a / key_c); never 0.
+static unsigned long long sac_phase_key(const ilsx_sac* s) {
+  unsigned long long k = 1469598103934665603ull;
+  auto mix = [&k](unsigned long long v) { k = (k ^ v) * 1099511628211ull; };
+  const ilsx_replay* rb = s->gather_rb;
+  mix((unsigned long long)(uintptr_t)rb); mix(rb ? (unsigned long long)(uintptr_t)rb->data : 0); mix(rb ? (unsigned long long)(uintptr_t)rb->dstate : 0);
+  mix(rb ? (unsigned long long)rb->rec : 0); mix(rb ? (unsigned long long)rb->seed : 0); mix(rb ? (unsigned long long)rb->rng_stream : 0);
+  mix((unsigned long long)s->B); mix(s->defer_tail ? 1 : 0); mix(s->eps_explicit ? 1 : 0); mix(s->fuse_now ? 1 : 0); mix((unsigned long long)s->cs);
+  mix((unsigned long long)(uintptr_t)s->tail_dev); mix((unsigned long long)(uintptr_t)s->slab);
+  return k ? k : 1;
+}
+
 static int sac_critic_backward(ilsx_sac* s) {
   const SacWs& w = s->ws;
   const int B = s->B, H = s->Lq.cfg.hidden, act = s->Lq.cfg.act, cs = s->cs;
@@ -513,7 +529,8 @@ static int sac_critic_backward(ilsx_sac* s) {
         sac_policy_fin(s, Fz, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
         PA.fin_pi = Fz.fin; PA.fin_pi.use_gather_step = 1; PA.fin_pi_on = 1;
       }
-      ILSX_TRY(launch_phase_a(s->ctx, PA, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
+      ILSX_TRY(launch_phase_a(s->ctx, PA, H, act, std::max(s->Lq.KP, s->Lp.KP), cs, &s->pct, sac_phase_key(s), s->phase_args_only));
+      if (s->phase_args_only) return ILSX_OK;
     } else {
       ILSX_TRY(sac_bwd(s, A, H, act, cs));
     }
@@ -589,7 +606,8 @@ static int sac_actor_backward(ilsx_sac* s) {
       else {   // split run: this rank's alpha-gradient partial lands in the arena's slot before the actor all-reduce (the tail is deferred)
         PC.aslot = s->G + 2 * s->nq + s->np; PC.aslot_logp = w.logp; PC.aslot_B = B; PC.aslot_te = s->target_entropy; PC.aslot_invB = sac_inv_B(s);
       }
-      ILSX_TRY(launch_phase_c(s->ctx, PC, H, act, std::max(s->Lq.KP, s->Lp.KP), cs));
+      ILSX_TRY(launch_phase_c(s->ctx, PC, H, act, std::max(s->Lq.KP, s->Lp.KP), cs, &s->pct, sac_phase_key(s), s->phase_args_only));
+      if (s->phase_args_only) return ILSX_OK;
     } else {
       ILSX_TRY(sac_bwd(s, A, H, act, cs));
     }
@@ -972,6 +990,21 @@ static int sac_phase_check(ilsx_sac* s, int B, bool deferred, const char* who, b
   return ILSX_OK;
 }
 
+// The two phase launches' descriptor blocks, built exactly as the step that follows will build them (same agent state) and put into this agent's
+// constant-memory slots — a dry pass that launches nothing, run before a capture begins (launch_phase_a / _c then find the slots current).
+static int sac_phase_const_prime(ilsx_sac* s, ilsx_replay* rb) {
+  phase_const_prepare(s->ctx, &s->pct);
+  if (s->pct.slot < 0 || s->cs <= 1) return ILSX_OK;
+  static const bool no_fuse = getenv("ILSX_NO_FUSE") != nullptr;
+  s->gather_rb = rb; s->phase_now = true; s->fuse_now = !no_fuse && !sac_is_split(s);
+  s->phase_args_only = true;
+  int rc = sac_critic_backward(s);
+  if (rc == ILSX_OK) rc = sac_actor_backward(s);
+  s->phase_args_only = false;
+  s->gather_rb = nullptr; s->phase_now = false; s->fuse_now = false;
+  return rc;
+}
+
 static int sac_sample_and_step(ilsx_sac* s, ilsx_replay* rb, int B) {
   const SacWs& w = s->ws;
   if (s->cs > 1) {
@@ -1110,6 +1143,7 @@ static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps,
     if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail || s->graph_phase != phase) {
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
       hipGraph_t g = nullptr;
+      if (phase) ILSX_TRY(sac_phase_const_prime(s, rb));   // the phase kernels' descriptor blocks into constant memory, before the capture begins
       HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       int rc = sac_sample_and_step(s, rb, B);
       hipError_t e = hipStreamEndCapture(st, &g);

@@ -1143,6 +1143,11 @@ struct PhaseCArgs {
 };
 
 static_assert(sizeof(PhaseAArgs) <= 4096 && sizeof(PhaseCArgs) <= 4096, "phase-kernel descriptors travel in the kernel-argument segment (4 KB)");
+#define PHASE_CONST_SLOTS 64
+#ifdef ILSX_KERNEL_IMPL
+__constant__ PhaseAArgs g_phase_a_tab[PHASE_CONST_SLOTS];
+__constant__ PhaseCArgs g_phase_c_tab[PHASE_CONST_SLOTS];
+#endif
 
 #ifdef ILSX_KERNEL_IMPL
 __device__ __forceinline__ void xch_arrive(unsigned* flag) {   // every thread of the workgroup calls it
@@ -1234,8 +1239,12 @@ __device__ __forceinline__ void policy_fin_tile(const PolicyFinishArgs& P, int r
 // Phase A: stage 1 = fwd{pi(s') | Q1(s,a) | Q2(s,a) | pi(s)} (tasks y = 0..3, rows drawn from the replay ring);
 //          stage 2 = fwd{TQ1, TQ2 (s', a')} on the workgroups of y = 0 / 3 (prologue: finish pi(s'); next_obs as the policy task published it);
 //          stage 3 = bwd{Q1, Q2 <- TD target} on the workgroups of y = 1 / 2;  y = 4: the deferred tail of the previous step.
-template <int H, int ACT, int CS>
-__global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) {
+// CT: the descriptor block is read from a `__constant__` copy (g_phase_a_tab[slot], uploaded once when the step is built) instead of the
+// kernel-argument segment: see g_fwd_tab above — fields come as scalar loads where they are used instead of sitting in (and spilling out
+// of) scalar registers from the kernel's entry on.  Pk is then unused.
+template <int H, int ACT, int CS, bool CT = false>
+__global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs Pk, int slot) {
+  const PhaseAArgs& P = CT ? g_phase_a_tab[slot] : Pk;
   constexpr int GRP = 0; constexpr bool XCH = true;
   constexpr int PH = 0, MT = 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1326,8 +1335,9 @@ __global__ __launch_bounds__(4 * H / CS) void k_sac_phase_a(const PhaseAArgs P) 
 // Phase C: stage 1 = fwd{Q1, Q2 (s, a~)} with the updated critics (prologue: finish pi(s) with the second noise draw);
 //          stage 2 = bwd{Q1, Q2 -> d(-min Q)/da~} on the same workgroups (y = 0 / 1);  stage 3 = bwd{pi} on workgroups of its own (y = 2);
 //          y = 3: advance the replay-draw counter (nothing in this launch reads it).
-template <int H, int ACT, int CS>
-__global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs P) {
+template <int H, int ACT, int CS, bool CT = false>
+__global__ __launch_bounds__(4 * H / CS) void k_sac_phase_c(const PhaseCArgs Pk, int slot) {
+  const PhaseCArgs& P = CT ? g_phase_c_tab[slot] : Pk;
   constexpr int GRP = 0; constexpr bool XCH = true;
   constexpr int PH = 0, MT = 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
