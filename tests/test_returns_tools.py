@@ -62,7 +62,7 @@ def test_last_session_acceptance_run_repeats_the_earlier_one_cell_for_cell():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import returns_compare as rc
     n_seeds = 0
-    for run in ("r06b_returns_async", "r06c_returns_async"):   # mid-session tree ; the round's final tree (tools/final_evidence.sh)
+    for run in ("r06b_returns_async", "r06c_returns_async", "r06d_returns_async"):   # mid-session trees ; the round's final tree (tools/final_evidence.sh)
         for s in range(10):
             a = list(csv.DictReader(open(os.path.join(ROOT, "profiles", run, f"seed{s}.csv"))))
             b = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_returns_async", f"seed{s}.csv"))))
@@ -71,4 +71,4 @@ def test_last_session_acceptance_run_repeats_the_earlier_one_cell_for_cell():
             assert n >= 103 and len(cols) >= 10
             assert all(ra[k] == rb[k] for ra, rb in zip(a[:n], b[:n]) for k in cols), (run, s)
             n_seeds += 1
-    assert n_seeds == 20
+    assert n_seeds == 30
