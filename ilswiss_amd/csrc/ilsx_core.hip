@@ -5,6 +5,7 @@
 #include <random>
 
 #define ILSX_KERNEL_IMPL 1  // the shared __global__ kernels of kernels.h are emitted by this TU only
+#include <mutex>
 #include "host_common.h"
 
 static thread_local std::string g_err = "";
@@ -565,17 +566,20 @@ bool phase_fits(ilsx_ctx* ctx, int rows, int H, int cs, int ntasks) {
 
 // ---- the phase kernels' descriptor blocks in constant memory (kernels.h g_phase_a_tab / g_phase_c_tab)
 static std::vector<bool> g_phase_slots[16];   // [device][slot] in use
+static std::mutex g_phase_slots_mu;           // agents are built and destroyed from more than one host thread (grouped runs, evaluation threads)
 int phase_const_alloc(int device) {
   static const bool off = []() { const char* e = getenv("ILSX_PHASE_CT"); return e && atoi(e) == 0; }();
   if (off || device < 0 || device >= 16) return -1;
+  std::lock_guard<std::mutex> lock(g_phase_slots_mu);
   auto& u = g_phase_slots[device];
   if (u.empty()) u.assign(PHASE_CONST_SLOTS, false);
   for (int i = 0; i < PHASE_CONST_SLOTS; ++i) if (!u[i]) { u[i] = true; return i; }
   return -1;
 }
 void phase_const_free(int device, int slot) {
-  if (device < 0 || device >= 16 || slot < 0 || slot >= PHASE_CONST_SLOTS || g_phase_slots[device].empty()) return;
-  g_phase_slots[device][slot] = false;
+  if (device < 0 || device >= 16 || slot < 0 || slot >= PHASE_CONST_SLOTS) return;
+  std::lock_guard<std::mutex> lock(g_phase_slots_mu);
+  if (!g_phase_slots[device].empty()) g_phase_slots[device][slot] = false;
 }
 void phase_const_prepare(ilsx_ctx* ctx, PhaseConst* ct) {
   if (!ct || ct->tried) return;
