@@ -41,6 +41,7 @@ struct ilsx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  std::vector<int> phase_slots;   // constant-table slots taken by this ctx's agents (PhaseConst): released with the ctx, whose agents die with it
   uint64_t seed = 0;
   uint32_t next_rng_stream = 1;
   unsigned long long act_calls = 0, ppo_act_calls = 0;   // Philox counters of ilsx_policy_act / ilsx_ppo_policy_act (one draw per call)

@@ -122,6 +122,8 @@ extern "C" int ilsx_ctx_destroy(ilsx_ctx* c) {
   ilsx_comm_destroy(c);
   for (auto& r : c->prof_pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (hipEvent_t e : c->prof_free) hipEventDestroy(e);
+  for (int slot : c->phase_slots) phase_const_free(c->device, slot);
+  c->phase_slots.clear();
   for (void* p : c->allocs) hipFree(p);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -586,6 +588,7 @@ void phase_const_prepare(ilsx_ctx* ctx, PhaseConst* ct) {
   ct->tried = true;
   ct->device = ctx->device;
   ct->slot = phase_const_alloc(ctx->device);
+  if (ct->slot >= 0) ctx->phase_slots.push_back(ct->slot);
 }
 // Does the slot hold `blk`?  A block that differs from the host's copy is uploaded when `stream` is not capturing (synchronised first: no launch
 // that reads the slot may be in flight; then the copy itself is waited for).  During a capture nothing can be uploaded — a copy would become a

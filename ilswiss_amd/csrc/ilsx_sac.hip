@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <algorithm>
 #include "host_common.h"
 
 enum { W_PI = 0, W_Q1 = 1, W_Q2 = 2, W_TQ1 = 3, W_TQ2 = 4 };
@@ -350,7 +351,12 @@ extern "C" int ilsx_sac_destroy(ilsx_sac* s) {
   hipStreamSynchronize(s->ctx->stream);
   if (s->graph) hipGraphExecDestroy(s->graph);
   for (hipGraphExec_t& g : s->seg_graph) if (g) { hipGraphExecDestroy(g); g = nullptr; }
-  if (s->pct.slot >= 0) { phase_const_free(s->pct.device, s->pct.slot); s->pct.slot = -1; }
+  if (s->pct.slot >= 0) {
+    phase_const_free(s->pct.device, s->pct.slot);
+    auto& v = s->ctx->phase_slots;
+    v.erase(std::remove(v.begin(), v.end(), s->pct.slot), v.end());
+    s->pct.slot = -1;
+  }
   if (s->tail_dev) ctx_free(s->ctx, s->tail_dev);
   if (s->snap) ctx_free(s->ctx, s->snap);
   if (s->vote) ctx_free(s->ctx, s->vote);
