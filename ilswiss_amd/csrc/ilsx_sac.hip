@@ -91,6 +91,7 @@ struct ilsx_sac {
   int* phase_err = nullptr;          // set by a workgroup whose wait timed out
   PhaseConst pct;                    // the phase kernels' descriptor blocks in constant memory (host_common.h)
   bool phase_args_only = false;      // dry pass: build the two blocks, upload them, launch nothing (sac_phase_const_prime)
+  bool no_ct = false;                // this launch sequence must not depend on the slots' contents (captures that are replayed without a re-prime)
   bool phase_now = false;            // this step runs on the phase kernels
   bool phase_broken = false;         // a timeout was seen once: stay on the 8-launch path
   bool phase_last = false;           // the last window of steps ran on the phase kernels
@@ -535,7 +536,7 @@ static int sac_critic_backward(ilsx_sac* s) {
         sac_policy_fin(s, Fz, eps2, s->rng_stream + 1, true, w.an, w.logp, w.ppart2);
         PA.fin_pi = Fz.fin; PA.fin_pi.use_gather_step = 1; PA.fin_pi_on = 1;
       }
-      ILSX_TRY(launch_phase_a(s->ctx, PA, H, act, std::max(s->Lq.KP, s->Lp.KP), cs, &s->pct, sac_phase_key(s), s->phase_args_only));
+      ILSX_TRY(launch_phase_a(s->ctx, PA, H, act, std::max(s->Lq.KP, s->Lp.KP), cs, s->no_ct ? nullptr : &s->pct, sac_phase_key(s), s->phase_args_only));
       if (s->phase_args_only) return ILSX_OK;
     } else {
       ILSX_TRY(sac_bwd(s, A, H, act, cs));
@@ -612,7 +613,7 @@ static int sac_actor_backward(ilsx_sac* s) {
       else {   // split run: this rank's alpha-gradient partial lands in the arena's slot before the actor all-reduce (the tail is deferred)
         PC.aslot = s->G + 2 * s->nq + s->np; PC.aslot_logp = w.logp; PC.aslot_B = B; PC.aslot_te = s->target_entropy; PC.aslot_invB = sac_inv_B(s);
       }
-      ILSX_TRY(launch_phase_c(s->ctx, PC, H, act, std::max(s->Lq.KP, s->Lp.KP), cs, &s->pct, sac_phase_key(s), s->phase_args_only));
+      ILSX_TRY(launch_phase_c(s->ctx, PC, H, act, std::max(s->Lq.KP, s->Lp.KP), cs, s->no_ct ? nullptr : &s->pct, sac_phase_key(s), s->phase_args_only));
       if (s->phase_args_only) return ILSX_OK;
     } else {
       ILSX_TRY(sac_bwd(s, A, H, act, cs));
@@ -1053,7 +1054,9 @@ static int sac_split_segments_step(ilsx_sac* s, ilsx_replay* rb, int B) {
     for (int seg = 0; seg < 3; ++seg) {
       hipGraph_t g = nullptr;
       HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      s->no_ct = true;   // these cached segments are not re-primed before their replays: their phase launches keep the argument segment
       const int rc = sac_split_segment(s, rb, B, seg);
+      s->no_ct = false;
       const hipError_t e = hipStreamEndCapture(st, &g);
       if (rc != ILSX_OK) { if (g) hipGraphDestroy(g); return rc; }
       if (e != hipSuccess) ILSX_FAIL(ILSX_ERR_HIP, "hipStreamEndCapture (split segment %d) failed: %s", seg, hipGetErrorString(e));
@@ -1146,10 +1149,16 @@ static int sac_train_from_replay_once(ilsx_sac* s, ilsx_replay* rb, int n_steps,
   } else {
     const bool phase = sac_phase_ok(s, B);
     s->phase_last = phase;
+    // The phase kernels' descriptor blocks into this agent's constant-memory slots — before a capture begins, and before EVERY replay of a
+    // cached graph too: between two calls another step form of the same agent (an explicit-batch step, the adversarial-IRL loop, a profiled
+    // window: direct launches under another state key) may have put ITS blocks there, and the graph's launches would read those.  The dry pass
+    // costs a few host microseconds when the slots are current.
+    static const bool no_reprime = getenv("ILSX_PHASE_CT_NO_REPRIME") != nullptr;   // test aid: shows what the re-prime is for (tests/test_hip_parity.py)
+    const bool rebuild = !s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail || s->graph_phase != phase;
+    if (phase && (rebuild || !no_reprime)) ILSX_TRY(sac_phase_const_prime(s, rb));
     if (!s->graph || s->graph_rb != rb || s->graph_B != B || s->graph_defer != s->defer_tail || s->graph_phase != phase) {
       if (s->graph) { hipGraphExecDestroy(s->graph); s->graph = nullptr; }
       hipGraph_t g = nullptr;
-      if (phase) ILSX_TRY(sac_phase_const_prime(s, rb));   // the phase kernels' descriptor blocks into constant memory, before the capture begins
       HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       int rc = sac_sample_and_step(s, rb, B);
       hipError_t e = hipStreamEndCapture(st, &g);

@@ -631,6 +631,61 @@ def test_deferred_tail_is_bitwise_the_tail_launch():
     assert outs["defer"] == outs["defer_nograph"], outs
 
 
+_CT_SCRIPT = r'''
+import ctypes as C, hashlib, json, sys
+import numpy as np
+sys.path.insert(0, ".")
+import ilswiss_amd as ia
+from ilswiss_amd import _lib
+from ilswiss_amd.replay import SimpleReplayBuffer
+o, a, hid, B, N = 11, 3, [256, 256], 256, 5000
+ctx = ia.Context(0, seed=77)
+rbs = []
+for k in range(2):
+    rng = np.random.default_rng(5 + k)
+    rb = SimpleReplayBuffer(8192, o, a, random_seed=3 + k, ctx=ctx)
+    rb.add_rows(rng.normal(k, 1, (N, o)).astype(np.float32), np.tanh(rng.normal(0, 1, (N, a))).astype(np.float32),
+                rng.normal(k, 1, N).astype(np.float32), rng.random(N) < 0.01, rng.normal(k, 1, (N, o)).astype(np.float32))
+    rbs.append(rb)
+pol = ia.ReparamTanhMultivariateGaussianPolicy(hid, o, a, ctx=ctx, seed=10)
+q1, q2 = ia.FlattenMlp(hid, 1, o + a, ctx=ctx, seed=20), ia.FlattenMlp(hid, 1, o + a, ctx=ctx, seed=30)
+tr = ia.SoftActorCritic(pol, q1, q2, policy_lr=3e-4, qf_lr=3e-4, soft_target_tau=0.005, max_batch=B)
+tr.eval_statistics = {}
+tr.train_from_replay(rbs[0], 3, B)            # captured graph, ring 0: its phase launches read this agent's constant-memory slots
+_lib.check(ctx.lib.ilsx_prof_enable(ctx.h, 1))
+tr.train_from_replay(rbs[1], 2, B)            # direct launches (kernel timing on), ring 1: another state key, ITS blocks go into the same slots
+_lib.check(ctx.lib.ilsx_prof_enable(ctx.h, 0))
+tr.train_from_replay(rbs[0], 3, B)            # the cached graph again: the slots must hold ring 0's blocks when it runs
+h = hashlib.sha256()
+for name in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+    h.update(np.ascontiguousarray(tr.get_params(name)).tobytes())
+fb = tr.phase_state()
+print(json.dumps(dict(params=h.hexdigest(), log_alpha=repr(tr.log_alpha), on_phase=fb["last_window_on_phase"], fallbacks=fb["fallbacks"])))
+'''
+
+
+@pytest.mark.gpu
+def test_phase_kernels_constant_slots_are_reprimed_before_a_cached_graph_replays():
+    """The merged phase kernels read their descriptor blocks from per-agent constant-memory slots (kernels.h g_phase_a_tab / g_phase_c_tab).  A cached
+    step graph is replayed across calls; in between, another step form of the SAME agent (here: direct launches on another ring) rewrites the slots —
+    ilsx_sac_train_from_replay therefore re-primes them before every replay.  Same parameters as with the blocks in the argument segment
+    (ILSX_PHASE_CT=0), bit for bit; and without the re-prime (ILSX_PHASE_CT_NO_REPRIME=1, a test aid) the result differs — the check has teeth."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, extra in (("ct", {}), ("args", {"ILSX_PHASE_CT": "0"}), ("stale", {"ILSX_PHASE_CT_NO_REPRIME": "1"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _CT_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs["ct"]["on_phase"] and outs["ct"]["fallbacks"] == 0, outs
+    assert outs["ct"] == outs["args"], outs
+    assert outs["stale"]["params"] != outs["ct"]["params"], outs
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["relu_200_100", "tanh_200_100", "relu_48_160_96", "tanh_100"])
 def test_mlp_unequal_widths_forward_golden(ctx, tag):
