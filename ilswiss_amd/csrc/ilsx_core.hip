@@ -615,7 +615,7 @@ int launch_phase_a(ilsx_ctx* ctx, const PhaseAArgs& P0, int H, int act, int KPma
   PhaseAArgs P = P0;
   P.f1.xs = P.f2.xs = P.b1.xs = 0; P.f1.rt = P.f2.rt = 1;
   P.f1.dbg = P.f2.dbg = nullptr; P.b1.dbg = nullptr;
-  P.dbg = ctx->dbg_next();
+  P.dbg = upload_only ? nullptr : ctx->dbg_next();   // (a dry pass takes no slab of the trace buffer)
   if (P.b1.ga_parts < 1) P.b1.ga_parts = 1;
   const int tiles = (P.f1.rows + 15) / 16;
   dim3 grid((tiles + 7) & ~7, 5, cs), block(4 * H / cs);
@@ -642,7 +642,7 @@ int launch_phase_c(ilsx_ctx* ctx, const PhaseCArgs& P0, int H, int act, int KPma
   PhaseCArgs P = P0;
   P.f3.xs = P.b2.xs = P.b3.xs = 0; P.f3.rt = 1;
   P.f3.dbg = nullptr; P.b2.dbg = P.b3.dbg = nullptr;
-  P.dbg = ctx->dbg_next();
+  P.dbg = upload_only ? nullptr : ctx->dbg_next();
   if (P.b2.ga_parts < 1) P.b2.ga_parts = 1;
   if (P.b3.ga_parts < 1) P.b3.ga_parts = 1;
   const int tiles = (P.f3.rows + 15) / 16;
