@@ -62,7 +62,7 @@ def test_last_session_acceptance_run_repeats_the_earlier_one_cell_for_cell():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import returns_compare as rc
     n_seeds = 0
-    for run in ("r06b_returns_async", "r06c_returns_async", "r06e_returns_async"):   # mid-session trees ; the round's final tree (tools/final_evidence.sh)
+    for run in ("r06b_returns_async", "r06c_returns_async", "r06f_returns_async"):   # mid-session trees ; the round's final tree (tools/final_evidence.sh)
         for s in range(10):
             a = list(csv.DictReader(open(os.path.join(ROOT, "profiles", run, f"seed{s}.csv"))))
             b = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_returns_async", f"seed{s}.csv"))))
