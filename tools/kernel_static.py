@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".hip") else "ilsx_core.hip"
-    filters = [a for a in sys.argv[1:] if not a.endswith(".hip")] or ["k_mlp2_fwd_split<256, 0, 4", "k_mlp2_bwd_split<256, 0, 4", "k_mlp_bwd_dw"]
+    filters = [a for a in sys.argv[1:] if not a.endswith(".hip")] or ["k_mlp2_fwd_split<256, 0, 4", "k_mlp2_bwd_split<256, 0, 4", "k_mlp_bwd_dw", "k_sac_phase_a<256, 0, 4", "k_sac_phase_c<256, 0, 4"]
     out = os.path.join(tempfile.mkdtemp(prefix="kstat_"), "dev.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only",
                            "-S", os.path.join(ROOT, "ilswiss_amd", "csrc", src), "-o", out], stderr=subprocess.DEVNULL)
